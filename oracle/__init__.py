@@ -1,0 +1,363 @@
+"""ctypes loader for the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package.  "parity unpinned" against reference-run outputs (no Nim
+toolchain; the reference's tests hold no literal vectors): see nimfm_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libnimfm_oracle.so")
+
+LOSS = {"squared": 0, "squared_hinge": 1, "logistic": 2, "huber": 3}
+SCHED = {"constant": 0, "optimal": 1, "invscaling": 2, "pegasos": 3}
+LOWER = {"explicit": 0, "augment": 1, "none": 2}
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("nimfm_oracle.c", "nimfm_slow.c", "nimfm_mb.c", "nimfm_oracle.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class CSR(C.Structure):
+    _fields_ = [("n", C.c_int64), ("d", C.c_int64), ("indptr", C.c_void_p), ("indices", C.c_void_p),
+                ("data", C.c_void_p), ("fields", C.c_void_p), ("n_fields", C.c_int64)]
+
+
+class SGDCfg(C.Structure):
+    _fields_ = [("eta0", C.c_double), ("alpha0", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
+                ("power", C.c_double), ("loss_param", C.c_double), ("loss", C.c_int32),
+                ("scheduling", C.c_int32), ("fit_linear", C.c_int32), ("fit_intercept", C.c_int32)]
+
+
+class AdaCfg(C.Structure):
+    _fields_ = [("eta0", C.c_double), ("alpha0", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
+                ("eps", C.c_double), ("loss_param", C.c_double), ("loss", C.c_int32),
+                ("fit_linear", C.c_int32), ("fit_intercept", C.c_int32), ("pad_", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        for name in ("orc_loss", "orc_dloss", "orc_get_eta", "orc_expit", "orc_rmse", "orc_accuracy_sign",
+                     "orc_regularization", "slow_anova"):
+            getattr(_lib, name).restype = C.c_double
+        _lib.orc_loss.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double]
+        _lib.orc_dloss.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double]
+        _lib.orc_get_eta.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int64]
+        _lib.orc_expit.argtypes = [C.c_double]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+class Dataset:
+    """Holds a CSR matrix in the reference's widths (int64 indices, fp64 values)."""
+
+    def __init__(self, indptr, indices, data, n, d, fields=None, n_fields=0):
+        self.indptr, self.indices, self.data = i64(indptr), i64(indices), f64(data)
+        self.fields = None if fields is None else i64(fields)
+        self.n, self.d, self.n_fields = int(n), int(d), int(n_fields)
+        self.c = CSR(self.n, self.d, _p(self.indptr), _p(self.indices), _p(self.data), _p(self.fields),
+                     self.n_fields)
+
+    @staticmethod
+    def from_dense(Xd, field_of=None, n_fields=0):
+        Xd = f64(Xd)
+        n, d = Xd.shape
+        mask = Xd != 0.0
+        indptr = np.concatenate([[0], np.cumsum(mask.sum(1))])
+        rows, cols = np.nonzero(mask)
+        fields = None if field_of is None else np.asarray(field_of)[cols]
+        return Dataset(indptr, cols, Xd[rows, cols], n, d, fields, n_fields)
+
+    def dense(self):
+        Xd = np.zeros((self.n, self.d))
+        for i in range(self.n):
+            s, e = self.indptr[i], self.indptr[i + 1]
+            Xd[i, self.indices[s:e]] = self.data[s:e]
+        return Xd
+
+
+def sgd_cfg(eta0=0.01, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squared", scheduling="optimal", power=1.0,
+            fit_linear=True, fit_intercept=True, loss_param=1.0):
+    return SGDCfg(eta0, alpha0, alpha, beta, power, loss_param, LOSS[loss], SCHED[scheduling],
+                  int(fit_linear), int(fit_intercept))
+
+
+def adagrad_cfg(eta0=0.1, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squared", eps=1e-10, fit_linear=True,
+                fit_intercept=True, loss_param=1.0):
+    return AdaCfg(eta0, alpha0, alpha, beta, eps, loss_param, LOSS[loss], int(fit_linear), int(fit_intercept), 0)
+
+
+def n_orders(degree, fit_lower):
+    return lib().orc_n_orders(degree, LOWER[fit_lower])
+
+
+def n_augments(degree, fit_lower, fit_linear):
+    return lib().orc_n_augments(degree, LOWER[fit_lower], int(fit_linear))
+
+
+class AdaState:
+    def __init__(self, n_blocks, da, k, d):
+        self.gsum_P = np.zeros((n_blocks, da, k))
+        self.gnorm_P = np.zeros((n_blocks, da, k))
+        self.gsum_w = np.zeros(d)
+        self.gnorm_w = np.zeros(d)
+        self.gsum_b = C.c_double(0.0)
+        self.gnorm_b = C.c_double(0.0)
+
+    def args(self):
+        return (_p(self.gsum_P), _p(self.gnorm_P), _p(self.gsum_w), _p(self.gnorm_w), C.byref(self.gsum_b),
+                C.byref(self.gnorm_b))
+
+
+def _perms(perms):
+    return None if perms is None else i64(perms)
+
+
+def fm_decision_function(X, degree, P, w, intercept, n_aug=0, lams=None):
+    O, k, da = P.shape
+    out = np.zeros(X.n)
+    lams = np.ones(k) if lams is None else f64(lams)
+    P, w = f64(P), f64(w)
+    rc = lib().orc_fm_decision_function(C.byref(X.c), degree, k, O, n_aug, _p(P), _p(lams), _p(w),
+                                        C.c_double(intercept), _p(out))
+    assert rc == 0
+    return out
+
+
+def fm_sgd_fit(X, y, degree, P, w, intercept, cfg, max_iter, n_aug=0, tol=0.0, perms=None, it=1,
+               hogwild_threads=0):
+    """Runs in place on copies; returns (P, w, intercept, it, epoch_loss, epoch_viol, n_run)."""
+    P, w, y = f64(P).copy(), f64(w).copy(), f64(y)
+    O, k, da = P.shape
+    b, itc, nrun = C.c_double(intercept), C.c_int64(it), C.c_int(0)
+    el, ev = np.zeros(max_iter), np.zeros(max_iter)
+    pm = _perms(perms)
+    if hogwild_threads:
+        rc = lib().orc_fm_sgd_fit_hogwild(C.byref(X.c), _p(y), degree, k, O, n_aug, _p(P), _p(w), C.byref(b),
+                                          C.byref(cfg), max_iter, C.c_double(tol), _p(pm), C.byref(itc),
+                                          hogwild_threads, _p(el), _p(ev), C.byref(nrun))
+    else:
+        rc = lib().orc_fm_sgd_fit(C.byref(X.c), _p(y), degree, k, O, n_aug, _p(P), _p(w), C.byref(b),
+                                  C.byref(cfg), max_iter, C.c_double(tol), _p(pm), C.byref(itc), _p(el),
+                                  _p(ev), C.byref(nrun))
+    assert rc == 0
+    return P, w, b.value, itc.value, el, ev, nrun.value
+
+
+def fm_adagrad_fit(X, y, degree, P, w, intercept, cfg, max_iter, n_aug=0, tol=0.0, perms=None, it=1, state=None):
+    P, w, y = f64(P).copy(), f64(w).copy(), f64(y)
+    O, k, da = P.shape
+    st = state if state is not None else AdaState(O, da, k, X.d)
+    b, itc, nrun = C.c_double(intercept), C.c_int64(it), C.c_int(0)
+    el, ev = np.zeros(max_iter), np.zeros(max_iter)
+    pm = _perms(perms)
+    rc = lib().orc_fm_adagrad_fit(C.byref(X.c), _p(y), degree, k, O, n_aug, _p(P), _p(w), C.byref(b),
+                                  C.byref(cfg), max_iter, C.c_double(tol), _p(pm), C.byref(itc), *st.args(),
+                                  _p(el), _p(ev), C.byref(nrun))
+    assert rc == 0
+    return P, w, b.value, itc.value, el, ev, nrun.value, st
+
+
+def ffm_decision_function(X, P, w, intercept):
+    F, d, k = P.shape
+    out = np.zeros(X.n)
+    P, w = f64(P), f64(w)
+    rc = lib().orc_ffm_decision_function(C.byref(X.c), k, _p(P), _p(w), C.c_double(intercept), _p(out))
+    assert rc == 0
+    return out
+
+
+def ffm_sgd_fit(X, y, P, w, intercept, cfg, max_iter, tol=0.0, perms=None, it=1):
+    P, w, y = f64(P).copy(), f64(w).copy(), f64(y)
+    F, d, k = P.shape
+    b, itc, nrun = C.c_double(intercept), C.c_int64(it), C.c_int(0)
+    el, ev = np.zeros(max_iter), np.zeros(max_iter)
+    pm = _perms(perms)
+    rc = lib().orc_ffm_sgd_fit(C.byref(X.c), _p(y), k, _p(P), _p(w), C.byref(b), C.byref(cfg), max_iter,
+                               C.c_double(tol), _p(pm), C.byref(itc), _p(el), _p(ev), C.byref(nrun))
+    assert rc == 0
+    return P, w, b.value, itc.value, el, ev, nrun.value
+
+
+def ffm_adagrad_fit(X, y, P, w, intercept, cfg, max_iter, tol=0.0, perms=None, it=1, state=None):
+    P, w, y = f64(P).copy(), f64(w).copy(), f64(y)
+    F, d, k = P.shape
+    st = state if state is not None else AdaState(F, d, k, d)
+    b, itc, nrun = C.c_double(intercept), C.c_int64(it), C.c_int(0)
+    el, ev = np.zeros(max_iter), np.zeros(max_iter)
+    pm = _perms(perms)
+    rc = lib().orc_ffm_adagrad_fit(C.byref(X.c), _p(y), k, _p(P), _p(w), C.byref(b), C.byref(cfg), max_iter,
+                                   C.c_double(tol), _p(pm), C.byref(itc), *st.args(), _p(el), _p(ev),
+                                   C.byref(nrun))
+    assert rc == 0
+    return P, w, b.value, itc.value, el, ev, nrun.value, st
+
+
+# ---- brute force (reference tests' slow models) ----
+def slow_anova(xrow, prow, m, degree):
+    xrow, prow = f64(xrow), f64(prow)
+    return lib().slow_anova(_p(xrow), _p(prow), len(xrow), m, degree)
+
+
+def slow_fm_decision_function(Xd, degree, P, w, intercept, n_aug=0):
+    Xd, P, w = f64(Xd), f64(P), f64(w)
+    n, d = Xd.shape
+    O, k, da = P.shape
+    out = np.zeros(n)
+    lib().slow_fm_decision_function(_p(Xd), C.c_int64(n), d, degree, k, O, n_aug, _p(P), _p(w),
+                                    C.c_double(intercept), _p(out))
+    return out
+
+
+def slow_fm_sgd_fit(Xd, y, degree, P, w, intercept, cfg, max_iter, n_aug=0, perms=None, it=1):
+    Xd, y, P, w = f64(Xd), f64(y), f64(P).copy(), f64(w).copy()
+    n, d = Xd.shape
+    O, k, da = P.shape
+    b, itc = C.c_double(intercept), C.c_int64(it)
+    pm = _perms(perms)
+    lib().slow_fm_sgd_fit(_p(Xd), C.c_int64(n), d, _p(y), degree, k, O, n_aug, _p(P), _p(w), C.byref(b),
+                          C.byref(cfg), max_iter, _p(pm), C.byref(itc))
+    return P, w, b.value, itc.value
+
+
+def slow_fm_adagrad_fit(Xd, y, degree, P, w, intercept, cfg, max_iter, n_aug=0, perms=None, it=1):
+    Xd, y, P, w = f64(Xd), f64(y), f64(P).copy(), f64(w).copy()
+    n, d = Xd.shape
+    O, k, da = P.shape
+    b, itc = C.c_double(intercept), C.c_int64(it)
+    pm = _perms(perms)
+    lib().slow_fm_adagrad_fit(_p(Xd), C.c_int64(n), d, _p(y), degree, k, O, n_aug, _p(P), _p(w), C.byref(b),
+                              C.byref(cfg), max_iter, _p(pm), C.byref(itc))
+    return P, w, b.value, itc.value
+
+
+def slow_ffm_decision_function(Xd, field_of, n_fields, P, w, intercept):
+    Xd, P, w, field_of = f64(Xd), f64(P), f64(w), i64(field_of)
+    n, d = Xd.shape
+    k = P.shape[2]
+    out = np.zeros(n)
+    lib().slow_ffm_decision_function(_p(Xd), C.c_int64(n), d, _p(field_of), n_fields, k, _p(P), _p(w),
+                                     C.c_double(intercept), _p(out))
+    return out
+
+
+def slow_ffm_sgd_fit(Xd, field_of, n_fields, y, P, w, intercept, cfg, max_iter, perms=None, it=1):
+    Xd, y, P, w, field_of = f64(Xd), f64(y), f64(P).copy(), f64(w).copy(), i64(field_of)
+    n, d = Xd.shape
+    k = P.shape[2]
+    b, itc = C.c_double(intercept), C.c_int64(it)
+    pm = _perms(perms)
+    lib().slow_ffm_sgd_fit(_p(Xd), C.c_int64(n), d, _p(field_of), n_fields, _p(y), k, _p(P), _p(w),
+                           C.byref(b), C.byref(cfg), max_iter, _p(pm), C.byref(itc))
+    return P, w, b.value, itc.value
+
+
+def slow_ffm_adagrad_fit(Xd, field_of, n_fields, y, P, w, intercept, cfg, max_iter, perms=None, it=1):
+    Xd, y, P, w, field_of = f64(Xd), f64(y), f64(P).copy(), f64(w).copy(), i64(field_of)
+    n, d = Xd.shape
+    k = P.shape[2]
+    b, itc = C.c_double(intercept), C.c_int64(it)
+    pm = _perms(perms)
+    lib().slow_ffm_adagrad_fit(_p(Xd), C.c_int64(n), d, _p(field_of), n_fields, _p(y), k, _p(P), _p(w),
+                               C.byref(b), C.byref(cfg), max_iter, _p(pm), C.byref(itc))
+    return P, w, b.value, itc.value
+
+
+# ---- this repository's mini-batch rule (see nimfm_mb.c) ----
+def fm_sgd_epoch_mb(X, y, degree, P, w, intercept, cfg, batch, n_aug=0, perm=None, begin=0, end=None, it=1):
+    """In place on P (model layout) and w; returns (intercept, it, loss_sum, viol_sum)."""
+    O, k, da = P.shape
+    assert P.dtype == np.float64 and P.flags.c_contiguous and w.flags.c_contiguous
+    y = f64(y)
+    end = X.n if end is None else end
+    b, itc, ls, vs = C.c_double(intercept), C.c_int64(it), C.c_double(0), C.c_double(0)
+    pm = _perms(perm)
+    rc = lib().orc_fm_sgd_epoch_mb(C.byref(X.c), _p(y), degree, k, O, n_aug, _p(P), _p(w), C.byref(b),
+                                   C.byref(cfg), _p(pm), C.c_int64(begin), C.c_int64(end), C.c_int64(batch),
+                                   C.byref(itc), C.byref(ls), C.byref(vs))
+    assert rc == 0
+    return b.value, itc.value, ls.value, vs.value
+
+
+def fm_adagrad_epoch_mb(X, y, degree, P, w, intercept, cfg, batch, state, n_aug=0, perm=None, begin=0,
+                        end=None, it=1):
+    O, k, da = P.shape
+    assert P.dtype == np.float64 and P.flags.c_contiguous and w.flags.c_contiguous
+    y = f64(y)
+    end = X.n if end is None else end
+    b, itc, ls, vs = C.c_double(intercept), C.c_int64(it), C.c_double(0), C.c_double(0)
+    pm = _perms(perm)
+    rc = lib().orc_fm_adagrad_epoch_mb(C.byref(X.c), _p(y), degree, k, O, n_aug, _p(P), _p(w), C.byref(b),
+                                       C.byref(cfg), _p(pm), C.c_int64(begin), C.c_int64(end),
+                                       C.c_int64(batch), C.byref(itc), *state.args(), C.byref(ls),
+                                       C.byref(vs))
+    assert rc == 0
+    return b.value, itc.value, ls.value, vs.value
+
+
+def fm_adagrad_finalize(degree, P, w, intercept, cfg, it, state, n_aug=0):
+    O, k, da = P.shape
+    b = C.c_double(intercept)
+    rc = lib().orc_fm_adagrad_finalize(degree, k, O, n_aug, C.c_int64(da - n_aug), _p(P), _p(w), C.byref(b),
+                                       C.byref(cfg), C.c_int64(it), *state.args())
+    assert rc == 0
+    return b.value
+
+
+def ffm_sgd_epoch_mb(X, y, P, w, intercept, cfg, batch, perm=None, begin=0, end=None, it=1):
+    F, d, k = P.shape
+    y = f64(y)
+    end = X.n if end is None else end
+    b, itc, ls, vs = C.c_double(intercept), C.c_int64(it), C.c_double(0), C.c_double(0)
+    pm = _perms(perm)
+    rc = lib().orc_ffm_sgd_epoch_mb(C.byref(X.c), _p(y), k, _p(P), _p(w), C.byref(b), C.byref(cfg), _p(pm),
+                                    C.c_int64(begin), C.c_int64(end), C.c_int64(batch), C.byref(itc),
+                                    C.byref(ls), C.byref(vs))
+    assert rc == 0
+    return b.value, itc.value, ls.value, vs.value
+
+
+def ffm_adagrad_epoch_mb(X, y, P, w, intercept, cfg, batch, state, perm=None, begin=0, end=None, it=1):
+    F, d, k = P.shape
+    y = f64(y)
+    end = X.n if end is None else end
+    b, itc, ls, vs = C.c_double(intercept), C.c_int64(it), C.c_double(0), C.c_double(0)
+    pm = _perms(perm)
+    rc = lib().orc_ffm_adagrad_epoch_mb(C.byref(X.c), _p(y), k, _p(P), _p(w), C.byref(b), C.byref(cfg),
+                                        _p(pm), C.c_int64(begin), C.c_int64(end), C.c_int64(batch),
+                                        C.byref(itc), *state.args(), C.byref(ls), C.byref(vs))
+    assert rc == 0
+    return b.value, itc.value, ls.value, vs.value
+
+
+def ffm_adagrad_finalize(P, w, intercept, cfg, it, state):
+    F, d, k = P.shape
+    b = C.c_double(intercept)
+    rc = lib().orc_adagrad_finalize(F, k, C.c_int64(d), C.c_int64(d), _p(P), _p(w), C.byref(b), C.byref(cfg),
+                                    C.c_int64(it), *state.args())
+    assert rc == 0
+    return b.value

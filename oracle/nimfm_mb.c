@@ -1,0 +1,305 @@
+/*
+ * oracle/nimfm_mb.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of THIS REPOSITORY's deterministic mini-batch rule
+ *  -- not a reference function.  The reference updates
+ * after every sample (optimizer/sgd.nim:298-308); its own parallel mode is a
+ * racy Hogwild (optimizer/sgd_multi.nim:83-101, README.md:56-58) with no
+ * reproducible result.  The HIP throughput kernels instead implement:
+ *
+ *   all samples of a batch see the parameters as of the batch start; their
+ *   per-sample updates (the reference's per-sample expressions, each with its
+ *   own step counter `it`) are summed in sample order; L2 decay is the product
+ *   of the per-step factors (1 - eta_t * reg) of the batch, applied to every
+ *   coordinate (which is what the reference's lazy scaling amounts to).
+ *
+ * With batch == 1 this IS the reference's sequential step in exact
+ * arithmetic (tests/test_oracle_mb.py checks that against nimfm_oracle.c).
+ * The per-sample forward/gradient code is shared with nimfm_oracle.c by
+ * textual inclusion so the two cannot drift.
+ */
+#include "nimfm_oracle.c"
+
+typedef double (*mb_predict_fn)(const orc_csr* X, int64_t i, int n_blocks, int k, int degree,
+                                int n_aug, const double* Pt, const double* w, double intercept,
+                                double* A, double* dA);
+
+static double mb_predict_fm(const orc_csr* X, int64_t i, int n_blocks, int k, int degree, int n_aug,
+                            const double* Pt, const double* w, double intercept, double* A,
+                            double* dA) {
+  return predict_with_grad(get_row(X, i), X->d, n_aug, k, n_blocks, degree, Pt, w, intercept, A, dA);
+}
+static double mb_predict_ffm(const orc_csr* X, int64_t i, int n_blocks, int k, int degree, int n_aug,
+                             const double* Pt, const double* w, double intercept, double* A,
+                             double* dA) {
+  (void)degree; (void)n_aug; (void)A;
+  return ffm_predict_with_grad(X, i, n_blocks, k, Pt, w, intercept, dA);
+}
+
+/* ---------------- SGD ---------------- */
+static int sgd_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict, int n_blocks,
+                        int k, int degree, int n_aug, double* Pt /*[n_blocks][da][k]*/, double* w,
+                        double* intercept, const orc_sgd_cfg* c, const int64_t* perm, int64_t begin,
+                        int64_t end, int64_t batch, int64_t* it, double* loss_sum,
+                        double* viol_sum) {
+  const int64_t d = X->d, da = d + n_aug;
+  const size_t np = (size_t)n_blocks * da * k;
+  double* dA = (double*)calloc(np ? np : 1, sizeof(double));
+  double* accP = (double*)calloc(np ? np : 1, sizeof(double));
+  double* accw = (double*)calloc(d ? d : 1, sizeof(double));
+  double* A = (double*)calloc((size_t)k * (degree + 2), sizeof(double));
+  if (!dA || !accP || !accw || !A) return -1;
+  double loss = 0.0, viol = 0.0;
+  if (batch < 1) batch = 1;
+  for (int64_t p0 = begin; p0 < end; p0 += batch) {
+    const int64_t p1 = p0 + batch < end ? p0 + batch : end;
+    memset(accP, 0, sizeof(double) * np);
+    memset(accw, 0, sizeof(double) * (size_t)d);
+    double accb = 0.0, DP = 1.0, Dw = 1.0, D0 = 1.0;
+    for (int64_t pos = p0; pos < p1; pos++) {
+      const int64_t i = perm ? perm[pos] : pos;
+      const int64_t t = *it + (pos - p0);
+      const double etaP = orc_get_eta(c->scheduling, c->eta0, c->power, c->beta, t);
+      const double etaw = orc_get_eta(c->scheduling, c->eta0, c->power, c->alpha, t);
+      const double eta0 = orc_get_eta(c->scheduling, c->eta0, c->power, c->alpha0, t);
+      row_view r = get_row(X, i);
+      const double y_pred = predict(X, i, n_blocks, k, degree, n_aug, Pt, w, *intercept, A, dA);
+      loss += orc_loss(c->loss, c->loss_param, y[i], y_pred);
+      const double dL = orc_dloss(c->loss, c->loss_param, y[i], y_pred);
+      for (int o = 0; o < n_blocks; o++)
+        for (int64_t q = 0; q < r.m + n_aug; q++) {
+          const int64_t j = ROW_J(r, q, d);
+          for (int s = 0; s < k; s++) {
+            const size_t e = ((size_t)o * da + j) * k + s;
+            viol += fabs(etaP * (dL * dA[e] + c->beta * Pt[e]));
+            accP[e] += etaP * (dL * dA[e]);
+          }
+        }
+      if (c->fit_intercept) {
+        viol += fabs(eta0 * (dL + c->alpha0 * *intercept));
+        accb += eta0 * dL;
+      }
+      if (c->fit_linear)
+        for (int64_t q = 0; q < r.m; q++) {
+          const int64_t j = r.idx[q];
+          viol += fabs(etaw * (dL * r.val[q] + c->alpha * w[j]));
+          accw[j] += etaw * (dL * r.val[q]);
+        }
+      DP *= (1 - etaP * c->beta);
+      Dw *= (1 - etaw * c->alpha);
+      D0 *= (1 - eta0 * c->alpha0);
+    }
+    for (size_t e = 0; e < np; e++) Pt[e] = DP * Pt[e] - accP[e];
+    if (c->fit_linear)
+      for (int64_t j = 0; j < d; j++) w[j] = Dw * w[j] - accw[j];
+    if (c->fit_intercept) *intercept = D0 * *intercept - accb;
+    *it += p1 - p0;
+  }
+  *loss_sum = loss;
+  *viol_sum = viol;
+  free(dA); free(accP); free(accw); free(A);
+  return 0;
+}
+
+int orc_fm_sgd_epoch_mb(const orc_csr* X, const double* y, int degree, int k, int n_orders,
+                        int n_aug, double* P, double* w, double* intercept,
+                        const orc_sgd_cfg* cfg, const int64_t* perm, int64_t begin, int64_t end,
+                        int64_t batch, int64_t* it, double* loss_sum, double* viol_sum) {
+  const int64_t da = X->d + n_aug;
+  const size_t np = (size_t)n_orders * da * k;
+  double* Pt = (double*)calloc(np ? np : 1, sizeof(double));
+  if (!Pt) return -1;
+  to_train_layout(Pt, P, n_orders, k, da);
+  int rc = sgd_epoch_mb(X, y, mb_predict_fm, n_orders, k, degree, n_aug, Pt, w, intercept, cfg,
+                        perm, begin, end, batch, it, loss_sum, viol_sum);
+  to_model_layout(P, Pt, n_orders, k, da);
+  free(Pt);
+  return rc;
+}
+
+int orc_ffm_sgd_epoch_mb(const orc_csr* X, const double* y, int k, double* P, double* w,
+                         double* intercept, const orc_sgd_cfg* cfg, const int64_t* perm,
+                         int64_t begin, int64_t end, int64_t batch, int64_t* it,
+                         double* loss_sum, double* viol_sum) {
+  return sgd_epoch_mb(X, y, mb_predict_ffm, (int)X->n_fields, k, 2, 0, P, w, intercept, cfg, perm,
+                      begin, end, batch, it, loss_sum, viol_sum);
+}
+
+/* ---------------- AdaGrad ----------------
+ * State is additive over samples (adagrad.nim:113-134), parameters are a pure
+ * function of (state, it) (adagrad.nim:87-110).  Per batch: parameters of the
+ * rows the batch touches are re-derived from the batch-start state with
+ * it' = it_b - 1 (the reference's `update`, once per unique row), every sample
+ * computes its gradient with them, the state receives the sum.  The reference
+ * skips `update` for the very first sample ever (it == 1, adagrad.nim:171):
+ * that sample is run as a batch of its own on the stored parameters. */
+static int ada_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict, int n_blocks,
+                        int k, int degree, int n_aug, double* Pt, double* w, double* intercept,
+                        const orc_adagrad_cfg* c, const int64_t* perm, int64_t begin, int64_t end,
+                        int64_t batch, int64_t* it, double* gsum_P, double* gnorm_P, double* gsum_w,
+                        double* gnorm_w, double* gsum_b, double* gnorm_b, double* loss_sum,
+                        double* viol_sum) {
+  const int64_t d = X->d, da = d + n_aug;
+  const size_t np = (size_t)n_blocks * da * k;
+  double* dA = (double*)calloc(np ? np : 1, sizeof(double));
+  double* accG = (double*)calloc(np ? np : 1, sizeof(double));
+  double* accN = (double*)calloc(np ? np : 1, sizeof(double));
+  double* accGw = (double*)calloc(d ? d : 1, sizeof(double));
+  double* accNw = (double*)calloc(d ? d : 1, sizeof(double));
+  int64_t* seen = (int64_t*)malloc(sizeof(int64_t) * (size_t)(da ? da : 1));
+  double* A = (double*)calloc((size_t)k * (degree + 2), sizeof(double));
+  if (!dA || !accG || !accN || !accGw || !accNw || !seen || !A) return -1;
+  for (int64_t j = 0; j < da; j++) seen[j] = -1;
+  ada_state S;
+  memset(&S, 0, sizeof(S));
+  S.n_blocks = n_blocks; S.k = k; S.d = d; S.da = da; S.P = Pt; S.w = w; S.intercept = intercept;
+  S.gsum_P = gsum_P; S.gnorm_P = gnorm_P; S.gsum_w = gsum_w; S.gnorm_w = gnorm_w;
+  S.gsum_b = gsum_b; S.gnorm_b = gnorm_b; S.cfg = *c; S.it = *it;
+  ada_init(&S);
+  double loss = 0.0, viol = 0.0;
+  if (batch < 1) batch = 1;
+  int64_t p0 = begin, batch_id = 0;
+  while (p0 < end) {
+    const int first = (*it == 1);
+    const int64_t p1 = first ? p0 + 1 : (p0 + batch < end ? p0 + batch : end);
+    const double itp = (double)(*it - 1);
+    memset(accG, 0, sizeof(double) * np);
+    memset(accN, 0, sizeof(double) * np);
+    memset(accGw, 0, sizeof(double) * (size_t)d);
+    memset(accNw, 0, sizeof(double) * (size_t)d);
+    double accGb = 0.0, accNb = 0.0;
+    if (!first) {
+      /* the reference's update(), once per unique touched row */
+      const double tmp = c->eta0 * itp * c->beta;
+      const double denw = itp * c->eta0 * c->alpha;
+      for (int64_t pos = p0; pos < p1; pos++) {
+        const int64_t i = perm ? perm[pos] : pos;
+        row_view r = get_row(X, i);
+        for (int64_t q = 0; q < r.m + n_aug; q++) {
+          const int64_t j = ROW_J(r, q, d);
+          if (seen[j] == batch_id) continue;
+          seen[j] = batch_id;
+          for (int o = 0; o < n_blocks; o++)
+            for (int s = 0; s < k; s++) {
+              const size_t e = ((size_t)o * da + j) * k + s;
+              const double pjs = Pt[e];
+              const double denom = tmp + sqrt(gnorm_P[e]);
+              Pt[e] = -(c->eta0 * gsum_P[e]) / denom;
+              viol += fabs(pjs - Pt[e]);
+            }
+          if (c->fit_linear && j < d) {
+            const double wj = w[j];
+            w[j] = -c->eta0 * gsum_w[j] / (denw + sqrt(gnorm_w[j]));
+            viol += fabs(wj - w[j]);
+          }
+        }
+      }
+      if (c->fit_intercept) {
+        const double old = *intercept;
+        const double denom = sqrt(*gnorm_b) + c->eta0 * itp * c->alpha0;
+        *intercept = -c->eta0 * *gsum_b / denom;
+        viol += fabs(old - *intercept);
+      }
+    }
+    for (int64_t pos = p0; pos < p1; pos++) {
+      const int64_t i = perm ? perm[pos] : pos;
+      row_view r = get_row(X, i);
+      const double y_pred = predict(X, i, n_blocks, k, degree, n_aug, Pt, w, *intercept, A, dA);
+      loss += orc_loss(c->loss, c->loss_param, y[i], y_pred);
+      const double dL = orc_dloss(c->loss, c->loss_param, y[i], y_pred);
+      for (int o = 0; o < n_blocks; o++)
+        for (int64_t q = 0; q < r.m + n_aug; q++) {
+          const int64_t j = ROW_J(r, q, d);
+          for (int s = 0; s < k; s++) {
+            const size_t e = ((size_t)o * da + j) * k + s;
+            const double grad = dL * dA[e];
+            accG[e] += grad;
+            accN[e] += grad * grad;
+          }
+        }
+      if (c->fit_intercept) { accGb += dL; accNb += dL * dL; }
+      if (c->fit_linear)
+        for (int64_t q = 0; q < r.m; q++) {
+          const int64_t j = r.idx[q];
+          const double g = dL * r.val[q];
+          accGw[j] += g;
+          accNw[j] += g * g;
+        }
+    }
+    for (size_t e = 0; e < np; e++) { gsum_P[e] += accG[e]; gnorm_P[e] += accN[e]; }
+    if (c->fit_linear)
+      for (int64_t j = 0; j < d; j++) { gsum_w[j] += accGw[j]; gnorm_w[j] += accNw[j]; }
+    if (c->fit_intercept) { *gsum_b += accGb; *gnorm_b += accNb; }
+    *it += p1 - p0;
+    p0 = p1;
+    batch_id++;
+  }
+  *loss_sum = loss;
+  *viol_sum = viol;
+  free(dA); free(accG); free(accN); free(accGw); free(accNw); free(seen); free(A);
+  return 0;
+}
+
+/* P in/out: model layout [O][k][d+a]; it is NOT finalised here (callers use
+ * orc_*_adagrad_finalize_mb, the reference's finalize, adagrad.nim:65-84). */
+int orc_fm_adagrad_epoch_mb(const orc_csr* X, const double* y, int degree, int k, int n_orders,
+                            int n_aug, double* P, double* w, double* intercept,
+                            const orc_adagrad_cfg* cfg, const int64_t* perm, int64_t begin,
+                            int64_t end, int64_t batch, int64_t* it, double* gsum_P,
+                            double* gnorm_P, double* gsum_w, double* gnorm_w, double* gsum_b,
+                            double* gnorm_b, double* loss_sum, double* viol_sum) {
+  const int64_t da = X->d + n_aug;
+  const size_t np = (size_t)n_orders * da * k;
+  double* Pt = (double*)calloc(np ? np : 1, sizeof(double));
+  if (!Pt) return -1;
+  to_train_layout(Pt, P, n_orders, k, da);
+  int rc = ada_epoch_mb(X, y, mb_predict_fm, n_orders, k, degree, n_aug, Pt, w, intercept, cfg,
+                        perm, begin, end, batch, it, gsum_P, gnorm_P, gsum_w, gnorm_w, gsum_b,
+                        gnorm_b, loss_sum, viol_sum);
+  to_model_layout(P, Pt, n_orders, k, da);
+  free(Pt);
+  return rc;
+}
+
+int orc_ffm_adagrad_epoch_mb(const orc_csr* X, const double* y, int k, double* P, double* w,
+                             double* intercept, const orc_adagrad_cfg* cfg, const int64_t* perm,
+                             int64_t begin, int64_t end, int64_t batch, int64_t* it,
+                             double* gsum_P, double* gnorm_P, double* gsum_w, double* gnorm_w,
+                             double* gsum_b, double* gnorm_b, double* loss_sum, double* viol_sum) {
+  return ada_epoch_mb(X, y, mb_predict_ffm, (int)X->n_fields, k, 2, 0, P, w, intercept, cfg, perm,
+                      begin, end, batch, it, gsum_P, gnorm_P, gsum_w, gnorm_w, gsum_b, gnorm_b,
+                      loss_sum, viol_sum);
+}
+
+/* the reference's finalize (adagrad.nim:65-84) on caller-held state; P in the
+ * TRAINING layout [n_blocks][da][k] (for FM convert with the transpose). */
+int orc_adagrad_finalize(int n_blocks, int k, int64_t d, int64_t da, double* Pt, double* w,
+                         double* intercept, const orc_adagrad_cfg* cfg, int64_t it,
+                         double* gsum_P, double* gnorm_P, double* gsum_w, double* gnorm_w,
+                         double* gsum_b, double* gnorm_b) {
+  ada_state S;
+  memset(&S, 0, sizeof(S));
+  S.n_blocks = n_blocks; S.k = k; S.d = d; S.da = da; S.P = Pt; S.w = w; S.intercept = intercept;
+  S.gsum_P = gsum_P; S.gnorm_P = gnorm_P; S.gsum_w = gsum_w; S.gnorm_w = gnorm_w;
+  S.gsum_b = gsum_b; S.gnorm_b = gnorm_b; S.cfg = *cfg; S.it = it;
+  ada_finalize(&S);
+  return 0;
+}
+
+/* FM convenience: P in the model layout [O][k][d+a]. */
+int orc_fm_adagrad_finalize(int degree, int k, int n_orders, int n_aug, int64_t d, double* P,
+                            double* w, double* intercept, const orc_adagrad_cfg* cfg, int64_t it,
+                            double* gsum_P, double* gnorm_P, double* gsum_w, double* gnorm_w,
+                            double* gsum_b, double* gnorm_b) {
+  (void)degree;
+  const int64_t da = d + n_aug;
+  const size_t np = (size_t)n_orders * da * k;
+  double* Pt = (double*)calloc(np ? np : 1, sizeof(double));
+  if (!Pt) return -1;
+  to_train_layout(Pt, P, n_orders, k, da);
+  orc_adagrad_finalize(n_orders, k, d, da, Pt, w, intercept, cfg, it, gsum_P, gnorm_P, gsum_w,
+                       gnorm_w, gsum_b, gnorm_b);
+  to_model_layout(P, Pt, n_orders, k, da);
+  free(Pt);
+  return 0;
+}
