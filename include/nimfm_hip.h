@@ -1,0 +1,194 @@
+/*
+ * include/nimfm_hip.h -- C ABI of libnimfm_hip.so, the MI355X (gfx950) hot path
+ * for nimfm factorization machines.
+ *
+ * The reference (neonnnnn/nimfm, /root/reference) is pure Nim with NO FFI or
+ * plugin boundary: `optim.fit(X, y, fm)` and `fm.decisionFunction(X)` are Nim
+ * procs resolved at compile time.  This header is therefore the
+ * FFI a Nim shim binds with {.importc, cdecl, dynlib.} (nim/nimfm_hip.nim,
+ * INTEGRATION.md); each entry point cites the reference proc(s) it replaces.
+ * All citations are relative to /root/reference/src/nimfm/.
+ *
+ * Conventions
+ *   - every function returns int32 status: 0 = NFM_OK, < 0 = error; nothing
+ *     throws; nfm_last_error() returns a thread-local message.
+ *   - plain pointers and sizes only.  Host pointers are caller-owned; the
+ *     library copies during the call and keeps nothing host-side.  "*_dev"
+ *     pointers are device pointers on the context's GPU.
+ *   - one nfm_ctx per GPU per process (one process per GPU); all work of a
+ *     context is issued on one HIP stream.  Not thread-safe per context.
+ *   - widths follow the reference: Nim int = int64_t, float64 = double.
+ *     Parameter layouts at this boundary are the reference's:
+ *       FM  P[nOrders][nComponents][nFeatures+nAugments] (model/factorization_machine.nim:31-34)
+ *       FFM P[nFields][nFeatures][nComponents]           (model/field_aware_factorization_machine.nim:16-17)
+ *       AdaGrad state g_sum/g_norm: P part [nOrders|nFields][nFeatures+nAugments][nComponents],
+ *       w part [nFeatures], intercept scalar               (optimizer/adagrad.nim:53-55,155; model/params.nim:5-10)
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry
+ *     point fails with NFM_ERR_HIP.
+ */
+#ifndef NIMFM_HIP_H
+#define NIMFM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFM_OK 0
+#define NFM_ERR_INVALID (-1)    /* ValueError in the reference */
+#define NFM_ERR_HIP (-2)        /* HIP runtime / no device */
+#define NFM_ERR_NOT_FITTED (-3) /* NotFittedError, model/fm_base.nim:13-15 */
+#define NFM_ERR_NOMEM (-4)
+#define NFM_ERR_UNSUPPORTED (-5)
+
+typedef struct nfm_ctx nfm_ctx;
+typedef struct nfm_dataset nfm_dataset;
+typedef struct nfm_model nfm_model;
+typedef struct nfm_opt nfm_opt;
+
+/* enums mirror the reference's */
+enum { NFM_TASK_REGRESSION = 0, NFM_TASK_CLASSIFICATION = 1 };                 /* model/fm_base.nim:6-8 */
+enum { NFM_KIND_FM = 0, NFM_KIND_FFM = 1 };
+enum { NFM_LOWER_EXPLICIT = 0, NFM_LOWER_AUGMENT = 1, NFM_LOWER_NONE = 2 };     /* model/factorization_machine.nim:6-9 */
+enum { NFM_LOSS_SQUARED = 0, NFM_LOSS_SQUARED_HINGE = 1, NFM_LOSS_LOGISTIC = 2, NFM_LOSS_HUBER = 3 }; /* loss.nim */
+enum { NFM_SCHED_CONSTANT = 0, NFM_SCHED_OPTIMAL = 1, NFM_SCHED_INVSCALING = 2, NFM_SCHED_PEGASOS = 3 }; /* optimizer/sgd.nim:7-11 */
+/* NFM_MODE_SEQUENTIAL: one sample at a time in the given order -- the
+ *   reference's single-thread semantics (optimizer/sgd.nim:294-308,
+ *   optimizer/adagrad.nim:164-184), the parity vehicle.
+ * NFM_MODE_MINIBATCH: this library's deterministic data-parallel rule
+ *   (DESIGN.md section 4); replaces the reference's racy Hogwild drivers
+ *   (optimizer/sgd_multi.nim:40-120, adagrad_multi.nim:39-115); equals the
+ *   sequential rule at batch == 1. */
+enum { NFM_MODE_SEQUENTIAL = 0, NFM_MODE_MINIBATCH = 1 };
+
+const char* nfm_last_error(void);
+int32_t nfm_version(void);
+/* number of visible HIP devices (0 and NFM_OK when none) */
+int32_t nfm_device_count(int32_t* n);
+
+/* ---- context: device + stream ---- */
+/* hip_stream: a hipStream_t to issue on (e.g. the host framework's current
+ * stream), or NULL to let the library create its own. */
+int32_t nfm_ctx_create(int32_t device_id, void* hip_stream, nfm_ctx** out);
+int32_t nfm_ctx_destroy(nfm_ctx* ctx);
+int32_t nfm_ctx_synchronize(nfm_ctx* ctx);
+/* per-kernel timing with HIP events on the context's stream (off by default).
+ * nfm_ctx_timing_get: accumulated launches / milliseconds of one kernel family
+ * ("row_phase", "col_phase", "predict", "sequential", "schedule", ...). */
+int32_t nfm_ctx_timing_enable(nfm_ctx* ctx, int32_t on);
+int32_t nfm_ctx_timing_reset(nfm_ctx* ctx);
+int32_t nfm_ctx_timing_get(nfm_ctx* ctx, const char* family, int64_t* launches, double* total_ms);
+
+/* ---- dataset: CSRDataset / CSRFieldDataset resident in HBM ----
+ * replaces tensor/sparse.nim:9-12,19-24 (CSRMatrix, CSRFieldMatrix) +
+ * dataset.nim:10-13,182-231 (row iterators incl. dummy features, which the
+ * kernels generate on the fly) as the thing `fit`/`decisionFunction` iterate.
+ * indices/fields are narrowed to int32 on the device.  y may be NULL for
+ * predict-only datasets.  Indices inside one row must be distinct. */
+int32_t nfm_dataset_create_csr(nfm_ctx* ctx, int64_t n_samples, int64_t n_features,
+                               const int64_t* indptr /*n+1*/, const int64_t* indices /*nnz*/,
+                               const double* data /*nnz*/, const int64_t* fields /*nnz or NULL*/,
+                               int64_t n_fields, const double* y /*n or NULL*/,
+                               nfm_dataset** out);
+/* same, adopting arrays that already live on the device (no copy; the caller
+ * keeps them alive until nfm_dataset_destroy). */
+int32_t nfm_dataset_create_csr_device(nfm_ctx* ctx, int64_t n_samples, int64_t n_features,
+                                      int64_t nnz, const int64_t* indptr_dev,
+                                      const int32_t* indices_dev, const double* data_dev,
+                                      const int32_t* fields_dev, int64_t n_fields,
+                                      const double* y_dev, nfm_dataset** out);
+/* model/fm_base.nim:29-36 checkTarget is applied by the optimizer according to
+ * the model's task; this replaces the targets (host array, n). */
+int32_t nfm_dataset_set_targets(nfm_dataset* ds, const double* y);
+int32_t nfm_dataset_destroy(nfm_dataset* ds);
+
+/* ---- model: FactorizationMachine / FieldAwareFactorizationMachine ---- */
+typedef struct nfm_model_cfg {
+  int32_t kind;          /* NFM_KIND_* */
+  int32_t task;          /* NFM_TASK_* */
+  int32_t degree;        /* FM only; FFM is degree 2 */
+  int32_t n_components;  /* k */
+  int32_t fit_lower;     /* NFM_LOWER_* (FM only) */
+  int32_t fit_intercept;
+  int32_t fit_linear;
+  int32_t reserved;
+  int64_t n_features;    /* d (without augments) */
+  int64_t n_fields;      /* FFM only */
+} nfm_model_cfg;
+
+/* newFactorizationMachine (model/factorization_machine.nim:43-78) /
+ * newFieldAwareFactorizationMachine (model/field_aware_factorization_machine.nim:24-46):
+ * NFM_ERR_INVALID if degree < 1 or n_components < 1 (:65-69). */
+int32_t nfm_model_create(nfm_ctx* ctx, const nfm_model_cfg* cfg, nfm_model** out);
+/* nOrders / nAugments (model/factorization_machine.nim:81-97); for FFM
+ * n_blocks = nFields and n_aug = 0. */
+int32_t nfm_model_shape(const nfm_model* m, int32_t* n_blocks, int32_t* n_aug);
+/* fm.init's result / a loaded model (model/factorization_machine.nim:125-139,
+ * 183-220): marks the model initialised.  lams may be NULL (= ones, :78). */
+int32_t nfm_model_set_params(nfm_model* m, const double* P, const double* w, double intercept,
+                             const double* lams);
+/* finalised parameters in the reference layout (what fm.P / fm.w /
+ * fm.intercept hold after fit; optimizer/sgd.nim:327-328).  For AdaGrad call
+ * nfm_opt_finalize first. */
+int32_t nfm_model_get_params(nfm_model* m, double* P, double* w, double* intercept);
+/* decisionFunction (model/factorization_machine.nim:100-122 -> kernels.nim:14-19,
+ * 46-64; FFM: model/field_aware_factorization_machine.nim:52-76).
+ * NFM_ERR_NOT_FITTED when not initialised, NFM_ERR_INVALID on nFeatures /
+ * nFields mismatch (:114-115, FFM :60-64).  out: n doubles. */
+int32_t nfm_decision_function(nfm_model* m, nfm_dataset* ds, double* out);
+int32_t nfm_decision_function_device(nfm_model* m, nfm_dataset* ds, double* out_dev);
+/* ||P||^2 and ||w||^2 for optimizer/utils.nim:56-59 `regularization` (verbose). */
+int32_t nfm_model_sqnorms(nfm_model* m, double* P_sq, double* w_sq);
+/* device views for the data-parallel exchange: pointers to
+ * the device-layout parameter buffers and their lengths in doubles. scalars
+ * holds {scale_P, scale_w, intercept}. */
+int32_t nfm_model_device_buffers(nfm_model* m, double** P_dev, int64_t* n_P, double** w_dev,
+                                 int64_t* n_w, double** scalars_dev, int64_t* n_scalars);
+int32_t nfm_model_destroy(nfm_model* m);
+
+/* ---- optimizers ---- */
+typedef struct nfm_sgd_cfg { /* newSGD, optimizer/sgd.nim:23-52 */
+  double eta0, alpha0, alpha, beta, power, loss_param /* Huber threshold */;
+  int32_t loss, scheduling, mode, reserved;
+  int64_t batch; /* NFM_MODE_MINIBATCH only */
+} nfm_sgd_cfg;
+
+typedef struct nfm_adagrad_cfg { /* newAdaGrad, optimizer/adagrad.nim:20-44 */
+  double eta0, alpha0, alpha, beta, eps, loss_param;
+  int32_t loss, mode, track_viol /* 1 = keep the reference's sum|dP| (adagrad.nim:99) */, reserved;
+  int64_t batch;
+} nfm_adagrad_cfg;
+
+int32_t nfm_sgd_create(nfm_model* m, const nfm_sgd_cfg* cfg, nfm_opt** out);
+int32_t nfm_adagrad_create(nfm_model* m, const nfm_adagrad_cfg* cfg, nfm_opt** out);
+/* the optimizer's `it` (optimizer/sgd.nim:18,55-56; adagrad.nim:14,50): starts
+ * at 1, +1 per sample; set to 1 to mimic a non-warm-start fit. */
+int32_t nfm_opt_set_it(nfm_opt* o, int64_t it);
+int32_t nfm_opt_get_it(nfm_opt* o, int64_t* it);
+/* AdaGrad g_sum / g_norm (optimizer/adagrad.nim:15-16), reference layout. */
+int32_t nfm_opt_get_state(nfm_opt* o, double* gsum_P, double* gnorm_P, double* gsum_w,
+                          double* gnorm_w, double* gsum_b, double* gnorm_b);
+int32_t nfm_opt_set_state(nfm_opt* o, const double* gsum_P, const double* gnorm_P,
+                          const double* gsum_w, const double* gnorm_w, double gsum_b,
+                          double gnorm_b);
+/* The body of one epoch of fit (optimizer/sgd.nim:298-308, adagrad.nim:169-184;
+ * FFM: sgd_ffm.nim:77-87, adagrad_ffm.nim:35-48) over samples
+ * perm[begin..end) (perm NULL = identity; perm is the host-side shuffle,
+ * sgd.nim:297).  Sub-ranges serve nCalls callbacks (sgd.nim:303-307).  Returns
+ * the running sums the reference prints/tests: sum of loss(y_i, yhat_i) and
+ * `viol`.  Classification targets are sign()-ed (fm_base.nim:32-34). */
+int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t begin,
+                      int64_t end, double* loss_sum, double* viol_sum);
+/* finalize (optimizer/sgd.nim:99-113; adagrad.nim:65-84): leaves the model's
+ * parameters as the reference's fm.P/w/intercept after fit. Idempotent. */
+int32_t nfm_opt_finalize(nfm_opt* o);
+/* device views of the AdaGrad state for the data-parallel exchange. */
+int32_t nfm_opt_device_state(nfm_opt* o, double** gsum_P, double** gnorm_P, int64_t* n_P,
+                             double** gsum_w, double** gnorm_w, int64_t* n_w,
+                             double** gscalars /* {gsum_b, gnorm_b} */);
+int32_t nfm_opt_destroy(nfm_opt* o);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

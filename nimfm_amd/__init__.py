@@ -1,0 +1,12 @@
+"""nimfm_amd -- MI355X (gfx950) hot path for nimfm factorization machines.
+
+Layout:
+  csrc/      hand-written HIP kernels + the C ABI (include/nimfm_hip.h) -> lib/libnimfm_hip.so
+  _capi.py   ctypes binding of that ABI (fails loudly when the library is missing)
+  host.py    host-side mirror of the reference's Nim surface (newSGD(...).fit(X, y, fm), ...)
+  dp.py      one-process-per-GPU data parallelism over torch.distributed (RCCL)
+"""
+from ._capi import NfmError, NotFittedError, build, lib  # noqa: F401
+from .host import (AdaGrad, Context, CSRDataset, FactorizationMachine, FieldAwareFactorizationMachine, SGD,  # noqa: F401
+                   accuracy, default_context, expit, newAdaGrad, newCSRDataset, newCSRFieldDataset,
+                   newFactorizationMachine, newFieldAwareFactorizationMachine, newSGD, rmse, set_default_context)

@@ -1,0 +1,664 @@
+// nimfm_amd/csrc/api.hip -- the C ABI of include/nimfm_hip.h over the HIP kernels.
+// Host-side bookkeeping only (allocation, layout conversion launches, plan cache, epoch driver);
+// every entry point validates shapes on the host before any kernel is launched.
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+
+#include "mb.h"
+
+using namespace nfm;
+
+struct nfm_dataset {
+  nfm_ctx* ctx = nullptr;
+  CsrView v{};
+  DevBuf indptr, indices, data, fields, y;
+  bool has_y = false;
+  int max_row = 0;
+  uint64_t serial = 0;  // bumps when targets change (plans do not depend on y; kept for clarity)
+};
+
+struct nfm_model {
+  nfm_ctx* ctx = nullptr;
+  nfm_model_cfg cfg{};
+  int nb = 0, n_aug = 0, k = 0, Kp = 0, L = 0;
+  int64_t d = 0, da = 0;
+  DevBuf P, w, sc, lams;
+  bool initialized = false;
+  ModelView view() const {
+    ModelView m{};
+    m.P = P.as<double>(); m.w = w.as<double>(); m.sc = sc.as<double>(); m.lams = lams.as<double>();
+    m.d = d; m.da = da; m.nb = nb; m.k = k; m.Kp = Kp; m.L = L;
+    m.degree = cfg.kind == NFM_KIND_FFM ? 2 : cfg.degree;
+    m.n_aug = n_aug; m.kind = cfg.kind; m.fit_linear = cfg.fit_linear; m.fit_intercept = cfg.fit_intercept;
+    m.task = cfg.task;
+    return m;
+  }
+  int64_t nP() const { return (int64_t)nb * da * Kp; }
+};
+
+struct nfm_opt {
+  nfm_model* m = nullptr;
+  int kind = OPT_SGD, mode = NFM_MODE_SEQUENTIAL;
+  int64_t batch = 1, it = 1;
+  OptView o{};
+  DevBuf G, N, Gw, Nw, gsc, out2, perm_dev;
+  bool state_ready = false;
+  MbWork W;
+  std::unique_ptr<Plan> plan;
+};
+
+static int use_device(nfm_ctx* ctx) {
+  NFM_HIP_CHECK(hipSetDevice(ctx->device));
+  return NFM_OK;
+}
+
+extern "C" {
+
+const char* nfm_last_error(void) { return nfm::last_error(); }
+int32_t nfm_version(void) { return 100; }
+
+int32_t nfm_device_count(int32_t* n) {
+  NFM_CHECK(n, NFM_ERR_INVALID, "null out pointer");
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  *n = c;
+  return NFM_OK;
+}
+
+int32_t nfm_ctx_create(int32_t device_id, void* hip_stream, nfm_ctx** out) {
+  NFM_CHECK(out, NFM_ERR_INVALID, "null out pointer");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess || c == 0)
+    return set_error(NFM_ERR_HIP, "no HIP device available (%s); libnimfm_hip has no CPU fallback",
+                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  NFM_CHECK(device_id >= 0 && device_id < c, NFM_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, c);
+  std::unique_ptr<nfm_ctx> ctx(new nfm_ctx());
+  ctx->device = device_id;
+  NFM_HIP_CHECK(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  NFM_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+  ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hip_stream) {
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  } else {
+    NFM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  *out = ctx.release();
+  return NFM_OK;
+}
+
+int32_t nfm_ctx_destroy(nfm_ctx* ctx) {
+  if (!ctx) return NFM_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& p : ctx->timing.pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+  for (auto e : ctx->timing.pool) (void)hipEventDestroy(e);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return NFM_OK;
+}
+
+int32_t nfm_ctx_synchronize(nfm_ctx* ctx) {
+  NFM_CHECK(ctx, NFM_ERR_INVALID, "null ctx");
+  NFM_TRY(use_device(ctx));
+  NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return NFM_OK;
+}
+
+int32_t nfm_ctx_timing_enable(nfm_ctx* ctx, int32_t on) {
+  NFM_CHECK(ctx, NFM_ERR_INVALID, "null ctx");
+  NFM_TRY(timing_flush(ctx));
+  ctx->timing.enabled = on != 0;
+  return NFM_OK;
+}
+int32_t nfm_ctx_timing_reset(nfm_ctx* ctx) {
+  NFM_CHECK(ctx, NFM_ERR_INVALID, "null ctx");
+  NFM_TRY(timing_flush(ctx));
+  ctx->timing.acc.clear();
+  return NFM_OK;
+}
+int32_t nfm_ctx_timing_get(nfm_ctx* ctx, const char* family, int64_t* launches, double* total_ms) {
+  NFM_CHECK(ctx && family, NFM_ERR_INVALID, "null argument");
+  NFM_TRY(timing_flush(ctx));
+  auto it = ctx->timing.acc.find(family);
+  if (launches) *launches = it == ctx->timing.acc.end() ? 0 : it->second.launches;
+  if (total_ms) *total_ms = it == ctx->timing.acc.end() ? 0.0 : it->second.ms;
+  return NFM_OK;
+}
+
+// ------------------------------------------------------------------ dataset
+static int validate_csr_host(int64_t n, int64_t d, const int64_t* indptr, const int64_t* indices, const int64_t* fields,
+                             int64_t n_fields, int* max_row) {
+  NFM_CHECK(n >= 0 && d >= 0, NFM_ERR_INVALID, "negative shape");
+  NFM_CHECK(d < (int64_t)2147483647 - 64, NFM_ERR_UNSUPPORTED, "n_features must fit int32");
+  NFM_CHECK(indptr, NFM_ERR_INVALID, "null indptr");
+  NFM_CHECK(indptr[0] == 0, NFM_ERR_INVALID, "indptr[0] != 0");
+  int64_t mr = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t len = indptr[i + 1] - indptr[i];
+    NFM_CHECK(len >= 0, NFM_ERR_INVALID, "indptr not non-decreasing at row %lld", (long long)i);
+    mr = std::max(mr, len);
+  }
+  NFM_CHECK(mr < (1 << 30), NFM_ERR_UNSUPPORTED, "row too long");
+  const int64_t nnz = indptr[n];
+  NFM_CHECK(nnz == 0 || indices, NFM_ERR_INVALID, "null indices");
+  for (int64_t q = 0; q < nnz; ++q) {
+    NFM_CHECK(indices[q] >= 0 && indices[q] < d, NFM_ERR_INVALID, "column index %lld out of range [0,%lld) at nnz %lld",
+              (long long)indices[q], (long long)d, (long long)q);
+    if (fields)
+      NFM_CHECK(fields[q] >= 0 && fields[q] < n_fields, NFM_ERR_INVALID, "field %lld out of range [0,%lld) at nnz %lld",
+                (long long)fields[q], (long long)n_fields, (long long)q);
+  }
+  *max_row = (int)mr;
+  return NFM_OK;
+}
+
+int32_t nfm_dataset_create_csr(nfm_ctx* ctx, int64_t n, int64_t d, const int64_t* indptr, const int64_t* indices,
+                               const double* data, const int64_t* fields, int64_t n_fields, const double* y,
+                               nfm_dataset** out) {
+  NFM_CHECK(ctx && out, NFM_ERR_INVALID, "null argument");
+  NFM_TRY(use_device(ctx));
+  int max_row = 0;
+  NFM_TRY(validate_csr_host(n, d, indptr, indices, fields, n_fields, &max_row));
+  const int64_t nnz = indptr[n];
+  NFM_CHECK(nnz == 0 || data, NFM_ERR_INVALID, "null data");
+  std::unique_ptr<nfm_dataset> ds(new nfm_dataset());
+  ds->ctx = ctx;
+  ds->max_row = max_row;
+  hipStream_t st = ctx->stream;
+  NFM_TRY(ds->indptr.alloc(sizeof(int64_t) * (n + 1)));
+  NFM_TRY(ds->indices.alloc(sizeof(int32_t) * nnz));
+  NFM_TRY(ds->data.alloc(sizeof(double) * nnz));
+  NFM_HIP_CHECK(hipMemcpyAsync(ds->indptr.p, indptr, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
+  if (nnz > 0) {
+    DevBuf wide;
+    NFM_TRY(wide.alloc(sizeof(int64_t) * nnz));
+    NFM_HIP_CHECK(hipMemcpyAsync(wide.p, indices, sizeof(int64_t) * nnz, hipMemcpyHostToDevice, st));
+    NFM_TRY(launch_narrow_i64_i32(ctx, wide.as<int64_t>(), ds->indices.as<int32_t>(), nnz));
+    if (fields) {
+      NFM_TRY(ds->fields.alloc(sizeof(int32_t) * nnz));
+      NFM_HIP_CHECK(hipMemcpyAsync(wide.p, fields, sizeof(int64_t) * nnz, hipMemcpyHostToDevice, st));
+      NFM_TRY(launch_narrow_i64_i32(ctx, wide.as<int64_t>(), ds->fields.as<int32_t>(), nnz));
+    }
+    NFM_HIP_CHECK(hipMemcpyAsync(ds->data.p, data, sizeof(double) * nnz, hipMemcpyHostToDevice, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  if (y) {
+    NFM_TRY(ds->y.alloc(sizeof(double) * n));
+    NFM_HIP_CHECK(hipMemcpyAsync(ds->y.p, y, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    ds->has_y = true;
+  }
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  ds->v.indptr = ds->indptr.as<int64_t>();
+  ds->v.indices = ds->indices.as<int32_t>();
+  ds->v.data = ds->data.as<double>();
+  ds->v.fields = fields ? ds->fields.as<int32_t>() : nullptr;
+  ds->v.y = ds->has_y ? ds->y.as<double>() : nullptr;
+  ds->v.n = n; ds->v.d = d; ds->v.nnz = nnz; ds->v.n_fields = fields ? (int32_t)n_fields : 0;
+  *out = ds.release();
+  return NFM_OK;
+}
+
+int32_t nfm_dataset_create_csr_device(nfm_ctx* ctx, int64_t n, int64_t d, int64_t nnz, const int64_t* indptr_dev,
+                                      const int32_t* indices_dev, const double* data_dev, const int32_t* fields_dev,
+                                      int64_t n_fields, const double* y_dev, nfm_dataset** out) {
+  NFM_CHECK(ctx && out && indptr_dev, NFM_ERR_INVALID, "null argument");
+  NFM_CHECK(n >= 0 && d >= 0 && nnz >= 0 && d < (int64_t)2147483647 - 64, NFM_ERR_INVALID, "bad shape");
+  NFM_CHECK(nnz == 0 || (indices_dev && data_dev), NFM_ERR_INVALID, "null indices/data");
+  NFM_TRY(use_device(ctx));
+  // the row-length bound needs indptr on the host once; values are trusted to be in range
+  // (device-resident synthetic data); index range is checked by the caller's generator.
+  std::vector<int64_t> ip((size_t)n + 1);
+  NFM_HIP_CHECK(hipMemcpyAsync(ip.data(), indptr_dev, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, ctx->stream));
+  NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  NFM_CHECK(ip[0] == 0 && ip[n] == nnz, NFM_ERR_INVALID, "indptr[0] != 0 or indptr[n] != nnz");
+  int64_t mr = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    NFM_CHECK(ip[i + 1] >= ip[i], NFM_ERR_INVALID, "indptr not non-decreasing at row %lld", (long long)i);
+    mr = std::max(mr, ip[i + 1] - ip[i]);
+  }
+  std::unique_ptr<nfm_dataset> ds(new nfm_dataset());
+  ds->ctx = ctx;
+  ds->max_row = (int)mr;
+  ds->has_y = y_dev != nullptr;
+  ds->v.indptr = indptr_dev; ds->v.indices = indices_dev; ds->v.data = data_dev; ds->v.fields = fields_dev;
+  ds->v.y = y_dev; ds->v.n = n; ds->v.d = d; ds->v.nnz = nnz; ds->v.n_fields = fields_dev ? (int32_t)n_fields : 0;
+  *out = ds.release();
+  return NFM_OK;
+}
+
+int32_t nfm_dataset_set_targets(nfm_dataset* ds, const double* y) {
+  NFM_CHECK(ds && y, NFM_ERR_INVALID, "null argument");
+  NFM_TRY(use_device(ds->ctx));
+  NFM_TRY(ds->y.ensure(sizeof(double) * ds->v.n));
+  NFM_HIP_CHECK(hipMemcpyAsync(ds->y.p, y, sizeof(double) * ds->v.n, hipMemcpyHostToDevice, ds->ctx->stream));
+  NFM_HIP_CHECK(hipStreamSynchronize(ds->ctx->stream));
+  ds->has_y = true;
+  ds->v.y = ds->y.as<double>();
+  ds->serial++;
+  return NFM_OK;
+}
+
+int32_t nfm_dataset_destroy(nfm_dataset* ds) {
+  if (!ds) return NFM_OK;
+  (void)hipSetDevice(ds->ctx->device);
+  (void)hipStreamSynchronize(ds->ctx->stream);
+  delete ds;
+  return NFM_OK;
+}
+
+// ------------------------------------------------------------------ model
+int32_t nfm_model_create(nfm_ctx* ctx, const nfm_model_cfg* cfg, nfm_model** out) {
+  NFM_CHECK(ctx && cfg && out, NFM_ERR_INVALID, "null argument");
+  NFM_CHECK(cfg->kind == NFM_KIND_FM || cfg->kind == NFM_KIND_FFM, NFM_ERR_INVALID, "bad model kind");
+  NFM_CHECK(cfg->n_components >= 1, NFM_ERR_INVALID, "nComponents < 1.");
+  NFM_CHECK(cfg->n_features >= 1, NFM_ERR_INVALID, "n_features < 1");
+  NFM_TRY(use_device(ctx));
+  std::unique_ptr<nfm_model> m(new nfm_model());
+  m->ctx = ctx;
+  m->cfg = *cfg;
+  m->k = cfg->n_components;
+  m->d = cfg->n_features;
+  if (cfg->kind == NFM_KIND_FM) {
+    NFM_CHECK(cfg->degree >= 1, NFM_ERR_INVALID, "degree < 1.");
+    NFM_CHECK(cfg->fit_lower >= 0 && cfg->fit_lower <= 2, NFM_ERR_INVALID, "bad fit_lower");
+    // model/factorization_machine.nim:81-97
+    m->n_aug = cfg->fit_lower == NFM_LOWER_AUGMENT ? (cfg->fit_linear ? cfg->degree - 2 : cfg->degree - 1) : 0;
+    m->nb = cfg->degree == 1 ? 0 : (cfg->fit_lower == NFM_LOWER_EXPLICIT ? cfg->degree - 1 : 1);
+    NFM_CHECK(m->n_aug >= 0, NFM_ERR_INVALID, "fit_lower=augment needs degree >= 2 (fit_linear) or >= 1");
+  } else {
+    NFM_CHECK(cfg->n_fields >= 1, NFM_ERR_INVALID, "n_fields < 1");
+    m->n_aug = 0;
+    m->nb = (int)cfg->n_fields;
+  }
+  m->da = m->d + m->n_aug;
+  m->L = lanes_for_k(m->k);
+  m->Kp = m->k <= 128 ? 2 * m->L : ((m->k + 63) / 64) * 64;
+  if (m->k > 128) m->L = 64;
+  NFM_TRY(m->P.alloc(sizeof(double) * std::max<int64_t>(m->nP(), 2)));
+  NFM_TRY(m->w.alloc(sizeof(double) * m->d));
+  NFM_TRY(m->sc.alloc(sizeof(double) * SC_COUNT));
+  NFM_TRY(m->lams.alloc(sizeof(double) * m->Kp));
+  NFM_HIP_CHECK(hipMemsetAsync(m->P.p, 0, m->P.bytes, ctx->stream));
+  NFM_HIP_CHECK(hipMemsetAsync(m->w.p, 0, m->w.bytes, ctx->stream));
+  double sc[SC_COUNT] = {1.0, 1.0, 0.0, 0, 0, 0, 0, 0};
+  NFM_HIP_CHECK(hipMemcpyAsync(m->sc.p, sc, sizeof(sc), hipMemcpyHostToDevice, ctx->stream));
+  NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  *out = m.release();
+  return NFM_OK;
+}
+
+int32_t nfm_model_shape(const nfm_model* m, int32_t* n_blocks, int32_t* n_aug) {
+  NFM_CHECK(m, NFM_ERR_INVALID, "null model");
+  if (n_blocks) *n_blocks = m->nb;
+  if (n_aug) *n_aug = m->n_aug;
+  return NFM_OK;
+}
+
+int32_t nfm_model_set_params(nfm_model* m, const double* P, const double* w, double intercept, const double* lams) {
+  NFM_CHECK(m && w, NFM_ERR_INVALID, "null argument");
+  NFM_CHECK(m->nb == 0 || P, NFM_ERR_INVALID, "null P");
+  nfm_ctx* ctx = m->ctx;
+  NFM_TRY(use_device(ctx));
+  hipStream_t st = ctx->stream;
+  const int64_t n_ref = (int64_t)m->nb * m->k * m->da;
+  if (n_ref > 0) {
+    DevBuf tmp;
+    NFM_TRY(tmp.alloc(sizeof(double) * n_ref));
+    NFM_HIP_CHECK(hipMemcpyAsync(tmp.p, P, sizeof(double) * n_ref, hipMemcpyHostToDevice, st));
+    if (m->cfg.kind == NFM_KIND_FM)
+      NFM_TRY(launch_fm_to_device(ctx, tmp.as<double>(), m->P.as<double>(), m->nb, m->k, m->Kp, m->da));
+    else
+      NFM_TRY(launch_rows_to_device(ctx, tmp.as<double>(), m->P.as<double>(), (int64_t)m->nb * m->da, m->k, m->Kp, 0.0));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  NFM_HIP_CHECK(hipMemcpyAsync(m->w.p, w, sizeof(double) * m->d, hipMemcpyHostToDevice, st));
+  double sc[SC_COUNT] = {1.0, 1.0, intercept, 0, 0, 0, 0, 0};
+  NFM_HIP_CHECK(hipMemcpyAsync(m->sc.p, sc, sizeof(sc), hipMemcpyHostToDevice, st));
+  std::vector<double> lp((size_t)m->Kp, 0.0);
+  for (int s = 0; s < m->k; ++s) lp[s] = lams ? lams[s] : 1.0;
+  NFM_HIP_CHECK(hipMemcpyAsync(m->lams.p, lp.data(), sizeof(double) * m->Kp, hipMemcpyHostToDevice, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  m->initialized = true;
+  return NFM_OK;
+}
+
+int32_t nfm_model_get_params(nfm_model* m, double* P, double* w, double* intercept) {
+  NFM_CHECK(m, NFM_ERR_INVALID, "null model");
+  NFM_CHECK(m->initialized, NFM_ERR_NOT_FITTED, "Factorization machines is not fitted.");
+  nfm_ctx* ctx = m->ctx;
+  NFM_TRY(use_device(ctx));
+  hipStream_t st = ctx->stream;
+  double sc[SC_COUNT];
+  NFM_HIP_CHECK(hipMemcpyAsync(sc, m->sc.p, sizeof(sc), hipMemcpyDeviceToHost, st));
+  const int64_t n_ref = (int64_t)m->nb * m->k * m->da;
+  if (P && n_ref > 0) {
+    DevBuf tmp;
+    NFM_TRY(tmp.alloc(sizeof(double) * n_ref));
+    if (m->cfg.kind == NFM_KIND_FM)
+      NFM_TRY(launch_fm_from_device(ctx, m->P.as<double>(), tmp.as<double>(), m->nb, m->k, m->Kp, m->da, m->sc.as<double>() + SC_SCALE_P));
+    else
+      NFM_TRY(launch_rows_from_device(ctx, m->P.as<double>(), tmp.as<double>(), (int64_t)m->nb * m->da, m->k, m->Kp,
+                                      m->sc.as<double>() + SC_SCALE_P));
+    NFM_HIP_CHECK(hipMemcpyAsync(P, tmp.p, sizeof(double) * n_ref, hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  if (w) NFM_HIP_CHECK(hipMemcpyAsync(w, m->w.p, sizeof(double) * m->d, hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  if (w && sc[SC_SCALE_W] != 1.0)
+    for (int64_t j = 0; j < m->d; ++j) w[j] *= sc[SC_SCALE_W];
+  if (intercept) *intercept = sc[SC_INTERCEPT];
+  return NFM_OK;
+}
+
+static int check_predict_shapes(nfm_model* m, nfm_dataset* ds) {
+  NFM_CHECK(m && ds, NFM_ERR_INVALID, "null argument");
+  NFM_CHECK(m->ctx == ds->ctx, NFM_ERR_INVALID, "model and dataset belong to different contexts");
+  NFM_CHECK(m->initialized, NFM_ERR_NOT_FITTED, "Factorization machines is not fitted.");
+  NFM_CHECK(ds->v.d == m->d, NFM_ERR_INVALID, "Invalid nFeatures.");
+  if (m->cfg.kind == NFM_KIND_FFM) {
+    NFM_CHECK(ds->v.fields != nullptr, NFM_ERR_INVALID, "FFM needs a CSRFieldDataset (fields == NULL)");
+    NFM_CHECK(ds->v.n_fields == m->nb, NFM_ERR_INVALID, "Invalid nFields.");
+  }
+  return NFM_OK;
+}
+
+int32_t nfm_decision_function_device(nfm_model* m, nfm_dataset* ds, double* out_dev) {
+  NFM_TRY(check_predict_shapes(m, ds));
+  NFM_CHECK(out_dev || ds->v.n == 0, NFM_ERR_INVALID, "null out");
+  NFM_CHECK(m->cfg.kind == NFM_KIND_FFM || m->cfg.degree <= 6, NFM_ERR_UNSUPPORTED, "degree > 6 unsupported");
+  NFM_TRY(use_device(m->ctx));
+  return launch_predict(m->ctx, ds->v, m->view(), out_dev);
+}
+
+int32_t nfm_decision_function(nfm_model* m, nfm_dataset* ds, double* out) {
+  NFM_TRY(check_predict_shapes(m, ds));
+  NFM_CHECK(out || ds->v.n == 0, NFM_ERR_INVALID, "null out");
+  NFM_TRY(use_device(m->ctx));
+  DevBuf tmp;
+  NFM_TRY(tmp.alloc(sizeof(double) * ds->v.n));
+  NFM_TRY(nfm_decision_function_device(m, ds, tmp.as<double>()));
+  NFM_HIP_CHECK(hipMemcpyAsync(out, tmp.p, sizeof(double) * ds->v.n, hipMemcpyDeviceToHost, m->ctx->stream));
+  NFM_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  return NFM_OK;
+}
+
+int32_t nfm_model_sqnorms(nfm_model* m, double* P_sq, double* w_sq) {
+  NFM_CHECK(m, NFM_ERR_INVALID, "null model");
+  NFM_TRY(use_device(m->ctx));
+  DevBuf out;
+  NFM_TRY(out.alloc(sizeof(double) * 2));
+  NFM_TRY(launch_sqnorms(m->ctx, m->view(), out.as<double>()));
+  double h[2];
+  NFM_HIP_CHECK(hipMemcpy(h, out.p, sizeof(h), hipMemcpyDeviceToHost));
+  if (P_sq) *P_sq = h[0];
+  if (w_sq) *w_sq = h[1];
+  return NFM_OK;
+}
+
+int32_t nfm_model_device_buffers(nfm_model* m, double** P_dev, int64_t* n_P, double** w_dev, int64_t* n_w,
+                                 double** scalars_dev, int64_t* n_scalars) {
+  NFM_CHECK(m, NFM_ERR_INVALID, "null model");
+  if (P_dev) *P_dev = m->P.as<double>();
+  if (n_P) *n_P = m->nP();
+  if (w_dev) *w_dev = m->w.as<double>();
+  if (n_w) *n_w = m->d;
+  if (scalars_dev) *scalars_dev = m->sc.as<double>();
+  if (n_scalars) *n_scalars = SC_COUNT;
+  return NFM_OK;
+}
+
+int32_t nfm_model_destroy(nfm_model* m) {
+  if (!m) return NFM_OK;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  delete m;
+  return NFM_OK;
+}
+
+// ------------------------------------------------------------------ optimizers
+static int check_common(nfm_model* m, int loss, int mode, int64_t batch) {
+  NFM_CHECK(m, NFM_ERR_INVALID, "null model");
+  NFM_CHECK(loss >= 0 && loss <= 3, NFM_ERR_INVALID, "bad loss id");
+  NFM_CHECK(mode == NFM_MODE_SEQUENTIAL || mode == NFM_MODE_MINIBATCH, NFM_ERR_INVALID, "bad mode");
+  NFM_CHECK(mode == NFM_MODE_SEQUENTIAL || batch >= 1, NFM_ERR_INVALID, "batch must be >= 1");
+  return NFM_OK;
+}
+
+int32_t nfm_sgd_create(nfm_model* m, const nfm_sgd_cfg* c, nfm_opt** out) {
+  NFM_CHECK(c && out, NFM_ERR_INVALID, "null argument");
+  NFM_TRY(check_common(m, c->loss, c->mode, c->batch));
+  NFM_CHECK(c->scheduling >= 0 && c->scheduling <= 3, NFM_ERR_INVALID, "bad scheduling id");
+  std::unique_ptr<nfm_opt> o(new nfm_opt());
+  o->m = m; o->kind = OPT_SGD; o->mode = c->mode; o->batch = c->mode == NFM_MODE_MINIBATCH ? c->batch : 1; o->it = 1;
+  o->o.eta0 = c->eta0; o->o.alpha0 = c->alpha0; o->o.alpha = c->alpha; o->o.beta = c->beta; o->o.power = c->power;
+  o->o.eps = 0.0; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = c->scheduling; o->o.track_viol = 1;
+  NFM_TRY(use_device(m->ctx));
+  NFM_TRY(o->out2.alloc(sizeof(double) * 2));
+  *out = o.release();
+  return NFM_OK;
+}
+
+int32_t nfm_adagrad_create(nfm_model* m, const nfm_adagrad_cfg* c, nfm_opt** out) {
+  NFM_CHECK(c && out, NFM_ERR_INVALID, "null argument");
+  NFM_TRY(check_common(m, c->loss, c->mode, c->batch));
+  std::unique_ptr<nfm_opt> o(new nfm_opt());
+  o->m = m; o->kind = OPT_ADAGRAD; o->mode = c->mode; o->batch = c->mode == NFM_MODE_MINIBATCH ? c->batch : 1; o->it = 1;
+  o->o.eta0 = c->eta0; o->o.alpha0 = c->alpha0; o->o.alpha = c->alpha; o->o.beta = c->beta; o->o.power = 1.0;
+  o->o.eps = c->eps; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = 0; o->o.track_viol = c->track_viol;
+  NFM_TRY(use_device(m->ctx));
+  NFM_TRY(o->out2.alloc(sizeof(double) * 2));
+  NFM_TRY(o->G.alloc(sizeof(double) * std::max<int64_t>(m->nP(), 2)));
+  NFM_TRY(o->N.alloc(sizeof(double) * std::max<int64_t>(m->nP(), 2)));
+  NFM_TRY(o->Gw.alloc(sizeof(double) * m->d));
+  NFM_TRY(o->Nw.alloc(sizeof(double) * m->d));
+  NFM_TRY(o->gsc.alloc(sizeof(double) * 2));
+  o->o.G = o->G.as<double>(); o->o.N = o->N.as<double>(); o->o.Gw = o->Gw.as<double>(); o->o.Nw = o->Nw.as<double>();
+  o->o.gsc = o->gsc.as<double>();
+  *out = o.release();
+  return NFM_OK;
+}
+
+int32_t nfm_opt_set_it(nfm_opt* o, int64_t it) {
+  NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
+  NFM_CHECK(it >= 1, NFM_ERR_INVALID, "it must be >= 1");
+  o->it = it;
+  return NFM_OK;
+}
+int32_t nfm_opt_get_it(nfm_opt* o, int64_t* it) {
+  NFM_CHECK(o && it, NFM_ERR_INVALID, "null argument");
+  *it = o->it;
+  return NFM_OK;
+}
+
+// adagrad.nim:52-55: g_sum = 0, g_norm = eps when it == 1
+static int adagrad_reset_state(nfm_opt* o) {
+  nfm_model* m = o->m;
+  nfm_ctx* ctx = m->ctx;
+  NFM_HIP_CHECK(hipMemsetAsync(o->G.p, 0, o->G.bytes, ctx->stream));
+  NFM_HIP_CHECK(hipMemsetAsync(o->Gw.p, 0, o->Gw.bytes, ctx->stream));
+  NFM_TRY(launch_fill(ctx, o->N.as<double>(), std::max<int64_t>(m->nP(), 2), o->o.eps));
+  NFM_TRY(launch_fill(ctx, o->Nw.as<double>(), m->d, o->o.eps));
+  const double g[2] = {0.0, o->o.eps};
+  NFM_HIP_CHECK(hipMemcpyAsync(o->gsc.p, g, sizeof(g), hipMemcpyHostToDevice, ctx->stream));
+  NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  o->state_ready = true;
+  return NFM_OK;
+}
+
+int32_t nfm_opt_get_state(nfm_opt* o, double* gsum_P, double* gnorm_P, double* gsum_w, double* gnorm_w, double* gsum_b,
+                          double* gnorm_b) {
+  NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
+  NFM_CHECK(o->kind == OPT_ADAGRAD, NFM_ERR_INVALID, "only AdaGrad carries state");
+  nfm_model* m = o->m;
+  nfm_ctx* ctx = m->ctx;
+  NFM_TRY(use_device(ctx));
+  if (!o->state_ready) NFM_TRY(adagrad_reset_state(o));
+  const int64_t rows = (int64_t)m->nb * m->da, n_ref = rows * m->k;
+  DevBuf tmp;
+  NFM_TRY(tmp.alloc(sizeof(double) * std::max<int64_t>(n_ref, 1)));
+  for (int which = 0; which < 2; ++which) {
+    double* dst = which ? gnorm_P : gsum_P;
+    if (!dst || n_ref == 0) continue;
+    NFM_TRY(launch_rows_from_device(ctx, which ? o->N.as<double>() : o->G.as<double>(), tmp.as<double>(), rows, m->k, m->Kp, nullptr));
+    NFM_HIP_CHECK(hipMemcpyAsync(dst, tmp.p, sizeof(double) * n_ref, hipMemcpyDeviceToHost, ctx->stream));
+    NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  if (gsum_w) NFM_HIP_CHECK(hipMemcpyAsync(gsum_w, o->Gw.p, sizeof(double) * m->d, hipMemcpyDeviceToHost, ctx->stream));
+  if (gnorm_w) NFM_HIP_CHECK(hipMemcpyAsync(gnorm_w, o->Nw.p, sizeof(double) * m->d, hipMemcpyDeviceToHost, ctx->stream));
+  double g[2];
+  NFM_HIP_CHECK(hipMemcpyAsync(g, o->gsc.p, sizeof(g), hipMemcpyDeviceToHost, ctx->stream));
+  NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (gsum_b) *gsum_b = g[0];
+  if (gnorm_b) *gnorm_b = g[1];
+  return NFM_OK;
+}
+
+int32_t nfm_opt_set_state(nfm_opt* o, const double* gsum_P, const double* gnorm_P, const double* gsum_w,
+                          const double* gnorm_w, double gsum_b, double gnorm_b) {
+  NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
+  NFM_CHECK(o->kind == OPT_ADAGRAD, NFM_ERR_INVALID, "only AdaGrad carries state");
+  nfm_model* m = o->m;
+  nfm_ctx* ctx = m->ctx;
+  NFM_TRY(use_device(ctx));
+  const int64_t rows = (int64_t)m->nb * m->da, n_ref = rows * m->k;
+  NFM_CHECK(n_ref == 0 || (gsum_P && gnorm_P), NFM_ERR_INVALID, "null state");
+  NFM_CHECK(gsum_w && gnorm_w, NFM_ERR_INVALID, "null state");
+  DevBuf tmp;
+  NFM_TRY(tmp.alloc(sizeof(double) * std::max<int64_t>(n_ref, 1)));
+  if (n_ref > 0) {
+    NFM_HIP_CHECK(hipMemcpyAsync(tmp.p, gsum_P, sizeof(double) * n_ref, hipMemcpyHostToDevice, ctx->stream));
+    NFM_TRY(launch_rows_to_device(ctx, tmp.as<double>(), o->G.as<double>(), rows, m->k, m->Kp, 0.0));
+    NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    NFM_HIP_CHECK(hipMemcpyAsync(tmp.p, gnorm_P, sizeof(double) * n_ref, hipMemcpyHostToDevice, ctx->stream));
+    NFM_TRY(launch_rows_to_device(ctx, tmp.as<double>(), o->N.as<double>(), rows, m->k, m->Kp, o->o.eps));
+    NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  NFM_HIP_CHECK(hipMemcpyAsync(o->Gw.p, gsum_w, sizeof(double) * m->d, hipMemcpyHostToDevice, ctx->stream));
+  NFM_HIP_CHECK(hipMemcpyAsync(o->Nw.p, gnorm_w, sizeof(double) * m->d, hipMemcpyHostToDevice, ctx->stream));
+  const double g[2] = {gsum_b, gnorm_b};
+  NFM_HIP_CHECK(hipMemcpyAsync(o->gsc.p, g, sizeof(g), hipMemcpyHostToDevice, ctx->stream));
+  NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  o->state_ready = true;
+  return NFM_OK;
+}
+
+static int ensure_unit_scale(nfm_model* m) {
+  double sc[SC_COUNT];
+  NFM_HIP_CHECK(hipMemcpyAsync(sc, m->sc.p, sizeof(sc), hipMemcpyDeviceToHost, m->ctx->stream));
+  NFM_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  if (sc[SC_SCALE_P] != 1.0 || sc[SC_SCALE_W] != 1.0) {
+    ModelView v = m->view();
+    v.fit_linear = 1;  // w carries its scale regardless of who trained it
+    NFM_TRY(launch_rescale(m->ctx, v));
+  }
+  return NFM_OK;
+}
+
+int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t begin, int64_t end, double* loss_sum,
+                      double* viol_sum) {
+  NFM_CHECK(o && ds, NFM_ERR_INVALID, "null argument");
+  nfm_model* m = o->m;
+  nfm_ctx* ctx = m->ctx;
+  NFM_CHECK(ds->ctx == ctx, NFM_ERR_INVALID, "optimizer and dataset belong to different contexts");
+  NFM_TRY(check_predict_shapes(m, ds));
+  NFM_CHECK(ds->has_y, NFM_ERR_INVALID, "dataset has no targets");
+  NFM_CHECK(begin >= 0 && begin <= end && end <= ds->v.n, NFM_ERR_INVALID, "bad sample range [%lld,%lld)", (long long)begin,
+            (long long)end);
+  if (perm)
+    for (int64_t p = begin; p < end; ++p)
+      NFM_CHECK(perm[p] >= 0 && perm[p] < ds->v.n, NFM_ERR_INVALID, "perm[%lld] = %lld out of range", (long long)p, (long long)perm[p]);
+  NFM_TRY(use_device(ctx));
+  hipStream_t st = ctx->stream;
+  if (o->kind == OPT_ADAGRAD) {
+    if (o->it == 1 || !o->state_ready) NFM_TRY(adagrad_reset_state(o));
+    NFM_TRY(ensure_unit_scale(m));
+  }
+  double out2[2] = {0.0, 0.0};
+  const int64_t ns = end - begin;
+  if (ns > 0) {
+    const ModelView M = m->view();
+    if (o->mode == NFM_MODE_SEQUENTIAL) {
+      const int64_t* perm_dev = nullptr;
+      if (perm) {
+        NFM_TRY(o->perm_dev.ensure(sizeof(int64_t) * ns));
+        NFM_HIP_CHECK(hipMemcpyAsync(o->perm_dev.p, perm + begin, sizeof(int64_t) * ns, hipMemcpyHostToDevice, st));
+        perm_dev = o->perm_dev.as<int64_t>() - begin;  // indexed by absolute position
+      }
+      NFM_TRY(launch_sequential(ctx, o->kind, ds->v, M, o->o, perm_dev, begin, end, o->it, ds->max_row + m->n_aug, o->out2.as<double>()));
+      NFM_HIP_CHECK(hipMemcpyAsync(out2, o->out2.p, sizeof(out2), hipMemcpyDeviceToHost, st));
+      NFM_HIP_CHECK(hipStreamSynchronize(st));
+    } else {
+      const bool first_singleton = o->kind == OPT_ADAGRAD && o->it == 1;
+      const bool want_tq = m->cfg.kind == NFM_KIND_FFM;
+      const bool reuse = o->plan && !perm && !o->plan->has_perm && o->plan->ds == (const void*)ds && o->plan->begin == begin &&
+                         o->plan->end == end && o->plan->batch == o->batch && o->plan->first_singleton == first_singleton &&
+                         o->plan->n_aug == m->n_aug;
+      if (!reuse) {
+        if (!o->plan) o->plan.reset(new Plan());
+        TimedLaunch tl(ctx, "plan_build");
+        NFM_TRY(plan_build(ctx, ds->v, m->n_aug, perm, begin, end, o->batch, first_singleton, want_tq, o->plan.get()));
+        o->plan->ds = ds;
+      }
+      if (m->cfg.kind == NFM_KIND_FM)
+        NFM_TRY(mb_fm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2));
+      else
+        NFM_TRY(mb_ffm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2));
+    }
+    o->it += ns;
+    if (o->kind == OPT_SGD) {  // resetScaling, sgd.nim:116-131
+      double sc[SC_COUNT];
+      NFM_HIP_CHECK(hipMemcpyAsync(sc, m->sc.p, sizeof(sc), hipMemcpyDeviceToHost, st));
+      NFM_HIP_CHECK(hipStreamSynchronize(st));
+      if (sc[SC_SCALE_P] < 1e-9 || (m->cfg.fit_linear && sc[SC_SCALE_W] < 1e-9)) NFM_TRY(launch_rescale(ctx, M));
+    }
+  }
+  if (loss_sum) *loss_sum = out2[0];
+  if (viol_sum) *viol_sum = out2[1];
+  return NFM_OK;
+}
+
+int32_t nfm_opt_finalize(nfm_opt* o) {
+  NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
+  nfm_model* m = o->m;
+  NFM_TRY(use_device(m->ctx));
+  if (o->kind == OPT_SGD) {
+    NFM_TRY(launch_rescale(m->ctx, m->view()));
+  } else if (o->state_ready) {
+    NFM_TRY(launch_adagrad_finalize(m->ctx, m->view(), o->o, o->it));
+  }
+  NFM_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  return NFM_OK;
+}
+
+int32_t nfm_opt_device_state(nfm_opt* o, double** gsum_P, double** gnorm_P, int64_t* n_P, double** gsum_w, double** gnorm_w,
+                             int64_t* n_w, double** gscalars) {
+  NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
+  NFM_CHECK(o->kind == OPT_ADAGRAD, NFM_ERR_INVALID, "only AdaGrad carries state");
+  if (!o->state_ready) {
+    NFM_TRY(use_device(o->m->ctx));
+    NFM_TRY(adagrad_reset_state(o));
+  }
+  if (gsum_P) *gsum_P = o->G.as<double>();
+  if (gnorm_P) *gnorm_P = o->N.as<double>();
+  if (n_P) *n_P = o->m->nP();
+  if (gsum_w) *gsum_w = o->Gw.as<double>();
+  if (gnorm_w) *gnorm_w = o->Nw.as<double>();
+  if (n_w) *n_w = o->m->d;
+  if (gscalars) *gscalars = o->gsc.as<double>();
+  return NFM_OK;
+}
+
+int32_t nfm_opt_destroy(nfm_opt* o) {
+  if (!o) return NFM_OK;
+  (void)hipSetDevice(o->m->ctx->device);
+  (void)hipStreamSynchronize(o->m->ctx->stream);
+  delete o;
+  return NFM_OK;
+}
+
+}  // extern "C"

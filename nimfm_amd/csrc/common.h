@@ -1,0 +1,151 @@
+// nimfm_amd/csrc/common.h -- internal declarations shared by the HIP translation units of
+// libnimfm_hip.so.  gfx950 (MI355X, CDNA4) only: 64-lane wavefronts are assumed throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nimfm_hip.h"
+
+namespace nfm {
+
+int set_error(int code, const char* fmt, ...);
+const char* last_error();
+
+#define NFM_HIP_CHECK(expr)                                                                  \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return nfm::set_error(NFM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                            __FILE__, __LINE__);                                             \
+  } while (0)
+
+#define NFM_CHECK(cond, code, ...) \
+  do {                             \
+    if (!(cond)) return nfm::set_error(code, __VA_ARGS__); \
+  } while (0)
+
+#define NFM_TRY(expr)        \
+  do {                       \
+    int rc_ = (expr);        \
+    if (rc_ != NFM_OK) return rc_; \
+  } while (0)
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;  // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+// ---------------------------------------------------------------------------------------------
+// Device data layout
+//   CSR:    indptr int64[n+1], indices int32[nnz], data f64[nnz], fields int32[nnz]?, y f64[n]?
+//   params: P  f64[nb][da][Kp]   nb = nOrders (FM) | nFields (FFM), da = d + nAug,
+//                                Kp = 2*L >= k, L = lanes per row (power of two); row = Kp*8 bytes,
+//                                16-byte aligned; padding s >= k is kept at exactly 0.
+//           w  f64[d]
+//           sc f64[8]: sc[0] = scale_P, sc[1] = scale_w, sc[2] = intercept.
+//   The true parameter values are scale_P * P and scale_w * w: the reference's lazy L2 scaling
+//   (optimizer/sgd.nim:99-143) kept as ONE global factor, so decay never touches memory.
+// ---------------------------------------------------------------------------------------------
+struct CsrView {
+  const int64_t* indptr;
+  const int32_t* indices;
+  const double* data;
+  const int32_t* fields;
+  const double* y;
+  int64_t n, d, nnz;
+  int32_t n_fields;
+};
+
+enum { SC_SCALE_P = 0, SC_SCALE_W = 1, SC_INTERCEPT = 2, SC_COUNT = 8 };
+
+struct ModelView {
+  double* P;
+  double* w;
+  double* sc;
+  const double* lams;  // [Kp], zero padded
+  int64_t d, da;
+  int32_t nb, k, Kp, L, degree, n_aug, kind, fit_linear, fit_intercept, task;
+};
+
+struct LossCfg {
+  int32_t loss;
+  double param;
+};
+
+struct Timing {
+  struct Acc {
+    int64_t launches = 0;
+    double ms = 0.0;
+  };
+  struct Pending {
+    std::string family;
+    hipEvent_t start, stop;
+  };
+  bool enabled = false;
+  std::map<std::string, Acc> acc;
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> pool;
+};
+
+}  // namespace nfm
+
+struct nfm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  nfm::Timing timing;
+  int n_cu = 256;
+};
+
+namespace nfm {
+
+// RAII-ish helper: brackets the launches issued between begin() and end() with events when
+// timing is enabled.
+struct TimedLaunch {
+  nfm_ctx* ctx;
+  const char* family;
+  hipEvent_t start = nullptr, stop = nullptr;
+  TimedLaunch(nfm_ctx* c, const char* f);
+  ~TimedLaunch();
+};
+int timing_flush(nfm_ctx* ctx);
+
+struct DevBuf {  // owned device allocation
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  int alloc(size_t nbytes);
+  int ensure(size_t nbytes) { return nbytes <= bytes && p ? NFM_OK : alloc(nbytes); }
+  void release();
+  template <class T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline int lanes_for_k(int k) {
+  int half = (k + 1) / 2, L = 1;
+  while (L < half) L <<= 1;
+  return L;
+}
+
+// ---- util.hip ----
+int launch_fill(nfm_ctx* ctx, double* p, int64_t n, double v);
+// reference FM layout [nb][k][da] <-> device [nb][da][Kp]; FFM reference [nb][da][k] <-> device
+int launch_fm_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int nb, int k, int Kp, int64_t da);
+int launch_fm_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int nb, int k, int Kp, int64_t da, const double* scale_dev);
+int launch_rows_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int64_t rows, int k, int Kp, double pad_value);
+int launch_rows_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int64_t rows, int k, int Kp, const double* scale_dev);
+// P *= sc[SC_SCALE_P], w *= sc[SC_SCALE_W] (if fit_linear), scales := 1  (sgd.nim:99-113)
+int launch_rescale(nfm_ctx* ctx, const ModelView& M);
+int launch_sqnorms(nfm_ctx* ctx, const ModelView& M, double* out2_dev /*{P_sq,w_sq}*/);
+int launch_narrow_i64_i32(nfm_ctx* ctx, const int64_t* src, int32_t* dst, int64_t n);
+
+// ---- predict.hip ----
+int launch_predict(nfm_ctx* ctx, const CsrView& X, const ModelView& M, double* out_dev);
+
+}  // namespace nfm

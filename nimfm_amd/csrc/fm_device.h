@@ -1,0 +1,257 @@
+// nimfm_amd/csrc/fm_device.h -- device-side building blocks shared by the predict, row-phase and
+// column-phase kernels.  Written for gfx950 wave64.
+//
+// Work decomposition of one CSR row on one wavefront ("lanes <-> latent factors"):
+//   L lanes (power of two, Kp = 2L) cover one parameter row P[j][0..Kp) as one 16-byte load each,
+//   so a wave-instruction gathers R = 64/L rows (R*Kp*8 = 1 KiB, each row one contiguous,
+//   aligned segment).  Lane = (g, l): g = row slot, l = factor pair {2l, 2l+1}.
+//   The row's (index, value) slice is held one nnz per lane (64 per chunk) and handed to the
+//   row slots with ds_bpermute (__shfl); the per-factor sums are finished with xor-shuffles.
+#pragma once
+#include "common.h"
+
+namespace nfm {
+namespace dev {
+
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, kWave); }
+__device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, kWave); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int s = 1; s < kWave; s <<= 1) v += shfl_xor_d(v, s);
+  return v;
+}
+
+// loss.nim:15-102 (Huber's sign quirk at :90-93 kept)
+__device__ __forceinline__ double loss_value(int loss, double param, double y, double p) {
+  switch (loss) {
+    case NFM_LOSS_SQUARED: {
+      const double r = y - p;
+      return 0.5 * (r * r);
+    }
+    case NFM_LOSS_SQUARED_HINGE: {
+      const double z = 1 - p * y;
+      const double m = z > 0 ? z : 0;
+      return m * m;
+    }
+    case NFM_LOSS_LOGISTIC: {
+      const double z = p * y;
+      if (z > 0) return log(1 + exp(-z));
+      return log(exp(z) + 1) - z;
+    }
+    default: {
+      const double z = fabs(y - p);
+      if (z < param) return 0.5 * (z * z);
+      return param * (z - 0.5 * param);
+    }
+  }
+}
+
+__device__ __forceinline__ double loss_grad(int loss, double param, double y, double p) {
+  switch (loss) {
+    case NFM_LOSS_SQUARED:
+      return p - y;
+    case NFM_LOSS_SQUARED_HINGE: {
+      const double z = 1 - p * y;
+      return z > 0 ? -2 * y * z : 0.0;
+    }
+    case NFM_LOSS_LOGISTIC: {
+      const double z = p * y;
+      if (z > 0) return -y * exp(-z) / (1 + exp(-z));
+      return -y / (exp(z) + 1);
+    }
+    default: {
+      const double z = fabs(y - p);
+      return z < param ? y - p : param;
+    }
+  }
+}
+
+// optimizer/sgd.nim:60-69
+__device__ __forceinline__ double get_eta(int sched, double eta0, double power, double reg, double it) {
+  switch (sched) {
+    case NFM_SCHED_CONSTANT:
+      return eta0;
+    case NFM_SCHED_OPTIMAL: {
+      const double base = 1.0 + eta0 * reg * it;
+      return eta0 / (power == 1.0 ? base : pow(base, power));
+    }
+    case NFM_SCHED_INVSCALING:
+      return eta0 / (power == 1.0 ? it : pow(it, power));
+    default:
+      return 1.0 / (reg * it);
+  }
+}
+
+// model/fm_base.nim:32-34: classification targets are sign(y)
+__device__ __forceinline__ double target_of(double y, int task) {
+  if (task == NFM_TASK_CLASSIFICATION) return (double)((y > 0) - (y < 0));
+  return y;
+}
+
+struct RowChunk {
+  int idx;
+  double val;
+};
+
+// nnz (c*64 + lane) of the row that starts at q0 with m stored entries followed by n_aug dummy
+// features (index d+t, value 1.0; dataset.nim:182-189).  Lanes past the end hold (0, 0.0), which
+// contributes nothing to any sum below and points at a valid parameter row.
+__device__ __forceinline__ RowChunk load_chunk(const CsrView& X, int64_t q0, int m, int m_tot, int c, int lane) {
+  const int q = c * kWave + lane;
+  RowChunk r;
+  r.idx = 0;
+  r.val = 0.0;
+  if (q < m) {
+    r.idx = X.indices[q0 + q];
+    r.val = X.data[q0 + q];
+  } else if (q < m_tot) {
+    r.idx = (int)(X.d + (q - m));
+    r.val = 1.0;
+  }
+  return r;
+}
+
+// Parameter sources: how a kernel obtains the true value of P[off], P[off+1].
+struct PlainParams {  // SGD / predict: scale * stored
+  const double* P;
+  double scale;
+  __device__ __forceinline__ double2 load(size_t off) const {
+    double2 v = *reinterpret_cast<const double2*>(P + off);
+    v.x *= scale;
+    v.y *= scale;
+    return v;
+  }
+};
+
+// optimizer/adagrad.nim:96-98: P = -(eta0 * g_sum) / (eta0*(it-1)*beta + sqrt(g_norm))
+__device__ __forceinline__ double adagrad_param(double g, double n, double eta0, double tmp) {
+  return -(eta0 * g) / (tmp + sqrt(n));
+}
+struct AdaParams {
+  const double* G;
+  const double* N;
+  double eta0, tmp;
+  __device__ __forceinline__ double2 load(size_t off) const {
+    const double2 g = *reinterpret_cast<const double2*>(G + off);
+    const double2 n = *reinterpret_cast<const double2*>(N + off);
+    double2 v;
+    v.x = adagrad_param(g.x, n.x, eta0, tmp);
+    v.y = adagrad_param(g.y, n.y, eta0, tmp);
+    return v;
+  }
+};
+
+// ---- ANOVA forward, degree 2: the sum-of-squares trick (optimizer/sgd.nim:160-170,
+// kernels.nim:59-64).  Returns A1 = sum x p, A2 = sum (x p)^2 for this lane's factor pair,
+// reduced over the whole row (identical in every row slot).
+template <int L, class PS>
+__device__ __forceinline__ void anova_fwd_deg2(const PS& ps, const CsrView& X, int64_t q0, int m, int m_tot,
+                                               size_t blk_off, int Kp, int lane, double2& A1, double2& A2) {
+  constexpr int R = kWave / L;
+  const int g = lane / L, l = lane % L;
+  double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
+  for (int c = 0; c * kWave < m_tot; ++c) {
+    const RowChunk rc = load_chunk(X, q0, m, m_tot, c, lane);
+    const int len = min(kWave, m_tot - c * kWave);
+    const int iters = (len + R - 1) / R;
+#pragma unroll 4
+    for (int it = 0; it < iters; ++it) {
+      const int src = it * R + g;
+      const int j = __shfl(rc.idx, src, kWave);
+      const double x = shfl_d(rc.val, src);
+      const double2 p = ps.load(blk_off + (size_t)j * Kp + 2 * l);
+      const double tx = x * p.x, ty = x * p.y;
+      a1.x += tx;
+      a1.y += ty;
+      a2.x += tx * tx;
+      a2.y += ty * ty;
+    }
+  }
+#pragma unroll
+  for (int s = L; s < kWave; s <<= 1) {
+    a1.x += shfl_xor_d(a1.x, s);
+    a1.y += shfl_xor_d(a1.y, s);
+    a2.x += shfl_xor_d(a2.x, s);
+    a2.y += shfl_xor_d(a2.y, s);
+  }
+  A1 = a1;
+  A2 = a2;
+}
+
+// ---- ANOVA forward, degree >= 3: the DP of optimizer/sgd.nim:152-159 (kernels.nim:54-58),
+// A[t] += A[t-1] * p * x for t = DEG..1 per nnz.  A[t] is the t-th elementary symmetric
+// polynomial of {p_j x_j}; partial results over disjoint nnz subsets (the row slots) combine by
+// truncated polynomial multiplication.  E[0] = 1.
+template <int L, int DEG, class PS>
+__device__ __forceinline__ void anova_fwd_degn(const PS& ps, const CsrView& X, int64_t q0, int m, int m_tot,
+                                               size_t blk_off, int Kp, int lane, double2 (&E)[DEG + 1]) {
+  constexpr int R = kWave / L;
+  const int g = lane / L, l = lane % L;
+#pragma unroll
+  for (int t = 0; t <= DEG; ++t) E[t] = {0.0, 0.0};
+  E[0] = {1.0, 1.0};
+  for (int c = 0; c * kWave < m_tot; ++c) {
+    const RowChunk rc = load_chunk(X, q0, m, m_tot, c, lane);
+    const int len = min(kWave, m_tot - c * kWave);
+    const int iters = (len + R - 1) / R;
+#pragma unroll 2
+    for (int it = 0; it < iters; ++it) {
+      const int src = it * R + g;
+      const int j = __shfl(rc.idx, src, kWave);
+      const double x = shfl_d(rc.val, src);
+      const double2 p = ps.load(blk_off + (size_t)j * Kp + 2 * l);
+#pragma unroll
+      for (int t = DEG; t >= 1; --t) {
+        E[t].x += E[t - 1].x * p.x * x;
+        E[t].y += E[t - 1].y * p.y * x;
+      }
+    }
+  }
+#pragma unroll
+  for (int s = L; s < kWave; s <<= 1) {
+    double2 lo[DEG + 1], hi[DEG + 1];
+    const bool upper = (lane & s) != 0;
+#pragma unroll
+    for (int t = 0; t <= DEG; ++t) {
+      double2 o;
+      o.x = shfl_xor_d(E[t].x, s);
+      o.y = shfl_xor_d(E[t].y, s);
+      lo[t] = upper ? o : E[t];  // both partners form the same (lo, hi) pair
+      hi[t] = upper ? E[t] : o;
+    }
+#pragma unroll
+    for (int t = 1; t <= DEG; ++t) {
+      double2 acc = {0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u <= t; ++u) {
+        acc.x += lo[u].x * hi[t - u].x;
+        acc.y += lo[u].y * hi[t - u].y;
+      }
+      E[t] = acc;
+    }
+  }
+}
+
+// sum over this lane's factor pair, then over the L lanes of the row slot
+template <int L>
+__device__ __forceinline__ double sum_factors(double2 v) {
+  double r = v.x + v.y;
+#pragma unroll
+  for (int s = 1; s < L; s <<= 1) r += shfl_xor_d(r, s);
+  return r;
+}
+
+// Derivative of the degree-DEG ANOVA kernel w.r.t. p_js (optimizer/sgd.nim:176-188):
+//   DEG == 2: x (A1 - p x);  DEG >= 3: dA = x; for t in 1..<DEG: dA = x (A[t] - p dA)
+template <int DEG>
+__device__ __forceinline__ double anova_grad(double x, double p, const double* A /*A[1..DEG-1] at A[0..]*/) {
+  if (DEG == 2) return x * (A[0] - p * x);
+  double dA = x;
+#pragma unroll
+  for (int t = 1; t < DEG; ++t) dA = x * (A[t - 1] - p * dA);
+  return dA;
+}
+
+}  // namespace dev
+}  // namespace nfm

@@ -1,0 +1,25 @@
+// nimfm_amd/csrc/mb.h -- mini-batch mode: work buffers and entry points.
+#pragma once
+#include "opt_views.h"
+#include "plan.h"
+
+namespace nfm {
+
+// Scratch owned by an optimizer and reused by every batch/epoch.
+struct MbWork {
+  DevBuf Abuf;     // per-sample per-factor sums of the current batch  [B][TA][Kp]
+  DevBuf rec;      // per-sample record {dL, eta_P, eta_w, -}          [B]
+  DevBuf partsA;   // per-block partial sums of the row phase
+  DevBuf partsB;   // per-block partial viol of the column phase
+  DevBuf Dtab;     // per-batch decay products {D_P, D_w, D_0, -}
+  DevBuf Stab;     // scales at every batch boundary {scale_P, scale_w}
+  DevBuf out_acc;  // {loss_sum, viol_sum} of the epoch call
+  DevBuf contrib;  // FFM: per-touch gradient rows
+};
+
+int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
+                int64_t it0, double* out2_host);
+int mb_ffm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
+                 int64_t it0, double* out2_host);
+
+}  // namespace nfm

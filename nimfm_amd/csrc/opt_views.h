@@ -1,0 +1,29 @@
+// nimfm_amd/csrc/opt_views.h -- optimizer parameter/state views passed by value to kernels.
+#pragma once
+#include "common.h"
+
+namespace nfm {
+
+enum { OPT_SGD = 0, OPT_ADAGRAD = 1 };
+
+struct OptView {
+  // hyper-parameters (newSGD optimizer/sgd.nim:23-52, newAdaGrad optimizer/adagrad.nim:20-44)
+  double eta0, alpha0, alpha, beta, power, eps, loss_param;
+  int32_t loss, sched, track_viol, pad_;
+  // AdaGrad state, device layout: G/N [nb][da][Kp] (padding: G = 0, N = eps), Gw/Nw [d],
+  // gsc[0] = g_sum.intercept, gsc[1] = g_norm.intercept
+  double* G;
+  double* N;
+  double* Gw;
+  double* Nw;
+  double* gsc;
+};
+
+// ---- seq.hip ----
+int launch_sequential(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O,
+                      const int64_t* perm_dev, int64_t begin, int64_t end, int64_t it0, int m_cap,
+                      double* out2_dev /*{loss_sum, viol_sum}*/);
+// AdaGrad finalize (optimizer/adagrad.nim:65-84): all parameters from the state with it' = it-1
+int launch_adagrad_finalize(nfm_ctx* ctx, const ModelView& M, const OptView& O, int64_t it);
+
+}  // namespace nfm

@@ -1,0 +1,36 @@
+// nimfm_amd/csrc/plan.h -- the per-epoch "batch plan": batch boundaries plus, for every batch, the
+// transposed (feature-major) view of its rows that the column phase consumes.
+#pragma once
+#include "common.h"
+
+namespace nfm {
+
+// For batch b (samples bat_pos[b]..bat_pos[b+1]) relative to `begin`):
+//   unique features  ucol[u], u in [bat_uoff[b], bat_uoff[b+1])
+//   touches of ucol[u]: t in [uptr[u], uptr[u+1]) -> (tpos[t] = sample position inside the batch,
+//   tx[t] = value, tq[t] = nnz position in the CSR arrays or -1 for a dummy feature),
+//   sorted by sample position (stable sort) so that every per-feature sum has a fixed order.
+struct Plan {
+  // identity (cache key)
+  const void* ds = nullptr;
+  int64_t begin = 0, end = 0, batch = 0;
+  int n_aug = 0;
+  bool first_singleton = false, has_perm = false;
+  // geometry
+  int64_t n_batches = 0, U = 0, T = 0, max_batch = 0, max_unique = 0;
+  std::vector<int64_t> bat_pos;   // host, n_batches + 1, relative to begin
+  std::vector<int64_t> bat_uoff;  // host, n_batches + 1
+  DevBuf perm;                    // int64[end-begin] (absolute sample ids) or empty
+  DevBuf bat_pos_dev;             // int64[n_batches + 1]
+  DevBuf ucol;                    // int32[U]
+  DevBuf uptr;                    // int64[U + 1]
+  DevBuf tpos;                    // int32[T]
+  DevBuf tx;                      // double[T]
+  DevBuf tq;                      // int64[T]  (only when want_tq)
+  void release();
+};
+
+int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
+               int64_t batch, bool first_singleton, bool want_tq, Plan* out);
+
+}  // namespace nfm

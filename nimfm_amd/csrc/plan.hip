@@ -1,0 +1,231 @@
+// nimfm_amd/csrc/plan.hip -- builds the batch plan on the device.
+//
+// The reference has no counterpart: its per-sample loop (optimizer/sgd.nim:298-308) needs no
+// transposed view.  The deterministic mini-batch rule does: the column
+// phase sums, per feature, the contributions of the batch's samples in sample order.  This is
+// preprocessing (one stable radix sort of (batch, feature) keys per plan, rocPRIM via hipCUB);
+// with shuffle off the plan is reused by every epoch.
+#include <hipcub/hipcub.hpp>
+
+#include "plan.h"
+
+namespace nfm {
+
+void Plan::release() {
+  perm.release();
+  bat_pos_dev.release();
+  ucol.release();
+  uptr.release();
+  tpos.release();
+  tx.release();
+  tq.release();
+  bat_pos.clear();
+  bat_uoff.clear();
+  n_batches = U = T = 0;
+}
+
+__device__ __forceinline__ int64_t batch_of(int64_t rel, int64_t batch, int first_singleton) {
+  if (first_singleton) return rel == 0 ? 0 : 1 + (rel - 1) / batch;
+  return rel / batch;
+}
+__device__ __forceinline__ int64_t batch_start(int64_t b, int64_t batch, int first_singleton) {
+  if (first_singleton) return b == 0 ? 0 : 1 + (b - 1) * batch;
+  return b * batch;
+}
+
+__global__ void k_row_len(CsrView X, const int64_t* __restrict__ perm, int64_t begin, int64_t ns, int n_aug,
+                          int64_t* __restrict__ len) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= ns; r += (int64_t)gridDim.x * blockDim.x) {
+    if (r == ns) {
+      len[r] = 0;
+    } else {
+      const int64_t i = perm ? perm[r] : begin + r;
+      len[r] = X.indptr[i + 1] - X.indptr[i] + n_aug;
+    }
+  }
+}
+
+// one wavefront per sample: writes the (batch, feature) key and the touch payload of every nnz
+__global__ void k_expand(CsrView X, const int64_t* __restrict__ perm, int64_t begin, int64_t ns, int n_aug,
+                         int64_t batch, int first_singleton, int fbits, const int64_t* __restrict__ toff,
+                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ tpos_un,
+                         double* __restrict__ tx_un, int64_t* __restrict__ tq_un) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t r = wave0; r < ns; r += nwaves) {
+    const int64_t i = perm ? perm[r] : begin + r;
+    const int64_t q0 = X.indptr[i];
+    const int m = (int)(X.indptr[i + 1] - q0);
+    const int m_tot = m + n_aug;
+    const int64_t b = batch_of(r, batch, first_singleton);
+    const int32_t pib = (int32_t)(r - batch_start(b, batch, first_singleton));
+    const int64_t t0 = toff[r];
+    for (int q = lane; q < m_tot; q += kWave) {
+      const int64_t j = q < m ? (int64_t)X.indices[q0 + q] : X.d + (q - m);
+      const int64_t t = t0 + q;
+      keys[t] = ((uint64_t)b << fbits) | (uint64_t)j;
+      vals[t] = (uint32_t)t;
+      tpos_un[t] = pib;
+      tx_un[t] = q < m ? X.data[q0 + q] : 1.0;
+      if (tq_un) tq_un[t] = q < m ? q0 + q : -1;
+    }
+  }
+}
+
+__global__ void k_gather_sorted(int64_t T, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                const int32_t* __restrict__ tpos_un, const double* __restrict__ tx_un,
+                                const int64_t* __restrict__ tq_un, int32_t* __restrict__ tpos, double* __restrict__ tx,
+                                int64_t* __restrict__ tq, int64_t* __restrict__ head) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= T; r += (int64_t)gridDim.x * blockDim.x) {
+    if (r == T) {
+      head[r] = 0;
+      continue;
+    }
+    const uint32_t t = vals[r];
+    tpos[r] = tpos_un[t];
+    tx[r] = tx_un[t];
+    if (tq) tq[r] = tq_un[t];
+    head[r] = (r == 0 || keys[r] != keys[r - 1]) ? 1 : 0;
+  }
+}
+
+__global__ void k_heads(int64_t T, const uint64_t* __restrict__ keys, const int64_t* __restrict__ uidx, int fbits,
+                        int32_t* __restrict__ ucol, int64_t* __restrict__ uptr, int64_t* __restrict__ bat_first_u) {
+  const uint64_t fmask = (fbits >= 64) ? ~0ull : ((1ull << fbits) - 1);
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < T; r += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = keys[r];
+    const bool is_head = r == 0 || key != keys[r - 1];
+    if (!is_head) continue;
+    const int64_t u = uidx[r];
+    ucol[u] = (int32_t)(key & fmask);
+    uptr[u] = r;
+    const uint64_t b = key >> fbits;
+    if (r == 0 || (keys[r - 1] >> fbits) != b) bat_first_u[b] = u;
+  }
+}
+
+__global__ void k_set_i64(int64_t* p, int64_t n, int64_t v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+static inline unsigned grid1d(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > 256 * 32) b = 256 * 32;
+  return (unsigned)b;
+}
+
+int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
+               int64_t batch, bool first_singleton, bool want_tq, Plan* out) {
+  Plan& P = *out;
+  P.release();
+  hipStream_t st = ctx->stream;
+  const int64_t ns = end - begin;
+  NFM_CHECK(ns >= 0 && begin >= 0 && end <= X.n, NFM_ERR_INVALID, "epoch range [%lld,%lld) outside [0,%lld)",
+            (long long)begin, (long long)end, (long long)X.n);
+  NFM_CHECK(batch >= 1, NFM_ERR_INVALID, "batch must be >= 1");
+  P.begin = begin; P.end = end; P.batch = batch; P.n_aug = n_aug;
+  P.first_singleton = first_singleton; P.has_perm = perm_host != nullptr;
+  // batch boundaries
+  P.bat_pos.clear();
+  P.bat_pos.push_back(0);
+  int64_t pos = 0;
+  if (first_singleton && ns > 0) { pos = 1; P.bat_pos.push_back(1); }
+  while (pos < ns) { pos = pos + batch < ns ? pos + batch : ns; P.bat_pos.push_back(pos); }
+  P.n_batches = (int64_t)P.bat_pos.size() - 1;
+  P.max_batch = 0;
+  for (int64_t b = 0; b < P.n_batches; ++b) P.max_batch = std::max(P.max_batch, P.bat_pos[b + 1] - P.bat_pos[b]);
+  P.bat_uoff.assign(P.n_batches + 1, 0);
+  if (ns == 0) return NFM_OK;
+  NFM_TRY(P.bat_pos_dev.alloc(sizeof(int64_t) * (P.n_batches + 1)));
+  NFM_HIP_CHECK(hipMemcpyAsync(P.bat_pos_dev.p, P.bat_pos.data(), sizeof(int64_t) * (P.n_batches + 1), hipMemcpyHostToDevice, st));
+  const int64_t* perm_dev = nullptr;
+  if (perm_host) {
+    NFM_TRY(P.perm.alloc(sizeof(int64_t) * ns));
+    NFM_HIP_CHECK(hipMemcpyAsync(P.perm.p, perm_host + begin, sizeof(int64_t) * ns, hipMemcpyHostToDevice, st));
+    perm_dev = P.perm.as<int64_t>();
+  }
+  // 1. row lengths -> touch offsets
+  DevBuf len, toff, tmp;
+  NFM_TRY(len.alloc(sizeof(int64_t) * (ns + 1)));
+  NFM_TRY(toff.alloc(sizeof(int64_t) * (ns + 1)));
+  hipLaunchKernelGGL(k_row_len, dim3(grid1d(ns + 1)), dim3(kBlock), 0, st, X, perm_dev, begin, ns, n_aug, len.as<int64_t>());
+  size_t tmp_bytes = 0;
+  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, len.as<int64_t>(), toff.as<int64_t>(), (int)(ns + 1), st));
+  NFM_TRY(tmp.alloc(tmp_bytes));
+  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, len.as<int64_t>(), toff.as<int64_t>(), (int)(ns + 1), st));
+  int64_t T = 0;
+  NFM_HIP_CHECK(hipMemcpyAsync(&T, toff.as<int64_t>() + ns, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  P.T = T;
+  NFM_CHECK(T < (int64_t)2147483647, NFM_ERR_UNSUPPORTED, "more than 2^31-1 nnz in one epoch range (%lld)", (long long)T);
+  len.release();
+  if (T == 0) { NFM_TRY(P.uptr.alloc(sizeof(int64_t))); NFM_HIP_CHECK(hipMemsetAsync(P.uptr.p, 0, sizeof(int64_t), st)); return NFM_OK; }
+  // 2. expand to (batch, feature) keys
+  int fbits = 1;
+  while (((int64_t)1 << fbits) < X.d + n_aug) ++fbits;
+  int bbits = 1;
+  while (((int64_t)1 << bbits) < P.n_batches) ++bbits;
+  NFM_CHECK(fbits + bbits <= 64, NFM_ERR_UNSUPPORTED, "key overflow");
+  DevBuf k0, k1, v0, v1, tpos_un, tx_un, tq_un;
+  NFM_TRY(k0.alloc(sizeof(uint64_t) * T)); NFM_TRY(k1.alloc(sizeof(uint64_t) * T));
+  NFM_TRY(v0.alloc(sizeof(uint32_t) * T)); NFM_TRY(v1.alloc(sizeof(uint32_t) * T));
+  NFM_TRY(tpos_un.alloc(sizeof(int32_t) * T)); NFM_TRY(tx_un.alloc(sizeof(double) * T));
+  if (want_tq) NFM_TRY(tq_un.alloc(sizeof(int64_t) * T));
+  {
+    int64_t blocks = (ns + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)blocks), dim3(kBlock), 0, st, X, perm_dev, begin, ns, n_aug, batch,
+                       first_singleton ? 1 : 0, fbits, toff.as<int64_t>(), k0.as<uint64_t>(), v0.as<uint32_t>(),
+                       tpos_un.as<int32_t>(), tx_un.as<double>(), want_tq ? tq_un.as<int64_t>() : nullptr);
+    NFM_HIP_CHECK(hipGetLastError());
+  }
+  // 3. stable sort by (batch, feature); ties keep sample order
+  hipcub::DoubleBuffer<uint64_t> dk(k0.as<uint64_t>(), k1.as<uint64_t>());
+  hipcub::DoubleBuffer<uint32_t> dv(v0.as<uint32_t>(), v1.as<uint32_t>());
+  tmp_bytes = 0;
+  NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, dk, dv, (int)T, 0, fbits + bbits, st));
+  NFM_TRY(tmp.alloc(tmp_bytes));
+  NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, dk, dv, (int)T, 0, fbits + bbits, st));
+  const uint64_t* keys = dk.Current();
+  const uint32_t* vals = dv.Current();
+  // 4. payload in sorted order + head flags -> unique index
+  DevBuf head, uidx;
+  NFM_TRY(P.tpos.alloc(sizeof(int32_t) * T)); NFM_TRY(P.tx.alloc(sizeof(double) * T));
+  if (want_tq) NFM_TRY(P.tq.alloc(sizeof(int64_t) * T));
+  NFM_TRY(head.alloc(sizeof(int64_t) * (T + 1))); NFM_TRY(uidx.alloc(sizeof(int64_t) * (T + 1)));
+  hipLaunchKernelGGL(k_gather_sorted, dim3(grid1d(T + 1)), dim3(kBlock), 0, st, T, keys, vals, tpos_un.as<int32_t>(),
+                     tx_un.as<double>(), want_tq ? tq_un.as<int64_t>() : nullptr, P.tpos.as<int32_t>(), P.tx.as<double>(),
+                     want_tq ? P.tq.as<int64_t>() : nullptr, head.as<int64_t>());
+  tmp_bytes = 0;
+  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, head.as<int64_t>(), uidx.as<int64_t>(), (int)(T + 1), st));
+  NFM_TRY(tmp.alloc(tmp_bytes));
+  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, head.as<int64_t>(), uidx.as<int64_t>(), (int)(T + 1), st));
+  int64_t U = 0;
+  NFM_HIP_CHECK(hipMemcpyAsync(&U, uidx.as<int64_t>() + T, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  P.U = U;
+  NFM_TRY(P.ucol.alloc(sizeof(int32_t) * U));
+  NFM_TRY(P.uptr.alloc(sizeof(int64_t) * (U + 1)));
+  DevBuf bfu;
+  NFM_TRY(bfu.alloc(sizeof(int64_t) * P.n_batches));
+  hipLaunchKernelGGL(k_set_i64, dim3(grid1d(P.n_batches)), dim3(kBlock), 0, st, bfu.as<int64_t>(), P.n_batches, (int64_t)-1);
+  hipLaunchKernelGGL(k_heads, dim3(grid1d(T)), dim3(kBlock), 0, st, T, keys, uidx.as<int64_t>(), fbits, P.ucol.as<int32_t>(),
+                     P.uptr.as<int64_t>(), bfu.as<int64_t>());
+  NFM_HIP_CHECK(hipGetLastError());
+  NFM_HIP_CHECK(hipMemcpyAsync(P.uptr.as<int64_t>() + U, &T, sizeof(int64_t), hipMemcpyHostToDevice, st));
+  std::vector<int64_t> first(P.n_batches);
+  NFM_HIP_CHECK(hipMemcpyAsync(first.data(), bfu.p, sizeof(int64_t) * P.n_batches, hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  P.bat_uoff[P.n_batches] = U;
+  for (int64_t b = P.n_batches - 1; b >= 0; --b) P.bat_uoff[b] = first[b] >= 0 ? first[b] : P.bat_uoff[b + 1];
+  P.max_unique = 0;
+  for (int64_t b = 0; b < P.n_batches; ++b) P.max_unique = std::max(P.max_unique, P.bat_uoff[b + 1] - P.bat_uoff[b]);
+  // temporaries are released by their destructors' explicit calls
+  k0.release(); k1.release(); v0.release(); v1.release(); tpos_un.release(); tx_un.release(); tq_un.release();
+  head.release(); uidx.release(); bfu.release(); tmp.release(); toff.release();
+  return NFM_OK;
+}
+
+}  // namespace nfm

@@ -1,0 +1,139 @@
+// nimfm_amd/csrc/predict.hip -- decisionFunction on the GPU.
+//
+// Replaces model/factorization_machine.nim:100-122 (-> kernels.nim:14-19 `linear`, :46-64
+// `anova`) and model/field_aware_factorization_machine.nim:52-76.  The reference makes nOrders*k
+// full passes over the CSR matrix, one per latent factor, gathering P[s][j] from k separate heap
+// rows; here one wavefront owns one sample, reads each parameter row once (coalesced, 16 B per
+// lane) from the [j][s] layout and finishes the per-factor sums with shuffles.
+// Bound: HBM/L2 gather of P rows; algorithmic bytes per sample 12m + 8 + O*8*m*k + 8m + 8
+// (SURVEY.md 8d).
+#include "fm_device.h"
+
+namespace nfm {
+
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_fm_predict(CsrView X, ModelView M, double* __restrict__ out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const double sw = M.sc[SC_SCALE_W], b = M.sc[SC_INTERCEPT];
+  const dev::PlainParams ps{M.P, M.sc[SC_SCALE_P]};
+  const int l = lane % L;
+  const double lam0 = M.lams[2 * l], lam1 = M.lams[2 * l + 1];
+  for (int64_t i = wave0; i < X.n; i += nwaves) {
+    const int64_t q0 = X.indptr[i];
+    const int m = (int)(X.indptr[i + 1] - q0);
+    const int m_tot = m + M.n_aug;
+    // linear term, one nnz per lane (kernels.nim:14-19; dummies excluded)
+    double lin = 0.0;
+    for (int c = 0; c * kWave < m; ++c) {
+      const int q = c * kWave + lane;
+      if (q < m) lin += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
+    }
+    lin = dev::wave_sum(lin);
+    double acc = 0.0;
+    for (int o = 0; o < M.nb; ++o) {
+      const size_t blk = (size_t)o * M.da * M.Kp;
+      const int deg = M.degree - o;
+      double2 ker;
+      switch (deg) {
+        case 2: {
+          double2 A1, A2;
+          dev::anova_fwd_deg2<L>(ps, X, q0, m, m_tot, blk, M.Kp, lane, A1, A2);
+          ker.x = (A1.x * A1.x - A2.x) / 2.0;
+          ker.y = (A1.y * A1.y - A2.y) / 2.0;
+          break;
+        }
+#define NFM_DEG_CASE(DG)                                                   \
+  case DG: {                                                               \
+    double2 E[DG + 1];                                                     \
+    dev::anova_fwd_degn<L, DG>(ps, X, q0, m, m_tot, blk, M.Kp, lane, E);   \
+    ker = E[DG];                                                           \
+    break;                                                                 \
+  }
+          NFM_DEG_CASE(3)
+          NFM_DEG_CASE(4)
+          NFM_DEG_CASE(5)
+          NFM_DEG_CASE(6)
+#undef NFM_DEG_CASE
+        default:
+          ker = {0.0, 0.0};
+      }
+      ker.x *= lam0;
+      ker.y *= lam1;
+      acc += dev::sum_factors<L>(ker);
+    }
+    if (lane == 0) out[i] = b + lin + acc;
+  }
+}
+
+// FFM: yhat = b + sum w x + sum_{j1<j2} x1 x2 <P[f2][j1], P[f1][j2]>
+// (model/field_aware_factorization_machine.nim:66-76).  The m*m ordered pairs of the row are
+// dealt to the R = 64/L row slots; a slot's L lanes form the dot product over the factors.
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_ffm_predict(CsrView X, ModelView M, double* __restrict__ out) {
+  constexpr int R = kWave / L;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int g = lane / L, l = lane % L;
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  const double sw = M.sc[SC_SCALE_W], b = M.sc[SC_INTERCEPT];
+  const dev::PlainParams ps{M.P, M.sc[SC_SCALE_P]};
+  for (int64_t i = wave0; i < X.n; i += nwaves) {
+    const int64_t q0 = X.indptr[i];
+    const int m = (int)(X.indptr[i + 1] - q0);
+    double lin = 0.0;
+    for (int c = 0; c * kWave < m; ++c) {
+      const int q = c * kWave + lane;
+      if (q < m) lin += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
+    }
+    double acc = 0.0;
+    const int64_t npairs = (int64_t)m * m;
+    for (int64_t pb = 0; pb < npairs; pb += R) {
+      const int64_t pr = pb + g;
+      if (pr < npairs) {
+        const int a = (int)(pr / m), c2 = (int)(pr % m);
+        const int j1 = X.indices[q0 + a], j2 = X.indices[q0 + c2];
+        if (j1 < j2) {
+          const int f1 = X.fields[q0 + a], f2 = X.fields[q0 + c2];
+          const double2 u = ps.load(((size_t)f2 * M.da + j1) * M.Kp + 2 * l);
+          const double2 v = ps.load(((size_t)f1 * M.da + j2) * M.Kp + 2 * l);
+          acc += (X.data[q0 + a] * X.data[q0 + c2]) * (u.x * v.x + u.y * v.y);
+        }
+      }
+    }
+    const double tot = dev::wave_sum(lin + acc);
+    if (lane == 0) out[i] = b + tot;
+  }
+}
+
+template <int L>
+static int launch_predict_L(nfm_ctx* ctx, const CsrView& X, const ModelView& M, double* out) {
+  if (X.n == 0) return NFM_OK;
+  int64_t blocks = (X.n + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t cap = (int64_t)ctx->n_cu * 8 * 4;  // grid-stride beyond ~32 waves per CU x 4
+  if (blocks > cap) blocks = cap;
+  TimedLaunch tl(ctx, "predict");
+  if (M.kind == NFM_KIND_FFM)
+    hipLaunchKernelGGL(k_ffm_predict<L>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, X, M, out);
+  else
+    hipLaunchKernelGGL(k_fm_predict<L>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, X, M, out);
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+
+int launch_predict(nfm_ctx* ctx, const CsrView& X, const ModelView& M, double* out) {
+  NFM_CHECK(M.Kp == 2 * M.L, NFM_ERR_UNSUPPORTED, "n_components > 128 is not supported by the wave-per-sample kernels");
+  switch (M.L) {
+    case 1: return launch_predict_L<1>(ctx, X, M, out);
+    case 2: return launch_predict_L<2>(ctx, X, M, out);
+    case 4: return launch_predict_L<4>(ctx, X, M, out);
+    case 8: return launch_predict_L<8>(ctx, X, M, out);
+    case 16: return launch_predict_L<16>(ctx, X, M, out);
+    case 32: return launch_predict_L<32>(ctx, X, M, out);
+    case 64: return launch_predict_L<64>(ctx, X, M, out);
+  }
+  return set_error(NFM_ERR_UNSUPPORTED, "n_components > 128 is not supported by the wave-per-sample kernels");
+}
+
+}  // namespace nfm

@@ -1,0 +1,267 @@
+// nimfm_amd/csrc/util.hip -- error/timing plumbing and the small streaming kernels around the hot
+// path: layout conversion between the reference's parameter layouts and the device layout,
+// the dense "finalize" rescale (optimizer/sgd.nim:99-113), squared norms for the verbose
+// `regularization` line (optimizer/utils.nim:56-59).  All are plain HBM-bound grid-stride
+// kernels, 16 B per lane where the layout allows.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace nfm {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+const char* last_error() { return g_err; }
+
+int DevBuf::alloc(size_t nbytes) {
+  release();
+  if (nbytes == 0) nbytes = 16;
+  hipError_t e = hipMalloc(&p, nbytes);
+  if (e != hipSuccess) {
+    p = nullptr;
+    return set_error(NFM_ERR_NOMEM, "hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e));
+  }
+  bytes = nbytes;
+  return NFM_OK;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  bytes = 0;
+}
+
+// ---- timing ----
+TimedLaunch::TimedLaunch(nfm_ctx* c, const char* f) : ctx(c), family(f) {
+  if (!ctx->timing.enabled) return;
+  auto get = [&]() {
+    hipEvent_t e = nullptr;
+    if (!ctx->timing.pool.empty()) {
+      e = ctx->timing.pool.back();
+      ctx->timing.pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+      e = nullptr;
+    }
+    return e;
+  };
+  start = get();
+  stop = get();
+  if (start) (void)hipEventRecord(start, ctx->stream);
+}
+TimedLaunch::~TimedLaunch() {
+  if (!start || !stop) return;
+  (void)hipEventRecord(stop, ctx->stream);
+  ctx->timing.pending.push_back({family, start, stop});
+}
+int timing_flush(nfm_ctx* ctx) {
+  for (auto& p : ctx->timing.pending) {
+    float ms = 0.f;
+    NFM_HIP_CHECK(hipEventSynchronize(p.stop));
+    NFM_HIP_CHECK(hipEventElapsedTime(&ms, p.start, p.stop));
+    auto& a = ctx->timing.acc[p.family];
+    a.launches += 1;
+    a.ms += ms;
+    ctx->timing.pool.push_back(p.start);
+    ctx->timing.pool.push_back(p.stop);
+  }
+  ctx->timing.pending.clear();
+  return NFM_OK;
+}
+
+static inline unsigned grid_for(int64_t n, int per_thread = 1) {
+  int64_t b = (n + (int64_t)kBlock * per_thread - 1) / ((int64_t)kBlock * per_thread);
+  if (b < 1) b = 1;
+  if (b > 256 * 16) b = 256 * 16;
+  return (unsigned)b;
+}
+
+__global__ void k_fill(double* __restrict__ p, int64_t n, double v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+int launch_fill(nfm_ctx* ctx, double* p, int64_t n, double v) {
+  if (n <= 0) return NFM_OK;
+  hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, p, n, v);
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+
+// reference FM model layout [nb][k][da]  ->  device [nb][da][Kp] (zero padded).
+// Tiled through LDS so that both the read (along j) and the write (along s) are coalesced.
+__global__ void k_fm_to_device(const double* __restrict__ src, double* __restrict__ dst, int k, int Kp, int64_t da) {
+  __shared__ double tile[32][33];
+  const int o = blockIdx.z;
+  const int64_t j0 = (int64_t)blockIdx.x * 32;
+  const int s0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int s = s0 + r;
+    const int64_t j = j0 + tx;
+    tile[r][tx] = (s < k && j < da) ? src[((size_t)o * k + s) * da + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t j = j0 + r;
+    const int s = s0 + tx;
+    if (j < da && s < Kp) dst[((size_t)o * da + j) * Kp + s] = tile[tx][r];
+  }
+}
+int launch_fm_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int nb, int k, int Kp, int64_t da) {
+  if (nb == 0 || da == 0) return NFM_OK;
+  dim3 grid((unsigned)((da + 31) / 32), (unsigned)((Kp + 31) / 32), (unsigned)nb);
+  hipLaunchKernelGGL(k_fm_to_device, grid, dim3(kBlock), 0, ctx->stream, src_ref, dst_dev, k, Kp, da);
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+
+__global__ void k_fm_from_device(const double* __restrict__ src, double* __restrict__ dst, int k, int Kp, int64_t da,
+                                 const double* __restrict__ scale) {
+  __shared__ double tile[32][33];
+  const double sc = scale ? *scale : 1.0;
+  const int o = blockIdx.z;
+  const int64_t j0 = (int64_t)blockIdx.x * 32;
+  const int s0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t j = j0 + r;
+    const int s = s0 + tx;
+    tile[r][tx] = (j < da && s < Kp) ? src[((size_t)o * da + j) * Kp + s] * sc : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int s = s0 + r;
+    const int64_t j = j0 + tx;
+    if (s < k && j < da) dst[((size_t)o * k + s) * da + j] = tile[tx][r];
+  }
+}
+int launch_fm_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int nb, int k, int Kp, int64_t da,
+                          const double* scale_dev) {
+  if (nb == 0 || da == 0) return NFM_OK;
+  dim3 grid((unsigned)((da + 31) / 32), (unsigned)((Kp + 31) / 32), (unsigned)nb);
+  hipLaunchKernelGGL(k_fm_from_device, grid, dim3(kBlock), 0, ctx->stream, src_dev, dst_ref, k, Kp, da, scale_dev);
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+
+// [rows][k] <-> [rows][Kp] (FFM parameters and every AdaGrad state tensor)
+__global__ void k_rows_to_device(const double* __restrict__ src, double* __restrict__ dst, int64_t rows, int k, int Kp,
+                                 double pad) {
+  const int64_t total = rows * Kp;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / Kp;
+    const int s = (int)(e % Kp);
+    dst[e] = s < k ? src[r * k + s] : pad;
+  }
+}
+int launch_rows_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int64_t rows, int k, int Kp, double pad) {
+  if (rows == 0) return NFM_OK;
+  hipLaunchKernelGGL(k_rows_to_device, dim3(grid_for(rows * Kp)), dim3(kBlock), 0, ctx->stream, src_ref, dst_dev, rows, k, Kp, pad);
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+__global__ void k_rows_from_device(const double* __restrict__ src, double* __restrict__ dst, int64_t rows, int k, int Kp,
+                                   const double* __restrict__ scale) {
+  const double sc = scale ? *scale : 1.0;
+  const int64_t total = rows * k;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / k;
+    const int s = (int)(e % k);
+    dst[e] = src[r * Kp + s] * sc;
+  }
+}
+int launch_rows_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int64_t rows, int k, int Kp,
+                            const double* scale_dev) {
+  if (rows == 0) return NFM_OK;
+  hipLaunchKernelGGL(k_rows_from_device, dim3(grid_for(rows * k)), dim3(kBlock), 0, ctx->stream, src_dev, dst_ref, rows, k, Kp, scale_dev);
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+
+// finalize (optimizer/sgd.nim:99-113): with one global scale per tensor it is a dense multiply.
+__global__ void k_rescale(double* __restrict__ p, int64_t n2 /*double2 count*/, const double* __restrict__ scale) {
+  const double sc = *scale;
+  double2* p2 = reinterpret_cast<double2*>(p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    double2 v = p2[i];
+    v.x *= sc;
+    v.y *= sc;
+    p2[i] = v;
+  }
+}
+__global__ void k_rescale_scalar(double* __restrict__ p, int64_t n, const double* __restrict__ scale) {
+  const double sc = *scale;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] *= sc;
+}
+__global__ void k_reset_scales(double* sc, int reset_w) {
+  sc[SC_SCALE_P] = 1.0;
+  if (reset_w) sc[SC_SCALE_W] = 1.0;
+}
+int launch_rescale(nfm_ctx* ctx, const ModelView& M) {
+  TimedLaunch tl(ctx, "rescale");
+  const int64_t nP = (int64_t)M.nb * M.da * M.Kp;
+  if (nP > 0)
+    hipLaunchKernelGGL(k_rescale, dim3(grid_for(nP / 2)), dim3(kBlock), 0, ctx->stream, M.P, nP / 2, M.sc + SC_SCALE_P);
+  if (M.fit_linear && M.d > 0)
+    hipLaunchKernelGGL(k_rescale_scalar, dim3(grid_for(M.d)), dim3(kBlock), 0, ctx->stream, M.w, M.d, M.sc + SC_SCALE_W);
+  hipLaunchKernelGGL(k_reset_scales, dim3(1), dim3(1), 0, ctx->stream, M.sc, M.fit_linear);
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+
+// sum of squares, deterministic: fixed grid, per-block tree in LDS, fixed-order final pass.
+__global__ void k_sqnorm_partial(const double* __restrict__ p, int64_t n, double scale_idx_unused, double* __restrict__ part) {
+  __shared__ double red[kBlock];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += p[i] * p[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void k_sqnorm_final(const double* __restrict__ part, int nparts, const double* __restrict__ scale, double* __restrict__ out) {
+  __shared__ double red[kBlock];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) acc += part[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0] * (*scale) * (*scale);
+}
+int launch_sqnorms(nfm_ctx* ctx, const ModelView& M, double* out2_dev) {
+  const int nparts = 1024;
+  DevBuf part;
+  NFM_TRY(part.alloc(sizeof(double) * nparts));
+  const int64_t nP = (int64_t)M.nb * M.da * M.Kp;
+  hipLaunchKernelGGL(k_sqnorm_partial, dim3(nparts), dim3(kBlock), 0, ctx->stream, M.P, nP, 0.0, part.as<double>());
+  hipLaunchKernelGGL(k_sqnorm_final, dim3(1), dim3(kBlock), 0, ctx->stream, part.as<double>(), nparts, M.sc + SC_SCALE_P, out2_dev);
+  hipLaunchKernelGGL(k_sqnorm_partial, dim3(nparts), dim3(kBlock), 0, ctx->stream, M.w, M.d, 0.0, part.as<double>());
+  hipLaunchKernelGGL(k_sqnorm_final, dim3(1), dim3(kBlock), 0, ctx->stream, part.as<double>(), nparts, M.sc + SC_SCALE_W, out2_dev + 1);
+  NFM_HIP_CHECK(hipGetLastError());
+  NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  part.release();
+  return NFM_OK;
+}
+
+__global__ void k_narrow(const int64_t* __restrict__ src, int32_t* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (int32_t)src[i];
+}
+int launch_narrow_i64_i32(nfm_ctx* ctx, const int64_t* src, int32_t* dst, int64_t n) {
+  if (n <= 0) return NFM_OK;
+  hipLaunchKernelGGL(k_narrow, dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream, src, dst, n);
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+
+}  // namespace nfm

@@ -1,0 +1,620 @@
+"""Host-side mirror of nimfm's FM surface over the C ABI (include/nimfm_hip.h).
+
+Same names, argument meaning, defaults and error behaviour as the reference procs it stands in
+for (citations relative to /root/reference/src/nimfm/), so that parity tests read like the
+reference's own tests:
+
+    newCSRDataset / newCSRFieldDataset       dataset.nim:116-123, tensor/sparse.nim:9-24
+    newFactorizationMachine, init, decisionFunction, predict, predictProba, score
+                                             model/factorization_machine.nim:43-139, model/fm_base.nim:13-48
+    newFieldAwareFactorizationMachine        model/field_aware_factorization_machine.nim:24-92
+    newSGD(...).fit(X, y, fm, callback)      optimizer/sgd.nim:23-52,261-328 (FFM: sgd_ffm.nim:49-106)
+    newAdaGrad(...).fit(X, y, fm, callback)  optimizer/adagrad.nim:20-44,137-203 (FFM: adagrad_ffm.nim:11-66)
+    fit(..., maxThreads=...)                 optimizer/sgd_multi.nim:40-42, adagrad_multi.nim:39-41
+
+The epoch loop, shuffle, stopping criterion, verbose lines and callbacks run here exactly where
+the Nim shim (nim/nimfm_hip.nim) runs them; everything per-sample runs in libnimfm_hip.so.
+The reference is Nim and no Nim toolchain exists in the build image, so this Python module is the
+executable stand-in for that shim (and what bench.py / torch.distributed drive).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi as capi
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+class Context:
+    """One GPU + one HIP stream (one process per GPU)."""
+
+    def __init__(self, device_id=0, stream=None):
+        self.h = C.c_void_p()
+        capi.check(capi.lib().nfm_ctx_create(device_id, stream, C.byref(self.h)))
+        self.device_id = device_id
+
+    def synchronize(self):
+        capi.check(capi.lib().nfm_ctx_synchronize(self.h))
+
+    def timing_enable(self, on=True):
+        capi.check(capi.lib().nfm_ctx_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        capi.check(capi.lib().nfm_ctx_timing_reset(self.h))
+
+    def timing_get(self, family):
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        capi.check(capi.lib().nfm_ctx_timing_get(self.h, family.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def close(self):
+        if self.h:
+            capi.lib().nfm_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def set_default_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+class CSRDataset:
+    """dataset.nim:10-16 BaseDataset[CSRMatrix]; rows resident in HBM."""
+
+    def __init__(self, data=None, indices=None, indptr=None, nSamples=0, nFeatures=0, fields=None, nFields=0,
+                 ctx=None, _handle=None, _keep=None):
+        self.ctx = ctx or default_context()
+        self.nSamples, self._nFeatures, self.nFields = int(nSamples), int(nFeatures), int(nFields)
+        self._keep = _keep
+        if _handle is not None:
+            self.h = _handle
+            return
+        data, indices, indptr = _f64(data), _i64(indices), _i64(indptr)
+        if len(indptr) != self.nSamples + 1:
+            raise ValueError("len(indptr) != nSamples + 1")
+        if len(indices) != len(data) or (len(indptr) and indptr[-1] != len(data)):
+            raise ValueError("indices/data/indptr sizes are inconsistent")
+        fl = None if fields is None else _i64(fields)
+        self.nnz = len(data)
+        self.h = C.c_void_p()
+        capi.check(capi.lib().nfm_dataset_create_csr(self.ctx.h, self.nSamples, self._nFeatures, _vp(indptr),
+                                                     _vp(indices), _vp(data), _vp(fl), self.nFields, None,
+                                                     C.byref(self.h)))
+
+    @classmethod
+    def from_device(cls, ctx, n, d, nnz, indptr_ptr, indices_ptr, data_ptr, y_ptr=None, fields_ptr=None, nFields=0,
+                    keep=None):
+        """Adopt device-resident arrays (raw device pointers, e.g. torch tensors' data_ptr())."""
+        h = C.c_void_p()
+        capi.check(capi.lib().nfm_dataset_create_csr_device(ctx.h, n, d, nnz, indptr_ptr, indices_ptr, data_ptr,
+                                                            fields_ptr, nFields, y_ptr, C.byref(h)))
+        ds = cls(nSamples=n, nFeatures=d, nFields=nFields, ctx=ctx, _handle=h, _keep=keep)
+        ds.nnz = nnz
+        return ds
+
+    @property
+    def nFeatures(self):
+        return self._nFeatures
+
+    @property
+    def shape(self):
+        return [self.nSamples, self._nFeatures]
+
+    def set_targets(self, y):
+        y = _f64(y)
+        if len(y) != self.nSamples:
+            raise ValueError("len(y) != nSamples")
+        capi.check(capi.lib().nfm_dataset_set_targets(self.h, _vp(y)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                capi.lib().nfm_dataset_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def newCSRDataset(data, indices, indptr, nSamples, nFeatures, ctx=None):
+    return CSRDataset(data, indices, indptr, nSamples, nFeatures, ctx=ctx)
+
+
+def newCSRFieldDataset(data, indices, indptr, fields, nSamples, nFeatures, nFields, ctx=None):
+    return CSRDataset(data, indices, indptr, nSamples, nFeatures, fields=fields, nFields=nFields, ctx=ctx)
+
+
+def expit(x):
+    """utils.nim:33"""
+    x = np.asarray(x, dtype=np.float64)
+    return np.exp(np.minimum(0.0, x)) / (1.0 + np.exp(-np.abs(x)))
+
+
+def rmse(yTrue, yScore):
+    """metrics.nim:5-13"""
+    yTrue, yScore = _f64(yTrue), _f64(yScore)
+    if len(yTrue) != len(yScore):
+        raise ValueError("len(yScore)=%d, but len(yTrue)=%d" % (len(yScore), len(yTrue)))
+    return math.sqrt(float(np.sum((yScore - yTrue) ** 2)) / len(yTrue))
+
+
+def accuracy(yTrue, yPred):
+    """metrics.nim:39-47"""
+    yTrue, yPred = np.asarray(yTrue), np.asarray(yPred)
+    if len(yTrue) != len(yPred):
+        raise ValueError("len(yPred)=%d, but len(yTrue)=%d" % (len(yPred), len(yTrue)))
+    return float(np.mean(yTrue == yPred))
+
+
+class _ModelBase:
+    """Fields/procs shared by FM and FFM (model/fm_base.nim)."""
+
+    def __init__(self):
+        self._h = None
+        self._ctx = None
+        self._dirty = True
+        self._P = None
+        self._w = None
+        self._intercept = 0.0
+        self.isInitialized = False
+
+    # host copies are the public truth (fm.P / fm.w / fm.intercept); assigning marks the device copy stale
+    @property
+    def P(self):
+        return self._P
+
+    @P.setter
+    def P(self, v):
+        self._P = _f64(v)
+        self._dirty = True
+
+    @property
+    def w(self):
+        return self._w
+
+    @w.setter
+    def w(self, v):
+        self._w = _f64(v)
+        self._dirty = True
+
+    @property
+    def intercept(self):
+        return self._intercept
+
+    @intercept.setter
+    def intercept(self, v):
+        self._intercept = float(v)
+        self._dirty = True
+
+    def checkInitialized(self):
+        if not self.isInitialized:
+            raise capi.NotFittedError(capi.ERR_NOT_FITTED, "Factorization machines is not fitted.")
+
+    def _handle(self, ctx):
+        if self._h is None or self._ctx is not ctx:
+            self._release()
+            cfg = self._cfg()
+            self._h = C.c_void_p()
+            capi.check(capi.lib().nfm_model_create(ctx.h, C.byref(cfg), C.byref(self._h)))
+            self._ctx = ctx
+            self._dirty = True
+        return self._h
+
+    def _push(self, ctx):
+        h = self._handle(ctx)
+        if self._dirty:
+            lams = getattr(self, "lams", None)
+            capi.check(capi.lib().nfm_model_set_params(h, _vp(self._P), _vp(self._w), self._intercept,
+                                                       None if lams is None else _vp(_f64(lams))))
+            self._dirty = False
+        return h
+
+    def _pull(self):
+        b = C.c_double(0.0)
+        capi.check(capi.lib().nfm_model_get_params(self._h, _vp(self._P), _vp(self._w), C.byref(b)))
+        self._intercept = b.value
+        self._dirty = False
+
+    def _release(self):
+        if self._h is not None:
+            capi.lib().nfm_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def decisionFunction(self, X):
+        """model/factorization_machine.nim:100-122 / field_aware_factorization_machine.nim:52-76"""
+        self.checkInitialized()
+        self._check_shapes(X)
+        h = self._push(X.ctx)
+        out = np.empty(X.nSamples, dtype=np.float64)
+        capi.check(capi.lib().nfm_decision_function(h, X.h, _vp(out)))
+        return out
+
+    def predict(self, X):
+        """model/fm_base.nim:18-20"""
+        return np.sign(self.decisionFunction(X)).astype(np.int64)
+
+    def predictProba(self, X):
+        """model/fm_base.nim:23-26"""
+        return expit(self.decisionFunction(X))
+
+    def checkTarget(self, y):
+        """model/fm_base.nim:29-36"""
+        y = _f64(y)
+        return np.sign(y) if self.task == "classification" else y
+
+    def score(self, X, y):
+        """model/fm_base.nim:39-48"""
+        yPred = self.decisionFunction(X)
+        if self.task == "regression":
+            return rmse(y, yPred)
+        return accuracy(np.sign(_f64(y)).astype(np.int64), np.sign(yPred).astype(np.int64))
+
+
+def _task_name(task):
+    t = {"r": "regression", "c": "classification"}.get(task, task)
+    if t not in ("regression", "classification"):
+        raise ValueError("unknown task %r" % (task,))
+    return t
+
+
+class FactorizationMachine(_ModelBase):
+    def __init__(self, task, degree=2, nComponents=30, fitLower="explicit", fitIntercept=True, fitLinear=True,
+                 warmStart=False, randomState=1, scale=0.01):
+        super().__init__()
+        self.task = _task_name(task)
+        if degree < 1:
+            raise ValueError("degree < 1.")
+        if nComponents < 1:
+            raise ValueError("nComponents < 1.")
+        if fitLower not in capi.LOWER:
+            raise ValueError("unknown fitLower %r" % (fitLower,))
+        self.degree, self.nComponents, self.fitLower = int(degree), int(nComponents), fitLower
+        self.fitIntercept, self.fitLinear, self.warmStart = bool(fitIntercept), bool(fitLinear), bool(warmStart)
+        self.randomState, self.scale = int(randomState), float(scale)
+        self.lams = np.ones(self.nComponents)
+        self._d = None
+
+    @property
+    def nAugments(self):
+        """model/factorization_machine.nim:81-86"""
+        if self.fitLower == "augment":
+            return self.degree - 2 if self.fitLinear else self.degree - 1
+        return 0
+
+    @property
+    def nOrders(self):
+        """model/factorization_machine.nim:89-97"""
+        if self.degree == 1:
+            return 0
+        return self.degree - 1 if self.fitLower == "explicit" else 1
+
+    def _cfg(self):
+        return capi.ModelCfg(capi.KIND_FM, capi.TASK[self.task], self.degree, self.nComponents,
+                             capi.LOWER[self.fitLower], int(self.fitIntercept), int(self.fitLinear), 0,
+                             int(self._d), 0)
+
+    def _check_shapes(self, X):
+        if X.nFeatures + self.nAugments != self._P.shape[2]:
+            raise ValueError("Invalid nFeatures.")
+
+    def init(self, X, force=False):
+        """model/factorization_machine.nim:125-139.  The reference draws P with Nim's stdlib RNG
+        (Box-Muller over xoroshiro128+), which is not part of the reference tree; numpy's generator
+        seeded with randomState is used instead (RNG parity is unpinned)."""
+        if force or not (self.warmStart and self.isInitialized):
+            d = X.nFeatures
+            rng = np.random.default_rng(self.randomState)
+            self._rng = rng
+            if self._d != d:
+                self._release()
+            self._d = d
+            self.w = np.zeros(d)
+            self.P = rng.standard_normal((self.nOrders, self.nComponents, d + self.nAugments)) * self.scale
+            self.intercept = 0.0
+        self.isInitialized = True
+
+    def set_params(self, P, w, intercept):
+        """Inject parameters (the reference's warm-start path: init is skipped when
+        warmStart and isInitialized, factorization_machine.nim:129)."""
+        P = _f64(P)
+        if P.ndim != 3 or P.shape[0] != self.nOrders or P.shape[1] != self.nComponents:
+            raise ValueError("P must have shape [nOrders, nComponents, nFeatures+nAugments]")
+        d = P.shape[2] - self.nAugments
+        if self._d != d:
+            self._release()
+        self._d = d
+        self.P, self.w, self.intercept = P.copy(), _f64(w).copy(), intercept
+        if len(self._w) != d:
+            raise ValueError("len(w) != nFeatures")
+        self.isInitialized = True
+
+
+class FieldAwareFactorizationMachine(_ModelBase):
+    def __init__(self, task, nComponents=10, fitIntercept=True, fitLinear=True, warmStart=False, randomState=1,
+                 scale=0.01):
+        super().__init__()
+        self.task = _task_name(task)
+        if nComponents < 1:
+            raise ValueError("nComponents < 1.")
+        self.nComponents = int(nComponents)
+        self.fitIntercept, self.fitLinear, self.warmStart = bool(fitIntercept), bool(fitLinear), bool(warmStart)
+        self.randomState, self.scale = int(randomState), float(scale)
+        self._d = None
+        self._F = None
+
+    nAugments = 0  # model/field_aware_factorization_machine.nim:49
+
+    def _cfg(self):
+        return capi.ModelCfg(capi.KIND_FFM, capi.TASK[self.task], 2, self.nComponents, 0, int(self.fitIntercept),
+                             int(self.fitLinear), 0, int(self._d), int(self._F))
+
+    def _check_shapes(self, X):
+        if X.nFeatures != self._P.shape[1]:
+            raise ValueError("Invalid nFeatures.")
+        if X.nFields != self._P.shape[0]:
+            raise ValueError("Invalid nFields.")
+
+    def init(self, X, force=False):
+        """model/field_aware_factorization_machine.nim:79-92"""
+        if force or not (self.warmStart and self.isInitialized):
+            d, F = X.nFeatures, X.nFields
+            rng = np.random.default_rng(self.randomState)
+            self._rng = rng
+            if (self._d, self._F) != (d, F):
+                self._release()
+            self._d, self._F = d, F
+            self.w = np.zeros(d)
+            self.P = rng.standard_normal((F, d, self.nComponents)) * self.scale
+            self.intercept = 0.0
+        self.isInitialized = True
+
+    def set_params(self, P, w, intercept):
+        P = _f64(P)
+        if P.ndim != 3 or P.shape[2] != self.nComponents:
+            raise ValueError("P must have shape [nFields, nFeatures, nComponents]")
+        if (self._d, self._F) != (P.shape[1], P.shape[0]):
+            self._release()
+        self._F, self._d = P.shape[0], P.shape[1]
+        self.P, self.w, self.intercept = P.copy(), _f64(w).copy(), intercept
+        self.isInitialized = True
+
+
+def newFactorizationMachine(task, degree=2, nComponents=30, fitLower="explicit", fitIntercept=True, fitLinear=True,
+                            warmStart=False, randomState=1, scale=0.01):
+    return FactorizationMachine(task, degree, nComponents, fitLower, fitIntercept, fitLinear, warmStart, randomState,
+                                scale)
+
+
+def newFieldAwareFactorizationMachine(task, nComponents=10, fitIntercept=True, fitLinear=True, warmStart=False,
+                                      randomState=1, scale=0.01):
+    return FieldAwareFactorizationMachine(task, nComponents, fitIntercept, fitLinear, warmStart, randomState, scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# optimizers
+# ------------------------------------------------------------------------------------------------
+def _echo_header(maxIter):
+    """optimizer/utils.nim:26-40"""
+    print("%s   %s   %s   Regularization" % ("Epoch".ljust(len(str(maxIter))), "Violation".ljust(10), "Loss".ljust(10)),
+          flush=True)
+
+
+def _echo_info(it, maxIter, viol, loss, regul):
+    """optimizer/utils.nim:43-53"""
+    print("%s   %-10.4e   %-10.4e   %-10.4e" % (str(it).ljust(max(5, len(str(maxIter)))), viol, loss, regul), flush=True)
+
+
+class _OptimizerBase:
+    """optimizer/optimizer_base.nim:2-8 + the fit driver shared by SGD and AdaGrad."""
+
+    def __init__(self, maxIter, alpha0, alpha, beta, loss, verbose, tol, shuffle, nCalls, mode, batch, lossParam):
+        if loss not in capi.LOSS:
+            raise ValueError("unknown loss %r" % (loss,))
+        if mode not in capi.MODE:
+            raise ValueError("unknown mode %r" % (mode,))
+        self.maxIter, self.alpha0, self.alpha, self.beta = int(maxIter), float(alpha0), float(alpha), float(beta)
+        self.loss, self.lossParam = loss, float(lossParam)
+        self.verbose, self.tol, self.shuffle, self.nCalls = int(verbose), float(tol), bool(shuffle), int(nCalls)
+        self.mode, self.batch = mode, int(batch)
+        self.it = 1
+        self._h = None
+        self._model = None
+        self._mode_built = None
+        self._mh = None
+        self.history = []  # (viol, mean loss) per epoch, what echoInfo prints
+
+    def _release(self):
+        if self._h is not None:
+            capi.lib().nfm_opt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _handle(self, fm, ctx, mode):
+        mh = fm._push(ctx)
+        if self._h is None or self._model is not fm or self._mode_built != (mode, self.batch) or self._mh != mh.value:
+            self._release()
+            self._h = C.c_void_p()
+            self._create(mh, mode)
+            self._model, self._mode_built, self._mh = fm, (mode, self.batch), mh.value
+        return self._h
+
+    def _epoch(self, X, perm, begin, end):
+        ls, vs = C.c_double(0.0), C.c_double(0.0)
+        capi.check(capi.lib().nfm_opt_epoch(self._h, X.h, _vp(perm), begin, end, C.byref(ls), C.byref(vs)))
+        return ls.value, vs.value
+
+    def _finalize_into(self, fm):
+        capi.check(capi.lib().nfm_opt_finalize(self._h))
+        fm._pull()
+
+    def _regularization(self, fm):
+        """optimizer/utils.nim:56-59"""
+        psq, wsq = C.c_double(0.0), C.c_double(0.0)
+        capi.check(capi.lib().nfm_model_sqnorms(fm._h, C.byref(psq), C.byref(wsq)))
+        b = C.c_double(0.0)
+        return 0.5 * self.alpha * wsq.value + 0.5 * self.beta * psq.value  # intercept term added by caller
+
+    def fit(self, X, y, fm, maxThreads=None, callback=None, perms=None):
+        """optimizer/sgd.nim:261-328, adagrad.nim:137-203 (and the FFM / *_multi overloads).
+        maxThreads (the reference's Hogwild overload) selects the data-parallel mini-batch mode.
+        perms ([maxIter][n], optional) replaces the internal shuffle with explicit permutations: the
+        reference shuffles with Nim's global RNG (sgd.nim:297), which a Nim host passes in here."""
+        fm.init(X)
+        y = _f64(y)
+        if len(y) != X.nSamples:
+            raise ValueError("len(y) != nSamples")
+        X.set_targets(y)  # checkTarget (fm_base.nim:29-36) is applied on the device from the model's task
+        mode = self.mode if maxThreads is None else "minibatch"
+        if not fm.warmStart:
+            self.it = 1  # sgd.nim:288-289, adagrad.nim:49-50
+        self._handle(fm, X.ctx, mode)
+        if fm._dirty:
+            fm._push(X.ctx)
+        capi.check(capi.lib().nfm_opt_set_it(self._h, self.it))
+        if self.verbose > 0:
+            _echo_header(self.maxIter)
+        n = X.nSamples
+        rng = getattr(fm, "_rng", None) or np.random.default_rng(getattr(fm, "randomState", 1))
+        indices = np.arange(n, dtype=np.int64)
+        isConverged = False
+        per_epoch_cb = self._per_epoch_callback(callback)
+        self.history = []
+        for epoch in range(self.maxIter):
+            viol = runningLoss = 0.0
+            perm = None
+            if perms is not None:
+                perm = _i64(perms[epoch])
+            elif self.shuffle:
+                rng.shuffle(indices)  # sgd.nim:297 (Nim's global RNG there)
+                perm = indices
+            if callback is not None and self.nCalls > 0 and mode == "sequential":
+                pos = 0
+                while pos < n:  # sgd.nim:303-308: callback whenever it mod nCalls == 0
+                    to_next = (self.nCalls - self.it % self.nCalls) % self.nCalls + 1
+                    end = min(n, pos + to_next)
+                    ls, vs = self._epoch(X, perm, pos, end)
+                    runningLoss += ls
+                    viol += vs
+                    self.it += end - pos
+                    pos = end
+                    if (self.it - 1) % self.nCalls == 0:
+                        self._finalize_into(fm)
+                        self.it -= 1  # the reference calls back before inc(self.it)
+                        callback(self, fm)
+                        self.it += 1
+            else:
+                runningLoss, viol = self._epoch(X, perm, 0, n)
+                self.it += n
+            runningLoss /= float(n)
+            if per_epoch_cb:
+                self._finalize_into(fm)
+                callback(self, fm)
+            self.history.append((viol, runningLoss))
+            # stoppingCriterion, sgd.nim:72-89
+            isContinue = True
+            if math.isnan(runningLoss):
+                print("Loss is NaN. Use smaller learning rate.")
+                isContinue = False
+            if self.verbose > 0:
+                b = C.c_double(0.0)
+                reg = self._regularization(fm)
+                capi.check(capi.lib().nfm_model_get_params(fm._h, None, None, C.byref(b)))
+                _echo_info(epoch + 1, self.maxIter, viol, runningLoss, reg + 0.5 * self.alpha0 * b.value ** 2)
+            if viol < self.tol:
+                if self.verbose > 0:
+                    print("Converged at epoch %d." % epoch)
+                isConverged = True
+                isContinue = False
+            if not isContinue:
+                break
+        if not isConverged and self.verbose > 0:
+            print("Objective did not converge. Increase maxIter.")
+        self._finalize_into(fm)
+        return self
+
+
+class SGD(_OptimizerBase):
+    def __init__(self, maxIter=100, eta0=0.01, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squared",
+                 scheduling="optimal", power=1.0, verbose=1, tol=1e-3, shuffle=True, nCalls=-1, mode="sequential",
+                 batch=8192, lossParam=1.0):
+        super().__init__(maxIter, alpha0, alpha, beta, loss, verbose, tol, shuffle, nCalls, mode, batch, lossParam)
+        if scheduling not in capi.SCHED:
+            raise ValueError("unknown scheduling %r" % (scheduling,))
+        self.eta0, self.scheduling, self.power = float(eta0), scheduling, float(power)
+
+    def _create(self, mh, mode):
+        cfg = capi.SGDCfg(self.eta0, self.alpha0, self.alpha, self.beta, self.power, self.lossParam,
+                          capi.LOSS[self.loss], capi.SCHED[self.scheduling], capi.MODE[mode], 0, self.batch)
+        capi.check(capi.lib().nfm_sgd_create(mh, C.byref(cfg), C.byref(self._h)))
+
+    def _per_epoch_callback(self, callback):
+        return callback is not None and (self.nCalls <= 0 or self.mode != "sequential")  # sgd.nim:312
+
+
+class AdaGrad(_OptimizerBase):
+    def __init__(self, maxIter=100, eta0=0.1, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squared", eps=1e-10,
+                 verbose=1, tol=1e-3, shuffle=True, nCalls=-1, mode="sequential", batch=8192, lossParam=1.0,
+                 trackViol=True):
+        super().__init__(maxIter, alpha0, alpha, beta, loss, verbose, tol, shuffle, nCalls, mode, batch, lossParam)
+        self.eta0, self.eps, self.trackViol = float(eta0), float(eps), bool(trackViol)
+
+    def _create(self, mh, mode):
+        cfg = capi.AdaGradCfg(self.eta0, self.alpha0, self.alpha, self.beta, self.eps, self.lossParam,
+                              capi.LOSS[self.loss], capi.MODE[mode], int(self.trackViol), 0, self.batch)
+        capi.check(capi.lib().nfm_adagrad_create(mh, C.byref(cfg), C.byref(self._h)))
+
+    def _per_epoch_callback(self, callback):
+        return callback is not None  # adagrad.nim:188-191
+
+    def get_state(self, fm):
+        """g_sum / g_norm (adagrad.nim:15-16) in the reference layout."""
+        nb, da, k = (fm._P.shape[0], fm._P.shape[2], fm._P.shape[1]) if isinstance(fm, FactorizationMachine) else (
+            fm._P.shape[0], fm._P.shape[1], fm._P.shape[2])
+        gs, gn = np.zeros((nb, da, k)), np.zeros((nb, da, k))
+        gsw, gnw = np.zeros(len(fm._w)), np.zeros(len(fm._w))
+        gsb, gnb = C.c_double(0.0), C.c_double(0.0)
+        capi.check(capi.lib().nfm_opt_get_state(self._h, _vp(gs), _vp(gn), _vp(gsw), _vp(gnw), C.byref(gsb),
+                                                C.byref(gnb)))
+        return gs, gn, gsw, gnw, gsb.value, gnb.value
+
+
+def newSGD(maxIter=100, eta0=0.01, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squared", scheduling="optimal",
+           power=1.0, verbose=1, tol=1e-3, shuffle=True, nCalls=-1, **gpu):
+    return SGD(maxIter, eta0, alpha0, alpha, beta, loss, scheduling, power, verbose, tol, shuffle, nCalls, **gpu)
+
+
+def newAdaGrad(maxIter=100, eta0=0.1, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squared", eps=1e-10, verbose=1,
+               tol=1e-3, shuffle=True, nCalls=-1, **gpu):
+    return AdaGrad(maxIter, eta0, alpha0, alpha, beta, loss, eps, verbose, tol, shuffle, nCalls, **gpu)

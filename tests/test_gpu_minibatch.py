@@ -1,0 +1,159 @@
+"""-m gpu: NFM_MODE_MINIBATCH (row phase / column phase kernels) vs the CPU restatement of the same
+rule (oracle/nimfm_mb.c), and vs the reference-faithful sequential oracle at batch == 1."""
+import itertools
+
+import numpy as np
+import pytest
+
+import nimfm_amd as nf
+import oracle as O
+from common import assert_close, init_fm, make_fm_dataset, make_perms, random_csr
+from gpu_common import gpu_fm, ragged_csr, to_gpu
+
+pytestmark = pytest.mark.gpu
+N, D, K = 80, 8, 4
+RTOL, ATOL = 1e-9, 1e-12
+
+
+def run_oracle_sgd_mb(Xo, y, degree, P0, w0, b0, cfg, batch, n_aug, perms, epochs):
+    P, w, b, it = P0.copy(), w0.copy(), b0, 1
+    hist = []
+    for e in range(epochs):
+        b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, degree, P, w, b, cfg, batch, n_aug,
+                                          perm=None if perms is None else perms[e], it=it)
+        hist.append((vs, ls / Xo.n))
+    return P, w, b, it, hist
+
+
+@pytest.mark.parametrize("degree,fit_lower,batch", itertools.product([2, 3, 4], ["explicit", "none", "augment"],
+                                                                     [1, 5, 16, 80, 1000]))
+def test_sgd_vs_mb_oracle(degree, fit_lower, batch):
+    Xo, Xd, y = make_fm_dataset(N, D, degree, K, 42, fit_lower, threshold=0.3)
+    P0, w0, b0, n_aug = init_fm(D, degree, K, fit_lower, True)
+    perms = make_perms(N, 3)
+    P, w, b, it, hist = run_oracle_sgd_mb(Xo, y, degree, P0, w0, b0, O.sgd_cfg(), batch, n_aug, perms, 3)
+    fm = gpu_fm("regression", degree, K, fit_lower, True, True, P0, w0, b0)
+    sgd = nf.newSGD(maxIter=3, verbose=0, tol=0, mode="minibatch", batch=batch)
+    sgd.fit(to_gpu(Xo), y, fm, perms=perms)
+    assert sgd.it == it
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
+    assert_close([h[1] for h in sgd.history], [h[1] for h in hist], 1e-10, 1e-13, "loss")
+    assert_close([h[0] for h in sgd.history], [h[0] for h in hist], 1e-9, 1e-12, "viol")
+    if batch == 1:  # the rule collapses to the reference's sequential step
+        Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, degree, P0, w0, b0, O.sgd_cfg(), 3, n_aug, perms=perms)
+        assert_close(fm.P, Pf, 1e-8, 1e-11, "P vs sequential")
+        assert_close(fm.w, wf, 1e-8, 1e-11, "w vs sequential")
+
+
+@pytest.mark.parametrize("fit_linear,fit_intercept,loss", itertools.product([False, True], [False, True],
+                                                                            ["squared", "logistic"]))
+def test_sgd_flags_and_losses(fit_linear, fit_intercept, loss):
+    Xo, Xd, y = make_fm_dataset(N, D, 2, K, 42, "explicit", fit_linear, fit_intercept, threshold=0.3)
+    task = "classification" if loss == "logistic" else "regression"
+    yo = np.sign(y) if task == "classification" else y
+    P0, w0, b0, n_aug = init_fm(D, 2, K, "explicit", fit_linear)
+    cfg = O.sgd_cfg(loss=loss, fit_linear=fit_linear, fit_intercept=fit_intercept, scheduling="invscaling", power=0.5)
+    P, w, b, it, hist = run_oracle_sgd_mb(Xo, yo, 2, P0, w0, b0, cfg, 16, n_aug, None, 3)
+    fm = gpu_fm(task, 2, K, "explicit", fit_linear, fit_intercept, P0, w0, b0)
+    sgd = nf.newSGD(maxIter=3, verbose=0, tol=0, shuffle=False, loss=loss, scheduling="invscaling", power=0.5,
+                    mode="minibatch", batch=16)
+    sgd.fit(to_gpu(Xo), y, fm)
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
+    if not fit_linear:
+        assert (fm.w == 0).all()
+    if not fit_intercept:
+        assert fm.intercept == 0.0
+
+
+@pytest.mark.parametrize("degree,fit_lower,batch,track", itertools.product([2, 3], ["explicit", "augment"],
+                                                                           [1, 7, 80], [True]))
+def test_adagrad_vs_mb_oracle(degree, fit_lower, batch, track):
+    Xo, Xd, y = make_fm_dataset(N, D, degree, K, 42, fit_lower, threshold=0.3)
+    P0, w0, b0, n_aug = init_fm(D, degree, K, fit_lower, True)
+    perms = make_perms(N, 3)
+    cfg = O.adagrad_cfg()
+    P, w, b, it = P0.copy(), w0.copy(), b0, 1
+    st = O.AdaState(P.shape[0], P.shape[2], K, D)
+    hist = []
+    for e in range(3):
+        b, it, ls, vs = O.fm_adagrad_epoch_mb(Xo, y, degree, P, w, b, cfg, batch, st, n_aug, perm=perms[e], it=it)
+        hist.append((vs, ls / N))
+    b = O.fm_adagrad_finalize(degree, P, w, b, cfg, it, st, n_aug)
+    fm = gpu_fm("regression", degree, K, fit_lower, True, True, P0, w0, b0)
+    ada = nf.newAdaGrad(maxIter=3, verbose=0, tol=0, mode="minibatch", batch=batch, trackViol=track)
+    ada.fit(to_gpu(Xo), y, fm, perms=perms)
+    assert ada.it == it
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
+    assert_close([h[1] for h in ada.history], [h[1] for h in hist], 1e-10, 1e-13, "loss")
+    assert_close([h[0] for h in ada.history], [h[0] for h in hist], 1e-9, 1e-12, "viol")
+    gs, gn, gsw, gnw, gsb, gnb = ada.get_state(fm)
+    assert_close(gs, st.gsum_P, RTOL, ATOL, "g_sum")
+    assert_close(gn, st.gnorm_P, RTOL, 1e-20, "g_norm")
+    if batch == 1:
+        Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, y, degree, P0, w0, b0, cfg, 3, n_aug, perms=perms)
+        assert_close(fm.P, Pf, 1e-8, 1e-11, "P vs sequential")
+
+
+@pytest.mark.parametrize("k", [1, 3, 8, 16, 30, 64, 128])
+def test_component_counts_ragged(k):
+    """every lanes-per-row instantiation, rows from empty to > 64 nnz, unsorted storage order"""
+    n, d = 300, 200
+    Xo = ragged_csr(n, d, seed=k)
+    rng = np.random.default_rng(k)
+    y = rng.standard_normal(n)
+    P0, w0 = rng.standard_normal((1, k, d)) * 0.1, np.zeros(d)
+    P, w, b, it, hist = run_oracle_sgd_mb(Xo, y, 2, P0, w0, 0.0, O.sgd_cfg(), 64, 0, None, 2)
+    fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, 0.0)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=64)
+    sgd.fit(to_gpu(Xo), y, fm)
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
+
+
+def test_medium_problem_sgd_and_adagrad():
+    """cfg2's shape scaled down to what the CPU oracle finishes in seconds: n=2e4, d=2e3, m=32, k=16."""
+    n, d, m, k, B = 20000, 2000, 32, 16, 1024
+    Xo = random_csr(n, d, m, seed=42)
+    rng = np.random.default_rng(1)
+    Pt = rng.standard_normal((1, k, d)) * 0.1
+    y = np.sign(O.fm_decision_function(Xo, 2, Pt, np.zeros(d), 0.0))
+    P0, w0 = rng.standard_normal((1, k, d)) * 0.01, np.zeros(d)
+    X = to_gpu(Xo)
+    P, w, b, it, hist = run_oracle_sgd_mb(Xo, y, 2, P0, w0, 0.0, O.sgd_cfg(loss="logistic"), B, 0, None, 2)
+    fm = gpu_fm("classification", 2, k, "explicit", True, True, P0, w0, 0.0)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False, loss="logistic", mode="minibatch", batch=B)
+    sgd.fit(X, y, fm)
+    assert abs(fm.intercept - b) < 1e-10
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
+    assert_close([h[1] for h in sgd.history], [h[1] for h in hist], 1e-10, 1e-13, "loss")
+    cfg = O.adagrad_cfg(loss="logistic")
+    P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
+    st = O.AdaState(1, d, k, d)
+    for e in range(2):
+        b, it, ls, vs = O.fm_adagrad_epoch_mb(Xo, y, 2, P, w, b, cfg, B, st, it=it)
+    b = O.fm_adagrad_finalize(2, P, w, b, cfg, it, st)
+    fm = gpu_fm("classification", 2, k, "explicit", True, True, P0, w0, 0.0)
+    nf.newAdaGrad(maxIter=2, verbose=0, tol=0, shuffle=False, loss="logistic", mode="minibatch", batch=B).fit(X, y, fm)
+    assert abs(fm.intercept - b) < 1e-10
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
+
+
+def test_maxthreads_overload_learns():
+    """fit(X, y, fm, maxThreads) (sgd_multi.nim:40-42) maps to the mini-batch mode; score improves
+    (tests/test_sgd.nim:129-151 on the parallel path)."""
+    Xo, Xd, y = make_fm_dataset(400, 16, 2, 4, 42)
+    P0, w0, b0, _ = init_fm(16, 2, 4, "explicit", True)
+    X = to_gpu(Xo)
+    fm = gpu_fm("regression", 2, 4, "explicit", True, True, P0, w0, b0)
+    before = fm.score(X, y)
+    nf.newSGD(maxIter=30, verbose=0, tol=0, alpha0=1e-9, alpha=1e-9, beta=1e-9, batch=32).fit(X, y, fm, maxThreads=4)
+    assert fm.score(X, y) < before

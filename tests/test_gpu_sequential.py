@@ -1,0 +1,185 @@
+"""-m gpu: NFM_MODE_SEQUENTIAL vs the reference-faithful CPU oracle, on the reference's own grids.
+
+tests/test_sgd.nim:92-126, test_adagrad.nim:92-126, test_sgd_ffm.nim:87-115, test_adagrad_ffm.nim:88-116
+compare fast and slow at rtol 1e-6 / atol 1e-9; the GPU is held to rtol 1e-8 / atol 1e-11 against the
+oracle's fast path (differences: one global L2 scale instead of per-feature snapshots, libm vs ocml)."""
+import itertools
+
+import numpy as np
+import pytest
+
+import nimfm_amd as nf
+import oracle as O
+from common import assert_close, init_ffm, init_fm, make_ffm_dataset, make_fm_dataset, make_perms
+from gpu_common import gpu_ffm, gpu_fm, to_gpu
+
+pytestmark = pytest.mark.gpu
+N, D, K = 80, 8, 4
+RTOL, ATOL = 1e-8, 1e-11
+GRID = list(itertools.product([2, 3, 4], ["explicit", "none", "augment"], [False, True], [False, True]))
+
+
+@pytest.mark.parametrize("degree,fit_lower,fit_linear,fit_intercept", GRID)
+def test_sgd_reference_grid(degree, fit_lower, fit_linear, fit_intercept):
+    Xo, Xd, y = make_fm_dataset(N, D, degree, K, 42, fit_lower, fit_linear, fit_intercept, threshold=0.3)
+    P0, w0, b0, n_aug = init_fm(D, degree, K, fit_lower, fit_linear)
+    perms = make_perms(N, 5)
+    Pf, wf, bf, it, el, ev, _ = O.fm_sgd_fit(Xo, y, degree, P0, w0, b0,
+                                             O.sgd_cfg(fit_linear=fit_linear, fit_intercept=fit_intercept), 5, n_aug,
+                                             perms=perms)
+    fm = gpu_fm("regression", degree, K, fit_lower, fit_linear, fit_intercept, P0, w0, b0)
+    sgd = nf.newSGD(maxIter=5, verbose=0, tol=0)
+    sgd.fit(to_gpu(Xo), y, fm, perms=perms)
+    assert sgd.it == it
+    assert abs(fm.intercept - bf) < 1e-9
+    assert_close(fm.w, wf, RTOL, ATOL, "w")
+    assert_close(fm.P, Pf, RTOL, ATOL, "P")
+    assert_close([h[1] for h in sgd.history], el, 1e-9, 1e-12, "loss")
+    assert_close([h[0] for h in sgd.history], ev, 1e-8, 1e-11, "viol")
+    # the brute-force SGDSlow at the reference's own tolerance
+    Ps, ws, bs, _ = O.slow_fm_sgd_fit(Xd, y, degree, P0, w0, b0,
+                                      O.sgd_cfg(fit_linear=fit_linear, fit_intercept=fit_intercept), 5, n_aug, perms)
+    assert abs(fm.intercept - bs) < 1e-7
+    assert_close(fm.w, ws, 1e-6, 1e-9, "w vs slow")
+    assert_close(fm.P, Ps, 1e-6, 1e-9, "P vs slow")
+    if not fit_linear:
+        assert (fm.w == 0.0).all()  # test_sgd.nim:16-34
+    if not fit_intercept:
+        assert fm.intercept == 0.0  # test_sgd.nim:37-55
+
+
+@pytest.mark.parametrize("loss,scheduling", itertools.product(["squared", "squared_hinge", "logistic", "huber"],
+                                                              ["constant", "optimal", "invscaling", "pegasos"]))
+def test_sgd_losses_and_schedules(loss, scheduling):
+    degree, fit_lower = 3, "explicit"
+    Xo, Xd, y = make_fm_dataset(N, D, degree, K, 42, fit_lower, threshold=0.3, scale=0.3)
+    task = "classification" if loss in ("squared_hinge", "logistic") else "regression"
+    P0, w0, b0, n_aug = init_fm(D, degree, K, fit_lower, True)
+    kw = dict(alpha0=0.5, alpha=0.5, beta=0.5) if scheduling == "pegasos" else {}
+    it0 = 20 if scheduling == "pegasos" else 1
+    perms = make_perms(N, 3)
+    yo = np.sign(y) if task == "classification" else y  # fm_base.nim:32-34 is applied by the library
+    Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, yo, degree, P0, w0, b0, O.sgd_cfg(loss=loss, scheduling=scheduling, power=0.75, **kw),
+                                  3, n_aug, perms=perms, it=it0)
+    fm = gpu_fm(task, degree, K, fit_lower, True, True, P0, w0, b0)
+    sgd = nf.newSGD(maxIter=3, verbose=0, tol=0, loss=loss, scheduling=scheduling, power=0.75, **kw)
+    sgd.it = it0
+    sgd.fit(to_gpu(Xo), y, fm, perms=perms)
+    assert abs(fm.intercept - bf) < 1e-9
+    assert_close(fm.w, wf, RTOL, ATOL, "w")
+    assert_close(fm.P, Pf, RTOL, ATOL, "P")
+
+
+@pytest.mark.parametrize("degree,fit_lower,fit_linear,fit_intercept",
+                         itertools.product([2, 3], ["explicit", "none", "augment"], [False, True], [False, True]))
+def test_adagrad_reference_grid(degree, fit_lower, fit_linear, fit_intercept):
+    Xo, Xd, y = make_fm_dataset(N, D, degree, K, 42, fit_lower, fit_linear, fit_intercept, threshold=0.3)
+    P0, w0, b0, n_aug = init_fm(D, degree, K, fit_lower, fit_linear)
+    perms = make_perms(N, 5)
+    cfg = O.adagrad_cfg(fit_linear=fit_linear, fit_intercept=fit_intercept)
+    Pf, wf, bf, it, el, ev, _, st = O.fm_adagrad_fit(Xo, y, degree, P0, w0, b0, cfg, 5, n_aug, perms=perms)
+    fm = gpu_fm("regression", degree, K, fit_lower, fit_linear, fit_intercept, P0, w0, b0)
+    ada = nf.newAdaGrad(maxIter=5, verbose=0, tol=0)
+    ada.fit(to_gpu(Xo), y, fm, perms=perms)
+    assert ada.it == it
+    assert abs(fm.intercept - bf) < 1e-9
+    assert_close(fm.w, wf, RTOL, ATOL, "w")
+    assert_close(fm.P, Pf, RTOL, ATOL, "P")
+    assert_close([h[1] for h in ada.history], el, 1e-9, 1e-12, "loss")
+    assert_close([h[0] for h in ada.history], ev, 1e-8, 1e-11, "viol")
+    gs, gn, gsw, gnw, gsb, gnb = ada.get_state(fm)
+    assert_close(gs, st.gsum_P, RTOL, ATOL, "g_sum.P")
+    assert_close(gn, st.gnorm_P, RTOL, ATOL, "g_norm.P")
+    if fit_linear:
+        assert_close(gsw, st.gsum_w, RTOL, ATOL)
+        assert_close(gnw, st.gnorm_w, RTOL, ATOL)
+    if fit_intercept:
+        assert abs(gsb - st.gsum_b.value) < 1e-9 and abs(gnb - st.gnorm_b.value) < 1e-9
+    Ps, ws, bs, _ = O.slow_fm_adagrad_fit(Xd, y, degree, P0, w0, b0, cfg, 5, n_aug, perms)
+    assert abs(fm.intercept - bs) < 1e-6
+    assert_close(fm.w, ws, 1e-6, 1e-9, "w vs slow")
+    assert_close(fm.P, Ps, 1e-6, 1e-9, "P vs slow")
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_warm_start(opt):
+    """test_sgd.nim:58-89 / test_adagrad.nim:58-89: 10 x fit(maxIter=1) == fit(maxIter=10), atol 1e-8."""
+    for degree, fit_lower in [(2, "explicit"), (3, "augment"), (4, "none")]:
+        Xo, Xd, y = make_fm_dataset(N, D, degree, K, 42, fit_lower)
+        P0, w0, b0, n_aug = init_fm(D, degree, K, fit_lower, True)
+        X = to_gpu(Xo)
+        mk = (lambda mi: nf.newSGD(maxIter=mi, verbose=0, tol=0, shuffle=False)) if opt == "sgd" else (
+            lambda mi: nf.newAdaGrad(maxIter=mi, verbose=0, tol=0, shuffle=False))
+        fmw = gpu_fm("regression", degree, K, fit_lower, True, True, P0, w0, b0)
+        ow = mk(1)
+        for _ in range(10):
+            ow.fit(X, y, fmw)
+        fm = gpu_fm("regression", degree, K, fit_lower, True, True, P0, w0, b0)
+        o1 = mk(10)
+        o1.fit(X, y, fm)
+        assert ow.it == o1.it == 10 * N + 1
+        assert abs(fm.intercept - fmw.intercept) < 1e-8
+        assert_close(fm.w, fmw.w, atol=1e-8)
+        assert_close(fm.P, fmw.P, atol=1e-8)
+
+
+def test_callbacks_ncalls():
+    """sgd.nim:303-307: callback sees a finalised model every nCalls steps; training is unaffected."""
+    Xo, Xd, y = make_fm_dataset(N, D, 2, K, 42)
+    P0, w0, b0, _ = init_fm(D, 2, K, "explicit", True)
+    X = to_gpu(Xo)
+    seen = []
+    fm = gpu_fm("regression", 2, K, "explicit", True, True, P0, w0, b0)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False, nCalls=32)
+    sgd.fit(X, y, fm, callback=lambda o, m: seen.append((o.it, m.P.copy())))
+    assert [s[0] for s in seen] == [32, 64, 96, 128]
+    fm2 = gpu_fm("regression", 2, K, "explicit", True, True, P0, w0, b0)
+    nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False).fit(X, y, fm2)
+    assert_close(fm.P, fm2.P, 1e-10, 1e-13)
+    Pq, *_ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, O.sgd_cfg(), 1)
+    # the callback after it=32 holds the model after 32 sequential steps of epoch 0
+    Xo32 = O.Dataset(Xo.indptr[:33], Xo.indices[:Xo.indptr[32]], Xo.data[:Xo.indptr[32]], 32, D)
+    P32, *_ = O.fm_sgd_fit(Xo32, y[:32], 2, P0, w0, b0, O.sgd_cfg(), 1)
+    assert_close(seen[0][1], P32, RTOL, ATOL)
+
+
+@pytest.mark.parametrize("fit_linear,fit_intercept", itertools.product([False, True], [False, True]))
+def test_ffm_reference_grid(fit_linear, fit_intercept):
+    n, d, F, k = 80, 20, 5, 4
+    Xo, Xd, field_of, y = make_ffm_dataset(n, d, F, k, 42, threshold=0.3)
+    P0, w0, b0 = init_ffm(d, F, k)
+    X = to_gpu(Xo)
+    Pf, wf, bf, it, el, ev, _ = O.ffm_sgd_fit(Xo, y, P0, w0, b0, O.sgd_cfg(fit_linear=fit_linear, fit_intercept=fit_intercept), 5)
+    ffm = gpu_ffm("regression", k, fit_linear, fit_intercept, P0, w0, b0)
+    sgd = nf.newSGD(maxIter=5, verbose=0, tol=0, shuffle=False)
+    sgd.fit(X, y, ffm)
+    assert abs(ffm.intercept - bf) < 1e-9
+    assert_close(ffm.w, wf, RTOL, ATOL, "w")
+    assert_close(ffm.P, Pf, RTOL, ATOL, "P")
+    assert_close([h[0] for h in sgd.history], ev, 1e-8, 1e-11, "viol")
+    Pf, wf, bf, it, el, ev, _, _ = O.ffm_adagrad_fit(Xo, y, P0, w0, b0,
+                                                     O.adagrad_cfg(fit_linear=fit_linear, fit_intercept=fit_intercept), 5)
+    ffm = gpu_ffm("regression", k, fit_linear, fit_intercept, P0, w0, b0)
+    ada = nf.newAdaGrad(maxIter=5, verbose=0, tol=0, shuffle=False)
+    ada.fit(X, y, ffm)
+    assert abs(ffm.intercept - bf) < 1e-9
+    assert_close(ffm.w, wf, RTOL, ATOL, "w")
+    assert_close(ffm.P, Pf, RTOL, ATOL, "P")
+    assert_close([h[0] for h in ada.history], ev, 1e-8, 1e-11, "viol")
+
+
+def test_stopping_criterion_and_scale_reset():
+    Xo, Xd, y = make_fm_dataset(N, D, 2, K, 42, threshold=0.3)
+    P0, w0, b0, _ = init_fm(D, 2, K, "explicit", True)
+    X = to_gpu(Xo)
+    fm = gpu_fm("regression", 2, K, "explicit", True, True, P0, w0, b0)
+    sgd = nf.newSGD(maxIter=50, verbose=0, tol=1e9, shuffle=False)
+    sgd.fit(X, y, fm)
+    assert len(sgd.history) == 1  # viol < tol after the first epoch (sgd.nim:85-89)
+    # scale_P drops below 1e-9 inside the epoch: the dense reset (sgd.nim:116-131) must be invisible
+    cfg = dict(eta0=0.5, alpha=1.5, beta=1.5, scheduling="constant")
+    Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, O.sgd_cfg(**cfg), 4)
+    fm = gpu_fm("regression", 2, K, "explicit", True, True, P0, w0, b0)
+    nf.newSGD(maxIter=4, verbose=0, tol=0, shuffle=False, **cfg).fit(X, y, fm)
+    assert_close(fm.w, wf, 1e-7, 1e-11, "w")
+    assert_close(fm.P, Pf, 1e-7, 1e-11, "P")
