@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- SGD training samples/s per epoch on synthetic CSR (BASELINE.json metric).
+
+One "step" = one pass of the hot path (nfm_opt_epoch, mini-batch mode) over the rank's whole
+synthetic shard, inputs already resident in HBM.  N = 1 runs BASELINE.json configs[1]
+("cfg2": synthetic CSR 1e6 x 1e5, 32 nnz/row, k = 16, SGD, Logistic loss, 1 MI355X).
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank trains on its own
+shard of the same size (weak scaling) and the replicas are averaged with one all-reduce of P / w /
+intercept per step; there is no collective inside the epoch.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), carrying
+  roofline     achieved algorithmic bytes/s of the per-batch kernel pair vs the 8 TB/s HBM peak,
+               durations from HIP events recorded by the library on its own stream
+  cpu_baseline the reference-faithful CPU port (oracle/, single thread) on the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: n, d, m, k, degree, solver, loss   (SURVEY.md 8d / BASELINE.md)
+    "cfg2": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic"),
+    "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="squared"),
+    "cfg3": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="squared"),
+    "tiny": dict(n=50_000, d=5_000, m=16, k=8, degree=2, solver="sgd", loss="logistic"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def algorithmic_bytes_per_sample(solver, m, k, n_orders=1):
+    """int32 idx, fp64 val, fp64 params."""
+    if solver == "sgd":
+        return 12 * m + 16 + n_orders * 16 * m * k + 16 * m + 8 * m
+    return 12 * m + 16 + n_orders * 32 * m * k + 32 * m
+
+
+def gen_shard(torch, dev, n, d, m, seed):
+    """m distinct uniform-random column indices per row (sorted), values U(-1,1)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    idx = torch.randint(0, d, (n, m), device=dev, generator=g, dtype=torch.int64)
+    idx, _ = torch.sort(idx, dim=1)
+    for _ in range(64):  # re-draw the few rows that contain a repeated index
+        bad = (idx[:, 1:] == idx[:, :-1]).any(dim=1).nonzero().flatten()
+        if bad.numel() == 0:
+            break
+        fresh = torch.randint(0, d, (bad.numel(), m), device=dev, generator=g, dtype=torch.int64)
+        idx[bad], _ = torch.sort(fresh, dim=1)
+    val = torch.rand((n, m), device=dev, generator=g, dtype=torch.float64) * 2.0 - 1.0
+    indptr = torch.arange(n + 1, device=dev, dtype=torch.int64) * m
+    return indptr, idx.to(torch.int32).reshape(-1).contiguous(), val.reshape(-1).contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--n", type=int, default=0, help="override samples per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=1_000_000)
+    args = ap.parse_args()
+
+    import torch
+
+    import nimfm_amd as nf
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libnimfm_hip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+    wl = dict(WORKLOADS[args.workload])
+    if args.n:
+        wl["n"] = args.n
+    n, d, m, k = wl["n"], wl["d"], wl["m"], wl["k"]
+
+    ctx = nf.Context(local_rank)
+    nf.set_default_context(ctx)
+    # ---- synthetic shard, generated on the device (data seed 42 + rank; model seed 1) ----
+    indptr, indices, data = gen_shard(torch, dev, n, d, m, 42 + rank)
+    torch.cuda.synchronize()
+    X = nf.CSRDataset.from_device(ctx, n, d, n * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(),
+                                  keep=(indptr, indices, data))
+    # labels from a planted FM (k, scale 0.1), like tests/utils.nim:29-47; classification -> sign
+    rng = np.random.default_rng(1234)
+    planted = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True)
+    planted.set_params(rng.standard_normal((1, k, d)) * 0.1, rng.standard_normal(d) * 0.1, 0.0)
+    y = planted.decisionFunction(X)
+    task = "classification" if wl["loss"] in ("logistic", "squared_hinge") else "regression"
+    if task == "classification":
+        y = np.sign(y)
+    del planted
+    fm = nf.newFactorizationMachine(task, degree=wl["degree"], nComponents=k, warmStart=True, randomState=1)
+    fm.init(X)  # w = 0, P ~ N(0, 0.01^2), intercept = 0 (model/factorization_machine.nim:125-139)
+    if wl["solver"] == "sgd":
+        opt = nf.newSGD(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch", batch=args.batch)
+    else:
+        opt = nf.newAdaGrad(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch",
+                            batch=args.batch)
+    X.set_targets(y)
+    opt._handle(fm, ctx, "minibatch")
+    import ctypes as C
+
+    from nimfm_amd import _capi as capi
+
+    views = None
+    if world > 1:
+        from nimfm_amd import dp
+
+        views = dp.ParamViews(torch, dev, fm, opt)
+
+    def step():
+        ls, vs = opt._epoch(X, None, 0, n)
+        opt.it += n
+        if world > 1:
+            views.average(dist, world)
+        return ls, vs
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = n * world / (dt / args.steps)
+
+    # ---- roofline leg: per-kernel durations from HIP events on the library's stream ----
+    roof = None
+    if rank == 0:
+        ctx.timing_reset()
+        ctx.timing_enable(True)
+        reps = 2
+        for _ in range(reps):
+            opt._epoch(X, None, 0, n)
+            opt.it += n
+        ctx.synchronize()
+        fam = {f: ctx.timing_get(f) for f in ("row_phase", "col_phase", "batch_finish", "schedule")}
+        ctx.timing_enable(False)
+        n_batches = fam["row_phase"][0] / reps
+        per_batch_ms = {f: (fam[f][1] / fam[f][0] if fam[f][0] else 0.0) for f in fam}
+        pair_ms = per_batch_ms["row_phase"] + per_batch_ms["col_phase"] + per_batch_ms["batch_finish"]
+        bps = algorithmic_bytes_per_sample(wl["solver"], m, k)
+        units = n / n_batches
+        achieved = bps * units / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": "k_row_phase+k_col_phase+k_batch_finish (one mini-batch)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_sample": bps, "samples_per_launch": units,
+                "avg_ms": {f: round(per_batch_ms[f], 5) for f in per_batch_ms},
+                "launches_per_step": {f: fam[f][0] / reps for f in fam}}
+
+    # ---- CPU baseline: reference-faithful port, single thread, same workload (rank 0, N = 1) ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle as O
+
+        nc = min(n, args.cpu_samples)
+        ip = indptr[: nc + 1].cpu().numpy()
+        ix = indices[: nc * m].cpu().numpy().astype(np.int64)
+        dv = data[: nc * m].cpu().numpy()
+        Xo = O.Dataset(ip, ix, dv, nc, d)
+        P0 = np.random.default_rng(1).standard_normal((1, k, d)) * 0.01
+        cfg = O.sgd_cfg(loss=wl["loss"]) if wl["solver"] == "sgd" else O.adagrad_cfg(loss=wl["loss"])
+        tc = time.perf_counter()
+        if wl["solver"] == "sgd":
+            O.fm_sgd_fit(Xo, y[:nc], 2, P0, np.zeros(d), 0.0, cfg, 1)
+        else:
+            O.fm_adagrad_fit(Xo, y[:nc], 2, P0, np.zeros(d), 0.0, cfg, 1)
+        t1 = time.perf_counter() - tc
+        threads = os.cpu_count() or 1
+        th = None
+        if wl["solver"] == "sgd":
+            tc = time.perf_counter()
+            O.fm_sgd_fit(Xo, y[:nc], 2, P0, np.zeros(d), 0.0, cfg, 1, hogwild_threads=threads)
+            th = time.perf_counter() - tc
+        cpu = {"value": round(nc / t1, 1), "unit": "samples/s", "cores": 1, "kind": "port",
+               "sample": "one sequential epoch (optimizer/sgd.nim:261-328 semantics) over the first %d samples of "
+                         "the same shard, C restatement -O2, 1 thread" % nc,
+               "hogwild": None if th is None else {"value": round(nc / th, 1), "threads": threads,
+                                                   "note": "optimizer/sgd_multi.nim semantics (racy), same port"}}
+
+    if rank == 0:
+        out = {"metric": "SGD training samples/sec/epoch", "value": round(value, 1), "unit": "samples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "%s: synthetic CSR %dx%d, %d nnz/row, k=%d, %s %s loss, mini-batch %d, "
+                                      "mode=minibatch" % (args.workload, n, d, m, k, wl["solver"].upper(),
+                                                          wl["loss"], args.batch),
+                          "samples_per_gpu": n, "batch": args.batch,
+                          "parallelism": "replicas=%d, parameter average per step" % world if world > 1 else "1 GPU"},
+               "last_step": {"mean_loss": last[0] / n, "viol": last[1]},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

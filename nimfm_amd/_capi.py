@@ -3,6 +3,7 @@
 There is no fallback: if the shared library is missing or a symbol is absent the import of the
 compute layer fails loudly.  Nothing here touches oracle/.
 """
+import atexit
 import ctypes as C
 import os
 import subprocess
@@ -72,6 +73,15 @@ def build(force=False):
 
 
 _lib = None
+alive = True  # cleared at interpreter exit: object finalizers then leave teardown to the OS
+
+
+def _at_exit():
+    global alive
+    alive = False
+
+
+atexit.register(_at_exit)
 
 
 def lib():

@@ -13,6 +13,7 @@ struct MbWork {
   DevBuf partsB;   // per-block partial viol of the column phase
   DevBuf Dtab;     // per-batch decay products {D_P, D_w, D_0, -}
   DevBuf Stab;     // scales at every batch boundary {scale_P, scale_w}
+  DevBuf Ftab;     // per-batch decay corrections by touch count [2][64]
   DevBuf out_acc;  // {loss_sum, viol_sum} of the epoch call
   DevBuf contrib;  // FFM: per-touch gradient rows
 };

@@ -36,8 +36,10 @@ static_assert(sizeof(SampleRec) == 32 && sizeof(PartA) == 32, "record layout");
 // ------------------------------------------------------------------------------------------------
 // schedule: per-batch decay products and scales (SGD only)
 // ------------------------------------------------------------------------------------------------
+constexpr int kFtab = 64;  // touch counts 1..kFtab have a tabulated decay correction
+
 __global__ void k_schedule(OptView O, int fit_linear, int fit_intercept, const int64_t* __restrict__ bat_pos, double it0,
-                           double* __restrict__ Dtab /*[nb][4]*/) {
+                           double* __restrict__ Dtab /*[nb][4]*/, double* __restrict__ Ftab /*[nb][2][kFtab]*/) {
   __shared__ double red[3][kBlock];
   const int b = blockIdx.x;
   const int64_t p0 = bat_pos[b], p1 = bat_pos[b + 1];
@@ -65,6 +67,13 @@ __global__ void k_schedule(OptView O, int fit_linear, int fit_intercept, const i
     Dtab[4 * b + 1] = red[1][0];
     Dtab[4 * b + 2] = red[2][0];
     Dtab[4 * b + 3] = 0.0;
+  }
+  // a coordinate touched c times receives D^(1/c) instead of D; relative to the global scale
+  // (which advances by D) that is the factor D^(1/c) / D, tabulated for c = 1..kFtab
+  if (threadIdx.x < 2 * kFtab) {
+    const int which = threadIdx.x / kFtab, c = threadIdx.x % kFtab + 1;
+    const double D = red[which][0];
+    Ftab[((size_t)b * 2 + which) * kFtab + (c - 1)] = c == 1 ? 1.0 : pow(D, 1.0 / (double)c) / D;
   }
 }
 
@@ -209,8 +218,8 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
       if (lane == 0) a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
       if (M.fit_intercept) {
         const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
-        r_viol = fabs(eta0 * (dL + O.alpha0 * b0));
         r_acc0 = eta0 * dL;
+        r_acc1 = eta0;
       }
     } else {
       if (lane == 0) a.rec[pib] = SampleRec{dL, 0.0, 0.0, 0.0};
@@ -252,6 +261,8 @@ struct ColArgs {
   int64_t u0, u1;
   const double* scales_b;  // {scale_P, scale_w} at the batch start
   const double* scales_n;  // ... at the next batch start
+  const double* Dtab_b;    // SGD: {D_P, D_w, D_0} of this batch
+  const double* Ftab_b;    // SGD: [2][kFtab] decay corrections by touch count
   const double* Abuf;
   const SampleRec* rec;
   double* parts;  // [gridDim.x]
@@ -262,7 +273,7 @@ struct ColArgs {
 // one parameter block (order) of one unique feature: this lane's factor pair at element e
 template <int DEG, int OPT>
 __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int slot, int l, int64_t t0, int64_t t1, double sP,
-                                            double sPn) {
+                                            double sPn, double fP) {
   const ModelView& M = a.M;
   const OptView& O = a.O;
   double viol = 0.0;
@@ -288,6 +299,7 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int slot
     }
   }
   double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
+  double seta = 0.0;
   for (int64_t t = t0; t < t1; ++t) {
     const int pib = a.tpos[t];
     const double x = a.tx[t];
@@ -302,10 +314,10 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int slot
     }
     const double dAx = dev::anova_grad<DEG>(x, p.x, Ax);
     const double dAy = dev::anova_grad<DEG>(x, p.y, Ay);
-    if (OPT == OPT_SGD) {  // sgd.nim:220-222
+    if (OPT == OPT_SGD) {  // sgd.nim:220-222, averaged per coordinate below
       acc.x += r.etaP * (r.dL * dAx);
       acc.y += r.etaP * (r.dL * dAy);
-      viol += fabs(r.etaP * (r.dL * dAx + O.beta * p.x)) + fabs(r.etaP * (r.dL * dAy + O.beta * p.y));
+      seta += r.etaP;
     } else {  // adagrad.nim:122-124
       const double gx = r.dL * dAx, gy = r.dL * dAy;
       acc.x += gx;
@@ -315,8 +327,10 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int slot
     }
   }
   if (OPT == OPT_SGD) {
-    stored.x -= acc.x / sPn;
-    stored.y -= acc.y / sPn;
+    const double c = (double)(t1 - t0);
+    viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
+    stored.x = stored.x * fP - (acc.x / c) / sPn;
+    stored.y = stored.y * fP - (acc.y / c) / sPn;
     *reinterpret_cast<double2*>(M.P + e) = stored;
   } else {
     g2.x += acc.x;
@@ -342,23 +356,33 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
   if (u < a.u1) {
     const int64_t j = a.ucol[u];
     const int64_t t0 = a.uptr[u], t1 = a.uptr[u + 1];
-    double sP = 1.0, sPn = 1.0, sw = 1.0, swn = 1.0;
+    double sP = 1.0, sPn = 1.0, sw = 1.0, swn = 1.0, fP = 1.0, fw = 1.0;
     if (OPT == OPT_SGD) {
       sP = a.scales_b[0];
       sw = a.scales_b[1];
       sPn = a.scales_n[0];
       swn = a.scales_n[1];
+      const int64_t c = t1 - t0;
+      if (c > 1) {
+        if (c <= kFtab) {
+          fP = a.Ftab_b[c - 1];
+          fw = a.Ftab_b[kFtab + c - 1];
+        } else {
+          fP = pow(a.Dtab_b[0], 1.0 / (double)c) / a.Dtab_b[0];
+          fw = pow(a.Dtab_b[1], 1.0 / (double)c) / a.Dtab_b[1];
+        }
+      }
     }
     int slot = 0;
     for (int o = 0; o < M.nb; ++o) {
       const size_t e = ((size_t)o * M.da + j) * M.Kp + 2 * l;
       const int deg = M.degree - o;
       switch (deg) {
-        case 2: viol += col_block<2, OPT>(a, e, slot, l, t0, t1, sP, sPn); break;
-        case 3: viol += col_block<3, OPT>(a, e, slot, l, t0, t1, sP, sPn); break;
-        case 4: viol += col_block<4, OPT>(a, e, slot, l, t0, t1, sP, sPn); break;
-        case 5: viol += col_block<5, OPT>(a, e, slot, l, t0, t1, sP, sPn); break;
-        case 6: viol += col_block<6, OPT>(a, e, slot, l, t0, t1, sP, sPn); break;
+        case 2: viol += col_block<2, OPT>(a, e, slot, l, t0, t1, sP, sPn, fP); break;
+        case 3: viol += col_block<3, OPT>(a, e, slot, l, t0, t1, sP, sPn, fP); break;
+        case 4: viol += col_block<4, OPT>(a, e, slot, l, t0, t1, sP, sPn, fP); break;
+        case 5: viol += col_block<5, OPT>(a, e, slot, l, t0, t1, sP, sPn, fP); break;
+        case 6: viol += col_block<6, OPT>(a, e, slot, l, t0, t1, sP, sPn, fP); break;
         default: break;
       }
       slot += deg - 1;
@@ -368,14 +392,15 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
       if (OPT == OPT_SGD) {
         const double wt = M.w[j];
         const double wj = sw * wt;
-        double accw = 0.0;
+        double accw = 0.0, setaw = 0.0;
         for (int64_t t = t0; t < t1; ++t) {
           const SampleRec r = a.rec[a.tpos[t]];
-          const double x = a.tx[t];
-          accw += r.etaw * (r.dL * x);
-          viol += fabs(r.etaw * (r.dL * x + O.alpha * wj));
+          accw += r.etaw * (r.dL * a.tx[t]);
+          setaw += r.etaw;
         }
-        M.w[j] = wt - accw / swn;
+        const double c = (double)(t1 - t0);
+        viol += fabs((accw + setaw * O.alpha * wj) / c);
+        M.w[j] = wt * fw - (accw / c) / swn;
       } else {
         const double wt = M.w[j];
         double gw = O.Gw[j], nw = O.Nw[j];
@@ -415,7 +440,7 @@ struct FinArgs {
   const double* partsB;
   const double* Dtab_b;  // SGD: {D_P, D_w, D_0}
   double* out_acc;       // {loss_sum, viol_sum}
-  double it_b;
+  double it_b, len;
   int32_t nA, nB, use_stored, opt;
 };
 
@@ -442,8 +467,11 @@ __global__ __launch_bounds__(kBlock) void k_batch_finish(FinArgs a) {
     const ModelView& M = a.M;
     const OptView& O = a.O;
     if (M.fit_intercept) {
-      if (a.opt == OPT_SGD) {
-        M.sc[SC_INTERCEPT] = a.Dtab_b[2] * M.sc[SC_INTERCEPT] - red[2][0];
+      if (a.opt == OPT_SGD) {  // the intercept is touched by every sample of the batch: c = len
+        const double b0 = M.sc[SC_INTERCEPT], D0 = a.Dtab_b[2];
+        const double f0 = a.len == 1.0 ? D0 : pow(D0, 1.0 / a.len);
+        viol += fabs((red[2][0] + red[3][0] * O.alpha0 * b0) / a.len);
+        M.sc[SC_INTERCEPT] = f0 * b0 - red[2][0] / a.len;
       } else {
         if (!a.use_stored) {  // adagrad.nim:102-106
           const double old = M.sc[SC_INTERCEPT];
@@ -487,14 +515,16 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     int nB = (int)((u1 - u0 + per_block - 1) / per_block);
     if (nB > 0) {
       ColArgs ca{M, O, P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(), u0, u1,
-                 OPT == OPT_SGD ? Stab + 2 * b : M.sc, OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc, W.Abuf.as<double>(),
+                 OPT == OPT_SGD ? Stab + 2 * b : M.sc, OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc,
+                 OPT == OPT_SGD ? Dtab + 4 * b : nullptr,
+                 OPT == OPT_SGD ? W.Ftab.as<double>() + (size_t)b * 2 * kFtab : nullptr, W.Abuf.as<double>(),
                  W.rec.as<SampleRec>(), W.partsB.as<double>(), it_b, TA, use_stored};
       TimedLaunch tl(ctx, "col_phase");
       hipLaunchKernelGGL((k_col_phase<L, OPT>), dim3(nB), dim3(kBlock), 0, st, ca);
     }
     {
       FinArgs fa{M, O, W.partsA.as<PartA>(), W.partsB.as<double>(), OPT == OPT_SGD ? Dtab + 4 * b : nullptr,
-                 W.out_acc.as<double>(), it_b, nA, nB, use_stored, OPT};
+                 W.out_acc.as<double>(), it_b, (double)len, nA, nB, use_stored, OPT};
       TimedLaunch tl(ctx, "batch_finish");
       hipLaunchKernelGGL(k_batch_finish, dim3(1), dim3(kBlock), 0, st, fa);
     }
@@ -525,12 +555,13 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   NFM_TRY(W.partsB.ensure(sizeof(double) * (size_t)(P.max_unique / kMinGroupsPerBlock + 1)));
   NFM_TRY(W.Dtab.ensure(sizeof(double) * 4 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Stab.ensure(sizeof(double) * 2 * (size_t)(P.n_batches + 1)));
+  NFM_TRY(W.Ftab.ensure(sizeof(double) * 2 * kFtab * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.out_acc.ensure(sizeof(double) * 2));
   NFM_HIP_CHECK(hipMemsetAsync(W.out_acc.p, 0, sizeof(double) * 2, st));
   if (P.n_batches > 0 && opt_kind == OPT_SGD) {
     TimedLaunch tl(ctx, "schedule");
     hipLaunchKernelGGL(k_schedule, dim3((unsigned)P.n_batches), dim3(kBlock), 0, st, O, M.fit_linear, M.fit_intercept,
-                       P.bat_pos_dev.as<int64_t>(), (double)it0, W.Dtab.as<double>());
+                       P.bat_pos_dev.as<int64_t>(), (double)it0, W.Dtab.as<double>(), W.Ftab.as<double>());
     hipLaunchKernelGGL(k_scale_prefix, dim3(1), dim3(1), 0, st, M.sc, W.Dtab.as<double>(), W.Stab.as<double>(), P.n_batches);
     NFM_HIP_CHECK(hipGetLastError());
   }

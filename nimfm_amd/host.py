@@ -60,9 +60,9 @@ class Context:
         return n.value, ms.value
 
     def close(self):
-        if self.h:
+        if self.h and capi.alive:
             capi.lib().nfm_ctx_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
 
 _default_ctx = None
@@ -130,7 +130,7 @@ class CSRDataset:
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
+            if capi.alive and getattr(self, "h", None):
                 capi.lib().nfm_dataset_destroy(self.h)
                 self.h = None
         except Exception:
@@ -237,9 +237,9 @@ class _ModelBase:
         self._dirty = False
 
     def _release(self):
-        if self._h is not None:
+        if self._h is not None and capi.alive:
             capi.lib().nfm_model_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
@@ -451,9 +451,9 @@ class _OptimizerBase:
         self.history = []  # (viol, mean loss) per epoch, what echoInfo prints
 
     def _release(self):
-        if self._h is not None:
+        if self._h is not None and capi.alive:
             capi.lib().nfm_opt_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:

@@ -9,9 +9,11 @@
  *
  *   all samples of a batch see the parameters as of the batch start; their
  *   per-sample updates (the reference's per-sample expressions, each with its
- *   own step counter `it`) are summed in sample order; L2 decay is the product
- *   of the per-step factors (1 - eta_t * reg) of the batch, applied to every
- *   coordinate (which is what the reference's lazy scaling amounts to).
+ *   own step counter `it`) are combined per coordinate in sample order -- SGD:
+ *   averaged over the samples that touch the coordinate, AdaGrad: summed into
+ *   the (additive) state; L2 decay is the product of the per-step factors
+ *   (1 - eta_t * reg) of the batch (what the reference's lazy scaling amounts
+ *   to).  Exact statements precede sgd_epoch_mb and ada_epoch_mb below.
  *
  * With batch == 1 this IS the reference's sequential step in exact
  * arithmetic (tests/test_oracle_mb.py checks that against nimfm_oracle.c).
@@ -36,7 +38,21 @@ static double mb_predict_ffm(const orc_csr* X, int64_t i, int n_blocks, int k, i
   return ffm_predict_with_grad(X, i, n_blocks, k, Pt, w, intercept, dA);
 }
 
-/* ---------------- SGD ---------------- */
+/* ---------------- SGD ----------------
+ * Per batch b (steps t = it_b .. it_b+len-1, parameters theta_b at the batch start), for every
+ * coordinate j touched by c_j >= 1 samples of the batch:
+ *     acc_j      = sum_{i touches j} eta_{t_i} * dL_i * dA_ij(theta_b)       (sample order)
+ *     theta_j   <- D_b^(1/c_j) * theta_j - acc_j / c_j
+ *     viol      += | (acc_j + (sum_i eta_{t_i}) * reg * theta_j) / c_j |
+ * untouched coordinates:  theta_j <- D_b * theta_j,   D_b = prod_t (1 - eta_t * reg).
+ * i.e. the per-sample steps of the reference (sgd.nim:217-231) are AVERAGED per coordinate
+ * instead of applied one after the other, and the coordinate receives len/c_j decay steps per
+ * gradient step, which keeps the loss/regulariser balance of the sequential process for sparse
+ * (c_j = 1: exactly the reference step after len-1 lazily applied decays) and dense (c_j = len:
+ * plain mini-batch SGD on the batch mean) coordinates alike.  A plain sum (Hogwild without lost
+ * updates) multiplies the step of a coordinate by c_j and diverges on dense ones (intercept).
+ * The intercept is a coordinate touched by every sample (c = len).  batch == 1 gives the
+ * reference's step exactly. */
 static int sgd_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict, int n_blocks,
                         int k, int degree, int n_aug, double* Pt /*[n_blocks][da][k]*/, double* w,
                         double* intercept, const orc_sgd_cfg* c, const int64_t* perm, int64_t begin,
@@ -47,15 +63,22 @@ static int sgd_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict
   double* dA = (double*)calloc(np ? np : 1, sizeof(double));
   double* accP = (double*)calloc(np ? np : 1, sizeof(double));
   double* accw = (double*)calloc(d ? d : 1, sizeof(double));
+  double* cnt = (double*)calloc(da ? da : 1, sizeof(double));     /* c_j */
+  double* setaP = (double*)calloc(da ? da : 1, sizeof(double));   /* sum of eta_P over touching samples */
+  double* setaw = (double*)calloc(da ? da : 1, sizeof(double));
   double* A = (double*)calloc((size_t)k * (degree + 2), sizeof(double));
-  if (!dA || !accP || !accw || !A) return -1;
+  if (!dA || !accP || !accw || !cnt || !setaP || !setaw || !A) return -1;
   double loss = 0.0, viol = 0.0;
   if (batch < 1) batch = 1;
   for (int64_t p0 = begin; p0 < end; p0 += batch) {
     const int64_t p1 = p0 + batch < end ? p0 + batch : end;
+    const double len = (double)(p1 - p0);
     memset(accP, 0, sizeof(double) * np);
     memset(accw, 0, sizeof(double) * (size_t)d);
-    double accb = 0.0, DP = 1.0, Dw = 1.0, D0 = 1.0;
+    memset(cnt, 0, sizeof(double) * (size_t)da);
+    memset(setaP, 0, sizeof(double) * (size_t)da);
+    memset(setaw, 0, sizeof(double) * (size_t)da);
+    double accb = 0.0, seta0 = 0.0, DP = 1.0, Dw = 1.0, D0 = 1.0;
     for (int64_t pos = p0; pos < p1; pos++) {
       const int64_t i = perm ? perm[pos] : pos;
       const int64_t t = *it + (pos - p0);
@@ -66,38 +89,57 @@ static int sgd_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict
       const double y_pred = predict(X, i, n_blocks, k, degree, n_aug, Pt, w, *intercept, A, dA);
       loss += orc_loss(c->loss, c->loss_param, y[i], y_pred);
       const double dL = orc_dloss(c->loss, c->loss_param, y[i], y_pred);
-      for (int o = 0; o < n_blocks; o++)
-        for (int64_t q = 0; q < r.m + n_aug; q++) {
-          const int64_t j = ROW_J(r, q, d);
+      for (int64_t q = 0; q < r.m + n_aug; q++) {
+        const int64_t j = ROW_J(r, q, d);
+        cnt[j] += 1.0;
+        setaP[j] += etaP;
+        setaw[j] += etaw;
+        for (int o = 0; o < n_blocks; o++)
           for (int s = 0; s < k; s++) {
             const size_t e = ((size_t)o * da + j) * k + s;
-            viol += fabs(etaP * (dL * dA[e] + c->beta * Pt[e]));
             accP[e] += etaP * (dL * dA[e]);
           }
-        }
-      if (c->fit_intercept) {
-        viol += fabs(eta0 * (dL + c->alpha0 * *intercept));
-        accb += eta0 * dL;
+        if (c->fit_linear && q < r.m) accw[j] += etaw * (dL * r.val[q]);
       }
-      if (c->fit_linear)
-        for (int64_t q = 0; q < r.m; q++) {
-          const int64_t j = r.idx[q];
-          viol += fabs(etaw * (dL * r.val[q] + c->alpha * w[j]));
-          accw[j] += etaw * (dL * r.val[q]);
-        }
+      accb += eta0 * dL;
+      seta0 += eta0;
       DP *= (1 - etaP * c->beta);
       Dw *= (1 - etaw * c->alpha);
       D0 *= (1 - eta0 * c->alpha0);
     }
-    for (size_t e = 0; e < np; e++) Pt[e] = DP * Pt[e] - accP[e];
-    if (c->fit_linear)
-      for (int64_t j = 0; j < d; j++) w[j] = Dw * w[j] - accw[j];
-    if (c->fit_intercept) *intercept = D0 * *intercept - accb;
+    for (int64_t j = 0; j < da; j++) {
+      const double cj = cnt[j];
+      const double fP = cj > 0 ? (cj == 1.0 ? DP : pow(DP, 1.0 / cj)) : DP;
+      for (int o = 0; o < n_blocks; o++)
+        for (int s = 0; s < k; s++) {
+          const size_t e = ((size_t)o * da + j) * k + s;
+          if (cj > 0) {
+            viol += fabs((accP[e] + setaP[j] * c->beta * Pt[e]) / cj);
+            Pt[e] = fP * Pt[e] - accP[e] / cj;
+          } else {
+            Pt[e] = DP * Pt[e];
+          }
+        }
+      if (c->fit_linear && j < d) {
+        if (cj > 0) {
+          const double fw = cj == 1.0 ? Dw : pow(Dw, 1.0 / cj);
+          viol += fabs((accw[j] + setaw[j] * c->alpha * w[j]) / cj);
+          w[j] = fw * w[j] - accw[j] / cj;
+        } else {
+          w[j] = Dw * w[j];
+        }
+      }
+    }
+    if (c->fit_intercept) {
+      const double f0 = len == 1.0 ? D0 : pow(D0, 1.0 / len);
+      viol += fabs((accb + seta0 * c->alpha0 * *intercept) / len);
+      *intercept = f0 * *intercept - accb / len;
+    }
     *it += p1 - p0;
   }
   *loss_sum = loss;
   *viol_sum = viol;
-  free(dA); free(accP); free(accw); free(A);
+  free(dA); free(accP); free(accw); free(cnt); free(setaP); free(setaw); free(A);
   return 0;
 }
 

@@ -107,7 +107,7 @@ def test_component_counts_ragged(k):
     Xo = ragged_csr(n, d, seed=k)
     rng = np.random.default_rng(k)
     y = rng.standard_normal(n)
-    P0, w0 = rng.standard_normal((1, k, d)) * 0.1, np.zeros(d)
+    P0, w0 = rng.standard_normal((1, k, d)) * (0.1 / np.sqrt(k)), np.zeros(d)
     P, w, b, it, hist = run_oracle_sgd_mb(Xo, y, 2, P0, w0, 0.0, O.sgd_cfg(), 64, 0, None, 2)
     fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, 0.0)
     sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=64)

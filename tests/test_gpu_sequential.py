@@ -132,7 +132,7 @@ def test_callbacks_ncalls():
     fm = gpu_fm("regression", 2, K, "explicit", True, True, P0, w0, b0)
     sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False, nCalls=32)
     sgd.fit(X, y, fm, callback=lambda o, m: seen.append((o.it, m.P.copy())))
-    assert [s[0] for s in seen] == [32, 64, 96, 128]
+    assert [s[0] for s in seen] == [32, 64, 96, 128, 160]
     fm2 = gpu_fm("regression", 2, K, "explicit", True, True, P0, w0, b0)
     nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False).fit(X, y, fm2)
     assert_close(fm.P, fm2.P, 1e-10, 1e-13)
