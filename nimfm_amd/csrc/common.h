@@ -127,6 +127,25 @@ struct DevBuf {  // owned device allocation
   T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// SPLIT (row slots per sample, fm_device.h) for a launch over n samples with avg_row nnz per row:
+// enough wavefronts to fill the chip (>= 16 per CU) and a serial chain of at most ~4 rounds of
+// kUnroll loads per lane; capped by the 64/L slots a wavefront has and by 16.
+inline int choose_split(int L, int64_t n, double avg_row, int n_cu) {
+  const int R = kWave / L;
+  auto p2 = [](double v) {
+    int r = 1;
+    while (r < v && r < 64) r <<= 1;
+    return r;
+  };
+  const double occ = (double)n_cu * 16.0 * kWave / ((double)(n > 0 ? n : 1) * L);
+  int s = p2(occ);
+  const int lat = p2(avg_row / 16.0);
+  if (lat > s) s = lat;
+  if (s > R) s = R;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : s;
+}
+
 inline int lanes_for_k(int k) {
   int half = (k + 1) / 2, L = 1;
   while (L < half) L <<= 1;

@@ -1,17 +1,21 @@
 // nimfm_amd/csrc/fm_device.h -- device-side building blocks shared by the predict, row-phase and
 // column-phase kernels.  Written for gfx950 wave64.
 //
-// Work decomposition of one CSR row on one wavefront ("lanes <-> latent factors"):
-//   L lanes (power of two, Kp = 2L) cover one parameter row P[j][0..Kp) as one 16-byte load each,
-//   so a wave-instruction gathers R = 64/L rows (R*Kp*8 = 1 KiB, each row one contiguous,
-//   aligned segment).  Lane = (g, l): g = row slot, l = factor pair {2l, 2l+1}.
-//   The row's (index, value) slice is held one nnz per lane (64 per chunk) and handed to the
-//   row slots with ds_bpermute (__shfl); the per-factor sums are finished with xor-shuffles.
+// Work decomposition of CSR rows on a wavefront ("lanes <-> latent factors"):
+//   L lanes (power of two, Kp = 2L) cover one parameter row P[j][0..Kp) with one 16-byte load each:
+//   a row is one contiguous, aligned segment of Kp*8 bytes.  A sample owns SPLIT such row slots
+//   (L*SPLIT lanes), slot q handles the row's nnz q, q+SPLIT, ...; a wavefront therefore carries
+//   64/(L*SPLIT) samples.  Per-factor sums are finished with xor-shuffles across the SPLIT slots,
+//   sums over the factors with xor-shuffles across the L lanes.  SPLIT trades per-sample latency
+//   (more slots = shorter serial chain) against fixed per-sample work (loss, step sizes, reductions)
+//   being amortised over more samples per wave-instruction.
 #pragma once
 #include "common.h"
 
 namespace nfm {
 namespace dev {
+
+constexpr int kMaxDeg = 6;
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, kWave); }
 __device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, kWave); }
@@ -89,29 +93,6 @@ __device__ __forceinline__ double target_of(double y, int task) {
   return y;
 }
 
-struct RowChunk {
-  int idx;
-  double val;
-};
-
-// nnz (c*64 + lane) of the row that starts at q0 with m stored entries followed by n_aug dummy
-// features (index d+t, value 1.0; dataset.nim:182-189).  Lanes past the end hold (0, 0.0), which
-// contributes nothing to any sum below and points at a valid parameter row.
-__device__ __forceinline__ RowChunk load_chunk(const CsrView& X, int64_t q0, int m, int m_tot, int c, int lane) {
-  const int q = c * kWave + lane;
-  RowChunk r;
-  r.idx = 0;
-  r.val = 0.0;
-  if (q < m) {
-    r.idx = X.indices[q0 + q];
-    r.val = X.data[q0 + q];
-  } else if (q < m_tot) {
-    r.idx = (int)(X.d + (q - m));
-    r.val = 1.0;
-  }
-  return r;
-}
-
 // Parameter sources: how a kernel obtains the true value of P[off], P[off+1].
 struct PlainParams {  // SGD / predict: scale * stored
   const double* P;
@@ -142,26 +123,41 @@ struct AdaParams {
   }
 };
 
+// nnz q of the row that starts at q0 with m stored entries followed by n_aug dummy features
+// (index d+t, value 1.0; dataset.nim:182-189).  Past the end: (0, 0.0), which contributes nothing
+// to any sum below and points at a valid parameter row.
+__device__ __forceinline__ void row_entry(const CsrView& X, int64_t q0, int m, int m_tot, int q, int& j, double& x) {
+  j = 0;
+  x = 0.0;
+  if (q < m) {
+    j = X.indices[q0 + q];
+    x = X.data[q0 + q];
+  } else if (q < m_tot) {
+    j = (int)(X.d + (q - m));
+    x = 1.0;
+  }
+}
+
+constexpr int kUnroll = 4;  // independent parameter-row loads in flight per lane
+
 // ---- ANOVA forward, degree 2: the sum-of-squares trick (optimizer/sgd.nim:160-170,
-// kernels.nim:59-64).  Returns A1 = sum x p, A2 = sum (x p)^2 for this lane's factor pair,
-// reduced over the whole row (identical in every row slot).
-template <int L, class PS>
+// kernels.nim:59-64).  A1 = sum x p, A2 = sum (x p)^2 for this lane's factor pair over the whole
+// row (identical in all SPLIT slots of the sample on return).
+template <int L, int SPLIT, class PS>
 __device__ __forceinline__ void anova_fwd_deg2(const PS& ps, const CsrView& X, int64_t q0, int m, int m_tot,
-                                               size_t blk_off, int Kp, int lane, double2& A1, double2& A2) {
-  constexpr int R = kWave / L;
-  const int g = lane / L, l = lane % L;
+                                               size_t blk_off, int Kp, int slot, int l, double2& A1, double2& A2) {
   double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
-  for (int c = 0; c * kWave < m_tot; ++c) {
-    const RowChunk rc = load_chunk(X, q0, m, m_tot, c, lane);
-    const int len = min(kWave, m_tot - c * kWave);
-    const int iters = (len + R - 1) / R;
-#pragma unroll 4
-    for (int it = 0; it < iters; ++it) {
-      const int src = it * R + g;
-      const int j = __shfl(rc.idx, src, kWave);
-      const double x = shfl_d(rc.val, src);
-      const double2 p = ps.load(blk_off + (size_t)j * Kp + 2 * l);
-      const double tx = x * p.x, ty = x * p.y;
+  for (int q = slot; q < m_tot; q += kUnroll * SPLIT) {
+    int j[kUnroll];
+    double x[kUnroll];
+    double2 p[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) row_entry(X, q0, m, m_tot, q + u * SPLIT, j[u], x[u]);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) p[u] = ps.load(blk_off + (size_t)j[u] * Kp + 2 * l);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const double tx = x[u] * p[u].x, ty = x[u] * p[u].y;
       a1.x += tx;
       a1.y += ty;
       a2.x += tx * tx;
@@ -169,7 +165,7 @@ __device__ __forceinline__ void anova_fwd_deg2(const PS& ps, const CsrView& X, i
     }
   }
 #pragma unroll
-  for (int s = L; s < kWave; s <<= 1) {
+  for (int s = L; s < L * SPLIT; s <<= 1) {
     a1.x += shfl_xor_d(a1.x, s);
     a1.y += shfl_xor_d(a1.y, s);
     a2.x += shfl_xor_d(a2.x, s);
@@ -179,41 +175,36 @@ __device__ __forceinline__ void anova_fwd_deg2(const PS& ps, const CsrView& X, i
   A2 = a2;
 }
 
-// ---- ANOVA forward, degree >= 3: the DP of optimizer/sgd.nim:152-159 (kernels.nim:54-58),
-// A[t] += A[t-1] * p * x for t = DEG..1 per nnz.  A[t] is the t-th elementary symmetric
-// polynomial of {p_j x_j}; partial results over disjoint nnz subsets (the row slots) combine by
-// truncated polynomial multiplication.  E[0] = 1.
-template <int L, int DEG, class PS>
+// ---- ANOVA forward, degree 3..kMaxDeg: the DP of optimizer/sgd.nim:152-159 (kernels.nim:54-58),
+// A[t] += A[t-1] * p * x for t = deg..1 per nnz.  A[t] is the t-th elementary symmetric polynomial
+// of {p_j x_j}; partial results over the SPLIT slots' disjoint nnz subsets combine by truncated
+// polynomial multiplication.  E[0] = 1.  deg is a run-time value (guards on unrolled loops keep E
+// in registers).
+template <int L, int SPLIT, class PS>
 __device__ __forceinline__ void anova_fwd_degn(const PS& ps, const CsrView& X, int64_t q0, int m, int m_tot,
-                                               size_t blk_off, int Kp, int lane, double2 (&E)[DEG + 1]) {
-  constexpr int R = kWave / L;
-  const int g = lane / L, l = lane % L;
+                                               size_t blk_off, int Kp, int slot, int l, int lane, int deg,
+                                               double2 (&E)[kMaxDeg + 1]) {
 #pragma unroll
-  for (int t = 0; t <= DEG; ++t) E[t] = {0.0, 0.0};
+  for (int t = 0; t <= kMaxDeg; ++t) E[t] = {0.0, 0.0};
   E[0] = {1.0, 1.0};
-  for (int c = 0; c * kWave < m_tot; ++c) {
-    const RowChunk rc = load_chunk(X, q0, m, m_tot, c, lane);
-    const int len = min(kWave, m_tot - c * kWave);
-    const int iters = (len + R - 1) / R;
-#pragma unroll 2
-    for (int it = 0; it < iters; ++it) {
-      const int src = it * R + g;
-      const int j = __shfl(rc.idx, src, kWave);
-      const double x = shfl_d(rc.val, src);
-      const double2 p = ps.load(blk_off + (size_t)j * Kp + 2 * l);
+  for (int q = slot; q < m_tot; q += SPLIT) {
+    int j;
+    double x;
+    row_entry(X, q0, m, m_tot, q, j, x);
+    const double2 p = ps.load(blk_off + (size_t)j * Kp + 2 * l);
 #pragma unroll
-      for (int t = DEG; t >= 1; --t) {
+    for (int t = kMaxDeg; t >= 1; --t)
+      if (t <= deg) {
         E[t].x += E[t - 1].x * p.x * x;
         E[t].y += E[t - 1].y * p.y * x;
       }
-    }
   }
 #pragma unroll
-  for (int s = L; s < kWave; s <<= 1) {
-    double2 lo[DEG + 1], hi[DEG + 1];
+  for (int s = L; s < L * SPLIT; s <<= 1) {
+    double2 lo[kMaxDeg + 1], hi[kMaxDeg + 1];
     const bool upper = (lane & s) != 0;
 #pragma unroll
-    for (int t = 0; t <= DEG; ++t) {
+    for (int t = 0; t <= kMaxDeg; ++t) {
       double2 o;
       o.x = shfl_xor_d(E[t].x, s);
       o.y = shfl_xor_d(E[t].y, s);
@@ -221,35 +212,44 @@ __device__ __forceinline__ void anova_fwd_degn(const PS& ps, const CsrView& X, i
       hi[t] = upper ? E[t] : o;
     }
 #pragma unroll
-    for (int t = 1; t <= DEG; ++t) {
+    for (int t = 1; t <= kMaxDeg; ++t) {
       double2 acc = {0.0, 0.0};
 #pragma unroll
       for (int u = 0; u <= t; ++u) {
         acc.x += lo[u].x * hi[t - u].x;
         acc.y += lo[u].y * hi[t - u].y;
       }
-      E[t] = acc;
+      if (t <= deg) E[t] = acc;
     }
   }
 }
 
+// value of a compile-time-unrolled array at a run-time index
+__device__ __forceinline__ double2 pick(const double2 (&E)[kMaxDeg + 1], int t) {
+  double2 r = {0.0, 0.0};
+#pragma unroll
+  for (int u = 0; u <= kMaxDeg; ++u)
+    if (u == t) r = E[u];
+  return r;
+}
+
 // sum over this lane's factor pair, then over the L lanes of the row slot
 template <int L>
-__device__ __forceinline__ double sum_factors(double2 v) {
-  double r = v.x + v.y;
+__device__ __forceinline__ double sum_lanes(double r) {
 #pragma unroll
   for (int s = 1; s < L; s <<= 1) r += shfl_xor_d(r, s);
   return r;
 }
 
-// Derivative of the degree-DEG ANOVA kernel w.r.t. p_js (optimizer/sgd.nim:176-188):
-//   DEG == 2: x (A1 - p x);  DEG >= 3: dA = x; for t in 1..<DEG: dA = x (A[t] - p dA)
-template <int DEG>
-__device__ __forceinline__ double anova_grad(double x, double p, const double* A /*A[1..DEG-1] at A[0..]*/) {
-  if (DEG == 2) return x * (A[0] - p * x);
+// Derivative of the degree-deg ANOVA kernel w.r.t. p_js (optimizer/sgd.nim:176-188):
+//   deg == 2: x (A1 - p x);  deg >= 3: dA = x; for t in 1..<deg: dA = x (A[t] - p dA)
+// A holds A[1..deg-1] at A[0..deg-2].
+__device__ __forceinline__ double anova_grad(int deg, double x, double p, const double (&A)[kMaxDeg - 1]) {
+  if (deg == 2) return x * (A[0] - p * x);
   double dA = x;
 #pragma unroll
-  for (int t = 1; t < DEG; ++t) dA = x * (A[t - 1] - p * dA);
+  for (int t = 1; t < kMaxDeg; ++t)
+    if (t < deg) dA = x * (A[t - 1] - p * dA);
   return dA;
 }
 

@@ -4,19 +4,21 @@
 // adagrad_multi.nim:15-36,78-96) -- T threads racing on shared P/w/intercept/it -- with a
 // deterministic rule: all samples of a batch see the batch-start
 // parameters; their per-sample updates (the reference's expressions: sgd.nim:205-243,
-// fit_linear.nim:41-47; adagrad.nim:87-134) are summed per coordinate in sample order.
+// fit_linear.nim:41-47; adagrad.nim:87-134) are combined per coordinate in sample order
+// (SGD: averaged over the samples touching the coordinate; AdaGrad: summed into the state).
 //
-// Two kernels per batch, both HBM/L2-gather bound, no atomics:
-//   row phase     one wavefront per SAMPLE: gathers the row's parameter rows (16 B per lane,
-//                 coalesced segments of Kp*8 bytes), forms A = sum x p (and sum (x p)^2) per factor
-//                 with shuffles, yhat, loss, dL; writes the per-factor sums A[s] (Kp doubles) and a
-//                 32-byte record {dL, eta_P, eta_w} per sample.
+// Two kernels per batch, no atomics, every sum in a fixed order:
+//   row phase     L*SPLIT lanes per SAMPLE: gathers the row's parameter rows (16 B per lane,
+//                 coalesced segments of Kp*8 bytes), forms A = sum x p (and sum (x p)^2) per factor,
+//                 yhat, loss, dL; writes the per-factor sums A[s] (Kp doubles) and a 32-byte record
+//                 {dL, eta_P, eta_w} per sample.
 //   column phase  L lanes per UNIQUE FEATURE of the batch (plan.hip): reads the parameter row once,
 //                 walks the feature's touches (sample, x) in sample order, recomputes
 //                 dA = x (A[s] - p x) from the sample's A row (L2-resident), accumulates, writes the
 //                 row once.  Rows touched c times in a batch are read and written once, not c times.
-//   batch finish  one workgroup: fixed-order reduction of the per-block partial sums (loss, viol,
-//                 intercept gradient), intercept update.
+//                 Workgroup 0 also closes the batch: fixed-order reduction of the row phase's
+//                 per-block partial sums (loss, intercept gradient), intercept update, and the
+//                 previous batch's per-block viol partials.
 // L2 decay is carried by the global scales (common.h): the schedule kernel forms the per-batch
 // products of (1 - eta_t * reg) and the prefix kernel the scale at every batch boundary.
 #include "fm_device.h"
@@ -108,130 +110,122 @@ struct RowArgs {
   PartA* parts;          // [gridDim.x]
 };
 
-template <int L, class PS>
+// forward over all orders; returns this lane's share of sum_o sum_s kernel (non-zero in slot 0
+// only) and stores the A rows the column phase needs.
+template <int L, int SPLIT, class PS>
 __device__ __forceinline__ double row_forward(const PS& ps, const CsrView& X, const ModelView& M, int64_t q0, int m,
-                                              int m_tot, int lane, double* __restrict__ Arow) {
-  const int g = lane / L, l = lane % L;
-  double acc = 0.0;
-  int slot = 0;
+                                              int m_tot, int slot, int l, int lane, bool valid,
+                                              double* __restrict__ Arow) {
+  double part = 0.0;
+  int slot_a = 0;
   for (int o = 0; o < M.nb; ++o) {
     const size_t blk = (size_t)o * M.da * M.Kp;
     const int deg = M.degree - o;
     double2 ker;
-    switch (deg) {
-      case 2: {
-        double2 A1, A2;
-        dev::anova_fwd_deg2<L>(ps, X, q0, m, m_tot, blk, M.Kp, lane, A1, A2);
-        ker.x = (A1.x * A1.x - A2.x) / 2;
-        ker.y = (A1.y * A1.y - A2.y) / 2;
-        if (g == 0) *reinterpret_cast<double2*>(Arow + (size_t)slot * M.Kp + 2 * l) = A1;
-        slot += 1;
-        break;
+    if (deg == 2) {
+      double2 A1, A2;
+      dev::anova_fwd_deg2<L, SPLIT>(ps, X, q0, m, m_tot, blk, M.Kp, slot, l, A1, A2);
+      ker.x = (A1.x * A1.x - A2.x) / 2;
+      ker.y = (A1.y * A1.y - A2.y) / 2;
+      if (valid && slot == 0) *reinterpret_cast<double2*>(Arow + (size_t)slot_a * M.Kp + 2 * l) = A1;
+    } else {
+      double2 E[dev::kMaxDeg + 1];
+      dev::anova_fwd_degn<L, SPLIT>(ps, X, q0, m, m_tot, blk, M.Kp, slot, l, lane, deg, E);
+      ker = dev::pick(E, deg);
+      if (valid && slot == 0) {
+#pragma unroll
+        for (int t = 1; t < dev::kMaxDeg; ++t)
+          if (t < deg) *reinterpret_cast<double2*>(Arow + (size_t)(slot_a + t - 1) * M.Kp + 2 * l) = E[t];
       }
-#define NFM_DEG_CASE(DG)                                                                       \
-  case DG: {                                                                                   \
-    double2 E[DG + 1];                                                                         \
-    dev::anova_fwd_degn<L, DG>(ps, X, q0, m, m_tot, blk, M.Kp, lane, E);                       \
-    ker = E[DG];                                                                               \
-    if (g == 0) {                                                                              \
-      _Pragma("unroll") for (int t = 1; t < DG; ++t)                                           \
-          *reinterpret_cast<double2*>(Arow + (size_t)(slot + t - 1) * M.Kp + 2 * l) = E[t];    \
-    }                                                                                          \
-    slot += DG - 1;                                                                            \
-    break;                                                                                     \
-  }
-        NFM_DEG_CASE(3)
-        NFM_DEG_CASE(4)
-        NFM_DEG_CASE(5)
-        NFM_DEG_CASE(6)
-#undef NFM_DEG_CASE
-      default:
-        ker = {0.0, 0.0};
     }
-    acc += dev::sum_factors<L>(ker);
+    slot_a += deg - 1;
+    if (slot == 0) part += ker.x + ker.y;
   }
-  return acc;
+  return part;
 }
 
-template <int L, int OPT>
+template <int L, int SPLIT, int OPT>
 __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
+  constexpr int LPS = L * SPLIT, SPW = kWave / LPS;
   __shared__ double red[kWavesPerBlock][4];
   const CsrView& X = a.X;
   const ModelView& M = a.M;
   const OptView& O = a.O;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-  const int pib = blockIdx.x * kWavesPerBlock + wv;
-  double r_loss = 0.0, r_viol = 0.0, r_acc0 = 0.0, r_acc1 = 0.0;
-  if (pib < a.len) {
+  const int sidx = lane / LPS, slot = (lane / L) % SPLIT, l = lane % L;
+  const int pib = (blockIdx.x * kWavesPerBlock + wv) * SPW + sidx;
+  const bool valid = pib < a.len;
+  const bool leader = valid && slot == 0 && l == 0;
+  int64_t i = 0, q0 = 0;
+  int m = 0, m_tot = 0;
+  double y = 0.0;
+  if (valid) {
     const int64_t pos = a.p0 + pib;
-    const int64_t i = a.perm ? a.perm[pos] : a.begin + pos;
-    const int64_t q0 = X.indptr[i];
-    const int m = (int)(X.indptr[i + 1] - q0);
-    const int m_tot = m + M.n_aug;
-    const double y = dev::target_of(X.y[i], M.task);
-    double* Arow = a.Abuf + (size_t)pib * a.TA * M.Kp;
-    double yh, b0;
-    if (OPT == OPT_SGD) {
-      const double sP = a.scales[0], sw = a.scales[1];
-      b0 = M.sc[SC_INTERCEPT];
-      double lin = 0.0;
-      for (int c = 0; c * kWave < m; ++c) {
-        const int q = c * kWave + lane;
-        if (q < m) lin += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
-      }
-      lin = dev::wave_sum(lin);
-      const dev::PlainParams ps{M.P, sP};
-      yh = b0 + lin + row_forward<L>(ps, X, M, q0, m, m_tot, lane, Arow);
-    } else {
-      const double itp = a.it_b - 1.0;
-      const bool stored = a.use_stored != 0;
-      b0 = M.sc[SC_INTERCEPT];
-      if (!stored && M.fit_intercept) b0 = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * itp * O.alpha0);
-      const double denw = itp * O.eta0 * O.alpha;
-      double lin = 0.0;
-      for (int c = 0; c * kWave < m; ++c) {
-        const int q = c * kWave + lane;
-        if (q < m) {
-          const int j = X.indices[q0 + q];
-          double wj = M.w[j];
-          if (!stored && M.fit_linear) wj = -O.eta0 * O.Gw[j] / (denw + sqrt(O.Nw[j]));
-          lin += wj * X.data[q0 + q];
-        }
-      }
-      lin = dev::wave_sum(lin);
-      double acc;
-      if (stored) {
-        const dev::PlainParams ps{M.P, 1.0};
-        acc = row_forward<L>(ps, X, M, q0, m, m_tot, lane, Arow);
-      } else {
-        const dev::AdaParams ps{O.G, O.N, O.eta0, O.eta0 * itp * O.beta};
-        acc = row_forward<L>(ps, X, M, q0, m, m_tot, lane, Arow);
-      }
-      yh = b0 + lin + acc;
+    i = a.perm ? a.perm[pos] : a.begin + pos;
+    q0 = X.indptr[i];
+    m = (int)(X.indptr[i + 1] - q0);
+    m_tot = m + M.n_aug;
+    y = dev::target_of(X.y[i], M.task);
+  }
+  double* Arow = a.Abuf + (size_t)(valid ? pib : 0) * a.TA * M.Kp;
+  double b0 = M.sc[SC_INTERCEPT];
+  double part = 0.0;
+  if (OPT == OPT_SGD) {
+    const double sP = a.scales[0], sw = a.scales[1];
+    for (int q = slot * L + l; q < m; q += LPS) part += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
+    const dev::PlainParams ps{M.P, sP};
+    part += row_forward<L, SPLIT>(ps, X, M, q0, m, m_tot, slot, l, lane, valid, Arow);
+  } else {
+    const double itp = a.it_b - 1.0;
+    const bool stored = a.use_stored != 0;
+    if (!stored && M.fit_intercept) b0 = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * itp * O.alpha0);
+    const double denw = itp * O.eta0 * O.alpha;
+    for (int q = slot * L + l; q < m; q += LPS) {
+      const int j = X.indices[q0 + q];
+      double wj = M.w[j];
+      if (!stored && M.fit_linear) wj = -O.eta0 * O.Gw[j] / (denw + sqrt(O.Nw[j]));
+      part += wj * X.data[q0 + q];
     }
-    const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
+    if (stored) {
+      const dev::PlainParams ps{M.P, 1.0};
+      part += row_forward<L, SPLIT>(ps, X, M, q0, m, m_tot, slot, l, lane, valid, Arow);
+    } else {
+      const dev::AdaParams ps{O.G, O.N, O.eta0, O.eta0 * itp * O.beta};
+      part += row_forward<L, SPLIT>(ps, X, M, q0, m, m_tot, slot, l, lane, valid, Arow);
+    }
+  }
+#pragma unroll
+  for (int s = 1; s < LPS; s <<= 1) part += dev::shfl_xor_d(part, s);
+  const double yh = b0 + part;
+  const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
+  double r_loss = 0.0, r_acc0 = 0.0, r_acc1 = 0.0;
+  if (leader) {
     r_loss = dev::loss_value(O.loss, O.loss_param, y, yh);
     if (OPT == OPT_SGD) {
       const double it = a.it_b + (double)pib;
       const double etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
       const double etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
-      if (lane == 0) a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
+      a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
       if (M.fit_intercept) {
         const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
         r_acc0 = eta0 * dL;
         r_acc1 = eta0;
       }
     } else {
-      if (lane == 0) a.rec[pib] = SampleRec{dL, 0.0, 0.0, 0.0};
+      a.rec[pib] = SampleRec{dL, 0.0, 0.0, 0.0};
       if (M.fit_intercept) {
         r_acc0 = dL;
         r_acc1 = dL * dL;
       }
     }
   }
+  // per-wave then per-block sums in a fixed order (lanes that are not sample leaders hold zeros)
+  r_loss = dev::wave_sum(r_loss);
+  r_acc0 = dev::wave_sum(r_acc0);
+  r_acc1 = dev::wave_sum(r_acc1);
   if (lane == 0) {
     red[wv][0] = r_loss;
-    red[wv][1] = r_viol;
+    red[wv][1] = 0.0;
     red[wv][2] = r_acc0;
     red[wv][3] = r_acc1;
   }
@@ -249,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// column phase
+// column phase (+ batch close in workgroup 0)
 // ------------------------------------------------------------------------------------------------
 struct ColArgs {
   ModelView M;
@@ -265,15 +259,25 @@ struct ColArgs {
   const double* Ftab_b;    // SGD: [2][kFtab] decay corrections by touch count
   const double* Abuf;
   const SampleRec* rec;
-  double* parts;  // [gridDim.x]
-  double it_b;
-  int32_t TA, use_stored;
+  double* parts;            // this batch's per-block viol partials [gridDim.x]
+  const PartA* partsA;      // row phase partials of this batch [nA]
+  const double* parts_prev; // previous batch's per-block viol partials [n_prev]
+  double* out_acc;          // {loss_sum, viol_sum}
+  double it_b, len;
+  int32_t TA, use_stored, nA, n_prev;
 };
 
-// one parameter block (order) of one unique feature: this lane's factor pair at element e
-template <int DEG, int OPT>
-__device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int slot, int l, int64_t t0, int64_t t1, double sP,
-                                            double sPn, double fP) {
+struct WAcc {  // linear-term accumulators of one feature
+  double a0 = 0.0, a1 = 0.0;
+};
+
+constexpr int kTouchUnroll = 4;
+
+// one parameter block (order) of one unique feature: this lane's factor pair at element e.
+// do_w: also accumulate the linear term's sums over the same touches.
+template <int OPT>
+__device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg, int slot, int l, int64_t t0, int64_t t1,
+                                            double sP, double sPn, double fP, bool do_w, WAcc& wacc) {
   const ModelView& M = a.M;
   const OptView& O = a.O;
   double viol = 0.0;
@@ -300,30 +304,92 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int slot
   }
   double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
   double seta = 0.0;
-  for (int64_t t = t0; t < t1; ++t) {
-    const int pib = a.tpos[t];
-    const double x = a.tx[t];
-    const SampleRec r = a.rec[pib];
-    const double* Ar = a.Abuf + ((size_t)pib * a.TA + slot) * M.Kp + 2 * l;
-    double Ax[DEG - 1], Ay[DEG - 1];
+  if (deg == 2) {
+    // touches in groups of kTouchUnroll: all loads of a group are issued before the first use;
+    // the accumulation itself stays in touch (= sample) order
+    for (int64_t t = t0; t < t1; t += kTouchUnroll) {
+      int pib[kTouchUnroll];
+      double x[kTouchUnroll];
+      SampleRec r[kTouchUnroll];
+      double2 A1[kTouchUnroll];
 #pragma unroll
-    for (int tt = 0; tt < DEG - 1; ++tt) {
-      const double2 v = *reinterpret_cast<const double2*>(Ar + (size_t)tt * M.Kp);
-      Ax[tt] = v.x;
-      Ay[tt] = v.y;
+      for (int u = 0; u < kTouchUnroll; ++u) {
+        const bool ok = t + u < t1;
+        pib[u] = ok ? a.tpos[t + u] : 0;
+        x[u] = ok ? a.tx[t + u] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kTouchUnroll; ++u) {
+        r[u] = a.rec[pib[u]];
+        A1[u] = *reinterpret_cast<const double2*>(a.Abuf + ((size_t)pib[u] * a.TA + slot) * M.Kp + 2 * l);
+      }
+#pragma unroll
+      for (int u = 0; u < kTouchUnroll; ++u) {
+        if (t + u < t1) {
+          const double dAx = x[u] * (A1[u].x - p.x * x[u]);
+          const double dAy = x[u] * (A1[u].y - p.y * x[u]);
+          if (OPT == OPT_SGD) {  // sgd.nim:220-222, averaged per coordinate below
+            acc.x += r[u].etaP * (r[u].dL * dAx);
+            acc.y += r[u].etaP * (r[u].dL * dAy);
+            seta += r[u].etaP;
+            if (do_w) {
+              wacc.a0 += r[u].etaw * (r[u].dL * x[u]);
+              wacc.a1 += r[u].etaw;
+            }
+          } else {  // adagrad.nim:122-124
+            const double gx = r[u].dL * dAx, gy = r[u].dL * dAy;
+            acc.x += gx;
+            acc.y += gy;
+            accn.x += gx * gx;
+            accn.y += gy * gy;
+            if (do_w) {
+              const double gw = r[u].dL * x[u];
+              wacc.a0 += gw;
+              wacc.a1 += gw * gw;
+            }
+          }
+        }
+      }
     }
-    const double dAx = dev::anova_grad<DEG>(x, p.x, Ax);
-    const double dAy = dev::anova_grad<DEG>(x, p.y, Ay);
-    if (OPT == OPT_SGD) {  // sgd.nim:220-222, averaged per coordinate below
-      acc.x += r.etaP * (r.dL * dAx);
-      acc.y += r.etaP * (r.dL * dAy);
-      seta += r.etaP;
-    } else {  // adagrad.nim:122-124
-      const double gx = r.dL * dAx, gy = r.dL * dAy;
-      acc.x += gx;
-      acc.y += gy;
-      accn.x += gx * gx;
-      accn.y += gy * gy;
+  } else {
+    for (int64_t t = t0; t < t1; ++t) {
+      const int pib = a.tpos[t];
+      const double x = a.tx[t];
+      const SampleRec r = a.rec[pib];
+      const double* Ar = a.Abuf + ((size_t)pib * a.TA + slot) * M.Kp + 2 * l;
+      double Ax[dev::kMaxDeg - 1], Ay[dev::kMaxDeg - 1];
+#pragma unroll
+      for (int tt = 0; tt < dev::kMaxDeg - 1; ++tt) {
+        Ax[tt] = 0.0;
+        Ay[tt] = 0.0;
+        if (tt < deg - 1) {
+          const double2 v = *reinterpret_cast<const double2*>(Ar + (size_t)tt * M.Kp);
+          Ax[tt] = v.x;
+          Ay[tt] = v.y;
+        }
+      }
+      const double dAx = dev::anova_grad(deg, x, p.x, Ax);
+      const double dAy = dev::anova_grad(deg, x, p.y, Ay);
+      if (OPT == OPT_SGD) {
+        acc.x += r.etaP * (r.dL * dAx);
+        acc.y += r.etaP * (r.dL * dAy);
+        seta += r.etaP;
+        if (do_w) {
+          wacc.a0 += r.etaw * (r.dL * x);
+          wacc.a1 += r.etaw;
+        }
+      } else {
+        const double gx = r.dL * dAx, gy = r.dL * dAy;
+        acc.x += gx;
+        acc.y += gy;
+        accn.x += gx * gx;
+        accn.y += gy * gy;
+        if (do_w) {
+          const double gw = r.dL * x;
+          wacc.a0 += gw;
+          wacc.a1 += gw * gw;
+        }
+      }
     }
   }
   if (OPT == OPT_SGD) {
@@ -346,7 +412,7 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int slot
 template <int L, int OPT>
 __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
   constexpr int R = kWave / L;
-  __shared__ double red[kWavesPerBlock];
+  __shared__ double red[5][kBlock];
   const ModelView& M = a.M;
   const OptView& O = a.O;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
@@ -373,79 +439,63 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
         }
       }
     }
+    const bool has_w = M.fit_linear && j < M.d;  // dummy features have no w
+    WAcc wacc;
     int slot = 0;
     for (int o = 0; o < M.nb; ++o) {
       const size_t e = ((size_t)o * M.da + j) * M.Kp + 2 * l;
       const int deg = M.degree - o;
-      switch (deg) {
-        case 2: viol += col_block<2, OPT>(a, e, slot, l, t0, t1, sP, sPn, fP); break;
-        case 3: viol += col_block<3, OPT>(a, e, slot, l, t0, t1, sP, sPn, fP); break;
-        case 4: viol += col_block<4, OPT>(a, e, slot, l, t0, t1, sP, sPn, fP); break;
-        case 5: viol += col_block<5, OPT>(a, e, slot, l, t0, t1, sP, sPn, fP); break;
-        case 6: viol += col_block<6, OPT>(a, e, slot, l, t0, t1, sP, sPn, fP); break;
-        default: break;
-      }
+      viol += col_block<OPT>(a, e, deg, slot, l, t0, t1, sP, sPn, fP, has_w && o == 0, wacc);
       slot += deg - 1;
     }
-    // linear term (fit_linear.nim:41-57); dummy features have no w
-    if (M.fit_linear && j < M.d && l == 0) {
-      if (OPT == OPT_SGD) {
-        const double wt = M.w[j];
-        const double wj = sw * wt;
-        double accw = 0.0, setaw = 0.0;
+    if (has_w) {
+      if (M.nb == 0) {  // degree-1 model: no parameter block walked the touches
         for (int64_t t = t0; t < t1; ++t) {
           const SampleRec r = a.rec[a.tpos[t]];
-          accw += r.etaw * (r.dL * a.tx[t]);
-          setaw += r.etaw;
+          const double x = a.tx[t];
+          if (OPT == OPT_SGD) {
+            wacc.a0 += r.etaw * (r.dL * x);
+            wacc.a1 += r.etaw;
+          } else {
+            wacc.a0 += r.dL * x;
+            wacc.a1 += (r.dL * x) * (r.dL * x);
+          }
         }
+      }
+      // linear term (fit_linear.nim:41-57); every lane of the feature holds the same sums
+      const double wt = M.w[j];
+      if (OPT == OPT_SGD) {
+        const double wj = sw * wt;
         const double c = (double)(t1 - t0);
-        viol += fabs((accw + setaw * O.alpha * wj) / c);
-        M.w[j] = wt * fw - (accw / c) / swn;
+        if (l == 0) {
+          viol += fabs((wacc.a0 + wacc.a1 * O.alpha * wj) / c);
+          M.w[j] = wt * fw - (wacc.a0 / c) / swn;
+        }
       } else {
-        const double wt = M.w[j];
-        double gw = O.Gw[j], nw = O.Nw[j];
-        if (!a.use_stored) {
-          const double wj = -O.eta0 * gw / ((a.it_b - 1.0) * O.eta0 * O.alpha + sqrt(nw));
-          viol += fabs(wt - wj);
-          M.w[j] = wj;
+        const double gw = O.Gw[j], nw = O.Nw[j];
+        if (l == 0) {
+          if (!a.use_stored) {
+            const double wj = -O.eta0 * gw / ((a.it_b - 1.0) * O.eta0 * O.alpha + sqrt(nw));
+            viol += fabs(wt - wj);
+            M.w[j] = wj;
+          }
+          O.Gw[j] = gw + wacc.a0;
+          O.Nw[j] = nw + wacc.a1;
         }
-        double ag = 0.0, an = 0.0;
-        for (int64_t t = t0; t < t1; ++t) {
-          const double gx = a.rec[a.tpos[t]].dL * a.tx[t];
-          ag += gx;
-          an += gx * gx;
-        }
-        O.Gw[j] = gw + ag;
-        O.Nw[j] = nw + an;
       }
     }
   }
   viol = dev::wave_sum(viol);
-  if (lane == 0) red[wv] = viol;
+  if (lane == 0) red[0][wv] = viol;
   __syncthreads();
   if (threadIdx.x == 0) {
     double v = 0.0;
-    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) v += red[w_];
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) v += red[0][w_];
     a.parts[blockIdx.x] = v;
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// batch finish
-// ------------------------------------------------------------------------------------------------
-struct FinArgs {
-  ModelView M;
-  OptView O;
-  const PartA* partsA;
-  const double* partsB;
-  const double* Dtab_b;  // SGD: {D_P, D_w, D_0}
-  double* out_acc;       // {loss_sum, viol_sum}
-  double it_b, len;
-  int32_t nA, nB, use_stored, opt;
-};
-
-__global__ __launch_bounds__(kBlock) void k_batch_finish(FinArgs a) {
-  __shared__ double red[5][kBlock];
+  if (blockIdx.x != 0) return;
+  // ---- workgroup 0 closes the batch: fixed-order reductions, intercept update ----
+  __syncthreads();
   double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < a.nA; i += kBlock) {
     const PartA p = a.partsA[i];
@@ -454,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_finish(FinArgs a) {
     s[2] += p.acc0;
     s[3] += p.acc1;
   }
-  for (int i = threadIdx.x; i < a.nB; i += kBlock) s[4] += a.partsB[i];
+  for (int i = threadIdx.x; i < a.n_prev; i += kBlock) s[4] += a.parts_prev[i];
   for (int c = 0; c < 5; ++c) red[c][threadIdx.x] = s[c];
   __syncthreads();
   for (int st = kBlock / 2; st > 0; st >>= 1) {
@@ -463,20 +513,18 @@ __global__ __launch_bounds__(kBlock) void k_batch_finish(FinArgs a) {
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    double viol = red[1][0] + red[4][0];
-    const ModelView& M = a.M;
-    const OptView& O = a.O;
+    double v = red[1][0] + red[4][0];
     if (M.fit_intercept) {
-      if (a.opt == OPT_SGD) {  // the intercept is touched by every sample of the batch: c = len
+      if (OPT == OPT_SGD) {  // the intercept is touched by every sample of the batch: c = len
         const double b0 = M.sc[SC_INTERCEPT], D0 = a.Dtab_b[2];
         const double f0 = a.len == 1.0 ? D0 : pow(D0, 1.0 / a.len);
-        viol += fabs((red[2][0] + red[3][0] * O.alpha0 * b0) / a.len);
+        v += fabs((red[2][0] + red[3][0] * O.alpha0 * b0) / a.len);
         M.sc[SC_INTERCEPT] = f0 * b0 - red[2][0] / a.len;
       } else {
         if (!a.use_stored) {  // adagrad.nim:102-106
           const double old = M.sc[SC_INTERCEPT];
           const double nb_ = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * (a.it_b - 1.0) * O.alpha0);
-          viol += fabs(old - nb_);
+          v += fabs(old - nb_);
           M.sc[SC_INTERCEPT] = nb_;
         }
         O.gsc[0] += red[2][0];
@@ -484,13 +532,35 @@ __global__ __launch_bounds__(kBlock) void k_batch_finish(FinArgs a) {
       }
     }
     a.out_acc[0] += red[0][0];
-    a.out_acc[1] += viol;
+    a.out_acc[1] += v;
   }
+}
+
+// adds the last batch's per-block viol partials (every other batch's are folded in by the next
+// batch's workgroup 0)
+__global__ __launch_bounds__(kBlock) void k_epoch_close(const double* __restrict__ parts, int n, double* __restrict__ out_acc) {
+  __shared__ double red[kBlock];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += kBlock) s += parts[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = kBlock / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_acc[1] += red[0];
 }
 
 // ------------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------------
+template <int L, int SPLIT, int OPT>
+static void launch_row(hipStream_t st, const RowArgs& ra) {
+  constexpr int SPW = kWave / (L * SPLIT);
+  const int nA = (ra.len + kWavesPerBlock * SPW - 1) / (kWavesPerBlock * SPW);
+  hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT>), dim3(nA), dim3(kBlock), 0, st, ra);
+}
+
 template <int L, int OPT>
 static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
                        int64_t it0, int TA) {
@@ -498,36 +568,50 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
   hipStream_t st = ctx->stream;
   const double* Stab = W.Stab.as<double>();
   const double* Dtab = W.Dtab.as<double>();
+  const double avg_row = X.n > 0 ? (double)X.nnz / (double)X.n + M.n_aug : 0.0;
+  const size_t partsB_half = W.partsB.bytes / sizeof(double) / 2;
+  int n_prev = 0;
   for (int64_t b = 0; b < P.n_batches; ++b) {
     const int64_t p0 = P.bat_pos[b];
     const int len = (int)(P.bat_pos[b + 1] - p0);
     const int use_stored = (OPT == OPT_ADAGRAD && P.first_singleton && b == 0) ? 1 : 0;
     const double it_b = (double)(it0 + p0);
-    const int nA = (len + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int split = choose_split(L, len, avg_row, ctx->n_cu);
+    int nA;
     {
       RowArgs ra{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, P.begin, p0, len, use_stored, TA, 0, it_b,
                  OPT == OPT_SGD ? Stab + 2 * b : M.sc, W.Abuf.as<double>(), W.rec.as<SampleRec>(), W.partsA.as<PartA>()};
       TimedLaunch tl(ctx, "row_phase");
-      hipLaunchKernelGGL((k_row_phase<L, OPT>), dim3(nA), dim3(kBlock), 0, st, ra);
+      int s_used;
+      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT>(st, ra); s_used = R >= 16 ? 16 : R; }
+      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT>(st, ra); s_used = R >= 8 ? 8 : R; }
+      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT>(st, ra); s_used = R >= 4 ? 4 : R; }
+      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT>(st, ra); s_used = R >= 2 ? 2 : R; }
+      else { launch_row<L, 1, OPT>(st, ra); s_used = 1; }
+      const int spw = kWave / (L * s_used);
+      nA = (len + kWavesPerBlock * spw - 1) / (kWavesPerBlock * spw);
     }
     const int64_t u0 = P.bat_uoff[b], u1 = P.bat_uoff[b + 1];
     const int per_block = kWavesPerBlock * R;
     int nB = (int)((u1 - u0 + per_block - 1) / per_block);
-    if (nB > 0) {
+    if (nB < 1) nB = 1;  // workgroup 0 closes the batch even when no feature was touched
+    double* parts_cur = W.partsB.as<double>() + (b & 1) * partsB_half;
+    const double* parts_prev = W.partsB.as<double>() + ((b + 1) & 1) * partsB_half;
+    {
       ColArgs ca{M, O, P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(), u0, u1,
                  OPT == OPT_SGD ? Stab + 2 * b : M.sc, OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc,
                  OPT == OPT_SGD ? Dtab + 4 * b : nullptr,
                  OPT == OPT_SGD ? W.Ftab.as<double>() + (size_t)b * 2 * kFtab : nullptr, W.Abuf.as<double>(),
-                 W.rec.as<SampleRec>(), W.partsB.as<double>(), it_b, TA, use_stored};
+                 W.rec.as<SampleRec>(), parts_cur, W.partsA.as<PartA>(), parts_prev, W.out_acc.as<double>(), it_b,
+                 (double)len, TA, use_stored, nA, n_prev};
       TimedLaunch tl(ctx, "col_phase");
       hipLaunchKernelGGL((k_col_phase<L, OPT>), dim3(nB), dim3(kBlock), 0, st, ca);
     }
-    {
-      FinArgs fa{M, O, W.partsA.as<PartA>(), W.partsB.as<double>(), OPT == OPT_SGD ? Dtab + 4 * b : nullptr,
-                 W.out_acc.as<double>(), it_b, (double)len, nA, nB, use_stored, OPT};
-      TimedLaunch tl(ctx, "batch_finish");
-      hipLaunchKernelGGL(k_batch_finish, dim3(1), dim3(kBlock), 0, st, fa);
-    }
+    n_prev = nB;
+  }
+  if (P.n_batches > 0) {
+    const double* parts_last = W.partsB.as<double>() + ((P.n_batches - 1) & 1) * partsB_half;
+    hipLaunchKernelGGL(k_epoch_close, dim3(1), dim3(kBlock), 0, st, parts_last, n_prev, W.out_acc.as<double>());
   }
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
@@ -543,8 +627,8 @@ static int run_batches_L(nfm_ctx* ctx, int opt_kind, const CsrView& X, const Mod
 int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
                 int64_t it0, double* out2_host) {
   NFM_CHECK(M.kind == NFM_KIND_FM, NFM_ERR_UNSUPPORTED, "mb_fm_epoch: FM only");
-  NFM_CHECK(M.degree <= 6, NFM_ERR_UNSUPPORTED, "mini-batch mode supports degree <= 6");
-  NFM_CHECK(M.Kp <= 128, NFM_ERR_UNSUPPORTED, "mini-batch mode supports n_components <= 128");
+  NFM_CHECK(M.degree <= dev::kMaxDeg, NFM_ERR_UNSUPPORTED, "mini-batch mode supports degree <= %d", dev::kMaxDeg);
+  NFM_CHECK(M.Kp == 2 * M.L && M.Kp <= 128, NFM_ERR_UNSUPPORTED, "mini-batch mode supports n_components <= 128");
   hipStream_t st = ctx->stream;
   int TA = 0;
   for (int o = 0; o < M.nb; ++o) TA += M.degree - o - 1;
@@ -552,7 +636,7 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   NFM_TRY(W.Abuf.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_batch, 1) * std::max(TA, 1) * M.Kp));
   NFM_TRY(W.rec.ensure(sizeof(SampleRec) * (size_t)std::max<int64_t>(P.max_batch, 1)));
   NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch / kWavesPerBlock + 1)));
-  NFM_TRY(W.partsB.ensure(sizeof(double) * (size_t)(P.max_unique / kMinGroupsPerBlock + 1)));
+  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique / kMinGroupsPerBlock + 2)));
   NFM_TRY(W.Dtab.ensure(sizeof(double) * 4 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Stab.ensure(sizeof(double) * 2 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Ftab.ensure(sizeof(double) * 2 * kFtab * (size_t)(P.n_batches + 1)));

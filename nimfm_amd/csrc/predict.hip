@@ -3,73 +3,59 @@
 // Replaces model/factorization_machine.nim:100-122 (-> kernels.nim:14-19 `linear`, :46-64
 // `anova`) and model/field_aware_factorization_machine.nim:52-76.  The reference makes nOrders*k
 // full passes over the CSR matrix, one per latent factor, gathering P[s][j] from k separate heap
-// rows; here one wavefront owns one sample, reads each parameter row once (coalesced, 16 B per
-// lane) from the [j][s] layout and finishes the per-factor sums with shuffles.
+// rows; here L*SPLIT lanes own one sample (fm_device.h), read each parameter row once (coalesced,
+// 16 B per lane) from the [j][s] layout and finish the per-factor sums with shuffles.
 // Bound: HBM/L2 gather of P rows; algorithmic bytes per sample 12m + 8 + O*8*m*k + 8m + 8
 // (SURVEY.md 8d).
 #include "fm_device.h"
 
 namespace nfm {
 
-template <int L>
+template <int L, int SPLIT>
 __global__ __launch_bounds__(kBlock) void k_fm_predict(CsrView X, ModelView M, double* __restrict__ out) {
+  constexpr int LPS = L * SPLIT, SPW = kWave / LPS;
   const int lane = threadIdx.x & (kWave - 1);
+  const int sidx = lane / LPS, slot = (lane / L) % SPLIT, l = lane % L;
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   const double sw = M.sc[SC_SCALE_W], b = M.sc[SC_INTERCEPT];
   const dev::PlainParams ps{M.P, M.sc[SC_SCALE_P]};
-  const int l = lane % L;
   const double lam0 = M.lams[2 * l], lam1 = M.lams[2 * l + 1];
-  for (int64_t i = wave0; i < X.n; i += nwaves) {
-    const int64_t q0 = X.indptr[i];
-    const int m = (int)(X.indptr[i + 1] - q0);
-    const int m_tot = m + M.n_aug;
-    // linear term, one nnz per lane (kernels.nim:14-19; dummies excluded)
-    double lin = 0.0;
-    for (int c = 0; c * kWave < m; ++c) {
-      const int q = c * kWave + lane;
-      if (q < m) lin += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
-    }
-    lin = dev::wave_sum(lin);
-    double acc = 0.0;
+  for (int64_t i0 = wave0 * SPW; i0 < X.n; i0 += nwaves * SPW) {
+    const int64_t i = i0 + sidx;
+    const bool valid = i < X.n;
+    const int64_t q0 = valid ? X.indptr[i] : 0;
+    const int m = valid ? (int)(X.indptr[i + 1] - q0) : 0;
+    const int m_tot = valid ? m + M.n_aug : 0;
+    // linear term (kernels.nim:14-19; dummies excluded): nnz dealt round-robin to the sample's lanes
+    double part = 0.0;
+    for (int q = slot * L + l; q < m; q += LPS) part += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
     for (int o = 0; o < M.nb; ++o) {
       const size_t blk = (size_t)o * M.da * M.Kp;
       const int deg = M.degree - o;
       double2 ker;
-      switch (deg) {
-        case 2: {
-          double2 A1, A2;
-          dev::anova_fwd_deg2<L>(ps, X, q0, m, m_tot, blk, M.Kp, lane, A1, A2);
-          ker.x = (A1.x * A1.x - A2.x) / 2.0;
-          ker.y = (A1.y * A1.y - A2.y) / 2.0;
-          break;
-        }
-#define NFM_DEG_CASE(DG)                                                   \
-  case DG: {                                                               \
-    double2 E[DG + 1];                                                     \
-    dev::anova_fwd_degn<L, DG>(ps, X, q0, m, m_tot, blk, M.Kp, lane, E);   \
-    ker = E[DG];                                                           \
-    break;                                                                 \
-  }
-          NFM_DEG_CASE(3)
-          NFM_DEG_CASE(4)
-          NFM_DEG_CASE(5)
-          NFM_DEG_CASE(6)
-#undef NFM_DEG_CASE
-        default:
-          ker = {0.0, 0.0};
+      if (deg == 2) {
+        double2 A1, A2;
+        dev::anova_fwd_deg2<L, SPLIT>(ps, X, q0, m, m_tot, blk, M.Kp, slot, l, A1, A2);
+        ker.x = (A1.x * A1.x - A2.x) / 2.0;
+        ker.y = (A1.y * A1.y - A2.y) / 2.0;
+      } else {
+        double2 E[dev::kMaxDeg + 1];
+        dev::anova_fwd_degn<L, SPLIT>(ps, X, q0, m, m_tot, blk, M.Kp, slot, l, lane, deg, E);
+        ker = dev::pick(E, deg);
       }
-      ker.x *= lam0;
-      ker.y *= lam1;
-      acc += dev::sum_factors<L>(ker);
+      if (slot == 0) part += ker.x * lam0 + ker.y * lam1;  // every slot holds the same totals
     }
-    if (lane == 0) out[i] = b + lin + acc;
+    // sum over the sample's L*SPLIT lanes
+#pragma unroll
+    for (int s = 1; s < LPS; s <<= 1) part += dev::shfl_xor_d(part, s);
+    if (valid && slot == 0 && l == 0) out[i] = b + part;
   }
 }
 
 // FFM: yhat = b + sum w x + sum_{j1<j2} x1 x2 <P[f2][j1], P[f1][j2]>
-// (model/field_aware_factorization_machine.nim:66-76).  The m*m ordered pairs of the row are
-// dealt to the R = 64/L row slots; a slot's L lanes form the dot product over the factors.
+// (model/field_aware_factorization_machine.nim:66-76).  One wavefront per sample: the m*m ordered
+// pairs of the row are dealt to the R = 64/L row slots; a slot's L lanes form the dot product.
 template <int L>
 __global__ __launch_bounds__(kBlock) void k_ffm_predict(CsrView X, ModelView M, double* __restrict__ out) {
   constexpr int R = kWave / L;
@@ -107,23 +93,42 @@ __global__ __launch_bounds__(kBlock) void k_ffm_predict(CsrView X, ModelView M, 
   }
 }
 
-template <int L>
-static int launch_predict_L(nfm_ctx* ctx, const CsrView& X, const ModelView& M, double* out) {
-  if (X.n == 0) return NFM_OK;
-  int64_t blocks = (X.n + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int64_t cap = (int64_t)ctx->n_cu * 8 * 4;  // grid-stride beyond ~32 waves per CU x 4
+template <int L, int SPLIT>
+static int launch_fm_predict(nfm_ctx* ctx, const CsrView& X, const ModelView& M, double* out) {
+  constexpr int SPW = kWave / (L * SPLIT);
+  int64_t blocks = (X.n + (int64_t)kWavesPerBlock * SPW - 1) / ((int64_t)kWavesPerBlock * SPW);
+  const int64_t cap = (int64_t)ctx->n_cu * 32;
   if (blocks > cap) blocks = cap;
   TimedLaunch tl(ctx, "predict");
-  if (M.kind == NFM_KIND_FFM)
-    hipLaunchKernelGGL(k_ffm_predict<L>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, X, M, out);
-  else
-    hipLaunchKernelGGL(k_fm_predict<L>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, X, M, out);
+  hipLaunchKernelGGL((k_fm_predict<L, SPLIT>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, X, M, out);
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }
 
+template <int L>
+static int launch_predict_L(nfm_ctx* ctx, const CsrView& X, const ModelView& M, double* out) {
+  if (X.n == 0) return NFM_OK;
+  if (M.kind == NFM_KIND_FFM) {
+    int64_t blocks = (X.n + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t cap = (int64_t)ctx->n_cu * 32;
+    if (blocks > cap) blocks = cap;
+    TimedLaunch tl(ctx, "predict");
+    hipLaunchKernelGGL(k_ffm_predict<L>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, X, M, out);
+    NFM_HIP_CHECK(hipGetLastError());
+    return NFM_OK;
+  }
+  constexpr int R = kWave / L;
+  const int split = choose_split(L, X.n, X.n > 0 ? (double)X.nnz / (double)X.n + M.n_aug : 0.0, ctx->n_cu);
+  if (R >= 16 && split >= 16) return launch_fm_predict<L, (R >= 16 ? 16 : R)>(ctx, X, M, out);
+  if (R >= 8 && split >= 8) return launch_fm_predict<L, (R >= 8 ? 8 : R)>(ctx, X, M, out);
+  if (R >= 4 && split >= 4) return launch_fm_predict<L, (R >= 4 ? 4 : R)>(ctx, X, M, out);
+  if (R >= 2 && split >= 2) return launch_fm_predict<L, (R >= 2 ? 2 : R)>(ctx, X, M, out);
+  return launch_fm_predict<L, 1>(ctx, X, M, out);
+}
+
 int launch_predict(nfm_ctx* ctx, const CsrView& X, const ModelView& M, double* out) {
   NFM_CHECK(M.Kp == 2 * M.L, NFM_ERR_UNSUPPORTED, "n_components > 128 is not supported by the wave-per-sample kernels");
+  NFM_CHECK(M.kind == NFM_KIND_FFM || M.degree <= dev::kMaxDeg, NFM_ERR_UNSUPPORTED, "degree > %d unsupported", dev::kMaxDeg);
   switch (M.L) {
     case 1: return launch_predict_L<1>(ctx, X, M, out);
     case 2: return launch_predict_L<2>(ctx, X, M, out);
