@@ -16,6 +16,14 @@ struct MbWork {
   DevBuf Ftab;     // per-batch decay corrections by touch count [2][64]
   DevBuf out_acc;  // {loss_sum, viol_sum} of the epoch call
   DevBuf contrib;  // FFM: per-touch gradient rows
+  DevBuf itbuf;    // device scalar: `it` at the start of the epoch call
+  // hipGraph of one epoch call over a reusable plan
+  bool use_graph = true;
+  void* graph_exec = nullptr;
+  uint64_t graph_plan_serial = 0;
+  int graph_opt = -1;
+  void drop_graph();
+  ~MbWork();
 };
 
 int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,

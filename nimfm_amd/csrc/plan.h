@@ -12,6 +12,7 @@ namespace nfm {
 //   sorted by sample position (stable sort) so that every per-feature sum has a fixed order.
 struct Plan {
   // identity (cache key)
+  uint64_t serial = 0;  // unique per build
   const void* ds = nullptr;
   int64_t begin = 0, end = 0, batch = 0;
   int n_aug = 0;

@@ -118,8 +118,10 @@ static inline unsigned grid1d(int64_t n) {
 
 int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
                int64_t batch, bool first_singleton, bool want_tq, Plan* out) {
+  static uint64_t g_serial = 0;
   Plan& P = *out;
   P.release();
+  P.serial = ++g_serial;
   hipStream_t st = ctx->stream;
   const int64_t ns = end - begin;
   NFM_CHECK(ns >= 0 && begin >= 0 && end <= X.n, NFM_ERR_INVALID, "epoch range [%lld,%lld) outside [0,%lld)",
