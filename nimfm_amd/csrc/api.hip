@@ -601,7 +601,8 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       if (!reuse) {
         if (!o->plan) o->plan.reset(new Plan());
         TimedLaunch tl(ctx, "plan_build");
-        NFM_TRY(plan_build(ctx, ds->v, m->n_aug, perm, begin, end, o->batch, first_singleton, want_tq, o->plan.get()));
+        const bool use_singles = m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2;  // single order of degree 2
+        NFM_TRY(plan_build(ctx, ds->v, m->n_aug, perm, begin, end, o->batch, first_singleton, want_tq, use_singles, o->plan.get()));
         o->plan->ds = ds;
       }
       if (m->cfg.kind == NFM_KIND_FM)

@@ -109,17 +109,29 @@ struct RowArgs {
   double it_b;            // batch start relative to the epoch call; the absolute step is it0p[0] + it_b
   const double* it0p;     // device scalar: the optimizer's `it` at the start of the epoch call
   const double* scales;  // {scale_P, scale_w} at the batch start
+  const double* scales_n;  // ... at the next batch start (SGD; singles are updated here)
+  const int64_t* toff;     // touch offset of every sample of the epoch call (plan), or null
+  const uint8_t* single;   // per nnz in sample order: 1 = feature touched once in this batch
   double* Abuf;          // [len][TA][Kp]
   SampleRec* rec;        // [len]
   PartA* parts;          // [gridDim.x]
 };
 
 // forward over all orders; returns this lane's share of sum_o sum_s kernel (non-zero in slot 0
-// only) and stores the A rows the column phase needs.
-template <int L, int SPLIT, class PS>
+// only) and stores the A rows the column phase needs.  GEN = false: the model is a single order of
+// degree 2 (the common case), whose A1 is also returned for the in-place update of singles.
+template <int L, int SPLIT, bool GEN, class PS>
 __device__ __forceinline__ double row_forward(const PS& ps, const CsrView& X, const ModelView& M, int64_t q0, int m,
                                               int m_tot, int slot, int l, int lane, bool valid,
-                                              double* __restrict__ Arow) {
+                                              double* __restrict__ Arow, double2& A1_out) {
+  if (!GEN) {
+    double2 A1, A2;
+    dev::anova_fwd_deg2<L, SPLIT>(ps, X, q0, m, m_tot, 0, M.Kp, slot, l, A1, A2);
+    if (valid && slot == 0) *reinterpret_cast<double2*>(Arow + 2 * l) = A1;
+    A1_out = A1;
+    return slot == 0 ? (A1.x * A1.x - A2.x) / 2 + (A1.y * A1.y - A2.y) / 2 : 0.0;
+  }
+  A1_out = {0.0, 0.0};
   double part = 0.0;
   int slot_a = 0;
   for (int o = 0; o < M.nb; ++o) {
@@ -148,7 +160,7 @@ __device__ __forceinline__ double row_forward(const PS& ps, const CsrView& X, co
   return part;
 }
 
-template <int L, int SPLIT, int OPT>
+template <int L, int SPLIT, int OPT, bool GEN>
 __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   constexpr int LPS = L * SPLIT, SPW = kWave / LPS;
   __shared__ double red[kWavesPerBlock][4];
@@ -174,14 +186,15 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   double* Arow = a.Abuf + (size_t)(valid ? pib : 0) * a.TA * M.Kp;
   double b0 = M.sc[SC_INTERCEPT];
   double part = 0.0;
+  double2 A1 = {0.0, 0.0};
+  const double itp = (a.it0p[0] + a.it_b) - 1.0;  // AdaGrad: it' = it_b - 1 (adagrad.nim:90)
+  const bool stored = a.use_stored != 0;
   if (OPT == OPT_SGD) {
     const double sP = a.scales[0], sw = a.scales[1];
     for (int q = slot * L + l; q < m; q += LPS) part += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
     const dev::PlainParams ps{M.P, sP};
-    part += row_forward<L, SPLIT>(ps, X, M, q0, m, m_tot, slot, l, lane, valid, Arow);
+    part += row_forward<L, SPLIT, GEN>(ps, X, M, q0, m, m_tot, slot, l, lane, valid, Arow, A1);
   } else {
-    const double itp = (a.it0p[0] + a.it_b) - 1.0;
-    const bool stored = a.use_stored != 0;
     if (!stored && M.fit_intercept) b0 = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * itp * O.alpha0);
     const double denw = itp * O.eta0 * O.alpha;
     for (int q = slot * L + l; q < m; q += LPS) {
@@ -192,44 +205,107 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
     }
     if (stored) {
       const dev::PlainParams ps{M.P, 1.0};
-      part += row_forward<L, SPLIT>(ps, X, M, q0, m, m_tot, slot, l, lane, valid, Arow);
+      part += row_forward<L, SPLIT, GEN>(ps, X, M, q0, m, m_tot, slot, l, lane, valid, Arow, A1);
     } else {
       const dev::AdaParams ps{O.G, O.N, O.eta0, O.eta0 * itp * O.beta};
-      part += row_forward<L, SPLIT>(ps, X, M, q0, m, m_tot, slot, l, lane, valid, Arow);
+      part += row_forward<L, SPLIT, GEN>(ps, X, M, q0, m, m_tot, slot, l, lane, valid, Arow, A1);
     }
   }
 #pragma unroll
   for (int s = 1; s < LPS; s <<= 1) part += dev::shfl_xor_d(part, s);
   const double yh = b0 + part;
   const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
-  double r_loss = 0.0, r_acc0 = 0.0, r_acc1 = 0.0;
+  double r_loss = 0.0, r_viol = 0.0, r_acc0 = 0.0, r_acc1 = 0.0;
+  double etaP = 0.0, etaw = 0.0;
+  if (OPT == OPT_SGD) {
+    const double it = (a.it0p[0] + a.it_b) + (double)pib;
+    etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+    etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
+    if (leader && M.fit_intercept) {
+      const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
+      r_acc0 = eta0 * dL;
+      r_acc1 = eta0;
+    }
+  } else if (leader && M.fit_intercept) {
+    r_acc0 = dL;
+    r_acc1 = dL * dL;
+  }
   if (leader) {
     r_loss = dev::loss_value(O.loss, O.loss_param, y, yh);
-    if (OPT == OPT_SGD) {
-      const double it = (a.it0p[0] + a.it_b) + (double)pib;
-      const double etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
-      const double etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
-      a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
-      if (M.fit_intercept) {
-        const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
-        r_acc0 = eta0 * dL;
-        r_acc1 = eta0;
-      }
-    } else {
-      a.rec[pib] = SampleRec{dL, 0.0, 0.0, 0.0};
-      if (M.fit_intercept) {
-        r_acc0 = dL;
-        r_acc1 = dL * dL;
+    a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
+  }
+  // ---- singles: a feature this sample alone touches in the batch gets its update right here
+  // (same arithmetic as the column phase with c = 1), so its row is read and written once ----
+  if (!GEN && a.single != nullptr && valid) {
+    const uint8_t* sg = a.single + a.toff[a.p0 + pib];
+    for (int q = slot; q < m_tot; q += SPLIT) {
+      if (!sg[q]) continue;
+      int j;
+      double x;
+      dev::row_entry(X, q0, m, m_tot, q, j, x);
+      const size_t e = (size_t)j * M.Kp + 2 * l;
+      const bool has_w = M.fit_linear && j < M.d && l == 0;
+      if (OPT == OPT_SGD) {
+        const double sP = a.scales[0], sw = a.scales[1], sPn = a.scales_n[0], swn = a.scales_n[1];
+        double2 st = *reinterpret_cast<const double2*>(M.P + e);
+        const double px = sP * st.x, py = sP * st.y;
+        const double ax = etaP * (dL * (x * (A1.x - px * x)));
+        const double ay = etaP * (dL * (x * (A1.y - py * x)));
+        r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
+        st.x = st.x - ax / sPn;
+        st.y = st.y - ay / sPn;
+        *reinterpret_cast<double2*>(M.P + e) = st;
+        if (has_w) {
+          const double wt = M.w[j], wj = sw * wt;
+          const double a0 = etaw * (dL * x);
+          r_viol += fabs(a0 + etaw * O.alpha * wj);
+          M.w[j] = wt - a0 / swn;
+        }
+      } else {
+        double2 g2 = *reinterpret_cast<const double2*>(O.G + e);
+        double2 n2 = *reinterpret_cast<const double2*>(O.N + e);
+        double2 p;
+        if (stored) {
+          p = *reinterpret_cast<const double2*>(M.P + e);
+        } else {
+          const double tmp = O.eta0 * itp * O.beta;
+          p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmp);
+          p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmp);
+          if (O.track_viol) {
+            const double2 old = *reinterpret_cast<const double2*>(M.P + e);
+            r_viol += fabs(old.x - p.x) + fabs(old.y - p.y);
+            *reinterpret_cast<double2*>(M.P + e) = p;
+          }
+        }
+        const double gx = dL * (x * (A1.x - p.x * x)), gy = dL * (x * (A1.y - p.y * x));
+        g2.x += gx;
+        g2.y += gy;
+        n2.x += gx * gx;
+        n2.y += gy * gy;
+        *reinterpret_cast<double2*>(O.G + e) = g2;
+        *reinterpret_cast<double2*>(O.N + e) = n2;
+        if (has_w) {
+          const double wt = M.w[j], gw = O.Gw[j], nw = O.Nw[j];
+          if (!stored) {
+            const double wj = -O.eta0 * gw / (itp * O.eta0 * O.alpha + sqrt(nw));
+            r_viol += fabs(wt - wj);
+            M.w[j] = wj;
+          }
+          const double g = dL * x;
+          O.Gw[j] = gw + g;
+          O.Nw[j] = nw + g * g;
+        }
       }
     }
   }
   // per-wave then per-block sums in a fixed order (lanes that are not sample leaders hold zeros)
   r_loss = dev::wave_sum(r_loss);
+  r_viol = dev::wave_sum(r_viol);
   r_acc0 = dev::wave_sum(r_acc0);
   r_acc1 = dev::wave_sum(r_acc1);
   if (lane == 0) {
     red[wv][0] = r_loss;
-    red[wv][1] = 0.0;
+    red[wv][1] = r_viol;
     red[wv][2] = r_acc0;
     red[wv][3] = r_acc1;
   }
@@ -280,7 +356,7 @@ constexpr int kTouchUnroll = 4;
 
 // one parameter block (order) of one unique feature: this lane's factor pair at element e.
 // do_w: also accumulate the linear term's sums over the same touches.
-template <int OPT>
+template <int OPT, bool GEN>
 __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg, int slot, int l, int64_t t0, int64_t t1,
                                             double sP, double sPn, double fP, bool do_w, WAcc& wacc) {
   const ModelView& M = a.M;
@@ -309,7 +385,7 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
   }
   double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
   double seta = 0.0;
-  if (deg == 2) {
+  if (!GEN || deg == 2) {
     // touches in groups of kTouchUnroll: all loads of a group are issued before the first use;
     // the accumulation itself stays in touch (= sample) order
     for (int64_t t = t0; t < t1; t += kTouchUnroll) {
@@ -414,7 +490,7 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
   return viol;
 }
 
-template <int L, int OPT>
+template <int L, int OPT, bool GEN>
 __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
   constexpr int R = kWave / L;
   __shared__ double red[5][kBlock];
@@ -451,7 +527,7 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
     for (int o = 0; o < M.nb; ++o) {
       const size_t e = ((size_t)o * M.da + j) * M.Kp + 2 * l;
       const int deg = M.degree - o;
-      viol += col_block<OPT>(a, e, deg, slot, l, t0, t1, sP, sPn, fP, has_w && o == 0, wacc);
+      viol += col_block<OPT, GEN>(a, e, deg, slot, l, t0, t1, sP, sPn, fP, has_w && o == 0, wacc);
       slot += deg - 1;
     }
     if (has_w) {
@@ -560,14 +636,14 @@ __global__ __launch_bounds__(kBlock) void k_epoch_close(const double* __restrict
 // ------------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------------
-template <int L, int SPLIT, int OPT>
+template <int L, int SPLIT, int OPT, bool GEN>
 static void launch_row(hipStream_t st, const RowArgs& ra) {
   constexpr int SPW = kWave / (L * SPLIT);
   const int nA = (ra.len + kWavesPerBlock * SPW - 1) / (kWavesPerBlock * SPW);
-  hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT>), dim3(nA), dim3(kBlock), 0, st, ra);
+  hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN>), dim3(nA), dim3(kBlock), 0, st, ra);
 }
 
-template <int L, int OPT>
+template <int L, int OPT, bool GEN>
 static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
                        int TA) {
   constexpr int R = kWave / L;
@@ -587,14 +663,17 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     int nA;
     {
       RowArgs ra{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, P.begin, p0, len, use_stored, TA, 0, it_b, it0p,
-                 OPT == OPT_SGD ? Stab + 2 * b : M.sc, W.Abuf.as<double>(), W.rec.as<SampleRec>(), W.partsA.as<PartA>()};
+                 OPT == OPT_SGD ? Stab + 2 * b : M.sc, OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc,
+                 (!GEN && P.use_singles) ? P.toff.as<int64_t>() : nullptr,
+                 (!GEN && P.use_singles) ? P.single.as<uint8_t>() : nullptr, W.Abuf.as<double>(), W.rec.as<SampleRec>(),
+                 W.partsA.as<PartA>()};
       TimedLaunch tl(ctx, "row_phase");
       int s_used;
-      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT>(st, ra); s_used = R >= 16 ? 16 : R; }
-      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT>(st, ra); s_used = R >= 8 ? 8 : R; }
-      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT>(st, ra); s_used = R >= 4 ? 4 : R; }
-      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT>(st, ra); s_used = R >= 2 ? 2 : R; }
-      else { launch_row<L, 1, OPT>(st, ra); s_used = 1; }
+      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra); s_used = R >= 16 ? 16 : R; }
+      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra); s_used = R >= 8 ? 8 : R; }
+      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra); s_used = R >= 4 ? 4 : R; }
+      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT, GEN>(st, ra); s_used = R >= 2 ? 2 : R; }
+      else { launch_row<L, 1, OPT, GEN>(st, ra); s_used = 1; }
       const int spw = kWave / (L * s_used);
       nA = (len + kWavesPerBlock * spw - 1) / (kWavesPerBlock * spw);
     }
@@ -612,7 +691,7 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
                  W.rec.as<SampleRec>(), parts_cur, W.partsA.as<PartA>(), parts_prev, W.out_acc.as<double>(), it_b,
                  (double)len, it0p, TA, use_stored, nA, n_prev};
       TimedLaunch tl(ctx, "col_phase");
-      hipLaunchKernelGGL((k_col_phase<L, OPT>), dim3(nB), dim3(kBlock), 0, st, ca);
+      hipLaunchKernelGGL((k_col_phase<L, OPT, GEN>), dim3(nB), dim3(kBlock), 0, st, ca);
     }
     n_prev = nB;
   }
@@ -638,10 +717,16 @@ static int enqueue_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const Mod
     hipLaunchKernelGGL(k_scale_prefix, dim3(1), dim3(1), 0, st, M.sc, W.Dtab.as<double>(), W.Stab.as<double>(), P.n_batches);
     NFM_HIP_CHECK(hipGetLastError());
   }
+  const bool gen = !(M.nb == 1 && M.degree == 2);  // anything but a single order of degree 2
+  NFM_CHECK(gen || !P.use_singles || (P.toff.p && P.single.p), NFM_ERR_INVALID, "plan lacks the singles tables");
+  NFM_CHECK(!gen || !P.use_singles, NFM_ERR_INVALID, "a plan with singles needs the degree-2 kernels");
 #define NFM_RUN(LL)                                                                     \
   case LL:                                                                              \
-    return opt_kind == OPT_SGD ? run_batches<LL, OPT_SGD>(ctx, X, M, O, P, W, TA)       \
-                               : run_batches<LL, OPT_ADAGRAD>(ctx, X, M, O, P, W, TA);
+    if (gen)                                                                            \
+      return opt_kind == OPT_SGD ? run_batches<LL, OPT_SGD, true>(ctx, X, M, O, P, W, TA)  \
+                                 : run_batches<LL, OPT_ADAGRAD, true>(ctx, X, M, O, P, W, TA); \
+    return opt_kind == OPT_SGD ? run_batches<LL, OPT_SGD, false>(ctx, X, M, O, P, W, TA) \
+                               : run_batches<LL, OPT_ADAGRAD, false>(ctx, X, M, O, P, W, TA);
   switch (M.L) {
     NFM_RUN(1)
     NFM_RUN(2)

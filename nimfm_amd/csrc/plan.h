@@ -16,22 +16,24 @@ struct Plan {
   const void* ds = nullptr;
   int64_t begin = 0, end = 0, batch = 0;
   int n_aug = 0;
-  bool first_singleton = false, has_perm = false;
+  bool first_singleton = false, has_perm = false, use_singles = false;
   // geometry
-  int64_t n_batches = 0, U = 0, T = 0, max_batch = 0, max_unique = 0;
+  int64_t n_batches = 0, U = 0, T = 0, TM = 0, max_batch = 0, max_unique = 0;  // T touches, TM of them in the column phase
   std::vector<int64_t> bat_pos;   // host, n_batches + 1, relative to begin
   std::vector<int64_t> bat_uoff;  // host, n_batches + 1
   DevBuf perm;                    // int64[end-begin] (absolute sample ids) or empty
   DevBuf bat_pos_dev;             // int64[n_batches + 1]
   DevBuf ucol;                    // int32[U]
   DevBuf uptr;                    // int64[U + 1]
-  DevBuf tpos;                    // int32[T]
-  DevBuf tx;                      // double[T]
-  DevBuf tq;                      // int64[T]  (only when want_tq)
+  DevBuf tpos;                    // int32[TM]
+  DevBuf tx;                      // double[TM]
+  DevBuf tq;                      // int64[TM] (only when want_tq)
+  DevBuf toff;                    // int64[end-begin+1] touch offset of every sample (only with use_singles)
+  DevBuf single;                  // uint8[T] in sample order: 1 = the feature is touched once in its batch
   void release();
 };
 
 int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
-               int64_t batch, bool first_singleton, bool want_tq, Plan* out);
+               int64_t batch, bool first_singleton, bool want_tq, bool use_singles, Plan* out);
 
 }  // namespace nfm

@@ -19,9 +19,11 @@ void Plan::release() {
   tpos.release();
   tx.release();
   tq.release();
+  toff.release();
+  single.release();
   bat_pos.clear();
   bat_uoff.clear();
-  n_batches = U = T = 0;
+  n_batches = U = T = TM = 0;
 }
 
 __device__ __forceinline__ int64_t batch_of(int64_t rel, int64_t batch, int first_singleton) {
@@ -73,35 +75,47 @@ __global__ void k_expand(CsrView X, const int64_t* __restrict__ perm, int64_t be
   }
 }
 
-__global__ void k_gather_sorted(int64_t T, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                const int32_t* __restrict__ tpos_un, const double* __restrict__ tx_un,
-                                const int64_t* __restrict__ tq_un, int32_t* __restrict__ tpos, double* __restrict__ tx,
-                                int64_t* __restrict__ tq, int64_t* __restrict__ head) {
+// per sorted touch r: is its feature touched exactly once in the batch (single), and is r the
+// first touch of a feature with >= 2 touches (head)?
+__global__ void k_classify(int64_t T, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, int use_singles,
+                           uint8_t* __restrict__ single_un, int64_t* __restrict__ multi, int64_t* __restrict__ head) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= T; r += (int64_t)gridDim.x * blockDim.x) {
     if (r == T) {
+      multi[r] = 0;
       head[r] = 0;
       continue;
     }
-    const uint32_t t = vals[r];
-    tpos[r] = tpos_un[t];
-    tx[r] = tx_un[t];
-    if (tq) tq[r] = tq_un[t];
-    head[r] = (r == 0 || keys[r] != keys[r - 1]) ? 1 : 0;
+    const uint64_t key = keys[r];
+    const bool first = r == 0 || keys[r - 1] != key;
+    const bool last = r + 1 == T || keys[r + 1] != key;
+    const bool is_single = use_singles && first && last;
+    if (single_un) single_un[vals[r]] = is_single ? 1 : 0;
+    multi[r] = is_single ? 0 : 1;
+    head[r] = (!is_single && first) ? 1 : 0;
   }
 }
 
-__global__ void k_heads(int64_t T, const uint64_t* __restrict__ keys, const int64_t* __restrict__ uidx, int fbits,
-                        int32_t* __restrict__ ucol, int64_t* __restrict__ uptr, int64_t* __restrict__ bat_first_u) {
+__global__ void k_compact(int64_t T, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                          const int64_t* __restrict__ mpos, const int64_t* __restrict__ uidx, int fbits,
+                          const int32_t* __restrict__ tpos_un, const double* __restrict__ tx_un,
+                          const int64_t* __restrict__ tq_un, int32_t* __restrict__ tpos, double* __restrict__ tx,
+                          int64_t* __restrict__ tq, int32_t* __restrict__ ucol, int64_t* __restrict__ uptr,
+                          int64_t* __restrict__ bat_first_u) {
   const uint64_t fmask = (fbits >= 64) ? ~0ull : ((1ull << fbits) - 1);
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < T; r += (int64_t)gridDim.x * blockDim.x) {
-    const uint64_t key = keys[r];
-    const bool is_head = r == 0 || key != keys[r - 1];
-    if (!is_head) continue;
+    const int64_t mp = mpos[r];
+    if (mpos[r + 1] == mp) continue;  // single
+    const uint32_t t = vals[r];
+    tpos[mp] = tpos_un[t];
+    tx[mp] = tx_un[t];
+    if (tq) tq[mp] = tq_un[t];
     const int64_t u = uidx[r];
-    ucol[u] = (int32_t)(key & fmask);
-    uptr[u] = r;
-    const uint64_t b = key >> fbits;
-    if (r == 0 || (keys[r - 1] >> fbits) != b) bat_first_u[b] = u;
+    if (uidx[r + 1] != u) {  // head of a multi-touch feature
+      const uint64_t key = keys[r];
+      ucol[u] = (int32_t)(key & fmask);
+      uptr[u] = mp;
+      atomicMin(reinterpret_cast<unsigned long long*>(bat_first_u + (key >> fbits)), (unsigned long long)u);
+    }
   }
 }
 
@@ -117,7 +131,7 @@ static inline unsigned grid1d(int64_t n) {
 }
 
 int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
-               int64_t batch, bool first_singleton, bool want_tq, Plan* out) {
+               int64_t batch, bool first_singleton, bool want_tq, bool use_singles, Plan* out) {
   static uint64_t g_serial = 0;
   Plan& P = *out;
   P.release();
@@ -128,7 +142,7 @@ int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_ho
             (long long)begin, (long long)end, (long long)X.n);
   NFM_CHECK(batch >= 1, NFM_ERR_INVALID, "batch must be >= 1");
   P.begin = begin; P.end = end; P.batch = batch; P.n_aug = n_aug;
-  P.first_singleton = first_singleton; P.has_perm = perm_host != nullptr;
+  P.first_singleton = first_singleton; P.has_perm = perm_host != nullptr; P.use_singles = use_singles;
   // batch boundaries
   P.bat_pos.clear();
   P.bat_pos.push_back(0);
@@ -192,42 +206,52 @@ int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_ho
   NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, dk, dv, (int)T, 0, fbits + bbits, st));
   const uint64_t* keys = dk.Current();
   const uint32_t* vals = dv.Current();
-  // 4. payload in sorted order + head flags -> unique index
-  DevBuf head, uidx;
-  NFM_TRY(P.tpos.alloc(sizeof(int32_t) * T)); NFM_TRY(P.tx.alloc(sizeof(double) * T));
-  if (want_tq) NFM_TRY(P.tq.alloc(sizeof(int64_t) * T));
+  // 4. classify: a feature touched exactly once in its batch is a "single" -- its update is applied
+  //    by the row phase itself (flag per nnz in sample order); only features with >= 2 touches go
+  //    to the column phase.  Their touches are compacted, payload in sorted order.
+  DevBuf multi, mpos, head, uidx;
+  if (use_singles) NFM_TRY(P.single.alloc(sizeof(uint8_t) * T));
+  NFM_TRY(multi.alloc(sizeof(int64_t) * (T + 1))); NFM_TRY(mpos.alloc(sizeof(int64_t) * (T + 1)));
   NFM_TRY(head.alloc(sizeof(int64_t) * (T + 1))); NFM_TRY(uidx.alloc(sizeof(int64_t) * (T + 1)));
-  hipLaunchKernelGGL(k_gather_sorted, dim3(grid1d(T + 1)), dim3(kBlock), 0, st, T, keys, vals, tpos_un.as<int32_t>(),
-                     tx_un.as<double>(), want_tq ? tq_un.as<int64_t>() : nullptr, P.tpos.as<int32_t>(), P.tx.as<double>(),
-                     want_tq ? P.tq.as<int64_t>() : nullptr, head.as<int64_t>());
+  hipLaunchKernelGGL(k_classify, dim3(grid1d(T + 1)), dim3(kBlock), 0, st, T, keys, vals, use_singles ? 1 : 0,
+                     use_singles ? P.single.as<uint8_t>() : nullptr, multi.as<int64_t>(), head.as<int64_t>());
   tmp_bytes = 0;
   NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, head.as<int64_t>(), uidx.as<int64_t>(), (int)(T + 1), st));
   NFM_TRY(tmp.alloc(tmp_bytes));
   NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, head.as<int64_t>(), uidx.as<int64_t>(), (int)(T + 1), st));
-  int64_t U = 0;
+  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, multi.as<int64_t>(), mpos.as<int64_t>(), (int)(T + 1), st));
+  int64_t U = 0, TM = 0;
   NFM_HIP_CHECK(hipMemcpyAsync(&U, uidx.as<int64_t>() + T, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipMemcpyAsync(&TM, mpos.as<int64_t>() + T, sizeof(int64_t), hipMemcpyDeviceToHost, st));
   NFM_HIP_CHECK(hipStreamSynchronize(st));
   P.U = U;
+  P.TM = TM;
+  NFM_TRY(P.tpos.alloc(sizeof(int32_t) * TM)); NFM_TRY(P.tx.alloc(sizeof(double) * TM));
+  if (want_tq) NFM_TRY(P.tq.alloc(sizeof(int64_t) * TM));
   NFM_TRY(P.ucol.alloc(sizeof(int32_t) * U));
   NFM_TRY(P.uptr.alloc(sizeof(int64_t) * (U + 1)));
   DevBuf bfu;
   NFM_TRY(bfu.alloc(sizeof(int64_t) * P.n_batches));
-  hipLaunchKernelGGL(k_set_i64, dim3(grid1d(P.n_batches)), dim3(kBlock), 0, st, bfu.as<int64_t>(), P.n_batches, (int64_t)-1);
-  hipLaunchKernelGGL(k_heads, dim3(grid1d(T)), dim3(kBlock), 0, st, T, keys, uidx.as<int64_t>(), fbits, P.ucol.as<int32_t>(),
+  const int64_t none = INT64_MAX;
+  hipLaunchKernelGGL(k_set_i64, dim3(grid1d(P.n_batches)), dim3(kBlock), 0, st, bfu.as<int64_t>(), P.n_batches, none);
+  hipLaunchKernelGGL(k_compact, dim3(grid1d(T)), dim3(kBlock), 0, st, T, keys, vals, mpos.as<int64_t>(), uidx.as<int64_t>(),
+                     fbits, tpos_un.as<int32_t>(), tx_un.as<double>(), want_tq ? tq_un.as<int64_t>() : nullptr,
+                     P.tpos.as<int32_t>(), P.tx.as<double>(), want_tq ? P.tq.as<int64_t>() : nullptr, P.ucol.as<int32_t>(),
                      P.uptr.as<int64_t>(), bfu.as<int64_t>());
   NFM_HIP_CHECK(hipGetLastError());
-  NFM_HIP_CHECK(hipMemcpyAsync(P.uptr.as<int64_t>() + U, &T, sizeof(int64_t), hipMemcpyHostToDevice, st));
+  NFM_HIP_CHECK(hipMemcpyAsync(P.uptr.as<int64_t>() + U, &TM, sizeof(int64_t), hipMemcpyHostToDevice, st));
   std::vector<int64_t> first(P.n_batches);
   NFM_HIP_CHECK(hipMemcpyAsync(first.data(), bfu.p, sizeof(int64_t) * P.n_batches, hipMemcpyDeviceToHost, st));
   NFM_HIP_CHECK(hipStreamSynchronize(st));
   P.bat_uoff[P.n_batches] = U;
-  for (int64_t b = P.n_batches - 1; b >= 0; --b) P.bat_uoff[b] = first[b] >= 0 ? first[b] : P.bat_uoff[b + 1];
+  for (int64_t b = P.n_batches - 1; b >= 0; --b) P.bat_uoff[b] = first[b] != none ? first[b] : P.bat_uoff[b + 1];
   P.max_unique = 0;
   for (int64_t b = 0; b < P.n_batches; ++b) P.max_unique = std::max(P.max_unique, P.bat_uoff[b + 1] - P.bat_uoff[b]);
-  // temporaries are released by their destructors' explicit calls
-  k0.release(); k1.release(); v0.release(); v1.release(); tpos_un.release(); tx_un.release(); tq_un.release();
-  head.release(); uidx.release(); bfu.release(); tmp.release(); toff.release();
-  return NFM_OK;
+  if (use_singles) {  // the row phase finds a sample's flags at single[toff[pos] + q]
+    P.toff.p = toff.p; P.toff.bytes = toff.bytes;
+    toff.p = nullptr; toff.bytes = 0;
+  }
+  return NFM_OK;  // temporaries are released by their destructors
 }
 
 }  // namespace nfm
