@@ -601,7 +601,11 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       if (!reuse) {
         if (!o->plan) o->plan.reset(new Plan());
         TimedLaunch tl(ctx, "plan_build");
-        const bool use_singles = m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2;  // single order of degree 2
+        // Features touched once per batch are updated by the row phase itself ("singles"); worth the
+        // second visit of the row only when they are a sizeable share of the touches.  With a touch
+        // rate lambda = batch * nnz_per_row / d per feature that share is about exp(-lambda).
+        const double lambda = (double)o->batch * ((double)ds->v.nnz / (double)std::max<int64_t>(ds->v.n, 1)) / (double)m->d;
+        const bool use_singles = m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2 && (o->batch == 1 || lambda <= 1.4);
         NFM_TRY(plan_build(ctx, ds->v, m->n_aug, perm, begin, end, o->batch, first_singleton, want_tq, use_singles, o->plan.get()));
         o->plan->ds = ds;
       }

@@ -162,16 +162,17 @@ __device__ __forceinline__ double row_forward(const PS& ps, const CsrView& X, co
 
 template <int L, int SPLIT, int OPT, bool GEN>
 __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
-  constexpr int LPS = L * SPLIT, SPW = kWave / LPS;
-  __shared__ double red[kWavesPerBlock][4];
+  constexpr int LPS = L * SPLIT, SPW = kWave / LPS, SPB = kWavesPerBlock * SPW;  // samples per wave / block
+  __shared__ double s_y[SPB], s_yh[SPB], s_dL[SPB], s_etaP[SPB], s_etaw[SPB];
+  __shared__ double s_part[4], s_viol[kWavesPerBlock];
   const CsrView& X = a.X;
   const ModelView& M = a.M;
   const OptView& O = a.O;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   const int sidx = lane / LPS, slot = (lane / L) % SPLIT, l = lane % L;
-  const int pib = (blockIdx.x * kWavesPerBlock + wv) * SPW + sidx;
+  const int sib = wv * SPW + sidx;  // sample inside the block
+  const int pib = blockIdx.x * SPB + sib;
   const bool valid = pib < a.len;
-  const bool leader = valid && slot == 0 && l == 0;
   int64_t i = 0, q0 = 0;
   int m = 0, m_tot = 0;
   double y = 0.0;
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   double2 A1 = {0.0, 0.0};
   const double itp = (a.it0p[0] + a.it_b) - 1.0;  // AdaGrad: it' = it_b - 1 (adagrad.nim:90)
   const bool stored = a.use_stored != 0;
+  // ---- 1. forward: yhat of every sample of the block ----
   if (OPT == OPT_SGD) {
     const double sP = a.scales[0], sw = a.scales[1];
     for (int q = slot * L + l; q < m; q += LPS) part += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
@@ -213,111 +215,162 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   }
 #pragma unroll
   for (int s = 1; s < LPS; s <<= 1) part += dev::shfl_xor_d(part, s);
-  const double yh = b0 + part;
-  const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
-  double r_loss = 0.0, r_viol = 0.0, r_acc0 = 0.0, r_acc1 = 0.0;
-  double etaP = 0.0, etaw = 0.0;
-  if (OPT == OPT_SGD) {
-    const double it = (a.it0p[0] + a.it_b) + (double)pib;
-    etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
-    etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
-    if (leader && M.fit_intercept) {
-      const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
-      r_acc0 = eta0 * dL;
-      r_acc1 = eta0;
+  if (slot == 0 && l == 0) {
+    s_y[sib] = y;
+    s_yh[sib] = b0 + part;
+  }
+  __syncthreads();
+  // ---- 2. loss, dL and step sizes: ONE LANE PER SAMPLE in the first wavefront, so the
+  // transcendental work (exp/log of the loss, the divisions of the schedules) is issued once per
+  // 64 samples instead of once per sample; the block's partial sums fall out of one wave reduction
+  if (wv == 0) {
+    double r_loss = 0.0, r_acc0 = 0.0, r_acc1 = 0.0;
+    for (int t = lane; t < SPB; t += kWave) {
+      const int pt = blockIdx.x * SPB + t;
+      if (pt < a.len) {
+        const double yt = s_y[t], yh = s_yh[t];
+        const double dL = dev::loss_grad(O.loss, O.loss_param, yt, yh);
+        r_loss += dev::loss_value(O.loss, O.loss_param, yt, yh);
+        double etaP = 0.0, etaw = 0.0;
+        if (OPT == OPT_SGD) {
+          const double it = (a.it0p[0] + a.it_b) + (double)pt;
+          etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+          etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
+          if (M.fit_intercept) {
+            const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
+            r_acc0 += eta0 * dL;
+            r_acc1 += eta0;
+          }
+        } else if (M.fit_intercept) {
+          r_acc0 += dL;
+          r_acc1 += dL * dL;
+        }
+        a.rec[pt] = SampleRec{dL, etaP, etaw, 0.0};
+        s_dL[t] = dL;
+        s_etaP[t] = etaP;
+        s_etaw[t] = etaw;
+      }
     }
-  } else if (leader && M.fit_intercept) {
-    r_acc0 = dL;
-    r_acc1 = dL * dL;
+    r_loss = dev::wave_sum(r_loss);
+    r_acc0 = dev::wave_sum(r_acc0);
+    r_acc1 = dev::wave_sum(r_acc1);
+    if (lane == 0) {
+      s_part[0] = r_loss;
+      s_part[2] = r_acc0;
+      s_part[3] = r_acc1;
+    }
   }
-  if (leader) {
-    r_loss = dev::loss_value(O.loss, O.loss_param, y, yh);
-    a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
-  }
-  // ---- singles: a feature this sample alone touches in the batch gets its update right here
+  __syncthreads();
+  const double dL = s_dL[sib], etaP = s_etaP[sib], etaw = s_etaw[sib];
+  double r_viol = 0.0;
+  // ---- 3. singles: a feature this sample alone touches in the batch gets its update right here
   // (same arithmetic as the column phase with c = 1), so its row is read and written once ----
   if (!GEN && a.single != nullptr && valid) {
     const uint8_t* sg = a.single + a.toff[a.p0 + pib];
-    for (int q = slot; q < m_tot; q += SPLIT) {
-      if (!sg[q]) continue;
-      int j;
-      double x;
-      dev::row_entry(X, q0, m, m_tot, q, j, x);
-      const size_t e = (size_t)j * M.Kp + 2 * l;
-      const bool has_w = M.fit_linear && j < M.d && l == 0;
-      if (OPT == OPT_SGD) {
-        const double sP = a.scales[0], sw = a.scales[1], sPn = a.scales_n[0], swn = a.scales_n[1];
-        double2 st = *reinterpret_cast<const double2*>(M.P + e);
-        const double px = sP * st.x, py = sP * st.y;
-        const double ax = etaP * (dL * (x * (A1.x - px * x)));
-        const double ay = etaP * (dL * (x * (A1.y - py * x)));
-        r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
-        st.x = st.x - ax / sPn;
-        st.y = st.y - ay / sPn;
-        *reinterpret_cast<double2*>(M.P + e) = st;
-        if (has_w) {
-          const double wt = M.w[j], wj = sw * wt;
-          const double a0 = etaw * (dL * x);
-          r_viol += fabs(a0 + etaw * O.alpha * wj);
-          M.w[j] = wt - a0 / swn;
+    const double sP = a.scales[0], sw = a.scales[1], sPn = a.scales_n[0], swn = a.scales_n[1];
+    const double tmpP = O.eta0 * itp * O.beta, denw = itp * O.eta0 * O.alpha;
+    // groups of kUnroll entries: flags, then (index, value), then the rows are all requested before
+    // the first use, so the second visit of the row costs one memory round trip per group
+    for (int q = slot; q < m_tot; q += dev::kUnroll * SPLIT) {
+      bool f[dev::kUnroll];
+      int j[dev::kUnroll];
+      double x[dev::kUnroll];
+      double2 r0[dev::kUnroll], r1[dev::kUnroll], r2[dev::kUnroll];
+      double w0[dev::kUnroll], w1[dev::kUnroll], w2[dev::kUnroll];
+#pragma unroll
+      for (int u = 0; u < dev::kUnroll; ++u) {
+        const int qq = q + u * SPLIT;
+        f[u] = qq < m_tot && sg[qq] != 0;
+      }
+#pragma unroll
+      for (int u = 0; u < dev::kUnroll; ++u) {
+        j[u] = 0;
+        x[u] = 0.0;
+        if (f[u]) dev::row_entry(X, q0, m, m_tot, q + u * SPLIT, j[u], x[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < dev::kUnroll; ++u) {
+        r0[u] = r1[u] = r2[u] = {0.0, 0.0};
+        w0[u] = w1[u] = w2[u] = 0.0;
+        if (f[u]) {
+          const size_t e = (size_t)j[u] * M.Kp + 2 * l;
+          const bool has_w = M.fit_linear && j[u] < M.d && l == 0;
+          if (OPT == OPT_SGD) {
+            r0[u] = *reinterpret_cast<const double2*>(M.P + e);
+            if (has_w) w0[u] = M.w[j[u]];
+          } else {
+            r1[u] = *reinterpret_cast<const double2*>(O.G + e);
+            r2[u] = *reinterpret_cast<const double2*>(O.N + e);
+            if (stored || O.track_viol) r0[u] = *reinterpret_cast<const double2*>(M.P + e);
+            if (has_w) {
+              w0[u] = M.w[j[u]];
+              w1[u] = O.Gw[j[u]];
+              w2[u] = O.Nw[j[u]];
+            }
+          }
         }
-      } else {
-        double2 g2 = *reinterpret_cast<const double2*>(O.G + e);
-        double2 n2 = *reinterpret_cast<const double2*>(O.N + e);
-        double2 p;
-        if (stored) {
-          p = *reinterpret_cast<const double2*>(M.P + e);
+      }
+#pragma unroll
+      for (int u = 0; u < dev::kUnroll; ++u) {
+        if (!f[u]) continue;
+        const size_t e = (size_t)j[u] * M.Kp + 2 * l;
+        const bool has_w = M.fit_linear && j[u] < M.d && l == 0;
+        const double xv = x[u];
+        if (OPT == OPT_SGD) {
+          double2 st = r0[u];
+          const double px = sP * st.x, py = sP * st.y;
+          const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
+          const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
+          r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
+          st.x = st.x - ax / sPn;
+          st.y = st.y - ay / sPn;
+          *reinterpret_cast<double2*>(M.P + e) = st;
+          if (has_w) {
+            const double wt = w0[u], wj = sw * wt;
+            const double a0 = etaw * (dL * xv);
+            r_viol += fabs(a0 + etaw * O.alpha * wj);
+            M.w[j[u]] = wt - a0 / swn;
+          }
         } else {
-          const double tmp = O.eta0 * itp * O.beta;
-          p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmp);
-          p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmp);
-          if (O.track_viol) {
-            const double2 old = *reinterpret_cast<const double2*>(M.P + e);
-            r_viol += fabs(old.x - p.x) + fabs(old.y - p.y);
-            *reinterpret_cast<double2*>(M.P + e) = p;
+          double2 g2 = r1[u], n2 = r2[u], p;
+          if (stored) {
+            p = r0[u];
+          } else {
+            p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmpP);
+            p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmpP);
+            if (O.track_viol) {
+              r_viol += fabs(r0[u].x - p.x) + fabs(r0[u].y - p.y);
+              *reinterpret_cast<double2*>(M.P + e) = p;
+            }
           }
-        }
-        const double gx = dL * (x * (A1.x - p.x * x)), gy = dL * (x * (A1.y - p.y * x));
-        g2.x += gx;
-        g2.y += gy;
-        n2.x += gx * gx;
-        n2.y += gy * gy;
-        *reinterpret_cast<double2*>(O.G + e) = g2;
-        *reinterpret_cast<double2*>(O.N + e) = n2;
-        if (has_w) {
-          const double wt = M.w[j], gw = O.Gw[j], nw = O.Nw[j];
-          if (!stored) {
-            const double wj = -O.eta0 * gw / (itp * O.eta0 * O.alpha + sqrt(nw));
-            r_viol += fabs(wt - wj);
-            M.w[j] = wj;
+          const double gx = dL * (xv * (A1.x - p.x * xv)), gy = dL * (xv * (A1.y - p.y * xv));
+          g2.x += gx;
+          g2.y += gy;
+          n2.x += gx * gx;
+          n2.y += gy * gy;
+          *reinterpret_cast<double2*>(O.G + e) = g2;
+          *reinterpret_cast<double2*>(O.N + e) = n2;
+          if (has_w) {
+            const double wt = w0[u], gw = w1[u], nw = w2[u];
+            if (!stored) {
+              const double wj = -O.eta0 * gw / (denw + sqrt(nw));
+              r_viol += fabs(wt - wj);
+              M.w[j[u]] = wj;
+            }
+            const double g = dL * xv;
+            O.Gw[j[u]] = gw + g;
+            O.Nw[j[u]] = nw + g * g;
           }
-          const double g = dL * x;
-          O.Gw[j] = gw + g;
-          O.Nw[j] = nw + g * g;
         }
       }
     }
   }
-  // per-wave then per-block sums in a fixed order (lanes that are not sample leaders hold zeros)
-  r_loss = dev::wave_sum(r_loss);
   r_viol = dev::wave_sum(r_viol);
-  r_acc0 = dev::wave_sum(r_acc0);
-  r_acc1 = dev::wave_sum(r_acc1);
-  if (lane == 0) {
-    red[wv][0] = r_loss;
-    red[wv][1] = r_viol;
-    red[wv][2] = r_acc0;
-    red[wv][3] = r_acc1;
-  }
+  if (lane == 0) s_viol[wv] = r_viol;
   __syncthreads();
   if (threadIdx.x == 0) {
-    PartA p{0.0, 0.0, 0.0, 0.0};
-    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) {
-      p.loss += red[w_][0];
-      p.viol += red[w_][1];
-      p.acc0 += red[w_][2];
-      p.acc1 += red[w_][3];
-    }
+    PartA p{s_part[0], 0.0, s_part[2], s_part[3]};
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) p.viol += s_viol[w_];
     a.parts[blockIdx.x] = p;
   }
 }

@@ -157,3 +157,46 @@ def test_maxthreads_overload_learns():
     before = fm.score(X, y)
     nf.newSGD(maxIter=30, verbose=0, tol=0, alpha0=1e-9, alpha=1e-9, beta=1e-9, batch=32).fit(X, y, fm, maxThreads=4)
     assert fm.score(X, y) < before
+
+
+@pytest.mark.parametrize("k,batch", [(4, 64), (16, 256), (64, 100)])
+def test_sparse_regime_singles(k, batch):
+    """d >> batch * nnz/row: most features are touched once per batch and are updated by the row phase
+    itself (the "singles" path); the rest go through the column phase.  Same rule, same oracle."""
+    n, d, m = 1500, 6000, 8
+    Xo = random_csr(n, d, m, seed=3)
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal(n)
+    P0, w0 = rng.standard_normal((1, k, d)) * (0.1 / np.sqrt(k)), np.zeros(d)
+    perms = make_perms(n, 2)
+    X = to_gpu(Xo)
+    P, w, b, it, hist = run_oracle_sgd_mb(Xo, y, 2, P0, w0, 0.0, O.sgd_cfg(), batch, 0, perms, 2)
+    fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, 0.0)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, mode="minibatch", batch=batch)
+    sgd.fit(X, y, fm, perms=perms)
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
+    assert_close([h[0] for h in sgd.history], [h[0] for h in hist], 1e-9, 1e-12, "viol")
+    cfg = O.adagrad_cfg()
+    P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
+    st = O.AdaState(1, d, k, d)
+    hist = []
+    for e in range(2):
+        b, it, ls, vs = O.fm_adagrad_epoch_mb(Xo, y, 2, P, w, b, cfg, batch, st, perm=perms[e], it=it)
+        hist.append(vs)
+    b = O.fm_adagrad_finalize(2, P, w, b, cfg, it, st)
+    fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, 0.0)
+    ada = nf.newAdaGrad(maxIter=2, verbose=0, tol=0, mode="minibatch", batch=batch)
+    ada.fit(X, y, fm, perms=perms)
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
+    assert_close([h[0] for h in ada.history], hist, 1e-9, 1e-12, "viol")
+    # no permutation: the plan is reused and replayed as a hipGraph from the second epoch on
+    P, w, b, it, hist = run_oracle_sgd_mb(Xo, y, 2, P0, w0, 0.0, O.sgd_cfg(), batch, 0, None, 12)
+    fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, 0.0)
+    nf.newSGD(maxIter=12, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=batch).fit(X, y, fm)
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
