@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <map>
 #include <string>
@@ -128,8 +129,8 @@ struct DevBuf {  // owned device allocation
 };
 
 // SPLIT (row slots per sample, fm_device.h) for a launch over n samples with avg_row nnz per row:
-// enough wavefronts to fill the chip (>= 16 per CU) and a serial chain of at most ~4 rounds of
-// kUnroll loads per lane; capped by the 64/L slots a wavefront has and by 16.
+// enough wavefronts to fill the chip (>= 16 per CU) and a serial chain of at most ~8 rounds of
+// kUnroll loads per lane (measured on cfg2: fewer slots win as soon as the chip is full); capped by the 64/L slots a wavefront has and by 16.
 inline int choose_split(int L, int64_t n, double avg_row, int n_cu) {
   const int R = kWave / L;
   auto p2 = [](double v) {
@@ -137,9 +138,13 @@ inline int choose_split(int L, int64_t n, double avg_row, int n_cu) {
     while (r < v && r < 64) r <<= 1;
     return r;
   };
+  if (const char* env = getenv("NFM_SPLIT")) {  // tuning override
+    int s = atoi(env);
+    if (s >= 1) return s > R ? R : (s > 16 ? 16 : p2(s));
+  }
   const double occ = (double)n_cu * 16.0 * kWave / ((double)(n > 0 ? n : 1) * L);
   int s = p2(occ);
-  const int lat = p2(avg_row / 16.0);
+  const int lat = p2(avg_row / 32.0);
   if (lat > s) s = lat;
   if (s > R) s = R;
   if (s > 16) s = 16;
