@@ -35,9 +35,10 @@ def alias(torch, dev, ptr, n):
     return torch.as_tensor(_DevArray(ptr, n), device=dev)
 
 
-def exchange(tensors, dist, world, rule, prevs=None):
-    """Reconcile replicas in place.  rule: "average" | "sum_deltas" (needs prevs, updated in place)."""
-    if world <= 1:
+def exchange(tensors, dist, world, rule, prevs=None, force=False):
+    """Reconcile replicas in place.  rule: "average" | "sum_deltas" (needs prevs, updated in place).
+    force runs the collective even for a single replica (used to test the plumbing on one GPU)."""
+    if world <= 1 and not force:
         return
     if rule == "average":
         for t in tensors:
@@ -77,10 +78,10 @@ class ParamViews:
                           alias(torch, dev, gs.value, 2)]
             self.state_prev = [t.clone() for t in self.state]
 
-    def average(self, dist, world):
+    def average(self, dist, world, force=False):
         """Called between epochs; the library has synchronised its stream when nfm_opt_epoch returns."""
         if self.is_adagrad:
-            exchange(self.state, dist, world, "sum_deltas", self.state_prev)
+            exchange(self.state, dist, world, "sum_deltas", self.state_prev, force)
         else:
-            exchange(self.params, dist, world, "average")
+            exchange(self.params, dist, world, "average", None, force)
         self.torch.cuda.synchronize(self.dev)

@@ -1,0 +1,90 @@
+// C++ host-mirror test (nimfm_amd/host/nimfm.hpp): the reference's own test ideas through the
+// compiled-language surface -- tests/test_sgd.nim:16-34 (fitLinear=false => w == 0), :58-89 (warm start),
+// :129-151 (score improves) -- on planted synthetic data.  Exit code 0 = all checks passed.
+#include <cstdio>
+#include <random>
+
+#include "../../nimfm_amd/host/nimfm.hpp"
+
+using namespace nimfm;
+
+static int fails = 0;
+#define CHECK(c) do { if (!(c)) { std::printf("CHECK failed: %s (line %d)\n", #c, __LINE__); ++fails; } } while (0)
+
+int main() {
+  const int64_t n = 200, d = 16;
+  const int k = 4;
+  std::mt19937_64 g(42);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  std::vector<double> data;
+  std::vector<int64_t> indices, indptr{0};
+  std::vector<std::vector<double>> dense(n, std::vector<double>(d, 0.0));
+  for (int64_t i = 0; i < n; ++i) {
+    for (int64_t j = 0; j < d; ++j) {
+      const double v = U(g);
+      if (std::fabs(v) < 0.3) continue;
+      dense[i][j] = v; data.push_back(v); indices.push_back(j);
+    }
+    indptr.push_back((int64_t)data.size());
+  }
+  // planted degree-2 FM labels
+  std::normal_distribution<double> N01(0.0, 1.0);
+  std::vector<double> Pt((size_t)k * d), y(n);
+  for (auto& v : Pt) v = N01(g);
+  for (int64_t i = 0; i < n; ++i) {
+    double acc = 0.0;
+    for (int s = 0; s < k; ++s) {
+      double a1 = 0, a2 = 0;
+      for (int64_t j = 0; j < d; ++j) { const double t = Pt[s * d + j] * dense[i][j]; a1 += t; a2 += t * t; }
+      acc += 0.5 * (a1 * a1 - a2);
+    }
+    y[i] = acc;
+  }
+  CSRDataset X(data, indices, indptr, n, d);
+
+  {  // not fitted -> NotFittedError (model/fm_base.nim:13-15)
+    FactorizationMachine fm(regression, 2, k);
+    bool threw = false;
+    try { fm.decisionFunction(X); } catch (const NotFittedError&) { threw = true; }
+    CHECK(threw);
+    bool bad = false;
+    try { FactorizationMachine f2(regression, 0, k); } catch (const std::invalid_argument&) { bad = true; }
+    CHECK(bad);
+  }
+  {  // score improves (test_sgd.nim:129-151), sequential and mini-batch (maxThreads overload)
+    for (int maxThreads : {0, 4}) {
+      FactorizationMachine fm(regression, 2, k);
+      fm.init(X);
+      const double before = fm.score(X, y);
+      SGD<Squared> sgd(20, 0.01, 1e-9, 1e-9, 1e-9, Squared(), optimal, 1.0, 0, 0.0);
+      sgd.batch = 16;
+      sgd.fit(X, y, fm, maxThreads);
+      CHECK(fm.score(X, y) < before);
+      CHECK(sgd.it == 20 * n + 1);
+    }
+  }
+  {  // fitLinear = false => w stays 0; fitIntercept = false => intercept 0 (test_sgd.nim:16-55)
+    FactorizationMachine fm(regression, 2, k, explicit_, false, false);
+    SGD<Squared> sgd(5, 0.01, 1e-6, 1e-3, 1e-3, Squared(), optimal, 1.0, 0, 0.0);
+    sgd.fit(X, y, fm);
+    for (double v : fm.w) CHECK(v == 0.0);
+    CHECK(fm.intercept == 0.0);
+  }
+  {  // warm start: 5 x fit(maxIter=1) == fit(maxIter=5), shuffle off (test_sgd.nim:58-89), SGD and AdaGrad
+    FactorizationMachine a(regression, 3, k, explicit_, true, true, true), b(regression, 3, k);
+    SGD<Squared> s1(1, 0.01, 1e-6, 1e-3, 1e-3, Squared(), optimal, 1.0, 0, 0.0, false);
+    SGD<Squared> s5(5, 0.01, 1e-6, 1e-3, 1e-3, Squared(), optimal, 1.0, 0, 0.0, false);
+    for (int r = 0; r < 5; ++r) s1.fit(X, y, a);
+    s5.fit(X, y, b);
+    CHECK(std::fabs(a.intercept - b.intercept) < 1e-8);
+    for (size_t e = 0; e < a.P.size(); ++e) CHECK(std::fabs(a.P[e] - b.P[e]) < 1e-8);
+    FactorizationMachine c(regression, 2, k, explicit_, true, true, true), e2(regression, 2, k);
+    AdaGrad<Squared> a1(1, 0.1, 1e-6, 1e-3, 1e-3, Squared(), 1e-10, 0, 0.0, false);
+    AdaGrad<Squared> a5(5, 0.1, 1e-6, 1e-3, 1e-3, Squared(), 1e-10, 0, 0.0, false);
+    for (int r = 0; r < 5; ++r) a1.fit(X, y, c);
+    a5.fit(X, y, e2);
+    for (size_t e = 0; e < c.P.size(); ++e) CHECK(std::fabs(c.P[e] - e2.P[e]) < 1e-8);
+  }
+  std::printf(fails ? "FAILED (%d)\n" : "host mirror ok\n", fails);
+  return fails ? 1 : 0;
+}
