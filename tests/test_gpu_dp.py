@@ -3,11 +3,15 @@ buffers (__cuda_array_interface__), an RCCL (backend "nccl") all-reduce over the
 and training continuing correctly afterwards."""
 import os
 import socket
+import sys
 
-import numpy as np
-import pytest
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-import oracle as O
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
+
+import oracle as O  # noqa: E402
 from common import assert_close, random_csr
 from gpu_common import gpu_fm, to_gpu
 
@@ -15,6 +19,16 @@ pytestmark = pytest.mark.gpu
 
 
 def test_alias_and_rccl_allreduce_world1():
+    """Runs in a fresh interpreter: torch must initialise its HIP runtime before libnimfm_hip.so is
+    loaded (as in bench.py); the other GPU tests of this process loaded the library first."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.abspath(__file__)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "dp world1 ok" in out.stdout
+
+
+def _main():
     import torch
     import torch.distributed as dist
 
@@ -63,3 +77,12 @@ def test_alias_and_rccl_allreduce_world1():
             assert_close(fm.P, P, 1e-9, 1e-12, solver + " P")
     finally:
         dist.destroy_process_group()
+    print("dp world1 ok")
+
+
+if __name__ == "__main__":
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    _main()
