@@ -39,6 +39,7 @@ struct nfm_model {
 };
 
 struct nfm_opt {
+  nfm_ctx* ctx = nullptr;  // kept separately: the optimizer may outlive its model handle
   nfm_model* m = nullptr;
   int kind = OPT_SGD, mode = NFM_MODE_SEQUENTIAL;
   int64_t batch = 1, it = 1;
@@ -434,7 +435,7 @@ int32_t nfm_sgd_create(nfm_model* m, const nfm_sgd_cfg* c, nfm_opt** out) {
   NFM_TRY(check_common(m, c->loss, c->mode, c->batch));
   NFM_CHECK(c->scheduling >= 0 && c->scheduling <= 3, NFM_ERR_INVALID, "bad scheduling id");
   std::unique_ptr<nfm_opt> o(new nfm_opt());
-  o->m = m; o->kind = OPT_SGD; o->mode = c->mode; o->batch = c->mode == NFM_MODE_MINIBATCH ? c->batch : 1; o->it = 1;
+  o->ctx = m->ctx; o->m = m; o->kind = OPT_SGD; o->mode = c->mode; o->batch = c->mode == NFM_MODE_MINIBATCH ? c->batch : 1; o->it = 1;
   o->o.eta0 = c->eta0; o->o.alpha0 = c->alpha0; o->o.alpha = c->alpha; o->o.beta = c->beta; o->o.power = c->power;
   o->o.eps = 0.0; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = c->scheduling; o->o.track_viol = 1;
   NFM_TRY(use_device(m->ctx));
@@ -447,7 +448,7 @@ int32_t nfm_adagrad_create(nfm_model* m, const nfm_adagrad_cfg* c, nfm_opt** out
   NFM_CHECK(c && out, NFM_ERR_INVALID, "null argument");
   NFM_TRY(check_common(m, c->loss, c->mode, c->batch));
   std::unique_ptr<nfm_opt> o(new nfm_opt());
-  o->m = m; o->kind = OPT_ADAGRAD; o->mode = c->mode; o->batch = c->mode == NFM_MODE_MINIBATCH ? c->batch : 1; o->it = 1;
+  o->ctx = m->ctx; o->m = m; o->kind = OPT_ADAGRAD; o->mode = c->mode; o->batch = c->mode == NFM_MODE_MINIBATCH ? c->batch : 1; o->it = 1;
   o->o.eta0 = c->eta0; o->o.alpha0 = c->alpha0; o->o.alpha = c->alpha; o->o.beta = c->beta; o->o.power = 1.0;
   o->o.eps = c->eps; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = 0; o->o.track_viol = c->track_viol;
   NFM_TRY(use_device(m->ctx));
@@ -660,8 +661,8 @@ int32_t nfm_opt_device_state(nfm_opt* o, double** gsum_P, double** gnorm_P, int6
 
 int32_t nfm_opt_destroy(nfm_opt* o) {
   if (!o) return NFM_OK;
-  (void)hipSetDevice(o->m->ctx->device);
-  (void)hipStreamSynchronize(o->m->ctx->stream);
+  (void)hipSetDevice(o->ctx->device);
+  (void)hipStreamSynchronize(o->ctx->stream);
   delete o;
   return NFM_OK;
 }

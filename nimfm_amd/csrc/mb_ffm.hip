@@ -1,11 +1,425 @@
-// nimfm_amd/csrc/mb_ffm.hip -- NFM_MODE_MINIBATCH for FieldAwareFactorizationMachine (placeholder
-// until the FFM row/column kernels land; the sequential mode covers FFM meanwhile).
+// nimfm_amd/csrc/mb_ffm.hip -- NFM_MODE_MINIBATCH for FieldAwareFactorizationMachine.
+//
+// Replaces the reference's FFM Hogwild drivers (optimizer/sgd_ffm_multi.nim, adagrad_ffm_multi.nim)
+// with the deterministic mini-batch rule of DESIGN.md section 4; the per-sample arithmetic is
+// optimizer/sgd_ffm.nim:11-30 (predictWithGrad) and sgd.nim:205-243 / adagrad.nim:87-134 with
+// "order" = field: a step touches ALL nFields rows P[f][j] of every feature j of the sample
+// (sgd_ffm.nim:43), and so does the rule here.
+//
+//   row phase     one wavefront per sample.  Output (q, f), q = nnz of the row, f = field:
+//                 dA[q][f] = x_q * sum_{q': field(q') = f, j_q' != j_q} x_q' * P[field(q)][j_q']
+//                 (the reference's dA[f][j_q], accumulated in the same q' order), written to the
+//                 contribution buffer at slot (toff + q) * F + f; yhat's pair sum is
+//                 1/2 sum_q sum_f <P[f][j_q], dA[q][f]>.
+//   column phase  L lanes per unique feature j of the batch: for every field f the row P[f][j] is
+//                 read once, the touches' contribution rows are combined in sample order, the row
+//                 is written once.  One extra workgroup closes the batch (as in mb_fm.hip).
+#include "fm_device.h"
 #include "mb.h"
 
 namespace nfm {
 
-int mb_ffm_epoch(nfm_ctx*, int, const CsrView&, const ModelView&, const OptView&, const Plan&, MbWork&, int64_t, double*) {
-  return set_error(NFM_ERR_UNSUPPORTED, "mini-batch mode for FFM is not implemented yet; use NFM_MODE_SEQUENTIAL");
+struct SampleRec {
+  double dL, etaP, etaw, pad;
+};
+struct PartA {
+  double loss, viol, acc0, acc1;
+};
+constexpr int kFtab = 64;
+
+// defined in mb_fm.hip
+__global__ void k_schedule(OptView O, int fit_linear, int fit_intercept, const int64_t* __restrict__ bat_pos,
+                           const double* __restrict__ it0p, double* __restrict__ Dtab, double* __restrict__ Ftab);
+__global__ void k_scale_prefix(double* __restrict__ sc, const double* __restrict__ Dtab, double* __restrict__ Stab, int64_t nb);
+__global__ void k_epoch_close(const double* __restrict__ parts, int n, double* __restrict__ out_acc);
+__global__ void k_set_double(double* p, double v);
+
+struct FRowArgs {
+  CsrView X;
+  ModelView M;
+  OptView O;
+  const int64_t* perm;
+  const int64_t* toff;  // touch offset of every sample of the epoch call
+  int64_t begin, p0, t_base;  // t_base = toff of the batch's first sample
+  int32_t len, use_stored;
+  double it_b;
+  const double* it0p;
+  const double* scales;
+  double* contrib;  // [batch touches][F][Kp]
+  SampleRec* rec;
+  PartA* parts;
+};
+
+template <int L, int OPT>
+__global__ __launch_bounds__(kBlock) void k_ffm_row_phase(FRowArgs a) {
+  constexpr int R = kWave / L;
+  __shared__ double red[kWavesPerBlock][4];
+  const CsrView& X = a.X;
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int pib = blockIdx.x * kWavesPerBlock + wv;
+  double r_loss = 0.0, r_acc0 = 0.0, r_acc1 = 0.0;
+  if (pib < a.len) {
+    const int64_t pos = a.p0 + pib;
+    const int64_t i = a.perm ? a.perm[pos] : a.begin + pos;
+    const int64_t q0 = X.indptr[i];
+    const int m = (int)(X.indptr[i + 1] - q0);
+    const int F = M.nb;
+    const double y = dev::target_of(X.y[i], M.task);
+    const double itp = (a.it0p[0] + a.it_b) - 1.0;
+    const bool stored = a.use_stored != 0;
+    double b0 = M.sc[SC_INTERCEPT];
+    const double sP = OPT == OPT_SGD ? a.scales[0] : 1.0, sw = OPT == OPT_SGD ? a.scales[1] : 1.0;
+    if (OPT == OPT_ADAGRAD && !stored && M.fit_intercept)
+      b0 = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * itp * O.alpha0);
+    const double tmpP = O.eta0 * itp * O.beta, denw = itp * O.eta0 * O.alpha;
+    auto load_p = [&](size_t e) -> double2 {
+      if (OPT == OPT_SGD || stored) {
+        double2 v = *reinterpret_cast<const double2*>(M.P + e);
+        v.x *= sP;
+        v.y *= sP;
+        return v;
+      }
+      const double2 gg = *reinterpret_cast<const double2*>(O.G + e);
+      const double2 nn = *reinterpret_cast<const double2*>(O.N + e);
+      double2 v;
+      v.x = dev::adagrad_param(gg.x, nn.x, O.eta0, tmpP);
+      v.y = dev::adagrad_param(gg.y, nn.y, O.eta0, tmpP);
+      return v;
+    };
+    double part = 0.0;
+    for (int q = lane; q < m; q += kWave) {
+      const int j = X.indices[q0 + q];
+      double wj = sw * M.w[j];
+      if (OPT == OPT_ADAGRAD && !stored && M.fit_linear) wj = -O.eta0 * O.Gw[j] / (denw + sqrt(O.Nw[j]));
+      part += wj * X.data[q0 + q];
+    }
+    double* C = a.contrib + (size_t)(a.toff[pos] - a.t_base) * F * M.Kp;
+    const int n_out = m * F;
+    for (int ob = 0; ob < n_out; ob += R) {
+      const int o = ob + g;
+      if (o < n_out) {
+        const int q = o / F, f = o % F;
+        const int jq = X.indices[q0 + q], fq = X.fields[q0 + q];
+        const double xq = X.data[q0 + q];
+        double2 v = {0.0, 0.0};
+        for (int q2 = 0; q2 < m; ++q2) {
+          if (X.fields[q0 + q2] != f) continue;
+          const int j2 = X.indices[q0 + q2];
+          if (j2 == jq) continue;
+          const double x2 = X.data[q0 + q2];
+          const double2 p = load_p(((size_t)fq * M.da + j2) * M.Kp + 2 * l);
+          // sgd_ffm.nim:29-30: dA += val1 * val2 * P  (left to right)
+          v.x += xq * x2 * p.x;
+          v.y += xq * x2 * p.y;
+        }
+        *reinterpret_cast<double2*>(C + ((size_t)q * F + f) * M.Kp + 2 * l) = v;
+        if (v.x != 0.0 || v.y != 0.0) {
+          const double2 pf = load_p(((size_t)f * M.da + jq) * M.Kp + 2 * l);
+          part += 0.5 * (pf.x * v.x + pf.y * v.y);
+        }
+      }
+    }
+    part = dev::wave_sum(part);
+    const double yh = b0 + part;
+    const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
+    r_loss = dev::loss_value(O.loss, O.loss_param, y, yh);
+    double etaP = 0.0, etaw = 0.0;
+    if (OPT == OPT_SGD) {
+      const double it = (a.it0p[0] + a.it_b) + (double)pib;
+      etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+      etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
+      if (M.fit_intercept) {
+        const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
+        r_acc0 = eta0 * dL;
+        r_acc1 = eta0;
+      }
+    } else if (M.fit_intercept) {
+      r_acc0 = dL;
+      r_acc1 = dL * dL;
+    }
+    if (lane == 0) a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
+  }
+  if (lane == 0) {
+    red[wv][0] = r_loss;
+    red[wv][1] = 0.0;
+    red[wv][2] = r_acc0;
+    red[wv][3] = r_acc1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PartA p{0.0, 0.0, 0.0, 0.0};
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) {
+      p.loss += red[w_][0];
+      p.acc0 += red[w_][2];
+      p.acc1 += red[w_][3];
+    }
+    a.parts[blockIdx.x] = p;
+  }
+}
+
+struct FColArgs {
+  ModelView M;
+  OptView O;
+  const int32_t* ucol;
+  const int64_t* uptr;
+  const int32_t* tpos;
+  const double* tx;
+  const int64_t* tq;  // sample-order touch index of every sorted touch
+  int64_t u0, u1, t_base;
+  const double* scales_b;
+  const double* scales_n;
+  const double* Dtab_b;
+  const double* Ftab_b;
+  const double* contrib;
+  const SampleRec* rec;
+  double* parts;
+  const PartA* partsA;
+  const double* parts_prev;
+  double* out_acc;
+  double it_b, len;
+  const double* it0p;
+  int32_t use_stored, nA, n_prev;
+};
+
+template <int L, int OPT>
+__global__ __launch_bounds__(kBlock) void k_ffm_col_phase(FColArgs a) {
+  constexpr int R = kWave / L;
+  __shared__ double red[5][kBlock];
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const bool closer = blockIdx.x == gridDim.x - 1;
+  const int64_t u = closer ? a.u1 : a.u0 + ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  const double itp = (a.it0p[0] + a.it_b) - 1.0;
+  double viol = 0.0;
+  if (u < a.u1) {
+    const int64_t j = a.ucol[u];
+    const int64_t t0 = a.uptr[u], t1 = a.uptr[u + 1];
+    const int F = M.nb;
+    const double c = (double)(t1 - t0);
+    double sP = 1.0, sPn = 1.0, sw = 1.0, swn = 1.0, fP = 1.0, fw = 1.0;
+    if (OPT == OPT_SGD) {
+      sP = a.scales_b[0]; sw = a.scales_b[1]; sPn = a.scales_n[0]; swn = a.scales_n[1];
+      const int64_t ci = t1 - t0;
+      if (ci > 1) {
+        if (ci <= kFtab) { fP = a.Ftab_b[ci - 1]; fw = a.Ftab_b[kFtab + ci - 1]; }
+        else { fP = pow(a.Dtab_b[0], 1.0 / c) / a.Dtab_b[0]; fw = pow(a.Dtab_b[1], 1.0 / c) / a.Dtab_b[1]; }
+      }
+    }
+    for (int f = 0; f < F; ++f) {
+      const size_t e = ((size_t)f * M.da + j) * M.Kp + 2 * l;
+      double2 st = {0.0, 0.0}, g2 = {0.0, 0.0}, n2 = {0.0, 0.0}, p;
+      if (OPT == OPT_SGD) {
+        st = *reinterpret_cast<const double2*>(M.P + e);
+        p.x = sP * st.x; p.y = sP * st.y;
+      } else {
+        g2 = *reinterpret_cast<const double2*>(O.G + e);
+        n2 = *reinterpret_cast<const double2*>(O.N + e);
+        if (a.use_stored) {
+          p = *reinterpret_cast<const double2*>(M.P + e);
+        } else {
+          const double tmp = O.eta0 * itp * O.beta;
+          p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmp);
+          p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmp);
+          if (O.track_viol) {
+            st = *reinterpret_cast<const double2*>(M.P + e);
+            viol += fabs(st.x - p.x) + fabs(st.y - p.y);
+            *reinterpret_cast<double2*>(M.P + e) = p;
+          }
+        }
+      }
+      double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
+      double seta = 0.0;
+      for (int64_t t = t0; t < t1; ++t) {
+        const SampleRec r = a.rec[a.tpos[t]];
+        const double2 v = *reinterpret_cast<const double2*>(a.contrib + ((size_t)(a.tq[t] - a.t_base) * F + f) * M.Kp + 2 * l);
+        if (OPT == OPT_SGD) {
+          acc.x += r.etaP * (r.dL * v.x);
+          acc.y += r.etaP * (r.dL * v.y);
+          seta += r.etaP;
+        } else {
+          const double gx = r.dL * v.x, gy = r.dL * v.y;
+          acc.x += gx; acc.y += gy;
+          accn.x += gx * gx; accn.y += gy * gy;
+        }
+      }
+      if (OPT == OPT_SGD) {
+        viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
+        st.x = st.x * fP - (acc.x / c) / sPn;
+        st.y = st.y * fP - (acc.y / c) / sPn;
+        *reinterpret_cast<double2*>(M.P + e) = st;
+      } else {
+        g2.x += acc.x; g2.y += acc.y; n2.x += accn.x; n2.y += accn.y;
+        *reinterpret_cast<double2*>(O.G + e) = g2;
+        *reinterpret_cast<double2*>(O.N + e) = n2;
+      }
+    }
+    if (M.fit_linear && l == 0) {
+      const double wt = M.w[j];
+      double a0 = 0.0, a1 = 0.0;
+      for (int64_t t = t0; t < t1; ++t) {
+        const SampleRec r = a.rec[a.tpos[t]];
+        const double x = a.tx[t];
+        if (OPT == OPT_SGD) { a0 += r.etaw * (r.dL * x); a1 += r.etaw; }
+        else { const double gw = r.dL * x; a0 += gw; a1 += gw * gw; }
+      }
+      if (OPT == OPT_SGD) {
+        const double wj = sw * wt;
+        viol += fabs((a0 + a1 * O.alpha * wj) / c);
+        M.w[j] = wt * fw - (a0 / c) / swn;
+      } else {
+        const double gw = O.Gw[j], nw = O.Nw[j];
+        if (!a.use_stored) {
+          const double wj = -O.eta0 * gw / (itp * O.eta0 * O.alpha + sqrt(nw));
+          viol += fabs(wt - wj);
+          M.w[j] = wj;
+        }
+        O.Gw[j] = gw + a0;
+        O.Nw[j] = nw + a1;
+      }
+    }
+  }
+  viol = dev::wave_sum(viol);
+  if (lane == 0) red[0][wv] = viol;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) v += red[0][w_];
+    a.parts[blockIdx.x] = v;
+  }
+  if (!closer) return;
+  __syncthreads();
+  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < a.nA; i += kBlock) {
+    const PartA p = a.partsA[i];
+    s[0] += p.loss; s[1] += p.viol; s[2] += p.acc0; s[3] += p.acc1;
+  }
+  for (int i = threadIdx.x; i < a.n_prev; i += kBlock) s[4] += a.parts_prev[i];
+  for (int cc = 0; cc < 5; ++cc) red[cc][threadIdx.x] = s[cc];
+  __syncthreads();
+  for (int st = kBlock / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st)
+      for (int cc = 0; cc < 5; ++cc) red[cc][threadIdx.x] += red[cc][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double v = red[1][0] + red[4][0];
+    if (M.fit_intercept) {
+      if (OPT == OPT_SGD) {
+        const double b0 = M.sc[SC_INTERCEPT], f0 = a.Dtab_b[3];
+        v += fabs((red[2][0] + red[3][0] * O.alpha0 * b0) / a.len);
+        M.sc[SC_INTERCEPT] = f0 * b0 - red[2][0] / a.len;
+      } else {
+        if (!a.use_stored) {
+          const double old = M.sc[SC_INTERCEPT];
+          const double nb_ = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * itp * O.alpha0);
+          v += fabs(old - nb_);
+          M.sc[SC_INTERCEPT] = nb_;
+        }
+        O.gsc[0] += red[2][0];
+        O.gsc[1] += red[3][0];
+      }
+    }
+    a.out_acc[0] += red[0][0];
+    a.out_acc[1] += v;
+  }
+}
+
+template <int L, int OPT>
+static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
+                   const std::vector<int64_t>& t_base) {
+  constexpr int R = kWave / L;
+  hipStream_t st = ctx->stream;
+  const double* Stab = W.Stab.as<double>();
+  const double* Dtab = W.Dtab.as<double>();
+  const double* it0p = W.itbuf.as<double>();
+  const size_t half = W.partsB.bytes / sizeof(double) / 2;
+  int n_prev = 0;
+  for (int64_t b = 0; b < P.n_batches; ++b) {
+    const int64_t p0 = P.bat_pos[b];
+    const int len = (int)(P.bat_pos[b + 1] - p0);
+    const int use_stored = (OPT == OPT_ADAGRAD && P.first_singleton && b == 0) ? 1 : 0;
+    const int nA = (len + kWavesPerBlock - 1) / kWavesPerBlock;
+    {
+      FRowArgs ra{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, P.toff.as<int64_t>(), P.begin, p0, t_base[b], len,
+                  use_stored, (double)p0, it0p, OPT == OPT_SGD ? Stab + 2 * b : M.sc, W.contrib.as<double>(),
+                  W.rec.as<SampleRec>(), W.partsA.as<PartA>()};
+      TimedLaunch tl(ctx, "row_phase");
+      hipLaunchKernelGGL((k_ffm_row_phase<L, OPT>), dim3(nA), dim3(kBlock), 0, st, ra);
+    }
+    const int64_t u0 = P.bat_uoff[b], u1 = P.bat_uoff[b + 1];
+    const int per_block = kWavesPerBlock * R;
+    const int nB = (int)((u1 - u0 + per_block - 1) / per_block) + 1;
+    {
+      FColArgs ca{M, O, P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(),
+                  P.tq.as<int64_t>(), u0, u1, t_base[b], OPT == OPT_SGD ? Stab + 2 * b : M.sc,
+                  OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc, OPT == OPT_SGD ? Dtab + 4 * b : nullptr,
+                  OPT == OPT_SGD ? W.Ftab.as<double>() + (size_t)b * 2 * kFtab : nullptr, W.contrib.as<double>(),
+                  W.rec.as<SampleRec>(), W.partsB.as<double>() + (b & 1) * half, W.partsA.as<PartA>(),
+                  W.partsB.as<double>() + ((b + 1) & 1) * half, W.out_acc.as<double>(), (double)p0, (double)len, it0p,
+                  use_stored, nA, n_prev};
+      TimedLaunch tl(ctx, "col_phase");
+      hipLaunchKernelGGL((k_ffm_col_phase<L, OPT>), dim3(nB), dim3(kBlock), 0, st, ca);
+    }
+    n_prev = nB;
+  }
+  if (P.n_batches > 0)
+    hipLaunchKernelGGL(k_epoch_close, dim3(1), dim3(kBlock), 0, st, W.partsB.as<double>() + ((P.n_batches - 1) & 1) * half,
+                       n_prev, W.out_acc.as<double>());
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+
+int mb_ffm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
+                 int64_t it0, double* out2_host) {
+  NFM_CHECK(M.kind == NFM_KIND_FFM, NFM_ERR_UNSUPPORTED, "mb_ffm_epoch: FFM only");
+  NFM_CHECK(M.Kp == 2 * M.L && M.Kp <= 128, NFM_ERR_UNSUPPORTED, "mini-batch mode supports n_components <= 128");
+  NFM_CHECK(P.toff.p && (P.TM == 0 || P.tq.p), NFM_ERR_INVALID, "FFM plan lacks the touch tables");
+  hipStream_t st = ctx->stream;
+  // touch base of every batch and the largest batch (in touches): from the plan's toff
+  const int64_t ns = P.end - P.begin;
+  std::vector<int64_t> toff_h((size_t)ns + 1);
+  NFM_HIP_CHECK(hipMemcpyAsync(toff_h.data(), P.toff.p, sizeof(int64_t) * (ns + 1), hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  std::vector<int64_t> t_base((size_t)P.n_batches + 1);
+  int64_t max_t = 1;
+  for (int64_t b = 0; b <= P.n_batches; ++b) t_base[b] = toff_h[P.bat_pos[b]];
+  for (int64_t b = 0; b < P.n_batches; ++b) max_t = std::max(max_t, t_base[b + 1] - t_base[b]);
+  NFM_TRY(W.contrib.ensure(sizeof(double) * (size_t)max_t * M.nb * M.Kp));
+  NFM_TRY(W.rec.ensure(sizeof(SampleRec) * (size_t)std::max<int64_t>(P.max_batch, 1)));
+  NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch / kWavesPerBlock + 1)));
+  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique / kWavesPerBlock + 2)));
+  NFM_TRY(W.Dtab.ensure(sizeof(double) * 4 * (size_t)(P.n_batches + 1)));
+  NFM_TRY(W.Stab.ensure(sizeof(double) * 2 * (size_t)(P.n_batches + 1)));
+  NFM_TRY(W.Ftab.ensure(sizeof(double) * 2 * kFtab * (size_t)(P.n_batches + 1)));
+  NFM_TRY(W.out_acc.ensure(sizeof(double) * 2));
+  NFM_TRY(W.itbuf.ensure(sizeof(double)));
+  hipLaunchKernelGGL(k_set_double, dim3(1), dim3(1), 0, st, W.itbuf.as<double>(), (double)it0);
+  NFM_HIP_CHECK(hipMemsetAsync(W.out_acc.p, 0, sizeof(double) * 2, st));
+  if (P.n_batches > 0 && opt_kind == OPT_SGD) {
+    TimedLaunch tl(ctx, "schedule");
+    hipLaunchKernelGGL(k_schedule, dim3((unsigned)P.n_batches), dim3(kBlock), 0, st, O, M.fit_linear, M.fit_intercept,
+                       P.bat_pos_dev.as<int64_t>(), W.itbuf.as<double>(), W.Dtab.as<double>(), W.Ftab.as<double>());
+    hipLaunchKernelGGL(k_scale_prefix, dim3(1), dim3(1), 0, st, M.sc, W.Dtab.as<double>(), W.Stab.as<double>(), P.n_batches);
+  }
+  int rc = NFM_ERR_UNSUPPORTED;
+#define NFM_RUN(LL)                                                                         \
+  case LL:                                                                                  \
+    rc = opt_kind == OPT_SGD ? run_ffm<LL, OPT_SGD>(ctx, X, M, O, P, W, t_base)             \
+                             : run_ffm<LL, OPT_ADAGRAD>(ctx, X, M, O, P, W, t_base);        \
+    break;
+  switch (M.L) {
+    NFM_RUN(1) NFM_RUN(2) NFM_RUN(4) NFM_RUN(8) NFM_RUN(16) NFM_RUN(32) NFM_RUN(64)
+  }
+#undef NFM_RUN
+  NFM_TRY(rc);
+  NFM_HIP_CHECK(hipMemcpyAsync(out2_host, W.out_acc.p, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  return NFM_OK;
 }
 
 }  // namespace nfm

@@ -8,7 +8,7 @@ namespace nfm {
 // For batch b (samples bat_pos[b]..bat_pos[b+1]) relative to `begin`):
 //   unique features  ucol[u], u in [bat_uoff[b], bat_uoff[b+1])
 //   touches of ucol[u]: t in [uptr[u], uptr[u+1]) -> (tpos[t] = sample position inside the batch,
-//   tx[t] = value, tq[t] = nnz position in the CSR arrays or -1 for a dummy feature),
+//   tx[t] = value, tq[t] = the touch's index in SAMPLE order, toff[pos] + q, where the row phase left its data),
 //   sorted by sample position (stable sort) so that every per-feature sum has a fixed order.
 struct Plan {
   // identity (cache key)
@@ -28,7 +28,7 @@ struct Plan {
   DevBuf tpos;                    // int32[TM]
   DevBuf tx;                      // double[TM]
   DevBuf tq;                      // int64[TM] (only when want_tq)
-  DevBuf toff;                    // int64[end-begin+1] touch offset of every sample (only with use_singles)
+  DevBuf toff;                    // int64[end-begin+1] touch offset of every sample (with use_singles / want_tq)
   DevBuf single;                  // uint8[T] in sample order: 1 = the feature is touched once in its batch
   void release();
 };

@@ -70,7 +70,7 @@ __global__ void k_expand(CsrView X, const int64_t* __restrict__ perm, int64_t be
       vals[t] = (uint32_t)t;
       tpos_un[t] = pib;
       tx_un[t] = q < m ? X.data[q0 + q] : 1.0;
-      if (tq_un) tq_un[t] = q < m ? q0 + q : -1;
+      if (tq_un) tq_un[t] = t;  // the touch's index in sample order (row-phase contribution slot)
     }
   }
 }
@@ -100,7 +100,7 @@ __global__ void k_compact(int64_t T, const uint64_t* __restrict__ keys, const ui
                           const int32_t* __restrict__ tpos_un, const double* __restrict__ tx_un,
                           const int64_t* __restrict__ tq_un, int32_t* __restrict__ tpos, double* __restrict__ tx,
                           int64_t* __restrict__ tq, int32_t* __restrict__ ucol, int64_t* __restrict__ uptr,
-                          int64_t* __restrict__ bat_first_u) {
+                          int64_t* __restrict__ ubatch) {
   const uint64_t fmask = (fbits >= 64) ? ~0ull : ((1ull << fbits) - 1);
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < T; r += (int64_t)gridDim.x * blockDim.x) {
     const int64_t mp = mpos[r];
@@ -114,9 +114,15 @@ __global__ void k_compact(int64_t T, const uint64_t* __restrict__ keys, const ui
       const uint64_t key = keys[r];
       ucol[u] = (int32_t)(key & fmask);
       uptr[u] = mp;
-      atomicMin(reinterpret_cast<unsigned long long*>(bat_first_u + (key >> fbits)), (unsigned long long)u);
+      ubatch[u] = (int64_t)(key >> fbits);
     }
   }
+}
+
+// first unique feature of every batch that has one
+__global__ void k_batch_first(int64_t U, const int64_t* __restrict__ ubatch, int64_t* __restrict__ bat_first_u) {
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x)
+    if (u == 0 || ubatch[u - 1] != ubatch[u]) bat_first_u[ubatch[u]] = u;
 }
 
 __global__ void k_set_i64(int64_t* p, int64_t n, int64_t v) {
@@ -230,14 +236,17 @@ int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_ho
   if (want_tq) NFM_TRY(P.tq.alloc(sizeof(int64_t) * TM));
   NFM_TRY(P.ucol.alloc(sizeof(int32_t) * U));
   NFM_TRY(P.uptr.alloc(sizeof(int64_t) * (U + 1)));
-  DevBuf bfu;
+  DevBuf bfu, ubatch;
   NFM_TRY(bfu.alloc(sizeof(int64_t) * P.n_batches));
+  NFM_TRY(ubatch.alloc(sizeof(int64_t) * (U + 1)));
   const int64_t none = INT64_MAX;
   hipLaunchKernelGGL(k_set_i64, dim3(grid1d(P.n_batches)), dim3(kBlock), 0, st, bfu.as<int64_t>(), P.n_batches, none);
   hipLaunchKernelGGL(k_compact, dim3(grid1d(T)), dim3(kBlock), 0, st, T, keys, vals, mpos.as<int64_t>(), uidx.as<int64_t>(),
                      fbits, tpos_un.as<int32_t>(), tx_un.as<double>(), want_tq ? tq_un.as<int64_t>() : nullptr,
                      P.tpos.as<int32_t>(), P.tx.as<double>(), want_tq ? P.tq.as<int64_t>() : nullptr, P.ucol.as<int32_t>(),
-                     P.uptr.as<int64_t>(), bfu.as<int64_t>());
+                     P.uptr.as<int64_t>(), ubatch.as<int64_t>());
+  if (U > 0)
+    hipLaunchKernelGGL(k_batch_first, dim3(grid1d(U)), dim3(kBlock), 0, st, U, ubatch.as<int64_t>(), bfu.as<int64_t>());
   NFM_HIP_CHECK(hipGetLastError());
   NFM_HIP_CHECK(hipMemcpyAsync(P.uptr.as<int64_t>() + U, &TM, sizeof(int64_t), hipMemcpyHostToDevice, st));
   std::vector<int64_t> first(P.n_batches);
@@ -247,7 +256,7 @@ int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_ho
   for (int64_t b = P.n_batches - 1; b >= 0; --b) P.bat_uoff[b] = first[b] != none ? first[b] : P.bat_uoff[b + 1];
   P.max_unique = 0;
   for (int64_t b = 0; b < P.n_batches; ++b) P.max_unique = std::max(P.max_unique, P.bat_uoff[b + 1] - P.bat_uoff[b]);
-  if (use_singles) {  // the row phase finds a sample's flags at single[toff[pos] + q]
+  if (use_singles || want_tq) {  // the row phase finds a sample's per-nnz slots at toff[pos] + q
     P.toff.p = toff.p; P.toff.bytes = toff.bytes;
     toff.p = nullptr; toff.bytes = 0;
   }

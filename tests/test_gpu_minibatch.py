@@ -200,3 +200,47 @@ def test_sparse_regime_singles(k, batch):
     assert abs(fm.intercept - b) < 1e-11
     assert_close(fm.w, w, RTOL, ATOL, "w")
     assert_close(fm.P, P, RTOL, ATOL, "P")
+
+
+@pytest.mark.parametrize("k,F,batch", [(4, 5, 1), (4, 5, 7), (8, 16, 64), (30, 3, 80)])
+def test_ffm_minibatch_vs_mb_oracle(k, F, batch):
+    """FieldAwareFactorizationMachine through the mini-batch kernels (mb_ffm.hip), SGD and AdaGrad."""
+    from common import init_ffm, make_ffm_dataset
+    from gpu_common import gpu_ffm
+    n, d = 120, {5: 60, 16: 48, 3: 48}[F]  # d divisible by F (tests/utils.nim:66-68)
+    Xo, Xd, field_of, y = make_ffm_dataset(n, d, F, k, 42, threshold=0.6)
+    P0, w0, b0 = init_ffm(d, F, k, scale=0.05)
+    perms = make_perms(n, 3)
+    X = to_gpu(Xo)
+    P, w, b, it = P0.copy(), w0.copy(), b0, 1
+    hist = []
+    for e in range(3):
+        b, it, ls, vs = O.ffm_sgd_epoch_mb(Xo, y, P, w, b, O.sgd_cfg(eta0=0.002), batch, perm=perms[e], it=it)
+        hist.append((vs, ls / n))
+    assert np.isfinite(b)
+    ffm = gpu_ffm("regression", k, True, True, P0, w0, b0)
+    sgd = nf.newSGD(maxIter=3, verbose=0, tol=0, eta0=0.002, mode="minibatch", batch=batch)
+    sgd.fit(X, y, ffm, perms=perms)
+    assert abs(ffm.intercept - b) < 1e-11
+    assert_close(ffm.w, w, RTOL, ATOL, "w")
+    assert_close(ffm.P, P, RTOL, ATOL, "P")
+    assert_close([h[1] for h in sgd.history], [h[1] for h in hist], 1e-10, 1e-13, "loss")
+    assert_close([h[0] for h in sgd.history], [h[0] for h in hist], 1e-9, 1e-12, "viol")
+    if batch == 1:
+        Pf, wf, bf, *_ = O.ffm_sgd_fit(Xo, y, P0, w0, b0, O.sgd_cfg(eta0=0.002), 3, perms=perms)
+        assert_close(ffm.P, Pf, 1e-8, 1e-11, "P vs sequential")
+    cfg = O.adagrad_cfg()
+    P, w, b, it = P0.copy(), w0.copy(), b0, 1
+    st = O.AdaState(F, d, k, d)
+    hist = []
+    for e in range(3):
+        b, it, ls, vs = O.ffm_adagrad_epoch_mb(Xo, y, P, w, b, cfg, batch, st, perm=perms[e], it=it)
+        hist.append(vs)
+    b = O.ffm_adagrad_finalize(P, w, b, cfg, it, st)
+    ffm = gpu_ffm("regression", k, True, True, P0, w0, b0)
+    ada = nf.newAdaGrad(maxIter=3, verbose=0, tol=0, mode="minibatch", batch=batch)
+    ada.fit(X, y, ffm, perms=perms)
+    assert abs(ffm.intercept - b) < 1e-11
+    assert_close(ffm.w, w, RTOL, ATOL, "w")
+    assert_close(ffm.P, P, RTOL, ATOL, "P")
+    assert_close([h[0] for h in ada.history], hist, 1e-9, 1e-12, "viol")
