@@ -29,7 +29,7 @@ WORKLOADS = {
     # cfg2 names no batch size; 32768 keeps the two dependent launches per batch off the critical path
     # (DESIGN.md section 7).  cfg3 / headline use the 8192 that BASELINE.json states.
     "cfg2": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768),
-    "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="squared", batch=8192),
+    "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="logistic", batch=8192),
     "cfg3": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="squared", batch=8192),
     "tiny": dict(n=50_000, d=5_000, m=16, k=8, degree=2, solver="sgd", loss="logistic", batch=4096),
 }

@@ -200,6 +200,7 @@ int32_t nfm_dataset_create_csr(nfm_ctx* ctx, int64_t n, int64_t d, const int64_t
   ds->v.fields = fields ? ds->fields.as<int32_t>() : nullptr;
   ds->v.y = ds->has_y ? ds->y.as<double>() : nullptr;
   ds->v.n = n; ds->v.d = d; ds->v.nnz = nnz; ds->v.n_fields = fields ? (int32_t)n_fields : 0;
+  ds->v.max_row = max_row;
   *out = ds.release();
   return NFM_OK;
 }
@@ -228,6 +229,7 @@ int32_t nfm_dataset_create_csr_device(nfm_ctx* ctx, int64_t n, int64_t d, int64_
   ds->has_y = y_dev != nullptr;
   ds->v.indptr = indptr_dev; ds->v.indices = indices_dev; ds->v.data = data_dev; ds->v.fields = fields_dev;
   ds->v.y = y_dev; ds->v.n = n; ds->v.d = d; ds->v.nnz = nnz; ds->v.n_fields = fields_dev ? (int32_t)n_fields : 0;
+  ds->v.max_row = (int32_t)mr;
   *out = ds.release();
   return NFM_OK;
 }

@@ -58,6 +58,7 @@ struct CsrView {
   const double* y;
   int64_t n, d, nnz;
   int32_t n_fields;
+  int32_t max_row;  // longest row (stored entries)
 };
 
 enum { SC_SCALE_P = 0, SC_SCALE_W = 1, SC_INTERCEPT = 2, SC_COUNT = 8 };

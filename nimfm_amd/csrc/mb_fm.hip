@@ -160,9 +160,15 @@ __device__ __forceinline__ double row_forward(const PS& ps, const CsrView& X, co
   return part;
 }
 
-template <int L, int SPLIT, int OPT, bool GEN>
+// NQ > 0 (SGD, single order of degree 2, rows of at most SPLIT*NQ entries): every lane keeps the NQ
+// parameter-row pieces it gathered for the forward pass in registers, so the in-place update of
+// the singles needs no second visit of the rows (HBM traffic of the row phase = the rows read once
+// + the single-touch rows written once).  NQ = 0: rows are streamed and singles re-read.
+template <int L, int SPLIT, int OPT, bool GEN, int NQ>
 __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   constexpr int LPS = L * SPLIT, SPW = kWave / LPS, SPB = kWavesPerBlock * SPW;  // samples per wave / block
+  constexpr bool REG = NQ > 0 && OPT == OPT_SGD && !GEN;
+  double2 prow[REG ? NQ : 1];
   __shared__ double s_y[SPB], s_yh[SPB], s_dL[SPB], s_etaP[SPB], s_etaw[SPB];
   __shared__ double s_part[4], s_viol[kWavesPerBlock];
   const CsrView& X = a.X;
@@ -191,7 +197,35 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   const double itp = (a.it0p[0] + a.it_b) - 1.0;  // AdaGrad: it' = it_b - 1 (adagrad.nim:90)
   const bool stored = a.use_stored != 0;
   // ---- 1. forward: yhat of every sample of the block ----
-  if (OPT == OPT_SGD) {
+  if (REG) {
+    const double sP = a.scales[0], sw = a.scales[1];
+    for (int q = slot * L + l; q < m; q += LPS) part += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
+    int jj[REG ? NQ : 1];
+    double xx[REG ? NQ : 1];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) dev::row_entry(X, q0, m, m_tot, slot + u * SPLIT, jj[u], xx[u]);
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) prow[u] = *reinterpret_cast<const double2*>(M.P + (size_t)jj[u] * M.Kp + 2 * l);
+    double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const double tx = xx[u] * (sP * prow[u].x), ty = xx[u] * (sP * prow[u].y);
+      a1.x += tx;
+      a1.y += ty;
+      a2.x += tx * tx;
+      a2.y += ty * ty;
+    }
+#pragma unroll
+    for (int s = L; s < L * SPLIT; s <<= 1) {
+      a1.x += dev::shfl_xor_d(a1.x, s);
+      a1.y += dev::shfl_xor_d(a1.y, s);
+      a2.x += dev::shfl_xor_d(a2.x, s);
+      a2.y += dev::shfl_xor_d(a2.y, s);
+    }
+    A1 = a1;
+    if (valid && slot == 0) *reinterpret_cast<double2*>(Arow + 2 * l) = A1;
+    if (slot == 0) part += (a1.x * a1.x - a2.x) / 2 + (a1.y * a1.y - a2.y) / 2;
+  } else if (OPT == OPT_SGD) {
     const double sP = a.scales[0], sw = a.scales[1];
     for (int q = slot * L + l; q < m; q += LPS) part += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
     const dev::PlainParams ps{M.P, sP};
@@ -265,7 +299,37 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   double r_viol = 0.0;
   // ---- 3. singles: a feature this sample alone touches in the batch gets its update right here
   // (same arithmetic as the column phase with c = 1), so its row is read and written once ----
-  if (!GEN && a.single != nullptr && valid) {
+  if (REG && a.single != nullptr && valid) {
+    const uint8_t* sg = a.single + a.toff[a.p0 + pib];
+    const double sP = a.scales[0], sw = a.scales[1], sPn = a.scales_n[0], swn = a.scales_n[1];
+    bool f[REG ? NQ : 1];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int qq = slot + u * SPLIT;
+      f[u] = qq < m_tot && sg[qq] != 0;
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      if (!f[u]) continue;
+      int j;
+      double xv;
+      dev::row_entry(X, q0, m, m_tot, slot + u * SPLIT, j, xv);
+      double2 st = prow[u];
+      const double px = sP * st.x, py = sP * st.y;
+      const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
+      const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
+      r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
+      st.x = st.x - ax / sPn;
+      st.y = st.y - ay / sPn;
+      *reinterpret_cast<double2*>(M.P + (size_t)j * M.Kp + 2 * l) = st;
+      if (M.fit_linear && j < M.d && l == 0) {
+        const double wt = M.w[j], wj = sw * wt;
+        const double a0 = etaw * (dL * xv);
+        r_viol += fabs(a0 + etaw * O.alpha * wj);
+        M.w[j] = wt - a0 / swn;
+      }
+    }
+  } else if (!GEN && a.single != nullptr && valid) {
     const uint8_t* sg = a.single + a.toff[a.p0 + pib];
     const double sP = a.scales[0], sw = a.scales[1], sPn = a.scales_n[0], swn = a.scales_n[1];
     const double tmpP = O.eta0 * itp * O.beta, denw = itp * O.eta0 * O.alpha;
@@ -690,10 +754,16 @@ __global__ __launch_bounds__(kBlock) void k_epoch_close(const double* __restrict
 // host driver
 // ------------------------------------------------------------------------------------------------
 template <int L, int SPLIT, int OPT, bool GEN>
-static void launch_row(hipStream_t st, const RowArgs& ra) {
+static void launch_row(hipStream_t st, const RowArgs& ra, int nq) {
   constexpr int SPW = kWave / (L * SPLIT);
   const int nA = (ra.len + kWavesPerBlock * SPW - 1) / (kWavesPerBlock * SPW);
-  hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN>), dim3(nA), dim3(kBlock), 0, st, ra);
+  constexpr bool CAN_REG = OPT == OPT_SGD && !GEN && L >= 8;  // register-resident rows: k >= 16
+  if (CAN_REG && nq == 16)
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 16 : 0)>), dim3(nA), dim3(kBlock), 0, st, ra);
+  else if (CAN_REG && nq == 32)
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 32 : 0)>), dim3(nA), dim3(kBlock), 0, st, ra);
+  else
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0>), dim3(nA), dim3(kBlock), 0, st, ra);
 }
 
 template <int L, int OPT, bool GEN>
@@ -713,6 +783,12 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     const int use_stored = (OPT == OPT_ADAGRAD && P.first_singleton && b == 0) ? 1 : 0;
     const double it_b = (double)p0;
     const int split = choose_split(L, len, avg_row, ctx->n_cu);
+    // rows per lane to keep in registers (0 = stream): only when the batch has singles to update
+    auto nq_for = [&](int s_used) {
+      if (OPT != OPT_SGD || GEN || !P.use_singles) return 0;
+      const int need = (X.max_row + M.n_aug + s_used - 1) / s_used;
+      return need <= 16 ? 16 : (need <= 32 ? 32 : 0);
+    };
     int nA;
     {
       RowArgs ra{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, P.begin, p0, len, use_stored, TA, 0, it_b, it0p,
@@ -722,11 +798,11 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
                  W.partsA.as<PartA>()};
       TimedLaunch tl(ctx, "row_phase");
       int s_used;
-      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra); s_used = R >= 16 ? 16 : R; }
-      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra); s_used = R >= 8 ? 8 : R; }
-      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra); s_used = R >= 4 ? 4 : R; }
-      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT, GEN>(st, ra); s_used = R >= 2 ? 2 : R; }
-      else { launch_row<L, 1, OPT, GEN>(st, ra); s_used = 1; }
+      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra, nq_for(R >= 16 ? 16 : R)); s_used = R >= 16 ? 16 : R; }
+      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra, nq_for(R >= 8 ? 8 : R)); s_used = R >= 8 ? 8 : R; }
+      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra, nq_for(R >= 4 ? 4 : R)); s_used = R >= 4 ? 4 : R; }
+      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT, GEN>(st, ra, nq_for(R >= 2 ? 2 : R)); s_used = R >= 2 ? 2 : R; }
+      else { launch_row<L, 1, OPT, GEN>(st, ra, nq_for(1)); s_used = 1; }
       const int spw = kWave / (L * s_used);
       nA = (len + kWavesPerBlock * spw - 1) / (kWavesPerBlock * spw);
     }
