@@ -161,6 +161,25 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = n * world / (dt / args.steps)
 
+    # ---- predict samples/s (the metric's second half): decisionFunction over the shard, output on device ----
+    pred = None
+    if rank == 0:
+        out_dev = torch.empty(n, dtype=torch.float64, device=dev)
+        opt._finalize_into(fm)
+        mh = fm._push(ctx)
+        for _ in range(2):
+            capi.check(capi.lib().nfm_decision_function_device(mh, X.h, out_dev.data_ptr()))
+        ctx.synchronize()
+        tp = time.perf_counter()
+        reps_p = 10
+        for _ in range(reps_p):
+            capi.check(capi.lib().nfm_decision_function_device(mh, X.h, out_dev.data_ptr()))
+        ctx.synchronize()
+        tp = (time.perf_counter() - tp) / reps_p
+        pbytes = 12 * m + 8 + 8 * m * k + 8 * m + 8  # SURVEY.md 8(d) predict bytes per sample
+        pred = {"value": round(n / tp, 1), "unit": "samples/s", "ms": round(tp * 1e3, 4),
+                "roofline_frac": round(pbytes * n / tp / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": pbytes}
+
     # ---- roofline leg: per-kernel durations from HIP events on the library's stream ----
     roof = None
     if rank == 0:
@@ -199,20 +218,21 @@ def main():
         P0 = np.random.default_rng(1).standard_normal((1, k, d)) * 0.01
         cfg = O.sgd_cfg(loss=wl["loss"]) if wl["solver"] == "sgd" else O.adagrad_cfg(loss=wl["loss"])
         tc = time.perf_counter()
+        cpu_epochs = 5  # ~10 s of single-thread work on cfg2
         if wl["solver"] == "sgd":
-            O.fm_sgd_fit(Xo, y[:nc], 2, P0, np.zeros(d), 0.0, cfg, 1)
+            O.fm_sgd_fit(Xo, y[:nc], 2, P0, np.zeros(d), 0.0, cfg, cpu_epochs)
         else:
-            O.fm_adagrad_fit(Xo, y[:nc], 2, P0, np.zeros(d), 0.0, cfg, 1)
-        t1 = time.perf_counter() - tc
+            O.fm_adagrad_fit(Xo, y[:nc], 2, P0, np.zeros(d), 0.0, cfg, cpu_epochs)
+        t1 = (time.perf_counter() - tc) / cpu_epochs
         threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
         th = None
         if wl["solver"] == "sgd":
             tc = time.perf_counter()
-            O.fm_sgd_fit(Xo, y[:nc], 2, P0, np.zeros(d), 0.0, cfg, 1, hogwild_threads=threads)
-            th = time.perf_counter() - tc
+            O.fm_sgd_fit(Xo, y[:nc], 2, P0, np.zeros(d), 0.0, cfg, cpu_epochs, hogwild_threads=threads)
+            th = (time.perf_counter() - tc) / cpu_epochs
         cpu = {"value": round(nc / t1, 1), "unit": "samples/s", "cores": 1, "kind": "port",
-               "sample": "one sequential epoch (optimizer/sgd.nim:261-328 semantics) over the first %d samples of "
-                         "the same shard, C restatement -O2, 1 thread" % nc,
+               "sample": "%d sequential epochs (optimizer/sgd.nim:261-328 semantics) over the first %d samples of "
+                         "the same shard, C restatement -O2, 1 thread" % (cpu_epochs, nc),
                "hogwild": None if th is None else {"value": round(nc / th, 1), "threads": threads,
                                                    "note": "optimizer/sgd_multi.nim semantics (racy), same port"}}
 
@@ -225,7 +245,7 @@ def main():
                                                           wl["loss"], args.batch),
                           "samples_per_gpu": n, "batch": args.batch,
                           "parallelism": "replicas=%d, parameter average per step" % world if world > 1 else "1 GPU"},
-               "last_step": {"mean_loss": last[0] / n, "viol": last[1]},
+               "last_step": {"mean_loss": last[0] / n, "viol": last[1]}, "predict": pred,
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:

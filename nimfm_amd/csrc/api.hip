@@ -608,7 +608,8 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         // second visit of the row only when they are a sizeable share of the touches.  With a touch
         // rate lambda = batch * nnz_per_row / d per feature that share is about exp(-lambda).
         const double lambda = (double)o->batch * ((double)ds->v.nnz / (double)std::max<int64_t>(ds->v.n, 1)) / (double)m->d;
-        const bool use_singles = m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2 && (o->batch == 1 || lambda <= 1.4);
+        bool use_singles = m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2 && (o->batch == 1 || lambda <= 1.4);
+        if (const char* env = getenv("NFM_SINGLES")) use_singles = use_singles && atoi(env) != 0;  // tuning override
         NFM_TRY(plan_build(ctx, ds->v, m->n_aug, perm, begin, end, o->batch, first_singleton, want_tq, use_singles, o->plan.get()));
         o->plan->ds = ds;
       }

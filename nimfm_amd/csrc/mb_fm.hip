@@ -440,6 +440,137 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// row phase, LDS-resident rows (SGD, single order of degree 2, batches with singles)
+//
+// One wavefront per sample at a time.  The sample's parameter rows are gathered straight into LDS
+// with global_load_lds_dwordx4 (per-lane source address, 1 KiB = 64/L rows per wave-instruction, no
+// VGPRs), every row is in flight at once; the forward pass reads them from LDS, and so does the
+// in-place update of the singles: HBM sees every row read once and the single-touch rows written
+// once, which is the algorithmic traffic.  Occupancy is set by LDS alone (rows * Kp * 8 B per wave).
+// ------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_row_phase_lds(RowArgs a, int m_cap) {
+  constexpr int R = kWave / L;
+  extern __shared__ __attribute__((aligned(16))) double lds_rows[];  // [waves][m_cap][Kp]
+  __shared__ double red[kWavesPerBlock][4];
+  const CsrView& X = a.X;
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int Kp = M.Kp;
+  double* wl = lds_rows + (size_t)wv * m_cap * Kp;
+  const double sP = a.scales[0], sw = a.scales[1], sPn = a.scales_n[0], swn = a.scales_n[1];
+  const double b0 = M.sc[SC_INTERCEPT];
+  double r_loss = 0.0, r_viol = 0.0, r_acc0 = 0.0, r_acc1 = 0.0;
+  for (int pib = blockIdx.x * kWavesPerBlock + wv; pib < a.len; pib += gridDim.x * kWavesPerBlock) {
+    const int64_t pos = a.p0 + pib;
+    const int64_t i = a.perm ? a.perm[pos] : a.begin + pos;
+    const int64_t q0 = X.indptr[i];
+    const int m = (int)(X.indptr[i + 1] - q0);
+    const int m_tot = m + M.n_aug;
+    const double y = dev::target_of(X.y[i], M.task);
+    const int iters = (m_tot + R - 1) / R;
+    // 1. every row of the sample on its way into LDS
+    for (int it = 0; it < iters; ++it) {
+      int j;
+      double x;
+      dev::row_entry(X, q0, m, m_tot, it * R + g, j, x);
+      const double* src = M.P + (size_t)j * Kp + 2 * l;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(wl + (size_t)it * R * Kp), 16, 0, 0);
+    }
+    double part = 0.0;
+    for (int q = lane; q < m; q += kWave) part += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA writes are not tracked by the compiler
+    __builtin_amdgcn_wave_barrier();
+    // 2. forward from LDS
+    double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
+    for (int it = 0; it < iters; ++it) {
+      int j;
+      double x;
+      dev::row_entry(X, q0, m, m_tot, it * R + g, j, x);
+      const double2 p = *reinterpret_cast<const double2*>(wl + ((size_t)it * R + g) * Kp + 2 * l);
+      const double tx = x * (sP * p.x), ty = x * (sP * p.y);
+      a1.x += tx;
+      a1.y += ty;
+      a2.x += tx * tx;
+      a2.y += ty * ty;
+    }
+#pragma unroll
+    for (int s = L; s < kWave; s <<= 1) {
+      a1.x += dev::shfl_xor_d(a1.x, s);
+      a1.y += dev::shfl_xor_d(a1.y, s);
+      a2.x += dev::shfl_xor_d(a2.x, s);
+      a2.y += dev::shfl_xor_d(a2.y, s);
+    }
+    if (g == 0) {
+      *reinterpret_cast<double2*>(a.Abuf + (size_t)pib * a.TA * Kp + 2 * l) = a1;
+      part += (a1.x * a1.x - a2.x) / 2 + (a1.y * a1.y - a2.y) / 2;
+    }
+    part = dev::wave_sum(part);
+    const double yh = b0 + part;
+    const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
+    const double it_abs = (a.it0p[0] + a.it_b) + (double)pib;
+    const double etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it_abs);
+    const double etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it_abs);
+    if (lane == 0) {
+      r_loss += dev::loss_value(O.loss, O.loss_param, y, yh);
+      a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
+      if (M.fit_intercept) {
+        const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it_abs);
+        r_acc0 += eta0 * dL;
+        r_acc1 += eta0;
+      }
+    }
+    // 3. singles, straight from LDS
+    const uint8_t* sg = a.single + a.toff[pos];
+    for (int it = 0; it < iters; ++it) {
+      const int q = it * R + g;
+      if (q < m_tot && sg[q] != 0) {
+        int j;
+        double xv;
+        dev::row_entry(X, q0, m, m_tot, q, j, xv);
+        double2 st = *reinterpret_cast<const double2*>(wl + (size_t)q * Kp + 2 * l);
+        const double px = sP * st.x, py = sP * st.y;
+        const double ax = etaP * (dL * (xv * (a1.x - px * xv)));
+        const double ay = etaP * (dL * (xv * (a1.y - py * xv)));
+        r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
+        st.x = st.x - ax / sPn;
+        st.y = st.y - ay / sPn;
+        *reinterpret_cast<double2*>(M.P + (size_t)j * Kp + 2 * l) = st;
+        if (M.fit_linear && j < M.d && l == 0) {
+          const double wt = M.w[j], wj = sw * wt;
+          const double a0 = etaw * (dL * xv);
+          r_viol += fabs(a0 + etaw * O.alpha * wj);
+          M.w[j] = wt - a0 / swn;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // LDS reads of this sample done before the next sample's DMA lands
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  r_viol = dev::wave_sum(r_viol);
+  if (lane == 0) {
+    red[wv][0] = r_loss;
+    red[wv][1] = r_viol;
+    red[wv][2] = r_acc0;
+    red[wv][3] = r_acc1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PartA p{0.0, 0.0, 0.0, 0.0};
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) {
+      p.loss += red[w_][0];
+      p.viol += red[w_][1];
+      p.acc0 += red[w_][2];
+      p.acc1 += red[w_][3];
+    }
+    a.parts[blockIdx.x] = p;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // column phase (+ batch close in workgroup 0)
 // ------------------------------------------------------------------------------------------------
 struct ColArgs {
@@ -786,6 +917,7 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     // rows per lane to keep in registers (0 = stream): only when the batch has singles to update
     auto nq_for = [&](int s_used) {
       if (OPT != OPT_SGD || GEN || !P.use_singles) return 0;
+      if (const char* env = getenv("NFM_NQ")) return atoi(env);  // tuning override
       const int need = (X.max_row + M.n_aug + s_used - 1) / s_used;
       return need <= 16 ? 16 : (need <= 32 ? 32 : 0);
     };
@@ -798,6 +930,22 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
                  W.partsA.as<PartA>()};
       TimedLaunch tl(ctx, "row_phase");
       int s_used;
+      // LDS-resident rows: SGD, degree 2, a batch with singles, rows that fit 160 KB per workgroup
+      const int m_cap = ((X.max_row + M.n_aug + R - 1) / R) * R;
+      const size_t lds_bytes = sizeof(double) * (size_t)kWavesPerBlock * std::max(m_cap, R) * M.Kp;
+      static const bool lds_on = !(getenv("NFM_LDS") && atoi(getenv("NFM_LDS")) == 0);
+      if (OPT == OPT_SGD && !GEN && P.use_singles && lds_on && lds_bytes <= 160 * 1024 - 256) {
+        auto kern = k_row_phase_lds<L>;
+        if (lds_bytes > 64 * 1024)
+          NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds_bytes));
+        int per_cu = (int)((160 * 1024) / (lds_bytes + 256));
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        nA = (len + kWavesPerBlock - 1) / kWavesPerBlock;
+        if (nA > ctx->n_cu * per_cu) nA = ctx->n_cu * per_cu;
+        hipLaunchKernelGGL(kern, dim3(nA), dim3(kBlock), lds_bytes, st, ra, std::max(m_cap, R));
+      } else {
       if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra, nq_for(R >= 16 ? 16 : R)); s_used = R >= 16 ? 16 : R; }
       else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra, nq_for(R >= 8 ? 8 : R)); s_used = R >= 8 ? 8 : R; }
       else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra, nq_for(R >= 4 ? 4 : R)); s_used = R >= 4 ? 4 : R; }
@@ -805,6 +953,7 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
       else { launch_row<L, 1, OPT, GEN>(st, ra, nq_for(1)); s_used = 1; }
       const int spw = kWave / (L * s_used);
       nA = (len + kWavesPerBlock * spw - 1) / (kWavesPerBlock * spw);
+      }
     }
     const int64_t u0 = P.bat_uoff[b], u1 = P.bat_uoff[b + 1];
     const int per_block = kWavesPerBlock * R;
