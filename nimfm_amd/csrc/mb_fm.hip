@@ -470,15 +470,22 @@ __global__ __launch_bounds__(kBlock) void k_row_phase_lds(RowArgs a, int m_cap) 
     const int m = (int)(X.indptr[i + 1] - q0);
     const int m_tot = m + M.n_aug;
     const double y = dev::target_of(X.y[i], M.task);
-    const int iters = (m_tot + R - 1) / R;
+    // The row's (index, value) slice is held one entry per lane (64 per chunk) and handed to the row
+    // slots with ds_bpermute: no vector-memory instruction sits between the LDS-DMA gathers, so all of
+    // them are in flight together (vmcnt counts them in order with ordinary loads).
+    const int n_chunks = (m_tot + kWave - 1) / kWave;
     // 1. every row of the sample on its way into LDS
-    for (int it = 0; it < iters; ++it) {
-      int j;
-      double x;
-      dev::row_entry(X, q0, m, m_tot, it * R + g, j, x);
-      const double* src = M.P + (size_t)j * Kp + 2 * l;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(wl + (size_t)it * R * Kp), 16, 0, 0);
+    for (int c = 0; c < n_chunks; ++c) {
+      int jl;
+      double xl;
+      dev::row_entry(X, q0, m, m_tot, c * kWave + lane, jl, xl);
+      const int len_c = min(kWave, m_tot - c * kWave);
+      for (int it = 0; it * R < len_c; ++it) {
+        const int j = __shfl(jl, it * R + g, kWave);
+        const double* src = M.P + (size_t)j * Kp + 2 * l;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(wl + ((size_t)c * kWave + it * R) * Kp), 16, 0, 0);
+      }
     }
     double part = 0.0;
     for (int q = lane; q < m; q += kWave) part += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
@@ -486,16 +493,20 @@ __global__ __launch_bounds__(kBlock) void k_row_phase_lds(RowArgs a, int m_cap) 
     __builtin_amdgcn_wave_barrier();
     // 2. forward from LDS
     double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
-    for (int it = 0; it < iters; ++it) {
-      int j;
-      double x;
-      dev::row_entry(X, q0, m, m_tot, it * R + g, j, x);
-      const double2 p = *reinterpret_cast<const double2*>(wl + ((size_t)it * R + g) * Kp + 2 * l);
-      const double tx = x * (sP * p.x), ty = x * (sP * p.y);
-      a1.x += tx;
-      a1.y += ty;
-      a2.x += tx * tx;
-      a2.y += ty * ty;
+    for (int c = 0; c < n_chunks; ++c) {
+      int jl;
+      double xl;
+      dev::row_entry(X, q0, m, m_tot, c * kWave + lane, jl, xl);
+      const int len_c = min(kWave, m_tot - c * kWave);
+      for (int it = 0; it * R < len_c; ++it) {
+        const double x = dev::shfl_d(xl, it * R + g);  // 0.0 past the row's end
+        const double2 p = *reinterpret_cast<const double2*>(wl + ((size_t)c * kWave + it * R + g) * Kp + 2 * l);
+        const double tx = x * (sP * p.x), ty = x * (sP * p.y);
+        a1.x += tx;
+        a1.y += ty;
+        a2.x += tx * tx;
+        a2.y += ty * ty;
+      }
     }
 #pragma unroll
     for (int s = L; s < kWave; s <<= 1) {
@@ -525,25 +536,33 @@ __global__ __launch_bounds__(kBlock) void k_row_phase_lds(RowArgs a, int m_cap) 
     }
     // 3. singles, straight from LDS
     const uint8_t* sg = a.single + a.toff[pos];
-    for (int it = 0; it < iters; ++it) {
-      const int q = it * R + g;
-      if (q < m_tot && sg[q] != 0) {
-        int j;
-        double xv;
-        dev::row_entry(X, q0, m, m_tot, q, j, xv);
-        double2 st = *reinterpret_cast<const double2*>(wl + (size_t)q * Kp + 2 * l);
-        const double px = sP * st.x, py = sP * st.y;
-        const double ax = etaP * (dL * (xv * (a1.x - px * xv)));
-        const double ay = etaP * (dL * (xv * (a1.y - py * xv)));
-        r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
-        st.x = st.x - ax / sPn;
-        st.y = st.y - ay / sPn;
-        *reinterpret_cast<double2*>(M.P + (size_t)j * Kp + 2 * l) = st;
-        if (M.fit_linear && j < M.d && l == 0) {
-          const double wt = M.w[j], wj = sw * wt;
-          const double a0 = etaw * (dL * xv);
-          r_viol += fabs(a0 + etaw * O.alpha * wj);
-          M.w[j] = wt - a0 / swn;
+    for (int c = 0; c < n_chunks; ++c) {
+      int jl;
+      double xl;
+      dev::row_entry(X, q0, m, m_tot, c * kWave + lane, jl, xl);
+      const int ql = c * kWave + lane;
+      const int fl = (ql < m_tot && sg[ql] != 0) ? 1 : 0;
+      const int len_c = min(kWave, m_tot - c * kWave);
+      for (int it = 0; it * R < len_c; ++it) {
+        const int src_lane = it * R + g;
+        const int j = __shfl(jl, src_lane, kWave);
+        const double xv = dev::shfl_d(xl, src_lane);
+        const int f = __shfl(fl, src_lane, kWave);
+        if (f) {
+          double2 st = *reinterpret_cast<const double2*>(wl + ((size_t)c * kWave + src_lane) * Kp + 2 * l);
+          const double px = sP * st.x, py = sP * st.y;
+          const double ax = etaP * (dL * (xv * (a1.x - px * xv)));
+          const double ay = etaP * (dL * (xv * (a1.y - py * xv)));
+          r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
+          st.x = st.x - ax / sPn;
+          st.y = st.y - ay / sPn;
+          *reinterpret_cast<double2*>(M.P + (size_t)j * Kp + 2 * l) = st;
+          if (M.fit_linear && j < M.d && l == 0) {
+            const double wt = M.w[j], wj = sw * wt;
+            const double a0 = etaw * (dL * xv);
+            r_viol += fabs(a0 + etaw * O.alpha * wj);
+            M.w[j] = wt - a0 / swn;
+          }
         }
       }
     }
@@ -917,9 +936,12 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     // rows per lane to keep in registers (0 = stream): only when the batch has singles to update
     auto nq_for = [&](int s_used) {
       if (OPT != OPT_SGD || GEN || !P.use_singles) return 0;
-      if (const char* env = getenv("NFM_NQ")) return atoi(env);  // tuning override
+      // register-resident rows measured slower than streaming on the headline shape (185 vs 154 us:
+      // 236 VGPRs leave 2 waves per SIMD); opt-in via NFM_NQ=16|32
+      const char* env = getenv("NFM_NQ");
+      const int want = env ? atoi(env) : 0;
       const int need = (X.max_row + M.n_aug + s_used - 1) / s_used;
-      return need <= 16 ? 16 : (need <= 32 ? 32 : 0);
+      return (want == 16 || want == 32) && need <= want ? want : 0;
     };
     int nA;
     {
@@ -931,9 +953,12 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
       TimedLaunch tl(ctx, "row_phase");
       int s_used;
       // LDS-resident rows: SGD, degree 2, a batch with singles, rows that fit 160 KB per workgroup
-      const int m_cap = ((X.max_row + M.n_aug + R - 1) / R) * R;
+      const int m_cap = ((X.max_row + M.n_aug + kWave - 1) / kWave) * kWave;  // whole 64-entry chunks
       const size_t lds_bytes = sizeof(double) * (size_t)kWavesPerBlock * std::max(m_cap, R) * M.Kp;
-      static const bool lds_on = !(getenv("NFM_LDS") && atoi(getenv("NFM_LDS")) == 0);
+      // measured on the headline shape (k=64, m=64, B=8192): streaming 154 us, LDS-resident 217 us per
+      // batch -- one sample per wavefront at a time is latency-bound without double buffering, so
+      // this variant is opt-in (NFM_LDS=1) until it is pipelined
+      static const bool lds_on = getenv("NFM_LDS") && atoi(getenv("NFM_LDS")) != 0;
       if (OPT == OPT_SGD && !GEN && P.use_singles && lds_on && lds_bytes <= 160 * 1024 - 256) {
         auto kern = k_row_phase_lds<L>;
         if (lds_bytes > 64 * 1024)
