@@ -160,6 +160,118 @@ __device__ __forceinline__ double row_forward(const PS& ps, const CsrView& X, co
   return part;
 }
 
+// In-place update of a sample's singles (features no other sample of the batch touches): the same
+// arithmetic as the column phase with c = 1.  Entries in groups of kUnroll: flags, then (index, value),
+// then the rows are all requested before the first use.  Called from the column-phase launch (extra
+// workgroups), so the bandwidth-bound singles run beside the latency-bound multi-touch features.
+template <int L, int SPLIT, int OPT>
+__device__ __forceinline__ double singles_update(const CsrView& X, const ModelView& M, const OptView& O,
+                                                 const uint8_t* __restrict__ sg, const double* scales_b,
+                                                 const double* scales_nx, int64_t q0, int m, int m_tot, int slot, int l,
+                                                 double dL, double etaP, double etaw, double2 A1, double itp, bool stored) {
+  double r_viol = 0.0;
+  {
+    const double sP = scales_b[0], sw = scales_b[1], sPn = scales_nx[0], swn = scales_nx[1];
+    const double tmpP = O.eta0 * itp * O.beta, denw = itp * O.eta0 * O.alpha;
+    // groups of kUnroll entries: flags, then (index, value), then the rows are all requested before
+    // the first use, so the second visit of the row costs one memory round trip per group
+    for (int q = slot; q < m_tot; q += dev::kUnroll * SPLIT) {
+      bool f[dev::kUnroll];
+      int j[dev::kUnroll];
+      double x[dev::kUnroll];
+      double2 r0[dev::kUnroll], r1[dev::kUnroll], r2[dev::kUnroll];
+      double w0[dev::kUnroll], w1[dev::kUnroll], w2[dev::kUnroll];
+#pragma unroll
+      for (int u = 0; u < dev::kUnroll; ++u) {
+        const int qq = q + u * SPLIT;
+        f[u] = qq < m_tot && sg[qq] != 0;
+      }
+#pragma unroll
+      for (int u = 0; u < dev::kUnroll; ++u) {
+        j[u] = 0;
+        x[u] = 0.0;
+        if (f[u]) dev::row_entry(X, q0, m, m_tot, q + u * SPLIT, j[u], x[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < dev::kUnroll; ++u) {
+        r0[u] = r1[u] = r2[u] = {0.0, 0.0};
+        w0[u] = w1[u] = w2[u] = 0.0;
+        if (f[u]) {
+          const size_t e = (size_t)j[u] * M.Kp + 2 * l;
+          const bool has_w = M.fit_linear && j[u] < M.d && l == 0;
+          if (OPT == OPT_SGD) {
+            r0[u] = *reinterpret_cast<const double2*>(M.P + e);
+            if (has_w) w0[u] = M.w[j[u]];
+          } else {
+            r1[u] = *reinterpret_cast<const double2*>(O.G + e);
+            r2[u] = *reinterpret_cast<const double2*>(O.N + e);
+            if (stored || O.track_viol) r0[u] = *reinterpret_cast<const double2*>(M.P + e);
+            if (has_w) {
+              w0[u] = M.w[j[u]];
+              w1[u] = O.Gw[j[u]];
+              w2[u] = O.Nw[j[u]];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < dev::kUnroll; ++u) {
+        if (!f[u]) continue;
+        const size_t e = (size_t)j[u] * M.Kp + 2 * l;
+        const bool has_w = M.fit_linear && j[u] < M.d && l == 0;
+        const double xv = x[u];
+        if (OPT == OPT_SGD) {
+          double2 st = r0[u];
+          const double px = sP * st.x, py = sP * st.y;
+          const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
+          const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
+          r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
+          st.x = st.x - ax / sPn;
+          st.y = st.y - ay / sPn;
+          *reinterpret_cast<double2*>(M.P + e) = st;
+          if (has_w) {
+            const double wt = w0[u], wj = sw * wt;
+            const double a0 = etaw * (dL * xv);
+            r_viol += fabs(a0 + etaw * O.alpha * wj);
+            M.w[j[u]] = wt - a0 / swn;
+          }
+        } else {
+          double2 g2 = r1[u], n2 = r2[u], p;
+          if (stored) {
+            p = r0[u];
+          } else {
+            p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmpP);
+            p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmpP);
+            if (O.track_viol) {
+              r_viol += fabs(r0[u].x - p.x) + fabs(r0[u].y - p.y);
+              *reinterpret_cast<double2*>(M.P + e) = p;
+            }
+          }
+          const double gx = dL * (xv * (A1.x - p.x * xv)), gy = dL * (xv * (A1.y - p.y * xv));
+          g2.x += gx;
+          g2.y += gy;
+          n2.x += gx * gx;
+          n2.y += gy * gy;
+          *reinterpret_cast<double2*>(O.G + e) = g2;
+          *reinterpret_cast<double2*>(O.N + e) = n2;
+          if (has_w) {
+            const double wt = w0[u], gw = w1[u], nw = w2[u];
+            if (!stored) {
+              const double wj = -O.eta0 * gw / (denw + sqrt(nw));
+              r_viol += fabs(wt - wj);
+              M.w[j[u]] = wj;
+            }
+            const double g = dL * xv;
+            O.Gw[j[u]] = gw + g;
+            O.Nw[j[u]] = nw + g * g;
+          }
+        }
+      }
+    }
+  }
+  return r_viol;
+}
+
 // NQ > 0 (SGD, single order of degree 2, rows of at most SPLIT*NQ entries): every lane keeps the NQ
 // parameter-row pieces it gathered for the forward pass in registers, so the in-place update of
 // the singles needs no second visit of the rows (HBM traffic of the row phase = the rows read once
@@ -330,104 +442,8 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
       }
     }
   } else if (!GEN && a.single != nullptr && valid) {
-    const uint8_t* sg = a.single + a.toff[a.p0 + pib];
-    const double sP = a.scales[0], sw = a.scales[1], sPn = a.scales_n[0], swn = a.scales_n[1];
-    const double tmpP = O.eta0 * itp * O.beta, denw = itp * O.eta0 * O.alpha;
-    // groups of kUnroll entries: flags, then (index, value), then the rows are all requested before
-    // the first use, so the second visit of the row costs one memory round trip per group
-    for (int q = slot; q < m_tot; q += dev::kUnroll * SPLIT) {
-      bool f[dev::kUnroll];
-      int j[dev::kUnroll];
-      double x[dev::kUnroll];
-      double2 r0[dev::kUnroll], r1[dev::kUnroll], r2[dev::kUnroll];
-      double w0[dev::kUnroll], w1[dev::kUnroll], w2[dev::kUnroll];
-#pragma unroll
-      for (int u = 0; u < dev::kUnroll; ++u) {
-        const int qq = q + u * SPLIT;
-        f[u] = qq < m_tot && sg[qq] != 0;
-      }
-#pragma unroll
-      for (int u = 0; u < dev::kUnroll; ++u) {
-        j[u] = 0;
-        x[u] = 0.0;
-        if (f[u]) dev::row_entry(X, q0, m, m_tot, q + u * SPLIT, j[u], x[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < dev::kUnroll; ++u) {
-        r0[u] = r1[u] = r2[u] = {0.0, 0.0};
-        w0[u] = w1[u] = w2[u] = 0.0;
-        if (f[u]) {
-          const size_t e = (size_t)j[u] * M.Kp + 2 * l;
-          const bool has_w = M.fit_linear && j[u] < M.d && l == 0;
-          if (OPT == OPT_SGD) {
-            r0[u] = *reinterpret_cast<const double2*>(M.P + e);
-            if (has_w) w0[u] = M.w[j[u]];
-          } else {
-            r1[u] = *reinterpret_cast<const double2*>(O.G + e);
-            r2[u] = *reinterpret_cast<const double2*>(O.N + e);
-            if (stored || O.track_viol) r0[u] = *reinterpret_cast<const double2*>(M.P + e);
-            if (has_w) {
-              w0[u] = M.w[j[u]];
-              w1[u] = O.Gw[j[u]];
-              w2[u] = O.Nw[j[u]];
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < dev::kUnroll; ++u) {
-        if (!f[u]) continue;
-        const size_t e = (size_t)j[u] * M.Kp + 2 * l;
-        const bool has_w = M.fit_linear && j[u] < M.d && l == 0;
-        const double xv = x[u];
-        if (OPT == OPT_SGD) {
-          double2 st = r0[u];
-          const double px = sP * st.x, py = sP * st.y;
-          const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
-          const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
-          r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
-          st.x = st.x - ax / sPn;
-          st.y = st.y - ay / sPn;
-          *reinterpret_cast<double2*>(M.P + e) = st;
-          if (has_w) {
-            const double wt = w0[u], wj = sw * wt;
-            const double a0 = etaw * (dL * xv);
-            r_viol += fabs(a0 + etaw * O.alpha * wj);
-            M.w[j[u]] = wt - a0 / swn;
-          }
-        } else {
-          double2 g2 = r1[u], n2 = r2[u], p;
-          if (stored) {
-            p = r0[u];
-          } else {
-            p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmpP);
-            p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmpP);
-            if (O.track_viol) {
-              r_viol += fabs(r0[u].x - p.x) + fabs(r0[u].y - p.y);
-              *reinterpret_cast<double2*>(M.P + e) = p;
-            }
-          }
-          const double gx = dL * (xv * (A1.x - p.x * xv)), gy = dL * (xv * (A1.y - p.y * xv));
-          g2.x += gx;
-          g2.y += gy;
-          n2.x += gx * gx;
-          n2.y += gy * gy;
-          *reinterpret_cast<double2*>(O.G + e) = g2;
-          *reinterpret_cast<double2*>(O.N + e) = n2;
-          if (has_w) {
-            const double wt = w0[u], gw = w1[u], nw = w2[u];
-            if (!stored) {
-              const double wj = -O.eta0 * gw / (denw + sqrt(nw));
-              r_viol += fabs(wt - wj);
-              M.w[j[u]] = wj;
-            }
-            const double g = dL * xv;
-            O.Gw[j[u]] = gw + g;
-            O.Nw[j[u]] = nw + g * g;
-          }
-        }
-      }
-    }
+    r_viol += singles_update<L, SPLIT, OPT>(X, M, O, a.single + a.toff[a.p0 + pib], a.scales, a.scales_n, q0, m, m_tot, slot, l,
+                                            dL, etaP, etaw, A1, itp, stored);
   }
   r_viol = dev::wave_sum(r_viol);
   if (lane == 0) s_viol[wv] = r_viol;
@@ -593,8 +609,15 @@ __global__ __launch_bounds__(kBlock) void k_row_phase_lds(RowArgs a, int m_cap) 
 // column phase (+ batch close in workgroup 0)
 // ------------------------------------------------------------------------------------------------
 struct ColArgs {
+  CsrView X;
   ModelView M;
   OptView O;
+  // singles workgroups (the first nS of the launch): one wavefront per sample of the batch
+  const int64_t* perm;
+  const int64_t* toff;
+  const uint8_t* single;
+  int64_t begin, p0;
+  int32_t len_i, nS;
   const int32_t* ucol;
   const int64_t* uptr;
   const int32_t* tpos;
@@ -623,7 +646,7 @@ constexpr int kTouchUnroll = 4;
 
 // one parameter block (order) of one unique feature: this lane's factor pair at element e.
 // do_w: also accumulate the linear term's sums over the same touches.
-template <int OPT, bool GEN>
+template <int OPT, bool GEN, int TU>
 __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg, int slot, int l, int64_t t0, int64_t t1,
                                             double sP, double sPn, double fP, bool do_w, WAcc& wacc) {
   const ModelView& M = a.M;
@@ -653,26 +676,26 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
   double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
   double seta = 0.0;
   if (!GEN || deg == 2) {
-    // touches in groups of kTouchUnroll: all loads of a group are issued before the first use;
+    // touches in groups of TU: all loads of a group are issued before the first use;
     // the accumulation itself stays in touch (= sample) order
-    for (int64_t t = t0; t < t1; t += kTouchUnroll) {
-      int pib[kTouchUnroll];
-      double x[kTouchUnroll];
-      SampleRec r[kTouchUnroll];
-      double2 A1[kTouchUnroll];
+    for (int64_t t = t0; t < t1; t += TU) {
+      int pib[TU];
+      double x[TU];
+      SampleRec r[TU];
+      double2 A1[TU];
 #pragma unroll
-      for (int u = 0; u < kTouchUnroll; ++u) {
+      for (int u = 0; u < TU; ++u) {
         const bool ok = t + u < t1;
         pib[u] = ok ? a.tpos[t + u] : 0;
         x[u] = ok ? a.tx[t + u] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < kTouchUnroll; ++u) {
+      for (int u = 0; u < TU; ++u) {
         r[u] = a.rec[pib[u]];
         A1[u] = *reinterpret_cast<const double2*>(a.Abuf + ((size_t)pib[u] * a.TA + slot) * M.Kp + 2 * l);
       }
 #pragma unroll
-      for (int u = 0; u < kTouchUnroll; ++u) {
+      for (int u = 0; u < TU; ++u) {
         if (t + u < t1) {
           const double dAx = x[u] * (A1[u].x - p.x * x[u]);
           const double dAy = x[u] * (A1[u].y - p.y * x[u]);
@@ -757,7 +780,7 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
   return viol;
 }
 
-template <int L, int OPT, bool GEN>
+template <int L, int OPT, bool GEN, int TU>
 __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
   constexpr int R = kWave / L;
   __shared__ double red[5][kBlock];
@@ -765,9 +788,37 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
   const OptView& O = a.O;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   const int g = lane / L, l = lane % L;
-  const bool closer = blockIdx.x == gridDim.x - 1;  // the extra, last workgroup only closes the batch
-  const int64_t u = closer ? a.u1 : a.u0 + ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
   double viol = 0.0;
+  if ((int)blockIdx.x < a.nS) {
+    // ---- singles workgroup: this wavefront updates the single-touch features of one sample ----
+    if (!GEN) {
+      const int pib = blockIdx.x * kWavesPerBlock + wv;
+      if (pib < a.len_i) {
+        const CsrView& X = a.X;
+        const int64_t pos = a.p0 + pib;
+        const int64_t i = a.perm ? a.perm[pos] : a.begin + pos;
+        const int64_t q0 = X.indptr[i];
+        const int m = (int)(X.indptr[i + 1] - q0);
+        const int m_tot = m + M.n_aug;
+        const SampleRec r = a.rec[pib];
+        const double2 A1 = *reinterpret_cast<const double2*>(a.Abuf + (size_t)pib * a.TA * M.Kp + 2 * l);
+        viol = singles_update<L, R, OPT>(X, M, O, a.single + a.toff[pos], a.scales_b, a.scales_n, q0, m, m_tot, g, l, r.dL,
+                                         r.etaP, r.etaw, A1, (a.it0p[0] + a.it_b) - 1.0, a.use_stored != 0);
+      }
+    }
+    viol = dev::wave_sum(viol);
+    if (lane == 0) red[0][wv] = viol;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v = 0.0;
+      for (int w_ = 0; w_ < kWavesPerBlock; ++w_) v += red[0][w_];
+      a.parts[blockIdx.x] = v;
+    }
+    return;
+  }
+  const int fb = blockIdx.x - a.nS;                 // feature workgroup index
+  const bool closer = blockIdx.x == gridDim.x - 1;  // the extra, last workgroup only closes the batch
+  const int64_t u = closer ? a.u1 : a.u0 + ((int64_t)fb * kWavesPerBlock + wv) * R + g;
   if (u < a.u1) {
     const int64_t j = a.ucol[u];
     const int64_t t0 = a.uptr[u], t1 = a.uptr[u + 1];
@@ -794,7 +845,7 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
     for (int o = 0; o < M.nb; ++o) {
       const size_t e = ((size_t)o * M.da + j) * M.Kp + 2 * l;
       const int deg = M.degree - o;
-      viol += col_block<OPT, GEN>(a, e, deg, slot, l, t0, t1, sP, sPn, fP, has_w && o == 0, wacc);
+      viol += col_block<OPT, GEN, TU>(a, e, deg, slot, l, t0, t1, sP, sPn, fP, has_w && o == 0, wacc);
       slot += deg - 1;
     }
     if (has_w) {
@@ -904,9 +955,13 @@ __global__ __launch_bounds__(kBlock) void k_epoch_close(const double* __restrict
 // host driver
 // ------------------------------------------------------------------------------------------------
 template <int L, int SPLIT, int OPT, bool GEN>
-static void launch_row(hipStream_t st, const RowArgs& ra, int nq) {
+static void launch_row(hipStream_t st, const RowArgs& ra, int nq, int pad_kb = 0) {
   constexpr int SPW = kWave / (L * SPLIT);
   const int nA = (ra.len + kWavesPerBlock * SPW - 1) / (kWavesPerBlock * SPW);
+  if (pad_kb > 0 && nq == 0) {  // tuning: unused dynamic LDS caps the workgroups per CU
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0>), dim3(nA), dim3(kBlock), (size_t)pad_kb * 1024, st, ra);
+    return;
+  }
   constexpr bool CAN_REG = OPT == OPT_SGD && !GEN && L >= 8;  // register-resident rows: k >= 16
   if (CAN_REG && nq == 16)
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 16 : 0)>), dim3(nA), dim3(kBlock), 0, st, ra);
@@ -926,6 +981,16 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
   const double* it0p = W.itbuf.as<double>();
   const double avg_row = X.n > 0 ? (double)X.nnz / (double)X.n + M.n_aug : 0.0;
   const size_t partsB_half = W.partsB.bytes / sizeof(double) / 2;
+  const char* tu_env = getenv("NFM_TU");
+  const bool few_touches = tu_env ? atoi(tu_env) == 2 : (P.U > 0 && (double)P.TM / (double)P.U < 3.0);
+  static const int row_pad_kb = getenv("NFM_ROW_PAD_KB") ? atoi(getenv("NFM_ROW_PAD_KB")) : 0;  // occupancy cap (tuning)
+  // Where the singles are updated: by extra workgroups of the column-phase launch (default: the
+  // bandwidth-bound singles then overlap the latency-bound multi-touch features), or inside the row
+  // phase (NFM_SINGLES_IN_ROW=1; also what the register/LDS-resident row variants need).
+  static const bool env_in_row = getenv("NFM_SINGLES_IN_ROW") && atoi(getenv("NFM_SINGLES_IN_ROW")) != 0;
+  const bool have_singles = !GEN && P.use_singles;
+  const bool singles_in_row = have_singles && (env_in_row || getenv("NFM_LDS") || getenv("NFM_NQ"));
+  const bool singles_in_col = have_singles && !singles_in_row;
   int n_prev = 0;
   for (int64_t b = 0; b < P.n_batches; ++b) {
     const int64_t p0 = P.bat_pos[b];
@@ -935,7 +1000,7 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     const int split = choose_split(L, len, avg_row, ctx->n_cu);
     // rows per lane to keep in registers (0 = stream): only when the batch has singles to update
     auto nq_for = [&](int s_used) {
-      if (OPT != OPT_SGD || GEN || !P.use_singles) return 0;
+      if (OPT != OPT_SGD || !singles_in_row) return 0;
       // register-resident rows measured slower than streaming on the headline shape (185 vs 154 us:
       // 236 VGPRs leave 2 waves per SIMD); opt-in via NFM_NQ=16|32
       const char* env = getenv("NFM_NQ");
@@ -947,8 +1012,8 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     {
       RowArgs ra{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, P.begin, p0, len, use_stored, TA, 0, it_b, it0p,
                  OPT == OPT_SGD ? Stab + 2 * b : M.sc, OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc,
-                 (!GEN && P.use_singles) ? P.toff.as<int64_t>() : nullptr,
-                 (!GEN && P.use_singles) ? P.single.as<uint8_t>() : nullptr, W.Abuf.as<double>(), W.rec.as<SampleRec>(),
+                 singles_in_row ? P.toff.as<int64_t>() : nullptr,
+                 singles_in_row ? P.single.as<uint8_t>() : nullptr, W.Abuf.as<double>(), W.rec.as<SampleRec>(),
                  W.partsA.as<PartA>()};
       TimedLaunch tl(ctx, "row_phase");
       int s_used;
@@ -959,7 +1024,7 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
       // batch -- one sample per wavefront at a time is latency-bound without double buffering, so
       // this variant is opt-in (NFM_LDS=1) until it is pipelined
       static const bool lds_on = getenv("NFM_LDS") && atoi(getenv("NFM_LDS")) != 0;
-      if (OPT == OPT_SGD && !GEN && P.use_singles && lds_on && lds_bytes <= 160 * 1024 - 256) {
+      if (OPT == OPT_SGD && singles_in_row && lds_on && lds_bytes <= 160 * 1024 - 256) {
         auto kern = k_row_phase_lds<L>;
         if (lds_bytes > 64 * 1024)
           NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -971,11 +1036,11 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
         if (nA > ctx->n_cu * per_cu) nA = ctx->n_cu * per_cu;
         hipLaunchKernelGGL(kern, dim3(nA), dim3(kBlock), lds_bytes, st, ra, std::max(m_cap, R));
       } else {
-      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra, nq_for(R >= 16 ? 16 : R)); s_used = R >= 16 ? 16 : R; }
-      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra, nq_for(R >= 8 ? 8 : R)); s_used = R >= 8 ? 8 : R; }
-      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra, nq_for(R >= 4 ? 4 : R)); s_used = R >= 4 ? 4 : R; }
-      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT, GEN>(st, ra, nq_for(R >= 2 ? 2 : R)); s_used = R >= 2 ? 2 : R; }
-      else { launch_row<L, 1, OPT, GEN>(st, ra, nq_for(1)); s_used = 1; }
+      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra, nq_for(R >= 16 ? 16 : R), row_pad_kb); s_used = R >= 16 ? 16 : R; }
+      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra, nq_for(R >= 8 ? 8 : R), row_pad_kb); s_used = R >= 8 ? 8 : R; }
+      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra, nq_for(R >= 4 ? 4 : R), row_pad_kb); s_used = R >= 4 ? 4 : R; }
+      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT, GEN>(st, ra, nq_for(R >= 2 ? 2 : R), row_pad_kb); s_used = R >= 2 ? 2 : R; }
+      else { launch_row<L, 1, OPT, GEN>(st, ra, nq_for(1), row_pad_kb); s_used = 1; }
       const int spw = kWave / (L * s_used);
       nA = (len + kWavesPerBlock * spw - 1) / (kWavesPerBlock * spw);
       }
@@ -984,17 +1049,26 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     const int per_block = kWavesPerBlock * R;
     int nB = (int)((u1 - u0 + per_block - 1) / per_block);
     nB += 1;  // + the closing workgroup
+    const int nS = singles_in_col ? (len + kWavesPerBlock - 1) / kWavesPerBlock : 0;
+    nB += nS;  // + the singles workgroups (first in the grid: they are the long pole)
     double* parts_cur = W.partsB.as<double>() + (b & 1) * partsB_half;
     const double* parts_prev = W.partsB.as<double>() + ((b + 1) & 1) * partsB_half;
     {
-      ColArgs ca{M, O, P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(), u0, u1,
+      ColArgs ca{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, singles_in_col ? P.toff.as<int64_t>() : nullptr,
+                 singles_in_col ? P.single.as<uint8_t>() : nullptr, P.begin, p0, len, nS,
+                 P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(), u0, u1,
                  OPT == OPT_SGD ? Stab + 2 * b : M.sc, OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc,
                  OPT == OPT_SGD ? Dtab + 4 * b : nullptr,
                  OPT == OPT_SGD ? W.Ftab.as<double>() + (size_t)b * 2 * kFtab : nullptr, W.Abuf.as<double>(),
                  W.rec.as<SampleRec>(), parts_cur, W.partsA.as<PartA>(), parts_prev, W.out_acc.as<double>(), it_b,
                  (double)len, it0p, TA, use_stored, nA, n_prev};
       TimedLaunch tl(ctx, "col_phase");
-      hipLaunchKernelGGL((k_col_phase<L, OPT, GEN>), dim3(nB), dim3(kBlock), 0, st, ca);
+      // touches are loaded in groups of TU before use; features touched only a few times (sparse
+      // regime) waste registers, hence occupancy, on a wide group
+      if (few_touches)
+        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 2>), dim3(nB), dim3(kBlock), 0, st, ca);
+      else
+        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 4>), dim3(nB), dim3(kBlock), 0, st, ca);
     }
     n_prev = nB;
   }
@@ -1064,7 +1138,7 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   NFM_TRY(W.Abuf.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_batch, 1) * std::max(TA, 1) * M.Kp));
   NFM_TRY(W.rec.ensure(sizeof(SampleRec) * (size_t)std::max<int64_t>(P.max_batch, 1)));
   NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch / kWavesPerBlock + 1)));
-  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique / kMinGroupsPerBlock + 2)));
+  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique / kMinGroupsPerBlock + P.max_batch / kWavesPerBlock + 4)));
   NFM_TRY(W.Dtab.ensure(sizeof(double) * 4 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Stab.ensure(sizeof(double) * 2 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Ftab.ensure(sizeof(double) * 2 * kFtab * (size_t)(P.n_batches + 1)));
