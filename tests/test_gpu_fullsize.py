@@ -1,0 +1,100 @@
+"""-m gpu: BASELINE.json configs[1] at FULL size (synthetic CSR 1e6 x 1e5, 32 nnz/row, k = 16, SGD,
+Logistic) -- the configuration bench.py reports -- against the CPU restatement of the mini-batch
+rule, plus size-independent properties of the path:
+  * determinism: two runs give bitwise identical parameters (no atomics anywhere),
+  * composition: one epoch call == two calls split at a batch boundary (nCalls callbacks),
+  * permutation equivariance of decisionFunction, linearity of the linear term,
+  * idempotence of finalize (warm-start invariant, tests/test_sgd.nim:58-89)."""
+import numpy as np
+import pytest
+
+import nimfm_amd as nf
+import oracle as O
+from common import assert_close
+from gpu_common import gpu_fm, to_gpu
+
+pytestmark = pytest.mark.gpu
+N, D, M, K, B = 1_000_000, 100_000, 32, 16, 32768
+
+
+def big_csr(n, d, m, seed):
+    rng = np.random.default_rng(seed)
+    idx = np.sort(rng.integers(0, d, size=(n, m)), axis=1)
+    while True:
+        bad = np.nonzero((idx[:, 1:] == idx[:, :-1]).any(axis=1))[0]
+        if len(bad) == 0:
+            break
+        idx[bad] = np.sort(rng.integers(0, d, size=(len(bad), m)), axis=1)
+    val = rng.uniform(-1.0, 1.0, size=(n, m))
+    return O.Dataset(np.arange(n + 1, dtype=np.int64) * m, idx.ravel(), val.ravel(), n, d)
+
+
+@pytest.fixture(scope="module")
+def problem():
+    Xo = big_csr(N, D, M, 42)
+    rng = np.random.default_rng(1)
+    Pt = rng.standard_normal((1, K, D)) * 0.1
+    y = np.sign(O.fm_decision_function(Xo, 2, Pt, rng.standard_normal(D) * 0.1, 0.0))
+    P0, w0 = rng.standard_normal((1, K, D)) * 0.01, np.zeros(D)
+    return Xo, to_gpu(Xo), y, P0, w0
+
+
+def test_cfg2_fullsize_vs_mb_oracle(problem):
+    Xo, X, y, P0, w0 = problem
+    P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
+    hist = []
+    for _ in range(2):
+        b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, b, O.sgd_cfg(loss="logistic"), B, it=it)
+        hist.append((vs, ls / N))
+    fm = gpu_fm("classification", 2, K, "explicit", True, True, P0, w0, 0.0)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False, loss="logistic", mode="minibatch", batch=B)
+    sgd.fit(X, y, fm)
+    assert sgd.it == it == 2 * N + 1
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, 1e-9, 1e-13, "w")
+    assert_close(fm.P, P, 1e-9, 1e-13, "P")
+    assert_close([h[1] for h in sgd.history], [h[1] for h in hist], 1e-11, 0, "mean loss")
+    assert_close([h[0] for h in sgd.history], [h[0] for h in hist], 1e-9, 0, "viol")
+    # predictions on the full set: north_star tolerance 1e-6 relative, asserted at 1e-10
+    assert_close(fm.decisionFunction(X), O.fm_decision_function(Xo, 2, P, w, b), 1e-10, 1e-13, "decision")
+    assert sgd.history[1][1] < sgd.history[0][1] < np.log(2.0)  # the loss goes down
+
+
+def test_determinism_and_composition(problem):
+    Xo, X, y, P0, w0 = problem
+    runs = []
+    for split in (None, None, 20 * B):
+        fm = gpu_fm("classification", 2, K, "explicit", True, True, P0, w0, 0.0)
+        sgd = nf.newSGD(maxIter=1, verbose=0, tol=0, shuffle=False, loss="logistic", mode="minibatch", batch=B)
+        X.set_targets(y)
+        sgd._handle(fm, X.ctx, "minibatch")
+        if split is None:
+            sgd._epoch(X, None, 0, N)
+        else:
+            sgd._epoch(X, None, 0, split)
+            sgd._epoch(X, None, split, N)
+        sgd._finalize_into(fm)
+        P1, w1, b1 = fm.P.copy(), fm.w.copy(), fm.intercept
+        sgd._finalize_into(fm)  # finalize is idempotent
+        assert np.array_equal(P1, fm.P) and np.array_equal(w1, fm.w) and b1 == fm.intercept
+        runs.append((P1, w1, b1))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2]
+    assert_close(runs[2][0], runs[0][0], 1e-12, 1e-15, "split epoch P")  # scales are re-based at the split
+    assert_close(runs[2][1], runs[0][1], 1e-12, 1e-15, "split epoch w")
+
+
+def test_predict_properties(problem):
+    Xo, X, y, P0, w0 = problem
+    rng = np.random.default_rng(5)
+    w1, w2 = rng.standard_normal(D), rng.standard_normal(D)
+    dec = {}
+    for name, (w, b) in {"w1": (w1, 0.5), "w2": (w2, -1.0), "sum": (w1 + w2, 0.0), "zero": (np.zeros(D), 0.0)}.items():
+        dec[name] = gpu_fm("regression", 2, K, "explicit", True, True, P0, w, b).decisionFunction(X)
+    # linear term + intercept are additive on top of the pairwise term
+    assert_close(dec["w1"] + dec["w2"] - dec["zero"], dec["sum"] - 0.5, 1e-9, 1e-9, "linearity")
+    # row permutation equivariance (a fresh dataset with permuted rows)
+    sub = rng.permutation(200_000)
+    Xp = O.Dataset(np.arange(len(sub) + 1, dtype=np.int64) * M, Xo.indices.reshape(N, M)[sub].ravel(),
+                   Xo.data.reshape(N, M)[sub].ravel(), len(sub), D)
+    got = gpu_fm("regression", 2, K, "explicit", True, True, P0, w1, 0.5).decisionFunction(to_gpu(Xp))
+    assert np.array_equal(got, dec["w1"][sub])
