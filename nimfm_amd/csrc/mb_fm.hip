@@ -441,9 +441,6 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
         M.w[j] = wt - a0 / swn;
       }
     }
-  } else if (!GEN && a.single != nullptr && valid) {
-    r_viol += singles_update<L, SPLIT, OPT>(X, M, O, a.single + a.toff[a.p0 + pib], a.scales, a.scales_n, q0, m, m_tot, slot, l,
-                                            dL, etaP, etaw, A1, itp, stored);
   }
   r_viol = dev::wave_sum(r_viol);
   if (lane == 0) s_viol[wv] = r_viol;
@@ -780,6 +777,40 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
   return viol;
 }
 
+// singles kernel: one wavefront per sample of the batch updates, in place, the features only that
+// sample touches (sparse regime).  Runs between the row and the column phase; disjoint rows.
+template <int L, int OPT>
+__global__ __launch_bounds__(kBlock) void k_singles(ColArgs a) {
+  constexpr int R = kWave / L;
+  __shared__ double red[kWavesPerBlock];
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int pib = blockIdx.x * kWavesPerBlock + wv;
+  double viol = 0.0;
+  if (pib < a.len_i) {
+    const CsrView& X = a.X;
+    const int64_t pos = a.p0 + pib;
+    const int64_t i = a.perm ? a.perm[pos] : a.begin + pos;
+    const int64_t q0 = X.indptr[i];
+    const int m = (int)(X.indptr[i + 1] - q0);
+    const int m_tot = m + M.n_aug;
+    const SampleRec r = a.rec[pib];
+    const double2 A1 = *reinterpret_cast<const double2*>(a.Abuf + (size_t)pib * a.TA * M.Kp + 2 * l);
+    viol = singles_update<L, R, OPT>(X, M, O, a.single + a.toff[pos], a.scales_b, a.scales_n, q0, m, m_tot, g, l, r.dL,
+                                     r.etaP, r.etaw, A1, (a.it0p[0] + a.it_b) - 1.0, a.use_stored != 0);
+  }
+  viol = dev::wave_sum(viol);
+  if (lane == 0) red[wv] = viol;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) v += red[w_];
+    a.parts[blockIdx.x] = v;
+  }
+}
+
 template <int L, int OPT, bool GEN, int TU>
 __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
   constexpr int R = kWave / L;
@@ -789,34 +820,7 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   const int g = lane / L, l = lane % L;
   double viol = 0.0;
-  if ((int)blockIdx.x < a.nS) {
-    // ---- singles workgroup: this wavefront updates the single-touch features of one sample ----
-    if (!GEN) {
-      const int pib = blockIdx.x * kWavesPerBlock + wv;
-      if (pib < a.len_i) {
-        const CsrView& X = a.X;
-        const int64_t pos = a.p0 + pib;
-        const int64_t i = a.perm ? a.perm[pos] : a.begin + pos;
-        const int64_t q0 = X.indptr[i];
-        const int m = (int)(X.indptr[i + 1] - q0);
-        const int m_tot = m + M.n_aug;
-        const SampleRec r = a.rec[pib];
-        const double2 A1 = *reinterpret_cast<const double2*>(a.Abuf + (size_t)pib * a.TA * M.Kp + 2 * l);
-        viol = singles_update<L, R, OPT>(X, M, O, a.single + a.toff[pos], a.scales_b, a.scales_n, q0, m, m_tot, g, l, r.dL,
-                                         r.etaP, r.etaw, A1, (a.it0p[0] + a.it_b) - 1.0, a.use_stored != 0);
-      }
-    }
-    viol = dev::wave_sum(viol);
-    if (lane == 0) red[0][wv] = viol;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double v = 0.0;
-      for (int w_ = 0; w_ < kWavesPerBlock; ++w_) v += red[0][w_];
-      a.parts[blockIdx.x] = v;
-    }
-    return;
-  }
-  const int fb = blockIdx.x - a.nS;                 // feature workgroup index
+  const int fb = blockIdx.x;                        // feature workgroup index
   const bool closer = blockIdx.x == gridDim.x - 1;  // the extra, last workgroup only closes the batch
   const int64_t u = closer ? a.u1 : a.u0 + ((int64_t)fb * kWavesPerBlock + wv) * R + g;
   if (u < a.u1) {
@@ -891,7 +895,7 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
   if (threadIdx.x == 0) {
     double v = 0.0;
     for (int w_ = 0; w_ < kWavesPerBlock; ++w_) v += red[0][w_];
-    a.parts[blockIdx.x] = v;
+    a.parts[a.nS + blockIdx.x] = v;  // the singles kernel owns parts[0, nS)
   }
   if (!closer) return;
   // ---- the closing workgroup: fixed-order reductions, intercept update; it runs beside the
@@ -984,12 +988,11 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
   const char* tu_env = getenv("NFM_TU");
   const bool few_touches = tu_env ? atoi(tu_env) == 2 : (P.U > 0 && (double)P.TM / (double)P.U < 3.0);
   static const int row_pad_kb = getenv("NFM_ROW_PAD_KB") ? atoi(getenv("NFM_ROW_PAD_KB")) : 0;  // occupancy cap (tuning)
-  // Where the singles are updated: by extra workgroups of the column-phase launch (default: the
-  // bandwidth-bound singles then overlap the latency-bound multi-touch features), or inside the row
-  // phase (NFM_SINGLES_IN_ROW=1; also what the register/LDS-resident row variants need).
-  static const bool env_in_row = getenv("NFM_SINGLES_IN_ROW") && atoi(getenv("NFM_SINGLES_IN_ROW")) != 0;
+  // Where the singles are updated: by their own kernel between the row and the column phase (default;
+  // running them as extra workgroups of the column launch was measured to conserve the sum of the two
+  // times: the memory system is the limit), or inside the register/LDS-resident row variants.
   const bool have_singles = !GEN && P.use_singles;
-  const bool singles_in_row = have_singles && (env_in_row || getenv("NFM_LDS") || getenv("NFM_NQ"));
+  const bool singles_in_row = have_singles && (getenv("NFM_LDS") || getenv("NFM_NQ"));
   const bool singles_in_col = have_singles && !singles_in_row;
   int n_prev = 0;
   for (int64_t b = 0; b < P.n_batches; ++b) {
@@ -1050,7 +1053,7 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     int nB = (int)((u1 - u0 + per_block - 1) / per_block);
     nB += 1;  // + the closing workgroup
     const int nS = singles_in_col ? (len + kWavesPerBlock - 1) / kWavesPerBlock : 0;
-    nB += nS;  // + the singles workgroups (first in the grid: they are the long pole)
+    // the singles kernel writes parts[0, nS), the column phase parts[nS, nS + nB)
     double* parts_cur = W.partsB.as<double>() + (b & 1) * partsB_half;
     const double* parts_prev = W.partsB.as<double>() + ((b + 1) & 1) * partsB_half;
     {
@@ -1062,6 +1065,10 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
                  OPT == OPT_SGD ? W.Ftab.as<double>() + (size_t)b * 2 * kFtab : nullptr, W.Abuf.as<double>(),
                  W.rec.as<SampleRec>(), parts_cur, W.partsA.as<PartA>(), parts_prev, W.out_acc.as<double>(), it_b,
                  (double)len, it0p, TA, use_stored, nA, n_prev};
+      if (nS > 0) {
+        TimedLaunch tls(ctx, "singles");
+        hipLaunchKernelGGL((k_singles<L, OPT>), dim3(nS), dim3(kBlock), 0, st, ca);
+      }
       TimedLaunch tl(ctx, "col_phase");
       // touches are loaded in groups of TU before use; features touched only a few times (sparse
       // regime) waste registers, hence occupancy, on a wide group
@@ -1070,7 +1077,7 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
       else
         hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 4>), dim3(nB), dim3(kBlock), 0, st, ca);
     }
-    n_prev = nB;
+    n_prev = nB + nS;
   }
   if (P.n_batches > 0) {
     const double* parts_last = W.partsB.as<double>() + ((P.n_batches - 1) & 1) * partsB_half;
