@@ -276,7 +276,7 @@ __device__ __forceinline__ double singles_update(const CsrView& X, const ModelVi
 // parameter-row pieces it gathered for the forward pass in registers, so the in-place update of
 // the singles needs no second visit of the rows (HBM traffic of the row phase = the rows read once
 // + the single-touch rows written once).  NQ = 0: rows are streamed and singles re-read.
-template <int L, int SPLIT, int OPT, bool GEN, int NQ>
+template <int L, int SPLIT, int OPT, bool GEN, int NQ, bool SING>
 __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   constexpr int LPS = L * SPLIT, SPW = kWave / LPS, SPB = kWavesPerBlock * SPW;  // samples per wave / block
   constexpr bool REG = NQ > 0 && OPT == OPT_SGD && !GEN;
@@ -441,6 +441,11 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
         M.w[j] = wt - a0 / swn;
       }
     }
+  } else if (SING && !GEN && a.single != nullptr && valid) {
+    // stage 3 (sparse regime): singles updated right after the forward pass, while their rows are
+    // as warm as they will get (measured 157 us fused vs 66 + 109 us as a separate kernel, k = 64)
+    r_viol += singles_update<L, SPLIT, OPT>(X, M, O, a.single + a.toff[a.p0 + pib], a.scales, a.scales_n, q0, m, m_tot, slot, l,
+                                            dL, etaP, etaw, A1, itp, stored);
   }
   r_viol = dev::wave_sum(r_viol);
   if (lane == 0) s_viol[wv] = r_viol;
@@ -643,7 +648,7 @@ constexpr int kTouchUnroll = 4;
 
 // one parameter block (order) of one unique feature: this lane's factor pair at element e.
 // do_w: also accumulate the linear term's sums over the same touches.
-template <int OPT, bool GEN, int TU>
+template <int OPT, bool GEN, int TU, int LG>
 __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg, int slot, int l, int64_t t0, int64_t t1,
                                             double sP, double sPn, double fP, bool do_w, WAcc& wacc) {
   const ModelView& M = a.M;
@@ -673,47 +678,56 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
   double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
   double seta = 0.0;
   if (!GEN || deg == 2) {
-    // touches in groups of TU: all loads of a group are issued before the first use;
-    // the accumulation itself stays in touch (= sample) order
-    for (int64_t t = t0; t < t1; t += TU) {
-      int pib[TU];
-      double x[TU];
-      SampleRec r[TU];
-      double2 A1[TU];
+    // The touches' (sample, value) pairs are fetched L at a time, one touch per lane of the feature's
+    // lane group (one coalesced load instead of L same-address loads and one dependent round trip
+    // instead of one per TU touches), and handed round with ds_bpermute; the records and A rows of
+    // TU touches are then requested together.  The accumulation stays in touch (= sample) order.
+    const int gbase = (int)(threadIdx.x & (kWave - 1)) - l;  // first lane of this feature's group
+    for (int64_t tb = t0; tb < t1; tb += LG) {
+      const int64_t tl = tb + l;
+      const int pib_l = tl < t1 ? a.tpos[tl] : 0;
+      const double x_l = tl < t1 ? a.tx[tl] : 0.0;
+      const int cnt = (int)(t1 - tb < LG ? t1 - tb : LG);
+      for (int ub = 0; ub < cnt; ub += TU) {
+        int pib[TU];
+        double x[TU];
+        SampleRec r[TU];
+        double2 A1[TU];
 #pragma unroll
-      for (int u = 0; u < TU; ++u) {
-        const bool ok = t + u < t1;
-        pib[u] = ok ? a.tpos[t + u] : 0;
-        x[u] = ok ? a.tx[t + u] : 0.0;
-      }
+        for (int u = 0; u < TU; ++u) {
+          const int src = gbase + ((ub + u) < LG ? (ub + u) : 0);
+          pib[u] = __shfl(pib_l, src, kWave);
+          x[u] = dev::shfl_d(x_l, src);
+        }
 #pragma unroll
-      for (int u = 0; u < TU; ++u) {
-        r[u] = a.rec[pib[u]];
-        A1[u] = *reinterpret_cast<const double2*>(a.Abuf + ((size_t)pib[u] * a.TA + slot) * M.Kp + 2 * l);
-      }
+        for (int u = 0; u < TU; ++u) {
+          r[u] = a.rec[pib[u]];
+          A1[u] = *reinterpret_cast<const double2*>(a.Abuf + ((size_t)pib[u] * a.TA + slot) * M.Kp + 2 * l);
+        }
 #pragma unroll
-      for (int u = 0; u < TU; ++u) {
-        if (t + u < t1) {
-          const double dAx = x[u] * (A1[u].x - p.x * x[u]);
-          const double dAy = x[u] * (A1[u].y - p.y * x[u]);
-          if (OPT == OPT_SGD) {  // sgd.nim:220-222, averaged per coordinate below
-            acc.x += r[u].etaP * (r[u].dL * dAx);
-            acc.y += r[u].etaP * (r[u].dL * dAy);
-            seta += r[u].etaP;
-            if (do_w) {
-              wacc.a0 += r[u].etaw * (r[u].dL * x[u]);
-              wacc.a1 += r[u].etaw;
-            }
-          } else {  // adagrad.nim:122-124
-            const double gx = r[u].dL * dAx, gy = r[u].dL * dAy;
-            acc.x += gx;
-            acc.y += gy;
-            accn.x += gx * gx;
-            accn.y += gy * gy;
-            if (do_w) {
-              const double gw = r[u].dL * x[u];
-              wacc.a0 += gw;
-              wacc.a1 += gw * gw;
+        for (int u = 0; u < TU; ++u) {
+          if (ub + u < cnt) {
+            const double dAx = x[u] * (A1[u].x - p.x * x[u]);
+            const double dAy = x[u] * (A1[u].y - p.y * x[u]);
+            if (OPT == OPT_SGD) {  // sgd.nim:220-222, averaged per coordinate below
+              acc.x += r[u].etaP * (r[u].dL * dAx);
+              acc.y += r[u].etaP * (r[u].dL * dAy);
+              seta += r[u].etaP;
+              if (do_w) {
+                wacc.a0 += r[u].etaw * (r[u].dL * x[u]);
+                wacc.a1 += r[u].etaw;
+              }
+            } else {  // adagrad.nim:122-124
+              const double gx = r[u].dL * dAx, gy = r[u].dL * dAy;
+              acc.x += gx;
+              acc.y += gy;
+              accn.x += gx * gx;
+              accn.y += gy * gy;
+              if (do_w) {
+                const double gw = r[u].dL * x[u];
+                wacc.a0 += gw;
+                wacc.a1 += gw * gw;
+              }
             }
           }
         }
@@ -849,7 +863,7 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
     for (int o = 0; o < M.nb; ++o) {
       const size_t e = ((size_t)o * M.da + j) * M.Kp + 2 * l;
       const int deg = M.degree - o;
-      viol += col_block<OPT, GEN, TU>(a, e, deg, slot, l, t0, t1, sP, sPn, fP, has_w && o == 0, wacc);
+      viol += col_block<OPT, GEN, TU, L>(a, e, deg, slot, l, t0, t1, sP, sPn, fP, has_w && o == 0, wacc);
       slot += deg - 1;
     }
     if (has_w) {
@@ -960,19 +974,22 @@ __global__ __launch_bounds__(kBlock) void k_epoch_close(const double* __restrict
 // ------------------------------------------------------------------------------------------------
 template <int L, int SPLIT, int OPT, bool GEN>
 static void launch_row(hipStream_t st, const RowArgs& ra, int nq, int pad_kb = 0) {
+  const bool sing = ra.single != nullptr;
   constexpr int SPW = kWave / (L * SPLIT);
   const int nA = (ra.len + kWavesPerBlock * SPW - 1) / (kWavesPerBlock * SPW);
   if (pad_kb > 0 && nq == 0) {  // tuning: unused dynamic LDS caps the workgroups per CU
-    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0>), dim3(nA), dim3(kBlock), (size_t)pad_kb * 1024, st, ra);
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0, !GEN>), dim3(nA), dim3(kBlock), (size_t)pad_kb * 1024, st, ra);
     return;
   }
   constexpr bool CAN_REG = OPT == OPT_SGD && !GEN && L >= 8;  // register-resident rows: k >= 16
   if (CAN_REG && nq == 16)
-    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 16 : 0)>), dim3(nA), dim3(kBlock), 0, st, ra);
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 16 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
   else if (CAN_REG && nq == 32)
-    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 32 : 0)>), dim3(nA), dim3(kBlock), 0, st, ra);
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 32 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
+  else if (sing && !GEN)
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0, !GEN>), dim3(nA), dim3(kBlock), 0, st, ra);
   else
-    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0>), dim3(nA), dim3(kBlock), 0, st, ra);
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0, false>), dim3(nA), dim3(kBlock), 0, st, ra);
 }
 
 template <int L, int OPT, bool GEN>
@@ -988,11 +1005,13 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
   const char* tu_env = getenv("NFM_TU");
   const bool few_touches = tu_env ? atoi(tu_env) == 2 : (P.U > 0 && (double)P.TM / (double)P.U < 3.0);
   static const int row_pad_kb = getenv("NFM_ROW_PAD_KB") ? atoi(getenv("NFM_ROW_PAD_KB")) : 0;  // occupancy cap (tuning)
-  // Where the singles are updated: by their own kernel between the row and the column phase (default;
-  // running them as extra workgroups of the column launch was measured to conserve the sum of the two
-  // times: the memory system is the limit), or inside the register/LDS-resident row variants.
+  // Where the singles are updated: as stage 3 of the row phase (default), or by their own kernel
+  // between the row and the column phase (NFM_SINGLES_KERNEL=1: 66 + 109 us vs 157 us fused at k = 64;
+  // as extra workgroups of the column launch the sum of the times was conserved as well: the memory
+  // system is the limit, not latency).
   const bool have_singles = !GEN && P.use_singles;
-  const bool singles_in_row = have_singles && (getenv("NFM_LDS") || getenv("NFM_NQ"));
+  static const bool env_kernel = getenv("NFM_SINGLES_KERNEL") && atoi(getenv("NFM_SINGLES_KERNEL")) != 0;
+  const bool singles_in_row = have_singles && !env_kernel;
   const bool singles_in_col = have_singles && !singles_in_row;
   int n_prev = 0;
   for (int64_t b = 0; b < P.n_batches; ++b) {
