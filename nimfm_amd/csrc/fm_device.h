@@ -138,7 +138,11 @@ __device__ __forceinline__ void row_entry(const CsrView& X, int64_t q0, int m, i
   }
 }
 
-constexpr int kUnroll = 4;  // independent parameter-row loads in flight per lane
+constexpr int kUnroll = 4;  // rows requested together per lane in the singles update
+#ifndef NFM_FWD_UNROLL
+#define NFM_FWD_UNROLL 8
+#endif
+constexpr int kFwdUnroll = NFM_FWD_UNROLL;  // independent parameter-row loads in flight per lane (forward)
 
 // ---- ANOVA forward, degree 2: the sum-of-squares trick (optimizer/sgd.nim:160-170,
 // kernels.nim:59-64).  A1 = sum x p, A2 = sum (x p)^2 for this lane's factor pair over the whole
@@ -147,16 +151,16 @@ template <int L, int SPLIT, class PS>
 __device__ __forceinline__ void anova_fwd_deg2(const PS& ps, const CsrView& X, int64_t q0, int m, int m_tot,
                                                size_t blk_off, int Kp, int slot, int l, double2& A1, double2& A2) {
   double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
-  for (int q = slot; q < m_tot; q += kUnroll * SPLIT) {
-    int j[kUnroll];
-    double x[kUnroll];
-    double2 p[kUnroll];
+  for (int q = slot; q < m_tot; q += kFwdUnroll * SPLIT) {
+    int j[kFwdUnroll];
+    double x[kFwdUnroll];
+    double2 p[kFwdUnroll];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) row_entry(X, q0, m, m_tot, q + u * SPLIT, j[u], x[u]);
+    for (int u = 0; u < kFwdUnroll; ++u) row_entry(X, q0, m, m_tot, q + u * SPLIT, j[u], x[u]);
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) p[u] = ps.load(blk_off + (size_t)j[u] * Kp + 2 * l);
+    for (int u = 0; u < kFwdUnroll; ++u) p[u] = ps.load(blk_off + (size_t)j[u] * Kp + 2 * l);
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
+    for (int u = 0; u < kFwdUnroll; ++u) {
       const double tx = x[u] * p[u].x, ty = x[u] * p[u].y;
       a1.x += tx;
       a1.y += ty;

@@ -1002,8 +1002,10 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
   const double* it0p = W.itbuf.as<double>();
   const double avg_row = X.n > 0 ? (double)X.nnz / (double)X.n + M.n_aug : 0.0;
   const size_t partsB_half = W.partsB.bytes / sizeof(double) / 2;
+  // records / A rows requested together per feature; 2 measured best on cfg2 and the headline shape
+  // (4: 104 VGPRs -> 4 waves per SIMD, 2: 80 -> 6)
   const char* tu_env = getenv("NFM_TU");
-  const bool few_touches = tu_env ? atoi(tu_env) == 2 : (P.U > 0 && (double)P.TM / (double)P.U < 3.0);
+  const int tu = tu_env ? atoi(tu_env) : 2;
   static const int row_pad_kb = getenv("NFM_ROW_PAD_KB") ? atoi(getenv("NFM_ROW_PAD_KB")) : 0;  // occupancy cap (tuning)
   // Where the singles are updated: as stage 3 of the row phase (default), or by their own kernel
   // between the row and the column phase (NFM_SINGLES_KERNEL=1: 66 + 109 us vs 157 us fused at k = 64;
@@ -1089,12 +1091,12 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
         hipLaunchKernelGGL((k_singles<L, OPT>), dim3(nS), dim3(kBlock), 0, st, ca);
       }
       TimedLaunch tl(ctx, "col_phase");
-      // touches are loaded in groups of TU before use; features touched only a few times (sparse
-      // regime) waste registers, hence occupancy, on a wide group
-      if (few_touches)
-        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 2>), dim3(nB), dim3(kBlock), 0, st, ca);
-      else
+      if (tu == 1)
+        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 1>), dim3(nB), dim3(kBlock), 0, st, ca);
+      else if (tu == 4)
         hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 4>), dim3(nB), dim3(kBlock), 0, st, ca);
+      else
+        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 2>), dim3(nB), dim3(kBlock), 0, st, ca);
     }
     n_prev = nB + nS;
   }
