@@ -32,6 +32,8 @@ WORKLOADS = {
     "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="logistic", batch=8192),
     "cfg3": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="squared", batch=8192),
     "tiny": dict(n=50_000, d=5_000, m=16, k=8, degree=2, solver="sgd", loss="logistic", batch=4096),
+    # cfg2 with Zipf(1.1) feature popularity: a few features are touched by most samples of a batch
+    "cfg2z": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768, zipf=1.1),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
@@ -43,18 +45,33 @@ def algorithmic_bytes_per_sample(solver, m, k, n_orders=1):
     return 12 * m + 16 + n_orders * 32 * m * k + 32 * m
 
 
-def gen_shard(torch, dev, n, d, m, seed):
-    """m distinct uniform-random column indices per row (sorted), values U(-1,1)."""
+def gen_shard(torch, dev, n, d, m, seed, zipf=0.0):
+    """m distinct column indices per row (sorted), values U(-1,1).  zipf = 0: uniform popularity;
+    zipf = s > 0: feature j drawn with probability ~ 1/(j+1)^s (SURVEY.md 8d secondary distribution)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    idx = torch.randint(0, d, (n, m), device=dev, generator=g, dtype=torch.int64)
-    idx, _ = torch.sort(idx, dim=1)
-    for _ in range(64):  # re-draw the few rows that contain a repeated index
-        bad = (idx[:, 1:] == idx[:, :-1]).any(dim=1).nonzero().flatten()
-        if bad.numel() == 0:
+    cdf = None
+    if zipf > 0:
+        pj = 1.0 / torch.arange(1, d + 1, device=dev, dtype=torch.float64) ** zipf
+        cdf = torch.cumsum(pj / pj.sum(), 0)
+
+    def draw(rows):
+        if cdf is None:
+            return torch.randint(0, d, (rows, m), device=dev, generator=g, dtype=torch.int64)
+        u = torch.rand((rows, m), device=dev, generator=g, dtype=torch.float64)
+        return torch.searchsorted(cdf, u).clamp_(max=d - 1)
+
+    idx, _ = torch.sort(draw(n), dim=1)
+    for _ in range(1000):  # re-draw the repeated entries (only those) until every row is distinct
+        dup = torch.zeros_like(idx, dtype=torch.bool)
+        dup[:, 1:] = idx[:, 1:] == idx[:, :-1]
+        k_dup = int(dup.sum())
+        if k_dup == 0:
             break
-        fresh = torch.randint(0, d, (bad.numel(), m), device=dev, generator=g, dtype=torch.int64)
-        idx[bad], _ = torch.sort(fresh, dim=1)
+        idx[dup] = draw((k_dup + m - 1) // m).reshape(-1)[:k_dup]
+        idx, _ = torch.sort(idx, dim=1)
+    else:
+        raise SystemExit("could not draw distinct indices")
     val = torch.rand((n, m), device=dev, generator=g, dtype=torch.float64) * 2.0 - 1.0
     indptr = torch.arange(n + 1, device=dev, dtype=torch.int64) * m
     return indptr, idx.to(torch.int32).reshape(-1).contiguous(), val.reshape(-1).contiguous()
@@ -98,7 +115,7 @@ def main():
     ctx = nf.Context(local_rank)
     nf.set_default_context(ctx)
     # ---- synthetic shard, generated on the device (data seed 42 + rank; model seed 1) ----
-    indptr, indices, data = gen_shard(torch, dev, n, d, m, 42 + rank)
+    indptr, indices, data = gen_shard(torch, dev, n, d, m, 42 + rank, wl.get("zipf", 0.0))
     torch.cuda.synchronize()
     X = nf.CSRDataset.from_device(ctx, n, d, n * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(),
                                   keep=(indptr, indices, data))

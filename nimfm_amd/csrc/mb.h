@@ -17,6 +17,7 @@ struct MbWork {
   DevBuf out_acc;  // {loss_sum, viol_sum} of the epoch call
   DevBuf contrib;  // FFM: per-touch gradient rows
   DevBuf itbuf;    // device scalar: `it` at the start of the epoch call
+  DevBuf hpart;    // heavy features: per-segment partial sums
   // hipGraph of one epoch call over a reusable plan
   bool use_graph = true;
   void* graph_exec = nullptr;

@@ -648,9 +648,15 @@ constexpr int kTouchUnroll = 4;
 
 // one parameter block (order) of one unique feature: this lane's factor pair at element e.
 // do_w: also accumulate the linear term's sums over the same touches.
-template <int OPT, bool GEN, int TU, int LG>
+// MODE 0: the whole feature (walk the touches, apply).  Heavy features (plan.h) are done in two steps:
+// MODE 1 walks ONE segment of the touches and stores the partial sums to hp (no side effects),
+// MODE 2 adds the nseg segments' partial sums in segment order and applies.  hp points at this
+// lane's slot of the feature's first segment; a segment's record is PW doubles:
+// [acc Kp][accn Kp][seta, wacc.a0, wacc.a1, -].
+template <int OPT, bool GEN, int TU, int LG, int MODE>
 __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg, int slot, int l, int64_t t0, int64_t t1,
-                                            double sP, double sPn, double fP, bool do_w, WAcc& wacc) {
+                                            double sP, double sPn, double fP, bool do_w, WAcc& wacc, double c_total = 0.0,
+                                            double* hp = nullptr, int64_t nseg = 0, int PW = 0) {
   const ModelView& M = a.M;
   const OptView& O = a.O;
   double viol = 0.0;
@@ -668,7 +674,7 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
       const double tmp = O.eta0 * ((a.it0p[0] + a.it_b) - 1.0) * O.beta;
       p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmp);
       p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmp);
-      if (O.track_viol) {  // adagrad.nim:96-99: sum |old - new| over the touched rows
+      if (O.track_viol && MODE != 1) {  // adagrad.nim:96-99: sum |old - new| over the touched rows
         stored = *reinterpret_cast<const double2*>(M.P + e);
         viol += fabs(stored.x - p.x) + fabs(stored.y - p.y);
         *reinterpret_cast<double2*>(M.P + e) = p;
@@ -677,7 +683,23 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
   }
   double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
   double seta = 0.0;
-  if (!GEN || deg == 2) {
+  if (MODE == 2) {
+    for (int64_t sg = 0; sg < nseg; ++sg) {
+      const double* rec_ = hp + (size_t)sg * PW;
+      const double2 pa = *reinterpret_cast<const double2*>(rec_);
+      const double2 pn = *reinterpret_cast<const double2*>(rec_ + M.Kp);
+      acc.x += pa.x;
+      acc.y += pa.y;
+      accn.x += pn.x;
+      accn.y += pn.y;
+      const double* sc_ = rec_ - 2 * l + 2 * M.Kp;
+      seta += sc_[0];
+      if (do_w) {
+        wacc.a0 += sc_[1];
+        wacc.a1 += sc_[2];
+      }
+    }
+  } else if (!GEN || deg == 2) {
     // The touches' (sample, value) pairs are fetched L at a time, one touch per lane of the feature's
     // lane group (one coalesced load instead of L same-address loads and one dependent round trip
     // instead of one per TU touches), and handed round with ds_bpermute; the records and A rows of
@@ -774,8 +796,20 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
       }
     }
   }
+  if (MODE == 1) {
+    *reinterpret_cast<double2*>(hp) = acc;
+    *reinterpret_cast<double2*>(hp + M.Kp) = accn;
+    if (l == 0) {
+      double* sc_ = hp + 2 * M.Kp;
+      sc_[0] = seta;
+      sc_[1] = wacc.a0;
+      sc_[2] = wacc.a1;
+      sc_[3] = 0.0;
+    }
+    return 0.0;
+  }
   if (OPT == OPT_SGD) {
-    const double c = (double)(t1 - t0);
+    const double c = MODE == 0 ? (double)(t1 - t0) : c_total;
     viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
     stored.x = stored.x * fP - (acc.x / c) / sPn;
     stored.y = stored.y * fP - (acc.y / c) / sPn;
@@ -789,6 +823,122 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
     *reinterpret_cast<double2*>(O.N + e) = n2;
   }
   return viol;
+}
+
+// linear term of one feature (fit_linear.nim:41-57); every lane of the feature holds the same sums
+template <int OPT>
+__device__ __forceinline__ double w_epilogue(const ColArgs& a, int64_t j, int l, double c, double sw, double swn, double fw,
+                                             const WAcc& wacc) {
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  double viol = 0.0;
+  const double wt = M.w[j];
+  if (OPT == OPT_SGD) {
+    const double wj = sw * wt;
+    if (l == 0) {
+      viol += fabs((wacc.a0 + wacc.a1 * O.alpha * wj) / c);
+      M.w[j] = wt * fw - (wacc.a0 / c) / swn;
+    }
+  } else {
+    const double gw = O.Gw[j], nw = O.Nw[j];
+    if (l == 0) {
+      if (!a.use_stored) {
+        const double wj = -O.eta0 * gw / (((a.it0p[0] + a.it_b) - 1.0) * O.eta0 * O.alpha + sqrt(nw));
+        viol += fabs(wt - wj);
+        M.w[j] = wj;
+      }
+      O.Gw[j] = gw + wacc.a0;
+      O.Nw[j] = nw + wacc.a1;
+    }
+  }
+  return viol;
+}
+
+// decay corrections of a coordinate touched c times (schedule kernel's table, pow beyond it)
+__device__ __forceinline__ void touch_factors(const ColArgs& a, int64_t c, double& fP, double& fw) {
+  fP = 1.0;
+  fw = 1.0;
+  if (c > 1) {
+    if (c <= kFtab) {
+      fP = a.Ftab_b[c - 1];
+      fw = a.Ftab_b[kFtab + c - 1];
+    } else {
+      fP = pow(a.Dtab_b[0], 1.0 / (double)c) / a.Dtab_b[0];
+      fw = pow(a.Dtab_b[1], 1.0 / (double)c) / a.Dtab_b[1];
+    }
+  }
+}
+
+// ---- heavy features (degree-2 models): segment partial sums, then per-feature apply ----
+struct HeavyArgs {
+  const int64_t* hv_u;     // heavy feature -> index into ucol / uptr
+  const int64_t* hv_seg0;  // heavy feature -> its first segment
+  int64_t h0, h1, s0, s1;  // this batch's heavy features / segments
+  double* hpart;           // [s1 - s0][PW]
+  double* parts;           // per-block viol partials of the apply kernel
+  int32_t PW, pad_;
+};
+
+template <int L, int OPT>
+__global__ __launch_bounds__(kBlock) void k_heavy_partial(ColArgs a, HeavyArgs hv) {
+  constexpr int R = kWave / L;
+  const ModelView& M = a.M;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int64_t gs = hv.s0 + ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  if (gs >= hv.s1) return;
+  int64_t lo = hv.h0, hi = hv.h1 - 1;  // last heavy feature whose first segment is <= gs
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (hv.hv_seg0[mid] <= gs) lo = mid; else hi = mid - 1;
+  }
+  const int64_t u = hv.hv_u[lo];
+  const int64_t j = a.ucol[u];
+  const int64_t t0 = a.uptr[u] + (gs - hv.hv_seg0[lo]) * kHeavySegment;
+  const int64_t t1 = min(t0 + (int64_t)kHeavySegment, a.uptr[u + 1]);
+  const double sP = OPT == OPT_SGD ? a.scales_b[0] : 1.0;
+  const bool has_w = M.fit_linear && j < M.d;
+  WAcc wacc;
+  col_block<OPT, false, 2, L, 1>(a, (size_t)j * M.Kp + 2 * l, 2, 0, l, t0, t1, sP, 1.0, 1.0, has_w, wacc, 0.0,
+                                 hv.hpart + (size_t)(gs - hv.s0) * hv.PW + 2 * l, 0, hv.PW);
+}
+
+template <int L, int OPT>
+__global__ __launch_bounds__(kBlock) void k_heavy_apply(ColArgs a, HeavyArgs hv) {
+  constexpr int R = kWave / L;
+  __shared__ double red[kWavesPerBlock];
+  const ModelView& M = a.M;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int64_t h = hv.h0 + ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  double viol = 0.0;
+  if (h < hv.h1) {
+    const int64_t u = hv.hv_u[h];
+    const int64_t j = a.ucol[u];
+    const int64_t c = a.uptr[u + 1] - a.uptr[u];
+    double sP = 1.0, sPn = 1.0, sw = 1.0, swn = 1.0, fP = 1.0, fw = 1.0;
+    if (OPT == OPT_SGD) {
+      sP = a.scales_b[0];
+      sw = a.scales_b[1];
+      sPn = a.scales_n[0];
+      swn = a.scales_n[1];
+      touch_factors(a, c, fP, fw);
+    }
+    const bool has_w = M.fit_linear && j < M.d;
+    WAcc wacc;
+    const int64_t sg0 = hv.hv_seg0[h], nseg = hv.hv_seg0[h + 1] - sg0;
+    viol += col_block<OPT, false, 2, L, 2>(a, (size_t)j * M.Kp + 2 * l, 2, 0, l, 0, 0, sP, sPn, fP, has_w, wacc, (double)c,
+                                           hv.hpart + (size_t)(sg0 - hv.s0) * hv.PW + 2 * l, nseg, hv.PW);
+    if (has_w) viol += w_epilogue<OPT>(a, j, l, (double)c, sw, swn, fw, wacc);
+  }
+  viol = dev::wave_sum(viol);
+  if (lane == 0) red[wv] = viol;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) v += red[w_];
+    hv.parts[blockIdx.x] = v;
+  }
 }
 
 // singles kernel: one wavefront per sample of the batch updates, in place, the features only that
@@ -837,7 +987,8 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
   const int fb = blockIdx.x;                        // feature workgroup index
   const bool closer = blockIdx.x == gridDim.x - 1;  // the extra, last workgroup only closes the batch
   const int64_t u = closer ? a.u1 : a.u0 + ((int64_t)fb * kWavesPerBlock + wv) * R + g;
-  if (u < a.u1) {
+  // heavy features of degree-2 models are summed by k_heavy_partial / k_heavy_apply
+  if (u < a.u1 && (GEN || a.uptr[u + 1] - a.uptr[u] <= kHeavyTouches)) {
     const int64_t j = a.ucol[u];
     const int64_t t0 = a.uptr[u], t1 = a.uptr[u + 1];
     double sP = 1.0, sPn = 1.0, sw = 1.0, swn = 1.0, fP = 1.0, fw = 1.0;
@@ -846,16 +997,7 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
       sw = a.scales_b[1];
       sPn = a.scales_n[0];
       swn = a.scales_n[1];
-      const int64_t c = t1 - t0;
-      if (c > 1) {
-        if (c <= kFtab) {
-          fP = a.Ftab_b[c - 1];
-          fw = a.Ftab_b[kFtab + c - 1];
-        } else {
-          fP = pow(a.Dtab_b[0], 1.0 / (double)c) / a.Dtab_b[0];
-          fw = pow(a.Dtab_b[1], 1.0 / (double)c) / a.Dtab_b[1];
-        }
-      }
+      touch_factors(a, t1 - t0, fP, fw);
     }
     const bool has_w = M.fit_linear && j < M.d;  // dummy features have no w
     WAcc wacc;
@@ -863,7 +1005,7 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
     for (int o = 0; o < M.nb; ++o) {
       const size_t e = ((size_t)o * M.da + j) * M.Kp + 2 * l;
       const int deg = M.degree - o;
-      viol += col_block<OPT, GEN, TU, L>(a, e, deg, slot, l, t0, t1, sP, sPn, fP, has_w && o == 0, wacc);
+      viol += col_block<OPT, GEN, TU, L, 0>(a, e, deg, slot, l, t0, t1, sP, sPn, fP, has_w && o == 0, wacc);
       slot += deg - 1;
     }
     if (has_w) {
@@ -880,27 +1022,7 @@ __global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
           }
         }
       }
-      // linear term (fit_linear.nim:41-57); every lane of the feature holds the same sums
-      const double wt = M.w[j];
-      if (OPT == OPT_SGD) {
-        const double wj = sw * wt;
-        const double c = (double)(t1 - t0);
-        if (l == 0) {
-          viol += fabs((wacc.a0 + wacc.a1 * O.alpha * wj) / c);
-          M.w[j] = wt * fw - (wacc.a0 / c) / swn;
-        }
-      } else {
-        const double gw = O.Gw[j], nw = O.Nw[j];
-        if (l == 0) {
-          if (!a.use_stored) {
-            const double wj = -O.eta0 * gw / (((a.it0p[0] + a.it_b) - 1.0) * O.eta0 * O.alpha + sqrt(nw));
-            viol += fabs(wt - wj);
-            M.w[j] = wj;
-          }
-          O.Gw[j] = gw + wacc.a0;
-          O.Nw[j] = nw + wacc.a1;
-        }
-      }
+      viol += w_epilogue<OPT>(a, j, l, (double)(t1 - t0), sw, swn, fw, wacc);
     }
   }
   viol = dev::wave_sum(viol);
@@ -1098,7 +1220,25 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
       else
         hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 2>), dim3(nB), dim3(kBlock), 0, st, ca);
     }
-    n_prev = nB + nS;
+    int nH = 0;
+    if (!GEN && P.bat_hoff[b + 1] > P.bat_hoff[b]) {
+      const int PW = 2 * M.Kp + 4;
+      HeavyArgs ha{P.hv_u.as<int64_t>(), P.hv_seg0.as<int64_t>(), P.bat_hoff[b], P.bat_hoff[b + 1], P.bat_soff[b],
+                   P.bat_soff[b + 1], W.hpart.as<double>(), parts_cur + nS + nB, PW, 0};
+      ColArgs ca{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, nullptr, nullptr, P.begin, p0, len, nS,
+                 P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(), u0, u1,
+                 OPT == OPT_SGD ? Stab + 2 * b : M.sc, OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc,
+                 OPT == OPT_SGD ? Dtab + 4 * b : nullptr,
+                 OPT == OPT_SGD ? W.Ftab.as<double>() + (size_t)b * 2 * kFtab : nullptr, W.Abuf.as<double>(),
+                 W.rec.as<SampleRec>(), parts_cur, W.partsA.as<PartA>(), parts_prev, W.out_acc.as<double>(), it_b,
+                 (double)len, it0p, TA, use_stored, nA, n_prev};
+      const int nsb = (int)((ha.s1 - ha.s0 + per_block - 1) / per_block);
+      nH = (int)((ha.h1 - ha.h0 + per_block - 1) / per_block);
+      TimedLaunch tl(ctx, "heavy");
+      hipLaunchKernelGGL((k_heavy_partial<L, OPT>), dim3(nsb), dim3(kBlock), 0, st, ca, ha);
+      hipLaunchKernelGGL((k_heavy_apply<L, OPT>), dim3(nH), dim3(kBlock), 0, st, ca, ha);
+    }
+    n_prev = nB + nS + nH;
   }
   if (P.n_batches > 0) {
     const double* parts_last = W.partsB.as<double>() + ((P.n_batches - 1) & 1) * partsB_half;
@@ -1162,17 +1302,18 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   int TA = 0;
   for (int o = 0; o < M.nb; ++o) TA += M.degree - o - 1;
   constexpr int kMinGroupsPerBlock = kWavesPerBlock;  // L = 64
-  const void* before[] = {W.Abuf.p, W.rec.p, W.partsA.p, W.partsB.p, W.Dtab.p, W.Stab.p, W.Ftab.p, W.out_acc.p, W.itbuf.p};
+  const void* before[] = {W.Abuf.p, W.rec.p, W.partsA.p, W.partsB.p, W.Dtab.p, W.Stab.p, W.Ftab.p, W.out_acc.p, W.itbuf.p, W.hpart.p};
   NFM_TRY(W.Abuf.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_batch, 1) * std::max(TA, 1) * M.Kp));
   NFM_TRY(W.rec.ensure(sizeof(SampleRec) * (size_t)std::max<int64_t>(P.max_batch, 1)));
   NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch / kWavesPerBlock + 1)));
-  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique / kMinGroupsPerBlock + P.max_batch / kWavesPerBlock + 4)));
+  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique / kMinGroupsPerBlock + P.max_batch / kWavesPerBlock + P.max_heavy / kMinGroupsPerBlock + 6)));
+  NFM_TRY(W.hpart.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_segs, 1) * (2 * M.Kp + 4)));
   NFM_TRY(W.Dtab.ensure(sizeof(double) * 4 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Stab.ensure(sizeof(double) * 2 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Ftab.ensure(sizeof(double) * 2 * kFtab * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.out_acc.ensure(sizeof(double) * 2));
   NFM_TRY(W.itbuf.ensure(sizeof(double)));
-  const void* after[] = {W.Abuf.p, W.rec.p, W.partsA.p, W.partsB.p, W.Dtab.p, W.Stab.p, W.Ftab.p, W.out_acc.p, W.itbuf.p};
+  const void* after[] = {W.Abuf.p, W.rec.p, W.partsA.p, W.partsB.p, W.Dtab.p, W.Stab.p, W.Ftab.p, W.out_acc.p, W.itbuf.p, W.hpart.p};
   for (size_t q = 0; q < sizeof(before) / sizeof(before[0]); ++q)
     if (before[q] != after[q]) W.drop_graph();
   hipLaunchKernelGGL(k_set_double, dim3(1), dim3(1), 0, st, W.itbuf.as<double>(), (double)it0);

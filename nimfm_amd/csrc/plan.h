@@ -30,8 +30,20 @@ struct Plan {
   DevBuf tq;                      // int64[TM] (only when want_tq)
   DevBuf toff;                    // int64[end-begin+1] touch offset of every sample (with use_singles / want_tq)
   DevBuf single;                  // uint8[T] in sample order: 1 = the feature is touched once in its batch
+  // "heavy" features (more than kHeavyTouches touches in one batch, e.g. Zipf heads or dummy features):
+  // their touch lists are cut into segments of kHeavySegment touches that separate lane groups sum,
+  // then one group per feature adds the segments' partial sums in segment order (deterministic).
+  int64_t H = 0, HS = 0;          // heavy features / their segments, all batches
+  std::vector<int64_t> bat_hoff;  // host, n_batches + 1: first heavy feature of every batch
+  std::vector<int64_t> bat_soff;  // host, n_batches + 1: first heavy segment of every batch
+  int64_t max_heavy = 0, max_segs = 0;
+  DevBuf hv_u;                    // int64[H]   index into ucol/uptr
+  DevBuf hv_seg0;                 // int64[H+1] first segment of every heavy feature
   void release();
 };
+
+constexpr int kHeavyTouches = 256;  // above this a feature's touches are summed by several lane groups
+constexpr int kHeavySegment = 128;
 
 int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
                int64_t batch, bool first_singleton, bool want_tq, bool use_singles, Plan* out);

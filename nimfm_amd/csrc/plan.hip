@@ -21,6 +21,11 @@ void Plan::release() {
   tq.release();
   toff.release();
   single.release();
+  hv_u.release();
+  hv_seg0.release();
+  bat_hoff.clear();
+  bat_soff.clear();
+  H = HS = max_heavy = max_segs = 0;
   bat_pos.clear();
   bat_uoff.clear();
   n_batches = U = T = TM = 0;
@@ -123,6 +128,32 @@ __global__ void k_compact(int64_t T, const uint64_t* __restrict__ keys, const ui
 __global__ void k_batch_first(int64_t U, const int64_t* __restrict__ ubatch, int64_t* __restrict__ bat_first_u) {
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x)
     if (u == 0 || ubatch[u - 1] != ubatch[u]) bat_first_u[ubatch[u]] = u;
+}
+
+// per unique feature: is it heavy, and how many segments does it need
+__global__ void k_heavy_flags(int64_t U, const int64_t* __restrict__ uptr, int64_t* __restrict__ hflag, int64_t* __restrict__ nseg) {
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u <= U; u += (int64_t)gridDim.x * blockDim.x) {
+    if (u == U) {
+      hflag[u] = 0;
+      nseg[u] = 0;
+      continue;
+    }
+    const int64_t c = uptr[u + 1] - uptr[u];
+    const bool heavy = c > kHeavyTouches;
+    hflag[u] = heavy ? 1 : 0;
+    nseg[u] = heavy ? (c + kHeavySegment - 1) / kHeavySegment : 0;
+  }
+}
+__global__ void k_heavy_compact(int64_t U, const int64_t* __restrict__ hidx, const int64_t* __restrict__ segoff,
+                                int64_t* __restrict__ hv_u, int64_t* __restrict__ hv_seg0) {
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x)
+    if (hidx[u + 1] != hidx[u]) {
+      hv_u[hidx[u]] = u;
+      hv_seg0[hidx[u]] = segoff[u];
+    }
+}
+__global__ void k_gather_i64(int64_t n, const int64_t* __restrict__ src, const int64_t* __restrict__ at, int64_t* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[at[i]];
 }
 
 __global__ void k_set_i64(int64_t* p, int64_t n, int64_t v) {
@@ -256,6 +287,47 @@ int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_ho
   for (int64_t b = P.n_batches - 1; b >= 0; --b) P.bat_uoff[b] = first[b] != none ? first[b] : P.bat_uoff[b + 1];
   P.max_unique = 0;
   for (int64_t b = 0; b < P.n_batches; ++b) P.max_unique = std::max(P.max_unique, P.bat_uoff[b + 1] - P.bat_uoff[b]);
+  // heavy features: flags -> scans -> compact lists + per-batch offsets
+  P.bat_hoff.assign(P.n_batches + 1, 0);
+  P.bat_soff.assign(P.n_batches + 1, 0);
+  if (U > 0) {
+    DevBuf hflag, nseg, hidx, segoff, uoff_dev, hoff_dev, soff_dev;
+    NFM_TRY(hflag.alloc(sizeof(int64_t) * (U + 1))); NFM_TRY(nseg.alloc(sizeof(int64_t) * (U + 1)));
+    NFM_TRY(hidx.alloc(sizeof(int64_t) * (U + 1))); NFM_TRY(segoff.alloc(sizeof(int64_t) * (U + 1)));
+    hipLaunchKernelGGL(k_heavy_flags, dim3(grid1d(U + 1)), dim3(kBlock), 0, st, U, P.uptr.as<int64_t>(), hflag.as<int64_t>(),
+                       nseg.as<int64_t>());
+    tmp_bytes = 0;
+    NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, hflag.as<int64_t>(), hidx.as<int64_t>(), (int)(U + 1), st));
+    NFM_TRY(tmp.alloc(tmp_bytes));
+    NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, hflag.as<int64_t>(), hidx.as<int64_t>(), (int)(U + 1), st));
+    NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, nseg.as<int64_t>(), segoff.as<int64_t>(), (int)(U + 1), st));
+    // offsets at the batch boundaries
+    NFM_TRY(uoff_dev.alloc(sizeof(int64_t) * (P.n_batches + 1)));
+    NFM_TRY(hoff_dev.alloc(sizeof(int64_t) * (P.n_batches + 1)));
+    NFM_TRY(soff_dev.alloc(sizeof(int64_t) * (P.n_batches + 1)));
+    NFM_HIP_CHECK(hipMemcpyAsync(uoff_dev.p, P.bat_uoff.data(), sizeof(int64_t) * (P.n_batches + 1), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather_i64, dim3(grid1d(P.n_batches + 1)), dim3(kBlock), 0, st, P.n_batches + 1, hidx.as<int64_t>(),
+                       uoff_dev.as<int64_t>(), hoff_dev.as<int64_t>());
+    hipLaunchKernelGGL(k_gather_i64, dim3(grid1d(P.n_batches + 1)), dim3(kBlock), 0, st, P.n_batches + 1, segoff.as<int64_t>(),
+                       uoff_dev.as<int64_t>(), soff_dev.as<int64_t>());
+    NFM_HIP_CHECK(hipMemcpyAsync(P.bat_hoff.data(), hoff_dev.p, sizeof(int64_t) * (P.n_batches + 1), hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipMemcpyAsync(P.bat_soff.data(), soff_dev.p, sizeof(int64_t) * (P.n_batches + 1), hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+    P.H = P.bat_hoff[P.n_batches];
+    P.HS = P.bat_soff[P.n_batches];
+    NFM_TRY(P.hv_u.alloc(sizeof(int64_t) * std::max<int64_t>(P.H, 1)));
+    NFM_TRY(P.hv_seg0.alloc(sizeof(int64_t) * (P.H + 1)));
+    if (P.H > 0) {
+      hipLaunchKernelGGL(k_heavy_compact, dim3(grid1d(U)), dim3(kBlock), 0, st, U, hidx.as<int64_t>(), segoff.as<int64_t>(),
+                         P.hv_u.as<int64_t>(), P.hv_seg0.as<int64_t>());
+      NFM_HIP_CHECK(hipMemcpyAsync(P.hv_seg0.as<int64_t>() + P.H, &P.HS, sizeof(int64_t), hipMemcpyHostToDevice, st));
+      NFM_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    for (int64_t b = 0; b < P.n_batches; ++b) {
+      P.max_heavy = std::max(P.max_heavy, P.bat_hoff[b + 1] - P.bat_hoff[b]);
+      P.max_segs = std::max(P.max_segs, P.bat_soff[b + 1] - P.bat_soff[b]);
+    }
+  }
   if (use_singles || want_tq) {  // the row phase finds a sample's per-nnz slots at toff[pos] + q
     P.toff.p = toff.p; P.toff.bytes = toff.bytes;
     toff.p = nullptr; toff.bytes = 0;

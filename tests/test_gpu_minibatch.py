@@ -244,3 +244,47 @@ def test_ffm_minibatch_vs_mb_oracle(k, F, batch):
     assert_close(ffm.w, w, RTOL, ATOL, "w")
     assert_close(ffm.P, P, RTOL, ATOL, "P")
     assert_close([h[0] for h in ada.history], hist, 1e-9, 1e-12, "viol")
+
+
+@pytest.mark.parametrize("solver,k", [("sgd", 4), ("sgd", 16), ("adagrad", 8)])
+def test_heavy_features(solver, k):
+    """Features touched by (almost) every sample of a batch -- Zipf heads, dummy features -- have their touch
+    lists cut into segments summed by separate lane groups (k_heavy_partial / k_heavy_apply); the result must
+    still be the rule's (sums are re-associated per segment, hence rtol 1e-9)."""
+    n, d, batch = 3000, 60, 1000
+    rng = np.random.default_rng(11)
+    rows, vals, indptr = [], [], [0]
+    for i in range(n):
+        rest = rng.choice(np.arange(2, d), size=4, replace=False)
+        idx = np.concatenate([[0], [1] if i % 3 else [], rest]).astype(np.int64)  # feature 0 in every row, 1 in 2/3
+        rows.append(idx)
+        vals.append(rng.uniform(-1, 1, size=len(idx)))
+        indptr.append(indptr[-1] + len(idx))
+    Xo = O.Dataset(np.array(indptr), np.concatenate(rows), np.concatenate(vals), n, d)
+    y = rng.standard_normal(n)
+    # fit_lower=augment with fit_linear=False: one dummy feature, touched by every sample
+    for fit_lower, fit_linear in (("explicit", True), ("augment", False)):
+        n_aug = O.n_augments(2, fit_lower, fit_linear)
+        P0, w0 = rng.standard_normal((1, k, d + n_aug)) * 0.05, np.zeros(d)
+        X = to_gpu(Xo)
+        fm = gpu_fm("regression", 2, k, fit_lower, fit_linear, True, P0, w0, 0.0)
+        if solver == "sgd":
+            cfg = O.sgd_cfg(fit_linear=fit_linear)
+            P, w, b, it, hist = run_oracle_sgd_mb(Xo, y, 2, P0, w0, 0.0, cfg, batch, n_aug, None, 3)
+            opt = nf.newSGD(maxIter=3, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=batch)
+            hv = [h[0] for h in hist]
+        else:
+            cfg = O.adagrad_cfg(fit_linear=fit_linear)
+            P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
+            st = O.AdaState(1, d + n_aug, k, d)
+            hv = []
+            for e in range(3):
+                b, it, ls, vs = O.fm_adagrad_epoch_mb(Xo, y, 2, P, w, b, cfg, batch, st, n_aug, it=it)
+                hv.append(vs)
+            b = O.fm_adagrad_finalize(2, P, w, b, cfg, it, st, n_aug)
+            opt = nf.newAdaGrad(maxIter=3, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=batch)
+        opt.fit(X, y, fm)
+        assert abs(fm.intercept - b) < 1e-11
+        assert_close(fm.w, w, RTOL, ATOL, "w")
+        assert_close(fm.P, P, RTOL, ATOL, "P")
+        assert_close([h[0] for h in opt.history], hv, 1e-9, 1e-12, "viol")
