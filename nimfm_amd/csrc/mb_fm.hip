@@ -684,7 +684,12 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
   double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
   double seta = 0.0;
   if (MODE == 2) {
-    for (int64_t sg = 0; sg < nseg; ++sg) {
+    // a whole wavefront works on one heavy feature: lane group g adds segments g, g + R, ... in
+    // order, then the groups' sums are combined by a fixed xor-shuffle tree; group 0 applies
+    constexpr int RG = kWave / LG;
+    const int g_ = (int)(threadIdx.x & (kWave - 1)) / LG;
+#pragma unroll 4
+    for (int64_t sg = g_; sg < nseg; sg += RG) {
       const double* rec_ = hp + (size_t)sg * PW;
       const double2 pa = *reinterpret_cast<const double2*>(rec_);
       const double2 pn = *reinterpret_cast<const double2*>(rec_ + M.Kp);
@@ -699,6 +704,17 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
         wacc.a1 += sc_[2];
       }
     }
+#pragma unroll
+    for (int sh = LG; sh < kWave; sh <<= 1) {
+      acc.x += dev::shfl_xor_d(acc.x, sh);
+      acc.y += dev::shfl_xor_d(acc.y, sh);
+      accn.x += dev::shfl_xor_d(accn.x, sh);
+      accn.y += dev::shfl_xor_d(accn.y, sh);
+      seta += dev::shfl_xor_d(seta, sh);
+      wacc.a0 += dev::shfl_xor_d(wacc.a0, sh);
+      wacc.a1 += dev::shfl_xor_d(wacc.a1, sh);
+    }
+    if (g_ != 0) return 0.0;  // one group applies (AdaGrad's viol / stored-P side effects above are idempotent)
   } else if (!GEN || deg == 2) {
     // The touches' (sample, value) pairs are fetched L at a time, one touch per lane of the feature's
     // lane group (one coalesced load instead of L same-address loads and one dependent round trip
@@ -910,7 +926,8 @@ __global__ __launch_bounds__(kBlock) void k_heavy_apply(ColArgs a, HeavyArgs hv)
   const ModelView& M = a.M;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   const int g = lane / L, l = lane % L;
-  const int64_t h = hv.h0 + ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  const int64_t h = hv.h0 + (int64_t)blockIdx.x * kWavesPerBlock + wv;  // one wavefront per heavy feature
+  (void)R;
   double viol = 0.0;
   if (h < hv.h1) {
     const int64_t u = hv.hv_u[h];
@@ -929,7 +946,7 @@ __global__ __launch_bounds__(kBlock) void k_heavy_apply(ColArgs a, HeavyArgs hv)
     const int64_t sg0 = hv.hv_seg0[h], nseg = hv.hv_seg0[h + 1] - sg0;
     viol += col_block<OPT, false, 2, L, 2>(a, (size_t)j * M.Kp + 2 * l, 2, 0, l, 0, 0, sP, sPn, fP, has_w, wacc, (double)c,
                                            hv.hpart + (size_t)(sg0 - hv.s0) * hv.PW + 2 * l, nseg, hv.PW);
-    if (has_w) viol += w_epilogue<OPT>(a, j, l, (double)c, sw, swn, fw, wacc);
+    if (has_w && g == 0) viol += w_epilogue<OPT>(a, j, l, (double)c, sw, swn, fw, wacc);
   }
   viol = dev::wave_sum(viol);
   if (lane == 0) red[wv] = viol;
@@ -1233,9 +1250,12 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
                  W.rec.as<SampleRec>(), parts_cur, W.partsA.as<PartA>(), parts_prev, W.out_acc.as<double>(), it_b,
                  (double)len, it0p, TA, use_stored, nA, n_prev};
       const int nsb = (int)((ha.s1 - ha.s0 + per_block - 1) / per_block);
-      nH = (int)((ha.h1 - ha.h0 + per_block - 1) / per_block);
-      TimedLaunch tl(ctx, "heavy");
-      hipLaunchKernelGGL((k_heavy_partial<L, OPT>), dim3(nsb), dim3(kBlock), 0, st, ca, ha);
+      nH = (int)((ha.h1 - ha.h0 + kWavesPerBlock - 1) / kWavesPerBlock);  // one wavefront per heavy feature
+      {
+        TimedLaunch tl(ctx, "heavy_partial");
+        hipLaunchKernelGGL((k_heavy_partial<L, OPT>), dim3(nsb), dim3(kBlock), 0, st, ca, ha);
+      }
+      TimedLaunch tl(ctx, "heavy_apply");
       hipLaunchKernelGGL((k_heavy_apply<L, OPT>), dim3(nH), dim3(kBlock), 0, st, ca, ha);
     }
     n_prev = nB + nS + nH;
@@ -1306,7 +1326,7 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   NFM_TRY(W.Abuf.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_batch, 1) * std::max(TA, 1) * M.Kp));
   NFM_TRY(W.rec.ensure(sizeof(SampleRec) * (size_t)std::max<int64_t>(P.max_batch, 1)));
   NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch / kWavesPerBlock + 1)));
-  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique / kMinGroupsPerBlock + P.max_batch / kWavesPerBlock + P.max_heavy / kMinGroupsPerBlock + 6)));
+  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique / kMinGroupsPerBlock + P.max_batch / kWavesPerBlock + P.max_heavy / kWavesPerBlock + 6)));
   NFM_TRY(W.hpart.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_segs, 1) * (2 * M.Kp + 4)));
   NFM_TRY(W.Dtab.ensure(sizeof(double) * 4 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Stab.ensure(sizeof(double) * 2 * (size_t)(P.n_batches + 1)));

@@ -42,8 +42,12 @@ struct Plan {
   void release();
 };
 
-constexpr int kHeavyTouches = 256;  // above this a feature's touches are summed by several lane groups
-constexpr int kHeavySegment = 128;
+// A lane group walks a feature's touches serially (~0.25 us per pair of touches, latency-bound): beyond
+// kHeavyTouches the list is cut into segments of kHeavySegment touches summed by separate lane groups.
+// (Measured on cfg2 with Zipf(1.1) popularity, B = 32768: 256/128 -> 245 us per batch, 48/32 -> 402 us: too
+// many small segments make the per-feature sum of partials the new tail.)
+constexpr int kHeavyTouches = 128;
+constexpr int kHeavySegment = 64;
 
 int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
                int64_t batch, bool first_singleton, bool want_tq, bool use_singles, Plan* out);
