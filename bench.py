@@ -31,6 +31,8 @@ WORKLOADS = {
     "cfg2": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768),
     "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="logistic", batch=8192),
     "cfg3": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="squared", batch=8192),
+    # cfg5: higher-order FM, degree 3 with fitLower=explicit -> two parameter blocks (ANOVA degree 3 and 2)
+    "cfg5": dict(n=1_000_000, d=100_000, m=32, k=8, degree=3, solver="sgd", loss="squared", batch=32768),
     "tiny": dict(n=50_000, d=5_000, m=16, k=8, degree=2, solver="sgd", loss="logistic", batch=4096),
     # cfg2 with Zipf(1.1) feature popularity: a few features are touched by most samples of a batch
     "cfg2z": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768, zipf=1.1),
@@ -109,6 +111,7 @@ def main():
     if args.n:
         wl["n"] = args.n
     n, d, m, k = wl["n"], wl["d"], wl["m"], wl["k"]
+    n_orders = wl["degree"] - 1  # fitLower=explicit (model/factorization_machine.nim:81-97)
     if not args.batch:
         args.batch = wl["batch"]
 
@@ -193,7 +196,7 @@ def main():
             capi.check(capi.lib().nfm_decision_function_device(mh, X.h, out_dev.data_ptr()))
         ctx.synchronize()
         tp = (time.perf_counter() - tp) / reps_p
-        pbytes = 12 * m + 8 + 8 * m * k + 8 * m + 8  # SURVEY.md 8(d) predict bytes per sample
+        pbytes = 12 * m + 8 + n_orders * 8 * m * k + 8 * m + 8  # SURVEY.md 8(d) predict bytes per sample
         pred = {"value": round(n / tp, 1), "unit": "samples/s", "ms": round(tp * 1e3, 4),
                 "roofline_frac": round(pbytes * n / tp / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": pbytes}
 
@@ -213,7 +216,7 @@ def main():
         per_batch_ms = {f: (fam[f][1] / fam[f][0] if fam[f][0] else 0.0) for f in fam}
         pair_ms = (per_batch_ms["row_phase"] + per_batch_ms["singles"] + per_batch_ms["col_phase"]
                    + (fam["heavy_partial"][1] + fam["heavy_apply"][1]) / max(fam["row_phase"][0], 1))
-        bps = algorithmic_bytes_per_sample(wl["solver"], m, k)
+        bps = algorithmic_bytes_per_sample(wl["solver"], m, k, n_orders)
         units = n / n_batches
         achieved = bps * units / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
         # HBM-side bytes per mini-batch from the last committed PMC run of this workload/batch
@@ -237,25 +240,26 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle as O
 
-        nc = min(n, args.cpu_samples)
+        cpu_epochs = 5
+        # bounded sample: ~10-30 s of single-thread work whatever the row size (cfg2: 1e6 samples x 5 epochs)
+        nc = min(n, args.cpu_samples, max(10_000, int(2.56e9 / (n_orders * m * k * cpu_epochs))))
         ip = indptr[: nc + 1].cpu().numpy()
         ix = indices[: nc * m].cpu().numpy().astype(np.int64)
         dv = data[: nc * m].cpu().numpy()
         Xo = O.Dataset(ip, ix, dv, nc, d)
-        P0 = np.random.default_rng(1).standard_normal((1, k, d)) * 0.01
+        P0 = np.random.default_rng(1).standard_normal((n_orders, k, d)) * 0.01
         cfg = O.sgd_cfg(loss=wl["loss"]) if wl["solver"] == "sgd" else O.adagrad_cfg(loss=wl["loss"])
         tc = time.perf_counter()
-        cpu_epochs = 5  # ~10 s of single-thread work on cfg2
         if wl["solver"] == "sgd":
-            O.fm_sgd_fit(Xo, y[:nc], 2, P0, np.zeros(d), 0.0, cfg, cpu_epochs)
+            O.fm_sgd_fit(Xo, y[:nc], wl["degree"], P0, np.zeros(d), 0.0, cfg, cpu_epochs)
         else:
-            O.fm_adagrad_fit(Xo, y[:nc], 2, P0, np.zeros(d), 0.0, cfg, cpu_epochs)
+            O.fm_adagrad_fit(Xo, y[:nc], wl["degree"], P0, np.zeros(d), 0.0, cfg, cpu_epochs)
         t1 = (time.perf_counter() - tc) / cpu_epochs
         threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
         th = None
         if wl["solver"] == "sgd":
             tc = time.perf_counter()
-            O.fm_sgd_fit(Xo, y[:nc], 2, P0, np.zeros(d), 0.0, cfg, cpu_epochs, hogwild_threads=threads)
+            O.fm_sgd_fit(Xo, y[:nc], wl["degree"], P0, np.zeros(d), 0.0, cfg, cpu_epochs, hogwild_threads=threads)
             th = (time.perf_counter() - tc) / cpu_epochs
         cpu = {"value": round(nc / t1, 1), "unit": "samples/s", "cores": 1, "kind": "port",
                "sample": "%d sequential epochs (optimizer/sgd.nim:261-328 semantics) over the first %d samples of "

@@ -141,7 +141,9 @@ int32_t nfm_decision_function_device(nfm_model* m, nfm_dataset* ds, double* out_
 int32_t nfm_model_sqnorms(nfm_model* m, double* P_sq, double* w_sq);
 /* device views for the data-parallel exchange: pointers to
  * the device-layout parameter buffers and their lengths in doubles. scalars
- * holds {scale_P, scale_w, intercept}. */
+ * holds {scale_P, scale_w, intercept, 5 unused}. The three buffers are pieces of
+ * ONE allocation in the order [P | w | scalars] (gaps are zero padding), so a
+ * single collective over [P_dev, scalars_dev + n_scalars) reconciles a replica. */
 int32_t nfm_model_device_buffers(nfm_model* m, double** P_dev, int64_t* n_P, double** w_dev,
                                  int64_t* n_w, double** scalars_dev, int64_t* n_scalars);
 int32_t nfm_model_destroy(nfm_model* m);
@@ -182,7 +184,9 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
 /* finalize (optimizer/sgd.nim:99-113; adagrad.nim:65-84): leaves the model's
  * parameters as the reference's fm.P/w/intercept after fit. Idempotent. */
 int32_t nfm_opt_finalize(nfm_opt* o);
-/* device views of the AdaGrad state for the data-parallel exchange. */
+/* device views of the AdaGrad state for the data-parallel exchange; pieces of ONE
+ * allocation in the order [gsum_P | gnorm_P | gsum_w | gnorm_w | gscalars]
+ * (gaps are zero padding): [gsum_P, gscalars + 2) is one collective. */
 int32_t nfm_opt_device_state(nfm_opt* o, double** gsum_P, double** gnorm_P, int64_t* n_P,
                              double** gsum_w, double** gnorm_w, int64_t* n_w,
                              double** gscalars /* {gsum_b, gnorm_b} */);

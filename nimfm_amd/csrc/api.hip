@@ -19,12 +19,23 @@ struct nfm_dataset {
   uint64_t serial = 0;  // bumps when targets change (plans do not depend on y; kept for clarity)
 };
 
+struct Span {  // a piece of an arena allocation
+  void* p = nullptr;
+  size_t bytes = 0;
+  template <class T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+static size_t pad256(size_t b) { return (b + 255) / 256 * 256; }
+
 struct nfm_model {
   nfm_ctx* ctx = nullptr;
   nfm_model_cfg cfg{};
   int nb = 0, n_aug = 0, k = 0, Kp = 0, L = 0;
   int64_t d = 0, da = 0;
-  DevBuf P, w, sc, lams;
+  // P, w and the scalars live back to back in ONE allocation ([P | w | scalars], each padded to 256 B,
+  // padding zero) so the data-parallel exchange is a single collective over the arena
+  DevBuf arena, lams;
+  Span P, w, sc;
   bool initialized = false;
   ModelView view() const {
     ModelView m{};
@@ -44,7 +55,9 @@ struct nfm_opt {
   int kind = OPT_SGD, mode = NFM_MODE_SEQUENTIAL;
   int64_t batch = 1, it = 1;
   OptView o{};
-  DevBuf G, N, Gw, Nw, gsc, out2, perm_dev;
+  // AdaGrad state, one allocation [G | N | Gw | Nw | gscalars] (each padded to 256 B, padding zero)
+  DevBuf state_arena, out2, perm_dev;
+  Span G, N, Gw, Nw, gsc;
   bool state_ready = false;
   MbWork W;
   std::unique_ptr<Plan> plan;
@@ -282,12 +295,16 @@ int32_t nfm_model_create(nfm_ctx* ctx, const nfm_model_cfg* cfg, nfm_model** out
   m->L = lanes_for_k(m->k);
   m->Kp = m->k <= 128 ? 2 * m->L : ((m->k + 63) / 64) * 64;
   if (m->k > 128) m->L = 64;
-  NFM_TRY(m->P.alloc(sizeof(double) * std::max<int64_t>(m->nP(), 2)));
-  NFM_TRY(m->w.alloc(sizeof(double) * m->d));
-  NFM_TRY(m->sc.alloc(sizeof(double) * SC_COUNT));
+  {
+    const size_t bP = pad256(sizeof(double) * std::max<int64_t>(m->nP(), 2)), bw = pad256(sizeof(double) * m->d);
+    NFM_TRY(m->arena.alloc(bP + bw + sizeof(double) * SC_COUNT));
+    NFM_HIP_CHECK(hipMemsetAsync(m->arena.p, 0, m->arena.bytes, ctx->stream));
+    char* base = m->arena.as<char>();
+    m->P = {base, bP};
+    m->w = {base + bP, bw};
+    m->sc = {base + bP + bw, sizeof(double) * SC_COUNT};
+  }
   NFM_TRY(m->lams.alloc(sizeof(double) * m->Kp));
-  NFM_HIP_CHECK(hipMemsetAsync(m->P.p, 0, m->P.bytes, ctx->stream));
-  NFM_HIP_CHECK(hipMemsetAsync(m->w.p, 0, m->w.bytes, ctx->stream));
   double sc[SC_COUNT] = {1.0, 1.0, 0.0, 0, 0, 0, 0, 0};
   NFM_HIP_CHECK(hipMemcpyAsync(m->sc.p, sc, sizeof(sc), hipMemcpyHostToDevice, ctx->stream));
   NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -455,11 +472,17 @@ int32_t nfm_adagrad_create(nfm_model* m, const nfm_adagrad_cfg* c, nfm_opt** out
   o->o.eps = c->eps; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = 0; o->o.track_viol = c->track_viol;
   NFM_TRY(use_device(m->ctx));
   NFM_TRY(o->out2.alloc(sizeof(double) * 2));
-  NFM_TRY(o->G.alloc(sizeof(double) * std::max<int64_t>(m->nP(), 2)));
-  NFM_TRY(o->N.alloc(sizeof(double) * std::max<int64_t>(m->nP(), 2)));
-  NFM_TRY(o->Gw.alloc(sizeof(double) * m->d));
-  NFM_TRY(o->Nw.alloc(sizeof(double) * m->d));
-  NFM_TRY(o->gsc.alloc(sizeof(double) * 2));
+  {
+    const size_t bP = pad256(sizeof(double) * std::max<int64_t>(m->nP(), 2)), bw = pad256(sizeof(double) * m->d);
+    NFM_TRY(o->state_arena.alloc(2 * bP + 2 * bw + sizeof(double) * 2));
+    NFM_HIP_CHECK(hipMemsetAsync(o->state_arena.p, 0, o->state_arena.bytes, m->ctx->stream));
+    char* base = o->state_arena.as<char>();
+    o->G = {base, bP};
+    o->N = {base + bP, bP};
+    o->Gw = {base + 2 * bP, bw};
+    o->Nw = {base + 2 * bP + bw, bw};
+    o->gsc = {base + 2 * bP + 2 * bw, sizeof(double) * 2};
+  }
   o->o.G = o->G.as<double>(); o->o.N = o->N.as<double>(); o->o.Gw = o->Gw.as<double>(); o->o.Nw = o->Nw.as<double>();
   o->o.gsc = o->gsc.as<double>();
   *out = o.release();

@@ -41,9 +41,13 @@ def exchange(tensors, dist, world, rule, prevs=None, force=False):
     if world <= 1 and not force:
         return
     if rule == "average":
+        avg = dist.get_backend() == "nccl"  # RCCL averages inside the collective; gloo has no AVG
         for t in tensors:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            t.div_(world)
+            if avg:
+                dist.all_reduce(t, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                t.div_(world)
     elif rule == "sum_deltas":
         for t, p in zip(tensors, prevs):
             t.sub_(p)
@@ -66,6 +70,8 @@ class ParamViews:
                                               C.byref(ns)))
         self.params = [alias(torch, dev, P.value, nP.value), alias(torch, dev, w.value, nw.value),
                        alias(torch, dev, sc.value, ns.value)]
+        # [P | w | scalars] is one allocation (include/nimfm_hip.h): one collective per exchange
+        self.arena = [alias(torch, dev, P.value, (sc.value + 8 * ns.value - P.value) // 8)]
         self.state, self.state_prev = [], []
         self.is_adagrad = type(opt).__name__ == "AdaGrad"
         if self.is_adagrad:
@@ -76,12 +82,14 @@ class ParamViews:
             self.state = [alias(torch, dev, G.value, n1.value), alias(torch, dev, N.value, n1.value),
                           alias(torch, dev, Gw.value, n2.value), alias(torch, dev, Nw.value, n2.value),
                           alias(torch, dev, gs.value, 2)]
-            self.state_prev = [t.clone() for t in self.state]
+            # [G | N | Gw | Nw | gscalars] is one allocation as well
+            self.state_arena = [alias(torch, dev, G.value, (gs.value + 16 - G.value) // 8)]
+            self.state_prev = [t.clone() for t in self.state_arena]
 
     def average(self, dist, world, force=False):
         """Called between epochs; the library has synchronised its stream when nfm_opt_epoch returns."""
         if self.is_adagrad:
-            exchange(self.state, dist, world, "sum_deltas", self.state_prev, force)
+            exchange(self.state_arena, dist, world, "sum_deltas", self.state_prev, force)
         else:
-            exchange(self.params, dist, world, "average", None, force)
+            exchange(self.arena, dist, world, "average", None, force)
         self.torch.cuda.synchronize(self.dev)
