@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnimfm_hip.so")
+# NIMFM_HIP_LIB: an alternative build of the same library (kernel tuning A/B runs)
+LIB_PATH = os.environ.get("NIMFM_HIP_LIB") or os.path.join(_HERE, "lib", "libnimfm_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 NFM_OK = 0

@@ -26,6 +26,13 @@
 
 namespace nfm {
 
+#ifndef NFM_WAVE_STAGE2
+#define NFM_WAVE_STAGE2 1
+#endif
+#ifndef NFM_COL_MINW
+#define NFM_COL_MINW 1
+#endif
+
 struct SampleRec {
   double dL, etaP, etaw, pad;
 };
@@ -279,7 +286,7 @@ __device__ __forceinline__ double singles_update(const CsrView& X, const ModelVi
 template <int L, int SPLIT, int OPT, bool GEN, int NQ, bool SING>
 __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   constexpr int LPS = L * SPLIT, SPW = kWave / LPS, SPB = kWavesPerBlock * SPW;  // samples per wave / block
-  constexpr bool REG = NQ > 0 && OPT == OPT_SGD && !GEN;
+  constexpr bool REG = NQ > 0 && OPT == OPT_SGD && !GEN && LPS == kWave && NQ * SPLIT == kWave;
   double2 prow[REG ? NQ : 1];
   __shared__ double s_y[SPB], s_yh[SPB], s_dL[SPB], s_etaP[SPB], s_etaw[SPB];
   __shared__ double s_part[4], s_viol[kWavesPerBlock];
@@ -306,22 +313,32 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   double b0 = M.sc[SC_INTERCEPT];
   double part = 0.0;
   double2 A1 = {0.0, 0.0};
+  int jq = 0, fq = 0;      // REG: this lane's entry of the sample's row
+  double xq = 0.0, wq = 0.0;
   const double itp = (a.it0p[0] + a.it_b) - 1.0;  // AdaGrad: it' = it_b - 1 (adagrad.nim:90)
   const bool stored = a.use_stored != 0;
   // ---- 1. forward: yhat of every sample of the block ----
   if (REG) {
+    // the sample's entries, one per lane (LPS == 64 >= m_tot): index, value, single flag and w stay in
+    // this lane's registers and are handed round with ds_bpermute, so neither the row loads below
+    // nor the update of the singles wait on a second look at the CSR arrays
     const double sP = a.scales[0], sw = a.scales[1];
-    for (int q = slot * L + l; q < m; q += LPS) part += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
-    int jj[REG ? NQ : 1];
-    double xx[REG ? NQ : 1];
+    dev::row_entry(X, q0, m, m_tot, lane, jq, xq);
+    if (a.single != nullptr && valid && lane < m_tot) fq = a.single[a.toff[a.p0 + pib] + lane];
+    if (lane < m) {
+      wq = M.w[jq];
+      part += (sw * wq) * xq;
+    }
 #pragma unroll
-    for (int u = 0; u < NQ; ++u) dev::row_entry(X, q0, m, m_tot, slot + u * SPLIT, jj[u], xx[u]);
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) prow[u] = *reinterpret_cast<const double2*>(M.P + (size_t)jj[u] * M.Kp + 2 * l);
+    for (int u = 0; u < NQ; ++u) {
+      const int jj = __shfl(jq, slot + u * SPLIT, kWave);
+      prow[u] = *reinterpret_cast<const double2*>(M.P + (size_t)jj * M.Kp + 2 * l);
+    }
     double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-      const double tx = xx[u] * (sP * prow[u].x), ty = xx[u] * (sP * prow[u].y);
+      const double xx = dev::shfl_d(xq, slot + u * SPLIT);
+      const double tx = xx * (sP * prow[u].x), ty = xx * (sP * prow[u].y);
       a1.x += tx;
       a1.y += ty;
       a2.x += tx * tx;
@@ -361,6 +378,34 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   }
 #pragma unroll
   for (int s = 1; s < LPS; s <<= 1) part += dev::shfl_xor_d(part, s);
+  double dL, etaP = 0.0, etaw = 0.0;
+  if (SPW == 1 && NFM_WAVE_STAGE2) {
+    // ---- 2'. one sample per wavefront (k > 32): every wavefront finishes its own sample, no
+    // workgroup barrier between the forward pass and the singles update, so the four wavefronts of a
+    // workgroup drift apart and their load and store phases overlap ----
+    const double yh = b0 + part;
+    dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
+    double r_acc0 = 0.0, r_acc1 = 0.0;
+    if (OPT == OPT_SGD) {
+      const double it = (a.it0p[0] + a.it_b) + (double)pib;
+      etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+      etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
+      if (M.fit_intercept) {
+        const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
+        r_acc0 = eta0 * dL;
+        r_acc1 = eta0;
+      }
+    } else if (M.fit_intercept) {
+      r_acc0 = dL;
+      r_acc1 = dL * dL;
+    }
+    if (lane == 0) {
+      if (valid) a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
+      s_y[sib] = valid ? dev::loss_value(O.loss, O.loss_param, y, yh) : 0.0;
+      s_dL[sib] = valid ? r_acc0 : 0.0;
+      s_etaP[sib] = valid ? r_acc1 : 0.0;
+    }
+  } else {
   if (slot == 0 && l == 0) {
     s_y[sib] = y;
     s_yh[sib] = b0 + part;
@@ -407,39 +452,37 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
     }
   }
   __syncthreads();
-  const double dL = s_dL[sib], etaP = s_etaP[sib], etaw = s_etaw[sib];
+  dL = s_dL[sib];
+  etaP = s_etaP[sib];
+  etaw = s_etaw[sib];
+  }
   double r_viol = 0.0;
   // ---- 3. singles: a feature this sample alone touches in the batch gets its update right here
   // (same arithmetic as the column phase with c = 1), so its row is read and written once ----
-  if (REG && a.single != nullptr && valid) {
-    const uint8_t* sg = a.single + a.toff[a.p0 + pib];
+  if (REG && a.single != nullptr) {
     const double sP = a.scales[0], sw = a.scales[1], sPn = a.scales_n[0], swn = a.scales_n[1];
-    bool f[REG ? NQ : 1];
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-      const int qq = slot + u * SPLIT;
-      f[u] = qq < m_tot && sg[qq] != 0;
-    }
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      if (!f[u]) continue;
-      int j;
-      double xv;
-      dev::row_entry(X, q0, m, m_tot, slot + u * SPLIT, j, xv);
-      double2 st = prow[u];
-      const double px = sP * st.x, py = sP * st.y;
-      const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
-      const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
-      r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
-      st.x = st.x - ax / sPn;
-      st.y = st.y - ay / sPn;
-      *reinterpret_cast<double2*>(M.P + (size_t)j * M.Kp + 2 * l) = st;
-      if (M.fit_linear && j < M.d && l == 0) {
-        const double wt = M.w[j], wj = sw * wt;
-        const double a0 = etaw * (dL * xv);
-        r_viol += fabs(a0 + etaw * O.alpha * wj);
-        M.w[j] = wt - a0 / swn;
+      const int q = slot + u * SPLIT;  // the shuffles run with every lane active
+      const int f = __shfl(fq, q, kWave);
+      const int j = __shfl(jq, q, kWave);
+      const double xv = dev::shfl_d(xq, q);
+      if (f) {
+        double2 st = prow[u];
+        const double px = sP * st.x, py = sP * st.y;
+        const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
+        const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
+        r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
+        st.x = st.x - ax / sPn;
+        st.y = st.y - ay / sPn;
+        *reinterpret_cast<double2*>(M.P + (size_t)j * M.Kp + 2 * l) = st;
       }
+    }
+    if (fq && M.fit_linear && lane < m) {  // the linear term, one entry per lane
+      const double wj = sw * wq;
+      const double a0 = etaw * (dL * xq);
+      r_viol += fabs(a0 + etaw * O.alpha * wj);
+      M.w[jq] = wq - a0 / swn;
     }
   } else if (SING && !GEN && a.single != nullptr && valid) {
     // stage 3 (sparse regime): singles updated right after the forward pass, while their rows are
@@ -451,7 +494,16 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   if (lane == 0) s_viol[wv] = r_viol;
   __syncthreads();
   if (threadIdx.x == 0) {
-    PartA p{s_part[0], 0.0, s_part[2], s_part[3]};
+    PartA p{0.0, 0.0, 0.0, 0.0};
+    if (SPW == 1 && NFM_WAVE_STAGE2) {
+      for (int w_ = 0; w_ < kWavesPerBlock; ++w_) {
+        p.loss += s_y[w_];
+        p.acc0 += s_dL[w_];
+        p.acc1 += s_etaP[w_];
+      }
+    } else {
+      p = PartA{s_part[0], 0.0, s_part[2], s_part[3]};
+    }
     for (int w_ = 0; w_ < kWavesPerBlock; ++w_) p.viol += s_viol[w_];
     a.parts[blockIdx.x] = p;
   }
@@ -993,7 +1045,7 @@ __global__ __launch_bounds__(kBlock) void k_singles(ColArgs a) {
 }
 
 template <int L, int OPT, bool GEN, int TU>
-__global__ __launch_bounds__(kBlock) void k_col_phase(ColArgs a) {
+__global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
   constexpr int R = kWave / L;
   __shared__ double red[5][kBlock];
   const ModelView& M = a.M;
@@ -1120,11 +1172,11 @@ static void launch_row(hipStream_t st, const RowArgs& ra, int nq, int pad_kb = 0
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0, !GEN>), dim3(nA), dim3(kBlock), (size_t)pad_kb * 1024, st, ra);
     return;
   }
-  constexpr bool CAN_REG = OPT == OPT_SGD && !GEN && L >= 8;  // register-resident rows: k >= 16
-  if (CAN_REG && nq == 16)
-    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 16 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
-  else if (CAN_REG && nq == 32)
-    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 32 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
+  // register-resident rows: one sample per wavefront (L * SPLIT == 64), rows of at most 64 entries,
+  // 64 / SPLIT row pieces per lane
+  constexpr int NQR = (OPT == OPT_SGD && !GEN && L * SPLIT == kWave && SPLIT >= 2 && SPLIT <= 8) ? kWave / SPLIT : 0;
+  if (NQR > 0 && nq == NQR)
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, NQR, false>), dim3(nA), dim3(kBlock), 0, st, ra);
   else if (sing && !GEN)
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0, !GEN>), dim3(nA), dim3(kBlock), 0, st, ra);
   else
@@ -1164,12 +1216,11 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     // rows per lane to keep in registers (0 = stream): only when the batch has singles to update
     auto nq_for = [&](int s_used) {
       if (OPT != OPT_SGD || !singles_in_row) return 0;
-      // register-resident rows measured slower than streaming on the headline shape (185 vs 154 us:
-      // 236 VGPRs leave 2 waves per SIMD); opt-in via NFM_NQ=16|32
-      const char* env = getenv("NFM_NQ");
-      const int want = env ? atoi(env) : 0;
-      const int need = (X.max_row + M.n_aug + s_used - 1) / s_used;
-      return (want == 16 || want == 32) && need <= want ? want : 0;
+      // register-resident rows (k_row_phase REG) whenever they fit: 106 vs 141 us per batch on the
+      // headline shape (k = 64, m = 64, B = 8192); NFM_NQ=0 switches back to streaming + re-read
+      static const bool want = !(getenv("NFM_NQ") && atoi(getenv("NFM_NQ")) == 0);
+      const bool fits = L * s_used == kWave && s_used >= 2 && s_used <= 8 && X.max_row + M.n_aug <= kWave;
+      return want && fits ? kWave / s_used : 0;
     };
     int nA;
     {

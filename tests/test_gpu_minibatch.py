@@ -202,6 +202,31 @@ def test_sparse_regime_singles(k, batch):
     assert_close(fm.P, P, RTOL, ATOL, "P")
 
 
+@pytest.mark.parametrize("k,fit_linear,max_m", [(64, True, 64), (64, False, 63), (32, True, 64), (16, True, 40), (40, False, 17)])
+def test_register_resident_rows(k, fit_linear, max_m):
+    """Sparse regime with one sample per wavefront (k > 8) and rows of at most 64 entries (dummy feature
+    included): the row phase keeps the gathered parameter rows in registers and updates the singles
+    without a second visit (k_row_phase REG).  Ragged rows, empty rows, unsorted storage order;
+    fit_linear=False with fitLower=augment adds a dummy feature every sample touches (a heavy column)."""
+    n, d = 700, 30000
+    Xo = ragged_csr(n, d, seed=k + max_m, max_m=max_m)
+    rng = np.random.default_rng(k)
+    y = rng.standard_normal(n)
+    fit_lower = "explicit" if fit_linear else "augment"
+    n_aug = 0 if fit_linear else 1
+    P0, w0 = rng.standard_normal((1, k, d + n_aug)) * (0.1 / np.sqrt(k)), np.zeros(d)
+    perms = make_perms(n, 2)
+    cfg = O.sgd_cfg(fit_linear=fit_linear)
+    P, w, b, it, hist = run_oracle_sgd_mb(Xo, y, 2, P0, w0, 0.0, cfg, 128, n_aug, perms, 2)
+    fm = gpu_fm("regression", 2, k, fit_lower, fit_linear, True, P0, w0, 0.0)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, mode="minibatch", batch=128)
+    sgd.fit(to_gpu(Xo), y, fm, perms=perms)
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
+    assert_close([h[0] for h in sgd.history], [h[0] for h in hist], 1e-9, 1e-12, "viol")
+
+
 @pytest.mark.parametrize("k,F,batch", [(4, 5, 1), (4, 5, 7), (8, 16, 64), (30, 3, 80)])
 def test_ffm_minibatch_vs_mb_oracle(k, F, batch):
     """FieldAwareFactorizationMachine through the mini-batch kernels (mb_ffm.hip), SGD and AdaGrad."""
