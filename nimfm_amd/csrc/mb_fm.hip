@@ -279,15 +279,31 @@ __device__ __forceinline__ double singles_update(const CsrView& X, const ModelVi
   return r_viol;
 }
 
-// NQ > 0 (SGD, single order of degree 2, rows of at most SPLIT*NQ entries): every lane keeps the NQ
-// parameter-row pieces it gathered for the forward pass in registers, so the in-place update of
-// the singles needs no second visit of the rows (HBM traffic of the row phase = the rows read once
-// + the single-touch rows written once).  NQ = 0: rows are streamed and singles re-read.
-template <int L, int SPLIT, int OPT, bool GEN, int NQ, bool SING>
+// How the row phase reads a sample's CSR row (models with one order of degree 2):
+//   MODE 0  streamed: (index, value) of every entry is loaded right before its parameter row -- two
+//           dependent round trips per group of rows, three in the update of the singles.  Any row length.
+//   MODE 1  held entries: the sample's L*SPLIT lanes load the whole row up front, E entries per lane
+//           (rows of at most held_capacity = E*L*SPLIT entries); index, value, single flag and linear
+//           weight stay in registers and are handed round with ds_bpermute, so a group of parameter
+//           rows costs one round trip.  Rows are streamed, singles re-read.
+//   MODE 2  MODE 1 + the parameter rows stay in registers between the forward pass and the update
+//           of the singles (SGD, one sample per wavefront, E = 1): HBM sees every row read once and
+//           the single-touch rows written once.
+template <int L, int SPLIT>
+constexpr int held_entries() {  // E: entries per lane; 0 = no held mode for this lane mapping
+  constexpr int LPS = L * SPLIT;
+  return LPS >= kWave ? 1 : (LPS >= 8 ? (kWave / LPS > 4 ? 4 : kWave / LPS) : 0);
+}
+
+template <int L, int SPLIT, int OPT, bool GEN, int MODE, bool SING>
 __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   constexpr int LPS = L * SPLIT, SPW = kWave / LPS, SPB = kWavesPerBlock * SPW;  // samples per wave / block
-  constexpr bool REG = NQ > 0 && OPT == OPT_SGD && !GEN && LPS == kWave && NQ * SPLIT == kWave;
-  double2 prow[REG ? NQ : 1];
+  constexpr int E = held_entries<L, SPLIT>() > 0 ? held_entries<L, SPLIT>() : 1;
+  constexpr bool HELD = MODE >= 1 && !GEN && held_entries<L, SPLIT>() > 0;
+  constexpr bool REG = MODE == 2 && HELD && OPT == OPT_SGD && LPS == kWave;
+  constexpr int NQ = REG ? L : 1;       // row pieces per lane kept in registers
+  constexpr int RPS = E * L;            // rows per slot in held mode
+  double2 prow[NQ];
   __shared__ double s_y[SPB], s_yh[SPB], s_dL[SPB], s_etaP[SPB], s_etaw[SPB];
   __shared__ double s_part[4], s_viol[kWavesPerBlock];
   const CsrView& X = a.X;
@@ -313,31 +329,56 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   double b0 = M.sc[SC_INTERCEPT];
   double part = 0.0;
   double2 A1 = {0.0, 0.0};
-  int jq = 0, fq = 0;      // REG: this lane's entry of the sample's row
-  double xq = 0.0, wq = 0.0;
+  // held mode: this lane's entries of the sample's row (entry q = e * LPS + lane-in-sample)
+  int jq[E], fq[E];
+  double xq[E], wq[E], gwq[E], nwq[E];
+  const int lis = lane % LPS, sbase = lane - lis;
+  int m_max = 0;  // longest row among the wavefront's samples (wave-uniform loop bound)
   const double itp = (a.it0p[0] + a.it_b) - 1.0;  // AdaGrad: it' = it_b - 1 (adagrad.nim:90)
   const bool stored = a.use_stored != 0;
   // ---- 1. forward: yhat of every sample of the block ----
-  if (REG) {
-    // the sample's entries, one per lane (LPS == 64 >= m_tot): index, value, single flag and w stay in
-    // this lane's registers and are handed round with ds_bpermute, so neither the row loads below
-    // nor the update of the singles wait on a second look at the CSR arrays
-    const double sP = a.scales[0], sw = a.scales[1];
-    dev::row_entry(X, q0, m, m_tot, lane, jq, xq);
-    if (a.single != nullptr && valid && lane < m_tot) fq = a.single[a.toff[a.p0 + pib] + lane];
-    if (lane < m) {
-      wq = M.w[jq];
-      part += (sw * wq) * xq;
+  if (HELD) {
+    // ---- 1h. held entries: the whole row in one round trip, linear term lane-parallel ----
+    const double sw = OPT == OPT_SGD ? a.scales[1] : 1.0;
+    const double denw = itp * O.eta0 * O.alpha;
+    if (OPT == OPT_ADAGRAD && !stored && M.fit_intercept)
+      b0 = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * itp * O.alpha0);
+    const uint8_t* sg = (a.single != nullptr && valid) ? a.single + a.toff[a.p0 + pib] : nullptr;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int q = e * LPS + lis;
+      dev::row_entry(X, q0, m, m_tot, q, jq[e], xq[e]);
+      fq[e] = (sg != nullptr && q < m_tot) ? (int)sg[q] : 0;
+      wq[e] = gwq[e] = nwq[e] = 0.0;
+      if (q < m) {
+        wq[e] = M.w[jq[e]];
+        double wj = sw * wq[e];
+        if (OPT == OPT_ADAGRAD && M.fit_linear) {
+          gwq[e] = O.Gw[jq[e]];
+          nwq[e] = O.Nw[jq[e]];
+          if (!stored) wj = -O.eta0 * gwq[e] / (denw + sqrt(nwq[e]));
+        }
+        part += wj * xq[e];
+      }
     }
+    m_max = m_tot;
+#pragma unroll
+    for (int s = LPS; s < kWave; s <<= 1) {
+      const int o = __shfl_xor(m_max, s, kWave);
+      m_max = o > m_max ? o : m_max;
+    }
+  }
+  if (REG) {
+    const double sP = a.scales[0];
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-      const int jj = __shfl(jq, slot + u * SPLIT, kWave);
+      const int jj = __shfl(jq[0], slot + u * SPLIT, kWave);
       prow[u] = *reinterpret_cast<const double2*>(M.P + (size_t)jj * M.Kp + 2 * l);
     }
     double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-      const double xx = dev::shfl_d(xq, slot + u * SPLIT);
+      const double xx = dev::shfl_d(xq[0], slot + u * SPLIT);
       const double tx = xx * (sP * prow[u].x), ty = xx * (sP * prow[u].y);
       a1.x += tx;
       a1.y += ty;
@@ -354,6 +395,51 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
     A1 = a1;
     if (valid && slot == 0) *reinterpret_cast<double2*>(Arow + 2 * l) = A1;
     if (slot == 0) part += (a1.x * a1.x - a2.x) / 2 + (a1.y * a1.y - a2.y) / 2;
+  } else if (HELD) {
+    // rows streamed in groups of U, addressed from the held entries: one round trip per group
+    constexpr int U = RPS < dev::kFwdUnroll ? RPS : dev::kFwdUnroll;
+    auto held_forward = [&](auto ps) {
+      double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
+#pragma unroll
+      for (int u0 = 0; u0 < RPS; u0 += U) {
+        if (u0 * SPLIT >= m_max) break;
+        int jj[U];
+        double xx[U];
+        double2 pp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = u0 + u, src = sbase + slot + (r % L) * SPLIT;
+          jj[u] = __shfl(jq[r / L], src, kWave);
+          xx[u] = dev::shfl_d(xq[r / L], src);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) pp[u] = ps.load((size_t)jj[u] * M.Kp + 2 * l);  // past the end: (row 0, x = 0)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const double tx = xx[u] * pp[u].x, ty = xx[u] * pp[u].y;
+          a1.x += tx;
+          a1.y += ty;
+          a2.x += tx * tx;
+          a2.y += ty * ty;
+        }
+      }
+#pragma unroll
+      for (int s = L; s < L * SPLIT; s <<= 1) {
+        a1.x += dev::shfl_xor_d(a1.x, s);
+        a1.y += dev::shfl_xor_d(a1.y, s);
+        a2.x += dev::shfl_xor_d(a2.x, s);
+        a2.y += dev::shfl_xor_d(a2.y, s);
+      }
+      A1 = a1;
+      if (valid && slot == 0) *reinterpret_cast<double2*>(Arow + 2 * l) = A1;
+      if (slot == 0) part += (a1.x * a1.x - a2.x) / 2 + (a1.y * a1.y - a2.y) / 2;
+    };
+    if (OPT == OPT_SGD)
+      held_forward(dev::PlainParams{M.P, a.scales[0]});
+    else if (stored)
+      held_forward(dev::PlainParams{M.P, 1.0});
+    else
+      held_forward(dev::AdaParams{O.G, O.N, O.eta0, O.eta0 * itp * O.beta});
   } else if (OPT == OPT_SGD) {
     const double sP = a.scales[0], sw = a.scales[1];
     for (int q = slot * L + l; q < m; q += LPS) part += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
@@ -459,30 +545,117 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   double r_viol = 0.0;
   // ---- 3. singles: a feature this sample alone touches in the batch gets its update right here
   // (same arithmetic as the column phase with c = 1), so its row is read and written once ----
-  if (REG && a.single != nullptr) {
-    const double sP = a.scales[0], sw = a.scales[1], sPn = a.scales_n[0], swn = a.scales_n[1];
+  if (HELD && a.single != nullptr) {
+    const double sP = OPT == OPT_SGD ? a.scales[0] : 1.0, sw = OPT == OPT_SGD ? a.scales[1] : 1.0;
+    const double sPn = OPT == OPT_SGD ? a.scales_n[0] : 1.0, swn = OPT == OPT_SGD ? a.scales_n[1] : 1.0;
+    const double tmpP = O.eta0 * itp * O.beta, denw = itp * O.eta0 * O.alpha;
+    if (REG) {
 #pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const int q = slot + u * SPLIT;  // the shuffles run with every lane active
-      const int f = __shfl(fq, q, kWave);
-      const int j = __shfl(jq, q, kWave);
-      const double xv = dev::shfl_d(xq, q);
-      if (f) {
-        double2 st = prow[u];
-        const double px = sP * st.x, py = sP * st.y;
-        const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
-        const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
-        r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
-        st.x = st.x - ax / sPn;
-        st.y = st.y - ay / sPn;
-        *reinterpret_cast<double2*>(M.P + (size_t)j * M.Kp + 2 * l) = st;
+      for (int u = 0; u < NQ; ++u) {
+        const int q = slot + u * SPLIT;  // the shuffles run with every lane active
+        const int f = __shfl(fq[0], q, kWave);
+        const int j = __shfl(jq[0], q, kWave);
+        const double xv = dev::shfl_d(xq[0], q);
+        if (f) {
+          double2 st = prow[u];
+          const double px = sP * st.x, py = sP * st.y;
+          const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
+          const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
+          r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
+          st.x = st.x - ax / sPn;
+          st.y = st.y - ay / sPn;
+          *reinterpret_cast<double2*>(M.P + (size_t)j * M.Kp + 2 * l) = st;
+        }
+      }
+    } else {
+      // singles re-read, but addressed from the held entries: per group of V rows one round trip
+      // (flags, indices and values come from registers), then the stores
+      constexpr int V = RPS < dev::kUnroll ? RPS : dev::kUnroll;
+#pragma unroll
+      for (int u0 = 0; u0 < RPS; u0 += V) {
+        if (u0 * SPLIT >= m_max) break;
+        int f[V], j[V];
+        double x[V];
+        double2 r0[V], r1[V], r2[V];
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+          const int r = u0 + u, src = sbase + slot + (r % L) * SPLIT;
+          f[u] = __shfl(fq[r / L], src, kWave);
+          j[u] = __shfl(jq[r / L], src, kWave);
+          x[u] = dev::shfl_d(xq[r / L], src);
+        }
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+          r0[u] = r1[u] = r2[u] = {0.0, 0.0};
+          if (f[u]) {
+            const size_t e = (size_t)j[u] * M.Kp + 2 * l;
+            if (OPT == OPT_SGD) {
+              r0[u] = *reinterpret_cast<const double2*>(M.P + e);
+            } else {
+              r1[u] = *reinterpret_cast<const double2*>(O.G + e);
+              r2[u] = *reinterpret_cast<const double2*>(O.N + e);
+              if (stored || O.track_viol) r0[u] = *reinterpret_cast<const double2*>(M.P + e);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+          if (!f[u]) continue;
+          const size_t e = (size_t)j[u] * M.Kp + 2 * l;
+          const double xv = x[u];
+          if (OPT == OPT_SGD) {
+            double2 st = r0[u];
+            const double px = sP * st.x, py = sP * st.y;
+            const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
+            const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
+            r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
+            st.x = st.x - ax / sPn;
+            st.y = st.y - ay / sPn;
+            *reinterpret_cast<double2*>(M.P + e) = st;
+          } else {
+            double2 g2 = r1[u], n2 = r2[u], p;
+            if (stored) {
+              p = r0[u];
+            } else {
+              p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmpP);
+              p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmpP);
+              if (O.track_viol) {
+                r_viol += fabs(r0[u].x - p.x) + fabs(r0[u].y - p.y);
+                *reinterpret_cast<double2*>(M.P + e) = p;
+              }
+            }
+            const double gx = dL * (xv * (A1.x - p.x * xv)), gy = dL * (xv * (A1.y - p.y * xv));
+            g2.x += gx;
+            g2.y += gy;
+            n2.x += gx * gx;
+            n2.y += gy * gy;
+            *reinterpret_cast<double2*>(O.G + e) = g2;
+            *reinterpret_cast<double2*>(O.N + e) = n2;
+          }
+        }
       }
     }
-    if (fq && M.fit_linear && lane < m) {  // the linear term, one entry per lane
-      const double wj = sw * wq;
-      const double a0 = etaw * (dL * xq);
-      r_viol += fabs(a0 + etaw * O.alpha * wj);
-      M.w[jq] = wq - a0 / swn;
+    // the linear term of the singles, one entry per lane
+    if (M.fit_linear) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (!fq[e] || e * LPS + lis >= m) continue;
+        if (OPT == OPT_SGD) {
+          const double wj = sw * wq[e];
+          const double a0 = etaw * (dL * xq[e]);
+          r_viol += fabs(a0 + etaw * O.alpha * wj);
+          M.w[jq[e]] = wq[e] - a0 / swn;
+        } else {
+          if (!stored) {
+            const double wj = -O.eta0 * gwq[e] / (denw + sqrt(nwq[e]));
+            r_viol += fabs(wq[e] - wj);
+            M.w[jq[e]] = wj;
+          }
+          const double g = dL * xq[e];
+          O.Gw[jq[e]] = gwq[e] + g;
+          O.Nw[jq[e]] = nwq[e] + g * g;
+        }
+      }
     }
   } else if (SING && !GEN && a.single != nullptr && valid) {
     // stage 3 (sparse regime): singles updated right after the forward pass, while their rows are
@@ -1168,23 +1341,31 @@ __global__ __launch_bounds__(kBlock) void k_epoch_close(const double* __restrict
 // host driver
 // ------------------------------------------------------------------------------------------------
 template <int L, int SPLIT, int OPT, bool GEN>
-static void launch_row(hipStream_t st, const RowArgs& ra, int nq, int pad_kb = 0) {
+static void launch_row(hipStream_t st, const RowArgs& ra, int mode, int pad_kb = 0) {
   const bool sing = ra.single != nullptr;
   constexpr int SPW = kWave / (L * SPLIT);
   const int nA = (ra.len + kWavesPerBlock * SPW - 1) / (kWavesPerBlock * SPW);
-  if (pad_kb > 0 && nq == 0) {  // tuning: unused dynamic LDS caps the workgroups per CU
+  if (pad_kb > 0 && mode == 0) {  // tuning: unused dynamic LDS caps the workgroups per CU
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0, !GEN>), dim3(nA), dim3(kBlock), (size_t)pad_kb * 1024, st, ra);
     return;
   }
-  // register-resident rows: one sample per wavefront (L * SPLIT == 64), rows of at most 64 entries,
-  // 64 / SPLIT row pieces per lane
-  constexpr int NQR = (OPT == OPT_SGD && !GEN && L * SPLIT == kWave && SPLIT >= 2 && SPLIT <= 8) ? kWave / SPLIT : 0;
-  if (NQR > 0 && nq == NQR)
-    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, NQR, false>), dim3(nA), dim3(kBlock), 0, st, ra);
+  constexpr bool CAN_HOLD = !GEN && held_entries<L, SPLIT>() > 0;
+  constexpr bool CAN_REG = CAN_HOLD && OPT == OPT_SGD && L * SPLIT == kWave;
+  if (CAN_REG && mode == 2)
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 2 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
+  else if (CAN_HOLD && mode >= 1)
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_HOLD ? 1 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
   else if (sing && !GEN)
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0, !GEN>), dim3(nA), dim3(kBlock), 0, st, ra);
   else
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0, false>), dim3(nA), dim3(kBlock), 0, st, ra);
+}
+
+// rows the held mode of lane mapping (L, s) can take: E * L * s entries (k_row_phase)
+static int held_capacity(int L, int s) {
+  const int lps = L * s;
+  const int e = lps >= kWave ? 1 : (lps >= 8 ? (kWave / lps > 4 ? 4 : kWave / lps) : 0);
+  return e * lps;
 }
 
 template <int L, int OPT, bool GEN>
@@ -1217,14 +1398,16 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     const int use_stored = (OPT == OPT_ADAGRAD && P.first_singleton && b == 0) ? 1 : 0;
     const double it_b = (double)p0;
     const int split = choose_split(L, len, avg_row, ctx->n_cu);
-    // rows per lane to keep in registers (0 = stream): only when the batch has singles to update
-    auto nq_for = [&](int s_used) {
-      if (OPT != OPT_SGD || !singles_in_row) return 0;
-      // register-resident rows (k_row_phase REG) whenever they fit: 106 vs 141 us per batch on the
-      // headline shape (k = 64, m = 64, B = 8192); NFM_NQ=0 switches back to streaming + re-read
-      static const bool want = !(getenv("NFM_NQ") && atoi(getenv("NFM_NQ")) == 0);
-      const bool fits = L * s_used == kWave && s_used >= 2 && s_used <= 8 && X.max_row + M.n_aug <= kWave;
-      return want && fits ? kWave / s_used : 0;
+    // row-phase mode (k_row_phase): 2 = held entries + register-resident rows (SGD, one sample per
+    // wavefront, a batch with singles: 106 vs 141 us per batch on the headline shape), 1 = held entries,
+    // 0 = streamed (rows longer than the held capacity, models with several orders).
+    // NFM_HELD=0 / NFM_NQ=0 switch the modes off (tuning).
+    auto mode_for = [&](int s_used) {
+      static const bool held_on = !(getenv("NFM_HELD") && atoi(getenv("NFM_HELD")) == 0);
+      static const bool reg_on = !(getenv("NFM_NQ") && atoi(getenv("NFM_NQ")) == 0);
+      if (GEN || !held_on || X.max_row + M.n_aug > held_capacity(L, s_used)) return 0;
+      if (reg_on && OPT == OPT_SGD && singles_in_row && L * s_used == kWave) return 2;
+      return 1;
     };
     int nA;
     {
@@ -1254,11 +1437,11 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
         if (nA > ctx->n_cu * per_cu) nA = ctx->n_cu * per_cu;
         hipLaunchKernelGGL(kern, dim3(nA), dim3(kBlock), lds_bytes, st, ra, std::max(m_cap, R));
       } else {
-      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra, nq_for(R >= 16 ? 16 : R), row_pad_kb); s_used = R >= 16 ? 16 : R; }
-      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra, nq_for(R >= 8 ? 8 : R), row_pad_kb); s_used = R >= 8 ? 8 : R; }
-      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra, nq_for(R >= 4 ? 4 : R), row_pad_kb); s_used = R >= 4 ? 4 : R; }
-      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT, GEN>(st, ra, nq_for(R >= 2 ? 2 : R), row_pad_kb); s_used = R >= 2 ? 2 : R; }
-      else { launch_row<L, 1, OPT, GEN>(st, ra, nq_for(1), row_pad_kb); s_used = 1; }
+      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra, mode_for(R >= 16 ? 16 : R), row_pad_kb); s_used = R >= 16 ? 16 : R; }
+      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra, mode_for(R >= 8 ? 8 : R), row_pad_kb); s_used = R >= 8 ? 8 : R; }
+      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra, mode_for(R >= 4 ? 4 : R), row_pad_kb); s_used = R >= 4 ? 4 : R; }
+      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT, GEN>(st, ra, mode_for(R >= 2 ? 2 : R), row_pad_kb); s_used = R >= 2 ? 2 : R; }
+      else { launch_row<L, 1, OPT, GEN>(st, ra, mode_for(1), row_pad_kb); s_used = 1; }
       const int spw = kWave / (L * s_used);
       nA = (len + kWavesPerBlock * spw - 1) / (kWavesPerBlock * spw);
       }
