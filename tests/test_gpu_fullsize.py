@@ -98,3 +98,57 @@ def test_predict_properties(problem):
                    Xo.data.reshape(N, M)[sub].ravel(), len(sub), D)
     got = gpu_fm("regression", 2, K, "explicit", True, True, P0, w1, 0.5).decisionFunction(to_gpu(Xp))
     assert np.array_equal(got, dec["w1"][sub])
+
+
+# ---- the north-star shape: d = 1e6, 64 nnz/row, k = 64, mini-batch 8192 (BASELINE.json configs[2] /
+# north_star).  n is cut to what the CPU restatement finishes in seconds; d, m, k and the batch size --
+# everything that decides which kernels run and how a batch's touches collide (about 60 % of a batch's
+# touches are singles, most other features are touched twice) -- are the full-size values.
+HN, HD, HM, HK, HB = 120_000, 1_000_000, 64, 64, 8192
+
+
+@pytest.fixture(scope="module")
+def headline_problem():
+    Xo = big_csr(HN, HD, HM, 43)
+    rng = np.random.default_rng(2)
+    y = np.sign(rng.standard_normal(HN))
+    P0, w0 = (rng.standard_normal((1, HK, HD)) * 0.01), np.zeros(HD)
+    return Xo, to_gpu(Xo), y, P0, w0
+
+
+def test_headline_shape_sgd_vs_mb_oracle(headline_problem):
+    Xo, X, y, P0, w0 = headline_problem
+    P, w = P0.copy(), w0.copy()
+    b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, 0.0, O.sgd_cfg(loss="logistic"), HB, it=1)
+    runs = []
+    for _ in range(2):
+        fm = gpu_fm("classification", 2, HK, "explicit", True, True, P0, w0, 0.0)
+        sgd = nf.newSGD(maxIter=1, verbose=0, tol=0, shuffle=False, loss="logistic", mode="minibatch", batch=HB)
+        sgd.fit(X, y, fm)
+        runs.append((fm.P.copy(), fm.w.copy(), fm.intercept, sgd.history[0]))
+    Pg, wg, bg, h = runs[0]
+    assert abs(bg - b) < 1e-11
+    assert_close(wg, w, 1e-9, 1e-13, "w")
+    assert_close(Pg, P, 1e-9, 1e-13, "P")
+    assert_close(h[1], ls / HN, 1e-11, 0, "mean loss")
+    assert_close(h[0], vs, 1e-9, 0, "viol")
+    # bitwise reproducible
+    assert np.array_equal(Pg, runs[1][0]) and np.array_equal(wg, runs[1][1]) and bg == runs[1][2]
+
+
+def test_headline_shape_adagrad_vs_mb_oracle(headline_problem):
+    Xo, X, y, P0, w0 = headline_problem
+    n = 4 * HB + 1  # the it == 1 singleton batch + four full batches
+    Xs = O.Dataset(Xo.indptr[: n + 1], Xo.indices[: n * HM], Xo.data[: n * HM], n, HD)
+    cfg = O.adagrad_cfg(loss="squared")
+    P, w = P0.copy(), w0.copy()
+    st = O.AdaState(1, HD, HK, HD)
+    b, it, ls, vs = O.fm_adagrad_epoch_mb(Xs, y[:n], 2, P, w, 0.0, cfg, HB, st, it=1)
+    b = O.fm_adagrad_finalize(2, P, w, b, cfg, it, st)
+    fm = gpu_fm("regression", 2, HK, "explicit", True, True, P0, w0, 0.0)
+    ada = nf.newAdaGrad(maxIter=1, verbose=0, tol=0, shuffle=False, loss="squared", mode="minibatch", batch=HB)
+    ada.fit(to_gpu(Xs), y[:n], fm)
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, 1e-9, 1e-13, "w")
+    assert_close(fm.P, P, 1e-9, 1e-13, "P")
+    assert_close(ada.history[0][0], vs, 1e-9, 0, "viol")
