@@ -33,6 +33,9 @@ WORKLOADS = {
     "cfg3": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="squared", batch=8192),
     # cfg5: higher-order FM, degree 3 with fitLower=explicit -> two parameter blocks (ANOVA degree 3 and 2)
     "cfg5": dict(n=1_000_000, d=100_000, m=32, k=8, degree=3, solver="sgd", loss="squared", batch=32768),
+    # cfg4: field-aware FM, 16 fields, one nnz per field (field f owns the indices [f d/F, (f+1) d/F),
+    # tests/utils.nim:66-68), AdaGrad
+    "cfg4": dict(n=1_000_000, d=100_000, m=16, k=8, degree=2, solver="adagrad", loss="squared", batch=32768, fields=16),
     "tiny": dict(n=50_000, d=5_000, m=16, k=8, degree=2, solver="sgd", loss="logistic", batch=4096),
     # cfg2 with Zipf(1.1) feature popularity: a few features are touched by most samples of a batch
     "cfg2z": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768, zipf=1.1),
@@ -40,8 +43,11 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def algorithmic_bytes_per_sample(solver, m, k, n_orders=1):
+def algorithmic_bytes_per_sample(solver, m, k, n_orders=1, fields=0):
     """int32 idx, fp64 val, fp64 params."""
+    if fields:  # FFM, the reference's touch set (all F rows of every feature of the sample)
+        per = 32 if solver == "adagrad" else 16
+        return 16 * m + 16 + per * fields * m * k + (32 if solver == "adagrad" else 24) * m
     if solver == "sgd":
         return 12 * m + 16 + n_orders * 16 * m * k + 16 * m + 8 * m
     return 12 * m + 16 + n_orders * 32 * m * k + 32 * m
@@ -118,10 +124,23 @@ def main():
     ctx = nf.Context(local_rank)
     nf.set_default_context(ctx)
     # ---- synthetic shard, generated on the device (data seed 42 + rank; model seed 1) ----
-    indptr, indices, data = gen_shard(torch, dev, n, d, m, 42 + rank, wl.get("zipf", 0.0))
+    F = wl.get("fields", 0)
+    fields = None
+    if F:
+        g = torch.Generator(device=dev)
+        g.manual_seed(42 + rank)
+        per = d // F
+        idx = torch.randint(0, per, (n, F), device=dev, generator=g, dtype=torch.int64) + torch.arange(F, device=dev) * per
+        indices = idx.reshape(-1).to(torch.int32)
+        fields = torch.arange(F, device=dev, dtype=torch.int32).repeat(n)
+        data = torch.rand((n * F,), device=dev, generator=g, dtype=torch.float64) * 2 - 1
+        indptr = torch.arange(n + 1, device=dev, dtype=torch.int64) * F
+    else:
+        indptr, indices, data = gen_shard(torch, dev, n, d, m, 42 + rank, wl.get("zipf", 0.0))
     torch.cuda.synchronize()
     X = nf.CSRDataset.from_device(ctx, n, d, n * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(),
-                                  keep=(indptr, indices, data))
+                                  fields_ptr=fields.data_ptr() if F else None, nFields=F,
+                                  keep=(indptr, indices, data, fields))
     # labels from a planted FM (k, scale 0.1), like tests/utils.nim:29-47; classification -> sign
     rng = np.random.default_rng(1234)
     planted = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True)
@@ -131,7 +150,10 @@ def main():
     if task == "classification":
         y = np.sign(y)
     del planted
-    fm = nf.newFactorizationMachine(task, degree=wl["degree"], nComponents=k, warmStart=True, randomState=1)
+    if F:
+        fm = nf.newFieldAwareFactorizationMachine(task, nComponents=k, warmStart=True, randomState=1)
+    else:
+        fm = nf.newFactorizationMachine(task, degree=wl["degree"], nComponents=k, warmStart=True, randomState=1)
     fm.init(X)  # w = 0, P ~ N(0, 0.01^2), intercept = 0 (model/factorization_machine.nim:125-139)
     if wl["solver"] == "sgd":
         opt = nf.newSGD(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch", batch=args.batch)
@@ -196,7 +218,7 @@ def main():
             capi.check(capi.lib().nfm_decision_function_device(mh, X.h, out_dev.data_ptr()))
         ctx.synchronize()
         tp = (time.perf_counter() - tp) / reps_p
-        pbytes = 12 * m + 8 + n_orders * 8 * m * k + 8 * m + 8  # SURVEY.md 8(d) predict bytes per sample
+        pbytes = 12 * m + 8 + (F * 8 * m * k if F else n_orders * 8 * m * k) + 8 * m + 8  # SURVEY.md 8(d) predict bytes per sample
         pred = {"value": round(n / tp, 1), "unit": "samples/s", "ms": round(tp * 1e3, 4),
                 "roofline_frac": round(pbytes * n / tp / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": pbytes}
 
@@ -216,7 +238,7 @@ def main():
         per_batch_ms = {f: (fam[f][1] / fam[f][0] if fam[f][0] else 0.0) for f in fam}
         pair_ms = (per_batch_ms["row_phase"] + per_batch_ms["singles"] + per_batch_ms["col_phase"]
                    + (fam["heavy_partial"][1] + fam["heavy_apply"][1]) / max(fam["row_phase"][0], 1))
-        bps = algorithmic_bytes_per_sample(wl["solver"], m, k, n_orders)
+        bps = algorithmic_bytes_per_sample(wl["solver"], m, k, n_orders, F)
         units = n / n_batches
         achieved = bps * units / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
         # HBM-side bytes per mini-batch from the last committed PMC run of this workload/batch
@@ -237,7 +259,7 @@ def main():
 
     # ---- CPU baseline: reference-faithful port, single thread, same workload (rank 0, N = 1) ----
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not F:
         import oracle as O
 
         cpu_epochs = 5

@@ -160,6 +160,178 @@ __global__ __launch_bounds__(kBlock) void k_ffm_row_phase(FRowArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// row phase, LDS-resident neighbourhood (rows of at most 64 entries, at most 64 fields, m*F rows that
+// fit the workgroup's LDS share): one wavefront per sample.
+//   1. lane t holds entry t (index, field, value); one ballot per field gives the entries of a field
+//   2. ALL m*F parameter rows P[f][j_q] of the sample are gathered into LDS, every load in flight at
+//      once (16 B per lane, a row = L consecutive lanes) -- each row is needed twice, as the
+//      partner row of one output and for yhat of the mirrored one
+//   3. outputs (q, f) from LDS: dA[q][f] = x_q * sum_{q' in field f, j_q' != j_q} x_q' P[f_q][j_q']
+//      in ascending q' (the reference's accumulation order, sgd_ffm.nim:24-30), written to the
+//      contribution buffer; yhat's pair sum = 1/2 sum <P[f][j_q], dA[q][f]>
+// ------------------------------------------------------------------------------------------------
+template <int L, int OPT>
+__global__ __launch_bounds__(kBlock) void k_ffm_row_phase_lds(FRowArgs a, int m_cap) {
+  constexpr int R = kWave / L;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ double red[kWavesPerBlock][4];
+  const CsrView& X = a.X;
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int F = M.nb, Kp = M.Kp;
+  // per-wavefront LDS: rows [m_cap * F][Kp] doubles, masks [F] u64, values [m_cap] doubles, indices/fields [m_cap] ints
+  const size_t per_wave = ((size_t)m_cap * F * Kp * 8 + (size_t)F * 8 + (size_t)m_cap * 16 + 15) / 16 * 16;
+  unsigned char* base = lds_raw + (size_t)wv * per_wave;
+  double* rows = reinterpret_cast<double*>(base);
+  unsigned long long* fmask = reinterpret_cast<unsigned long long*>(base + (size_t)m_cap * F * Kp * 8);
+  double* xs = reinterpret_cast<double*>(base + (size_t)m_cap * F * Kp * 8 + (size_t)F * 8);
+  int* js = reinterpret_cast<int*>(xs + m_cap);
+  int* fs = js + m_cap;
+  const int pib = blockIdx.x * kWavesPerBlock + wv;
+  const bool valid = pib < a.len;
+  int64_t q0 = 0;
+  int m = 0;
+  double y = 0.0;
+  int64_t pos = 0;
+  if (valid) {
+    pos = a.p0 + pib;
+    const int64_t i = a.perm ? a.perm[pos] : a.begin + pos;
+    q0 = X.indptr[i];
+    m = (int)(X.indptr[i + 1] - q0);
+    y = dev::target_of(X.y[i], M.task);
+  }
+  const double itp = (a.it0p[0] + a.it_b) - 1.0;
+  const bool stored = a.use_stored != 0;
+  double b0 = M.sc[SC_INTERCEPT];
+  const double sP = OPT == OPT_SGD ? a.scales[0] : 1.0, sw = OPT == OPT_SGD ? a.scales[1] : 1.0;
+  if (OPT == OPT_ADAGRAD && !stored && M.fit_intercept) b0 = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * itp * O.alpha0);
+  const double tmpP = O.eta0 * itp * O.beta, denw = itp * O.eta0 * O.alpha;
+  // 1. this lane's entry; linear term; per-field entry masks
+  int jt = 0, ft = -1;
+  double xt = 0.0, part = 0.0;
+  if (lane < m) {
+    jt = X.indices[q0 + lane];
+    ft = X.fields[q0 + lane];
+    xt = X.data[q0 + lane];
+    double wj = sw * M.w[jt];
+    if (OPT == OPT_ADAGRAD && !stored && M.fit_linear) wj = -O.eta0 * O.Gw[jt] / (denw + sqrt(O.Nw[jt]));
+    part += wj * xt;
+    xs[lane] = xt;
+    js[lane] = jt;
+    fs[lane] = ft;
+  }
+  for (int f = 0; f < F; ++f) {
+    const unsigned long long mk = __ballot(ft == f);
+    if (lane == 0) fmask[f] = mk;
+  }
+  // 2. gather the m * F rows
+  const int n_out = m * F;
+  constexpr int U = 8;
+  for (int ob = 0; ob < n_out; ob += R * U) {
+    double2 r0[U], r1[U];
+    int oo[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int o = ob + u * R + g;
+      oo[u] = o < n_out ? o : -1;
+      const int q = o < n_out ? o / F : 0, f = o < n_out ? o % F : 0;
+      const int jq = __shfl(jt, q, kWave);
+      const size_t e = ((size_t)f * M.da + jq) * Kp + 2 * l;
+      r0[u] = r1[u] = {0.0, 0.0};
+      if (oo[u] >= 0) {
+        if (OPT == OPT_SGD || stored) {
+          r0[u] = *reinterpret_cast<const double2*>(M.P + e);
+        } else {
+          r0[u] = *reinterpret_cast<const double2*>(O.G + e);
+          r1[u] = *reinterpret_cast<const double2*>(O.N + e);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (oo[u] < 0) continue;
+      double2 p;
+      if (OPT == OPT_SGD || stored) {
+        p.x = sP * r0[u].x;
+        p.y = sP * r0[u].y;
+      } else {
+        p.x = dev::adagrad_param(r0[u].x, r1[u].x, O.eta0, tmpP);
+        p.y = dev::adagrad_param(r0[u].y, r1[u].y, O.eta0, tmpP);
+      }
+      *reinterpret_cast<double2*>(rows + (size_t)oo[u] * Kp + 2 * l) = p;
+    }
+  }
+  __syncthreads();
+  // 3. outputs
+  double* C = a.contrib + (size_t)(valid ? a.toff[pos] - a.t_base : 0) * F * Kp;
+  for (int ob = 0; ob < n_out; ob += R) {
+    const int o = ob + g;
+    if (o < n_out) {
+      const int q = o / F, f = o % F;
+      const int jq = js[q], fq = fs[q];
+      const double xq = xs[q];
+      unsigned long long mk = fmask[f] & ~(1ull << q);
+      double2 v = {0.0, 0.0};
+      while (mk) {
+        const int q2 = __ffsll((long long)mk) - 1;
+        mk &= mk - 1;
+        if (js[q2] == jq) continue;
+        const double2 p = *reinterpret_cast<const double2*>(rows + ((size_t)q2 * F + fq) * Kp + 2 * l);
+        const double x2 = xs[q2];
+        v.x += xq * x2 * p.x;  // sgd_ffm.nim:29-30: dA += val1 * val2 * P  (left to right)
+        v.y += xq * x2 * p.y;
+      }
+      *reinterpret_cast<double2*>(C + (size_t)o * Kp + 2 * l) = v;
+      if (v.x != 0.0 || v.y != 0.0) {
+        const double2 pf = *reinterpret_cast<const double2*>(rows + (size_t)o * Kp + 2 * l);
+        part += 0.5 * (pf.x * v.x + pf.y * v.y);
+      }
+    }
+  }
+  part = dev::wave_sum(part);
+  double r_loss = 0.0, r_acc0 = 0.0, r_acc1 = 0.0;
+  if (valid) {
+    const double yh = b0 + part;
+    const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
+    r_loss = dev::loss_value(O.loss, O.loss_param, y, yh);
+    double etaP = 0.0, etaw = 0.0;
+    if (OPT == OPT_SGD) {
+      const double it = (a.it0p[0] + a.it_b) + (double)pib;
+      etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+      etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
+      if (M.fit_intercept) {
+        const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
+        r_acc0 = eta0 * dL;
+        r_acc1 = eta0;
+      }
+    } else if (M.fit_intercept) {
+      r_acc0 = dL;
+      r_acc1 = dL * dL;
+    }
+    if (lane == 0) a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
+  }
+  if (lane == 0) {
+    red[wv][0] = r_loss;
+    red[wv][1] = 0.0;
+    red[wv][2] = r_acc0;
+    red[wv][3] = r_acc1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PartA p{0.0, 0.0, 0.0, 0.0};
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) {
+      p.loss += red[w_][0];
+      p.acc0 += red[w_][2];
+      p.acc1 += red[w_][3];
+    }
+    a.parts[blockIdx.x] = p;
+  }
+}
+
 struct FColArgs {
   ModelView M;
   OptView O;
@@ -339,6 +511,19 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
   const double* it0p = W.itbuf.as<double>();
   const size_t half = W.partsB.bytes / sizeof(double) / 2;
   int n_prev = 0;
+  // LDS-resident neighbourhood (k_ffm_row_phase_lds): rows <= 64 entries, <= 64 fields, at most 64 KiB
+  // per wavefront (2 workgroups per CU at 160 KiB); NFM_FFM_LDS=0 falls back to the generic kernel
+  static const bool lds_on = !(getenv("NFM_FFM_LDS") && atoi(getenv("NFM_FFM_LDS")) == 0);
+  const int m_cap = (int)std::max<int64_t>(X.max_row, 1);
+  size_t lds_bytes = 0;
+  if (lds_on && X.max_row <= kWave && M.nb <= kWave) {
+    size_t per_wave = (size_t)m_cap * M.nb * M.Kp * 8 + (size_t)M.nb * 8 + (size_t)m_cap * 16;
+    per_wave = (per_wave + 15) / 16 * 16;
+    if (per_wave * kWavesPerBlock <= 150 * 1024) lds_bytes = per_wave * kWavesPerBlock;
+  }
+  if (lds_bytes > 64 * 1024)
+    NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffm_row_phase_lds<L, OPT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   for (int64_t b = 0; b < P.n_batches; ++b) {
     const int64_t p0 = P.bat_pos[b];
     const int len = (int)(P.bat_pos[b + 1] - p0);
@@ -349,7 +534,10 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
                   use_stored, (double)p0, it0p, OPT == OPT_SGD ? Stab + 2 * b : M.sc, W.contrib.as<double>(),
                   W.rec.as<SampleRec>(), W.partsA.as<PartA>()};
       TimedLaunch tl(ctx, "row_phase");
-      hipLaunchKernelGGL((k_ffm_row_phase<L, OPT>), dim3(nA), dim3(kBlock), 0, st, ra);
+      if (lds_bytes > 0)
+        hipLaunchKernelGGL((k_ffm_row_phase_lds<L, OPT>), dim3(nA), dim3(kBlock), lds_bytes, st, ra, m_cap);
+      else
+        hipLaunchKernelGGL((k_ffm_row_phase<L, OPT>), dim3(nA), dim3(kBlock), 0, st, ra);
     }
     const int64_t u0 = P.bat_uoff[b], u1 = P.bat_uoff[b + 1];
     const int per_block = kWavesPerBlock * R;
