@@ -365,13 +365,17 @@ __global__ __launch_bounds__(kBlock) void k_ffm_col_phase(FColArgs a) {
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   const int g = lane / L, l = lane % L;
   const bool closer = blockIdx.x == gridDim.x - 1;
-  const int64_t u = closer ? a.u1 : a.u0 + ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  // work unit = (unique feature, field): L lanes read the row P[f][j] once, combine the touches'
+  // contribution rows in sample order, write the row once; the unit of field 0 also updates w[j]
+  const int F = M.nb;
+  const int64_t unit = closer ? -1 : ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  const int64_t u = closer ? a.u1 : a.u0 + unit / F;
+  const int f = closer ? 0 : (int)(unit % F);
   const double itp = (a.it0p[0] + a.it_b) - 1.0;
   double viol = 0.0;
   if (u < a.u1) {
     const int64_t j = a.ucol[u];
     const int64_t t0 = a.uptr[u], t1 = a.uptr[u + 1];
-    const int F = M.nb;
     const double c = (double)(t1 - t0);
     double sP = 1.0, sPn = 1.0, sw = 1.0, swn = 1.0, fP = 1.0, fw = 1.0;
     if (OPT == OPT_SGD) {
@@ -382,7 +386,8 @@ __global__ __launch_bounds__(kBlock) void k_ffm_col_phase(FColArgs a) {
         else { fP = pow(a.Dtab_b[0], 1.0 / c) / a.Dtab_b[0]; fw = pow(a.Dtab_b[1], 1.0 / c) / a.Dtab_b[1]; }
       }
     }
-    for (int f = 0; f < F; ++f) {
+    const bool do_w = M.fit_linear && f == 0;
+    {
       const size_t e = ((size_t)f * M.da + j) * M.Kp + 2 * l;
       double2 st = {0.0, 0.0}, g2 = {0.0, 0.0}, n2 = {0.0, 0.0}, p;
       if (OPT == OPT_SGD) {
@@ -405,18 +410,40 @@ __global__ __launch_bounds__(kBlock) void k_ffm_col_phase(FColArgs a) {
         }
       }
       double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
-      double seta = 0.0;
-      for (int64_t t = t0; t < t1; ++t) {
-        const SampleRec r = a.rec[a.tpos[t]];
-        const double2 v = *reinterpret_cast<const double2*>(a.contrib + ((size_t)(a.tq[t] - a.t_base) * F + f) * M.Kp + 2 * l);
-        if (OPT == OPT_SGD) {
-          acc.x += r.etaP * (r.dL * v.x);
-          acc.y += r.etaP * (r.dL * v.y);
-          seta += r.etaP;
-        } else {
-          const double gx = r.dL * v.x, gy = r.dL * v.y;
-          acc.x += gx; acc.y += gy;
-          accn.x += gx * gx; accn.y += gy * gy;
+      double seta = 0.0, a0 = 0.0, a1 = 0.0;
+      constexpr int TU = 4;  // touches requested together
+      for (int64_t tb = t0; tb < t1; tb += TU) {
+        int pib[TU];
+        int64_t tq[TU];
+        double x[TU];
+        SampleRec r[TU];
+        double2 v[TU];
+#pragma unroll
+        for (int q = 0; q < TU; ++q) {
+          const int64_t t = tb + q < t1 ? tb + q : t1 - 1;
+          pib[q] = a.tpos[t];
+          tq[q] = a.tq[t];
+          x[q] = do_w ? a.tx[t] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < TU; ++q) {
+          r[q] = a.rec[pib[q]];
+          v[q] = *reinterpret_cast<const double2*>(a.contrib + ((size_t)(tq[q] - a.t_base) * F + f) * M.Kp + 2 * l);
+        }
+#pragma unroll
+        for (int q = 0; q < TU; ++q) {
+          if (tb + q >= t1) break;
+          if (OPT == OPT_SGD) {
+            acc.x += r[q].etaP * (r[q].dL * v[q].x);
+            acc.y += r[q].etaP * (r[q].dL * v[q].y);
+            seta += r[q].etaP;
+            if (do_w) { a0 += r[q].etaw * (r[q].dL * x[q]); a1 += r[q].etaw; }
+          } else {
+            const double gx = r[q].dL * v[q].x, gy = r[q].dL * v[q].y;
+            acc.x += gx; acc.y += gy;
+            accn.x += gx * gx; accn.y += gy * gy;
+            if (do_w) { const double gw = r[q].dL * x[q]; a0 += gw; a1 += gw * gw; }
+          }
         }
       }
       if (OPT == OPT_SGD) {
@@ -429,29 +456,22 @@ __global__ __launch_bounds__(kBlock) void k_ffm_col_phase(FColArgs a) {
         *reinterpret_cast<double2*>(O.G + e) = g2;
         *reinterpret_cast<double2*>(O.N + e) = n2;
       }
-    }
-    if (M.fit_linear && l == 0) {
-      const double wt = M.w[j];
-      double a0 = 0.0, a1 = 0.0;
-      for (int64_t t = t0; t < t1; ++t) {
-        const SampleRec r = a.rec[a.tpos[t]];
-        const double x = a.tx[t];
-        if (OPT == OPT_SGD) { a0 += r.etaw * (r.dL * x); a1 += r.etaw; }
-        else { const double gw = r.dL * x; a0 += gw; a1 += gw * gw; }
-      }
-      if (OPT == OPT_SGD) {
-        const double wj = sw * wt;
-        viol += fabs((a0 + a1 * O.alpha * wj) / c);
-        M.w[j] = wt * fw - (a0 / c) / swn;
-      } else {
-        const double gw = O.Gw[j], nw = O.Nw[j];
-        if (!a.use_stored) {
-          const double wj = -O.eta0 * gw / (itp * O.eta0 * O.alpha + sqrt(nw));
-          viol += fabs(wt - wj);
-          M.w[j] = wj;
+      if (do_w && l == 0) {
+        const double wt = M.w[j];
+        if (OPT == OPT_SGD) {
+          const double wj = sw * wt;
+          viol += fabs((a0 + a1 * O.alpha * wj) / c);
+          M.w[j] = wt * fw - (a0 / c) / swn;
+        } else {
+          const double gw = O.Gw[j], nw = O.Nw[j];
+          if (!a.use_stored) {
+            const double wj = -O.eta0 * gw / (itp * O.eta0 * O.alpha + sqrt(nw));
+            viol += fabs(wt - wj);
+            M.w[j] = wj;
+          }
+          O.Gw[j] = gw + a0;
+          O.Nw[j] = nw + a1;
         }
-        O.Gw[j] = gw + a0;
-        O.Nw[j] = nw + a1;
       }
     }
   }
@@ -541,7 +561,7 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
     }
     const int64_t u0 = P.bat_uoff[b], u1 = P.bat_uoff[b + 1];
     const int per_block = kWavesPerBlock * R;
-    const int nB = (int)((u1 - u0 + per_block - 1) / per_block) + 1;
+    const int nB = (int)(((u1 - u0) * M.nb + per_block - 1) / per_block) + 1;  // units = (feature, field)
     {
       FColArgs ca{M, O, P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(),
                   P.tq.as<int64_t>(), u0, u1, t_base[b], OPT == OPT_SGD ? Stab + 2 * b : M.sc,
@@ -580,7 +600,7 @@ int mb_ffm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& 
   NFM_TRY(W.contrib.ensure(sizeof(double) * (size_t)max_t * M.nb * M.Kp));
   NFM_TRY(W.rec.ensure(sizeof(SampleRec) * (size_t)std::max<int64_t>(P.max_batch, 1)));
   NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch / kWavesPerBlock + 1)));
-  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique / kWavesPerBlock + 2)));
+  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique * M.nb / kWavesPerBlock + 2)));
   NFM_TRY(W.Dtab.ensure(sizeof(double) * 4 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Stab.ensure(sizeof(double) * 2 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Ftab.ensure(sizeof(double) * 2 * kFtab * (size_t)(P.n_batches + 1)));
