@@ -11,8 +11,6 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-python3 bench.py --workload $WL --batch $B "$@" > $OUT/${TAG}_bench.json
-cat $OUT/${TAG}_bench.json
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o ${TAG} -- python3 $ROOT/bench.py --workload $WL --batch $B --no-cpu-baseline "$@" > $OUT/${TAG}_prof.log 2>&1
 cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
@@ -22,6 +20,9 @@ cd $ROOT
 python3 tools/pmc_traffic.py $(find $OUT/${TAG}_pmc_fetch -name "*counter_collection.csv" | head -1) \
   $(find $OUT/${TAG}_pmc_write -name "*counter_collection.csv" | head -1) $WL $B $TAG
 cp profiles/${TAG}_pmc_traffic.json $OUT/
+# the bench line last, so that its roofline.traffic is this run's PMC result
+python3 bench.py --workload $WL --batch $B "$@" > $OUT/${TAG}_bench.json
+cat $OUT/${TAG}_bench.json
 # the raw per-dispatch counter CSVs are large; keep only the summary
 rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
 find $OUT/${TAG}_prof -name "*kernel_trace.csv" -delete
