@@ -97,6 +97,34 @@ int32_t nfm_dataset_create_csr_device(nfm_ctx* ctx, int64_t n_samples, int64_t n
                                       const int32_t* indices_dev, const double* data_dev,
                                       const int32_t* fields_dev, int64_t n_fields,
                                       const double* y_dev, nfm_dataset** out);
+/* ---- text ingest, parsed on the GPU ----
+ * loadSVMLightFile (dataset.nim:562-632): "target idx:val idx:val ..." per line;
+ * loadFFMFile (dataset.nim:696-790): "target field:idx:val ...".  The index
+ * base is detected from the file (0-based iff an index 0 occurs, else 1-based,
+ * :589/:732-733), nFeatures = max index + 1 - base (nFields likewise); a
+ * positive n_features / n_fields smaller than that is NFM_ERR_INVALID (the
+ * reference's ValueError, :623-626, :777-785), a larger one wins (:631, :788).
+ * A negative index is NFM_ERR_INVALID ("Negative index is included.", :587).
+ * Numbers are read as Nim's parseInt / parseFloat read them (correctly rounded
+ * binary64).  Targets are stored with the dataset (nfm_dataset_get_targets).
+ * nfm_dataset_parse_text: the same from a memory buffer. */
+int32_t nfm_dataset_load_svmlight(nfm_ctx* ctx, const char* path, int64_t n_features,
+                                  nfm_dataset** out);
+int32_t nfm_dataset_load_ffm(nfm_ctx* ctx, const char* path, int64_t n_features, int64_t n_fields,
+                             nfm_dataset** out);
+int32_t nfm_dataset_parse_text(nfm_ctx* ctx, const char* text, int64_t len, int32_t with_fields,
+                               int64_t n_features, int64_t n_fields, nfm_dataset** out);
+/* nSamples / nFeatures / nnz / nFields (dataset.nim:44-51, tensor/sparse.nim:26-40) */
+int32_t nfm_dataset_shape(const nfm_dataset* ds, int64_t* n_samples, int64_t* n_features,
+                          int64_t* nnz, int64_t* n_fields);
+/* bytes of text, upload and parse time of the loader that made this dataset */
+int32_t nfm_dataset_ingest_stats(const nfm_dataset* ds, int64_t* bytes, double* upload_ms,
+                                 double* parse_ms);
+/* read-back in the reference's widths (CSRMatrix data/indices/indptr, fields:
+ * tensor/sparse.nim:9-12,19-24); any pointer may be NULL */
+int32_t nfm_dataset_get_targets(nfm_dataset* ds, double* y /*n*/);
+int32_t nfm_dataset_get_csr(nfm_dataset* ds, int64_t* indptr /*n+1*/, int64_t* indices /*nnz*/,
+                            double* data /*nnz*/, int64_t* fields /*nnz*/);
 /* model/fm_base.nim:29-36 checkTarget is applied by the optimizer according to
  * the model's task; this replaces the targets (host array, n). */
 int32_t nfm_dataset_set_targets(nfm_dataset* ds, const double* y);

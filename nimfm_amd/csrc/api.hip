@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <memory>
+#include <vector>
 
+#include "ingest.h"
 #include "mb.h"
 
 using namespace nfm;
@@ -16,6 +18,8 @@ struct nfm_dataset {
   DevBuf indptr, indices, data, fields, y;
   bool has_y = false;
   int max_row = 0;
+  int64_t ingest_bytes = 0;  // set by the text loaders (ingest.hip)
+  double ingest_upload_ms = 0.0, ingest_parse_ms = 0.0;
   uint64_t serial = 0;  // bumps when targets change (plans do not depend on y; kept for clarity)
 };
 
@@ -256,6 +260,118 @@ int32_t nfm_dataset_set_targets(nfm_dataset* ds, const double* y) {
   ds->has_y = true;
   ds->v.y = ds->y.as<double>();
   ds->serial++;
+  return NFM_OK;
+}
+
+// ---- text ingest (ingest.hip) ----
+static int dataset_from_ingest(nfm_ctx* ctx, IngestResult& r, bool with_fields, int64_t n_features, int64_t n_fields,
+                               nfm_dataset** out) {
+  // dataset.nim:623-631, 777-790: a given nFeatures / nFields smaller than what the file needs is an error,
+  // a larger one wins
+  if (n_features > 0 && r.d > n_features)
+    return set_error(NFM_ERR_INVALID, "nFeatures is %lld but dataset has at least %lld features.", (long long)n_features,
+                     (long long)r.d);
+  if (with_fields && n_fields > 0 && r.n_fields > n_fields)
+    return set_error(NFM_ERR_INVALID, "nFields is %lld but dataset has at least %lld fields.", (long long)n_fields,
+                     (long long)r.n_fields);
+  std::unique_ptr<nfm_dataset> ds(new nfm_dataset());
+  ds->ctx = ctx;
+  ds->max_row = r.max_row;
+  ds->indptr.take(r.indptr);
+  ds->indices.take(r.indices);
+  ds->data.take(r.data);
+  ds->y.take(r.y);
+  if (with_fields) ds->fields.take(r.fields);
+  ds->has_y = true;
+  ds->v.indptr = ds->indptr.as<int64_t>();
+  ds->v.indices = ds->indices.as<int32_t>();
+  ds->v.data = ds->data.as<double>();
+  ds->v.fields = with_fields ? ds->fields.as<int32_t>() : nullptr;
+  ds->v.y = ds->y.as<double>();
+  ds->v.n = r.n;
+  ds->v.d = std::max<int64_t>(r.d, n_features);
+  ds->v.nnz = r.nnz;
+  ds->v.n_fields = with_fields ? (int32_t)std::max<int64_t>(r.n_fields, n_fields) : 0;
+  ds->v.max_row = r.max_row;
+  ds->ingest_bytes = r.bytes;
+  ds->ingest_upload_ms = r.upload_ms;
+  ds->ingest_parse_ms = r.parse_ms;
+  *out = ds.release();
+  return NFM_OK;
+}
+
+int32_t nfm_dataset_load_svmlight(nfm_ctx* ctx, const char* path, int64_t n_features, nfm_dataset** out) {
+  NFM_CHECK(ctx && path && out, NFM_ERR_INVALID, "null argument");
+  NFM_TRY(use_device(ctx));
+  IngestResult r;
+  NFM_TRY(ingest_text(ctx, path, nullptr, 0, false, &r));
+  return dataset_from_ingest(ctx, r, false, n_features, 0, out);
+}
+
+int32_t nfm_dataset_load_ffm(nfm_ctx* ctx, const char* path, int64_t n_features, int64_t n_fields, nfm_dataset** out) {
+  NFM_CHECK(ctx && path && out, NFM_ERR_INVALID, "null argument");
+  NFM_TRY(use_device(ctx));
+  IngestResult r;
+  NFM_TRY(ingest_text(ctx, path, nullptr, 0, true, &r));
+  return dataset_from_ingest(ctx, r, true, n_features, n_fields, out);
+}
+
+int32_t nfm_dataset_parse_text(nfm_ctx* ctx, const char* text, int64_t len, int32_t with_fields, int64_t n_features,
+                               int64_t n_fields, nfm_dataset** out) {
+  NFM_CHECK(ctx && out && len >= 0, NFM_ERR_INVALID, "null argument");
+  NFM_TRY(use_device(ctx));
+  IngestResult r;
+  NFM_TRY(ingest_text(ctx, nullptr, text, len, with_fields != 0, &r));
+  return dataset_from_ingest(ctx, r, with_fields != 0, n_features, n_fields, out);
+}
+
+int32_t nfm_dataset_shape(const nfm_dataset* ds, int64_t* n_samples, int64_t* n_features, int64_t* nnz, int64_t* n_fields) {
+  NFM_CHECK(ds, NFM_ERR_INVALID, "null dataset");
+  if (n_samples) *n_samples = ds->v.n;
+  if (n_features) *n_features = ds->v.d;
+  if (nnz) *nnz = ds->v.nnz;
+  if (n_fields) *n_fields = ds->v.n_fields;
+  return NFM_OK;
+}
+
+int32_t nfm_dataset_ingest_stats(const nfm_dataset* ds, int64_t* bytes, double* upload_ms, double* parse_ms) {
+  NFM_CHECK(ds, NFM_ERR_INVALID, "null dataset");
+  if (bytes) *bytes = ds->ingest_bytes;
+  if (upload_ms) *upload_ms = ds->ingest_upload_ms;
+  if (parse_ms) *parse_ms = ds->ingest_parse_ms;
+  return NFM_OK;
+}
+
+int32_t nfm_dataset_get_targets(nfm_dataset* ds, double* y) {
+  NFM_CHECK(ds && y, NFM_ERR_INVALID, "null argument");
+  NFM_CHECK(ds->has_y, NFM_ERR_INVALID, "the dataset has no targets");
+  NFM_TRY(use_device(ds->ctx));
+  NFM_HIP_CHECK(hipMemcpyAsync(y, ds->v.y, sizeof(double) * ds->v.n, hipMemcpyDeviceToHost, ds->ctx->stream));
+  NFM_HIP_CHECK(hipStreamSynchronize(ds->ctx->stream));
+  return NFM_OK;
+}
+
+int32_t nfm_dataset_get_csr(nfm_dataset* ds, int64_t* indptr, int64_t* indices, double* data, int64_t* fields) {
+  NFM_CHECK(ds, NFM_ERR_INVALID, "null dataset");
+  NFM_TRY(use_device(ds->ctx));
+  hipStream_t st = ds->ctx->stream;
+  const int64_t n = ds->v.n, nnz = ds->v.nnz;
+  if (indptr) NFM_HIP_CHECK(hipMemcpyAsync(indptr, ds->v.indptr, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, st));
+  if (data && nnz) NFM_HIP_CHECK(hipMemcpyAsync(data, ds->v.data, sizeof(double) * nnz, hipMemcpyDeviceToHost, st));
+  std::vector<int32_t> tmp;
+  if ((indices || fields) && nnz) tmp.resize((size_t)nnz);
+  if (indices && nnz) {
+    NFM_HIP_CHECK(hipMemcpyAsync(tmp.data(), ds->v.indices, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+    for (int64_t q = 0; q < nnz; ++q) indices[q] = tmp[q];
+  }
+  if (fields && nnz) {
+    NFM_CHECK(ds->v.fields, NFM_ERR_INVALID, "the dataset has no fields");
+    NFM_HIP_CHECK(hipMemcpyAsync(tmp.data(), ds->v.fields, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+    for (int64_t q = 0; q < nnz; ++q) fields[q] = tmp[q];
+  }
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
   return NFM_OK;
 }
 

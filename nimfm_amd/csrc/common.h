@@ -125,6 +125,13 @@ struct DevBuf {  // owned device allocation
   int alloc(size_t nbytes);
   int ensure(size_t nbytes) { return nbytes <= bytes && p ? NFM_OK : alloc(nbytes); }
   void release();
+  void take(DevBuf& o) {  // move
+    release();
+    p = o.p;
+    bytes = o.bytes;
+    o.p = nullptr;
+    o.bytes = 0;
+  }
   template <class T>
   T* as() const { return reinterpret_cast<T*>(p); }
 };

@@ -1,0 +1,19 @@
+// nimfm_amd/csrc/ingest.h -- text datasets parsed on the GPU (ingest.hip)
+#pragma once
+#include "common.h"
+
+namespace nfm {
+
+struct IngestResult {
+  DevBuf indptr, indices, data, fields, y;  // int64[n+1], int32[nnz], double[nnz], int32[nnz] (FFM), double[n]
+  int64_t n = 0, d = 0, nnz = 0, n_fields = 0;
+  int64_t offset = 0, offset_field = 0;     // index base found in the file (dataset.nim:589, 733)
+  int max_row = 0;
+  int64_t bytes = 0;
+  double upload_ms = 0.0, parse_ms = 0.0;
+};
+
+// path != nullptr: read the file; else parse mem[0, mem_len).  with_fields: libffm "field:index:value".
+int ingest_text(nfm_ctx* ctx, const char* path, const char* mem, int64_t mem_len, bool with_fields, IngestResult* out);
+
+}  // namespace nfm

@@ -1,0 +1,419 @@
+// nimfm_amd/csrc/ingest.hip -- svmlight / libffm text -> CSR resident in HBM, parsed ON the GPU.
+//
+// Replaces the reference's two-pass, line-by-line host loaders loadSVMLightFile (dataset.nim:562-632)
+// and loadFFMFile (dataset.nim:696-790): "target idx:val idx:val ..." / "target field:idx:val ...",
+// one sample per line, index base detected from the file (0-based iff an index 0 occurs, :589/:732;
+// negative index = ValueError), nFeatures = maxIndex + 1 - offset (nFields likewise, :733-734, with the
+// reference's initial maxFieldIndex = 1).
+//
+// The file goes to HBM as bytes (pinned double buffer); everything after that is data-parallel:
+//   1. count, then list the positions of '\n' and ':' (hipcub select over a counting iterator)
+//   2. one thread per LINE: its span, the colons inside it (binary search) -> row length and, because
+//      entries appear in file order, indptr[i] = (#colons before the line) / colons-per-entry; the
+//      target with parse_float (parse_num.h: correctly rounded, as Nim's parseFloat)
+//   3. one thread per ENTRY: the integer token that ends at the colon (backward scan), the value that
+//      starts after it; wave-reduced min/max of the indices -> offset
+//   4. indices narrowed to int32 with the offset applied
+// Tokens the GPU cannot round for sure (> 19 significant digits where the cut matters) are listed and
+// re-read by the host with strtod.  Where the reference's tokenizer is well defined (single separators)
+// the result is identical; malformed text (a token glued to the wrong neighbour, colons that do not
+// pair up) is an error here, while the reference would read garbage.
+#include <hipcub/hipcub.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ingest.h"
+#include "parse_num.h"
+
+namespace nfm {
+
+using num::Pow5;
+
+static const Pow5 kPow5Host[] = NFM_POW5_TABLE_INIT;
+constexpr int kPow5N = NFM_POW5_QMAX - NFM_POW5_QMIN + 1;
+
+enum {  // status words the kernels raise (device int64 counters)
+  ST_MALFORMED = 0, ST_NO_TARGET = 1, ST_STRTOD = 2, ST_MIN_IDX = 3, ST_MAX_IDX = 4, ST_MIN_FLD = 5, ST_MAX_FLD = 6,
+  ST_MAX_ROW = 7, ST_FIRST_BAD = 8, ST_COUNT = 16
+};
+constexpr int kMaxFix = 1 << 20;  // tokens the host may have to re-read
+
+struct FixRec {
+  int64_t pos;    // byte offset of the token
+  int64_t slot;   // entry index (value) or line index (target)
+  int32_t kind;   // 0 = value, 1 = target
+  int32_t pad;
+};
+
+struct IsChar {
+  const char* t;
+  char c;
+  __device__ bool operator()(const int64_t& i) const { return t[i] == c; }
+};
+
+__global__ void k_count_chars(const char* __restrict__ t, int64_t len, unsigned long long* __restrict__ cnt) {
+  unsigned long long nl = 0, co = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+    const char c = t[i];
+    nl += c == '\n';
+    co += c == ':';
+  }
+  for (int s = 1; s < kWave; s <<= 1) {
+    nl += __shfl_xor(nl, s, kWave);
+    co += __shfl_xor(co, s, kWave);
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    if (nl) atomicAdd(&cnt[0], nl);
+    if (co) atomicAdd(&cnt[1], co);
+  }
+}
+
+__device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a, int64_t n, int64_t v) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ bool is_sep(char c) { return c == ' ' || c == '\t'; }
+
+// what may follow a target or a value at position p: the end of the line (after at most one
+// separator, as the reference's "skip one character" allows), or one separator and the next
+// entry's integer token, which has to end in ':'
+__device__ __forceinline__ bool good_tail(const char* __restrict__ t, int64_t len, int64_t p) {
+  auto eol = [&](int64_t q) { return q >= len || t[q] == '\n' || t[q] == '\r'; };
+  if (eol(p)) return true;
+  if (!is_sep(t[p])) return false;
+  int64_t q = p + 1;
+  if (eol(q)) return true;
+  const int64_t q0 = q;
+  while (q < len && q - q0 < 24 && (num::is_digit(t[q]) || t[q] == '-' || t[q] == '+')) ++q;
+  return q > q0 && q < len && t[q] == ':';
+}
+
+__device__ __forceinline__ void raise_bad(long long* st, int64_t pos) {
+  atomicAdd((unsigned long long*)&st[ST_MALFORMED], 1ull);
+  atomicMin(&st[ST_FIRST_BAD], (long long)pos);
+}
+
+__device__ __forceinline__ void push_fix(long long* st, FixRec* fix, int64_t pos, int64_t slot, int kind) {
+  const unsigned long long k = atomicAdd((unsigned long long*)&st[ST_STRTOD], 1ull);
+  if (k < (unsigned long long)kMaxFix) fix[k] = FixRec{pos, slot, kind, 0};
+}
+
+// one thread per line
+__global__ void k_lines(const char* __restrict__ t, int64_t len, const int64_t* __restrict__ nl, int64_t n_nl, int64_t n_lines,
+                        const int64_t* __restrict__ co, int64_t n_co, int cpe, const Pow5* __restrict__ table,
+                        int64_t* __restrict__ indptr, double* __restrict__ y, uint8_t* __restrict__ y_missing,
+                        long long* __restrict__ st, FixRec* __restrict__ fix) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_lines; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i == n_lines) {
+      indptr[i] = n_co / cpe;
+      continue;
+    }
+    const int64_t s = i ? nl[i - 1] + 1 : 0;
+    int64_t e = i < n_nl ? nl[i] : len;
+    if (e > s && t[e - 1] == '\r') --e;
+    const int64_t c0 = lower_bound_i64(co, n_co, s), c1 = lower_bound_i64(co, n_co, e);
+    if ((c0 % cpe) || ((c1 - c0) % cpe)) raise_bad(st, s);
+    indptr[i] = c0 / cpe;
+    atomicMax(&st[ST_MAX_ROW], (long long)((c1 - c0) / cpe));
+    double v = 0.0;
+    int fl = 0;
+    const int used = num::parse_float(t + s, e - s, &v, &fl, table);
+    y_missing[i] = used == 0;
+    if (used == 0) {
+      atomicAdd((unsigned long long*)&st[ST_NO_TARGET], 1ull);
+      if (e > s) raise_bad(st, s);  // a non-empty line has to start with its target
+    } else if (!good_tail(t, e, s + used)) {
+      raise_bad(st, s + used);
+    }
+    if (fl & num::kNeedsStrtod) push_fix(st, fix, s, i, 1);
+    y[i] = v;
+  }
+}
+
+// one thread per entry
+__global__ void k_entries(const char* __restrict__ t, int64_t len, const int64_t* __restrict__ co, int64_t n_ent, int cpe,
+                          const Pow5* __restrict__ table, int64_t* __restrict__ idx_raw, int64_t* __restrict__ fld_raw,
+                          double* __restrict__ data, long long* __restrict__ st, FixRec* __restrict__ fix) {
+  long long mn = INT64_MAX, mx = INT64_MIN, fmn = INT64_MAX, fmx = INT64_MIN;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_ent; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p0 = co[e * cpe], p1 = co[e * cpe + cpe - 1];
+    // the integer token that ends right before the first colon
+    int64_t ts = p0;
+    while (ts > 0 && p0 - ts < 24 && (num::is_digit(t[ts - 1]) || t[ts - 1] == '-' || t[ts - 1] == '+')) --ts;
+    int64_t a = 0, b = 0;
+    bool ok = ts < p0 && ts > 0 && is_sep(t[ts - 1]) && num::parse_int(t + ts, p0 - ts, &a) == p0 - ts;
+    if (cpe == 2) {
+      ok = ok && p1 > p0 + 1 && num::parse_int(t + p0 + 1, p1 - p0 - 1, &b) == p1 - p0 - 1;
+      fld_raw[e] = a;
+      idx_raw[e] = b;
+      fmn = a < fmn ? a : fmn;
+      fmx = a > fmx ? a : fmx;
+    } else {
+      idx_raw[e] = a;
+      b = a;
+    }
+    mn = b < mn ? b : mn;
+    mx = b > mx ? b : mx;
+    double v = 0.0;
+    int fl = 0;
+    const int used = num::parse_float(t + p1 + 1, len - (p1 + 1), &v, &fl, table);
+    const int64_t ve = p1 + 1 + used;
+    ok = ok && used > 0 && good_tail(t, len, ve);
+    if (!ok) raise_bad(st, p0);
+    if (fl & num::kNeedsStrtod) push_fix(st, fix, p1 + 1, e, 0);
+    data[e] = v;
+  }
+  for (int s = 1; s < kWave; s <<= 1) {
+    const long long a = __shfl_xor(mn, s, kWave), b = __shfl_xor(mx, s, kWave);
+    const long long c = __shfl_xor(fmn, s, kWave), d = __shfl_xor(fmx, s, kWave);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+    fmn = c < fmn ? c : fmn;
+    fmx = d > fmx ? d : fmx;
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    if (mn != INT64_MAX) {
+      atomicMin(&st[ST_MIN_IDX], mn);
+      atomicMax(&st[ST_MAX_IDX], mx);
+    }
+    if (fmn != INT64_MAX) {
+      atomicMin(&st[ST_MIN_FLD], fmn);
+      atomicMax(&st[ST_MAX_FLD], fmx);
+    }
+  }
+}
+
+__global__ void k_narrow(int64_t n, const int64_t* __restrict__ raw, int64_t off, int32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (int32_t)(raw[i] - off);
+}
+
+static inline unsigned grid_for(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > 256 * 64) b = 256 * 64;
+  return (unsigned)b;
+}
+
+// positions of character c in t[0, len) -> out[0, expect)
+static int select_positions(nfm_ctx* ctx, const char* t, int64_t len, char c, int64_t* out, int64_t expect) {
+  hipStream_t st = ctx->stream;
+  DevBuf tmp, nsel;
+  NFM_TRY(nsel.alloc(sizeof(int64_t)));
+  int64_t done = 0;
+  const int64_t chunk = (int64_t)1 << 30;
+  for (int64_t base = 0; base < len; base += chunk) {
+    const int items = (int)std::min<int64_t>(chunk, len - base);
+    hipcub::CountingInputIterator<int64_t> it(base);
+    size_t bytes = 0;
+    NFM_HIP_CHECK(hipcub::DeviceSelect::If(nullptr, bytes, it, out + done, nsel.as<int64_t>(), items, IsChar{t, c}, st));
+    NFM_TRY(tmp.ensure(bytes));
+    NFM_HIP_CHECK(hipcub::DeviceSelect::If(tmp.p, bytes, it, out + done, nsel.as<int64_t>(), items, IsChar{t, c}, st));
+    int64_t got = 0;
+    NFM_HIP_CHECK(hipMemcpyAsync(&got, nsel.p, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+    done += got;
+  }
+  NFM_CHECK(done == expect, NFM_ERR_HIP, "ingest: position list has %lld entries, expected %lld", (long long)done, (long long)expect);
+  return NFM_OK;
+}
+
+// file -> device bytes through two pinned buffers (read of chunk c+1 overlaps the copy of chunk c)
+static int upload_file(nfm_ctx* ctx, const char* path, DevBuf* text, int64_t* len_out) {
+  FILE* f = fopen(path, "rb");
+  NFM_CHECK(f, NFM_ERR_INVALID, "%s cannot be read.", path);
+  fseeko(f, 0, SEEK_END);
+  const int64_t len = (int64_t)ftello(f);
+  fseeko(f, 0, SEEK_SET);
+  int rc = text->alloc((size_t)len + 64);
+  if (rc != NFM_OK) { fclose(f); return rc; }
+  const size_t chunk = (size_t)64 << 20;
+  void* pin[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipError_t herr = hipSuccess;
+  for (int i = 0; i < 2 && herr == hipSuccess; ++i) {
+    herr = hipHostMalloc(&pin[i], chunk, hipHostMallocDefault);
+    if (herr == hipSuccess) herr = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+  }
+  int64_t off = 0;
+  int which = 0;
+  bool used[2] = {false, false};
+  while (herr == hipSuccess && off < len) {
+    if (used[which]) herr = hipEventSynchronize(ev[which]);
+    if (herr != hipSuccess) break;
+    const size_t want = (size_t)std::min<int64_t>((int64_t)chunk, len - off);
+    const size_t got = fread(pin[which], 1, want, f);
+    if (got != want) { rc = set_error(NFM_ERR_INVALID, "%s: short read", path); break; }
+    herr = hipMemcpyAsync(text->as<char>() + off, pin[which], got, hipMemcpyHostToDevice, ctx->stream);
+    if (herr == hipSuccess) herr = hipEventRecord(ev[which], ctx->stream);
+    used[which] = true;
+    off += (int64_t)got;
+    which ^= 1;
+  }
+  if (herr == hipSuccess) herr = hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 2; ++i) {
+    if (ev[i]) (void)hipEventDestroy(ev[i]);
+    if (pin[i]) (void)hipHostFree(pin[i]);
+  }
+  fclose(f);
+  if (rc != NFM_OK) return rc;
+  if (herr != hipSuccess) return set_error(NFM_ERR_HIP, "ingest upload: %s", hipGetErrorString(herr));
+  *len_out = len;
+  return NFM_OK;
+}
+
+int ingest_text(nfm_ctx* ctx, const char* path, const char* mem, int64_t mem_len, bool with_fields, IngestResult* out) {
+  hipStream_t st = ctx->stream;
+  hipEvent_t e0, e1, e2;
+  NFM_HIP_CHECK(hipEventCreate(&e0));
+  NFM_HIP_CHECK(hipEventCreate(&e1));
+  NFM_HIP_CHECK(hipEventCreate(&e2));
+  struct EvGuard {
+    hipEvent_t a, b, c;
+    ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); }
+  } guard{e0, e1, e2};
+  NFM_HIP_CHECK(hipEventRecord(e0, st));
+  DevBuf text;
+  int64_t len = 0;
+  if (path) {
+    NFM_TRY(upload_file(ctx, path, &text, &len));
+  } else {
+    NFM_CHECK(mem || mem_len == 0, NFM_ERR_INVALID, "null text");
+    len = mem_len;
+    NFM_TRY(text.alloc((size_t)len + 64));
+    if (len) NFM_HIP_CHECK(hipMemcpyAsync(text.p, mem, (size_t)len, hipMemcpyHostToDevice, st));
+  }
+  NFM_HIP_CHECK(hipEventRecord(e1, st));
+  const char* t = text.as<char>();
+  const int cpe = with_fields ? 2 : 1;
+  // 1. counts and positions
+  DevBuf cnt, table, status, fix;
+  NFM_TRY(cnt.alloc(2 * sizeof(unsigned long long)));
+  NFM_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 2 * sizeof(unsigned long long), st));
+  if (len) hipLaunchKernelGGL(k_count_chars, dim3(grid_for(len)), dim3(kBlock), 0, st, t, len, cnt.as<unsigned long long>());
+  unsigned long long h_cnt[2] = {0, 0};
+  NFM_HIP_CHECK(hipMemcpyAsync(h_cnt, cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
+  char last = '\n';
+  if (len) NFM_HIP_CHECK(hipMemcpyAsync(&last, t + len - 1, 1, hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  const int64_t n_nl = (int64_t)h_cnt[0], n_co = (int64_t)h_cnt[1];
+  const int64_t n_lines = n_nl + ((len > 0 && last != '\n') ? 1 : 0);  // Nim's `lines`: no empty line after a final "\n"
+  NFM_CHECK(n_co % cpe == 0, NFM_ERR_INVALID, "malformed file: %lld ':' do not form %s entries", (long long)n_co,
+            with_fields ? "field:index:value" : "index:value");
+  const int64_t n_ent = n_co / cpe;
+  DevBuf nl, co;
+  NFM_TRY(nl.alloc(sizeof(int64_t) * std::max<int64_t>(n_nl, 1)));
+  NFM_TRY(co.alloc(sizeof(int64_t) * std::max<int64_t>(n_co, 1)));
+  if (n_nl) NFM_TRY(select_positions(ctx, t, len, '\n', nl.as<int64_t>(), n_nl));
+  if (n_co) NFM_TRY(select_positions(ctx, t, len, ':', co.as<int64_t>(), n_co));
+  // 2. lines, 3. entries
+  NFM_TRY(table.alloc(sizeof(Pow5) * kPow5N));
+  NFM_HIP_CHECK(hipMemcpyAsync(table.p, kPow5Host, sizeof(Pow5) * kPow5N, hipMemcpyHostToDevice, st));
+  long long h_st[ST_COUNT];
+  for (int i = 0; i < ST_COUNT; ++i) h_st[i] = 0;
+  h_st[ST_MIN_IDX] = h_st[ST_MIN_FLD] = h_st[ST_FIRST_BAD] = INT64_MAX;
+  h_st[ST_MAX_IDX] = h_st[ST_MAX_FLD] = INT64_MIN;
+  NFM_TRY(status.alloc(sizeof(h_st)));
+  NFM_HIP_CHECK(hipMemcpyAsync(status.p, h_st, sizeof(h_st), hipMemcpyHostToDevice, st));
+  NFM_TRY(fix.alloc(sizeof(FixRec) * kMaxFix));
+  DevBuf y_missing, idx_raw, fld_raw;
+  NFM_TRY(out->indptr.alloc(sizeof(int64_t) * (n_lines + 1)));
+  NFM_TRY(out->y.alloc(sizeof(double) * std::max<int64_t>(n_lines, 1)));
+  NFM_TRY(y_missing.alloc((size_t)std::max<int64_t>(n_lines, 1)));
+  NFM_TRY(out->data.alloc(sizeof(double) * std::max<int64_t>(n_ent, 1)));
+  NFM_TRY(idx_raw.alloc(sizeof(int64_t) * std::max<int64_t>(n_ent, 1)));
+  if (with_fields) NFM_TRY(fld_raw.alloc(sizeof(int64_t) * std::max<int64_t>(n_ent, 1)));
+  hipLaunchKernelGGL(k_lines, dim3(grid_for(n_lines + 1)), dim3(kBlock), 0, st, t, len, nl.as<int64_t>(), n_nl, n_lines,
+                     co.as<int64_t>(), n_co, cpe, table.as<Pow5>(), out->indptr.as<int64_t>(), out->y.as<double>(),
+                     y_missing.as<uint8_t>(), status.as<long long>(), fix.as<FixRec>());
+  if (n_ent)
+    hipLaunchKernelGGL(k_entries, dim3(grid_for(n_ent)), dim3(kBlock), 0, st, t, len, co.as<int64_t>(), n_ent, cpe,
+                       table.as<Pow5>(), idx_raw.as<int64_t>(), fld_raw.as<int64_t>(), out->data.as<double>(),
+                       status.as<long long>(), fix.as<FixRec>());
+  NFM_HIP_CHECK(hipGetLastError());
+  NFM_HIP_CHECK(hipMemcpyAsync(h_st, status.p, sizeof(h_st), hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  NFM_CHECK(h_st[ST_MALFORMED] == 0, NFM_ERR_INVALID, "malformed %s text: %lld bad tokens, first near byte %lld",
+            with_fields ? "libffm" : "svmlight", h_st[ST_MALFORMED], h_st[ST_FIRST_BAD]);
+  // offsets and shapes (dataset.nim:586-590, 729-734)
+  long long min_idx = 1, max_idx = 0, min_fld = 1, max_fld = 1;  // the reference's initial values
+  if (n_ent) {
+    min_idx = std::min<long long>(min_idx, h_st[ST_MIN_IDX]);
+    max_idx = std::max<long long>(max_idx, h_st[ST_MAX_IDX]);
+    if (with_fields) {
+      min_fld = std::min<long long>(min_fld, h_st[ST_MIN_FLD]);
+      max_fld = std::max<long long>(max_fld, h_st[ST_MAX_FLD]);
+    }
+  }
+  NFM_CHECK(min_idx >= 0, NFM_ERR_INVALID, "Negative index is included.");
+  NFM_CHECK(!with_fields || min_fld >= 0, NFM_ERR_INVALID, "Negative field index is included.");
+  out->offset = min_idx == 0 ? 0 : 1;
+  out->d = max_idx + 1 - out->offset;
+  out->offset_field = min_fld == 0 ? 0 : 1;
+  out->n_fields = with_fields ? max_fld + 1 - out->offset_field : 0;
+  NFM_CHECK(out->d < (int64_t)2147483647 - 64, NFM_ERR_UNSUPPORTED, "feature index %lld does not fit int32", max_idx);
+  out->n = n_lines;
+  out->nnz = n_ent;
+  out->max_row = (int)h_st[ST_MAX_ROW];
+  // 4. narrow with the offsets applied
+  NFM_TRY(out->indices.alloc(sizeof(int32_t) * std::max<int64_t>(n_ent, 1)));
+  if (n_ent) hipLaunchKernelGGL(k_narrow, dim3(grid_for(n_ent)), dim3(kBlock), 0, st, n_ent, idx_raw.as<int64_t>(), out->offset,
+                                out->indices.as<int32_t>());
+  if (with_fields) {
+    NFM_TRY(out->fields.alloc(sizeof(int32_t) * std::max<int64_t>(n_ent, 1)));
+    if (n_ent) hipLaunchKernelGGL(k_narrow, dim3(grid_for(n_ent)), dim3(kBlock), 0, st, n_ent, fld_raw.as<int64_t>(),
+                                  out->offset_field, out->fields.as<int32_t>());
+  }
+  // tokens for strtod (rare): re-read from the device text
+  if (h_st[ST_STRTOD] > 0) {
+    NFM_CHECK(h_st[ST_STRTOD] <= kMaxFix, NFM_ERR_UNSUPPORTED, "%lld tokens with more than 19 significant digits", h_st[ST_STRTOD]);
+    std::vector<FixRec> fx((size_t)h_st[ST_STRTOD]);
+    NFM_HIP_CHECK(hipMemcpyAsync(fx.data(), fix.p, sizeof(FixRec) * fx.size(), hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+    char buf[512];
+    for (const FixRec& r : fx) {
+      const size_t take = (size_t)std::min<int64_t>((int64_t)sizeof(buf) - 1, len - r.pos);
+      NFM_HIP_CHECK(hipMemcpy(buf, t + r.pos, take, hipMemcpyDeviceToHost));
+      buf[take] = 0;
+      for (size_t k = 0; k < take; ++k)
+        if (buf[k] == ' ' || buf[k] == '\t' || buf[k] == '\n' || buf[k] == '\r' || buf[k] == ':') { buf[k] = 0; break; }
+      const double v = strtod(buf, nullptr);
+      double* dst = r.kind == 0 ? out->data.as<double>() + r.slot : out->y.as<double>() + r.slot;
+      NFM_HIP_CHECK(hipMemcpy(dst, &v, sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
+  // empty lines: parseFloat reads nothing and `target` keeps the previous line's value (dataset.nim:574,602)
+  if (h_st[ST_NO_TARGET] > 0) {
+    std::vector<double> yh((size_t)n_lines);
+    std::vector<uint8_t> miss((size_t)n_lines);
+    NFM_HIP_CHECK(hipMemcpyAsync(yh.data(), out->y.p, sizeof(double) * n_lines, hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipMemcpyAsync(miss.data(), y_missing.p, (size_t)n_lines, hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+    double prev = 0.0;
+    for (int64_t i = 0; i < n_lines; ++i) {
+      if (miss[i]) yh[i] = prev;
+      prev = yh[i];
+    }
+    NFM_HIP_CHECK(hipMemcpyAsync(out->y.p, yh.data(), sizeof(double) * n_lines, hipMemcpyHostToDevice, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  NFM_HIP_CHECK(hipEventRecord(e2, st));
+  NFM_HIP_CHECK(hipEventSynchronize(e2));
+  float ms_up = 0, ms_parse = 0;
+  NFM_HIP_CHECK(hipEventElapsedTime(&ms_up, e0, e1));
+  NFM_HIP_CHECK(hipEventElapsedTime(&ms_parse, e1, e2));
+  out->bytes = len;
+  out->upload_ms = ms_up;
+  out->parse_ms = ms_parse;
+  return NFM_OK;
+}
+
+}  // namespace nfm

@@ -18,6 +18,7 @@ The reference is Nim and no Nim toolchain exists in the build image, so this Pyt
 executable stand-in for that shim (and what bench.py / torch.distributed drive).
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -113,6 +114,35 @@ class CSRDataset:
         ds = cls(nSamples=n, nFeatures=d, nFields=nFields, ctx=ctx, _handle=h, _keep=keep)
         ds.nnz = nnz
         return ds
+
+    @classmethod
+    def _from_loader(cls, ctx, h):
+        n, d, nnz, nf = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        capi.check(capi.lib().nfm_dataset_shape(h, C.byref(n), C.byref(d), C.byref(nnz), C.byref(nf)))
+        ds = cls(nSamples=n.value, nFeatures=d.value, nFields=nf.value, ctx=ctx, _handle=h)
+        ds.nnz = nnz.value
+        return ds
+
+    def targets(self):
+        """the targets stored with the dataset (the loaders' y)"""
+        y = np.zeros(self.nSamples)
+        capi.check(capi.lib().nfm_dataset_get_targets(self.h, _vp(y)))
+        return y
+
+    def to_host(self):
+        """(indptr, indices, data, fields or None) in the reference's widths (tensor/sparse.nim:9-12, 19-24)"""
+        indptr = np.zeros(self.nSamples + 1, dtype=np.int64)
+        indices = np.zeros(self.nnz, dtype=np.int64)
+        data = np.zeros(self.nnz)
+        fields = np.zeros(self.nnz, dtype=np.int64) if self.nFields else None
+        capi.check(capi.lib().nfm_dataset_get_csr(self.h, _vp(indptr), _vp(indices), _vp(data), _vp(fields)))
+        return indptr, indices, data, fields
+
+    def ingest_stats(self):
+        """(bytes of text, upload ms, parse ms) of the loader that built this dataset"""
+        b, u, p = C.c_int64(), C.c_double(), C.c_double()
+        capi.check(capi.lib().nfm_dataset_ingest_stats(self.h, C.byref(b), C.byref(u), C.byref(p)))
+        return b.value, u.value, p.value
 
     @property
     def nFeatures(self):
@@ -415,6 +445,40 @@ def newFactorizationMachine(task, degree=2, nComponents=30, fitLower="explicit",
 def newFieldAwareFactorizationMachine(task, nComponents=10, fitIntercept=True, fitLinear=True, warmStart=False,
                                       randomState=1, scale=0.01):
     return FieldAwareFactorizationMachine(task, nComponents, fitIntercept, fitLinear, warmStart, randomState, scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# loaders (dataset.nim:616-632, 768-790): text parsed on the GPU, the dataset stays in HBM
+# ------------------------------------------------------------------------------------------------
+def loadSVMLightFile(f, nFeatures=-1, ctx=None):
+    """-> (CSRDataset, y).  The reference fills `var dataset` / `var y` (dataset.nim:616-617)."""
+    ctx = ctx or default_context()
+    h = C.c_void_p()
+    capi.check(capi.lib().nfm_dataset_load_svmlight(ctx.h, os.path.expanduser(f).encode(), int(nFeatures), C.byref(h)))
+    ds = CSRDataset._from_loader(ctx, h)
+    return ds, ds.targets()
+
+
+def loadFFMFile(f, nFeatures=-1, nFields=-1, ctx=None):
+    """-> (CSRFieldDataset, y) (dataset.nim:768-790)."""
+    ctx = ctx or default_context()
+    h = C.c_void_p()
+    capi.check(capi.lib().nfm_dataset_load_ffm(ctx.h, os.path.expanduser(f).encode(), int(nFeatures), int(nFields),
+                                               C.byref(h)))
+    ds = CSRDataset._from_loader(ctx, h)
+    return ds, ds.targets()
+
+
+def parseText(text, withFields=False, nFeatures=-1, nFields=-1, ctx=None):
+    """the loaders on an in-memory buffer (bytes)"""
+    ctx = ctx or default_context()
+    if isinstance(text, str):
+        text = text.encode()
+    h = C.c_void_p()
+    capi.check(capi.lib().nfm_dataset_parse_text(ctx.h, text, len(text), int(bool(withFields)), int(nFeatures),
+                                                 int(nFields), C.byref(h)))
+    ds = CSRDataset._from_loader(ctx, h)
+    return ds, ds.targets()
 
 
 # ------------------------------------------------------------------------------------------------

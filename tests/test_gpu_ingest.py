@@ -1,0 +1,138 @@
+"""-m gpu: svmlight / libffm text parsed on the GPU (ingest.hip, through nfm_dataset_load_* /
+nfm_dataset_parse_text) against the CPU restatement of the reference's loaders (oracle/ingest.py <-
+dataset.nim:562-632, 696-790): committed fixtures, the reference's dump -> load round trip
+(tests/test_dataset.nim), edge cases, error behaviour, and a file large enough to time."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import nimfm_amd as nf
+from oracle import ingest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FILES = ["ingest_svm_1based.txt", "ingest_svm_0based.txt", "ingest_svm_digits.txt", "ingest_ffm_1based.txt",
+         "ingest_ffm_0based.txt"]
+
+
+def same(ds, y, r, with_fields):
+    indptr, indices, data, fields = ds.to_host()
+    assert ds.nSamples == len(r["y"]) and ds.nFeatures == r["n_features"]
+    assert np.array_equal(indptr, r["indptr"]) and np.array_equal(indices, r["indices"])
+    assert np.array_equal(data.view(np.uint64), r["data"].view(np.uint64))  # bit for bit
+    assert np.array_equal(y.view(np.uint64), r["y"].view(np.uint64))
+    if with_fields:
+        assert ds.nFields == r["n_fields"] and np.array_equal(fields, r["fields"])
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_fixtures_from_file(name):
+    path = os.path.join(GOLD, name)
+    with open(path, newline="") as f:
+        text = f.read()
+    ffm = "ffm" in name
+    ds, y = nf.loadFFMFile(path) if ffm else nf.loadSVMLightFile(path)
+    same(ds, y, ingest.load_ffm(text) if ffm else ingest.load_svmlight(text), ffm)
+    g = np.load(os.path.join(GOLD, "ingest_golden.npz"))
+    assert np.array_equal(ds.to_host()[1], g[name + ":indices"])
+
+
+def random_csr_text(rng, n, d, density, ffm=False, n_fields=4, wide=True):
+    mask = rng.random((n, d)) < density
+    mask[0, 0] = mask[n - 1, d - 1] = True
+    rows, cols = np.nonzero(mask)
+    data = rng.uniform(-1, 1, size=len(rows))
+    if wide:  # many decades, so that the exponent forms of repr() are exercised
+        data = data * 10.0 ** rng.integers(-8, 8, size=len(rows))
+    indptr = np.concatenate([[0], np.cumsum(mask.sum(1))])
+    y = rng.standard_normal(n)
+    if ffm:
+        fields = cols % n_fields
+        return ingest.dump_ffm(indptr, cols, fields, data, y)
+    return ingest.dump_svmlight(indptr, cols, data, y)
+
+
+@pytest.mark.parametrize("ffm", [False, True])
+def test_dump_then_load_round_trip(ffm, tmp_path):
+    rng = np.random.default_rng(3)
+    text = random_csr_text(rng, 300, 120, 0.2, ffm)
+    r = ingest.load_ffm(text) if ffm else ingest.load_svmlight(text)
+    ds, y = nf.parseText(text, withFields=ffm)
+    same(ds, y, r, ffm)
+    p = tmp_path / "data.txt"
+    p.write_text(text + "\n")  # with a final newline: same samples (Nim's `lines`)
+    ds2, y2 = nf.loadFFMFile(str(p)) if ffm else nf.loadSVMLightFile(str(p))
+    same(ds2, y2, r, ffm)
+
+
+def test_edge_cases():
+    for text in ["", "\n", "1.5", "1.5\n", "2 1:1\n\n\n3 2:2", "1 1:1\t2:2\r\n0 3:3\r\n", "-0.0 7:-0.0", "nan 1:inf 2:-inf"]:
+        r = ingest.load_svmlight(text)
+        ds, y = nf.parseText(text)
+        assert ds.nSamples == len(r["y"]), repr(text)
+        indptr, indices, data, _ = ds.to_host()
+        assert np.array_equal(indptr, r["indptr"]) and np.array_equal(indices, r["indices"]), repr(text)
+        assert np.array_equal(data.view(np.uint64), r["data"].view(np.uint64)), repr(text)
+        assert np.array_equal(np.isnan(y), np.isnan(r["y"])) and np.array_equal(y[~np.isnan(y)], r["y"][~np.isnan(y)]), repr(text)
+    # nFeatures given: larger wins, smaller is the reference's ValueError
+    ds, _ = nf.parseText("1 1:0.5 5:1", nFeatures=9)
+    assert ds.nFeatures == 9
+    with pytest.raises(ValueError, match="nFeatures is 3"):
+        nf.parseText("1 1:0.5 5:1", nFeatures=3)
+    with pytest.raises(ValueError, match="Negative index"):
+        nf.parseText("1 -1:0.5 2:1")
+    with pytest.raises(ValueError, match="nFields is 1"):
+        nf.parseText("1 1:1:0.5 3:5:1", withFields=True, nFields=1)
+    # text the reference would mis-read silently is an error here
+    for bad in ["1 1:0.5 2", "1 1:0.5junk", "1 a:0.5", "1 1:1:0.5", "1 1:", "x 1:2"]:
+        with pytest.raises(ValueError):
+            nf.parseText(bad)
+    with pytest.raises(ValueError):
+        nf.parseText("1 1:0.5", withFields=True)
+    with pytest.raises(ValueError, match="cannot be read"):
+        nf.loadSVMLightFile("/nonexistent/file.svm")
+
+
+def test_loaded_dataset_trains_like_the_host_built_one(tmp_path):
+    rng = np.random.default_rng(5)
+    n, d, k = 400, 64, 8
+    text = random_csr_text(rng, n, d, 0.15, wide=False)
+    p = tmp_path / "train.svm"
+    p.write_text(text)
+    X, y = nf.loadSVMLightFile(str(p))
+    r = ingest.load_svmlight(text)
+    Xh = nf.newCSRDataset(data=r["data"], indices=r["indices"], indptr=r["indptr"], nSamples=n, nFeatures=d)
+    outs = []
+    for ds in (X, Xh):
+        fm = nf.newFactorizationMachine("regression", nComponents=k, randomState=1)
+        nf.newSGD(maxIter=3, verbose=0, tol=0, shuffle=False).fit(ds, y, fm)
+        outs.append((fm.P.copy(), fm.w.copy(), fm.intercept))
+    assert np.all(np.isfinite(outs[0][0]))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+
+
+def test_larger_file_and_throughput(tmp_path, capsys):
+    rng = np.random.default_rng(9)
+    n, d, m = 200_000, 100_000, 32
+    idx = np.sort(rng.integers(0, d, size=(n, m)), axis=1)
+    idx[:, 1:] += (idx[:, 1:] <= idx[:, :-1]) * 0  # duplicates inside a row do not matter to the loader
+    idx[0, 0], idx[-1, -1] = 0, d - 1
+    val = rng.uniform(-1, 1, size=(n, m))
+    y = np.sign(rng.standard_normal(n))
+    p = tmp_path / "big.svm"
+    with open(p, "w") as f:
+        for i in range(n):
+            f.write(repr(float(y[i])) + " " + " ".join("%d:%r" % (idx[i, q] + 1, float(val[i, q])) for q in range(m)) + "\n")
+    t0 = time.perf_counter()
+    ds, yg = nf.loadSVMLightFile(str(p))
+    wall = time.perf_counter() - t0
+    indptr, indices, data, _ = ds.to_host()
+    assert ds.nSamples == n and ds.nFeatures == d
+    assert np.array_equal(indptr, np.arange(n + 1) * m) and np.array_equal(indices, idx.ravel())
+    assert np.array_equal(data, val.ravel()) and np.array_equal(yg, y)
+    nbytes, up_ms, parse_ms = ds.ingest_stats()
+    with capsys.disabled():
+        print("\n[ingest] %.1f MB text: read+upload %.1f ms, GPU parse %.1f ms (%.1f GB/s), wall %.2f s"
+              % (nbytes / 1e6, up_ms, parse_ms, nbytes / parse_ms / 1e6, wall))

@@ -1,0 +1,64 @@
+"""CPU: the restatement of the reference's text loaders (oracle/ingest.py <- dataset.nim:562-632, 696-790)
+against the committed fixtures (tests/golden/ingest_*.txt + ingest_golden.npz) and the reference's own
+test shape -- dump, load, compare (tests/test_dataset.nim) -- plus its error behaviour."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ingest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FILES = ["ingest_svm_1based.txt", "ingest_svm_0based.txt", "ingest_svm_digits.txt", "ingest_ffm_1based.txt",
+         "ingest_ffm_0based.txt"]
+
+
+def read(name):
+    with open(os.path.join(GOLD, name), newline="") as f:
+        return f.read()
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_oracle_matches_fixtures(name):
+    g = np.load(os.path.join(GOLD, "ingest_golden.npz"))
+    r = ingest.load_ffm(read(name)) if "ffm" in name else ingest.load_svmlight(read(name))
+    for k, v in r.items():
+        want = g[name + ":" + k]
+        assert np.array_equal(np.asarray(v), want, equal_nan=True), (name, k)
+
+
+def test_hand_checked_values():
+    r = ingest.load_svmlight(read("ingest_svm_0based.txt"))
+    assert r["offset"] == 0 and r["n_features"] == 10
+    assert r["indptr"].tolist() == [0, 2, 5, 5, 6] and r["indices"].tolist() == [0, 4, 1, 2, 3, 9]
+    assert r["y"].tolist() == [3.0, -2.0, -2.0, 7.0]  # the empty line keeps the previous target
+    r = ingest.load_ffm(read("ingest_ffm_1based.txt"))
+    assert (r["offset"], r["offset_field"], r["n_features"], r["n_fields"]) == (1, 1, 8, 4)
+    assert r["fields"].tolist() == [0, 1, 3, 2, 0, 3] and r["indices"].tolist() == [0, 2, 6, 1, 0, 7]
+
+
+def test_round_trip_like_the_reference_test():
+    rng = np.random.default_rng(0)
+    n, d = 50, 30
+    dense = rng.uniform(-1, 1, size=(n, d)) * (rng.random((n, d)) < 0.3)
+    dense[:, 0][0] = 0.7  # column 0 present: 1-based dump starts at index 1
+    dense[-1, d - 1] = -0.3
+    indptr = np.concatenate([[0], np.cumsum((dense != 0).sum(1))])
+    rows, cols = np.nonzero(dense)
+    y = rng.standard_normal(n)
+    r = ingest.load_svmlight(ingest.dump_svmlight(indptr, cols, dense[rows, cols], y))
+    assert r["n_features"] == d and np.array_equal(r["indptr"], indptr) and np.array_equal(r["indices"], cols)
+    assert np.array_equal(r["data"], dense[rows, cols]) and np.array_equal(r["y"], y)
+    fields = cols // 10
+    r = ingest.load_ffm(ingest.dump_ffm(indptr, cols, fields, dense[rows, cols], y))
+    assert np.array_equal(r["fields"], fields) and r["n_fields"] == 3 and np.array_equal(r["data"], dense[rows, cols])
+
+
+def test_errors():
+    with pytest.raises(ValueError, match="Negative index"):
+        ingest.load_svmlight("1 -1:0.5 2:1")
+    with pytest.raises(ValueError, match="nFeatures is 3"):
+        ingest.load_svmlight("1 1:0.5 5:1", n_features=3)
+    assert ingest.load_svmlight("1 1:0.5 5:1", n_features=9)["n_features"] == 9
+    with pytest.raises(ValueError, match="nFields is 1"):
+        ingest.load_ffm("1 1:1:0.5 3:5:1", n_fields=1)
