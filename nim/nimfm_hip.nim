@@ -41,6 +41,10 @@ proc nfm_ctx_destroy(ctx: NfmCtx): int32
 proc nfm_dataset_create_csr(ctx: NfmCtx, n, d: int64, indptr, indices: ptr int64, data: ptr float64,
                             fields: ptr int64, nFields: int64, y: ptr float64, outp: ptr NfmDataset): int32
 proc nfm_dataset_set_targets(ds: NfmDataset, y: ptr float64): int32
+proc nfm_dataset_load_svmlight(ctx: NfmCtx, path: cstring, nFeatures: int64, outp: ptr NfmDataset): int32
+proc nfm_dataset_load_ffm(ctx: NfmCtx, path: cstring, nFeatures, nFields: int64, outp: ptr NfmDataset): int32
+proc nfm_dataset_shape(ds: NfmDataset, nSamples, nFeatures, nnz, nFields: ptr int64): int32
+proc nfm_dataset_get_targets(ds: NfmDataset, y: ptr float64): int32
 proc nfm_dataset_destroy(ds: NfmDataset): int32
 proc nfm_model_create(ctx: NfmCtx, cfg: ptr NfmModelCfg, outp: ptr NfmModel): int32
 proc nfm_model_set_params(m: NfmModel, P, w: ptr float64, intercept: float64, lams: ptr float64): int32

@@ -361,3 +361,22 @@ def ffm_adagrad_finalize(P, w, intercept, cfg, it, state):
                                     C.c_int64(it), *state.args())
     assert rc == 0
     return b.value
+
+
+def svmlight_load_c(text):
+    """nimfm_ingest.c (the C restatement of dataset.nim:562-613): -> dict like oracle.ingest.load_svmlight."""
+    if isinstance(text, str):
+        text = text.encode()
+    L = lib()
+    n, nnz, d, off = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    L.orc_svmlight_scan.restype = C.c_int
+    rc = L.orc_svmlight_scan(text, C.c_int64(len(text)), C.byref(n), C.byref(nnz), C.byref(d), C.byref(off))
+    if rc != 0:
+        raise ValueError("Negative index is included.")
+    indptr = np.zeros(n.value + 1, dtype=np.int64)
+    indices = np.zeros(nnz.value, dtype=np.int64)
+    data = np.zeros(nnz.value)
+    y = np.zeros(n.value)
+    L.orc_svmlight_fill.restype = None
+    L.orc_svmlight_fill(text, C.c_int64(len(text)), off, _p(indptr), _p(indices), _p(data), _p(y))
+    return dict(indptr=indptr, indices=indices, data=data, y=y, n_features=d.value, offset=off.value)

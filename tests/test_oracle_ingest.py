@@ -62,3 +62,23 @@ def test_errors():
     assert ingest.load_svmlight("1 1:0.5 5:1", n_features=9)["n_features"] == 9
     with pytest.raises(ValueError, match="nFields is 1"):
         ingest.load_ffm("1 1:1:0.5 3:5:1", n_fields=1)
+
+
+def test_c_restatement_matches_python_restatement():
+    """oracle/nimfm_ingest.c (the CPU baseline of tools/bench_ingest.py) == oracle/ingest.py"""
+    import oracle as O
+
+    rng = np.random.default_rng(4)
+    texts = [read(n) for n in FILES if "svm" in n]
+    n, d = 200, 90
+    dense = rng.uniform(-1, 1, size=(n, d)) * 10.0 ** rng.integers(-6, 6, size=(n, d)) * (rng.random((n, d)) < 0.2)
+    rows, cols = np.nonzero(dense)
+    indptr = np.concatenate([[0], np.cumsum((dense != 0).sum(1))])
+    texts.append(ingest.dump_svmlight(indptr, cols, dense[rows, cols], rng.standard_normal(n)))
+    texts += ["", "1.5\n", "2 1:1\n\n3 2:2"]
+    for t in texts:
+        a, b = ingest.load_svmlight(t), O.svmlight_load_c(t)
+        for k in ("indptr", "indices", "n_features", "offset"):
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (k, t[:40])
+        assert np.array_equal(a["data"].view(np.uint64), b["data"].view(np.uint64))
+        assert np.array_equal(a["y"].view(np.uint64), b["y"].view(np.uint64))
