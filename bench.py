@@ -218,9 +218,18 @@ def main():
             capi.check(capi.lib().nfm_decision_function_device(mh, X.h, out_dev.data_ptr()))
         ctx.synchronize()
         tp = (time.perf_counter() - tp) / reps_p
+        # score on the device (decisionFunction + reduction, only the scalar comes back)
+        sc = C.c_double()
+        capi.check(capi.lib().nfm_score(mh, X.h, C.byref(sc)))
+        ctx.synchronize()
+        ts = time.perf_counter()
+        for _ in range(5):
+            capi.check(capi.lib().nfm_score(mh, X.h, C.byref(sc)))
+        ts = (time.perf_counter() - ts) / 5
         pbytes = 12 * m + 8 + (F * 8 * m * k if F else n_orders * 8 * m * k) + 8 * m + 8  # SURVEY.md 8(d) predict bytes per sample
         pred = {"value": round(n / tp, 1), "unit": "samples/s", "ms": round(tp * 1e3, 4),
-                "roofline_frac": round(pbytes * n / tp / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": pbytes}
+                "roofline_frac": round(pbytes * n / tp / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": pbytes,
+                "score": {"value": round(n / ts, 1), "unit": "samples/s", "ms": round(ts * 1e3, 4), "result": sc.value}}
 
     # ---- roofline leg: per-kernel durations from HIP events on the library's stream ----
     roof = None

@@ -165,6 +165,13 @@ int32_t nfm_model_get_params(nfm_model* m, double* P, double* w, double* interce
  * nFields mismatch (:114-115, FFM :60-64).  out: n doubles. */
 int32_t nfm_decision_function(nfm_model* m, nfm_dataset* ds, double* out);
 int32_t nfm_decision_function_device(nfm_model* m, nfm_dataset* ds, double* out_dev);
+/* score (model/fm_base.nim:39-48): rmse for regression, accuracy of the signs for
+ * classification, of decisionFunction(ds) against the dataset's targets -- computed
+ * on the device, only the scalar comes back. */
+int32_t nfm_score(nfm_model* m, nfm_dataset* ds, double* out);
+/* metrics.nim:5-13 (rmse), :39-47 (accuracy of signs), :76-103 (rocauc, pos = 1) of
+ * decisionFunction(ds) against the dataset's targets; any pointer may be NULL. */
+int32_t nfm_metrics(nfm_model* m, nfm_dataset* ds, double* rmse, double* accuracy, double* rocauc);
 /* ||P||^2 and ||w||^2 for optimizer/utils.nim:56-59 `regularization` (verbose). */
 int32_t nfm_model_sqnorms(nfm_model* m, double* P_sq, double* w_sq);
 /* device views for the data-parallel exchange: pointers to

@@ -32,7 +32,7 @@ SYMBOLS = [
     "nfm_dataset_load_svmlight", "nfm_dataset_load_ffm", "nfm_dataset_parse_text", "nfm_dataset_shape",
     "nfm_dataset_ingest_stats", "nfm_dataset_get_targets", "nfm_dataset_get_csr",
     "nfm_model_create", "nfm_model_shape", "nfm_model_set_params", "nfm_model_get_params",
-    "nfm_decision_function", "nfm_decision_function_device", "nfm_model_sqnorms", "nfm_model_device_buffers",
+    "nfm_decision_function", "nfm_decision_function_device", "nfm_score", "nfm_metrics", "nfm_model_sqnorms", "nfm_model_device_buffers",
     "nfm_model_destroy",
     "nfm_sgd_create", "nfm_adagrad_create", "nfm_opt_set_it", "nfm_opt_get_it", "nfm_opt_get_state",
     "nfm_opt_set_state", "nfm_opt_epoch", "nfm_opt_finalize", "nfm_opt_device_state", "nfm_opt_destroy",
@@ -128,6 +128,8 @@ def lib():
         "nfm_decision_function": [vp, vp, vp],
         "nfm_decision_function_device": [vp, vp, vp],
         "nfm_model_sqnorms": [vp, C.POINTER(dbl), C.POINTER(dbl)],
+        "nfm_score": [vp, vp, C.POINTER(dbl)],
+        "nfm_metrics": [vp, vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)],
         "nfm_model_device_buffers": [vp, pp, C.POINTER(i64), pp, C.POINTER(i64), pp, C.POINTER(i64)],
         "nfm_model_destroy": [vp],
         "nfm_sgd_create": [vp, C.POINTER(SGDCfg), pp],

@@ -523,6 +523,24 @@ int32_t nfm_decision_function(nfm_model* m, nfm_dataset* ds, double* out) {
   return NFM_OK;
 }
 
+// score / metrics on the device: decisionFunction stays in HBM, only scalars come back
+int32_t nfm_metrics(nfm_model* m, nfm_dataset* ds, double* rmse, double* accuracy, double* rocauc) {
+  NFM_TRY(check_predict_shapes(m, ds));
+  NFM_CHECK(ds->has_y, NFM_ERR_INVALID, "the dataset has no targets");
+  NFM_TRY(use_device(m->ctx));
+  DevBuf scores;
+  NFM_TRY(scores.alloc(sizeof(double) * std::max<int64_t>(ds->v.n, 1)));
+  NFM_TRY(nfm_decision_function_device(m, ds, scores.as<double>()));
+  return launch_metrics(m->ctx, ds->v.n, scores.as<double>(), ds->v.y, rmse, accuracy, rocauc);
+}
+
+int32_t nfm_score(nfm_model* m, nfm_dataset* ds, double* out) {
+  NFM_CHECK(m && out, NFM_ERR_INVALID, "null argument");
+  // model/fm_base.nim:39-48: rmse for regression, accuracy (of signs) for classification
+  if (m->cfg.task == NFM_TASK_REGRESSION) return nfm_metrics(m, ds, out, nullptr, nullptr);
+  return nfm_metrics(m, ds, nullptr, out, nullptr);
+}
+
 int32_t nfm_model_sqnorms(nfm_model* m, double* P_sq, double* w_sq) {
   NFM_CHECK(m, NFM_ERR_INVALID, "null model");
   NFM_TRY(use_device(m->ctx));

@@ -179,5 +179,7 @@ int launch_narrow_i64_i32(nfm_ctx* ctx, const int64_t* src, int32_t* dst, int64_
 
 // ---- predict.hip ----
 int launch_predict(nfm_ctx* ctx, const CsrView& X, const ModelView& M, double* out_dev);
+int launch_metrics(nfm_ctx* ctx, int64_t n, const double* scores, const double* y, double* rmse, double* accuracy,
+                   double* rocauc);
 
 }  // namespace nfm

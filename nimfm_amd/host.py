@@ -300,11 +300,24 @@ class _ModelBase:
         return np.sign(y) if self.task == "classification" else y
 
     def score(self, X, y):
-        """model/fm_base.nim:39-48"""
-        yPred = self.decisionFunction(X)
-        if self.task == "regression":
-            return rmse(y, yPred)
-        return accuracy(np.sign(_f64(y)).astype(np.int64), np.sign(yPred).astype(np.int64))
+        """model/fm_base.nim:39-48: rmse (regression) or accuracy of the signs (classification) of
+        decisionFunction(X) against y -- reduced on the device, only the scalar comes back."""
+        self.checkInitialized()
+        self._check_shapes(X)
+        X.set_targets(_f64(y))
+        out = C.c_double()
+        capi.check(capi.lib().nfm_score(self._push(X.ctx), X.h, C.byref(out)))
+        return out.value
+
+    def metrics(self, X, y):
+        """rmse, accuracy (of signs) and rocauc (pos = 1) of decisionFunction(X) against y
+        (metrics.nim:5-13, 39-47, 76-103), computed on the device."""
+        self.checkInitialized()
+        self._check_shapes(X)
+        X.set_targets(_f64(y))
+        r, a, u = C.c_double(), C.c_double(), C.c_double()
+        capi.check(capi.lib().nfm_metrics(self._push(X.ctx), X.h, C.byref(r), C.byref(a), C.byref(u)))
+        return {"rmse": r.value, "accuracy": a.value, "rocauc": u.value}
 
 
 def _task_name(task):
