@@ -114,6 +114,19 @@ int32_t nfm_dataset_load_ffm(nfm_ctx* ctx, const char* path, int64_t n_features,
                              nfm_dataset** out);
 int32_t nfm_dataset_parse_text(nfm_ctx* ctx, const char* text, int64_t len, int32_t with_fields,
                                int64_t n_features, int64_t n_fields, nfm_dataset** out);
+/* The reference's binary out-of-core format (tensor/sparse_stream.nim:3-33;
+ * newStreamCSRDataset, dataset.nim:170-174): "STREAMCSR" | {nRows, nCols, nnz:
+ * int64; max, min: float64} | per row nnz: int64 + nnz x {val: float64, id:
+ * int64} ("STREAMCSRFIELD": + nFields, elements {field, val, id}).  The whole
+ * matrix is made resident in HBM (the reference streams row blocks through a
+ * host cache).  y_path: raw float64 labels (loadStreamLabel, dataset.nim:
+ * 1007-1014) or NULL.  A STREAMCSC file is NFM_ERR_UNSUPPORTED. */
+int32_t nfm_dataset_load_stream(nfm_ctx* ctx, const char* x_path, const char* y_path,
+                                nfm_dataset** out);
+/* convertSVMLightFile (dataset.nim:1017-1097): svmlight text -> STREAMCSR file +
+ * raw float64 label file; the text is parsed on the GPU. */
+int32_t nfm_convert_svmlight(nfm_ctx* ctx, const char* f_in, const char* f_out_x,
+                             const char* f_out_y);
 /* nSamples / nFeatures / nnz / nFields (dataset.nim:44-51, tensor/sparse.nim:26-40) */
 int32_t nfm_dataset_shape(const nfm_dataset* ds, int64_t* n_samples, int64_t* n_features,
                           int64_t* nnz, int64_t* n_fields);

@@ -29,7 +29,8 @@ SYMBOLS = [
     "nfm_ctx_create", "nfm_ctx_destroy", "nfm_ctx_synchronize",
     "nfm_ctx_timing_enable", "nfm_ctx_timing_reset", "nfm_ctx_timing_get",
     "nfm_dataset_create_csr", "nfm_dataset_create_csr_device", "nfm_dataset_set_targets", "nfm_dataset_destroy",
-    "nfm_dataset_load_svmlight", "nfm_dataset_load_ffm", "nfm_dataset_parse_text", "nfm_dataset_shape",
+    "nfm_dataset_load_svmlight", "nfm_dataset_load_ffm", "nfm_dataset_parse_text", "nfm_dataset_load_stream",
+    "nfm_convert_svmlight", "nfm_dataset_shape",
     "nfm_dataset_ingest_stats", "nfm_dataset_get_targets", "nfm_dataset_get_csr",
     "nfm_model_create", "nfm_model_shape", "nfm_model_set_params", "nfm_model_get_params",
     "nfm_decision_function", "nfm_decision_function_device", "nfm_score", "nfm_metrics", "nfm_model_sqnorms", "nfm_model_device_buffers",
@@ -117,6 +118,8 @@ def lib():
         "nfm_dataset_load_svmlight": [vp, C.c_char_p, i64, pp],
         "nfm_dataset_load_ffm": [vp, C.c_char_p, i64, i64, pp],
         "nfm_dataset_parse_text": [vp, C.c_char_p, i64, i32, i64, i64, pp],
+        "nfm_dataset_load_stream": [vp, C.c_char_p, C.c_char_p, pp],
+        "nfm_convert_svmlight": [vp, C.c_char_p, C.c_char_p, C.c_char_p],
         "nfm_dataset_shape": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
         "nfm_dataset_ingest_stats": [vp, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)],
         "nfm_dataset_get_targets": [vp, vp],

@@ -325,6 +325,20 @@ int32_t nfm_dataset_parse_text(nfm_ctx* ctx, const char* text, int64_t len, int3
   return dataset_from_ingest(ctx, r, with_fields != 0, n_features, n_fields, out);
 }
 
+int32_t nfm_dataset_load_stream(nfm_ctx* ctx, const char* x_path, const char* y_path, nfm_dataset** out) {
+  NFM_CHECK(ctx && x_path && out, NFM_ERR_INVALID, "null argument");
+  NFM_TRY(use_device(ctx));
+  IngestResult r;
+  NFM_TRY(ingest_stream(ctx, x_path, y_path, &r));
+  return dataset_from_ingest(ctx, r, r.n_fields > 0, -1, -1, out);
+}
+
+int32_t nfm_convert_svmlight(nfm_ctx* ctx, const char* f_in, const char* f_out_x, const char* f_out_y) {
+  NFM_CHECK(ctx && f_in && f_out_x && f_out_y, NFM_ERR_INVALID, "null argument");
+  NFM_TRY(use_device(ctx));
+  return convert_svmlight(ctx, f_in, f_out_x, f_out_y);
+}
+
 int32_t nfm_dataset_shape(const nfm_dataset* ds, int64_t* n_samples, int64_t* n_features, int64_t* nnz, int64_t* n_fields) {
   NFM_CHECK(ds, NFM_ERR_INVALID, "null dataset");
   if (n_samples) *n_samples = ds->v.n;

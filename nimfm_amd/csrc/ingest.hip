@@ -20,6 +20,7 @@
 // pair up) is an error here, while the reference would read garbage.
 #include <hipcub/hipcub.hpp>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -355,6 +356,8 @@ int ingest_text(nfm_ctx* ctx, const char* path, const char* mem, int64_t mem_len
   }
   NFM_CHECK(min_idx >= 0, NFM_ERR_INVALID, "Negative index is included.");
   NFM_CHECK(!with_fields || min_fld >= 0, NFM_ERR_INVALID, "Negative field index is included.");
+  out->min_index = min_idx;
+  out->max_index = max_idx;
   out->offset = min_idx == 0 ? 0 : 1;
   out->d = max_idx + 1 - out->offset;
   out->offset_field = min_fld == 0 ? 0 : 1;
@@ -413,6 +416,188 @@ int ingest_text(nfm_ctx* ctx, const char* path, const char* mem, int64_t mem_len
   out->bytes = len;
   out->upload_ms = ms_up;
   out->parse_ms = ms_parse;
+  return NFM_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// STREAMCSR binary files (the reference's out-of-core format, tensor/sparse_stream.nim:3-33):
+//   magic "STREAMCSR" (9 bytes) | header {nRows, nCols, nnz: int64; max, min: float64} |
+//   per row: nnz: int64, then nnz x {val: float64, id: int64}
+//   magic "STREAMCSRFIELD" (14 bytes) | header {nRows, nCols, nnz, nFields: int64; max, min} |
+//   per row: nnz: int64, then nnz x {field: int64, val: float64, id: int64}
+// The reference streams row blocks through a host cache (readCache, sgd_multi.nim:83-97); with 288 GB of
+// HBM the whole matrix is made resident instead.  Row starts depend on all earlier row lengths, so the
+// host walks the row headers once (8 bytes per row) for indptr; the (value, id) pairs are split on the GPU.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t load_i64_unaligned(const unsigned char* p) {
+  uint64_t v = 0;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) v |= (uint64_t)p[b] << (8 * b);
+  return (int64_t)v;
+}
+
+__global__ void k_stream_split(const unsigned char* __restrict__ raw, int64_t base, int esize, int with_fields, int64_t n_rows,
+                               const int64_t* __restrict__ indptr, int64_t nnz, int32_t* __restrict__ indices,
+                               double* __restrict__ data, int32_t* __restrict__ fields, long long* __restrict__ st) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = n_rows;  // row of entry e: last r with indptr[r] <= e
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (indptr[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    const unsigned char* p = raw + base + 8 * (lo + 1) + (int64_t)esize * e;
+    int64_t f = 0;
+    if (with_fields) {
+      f = load_i64_unaligned(p);
+      p += 8;
+    }
+    const int64_t vb = load_i64_unaligned(p), id = load_i64_unaligned(p + 8);
+    data[e] = __longlong_as_double(vb);
+    indices[e] = (int32_t)id;
+    if (with_fields) fields[e] = (int32_t)f;
+    if (id < 0 || id > 2147483000ll || f < 0 || f > 2147483000ll) atomicAdd((unsigned long long*)&st[ST_MALFORMED], 1ull);
+  }
+}
+
+static int read_whole(const char* path, std::vector<unsigned char>* buf) {
+  FILE* f = fopen(path, "rb");
+  NFM_CHECK(f, NFM_ERR_INVALID, "%s cannot be opened.", path);
+  fseeko(f, 0, SEEK_END);
+  const int64_t len = (int64_t)ftello(f);
+  fseeko(f, 0, SEEK_SET);
+  buf->resize((size_t)len);
+  const size_t got = len ? fread(buf->data(), 1, (size_t)len, f) : 0;
+  fclose(f);
+  NFM_CHECK((int64_t)got == len, NFM_ERR_INVALID, "%s: short read", path);
+  return NFM_OK;
+}
+
+int ingest_stream(nfm_ctx* ctx, const char* x_path, const char* y_path, IngestResult* out) {
+  hipStream_t st = ctx->stream;
+  std::vector<unsigned char> raw;
+  NFM_TRY(read_whole(x_path, &raw));
+  const int64_t len = (int64_t)raw.size();
+  bool with_fields = false;
+  int64_t base = 0;
+  if (len >= 14 && !memcmp(raw.data(), "STREAMCSRFIELD", 14)) {
+    with_fields = true;
+    base = 14 + 48;
+  } else if (len >= 9 && !memcmp(raw.data(), "STREAMCSR", 9)) {
+    base = 9 + 40;
+  } else if (len >= 9 && !memcmp(raw.data(), "STREAMCSC", 9)) {
+    return set_error(NFM_ERR_UNSUPPORTED, "%s is a column-major (STREAMCSC) file; the row-wise optimizers need STREAMCSR", x_path);
+  } else {
+    return set_error(NFM_ERR_INVALID, "%s is not a StreamCSR file.", x_path);
+  }
+  NFM_CHECK(len >= base, NFM_ERR_INVALID, "%s: truncated header", x_path);
+  int64_t hdr[4] = {0, 0, 0, 0};
+  memcpy(hdr, raw.data() + (with_fields ? 14 : 9), with_fields ? 32 : 24);
+  const int64_t n = hdr[0], d = hdr[1], nnz = hdr[2], nf = with_fields ? hdr[3] : 0;
+  NFM_CHECK(n >= 0 && d >= 0 && nnz >= 0 && d < (int64_t)2147483647 - 64, NFM_ERR_INVALID, "%s: bad header", x_path);
+  const int esize = with_fields ? 24 : 16;
+  std::vector<int64_t> indptr((size_t)n + 1);
+  int64_t pos = base, acc = 0, max_row = 0;
+  indptr[0] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    NFM_CHECK(pos + 8 <= len, NFM_ERR_INVALID, "%s: truncated at row %lld", x_path, (long long)i);
+    int64_t r;
+    memcpy(&r, raw.data() + pos, 8);
+    NFM_CHECK(r >= 0 && pos + 8 + r * esize <= len, NFM_ERR_INVALID, "%s: row %lld overruns the file", x_path, (long long)i);
+    pos += 8 + r * esize;
+    acc += r;
+    indptr[i + 1] = acc;
+    max_row = std::max(max_row, r);
+  }
+  NFM_CHECK(acc == nnz, NFM_ERR_INVALID, "%s: rows hold %lld entries, header says %lld", x_path, (long long)acc, (long long)nnz);
+  DevBuf dev_raw, status;
+  NFM_TRY(dev_raw.alloc((size_t)len + 64));
+  NFM_HIP_CHECK(hipMemcpyAsync(dev_raw.p, raw.data(), (size_t)len, hipMemcpyHostToDevice, st));
+  NFM_TRY(out->indptr.alloc(sizeof(int64_t) * (n + 1)));
+  NFM_HIP_CHECK(hipMemcpyAsync(out->indptr.p, indptr.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
+  NFM_TRY(out->indices.alloc(sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+  NFM_TRY(out->data.alloc(sizeof(double) * std::max<int64_t>(nnz, 1)));
+  if (with_fields) NFM_TRY(out->fields.alloc(sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+  long long h_st[ST_COUNT];
+  for (int i = 0; i < ST_COUNT; ++i) h_st[i] = 0;
+  NFM_TRY(status.alloc(sizeof(h_st)));
+  NFM_HIP_CHECK(hipMemcpyAsync(status.p, h_st, sizeof(h_st), hipMemcpyHostToDevice, st));
+  if (nnz)
+    hipLaunchKernelGGL(k_stream_split, dim3(grid_for(nnz)), dim3(kBlock), 0, st, dev_raw.as<unsigned char>(), base, esize,
+                       with_fields ? 1 : 0, n, out->indptr.as<int64_t>(), nnz, out->indices.as<int32_t>(),
+                       out->data.as<double>(), with_fields ? out->fields.as<int32_t>() : nullptr, status.as<long long>());
+  NFM_HIP_CHECK(hipGetLastError());
+  NFM_HIP_CHECK(hipMemcpyAsync(h_st, status.p, sizeof(h_st), hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  NFM_CHECK(h_st[ST_MALFORMED] == 0, NFM_ERR_INVALID, "%s: %lld entries with an id or field outside int32", x_path, h_st[ST_MALFORMED]);
+  NFM_TRY(out->y.alloc(sizeof(double) * std::max<int64_t>(n, 1)));
+  if (y_path) {  // loadStreamLabel (dataset.nim:1007-1014): raw float64, one per sample
+    std::vector<unsigned char> yraw;
+    NFM_TRY(read_whole(y_path, &yraw));
+    NFM_CHECK((int64_t)yraw.size() == 8 * n, NFM_ERR_INVALID, "%s holds %lld labels, the matrix has %lld rows", y_path,
+              (long long)(yraw.size() / 8), (long long)n);
+    if (n) NFM_HIP_CHECK(hipMemcpy(out->y.p, yraw.data(), (size_t)(8 * n), hipMemcpyHostToDevice));
+  } else {
+    NFM_HIP_CHECK(hipMemsetAsync(out->y.p, 0, sizeof(double) * std::max<int64_t>(n, 1), st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  out->n = n;
+  out->d = d;
+  out->nnz = nnz;
+  out->n_fields = nf;
+  out->max_row = (int)max_row;
+  out->bytes = len;
+  return NFM_OK;
+}
+
+int convert_svmlight(nfm_ctx* ctx, const char* f_in, const char* f_out_x, const char* f_out_y) {
+  IngestResult r;
+  NFM_TRY(ingest_text(ctx, f_in, nullptr, 0, false, &r));
+  hipStream_t st = ctx->stream;
+  std::vector<int64_t> indptr((size_t)r.n + 1);
+  std::vector<int32_t> idx((size_t)r.nnz);
+  std::vector<double> val((size_t)r.nnz), y((size_t)r.n);
+  NFM_HIP_CHECK(hipMemcpyAsync(indptr.data(), r.indptr.p, sizeof(int64_t) * (r.n + 1), hipMemcpyDeviceToHost, st));
+  if (r.nnz) {
+    NFM_HIP_CHECK(hipMemcpyAsync(idx.data(), r.indices.p, sizeof(int32_t) * r.nnz, hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipMemcpyAsync(val.data(), r.data.p, sizeof(double) * r.nnz, hipMemcpyDeviceToHost, st));
+  }
+  if (r.n) NFM_HIP_CHECK(hipMemcpyAsync(y.data(), r.y.p, sizeof(double) * r.n, hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  // dataset.nim:1021-1058: ids are shifted by the smallest index seen (NOT by the 0/1 base of the
+  // text loaders), nCols = maxIndex - minIndex + 1, the header carries the value range
+  const int64_t shift = r.min_index - r.offset;  // what is still to subtract from the loader's 0-based ids
+  double vmin = HUGE_VAL, vmax = -HUGE_VAL;  // Nim's high(float64) / low(float64) are +-Inf
+  for (double v : val) {
+    vmin = v < vmin ? v : vmin;  // min(minVal, val) / max(maxVal, val): a NaN never replaces the bound
+    vmax = v > vmax ? v : vmax;
+  }
+  FILE* fx = fopen(f_out_x, "wb");
+  NFM_CHECK(fx, NFM_ERR_INVALID, "%s cannot be read.", f_out_x);
+  FILE* fy = fopen(f_out_y, "wb");
+  if (!fy) {
+    fclose(fx);
+    return set_error(NFM_ERR_INVALID, "%s cannot be read.", f_out_y);
+  }
+  const int64_t hdr[3] = {r.n, r.max_index - r.min_index + 1, r.nnz};
+  const double mm[2] = {vmax, vmin};
+  bool ok = fwrite("STREAMCSR", 1, 9, fx) == 9 && fwrite(hdr, 8, 3, fx) == 3 && fwrite(mm, 8, 2, fx) == 2;
+  std::vector<unsigned char> row;
+  for (int64_t i = 0; ok && i < r.n; ++i) {
+    const int64_t a = indptr[i], b = indptr[i + 1], m = b - a;
+    row.resize((size_t)(8 + 16 * m));
+    memcpy(row.data(), &m, 8);
+    for (int64_t q = 0; q < m; ++q) {
+      const int64_t id = (int64_t)idx[a + q] - shift;
+      memcpy(row.data() + 8 + 16 * q, &val[a + q], 8);
+      memcpy(row.data() + 16 + 16 * q, &id, 8);
+    }
+    ok = fwrite(row.data(), 1, row.size(), fx) == row.size();
+  }
+  ok = ok && (r.n == 0 || fwrite(y.data(), 8, (size_t)r.n, fy) == (size_t)r.n);
+  fclose(fx);
+  fclose(fy);
+  NFM_CHECK(ok, NFM_ERR_INVALID, "write to %s / %s failed", f_out_x, f_out_y);
   return NFM_OK;
 }
 

@@ -482,6 +482,25 @@ def loadFFMFile(f, nFeatures=-1, nFields=-1, ctx=None):
     return ds, ds.targets()
 
 
+def newStreamCSRDataset(f, fY=None, ctx=None):
+    """dataset.nim:170-174 newStreamCSRDataset (+ loadStreamLabel, :1007-1014, when fY is given): the
+    STREAMCSR / STREAMCSRFIELD file is made resident in HBM instead of being streamed through a host cache.
+    -> (dataset, y)"""
+    ctx = ctx or default_context()
+    h = C.c_void_p()
+    capi.check(capi.lib().nfm_dataset_load_stream(ctx.h, os.path.expanduser(f).encode(),
+                                                  None if fY is None else os.path.expanduser(fY).encode(), C.byref(h)))
+    ds = CSRDataset._from_loader(ctx, h)
+    return ds, ds.targets()
+
+
+def convertSVMLightFile(fIn, fOutX, fOutY, ctx=None):
+    """dataset.nim:1017-1097: svmlight text -> STREAMCSR binary + raw float64 labels"""
+    ctx = ctx or default_context()
+    capi.check(capi.lib().nfm_convert_svmlight(ctx.h, os.path.expanduser(fIn).encode(), os.path.expanduser(fOutX).encode(),
+                                               os.path.expanduser(fOutY).encode()))
+
+
 def parseText(text, withFields=False, nFeatures=-1, nFields=-1, ctx=None):
     """the loaders on an in-memory buffer (bytes)"""
     ctx = ctx or default_context()

@@ -162,3 +162,103 @@ def dump_ffm(indptr, indices, fields, data, y):
             s += " %d:%d:%s" % (fields[q] + 1, indices[q] + 1, repr(float(data[q])))
         rows.append(s)
     return "\n".join(rows)
+
+
+# ---- the reference's binary out-of-core format (tensor/sparse_stream.nim:3-33) ----
+def convert_svmlight(text):
+    """convertSVMLightFile (dataset.nim:1017-1097) -> (bytes of the STREAMCSR file, bytes of the label file).
+    Ids are shifted by minIndex (initial 1, dataset.nim:1025), nCols = maxIndex - minIndex + 1, the
+    header carries max / min of the values (initial low/high(float64) = -Inf/+Inf)."""
+    import struct
+
+    lines = _lines(text)
+    min_index, max_index = 1, 0
+    min_val, max_val = float("inf"), float("-inf")
+    j, val, target = 0, 0.0, 0.0
+    n_samples = nnz = 0
+    for line in lines:
+        pos = 0
+        n_samples += 1
+        c, target = parse_float(line, pos, target)
+        pos += c + 1
+        while pos < len(line):
+            c, j = parse_int(line, pos, j)
+            pos += c
+            min_index, max_index = min(j, min_index), max(j, max_index)
+            pos += 1
+            c, val = parse_float(line, pos, val)
+            pos += c
+            min_val, max_val = min(min_val, val), max(max_val, val)
+            pos += 1
+            nnz += 1
+    if min_index < 0:
+        raise ValueError("Negative index is included.")
+    x = bytearray(b"STREAMCSR")
+    x += struct.pack("<qqqdd", n_samples, max_index - min_index + 1, nnz, max_val, min_val)
+    y = bytearray()
+    for line in lines:
+        pos = 0
+        c, target = parse_float(line, pos, target)
+        pos += c + 1
+        y += struct.pack("<d", target)
+        row = []
+        while pos < len(line):
+            c, j = parse_int(line, pos, j)
+            pos += c + 1
+            c, val = parse_float(line, pos, val)
+            pos += c + 1
+            row.append((val, j - min_index))
+        x += struct.pack("<q", len(row))
+        for v, i in row:
+            x += struct.pack("<dq", v, i)
+    return bytes(x), bytes(y)
+
+
+def read_stream(xbytes, ybytes=None):
+    """what newStreamCSRMatrix / newStreamCSRFieldMatrix + readCache deliver when the cache holds every row
+    (tensor/sparse_stream.nim:95-170, 200-260): header, then per row nnz and the elements."""
+    import struct
+
+    if xbytes[:14] == b"STREAMCSRFIELD":
+        n, d, nnz, nf, mx, mn = struct.unpack_from("<qqqqdd", xbytes, 14)
+        pos, fielded = 14 + 48, True
+    elif xbytes[:9] == b"STREAMCSR":
+        n, d, nnz, mx, mn = struct.unpack_from("<qqqdd", xbytes, 9)
+        nf, pos, fielded = 0, 9 + 40, False
+    else:
+        raise IOError("not a StreamCSR file.")
+    indptr, indices, data, fields = [0], [], [], []
+    for _ in range(n):
+        (r,) = struct.unpack_from("<q", xbytes, pos)
+        pos += 8
+        for _ in range(r):
+            if fielded:
+                f, v, i = struct.unpack_from("<qdq", xbytes, pos)
+                pos += 24
+                fields.append(f)
+            else:
+                v, i = struct.unpack_from("<dq", xbytes, pos)
+                pos += 16
+            data.append(v)
+            indices.append(i)
+        indptr.append(len(indices))
+    y = np.frombuffer(ybytes, dtype="<f8").copy() if ybytes is not None else np.zeros(n)
+    return dict(indptr=np.array(indptr, dtype=np.int64), indices=np.array(indices, dtype=np.int64),
+                data=np.array(data, dtype=np.float64), fields=np.array(fields, dtype=np.int64), y=y,
+                n_features=d, n_fields=nf, nnz=nnz, max=mx, min=mn)
+
+
+def write_stream_field(indptr, indices, fields, data, n_cols, n_fields):
+    """a STREAMCSRFIELD file as convertFFMFile lays it out (dataset.nim:1202-1299: magic, header
+    {nRows, nCols, nnz, nFields, max, min}, rows of {field, val, id})"""
+    import struct
+
+    n = len(indptr) - 1
+    x = bytearray(b"STREAMCSRFIELD")
+    x += struct.pack("<qqqqdd", n, n_cols, len(data), n_fields, float(np.max(data)) if len(data) else float("-inf"),
+                     float(np.min(data)) if len(data) else float("inf"))
+    for i in range(n):
+        x += struct.pack("<q", indptr[i + 1] - indptr[i])
+        for q in range(indptr[i], indptr[i + 1]):
+            x += struct.pack("<qdq", int(fields[q]), float(data[q]), int(indices[q]))
+    return bytes(x)

@@ -136,3 +136,40 @@ def test_larger_file_and_throughput(tmp_path, capsys):
     with capsys.disabled():
         print("\n[ingest] %.1f MB text: read+upload %.1f ms, GPU parse %.1f ms (%.1f GB/s), wall %.2f s"
               % (nbytes / 1e6, up_ms, parse_ms, nbytes / parse_ms / 1e6, wall))
+
+
+def test_stream_files(tmp_path):
+    """STREAMCSR / STREAMCSRFIELD files (tensor/sparse_stream.nim:3-33): written by the restatement of
+    convertSVMLightFile and by nfm_convert_svmlight, read back by nfm_dataset_load_stream"""
+    rng = np.random.default_rng(11)
+    text = random_csr_text(rng, 500, 200, 0.1)
+    src = tmp_path / "in.svm"
+    src.write_text(text)
+    xb, yb = ingest.convert_svmlight(text)
+    # the converter: byte-identical files
+    nf.convertSVMLightFile(str(src), str(tmp_path / "x.bin"), str(tmp_path / "y.bin"))
+    assert (tmp_path / "x.bin").read_bytes() == xb and (tmp_path / "y.bin").read_bytes() == yb
+    # the reader
+    ds, y = nf.newStreamCSRDataset(str(tmp_path / "x.bin"), str(tmp_path / "y.bin"))
+    same(ds, y, ingest.read_stream(xb, yb), False)
+    same(ds, y, ingest.load_svmlight(text), False)
+    ds0, y0 = nf.newStreamCSRDataset(str(tmp_path / "x.bin"))
+    assert np.array_equal(y0, np.zeros(ds0.nSamples))
+    # field variant
+    r = ingest.load_ffm(random_csr_text(rng, 300, 90, 0.15, ffm=True, n_fields=6))
+    fb = ingest.write_stream_field(r["indptr"], r["indices"], r["fields"], r["data"], r["n_features"], r["n_fields"])
+    (tmp_path / "f.bin").write_bytes(fb)
+    dsf, _ = nf.newStreamCSRDataset(str(tmp_path / "f.bin"))
+    indptr, indices, data, fields = dsf.to_host()
+    assert dsf.nFields == r["n_fields"] and np.array_equal(fields, r["fields"]) and np.array_equal(indices, r["indices"])
+    assert np.array_equal(indptr, r["indptr"]) and np.array_equal(data, r["data"])
+    # errors
+    (tmp_path / "bad.bin").write_bytes(b"STREAMCSC" + xb[9:])
+    with pytest.raises(nf.NfmError):
+        nf.newStreamCSRDataset(str(tmp_path / "bad.bin"))
+    (tmp_path / "trunc.bin").write_bytes(xb[:-5])
+    with pytest.raises(ValueError):
+        nf.newStreamCSRDataset(str(tmp_path / "trunc.bin"))
+    (tmp_path / "junk.bin").write_bytes(b"hello world, not a matrix")
+    with pytest.raises(ValueError, match="not a StreamCSR"):
+        nf.newStreamCSRDataset(str(tmp_path / "junk.bin"))

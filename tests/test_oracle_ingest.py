@@ -82,3 +82,16 @@ def test_c_restatement_matches_python_restatement():
             assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (k, t[:40])
         assert np.array_equal(a["data"].view(np.uint64), b["data"].view(np.uint64))
         assert np.array_equal(a["y"].view(np.uint64), b["y"].view(np.uint64))
+
+
+def test_stream_format_round_trip():
+    """convertSVMLightFile -> newStreamCSRDataset == loadSVMLightFile on the same text (ids shifted by the
+    smallest index = the loaders' 0/1 base), header fields as the reference writes them"""
+    for name in ("ingest_svm_1based.txt", "ingest_svm_0based.txt"):
+        text = read(name)
+        xb, yb = ingest.convert_svmlight(text)
+        assert xb[:9] == b"STREAMCSR" and len(yb) == 8 * len(ingest.load_svmlight(text)["y"])
+        a, b = ingest.load_svmlight(text), ingest.read_stream(xb, yb)
+        for k in ("indptr", "indices", "data", "y", "n_features"):
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (name, k)
+        assert b["max"] == a["data"].max() and b["min"] == a["data"].min() and b["nnz"] == len(a["data"])
