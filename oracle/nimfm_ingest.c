@@ -3,7 +3,7 @@
  * the file (/root/reference/src/nimfm/dataset.nim:562-613): parseFloat / parseInt return the number
  * of characters consumed (0: the variable keeps its value), one character is skipped after every
  * token.  strtod is correctly rounded like Nim's parseFloat.  Used as the CPU baseline of
- * tools/bench_ingest.py and checked against oracle/ingest.py in tests/test_oracle_ingest.py.
+ * bench.py --workload ingest and checked against oracle/ingest.py in tests/test_oracle_ingest.py.
  * Parity unpinned against reference-run outputs (no Nim toolchain here). */
 #include <stdint.h>
 #include <stdlib.h>

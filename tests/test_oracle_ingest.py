@@ -65,7 +65,7 @@ def test_errors():
 
 
 def test_c_restatement_matches_python_restatement():
-    """oracle/nimfm_ingest.c (the CPU baseline of tools/bench_ingest.py) == oracle/ingest.py"""
+    """oracle/nimfm_ingest.c (the CPU baseline of bench.py --workload ingest) == oracle/ingest.py"""
     import oracle as O
 
     rng = np.random.default_rng(4)
