@@ -887,22 +887,22 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
   double viol = 0.0;
   double2 stored = {0.0, 0.0}, g2 = {0.0, 0.0}, n2 = {0.0, 0.0}, p;
   if (OPT == OPT_SGD) {
-    stored = *reinterpret_cast<const double2*>(M.P + e);
+    stored = dev::ld_stream(M.P + e);
     p.x = sP * stored.x;
     p.y = sP * stored.y;
   } else {
-    g2 = *reinterpret_cast<const double2*>(O.G + e);
-    n2 = *reinterpret_cast<const double2*>(O.N + e);
+    g2 = dev::ld_stream(O.G + e);
+    n2 = dev::ld_stream(O.N + e);
     if (a.use_stored) {
-      p = *reinterpret_cast<const double2*>(M.P + e);
+      p = dev::ld_stream(M.P + e);
     } else {
       const double tmp = O.eta0 * ((a.it0p[0] + a.it_b) - 1.0) * O.beta;
       p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmp);
       p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmp);
       if (O.track_viol && MODE != 1) {  // adagrad.nim:96-99: sum |old - new| over the touched rows
-        stored = *reinterpret_cast<const double2*>(M.P + e);
+        stored = dev::ld_stream(M.P + e);
         viol += fabs(stored.x - p.x) + fabs(stored.y - p.y);
-        *reinterpret_cast<double2*>(M.P + e) = p;
+        dev::st_stream(M.P + e, p);
       }
     }
   }
@@ -1054,14 +1054,14 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
     viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
     stored.x = stored.x * fP - (acc.x / c) / sPn;
     stored.y = stored.y * fP - (acc.y / c) / sPn;
-    *reinterpret_cast<double2*>(M.P + e) = stored;
+    dev::st_stream(M.P + e, stored);
   } else {
     g2.x += acc.x;
     g2.y += acc.y;
     n2.x += accn.x;
     n2.y += accn.y;
-    *reinterpret_cast<double2*>(O.G + e) = g2;
-    *reinterpret_cast<double2*>(O.N + e) = n2;
+    dev::st_stream(O.G + e, g2);
+    dev::st_stream(O.N + e, n2);
   }
   return viol;
 }
