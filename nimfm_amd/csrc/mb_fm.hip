@@ -289,6 +289,8 @@ __device__ __forceinline__ double singles_update(const CsrView& X, const ModelVi
 //   MODE 2  MODE 1 + the parameter rows stay in registers between the forward pass and the update
 //           of the singles (SGD, one sample per wavefront, E = 1): HBM sees every row read once and
 //           the single-touch rows written once.
+//   MODE 3  MODE 1 for rows of any length: the row is taken in chunks of held_capacity entries (a
+//           separate instantiation: the chunk loop costs registers -- 38 vs 26 us on cfg2's row phase).
 template <int L, int SPLIT>
 constexpr int held_entries() {  // E: entries per lane; 0 = no held mode for this lane mapping
   constexpr int LPS = L * SPLIT;
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   constexpr int E = held_entries<L, SPLIT>() > 0 ? held_entries<L, SPLIT>() : 1;
   constexpr bool HELD = MODE >= 1 && !GEN && held_entries<L, SPLIT>() > 0;
   constexpr bool REG = MODE == 2 && HELD && OPT == OPT_SGD && LPS == kWave;
+  constexpr bool CHUNKED = MODE == 3;  // rows longer than one chunk of held entries
   constexpr int NQ = REG ? L : 1;       // row pieces per lane kept in registers
   constexpr int RPS = E * L;            // rows per slot in held mode
   double2 prow[NQ];
@@ -337,16 +340,16 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   const double itp = (a.it0p[0] + a.it_b) - 1.0;  // AdaGrad: it' = it_b - 1 (adagrad.nim:90)
   const bool stored = a.use_stored != 0;
   // ---- 1. forward: yhat of every sample of the block ----
-  if (HELD) {
-    // ---- 1h. held entries: the whole row in one round trip, linear term lane-parallel ----
+  // ---- held entries: a chunk of CAP = E * LPS entries of the row in one round trip (index, value, single
+  // flag, linear weight), linear term lane-parallel.  Rows longer than CAP take several chunks.
+  constexpr int CAP = E * LPS;
+  const uint8_t* sg = (HELD && a.single != nullptr && valid) ? a.single + a.toff[a.p0 + pib] : nullptr;
+  auto load_chunk = [&](int base, bool with_linear) {
     const double sw = OPT == OPT_SGD ? a.scales[1] : 1.0;
     const double denw = itp * O.eta0 * O.alpha;
-    if (OPT == OPT_ADAGRAD && !stored && M.fit_intercept)
-      b0 = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * itp * O.alpha0);
-    const uint8_t* sg = (a.single != nullptr && valid) ? a.single + a.toff[a.p0 + pib] : nullptr;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const int q = e * LPS + lis;
+      const int q = base + e * LPS + lis;
       dev::row_entry(X, q0, m, m_tot, q, jq[e], xq[e]);
       fq[e] = (sg != nullptr && q < m_tot) ? (int)sg[q] : 0;
       wq[e] = gwq[e] = nwq[e] = 0.0;
@@ -358,69 +361,66 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
           nwq[e] = O.Nw[jq[e]];
           if (!stored) wj = -O.eta0 * gwq[e] / (denw + sqrt(nwq[e]));
         }
-        part += wj * xq[e];
+        if (with_linear) part += wj * xq[e];
       }
     }
+  };
+  if (HELD) {
+    if (OPT == OPT_ADAGRAD && !stored && M.fit_intercept)
+      b0 = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * itp * O.alpha0);
     m_max = m_tot;
 #pragma unroll
     for (int s = LPS; s < kWave; s <<= 1) {
       const int o = __shfl_xor(m_max, s, kWave);
       m_max = o > m_max ? o : m_max;
     }
-  }
-  if (REG) {
-    const double sP = a.scales[0];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const int jj = __shfl(jq[0], slot + u * SPLIT, kWave);
-      prow[u] = *reinterpret_cast<const double2*>(M.P + (size_t)jj * M.Kp + 2 * l);
-    }
-    double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const double xx = dev::shfl_d(xq[0], slot + u * SPLIT);
-      const double tx = xx * (sP * prow[u].x), ty = xx * (sP * prow[u].y);
-      a1.x += tx;
-      a1.y += ty;
-      a2.x += tx * tx;
-      a2.y += ty * ty;
-    }
-#pragma unroll
-    for (int s = L; s < L * SPLIT; s <<= 1) {
-      a1.x += dev::shfl_xor_d(a1.x, s);
-      a1.y += dev::shfl_xor_d(a1.y, s);
-      a2.x += dev::shfl_xor_d(a2.x, s);
-      a2.y += dev::shfl_xor_d(a2.y, s);
-    }
-    A1 = a1;
-    if (valid && slot == 0) *reinterpret_cast<double2*>(Arow + 2 * l) = A1;
-    if (slot == 0) part += (a1.x * a1.x - a2.x) / 2 + (a1.y * a1.y - a2.y) / 2;
-  } else if (HELD) {
-    // rows streamed in groups of U, addressed from the held entries: one round trip per group
+    // MODE 2: the first chunk's parameter rows stay in registers (prow); further chunks and MODE 1
+    // stream the rows in groups of U, addressed from the held entries: one round trip per group
     constexpr int U = RPS < dev::kFwdUnroll ? RPS : dev::kFwdUnroll;
     auto held_forward = [&](auto ps) {
       double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
+      for (int base = 0; base == 0 || (CHUNKED && base < m_max); base += CAP) {
+        load_chunk(base, true);
+        if (REG && base == 0) {
+          const double sP = a.scales[0];
 #pragma unroll
-      for (int u0 = 0; u0 < RPS; u0 += U) {
-        if (u0 * SPLIT >= m_max) break;
-        int jj[U];
-        double xx[U];
-        double2 pp[U];
+          for (int u = 0; u < NQ; ++u) {
+            const int jj = __shfl(jq[0], slot + u * SPLIT, kWave);
+            prow[u] = *reinterpret_cast<const double2*>(M.P + (size_t)jj * M.Kp + 2 * l);
+          }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int r = u0 + u, src = sbase + slot + (r % L) * SPLIT;
-          jj[u] = __shfl(jq[r / L], src, kWave);
-          xx[u] = dev::shfl_d(xq[r / L], src);
-        }
+          for (int u = 0; u < NQ; ++u) {
+            const double xx = dev::shfl_d(xq[0], slot + u * SPLIT);
+            const double tx = xx * (sP * prow[u].x), ty = xx * (sP * prow[u].y);
+            a1.x += tx;
+            a1.y += ty;
+            a2.x += tx * tx;
+            a2.y += ty * ty;
+          }
+        } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) pp[u] = ps.load((size_t)jj[u] * M.Kp + 2 * l);  // past the end: (row 0, x = 0)
+          for (int u0 = 0; u0 < RPS; u0 += U) {
+            if (base + u0 * SPLIT >= m_max) break;
+            int jj[U];
+            double xx[U];
+            double2 pp[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const double tx = xx[u] * pp[u].x, ty = xx[u] * pp[u].y;
-          a1.x += tx;
-          a1.y += ty;
-          a2.x += tx * tx;
-          a2.y += ty * ty;
+            for (int u = 0; u < U; ++u) {
+              const int r = u0 + u, src = sbase + slot + (r % L) * SPLIT;
+              jj[u] = __shfl(jq[r / L], src, kWave);
+              xx[u] = dev::shfl_d(xq[r / L], src);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) pp[u] = ps.load((size_t)jj[u] * M.Kp + 2 * l);  // past the end: (row 0, x = 0)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const double tx = xx[u] * pp[u].x, ty = xx[u] * pp[u].y;
+              a1.x += tx;
+              a1.y += ty;
+              a2.x += tx * tx;
+              a2.y += ty * ty;
+            }
+          }
         }
       }
 #pragma unroll
@@ -549,111 +549,115 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
     const double sP = OPT == OPT_SGD ? a.scales[0] : 1.0, sw = OPT == OPT_SGD ? a.scales[1] : 1.0;
     const double sPn = OPT == OPT_SGD ? a.scales_n[0] : 1.0, swn = OPT == OPT_SGD ? a.scales_n[1] : 1.0;
     const double tmpP = O.eta0 * itp * O.beta, denw = itp * O.eta0 * O.alpha;
-    if (REG) {
-#pragma unroll
-      for (int u = 0; u < NQ; ++u) {
-        const int q = slot + u * SPLIT;  // the shuffles run with every lane active
-        const int f = __shfl(fq[0], q, kWave);
-        const int j = __shfl(jq[0], q, kWave);
-        const double xv = dev::shfl_d(xq[0], q);
-        if (f) {
-          double2 st = prow[u];
-          const double px = sP * st.x, py = sP * st.y;
-          const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
-          const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
-          r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
-          st.x = st.x - ax / sPn;
-          st.y = st.y - ay / sPn;
-          *reinterpret_cast<double2*>(M.P + (size_t)j * M.Kp + 2 * l) = st;
-        }
-      }
-    } else {
-      // singles re-read, but addressed from the held entries: per group of V rows one round trip
-      // (flags, indices and values come from registers), then the stores
-      constexpr int V = RPS < dev::kUnroll ? RPS : dev::kUnroll;
-#pragma unroll
-      for (int u0 = 0; u0 < RPS; u0 += V) {
-        if (u0 * SPLIT >= m_max) break;
-        int f[V], j[V];
-        double x[V];
-        double2 r0[V], r1[V], r2[V];
-#pragma unroll
-        for (int u = 0; u < V; ++u) {
-          const int r = u0 + u, src = sbase + slot + (r % L) * SPLIT;
-          f[u] = __shfl(fq[r / L], src, kWave);
-          j[u] = __shfl(jq[r / L], src, kWave);
-          x[u] = dev::shfl_d(xq[r / L], src);
-        }
-#pragma unroll
-        for (int u = 0; u < V; ++u) {
-          r0[u] = r1[u] = r2[u] = {0.0, 0.0};
-          if (f[u]) {
-            const size_t e = (size_t)j[u] * M.Kp + 2 * l;
-            if (OPT == OPT_SGD) {
-              r0[u] = *reinterpret_cast<const double2*>(M.P + e);
-            } else {
-              r1[u] = *reinterpret_cast<const double2*>(O.G + e);
-              r2[u] = *reinterpret_cast<const double2*>(O.N + e);
-              if (stored || O.track_viol) r0[u] = *reinterpret_cast<const double2*>(M.P + e);
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < V; ++u) {
-          if (!f[u]) continue;
-          const size_t e = (size_t)j[u] * M.Kp + 2 * l;
-          const double xv = x[u];
-          if (OPT == OPT_SGD) {
-            double2 st = r0[u];
+    const bool chunks = CHUNKED && m_max > CAP;  // several chunks: the entries are loaded again per chunk
+    for (int base = 0; base == 0 || (CHUNKED && base < m_max); base += CAP) {
+      if (chunks) load_chunk(base, false);
+      if (REG && base == 0) {
+  #pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+          const int q = slot + u * SPLIT;  // the shuffles run with every lane active
+          const int f = __shfl(fq[0], q, kWave);
+          const int j = __shfl(jq[0], q, kWave);
+          const double xv = dev::shfl_d(xq[0], q);
+          if (f) {
+            double2 st = prow[u];
             const double px = sP * st.x, py = sP * st.y;
             const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
             const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
             r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
             st.x = st.x - ax / sPn;
             st.y = st.y - ay / sPn;
-            *reinterpret_cast<double2*>(M.P + e) = st;
-          } else {
-            double2 g2 = r1[u], n2 = r2[u], p;
-            if (stored) {
-              p = r0[u];
-            } else {
-              p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmpP);
-              p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmpP);
-              if (O.track_viol) {
-                r_viol += fabs(r0[u].x - p.x) + fabs(r0[u].y - p.y);
-                *reinterpret_cast<double2*>(M.P + e) = p;
+            *reinterpret_cast<double2*>(M.P + (size_t)j * M.Kp + 2 * l) = st;
+          }
+        }
+      } else {
+        // singles re-read, but addressed from the held entries: per group of V rows one round trip
+        // (flags, indices and values come from registers), then the stores
+        constexpr int V = RPS < dev::kUnroll ? RPS : dev::kUnroll;
+  #pragma unroll
+        for (int u0 = 0; u0 < RPS; u0 += V) {
+          if (base + u0 * SPLIT >= m_max) break;
+          int f[V], j[V];
+          double x[V];
+          double2 r0[V], r1[V], r2[V];
+  #pragma unroll
+          for (int u = 0; u < V; ++u) {
+            const int r = u0 + u, src = sbase + slot + (r % L) * SPLIT;
+            f[u] = __shfl(fq[r / L], src, kWave);
+            j[u] = __shfl(jq[r / L], src, kWave);
+            x[u] = dev::shfl_d(xq[r / L], src);
+          }
+  #pragma unroll
+          for (int u = 0; u < V; ++u) {
+            r0[u] = r1[u] = r2[u] = {0.0, 0.0};
+            if (f[u]) {
+              const size_t e = (size_t)j[u] * M.Kp + 2 * l;
+              if (OPT == OPT_SGD) {
+                r0[u] = *reinterpret_cast<const double2*>(M.P + e);
+              } else {
+                r1[u] = *reinterpret_cast<const double2*>(O.G + e);
+                r2[u] = *reinterpret_cast<const double2*>(O.N + e);
+                if (stored || O.track_viol) r0[u] = *reinterpret_cast<const double2*>(M.P + e);
               }
             }
-            const double gx = dL * (xv * (A1.x - p.x * xv)), gy = dL * (xv * (A1.y - p.y * xv));
-            g2.x += gx;
-            g2.y += gy;
-            n2.x += gx * gx;
-            n2.y += gy * gy;
-            *reinterpret_cast<double2*>(O.G + e) = g2;
-            *reinterpret_cast<double2*>(O.N + e) = n2;
+          }
+  #pragma unroll
+          for (int u = 0; u < V; ++u) {
+            if (!f[u]) continue;
+            const size_t e = (size_t)j[u] * M.Kp + 2 * l;
+            const double xv = x[u];
+            if (OPT == OPT_SGD) {
+              double2 st = r0[u];
+              const double px = sP * st.x, py = sP * st.y;
+              const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
+              const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
+              r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
+              st.x = st.x - ax / sPn;
+              st.y = st.y - ay / sPn;
+              *reinterpret_cast<double2*>(M.P + e) = st;
+            } else {
+              double2 g2 = r1[u], n2 = r2[u], p;
+              if (stored) {
+                p = r0[u];
+              } else {
+                p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmpP);
+                p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmpP);
+                if (O.track_viol) {
+                  r_viol += fabs(r0[u].x - p.x) + fabs(r0[u].y - p.y);
+                  *reinterpret_cast<double2*>(M.P + e) = p;
+                }
+              }
+              const double gx = dL * (xv * (A1.x - p.x * xv)), gy = dL * (xv * (A1.y - p.y * xv));
+              g2.x += gx;
+              g2.y += gy;
+              n2.x += gx * gx;
+              n2.y += gy * gy;
+              *reinterpret_cast<double2*>(O.G + e) = g2;
+              *reinterpret_cast<double2*>(O.N + e) = n2;
+            }
           }
         }
       }
-    }
-    // the linear term of the singles, one entry per lane
-    if (M.fit_linear) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        if (!fq[e] || e * LPS + lis >= m) continue;
-        if (OPT == OPT_SGD) {
-          const double wj = sw * wq[e];
-          const double a0 = etaw * (dL * xq[e]);
-          r_viol += fabs(a0 + etaw * O.alpha * wj);
-          M.w[jq[e]] = wq[e] - a0 / swn;
-        } else {
-          if (!stored) {
-            const double wj = -O.eta0 * gwq[e] / (denw + sqrt(nwq[e]));
-            r_viol += fabs(wq[e] - wj);
-            M.w[jq[e]] = wj;
+      // the linear term of the singles, one entry per lane
+      if (M.fit_linear) {
+  #pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if (!fq[e] || base + e * LPS + lis >= m) continue;
+          if (OPT == OPT_SGD) {
+            const double wj = sw * wq[e];
+            const double a0 = etaw * (dL * xq[e]);
+            r_viol += fabs(a0 + etaw * O.alpha * wj);
+            M.w[jq[e]] = wq[e] - a0 / swn;
+          } else {
+            if (!stored) {
+              const double wj = -O.eta0 * gwq[e] / (denw + sqrt(nwq[e]));
+              r_viol += fabs(wq[e] - wj);
+              M.w[jq[e]] = wj;
+            }
+            const double g = dL * xq[e];
+            O.Gw[jq[e]] = gwq[e] + g;
+            O.Nw[jq[e]] = nwq[e] + g * g;
           }
-          const double g = dL * xq[e];
-          O.Gw[jq[e]] = gwq[e] + g;
-          O.Nw[jq[e]] = nwq[e] + g * g;
         }
       }
     }
@@ -1353,6 +1357,8 @@ static void launch_row(hipStream_t st, const RowArgs& ra, int mode, int pad_kb =
   constexpr bool CAN_REG = CAN_HOLD && OPT == OPT_SGD && L * SPLIT == kWave;
   if (CAN_REG && mode == 2)
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 2 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
+  else if (CAN_HOLD && mode == 3)
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_HOLD ? 3 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
   else if (CAN_HOLD && mode >= 1)
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_HOLD ? 1 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
   else if (sing && !GEN)
@@ -1400,12 +1406,14 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     const int split = choose_split(L, len, avg_row, ctx->n_cu);
     // row-phase mode (k_row_phase): 2 = held entries + register-resident rows (SGD, one sample per
     // wavefront, a batch with singles: 106 vs 141 us per batch on the headline shape), 1 = held entries,
-    // 0 = streamed (rows longer than the held capacity, models with several orders).
+    // 3 = held entries in chunks (rows longer than the held capacity), 0 = streamed (models with several
+    // orders, samples spread over fewer than 8 lanes).
     // NFM_HELD=0 / NFM_NQ=0 switch the modes off (tuning).
     auto mode_for = [&](int s_used) {
       static const bool held_on = !(getenv("NFM_HELD") && atoi(getenv("NFM_HELD")) == 0);
       static const bool reg_on = !(getenv("NFM_NQ") && atoi(getenv("NFM_NQ")) == 0);
-      if (GEN || !held_on || X.max_row + M.n_aug > held_capacity(L, s_used)) return 0;
+      if (GEN || !held_on || held_capacity(L, s_used) == 0) return 0;
+      if (X.max_row + M.n_aug > held_capacity(L, s_used)) return 3;  // long rows: chunks of held entries
       if (reg_on && OPT == OPT_SGD && singles_in_row && L * s_used == kWave) return 2;
       return 1;
     };

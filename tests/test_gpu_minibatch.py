@@ -202,11 +202,12 @@ def test_sparse_regime_singles(k, batch):
     assert_close(fm.P, P, RTOL, ATOL, "P")
 
 
-@pytest.mark.parametrize("k,fit_linear,max_m", [(64, True, 64), (64, False, 63), (32, True, 64), (16, True, 40), (40, False, 17)])
+@pytest.mark.parametrize("k,fit_linear,max_m", [(64, True, 64), (64, False, 63), (32, True, 64), (16, True, 40), (40, False, 17),
+                                                (64, True, 150), (48, False, 64), (16, True, 100), (8, True, 70)])
 def test_register_resident_rows(k, fit_linear, max_m):
-    """Sparse regime with one sample per wavefront (k > 8) and rows of at most 64 entries (dummy feature
-    included): the row phase keeps the gathered parameter rows in registers and updates the singles
-    without a second visit (k_row_phase REG).  Ragged rows, empty rows, unsorted storage order;
+    """Sparse regime, held-entries row phase: with one sample per wavefront (k > 8) the first 64 entries' parameter
+    rows stay in registers and the singles are updated without a second visit (k_row_phase MODE 2); longer rows
+    (max_m > 64, or 64 + the dummy feature) continue in further chunks.  Ragged rows, empty rows, unsorted storage order;
     fit_linear=False with fitLower=augment adds a dummy feature every sample touches (a heavy column)."""
     n, d = 700, 30000
     Xo = ragged_csr(n, d, seed=k + max_m, max_m=max_m)
