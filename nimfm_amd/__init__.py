@@ -8,6 +8,6 @@ Layout:
 """
 from ._capi import NfmError, NotFittedError, build, lib  # noqa: F401
 from .host import (AdaGrad, Context, CSRDataset, FactorizationMachine, FieldAwareFactorizationMachine, SGD,  # noqa: F401
-                   accuracy, convertSVMLightFile, default_context, expit, loadFFMFile, loadSVMLightFile, newAdaGrad, newCSRDataset, newCSRFieldDataset,
+                   accuracy, convertSVMLightFile, default_context, expit, load, loadFFMFile, loadSVMLightFile, newAdaGrad, newCSRDataset, newCSRFieldDataset,
                    newFactorizationMachine, newFieldAwareFactorizationMachine, newSGD, newStreamCSRDataset, parseText, rmse,
                    set_default_context)

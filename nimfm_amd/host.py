@@ -399,6 +399,82 @@ class FactorizationMachine(_ModelBase):
         self.isInitialized = True
 
 
+def _nim_float(v):
+    """Nim's `$float64`: the shortest form that reads back exactly (repr), "inf"/"nan" spelled Nim's way"""
+    v = float(v)
+    if v != v:
+        return "nan"
+    if v in (float("inf"), float("-inf")):
+        return "inf" if v > 0 else "-inf"
+    return repr(v)
+
+
+def _dump_fm(self, fname):
+    """model/factorization_machine.nim:142-165: the reference's text model format"""
+    self.checkInitialized()
+    P, w = self.P, self.w
+    d = P.shape[2] - self.nAugments
+    with open(os.path.expanduser(fname), "w") as f:
+        f.write("task: %s\n" % self.task)
+        f.write("nFeatures: %d\n" % d)
+        f.write("degree: %d\n" % self.degree)
+        f.write("nComponents: %d\n" % self.nComponents)
+        f.write("fitLower: %s\n" % self.fitLower)
+        f.write("fitIntercept: %s\n" % ("true" if self.fitIntercept else "false"))
+        f.write("fitLinear: %s\n" % ("true" if self.fitLinear else "false"))
+        f.write("randomState: %d\n" % self.randomState)
+        f.write("scale: %s\n" % _nim_float(self.scale))
+        f.write("lams:\n")
+        f.write(" ".join(_nim_float(v) for v in self.lams) + "\n")
+        for order in range(P.shape[0]):
+            f.write("P[%d]:\n" % order)
+            for s_ in range(self.nComponents):
+                f.write(" ".join(_nim_float(v) for v in P[order, s_]) + "\n")
+        f.write("w:\n")
+        f.write(" ".join(_nim_float(v) for v in w) + "\n")
+        f.write("intercept: %s\n" % _nim_float(self.intercept))
+
+
+FactorizationMachine.dump = _dump_fm
+
+
+def load(fname, warmStart):
+    """model/factorization_machine.nim:168-220 `load(fm, fname, warmStart)`: -> FactorizationMachine"""
+    with open(os.path.expanduser(fname)) as f:
+        lines = f.read().split("\n")
+    it = iter(lines)
+
+    def field():
+        return next(it).split(" ")[1]
+
+    task = field()
+    d = int(field())
+    degree = int(field())
+    k = int(field())
+    fit_lower = field()
+    fit_intercept = field().lower() in ("true", "y", "yes", "1", "on")  # Nim's parseBool
+    fit_linear = field().lower() in ("true", "y", "yes", "1", "on")
+    random_state = int(field())
+    scale = float(field())
+    fm = FactorizationMachine(task, degree, k, fit_lower, fit_intercept, fit_linear, bool(warmStart), random_state, scale)
+    next(it)  # "lams:"
+    lams = np.array([float(v) for v in next(it).split(" ") if v][:k])
+    P = np.zeros((fm.nOrders, k, d + fm.nAugments))
+    for order in range(fm.nOrders):
+        next(it)  # "P[order]:"
+        for s_ in range(k):
+            row = [float(v) for v in next(it).split(" ") if v]
+            P[order, s_] = row[: d + fm.nAugments]
+    next(it)  # "w:"
+    w = np.array([float(v) for v in next(it).split(" ") if v][:d])
+    if len(w) != d:
+        w = np.zeros(d)
+    intercept = float(next(it).split(" ")[1])
+    fm.set_params(P, w, intercept)
+    fm.lams = lams
+    return fm
+
+
 class FieldAwareFactorizationMachine(_ModelBase):
     def __init__(self, task, nComponents=10, fitIntercept=True, fitLinear=True, warmStart=False, randomState=1,
                  scale=0.01):
