@@ -687,156 +687,6 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// row phase, LDS-resident rows (SGD, single order of degree 2, batches with singles)
-//
-// One wavefront per sample at a time.  The sample's parameter rows are gathered straight into LDS
-// with global_load_lds_dwordx4 (per-lane source address, 1 KiB = 64/L rows per wave-instruction, no
-// VGPRs), every row is in flight at once; the forward pass reads them from LDS, and so does the
-// in-place update of the singles: HBM sees every row read once and the single-touch rows written
-// once, which is the algorithmic traffic.  Occupancy is set by LDS alone (rows * Kp * 8 B per wave).
-// ------------------------------------------------------------------------------------------------
-template <int L>
-__global__ __launch_bounds__(kBlock) void k_row_phase_lds(RowArgs a, int m_cap) {
-  constexpr int R = kWave / L;
-  extern __shared__ __attribute__((aligned(16))) double lds_rows[];  // [waves][m_cap][Kp]
-  __shared__ double red[kWavesPerBlock][4];
-  const CsrView& X = a.X;
-  const ModelView& M = a.M;
-  const OptView& O = a.O;
-  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-  const int g = lane / L, l = lane % L;
-  const int Kp = M.Kp;
-  double* wl = lds_rows + (size_t)wv * m_cap * Kp;
-  const double sP = a.scales[0], sw = a.scales[1], sPn = a.scales_n[0], swn = a.scales_n[1];
-  const double b0 = M.sc[SC_INTERCEPT];
-  double r_loss = 0.0, r_viol = 0.0, r_acc0 = 0.0, r_acc1 = 0.0;
-  for (int pib = blockIdx.x * kWavesPerBlock + wv; pib < a.len; pib += gridDim.x * kWavesPerBlock) {
-    const int64_t pos = a.p0 + pib;
-    const int64_t i = a.perm ? a.perm[pos] : a.begin + pos;
-    const int64_t q0 = X.indptr[i];
-    const int m = (int)(X.indptr[i + 1] - q0);
-    const int m_tot = m + M.n_aug;
-    const double y = dev::target_of(X.y[i], M.task);
-    // The row's (index, value) slice is held one entry per lane (64 per chunk) and handed to the row
-    // slots with ds_bpermute: no vector-memory instruction sits between the LDS-DMA gathers, so all of
-    // them are in flight together (vmcnt counts them in order with ordinary loads).
-    const int n_chunks = (m_tot + kWave - 1) / kWave;
-    // 1. every row of the sample on its way into LDS
-    for (int c = 0; c < n_chunks; ++c) {
-      int jl;
-      double xl;
-      dev::row_entry(X, q0, m, m_tot, c * kWave + lane, jl, xl);
-      const int len_c = min(kWave, m_tot - c * kWave);
-      for (int it = 0; it * R < len_c; ++it) {
-        const int j = __shfl(jl, it * R + g, kWave);
-        const double* src = M.P + (size_t)j * Kp + 2 * l;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(wl + ((size_t)c * kWave + it * R) * Kp), 16, 0, 0);
-      }
-    }
-    double part = 0.0;
-    for (int q = lane; q < m; q += kWave) part += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA writes are not tracked by the compiler
-    __builtin_amdgcn_wave_barrier();
-    // 2. forward from LDS
-    double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
-    for (int c = 0; c < n_chunks; ++c) {
-      int jl;
-      double xl;
-      dev::row_entry(X, q0, m, m_tot, c * kWave + lane, jl, xl);
-      const int len_c = min(kWave, m_tot - c * kWave);
-      for (int it = 0; it * R < len_c; ++it) {
-        const double x = dev::shfl_d(xl, it * R + g);  // 0.0 past the row's end
-        const double2 p = *reinterpret_cast<const double2*>(wl + ((size_t)c * kWave + it * R + g) * Kp + 2 * l);
-        const double tx = x * (sP * p.x), ty = x * (sP * p.y);
-        a1.x += tx;
-        a1.y += ty;
-        a2.x += tx * tx;
-        a2.y += ty * ty;
-      }
-    }
-#pragma unroll
-    for (int s = L; s < kWave; s <<= 1) {
-      a1.x += dev::shfl_xor_d(a1.x, s);
-      a1.y += dev::shfl_xor_d(a1.y, s);
-      a2.x += dev::shfl_xor_d(a2.x, s);
-      a2.y += dev::shfl_xor_d(a2.y, s);
-    }
-    if (g == 0) {
-      *reinterpret_cast<double2*>(a.Abuf + (size_t)pib * a.TA * Kp + 2 * l) = a1;
-      part += (a1.x * a1.x - a2.x) / 2 + (a1.y * a1.y - a2.y) / 2;
-    }
-    part = dev::wave_sum(part);
-    const double yh = b0 + part;
-    const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
-    const double it_abs = (a.it0p[0] + a.it_b) + (double)pib;
-    const double etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it_abs);
-    const double etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it_abs);
-    if (lane == 0) {
-      r_loss += dev::loss_value(O.loss, O.loss_param, y, yh);
-      a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
-      if (M.fit_intercept) {
-        const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it_abs);
-        r_acc0 += eta0 * dL;
-        r_acc1 += eta0;
-      }
-    }
-    // 3. singles, straight from LDS
-    const uint8_t* sg = a.single + a.toff[pos];
-    for (int c = 0; c < n_chunks; ++c) {
-      int jl;
-      double xl;
-      dev::row_entry(X, q0, m, m_tot, c * kWave + lane, jl, xl);
-      const int ql = c * kWave + lane;
-      const int fl = (ql < m_tot && sg[ql] != 0) ? 1 : 0;
-      const int len_c = min(kWave, m_tot - c * kWave);
-      for (int it = 0; it * R < len_c; ++it) {
-        const int src_lane = it * R + g;
-        const int j = __shfl(jl, src_lane, kWave);
-        const double xv = dev::shfl_d(xl, src_lane);
-        const int f = __shfl(fl, src_lane, kWave);
-        if (f) {
-          double2 st = *reinterpret_cast<const double2*>(wl + ((size_t)c * kWave + src_lane) * Kp + 2 * l);
-          const double px = sP * st.x, py = sP * st.y;
-          const double ax = etaP * (dL * (xv * (a1.x - px * xv)));
-          const double ay = etaP * (dL * (xv * (a1.y - py * xv)));
-          r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
-          st.x = st.x - ax / sPn;
-          st.y = st.y - ay / sPn;
-          *reinterpret_cast<double2*>(M.P + (size_t)j * Kp + 2 * l) = st;
-          if (M.fit_linear && j < M.d && l == 0) {
-            const double wt = M.w[j], wj = sw * wt;
-            const double a0 = etaw * (dL * xv);
-            r_viol += fabs(a0 + etaw * O.alpha * wj);
-            M.w[j] = wt - a0 / swn;
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();  // LDS reads of this sample done before the next sample's DMA lands
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-  r_viol = dev::wave_sum(r_viol);
-  if (lane == 0) {
-    red[wv][0] = r_loss;
-    red[wv][1] = r_viol;
-    red[wv][2] = r_acc0;
-    red[wv][3] = r_acc1;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    PartA p{0.0, 0.0, 0.0, 0.0};
-    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) {
-      p.loss += red[w_][0];
-      p.viol += red[w_][1];
-      p.acc0 += red[w_][2];
-      p.acc1 += red[w_][3];
-    }
-    a.parts[blockIdx.x] = p;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // column phase (+ batch close in workgroup 0)
 // ------------------------------------------------------------------------------------------------
 struct ColArgs {
@@ -872,8 +722,6 @@ struct ColArgs {
 struct WAcc {  // linear-term accumulators of one feature
   double a0 = 0.0, a1 = 0.0;
 };
-
-constexpr int kTouchUnroll = 4;
 
 // one parameter block (order) of one unique feature: this lane's factor pair at element e.
 // do_w: also accumulate the linear term's sums over the same touches.
@@ -1345,14 +1193,10 @@ __global__ __launch_bounds__(kBlock) void k_epoch_close(const double* __restrict
 // host driver
 // ------------------------------------------------------------------------------------------------
 template <int L, int SPLIT, int OPT, bool GEN>
-static void launch_row(hipStream_t st, const RowArgs& ra, int mode, int pad_kb = 0) {
+static void launch_row(hipStream_t st, const RowArgs& ra, int mode) {
   const bool sing = ra.single != nullptr;
   constexpr int SPW = kWave / (L * SPLIT);
   const int nA = (ra.len + kWavesPerBlock * SPW - 1) / (kWavesPerBlock * SPW);
-  if (pad_kb > 0 && mode == 0) {  // tuning: unused dynamic LDS caps the workgroups per CU
-    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, 0, !GEN>), dim3(nA), dim3(kBlock), (size_t)pad_kb * 1024, st, ra);
-    return;
-  }
   constexpr bool CAN_HOLD = !GEN && held_entries<L, SPLIT>() > 0;
   constexpr bool CAN_REG = CAN_HOLD && OPT == OPT_SGD && L * SPLIT == kWave;
   if (CAN_REG && mode == 2)
@@ -1388,7 +1232,6 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
   // (4: 104 VGPRs -> 4 waves per SIMD, 2: 80 -> 6)
   const char* tu_env = getenv("NFM_TU");
   const int tu = tu_env ? atoi(tu_env) : 2;
-  static const int row_pad_kb = getenv("NFM_ROW_PAD_KB") ? atoi(getenv("NFM_ROW_PAD_KB")) : 0;  // occupancy cap (tuning)
   // Where the singles are updated: as stage 3 of the row phase (default), or by their own kernel
   // between the row and the column phase (NFM_SINGLES_KERNEL=1: 66 + 109 us vs 157 us fused at k = 64;
   // as extra workgroups of the column launch the sum of the times was conserved as well: the memory
@@ -1426,33 +1269,13 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
                  W.partsA.as<PartA>()};
       TimedLaunch tl(ctx, "row_phase");
       int s_used;
-      // LDS-resident rows: SGD, degree 2, a batch with singles, rows that fit 160 KB per workgroup
-      const int m_cap = ((X.max_row + M.n_aug + kWave - 1) / kWave) * kWave;  // whole 64-entry chunks
-      const size_t lds_bytes = sizeof(double) * (size_t)kWavesPerBlock * std::max(m_cap, R) * M.Kp;
-      // measured on the headline shape (k=64, m=64, B=8192): streaming 154 us, LDS-resident 217 us per
-      // batch -- one sample per wavefront at a time is latency-bound without double buffering, so
-      // this variant is opt-in (NFM_LDS=1) until it is pipelined
-      static const bool lds_on = getenv("NFM_LDS") && atoi(getenv("NFM_LDS")) != 0;
-      if (OPT == OPT_SGD && singles_in_row && lds_on && lds_bytes <= 160 * 1024 - 256) {
-        auto kern = k_row_phase_lds<L>;
-        if (lds_bytes > 64 * 1024)
-          NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds_bytes));
-        int per_cu = (int)((160 * 1024) / (lds_bytes + 256));
-        if (per_cu > 8) per_cu = 8;
-        if (per_cu < 1) per_cu = 1;
-        nA = (len + kWavesPerBlock - 1) / kWavesPerBlock;
-        if (nA > ctx->n_cu * per_cu) nA = ctx->n_cu * per_cu;
-        hipLaunchKernelGGL(kern, dim3(nA), dim3(kBlock), lds_bytes, st, ra, std::max(m_cap, R));
-      } else {
-      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra, mode_for(R >= 16 ? 16 : R), row_pad_kb); s_used = R >= 16 ? 16 : R; }
-      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra, mode_for(R >= 8 ? 8 : R), row_pad_kb); s_used = R >= 8 ? 8 : R; }
-      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra, mode_for(R >= 4 ? 4 : R), row_pad_kb); s_used = R >= 4 ? 4 : R; }
-      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT, GEN>(st, ra, mode_for(R >= 2 ? 2 : R), row_pad_kb); s_used = R >= 2 ? 2 : R; }
-      else { launch_row<L, 1, OPT, GEN>(st, ra, mode_for(1), row_pad_kb); s_used = 1; }
+      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra, mode_for(R >= 16 ? 16 : R)); s_used = R >= 16 ? 16 : R; }
+      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra, mode_for(R >= 8 ? 8 : R)); s_used = R >= 8 ? 8 : R; }
+      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra, mode_for(R >= 4 ? 4 : R)); s_used = R >= 4 ? 4 : R; }
+      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT, GEN>(st, ra, mode_for(R >= 2 ? 2 : R)); s_used = R >= 2 ? 2 : R; }
+      else { launch_row<L, 1, OPT, GEN>(st, ra, mode_for(1)); s_used = 1; }
       const int spw = kWave / (L * s_used);
       nA = (len + kWavesPerBlock * spw - 1) / (kWavesPerBlock * spw);
-      }
     }
     const int64_t u0 = P.bat_uoff[b], u1 = P.bat_uoff[b + 1];
     const int per_block = kWavesPerBlock * R;
