@@ -279,6 +279,25 @@ __device__ __forceinline__ double singles_update(const CsrView& X, const ModelVi
   return r_viol;
 }
 
+// value held by lane (slot + u * SPLIT) of this wavefront, u a compile-time constant: v_readlane into
+// SGPRs (one per slot) and a select -- no LDS-pipe traffic and no vector registers held, unlike
+// ds_bpermute, which the scheduler hoists by the dozen next to 128 registers of resident rows
+template <int SPLIT>
+__device__ __forceinline__ int lane_bcast_i(int v, int u, int slot) {
+  int r = __builtin_amdgcn_readlane(v, u * SPLIT);
+#pragma unroll
+  for (int s = 1; s < SPLIT; ++s) {
+    const int t = __builtin_amdgcn_readlane(v, u * SPLIT + s);
+    r = slot == s ? t : r;
+  }
+  return r;
+}
+template <int SPLIT>
+__device__ __forceinline__ double lane_bcast_d(double v, int u, int slot) {
+  const int lo = lane_bcast_i<SPLIT>(__double2loint(v), u, slot), hi = lane_bcast_i<SPLIT>(__double2hiint(v), u, slot);
+  return __hiloint2double(hi, lo);
+}
+
 // How the row phase reads a sample's CSR row (models with one order of degree 2):
 //   MODE 0  streamed: (index, value) of every entry is loaded right before its parameter row -- two
 //           dependent round trips per group of rows, three in the update of the singles.  Any row length.
@@ -297,8 +316,11 @@ constexpr int held_entries() {  // E: entries per lane; 0 = no held mode for thi
   return LPS >= kWave ? 1 : (LPS >= 8 ? (kWave / LPS > 4 ? 4 : kWave / LPS) : 0);
 }
 
+#ifndef NFM_REG_MINW
+#define NFM_REG_MINW 1
+#endif
 template <int L, int SPLIT, int OPT, bool GEN, int MODE, bool SING>
-__global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
+__global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_phase(RowArgs a) {
   constexpr int LPS = L * SPLIT, SPW = kWave / LPS, SPB = kWavesPerBlock * SPW;  // samples per wave / block
   constexpr int E = held_entries<L, SPLIT>() > 0 ? held_entries<L, SPLIT>() : 1;
   constexpr bool HELD = MODE >= 1 && !GEN && held_entries<L, SPLIT>() > 0;
@@ -339,6 +361,16 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   int m_max = 0;  // longest row among the wavefront's samples (wave-uniform loop bound)
   const double itp = (a.it0p[0] + a.it_b) - 1.0;  // AdaGrad: it' = it_b - 1 (adagrad.nim:90)
   const bool stored = a.use_stored != 0;
+  // one sample per wavefront: the step sizes depend on the sample's position only, so they are
+  // formed BEFORE the parameter rows are gathered -- pow / division sequences need dozens of
+  // registers, which must not coincide with the rows held in registers (MODE 2)
+  double etaP = 0.0, etaw = 0.0, eta_b = 0.0;
+  if (SPW == 1 && NFM_WAVE_STAGE2 && OPT == OPT_SGD) {
+    const double it = (a.it0p[0] + a.it_b) + (double)pib;
+    etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+    etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
+    if (M.fit_intercept) eta_b = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
+  }
   // ---- 1. forward: yhat of every sample of the block ----
   // ---- held entries: a chunk of CAP = E * LPS entries of the row in one round trip (index, value, single
   // flag, linear weight), linear term lane-parallel.  Rows longer than CAP take several chunks.
@@ -385,12 +417,12 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
           const double sP = a.scales[0];
 #pragma unroll
           for (int u = 0; u < NQ; ++u) {
-            const int jj = __shfl(jq[0], slot + u * SPLIT, kWave);
+            const int jj = lane_bcast_i<SPLIT>(jq[0], u, slot);
             prow[u] = *reinterpret_cast<const double2*>(M.P + (size_t)jj * M.Kp + 2 * l);
           }
 #pragma unroll
           for (int u = 0; u < NQ; ++u) {
-            const double xx = dev::shfl_d(xq[0], slot + u * SPLIT);
+            const double xx = lane_bcast_d<SPLIT>(xq[0], u, slot);
             const double tx = xx * (sP * prow[u].x), ty = xx * (sP * prow[u].y);
             a1.x += tx;
             a1.y += ty;
@@ -464,22 +496,19 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   }
 #pragma unroll
   for (int s = 1; s < LPS; s <<= 1) part += dev::shfl_xor_d(part, s);
-  double dL, etaP = 0.0, etaw = 0.0;
+  double dL, yh_w = 0.0;
   if (SPW == 1 && NFM_WAVE_STAGE2) {
     // ---- 2'. one sample per wavefront (k > 32): every wavefront finishes its own sample, no
     // workgroup barrier between the forward pass and the singles update, so the four wavefronts of a
     // workgroup drift apart and their load and store phases overlap ----
     const double yh = b0 + part;
+    yh_w = yh;
     dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
     double r_acc0 = 0.0, r_acc1 = 0.0;
     if (OPT == OPT_SGD) {
-      const double it = (a.it0p[0] + a.it_b) + (double)pib;
-      etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
-      etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
       if (M.fit_intercept) {
-        const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
-        r_acc0 = eta0 * dL;
-        r_acc1 = eta0;
+        r_acc0 = eta_b * dL;
+        r_acc1 = eta_b;
       }
     } else if (M.fit_intercept) {
       r_acc0 = dL;
@@ -487,10 +516,9 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
     }
     if (lane == 0) {
       if (valid) a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
-      s_y[sib] = valid ? dev::loss_value(O.loss, O.loss_param, y, yh) : 0.0;
       s_dL[sib] = valid ? r_acc0 : 0.0;
       s_etaP[sib] = valid ? r_acc1 : 0.0;
-    }
+    }  // the loss VALUE (log / exp) waits until the rows are written back, see below
   } else {
   if (slot == 0 && l == 0) {
     s_y[sib] = y;
@@ -549,24 +577,26 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
     const double sP = OPT == OPT_SGD ? a.scales[0] : 1.0, sw = OPT == OPT_SGD ? a.scales[1] : 1.0;
     const double sPn = OPT == OPT_SGD ? a.scales_n[0] : 1.0, swn = OPT == OPT_SGD ? a.scales_n[1] : 1.0;
     const double tmpP = O.eta0 * itp * O.beta, denw = itp * O.eta0 * O.alpha;
+    // register-resident path: one reciprocal instead of two fp64 divisions per row (a division holds ~10
+    // registers while it runs, and the scheduler overlaps several)
+    const double rsPn = 1.0 / sPn;
     const bool chunks = CHUNKED && m_max > CAP;  // several chunks: the entries are loaded again per chunk
     for (int base = 0; base == 0 || (CHUNKED && base < m_max); base += CAP) {
       if (chunks) load_chunk(base, false);
       if (REG && base == 0) {
   #pragma unroll
         for (int u = 0; u < NQ; ++u) {
-          const int q = slot + u * SPLIT;  // the shuffles run with every lane active
-          const int f = __shfl(fq[0], q, kWave);
-          const int j = __shfl(jq[0], q, kWave);
-          const double xv = dev::shfl_d(xq[0], q);
+          const int f = lane_bcast_i<SPLIT>(fq[0], u, slot);  // read with every lane active
+          const int j = lane_bcast_i<SPLIT>(jq[0], u, slot);
+          const double xv = lane_bcast_d<SPLIT>(xq[0], u, slot);
           if (f) {
             double2 st = prow[u];
             const double px = sP * st.x, py = sP * st.y;
             const double ax = etaP * (dL * (xv * (A1.x - px * xv)));
             const double ay = etaP * (dL * (xv * (A1.y - py * xv)));
             r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
-            st.x = st.x - ax / sPn;
-            st.y = st.y - ay / sPn;
+            st.x = st.x - ax * rsPn;
+            st.y = st.y - ay * rsPn;
             *reinterpret_cast<double2*>(M.P + (size_t)j * M.Kp + 2 * l) = st;
           }
         }
@@ -669,6 +699,7 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
   }
   r_viol = dev::wave_sum(r_viol);
   if (lane == 0) s_viol[wv] = r_viol;
+  if (SPW == 1 && NFM_WAVE_STAGE2 && lane == 0) s_y[sib] = valid ? dev::loss_value(O.loss, O.loss_param, y, yh_w) : 0.0;
   __syncthreads();
   if (threadIdx.x == 0) {
     PartA p{0.0, 0.0, 0.0, 0.0};
@@ -682,6 +713,170 @@ __global__ __launch_bounds__(kBlock) void k_row_phase(RowArgs a) {
       p = PartA{s_part[0], 0.0, s_part[2], s_part[3]};
     }
     for (int w_ = 0; w_ < kWavesPerBlock; ++w_) p.viol += s_viol[w_];
+    a.parts[blockIdx.x] = p;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row phase, register-resident rows, persistent wavefronts (SGD, one order of degree 2, one sample per
+// wavefront = L * SPLIT == 64, rows of at most 64 entries incl. dummy features).
+//
+// Same arithmetic as k_row_phase MODE 2.  What differs is the schedule: the launch holds one resident
+// set of wavefronts (2 per SIMD at ~230 VGPRs) and each wavefront walks samples w, w + W, w + 2W, ...;
+// while it works on a sample it has the NEXT sample's CSR header (indptr, target, touch offset) and
+// entries (index, value, single flag, linear weight) in flight -- the header loads are issued before
+// the current sample's 32 row loads (so waiting for them does not wait for the rows: vmcnt retires
+// in order), the entry loads right after.  The three dependent round trips in front of a sample's row
+// loads (perm/indptr -> entries -> rows) are thereby off the critical path.
+// ------------------------------------------------------------------------------------------------
+template <int L, int SPLIT>
+__global__ __launch_bounds__(kBlock, 2) void k_row_phase_reg(RowArgs a) {  // 2 wavefronts per SIMD: <= 256 registers
+  static_assert(L * SPLIT == kWave, "one sample per wavefront");
+  constexpr int NQ = L;
+  __shared__ double s_red[kWavesPerBlock][4];
+  const CsrView& X = a.X;
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int slot = lane / L, l = lane % L;
+  const int n_waves = gridDim.x * kWavesPerBlock;
+  const double sP = a.scales[0], sw = a.scales[1], sPn = a.scales_n[0], swn = a.scales_n[1];
+  const double rsPn = 1.0 / sPn;
+  const double b0 = M.sc[SC_INTERCEPT];
+  const double it_base = a.it0p[0] + a.it_b;
+  double w_loss = 0.0, w_acc0 = 0.0, w_acc1 = 0.0, w_viol = 0.0;  // this wavefront's partial sums
+
+  struct Hdr {
+    int64_t q0;
+    const uint8_t* sg;
+    double y;
+    int m, m_tot;
+  };
+  auto load_hdr = [&](int pib) {
+    Hdr h{0, nullptr, 0.0, 0, 0};
+    if (pib < a.len) {
+      const int64_t pos = a.p0 + pib;
+      const int64_t i = a.perm ? a.perm[pos] : a.begin + pos;
+      h.q0 = X.indptr[i];
+      h.m = (int)(X.indptr[i + 1] - h.q0);
+      h.m_tot = h.m + M.n_aug;
+      h.y = dev::target_of(X.y[i], M.task);
+      h.sg = a.single + a.toff[pos];
+    }
+    return h;
+  };
+  struct Ent {
+    int j, f;
+    double x, w;
+  };
+  auto load_ent = [&](const Hdr& h) {
+    Ent e{0, 0, 0.0, 0.0};
+    dev::row_entry(X, h.q0, h.m, h.m_tot, lane, e.j, e.x);
+    if (lane < h.m_tot) e.f = (int)h.sg[lane];
+    if (lane < h.m) e.w = M.w[e.j];
+    return e;
+  };
+
+  int pib = blockIdx.x * kWavesPerBlock + wv;
+  Hdr h = load_hdr(pib);
+  Ent en = load_ent(h);
+#pragma unroll 1
+  while (pib < a.len) {  // wave-uniform
+    const int pib_n = pib + n_waves;
+    const Hdr hn = load_hdr(pib_n);  // issued before this sample's row loads
+    double2 prow[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int jj = lane_bcast_i<SPLIT>(en.j, u, slot);
+      prow[u] = *reinterpret_cast<const double2*>(M.P + (size_t)jj * M.Kp + 2 * l);
+    }
+    const Ent nx = load_ent(hn);  // in flight behind the rows, consumed in the next iteration
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- forward ----
+    double part = lane < h.m ? (sw * en.w) * en.x : 0.0;
+    double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const double xx = lane_bcast_d<SPLIT>(en.x, u, slot);
+      const double tx = xx * (sP * prow[u].x), ty = xx * (sP * prow[u].y);
+      a1.x += tx;
+      a1.y += ty;
+      a2.x += tx * tx;
+      a2.y += ty * ty;
+    }
+#pragma unroll
+    for (int s = L; s < kWave; s <<= 1) {
+      a1.x += dev::shfl_xor_d(a1.x, s);
+      a1.y += dev::shfl_xor_d(a1.y, s);
+      a2.x += dev::shfl_xor_d(a2.x, s);
+      a2.y += dev::shfl_xor_d(a2.y, s);
+    }
+    if (slot == 0) {
+      *reinterpret_cast<double2*>(a.Abuf + (size_t)pib * a.TA * M.Kp + 2 * l) = a1;
+      part += (a1.x * a1.x - a2.x) / 2 + (a1.y * a1.y - a2.y) / 2;
+    }
+#pragma unroll
+    for (int s = 1; s < kWave; s <<= 1) part += dev::shfl_xor_d(part, s);
+    // ---- loss, step sizes ----
+    const double yh = b0 + part;
+    const double dL = dev::loss_grad(O.loss, O.loss_param, h.y, yh);
+    const double it = it_base + (double)pib;
+    const double etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+    const double etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
+    if (lane == 0) {
+      a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
+      w_loss += dev::loss_value(O.loss, O.loss_param, h.y, yh);
+      if (M.fit_intercept) {
+        const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
+        w_acc0 += eta0 * dL;
+        w_acc1 += eta0;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- singles: updated from the rows still in registers ----
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      if ((u & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // keep the broadcasts next to their use
+      const int f = lane_bcast_i<SPLIT>(en.f, u, slot);  // read with every lane active
+      const int j = lane_bcast_i<SPLIT>(en.j, u, slot);
+      const double xv = lane_bcast_d<SPLIT>(en.x, u, slot);
+      if (f) {
+        double2 st = prow[u];
+        const double px = sP * st.x, py = sP * st.y;
+        const double ax = etaP * (dL * (xv * (a1.x - px * xv)));
+        const double ay = etaP * (dL * (xv * (a1.y - py * xv)));
+        w_viol += fabs(ax + etaP * O.beta * px) + fabs(ay + etaP * O.beta * py);
+        st.x = st.x - ax * rsPn;
+        st.y = st.y - ay * rsPn;
+        *reinterpret_cast<double2*>(M.P + (size_t)j * M.Kp + 2 * l) = st;
+      }
+    }
+    if (en.f && M.fit_linear && lane < h.m) {  // the linear term, one entry per lane
+      const double wj = sw * en.w;
+      const double a0 = etaw * (dL * en.x);
+      w_viol += fabs(a0 + etaw * O.alpha * wj);
+      M.w[en.j] = en.w - a0 / swn;
+    }
+    h = hn;
+    en = nx;
+    pib = pib_n;
+  }
+  w_viol = dev::wave_sum(w_viol);
+  if (lane == 0) {
+    s_red[wv][0] = w_loss;
+    s_red[wv][1] = w_viol;
+    s_red[wv][2] = w_acc0;
+    s_red[wv][3] = w_acc1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PartA p{0.0, 0.0, 0.0, 0.0};
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) {
+      p.loss += s_red[w_][0];
+      p.viol += s_red[w_][1];
+      p.acc0 += s_red[w_][2];
+      p.acc1 += s_red[w_][3];
+    }
     a.parts[blockIdx.x] = p;
   }
 }
@@ -1193,14 +1388,26 @@ __global__ __launch_bounds__(kBlock) void k_epoch_close(const double* __restrict
 // host driver
 // ------------------------------------------------------------------------------------------------
 template <int L, int SPLIT, int OPT, bool GEN>
-static void launch_row(hipStream_t st, const RowArgs& ra, int mode) {
+static void launch_row(hipStream_t st, const RowArgs& ra, int mode, int n_cu, int* n_blocks) {
   const bool sing = ra.single != nullptr;
   constexpr int SPW = kWave / (L * SPLIT);
   const int nA = (ra.len + kWavesPerBlock * SPW - 1) / (kWavesPerBlock * SPW);
+  *n_blocks = nA;
   constexpr bool CAN_HOLD = !GEN && held_entries<L, SPLIT>() > 0;
   constexpr bool CAN_REG = CAN_HOLD && OPT == OPT_SGD && L * SPLIT == kWave;
-  if (CAN_REG && mode == 2)
-    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 2 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
+  if (CAN_REG && mode == 2) {
+    // NFM_REG_PERSIST=1: persistent wavefronts with the next sample's CSR row prefetched (k_row_phase_reg).
+    // Off by default: the compiler does not fit the loop into 256 registers (200 spilled: 197 vs 110 us)
+    static const bool persist = getenv("NFM_REG_PERSIST") && atoi(getenv("NFM_REG_PERSIST")) != 0;
+    static const int wg_per_cu = getenv("NFM_REG_WG") ? atoi(getenv("NFM_REG_WG")) : 2;
+    if (persist) {
+      const int grid = nA < n_cu * wg_per_cu ? nA : n_cu * wg_per_cu;
+      hipLaunchKernelGGL((k_row_phase_reg<(CAN_REG ? L : 32), (CAN_REG ? SPLIT : 2)>), dim3(grid), dim3(kBlock), 0, st, ra);
+      *n_blocks = grid;
+    } else {
+      hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 2 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
+    }
+  }
   else if (CAN_HOLD && mode == 3)
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_HOLD ? 3 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
   else if (CAN_HOLD && mode >= 1)
@@ -1269,13 +1476,12 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
                  W.partsA.as<PartA>()};
       TimedLaunch tl(ctx, "row_phase");
       int s_used;
-      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra, mode_for(R >= 16 ? 16 : R)); s_used = R >= 16 ? 16 : R; }
-      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra, mode_for(R >= 8 ? 8 : R)); s_used = R >= 8 ? 8 : R; }
-      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra, mode_for(R >= 4 ? 4 : R)); s_used = R >= 4 ? 4 : R; }
-      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT, GEN>(st, ra, mode_for(R >= 2 ? 2 : R)); s_used = R >= 2 ? 2 : R; }
-      else { launch_row<L, 1, OPT, GEN>(st, ra, mode_for(1)); s_used = 1; }
-      const int spw = kWave / (L * s_used);
-      nA = (len + kWavesPerBlock * spw - 1) / (kWavesPerBlock * spw);
+      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra, mode_for(R >= 16 ? 16 : R), ctx->n_cu, &nA); s_used = R >= 16 ? 16 : R; }
+      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra, mode_for(R >= 8 ? 8 : R), ctx->n_cu, &nA); s_used = R >= 8 ? 8 : R; }
+      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra, mode_for(R >= 4 ? 4 : R), ctx->n_cu, &nA); s_used = R >= 4 ? 4 : R; }
+      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT, GEN>(st, ra, mode_for(R >= 2 ? 2 : R), ctx->n_cu, &nA); s_used = R >= 2 ? 2 : R; }
+      else { launch_row<L, 1, OPT, GEN>(st, ra, mode_for(1), ctx->n_cu, &nA); s_used = 1; }
+      (void)s_used;  // nA = workgroups launched (their per-workgroup partials are what the closer adds up)
     }
     const int64_t u0 = P.bat_uoff[b], u1 = P.bat_uoff[b + 1];
     const int per_block = kWavesPerBlock * R;
