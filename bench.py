@@ -172,13 +172,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libnimfm_hip has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; NIMFM_BENCH_BACKEND=gloo rehearses the multi-process path on fewer GPUs than
+    # ranks (ranks then share devices; RCCL needs one GPU per rank)
+    backend = os.environ.get("NIMFM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     wl = dict(WORKLOADS[args.workload])
     if args.n:
         wl["n"] = args.n
@@ -187,7 +194,7 @@ def main():
     if not args.batch:
         args.batch = wl["batch"]
 
-    ctx = nf.Context(local_rank)
+    ctx = nf.Context(dev_index)
     nf.set_default_context(ctx)
     # ---- synthetic shard, generated on the device (data seed 42 + rank; model seed 1) ----
     F = wl.get("fields", 0)

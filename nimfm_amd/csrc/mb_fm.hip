@@ -718,170 +718,6 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
 }
 
 // ------------------------------------------------------------------------------------------------
-// row phase, register-resident rows, persistent wavefronts (SGD, one order of degree 2, one sample per
-// wavefront = L * SPLIT == 64, rows of at most 64 entries incl. dummy features).
-//
-// Same arithmetic as k_row_phase MODE 2.  What differs is the schedule: the launch holds one resident
-// set of wavefronts (2 per SIMD at ~230 VGPRs) and each wavefront walks samples w, w + W, w + 2W, ...;
-// while it works on a sample it has the NEXT sample's CSR header (indptr, target, touch offset) and
-// entries (index, value, single flag, linear weight) in flight -- the header loads are issued before
-// the current sample's 32 row loads (so waiting for them does not wait for the rows: vmcnt retires
-// in order), the entry loads right after.  The three dependent round trips in front of a sample's row
-// loads (perm/indptr -> entries -> rows) are thereby off the critical path.
-// ------------------------------------------------------------------------------------------------
-template <int L, int SPLIT>
-__global__ __launch_bounds__(kBlock, 2) void k_row_phase_reg(RowArgs a) {  // 2 wavefronts per SIMD: <= 256 registers
-  static_assert(L * SPLIT == kWave, "one sample per wavefront");
-  constexpr int NQ = L;
-  __shared__ double s_red[kWavesPerBlock][4];
-  const CsrView& X = a.X;
-  const ModelView& M = a.M;
-  const OptView& O = a.O;
-  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-  const int slot = lane / L, l = lane % L;
-  const int n_waves = gridDim.x * kWavesPerBlock;
-  const double sP = a.scales[0], sw = a.scales[1], sPn = a.scales_n[0], swn = a.scales_n[1];
-  const double rsPn = 1.0 / sPn;
-  const double b0 = M.sc[SC_INTERCEPT];
-  const double it_base = a.it0p[0] + a.it_b;
-  double w_loss = 0.0, w_acc0 = 0.0, w_acc1 = 0.0, w_viol = 0.0;  // this wavefront's partial sums
-
-  struct Hdr {
-    int64_t q0;
-    const uint8_t* sg;
-    double y;
-    int m, m_tot;
-  };
-  auto load_hdr = [&](int pib) {
-    Hdr h{0, nullptr, 0.0, 0, 0};
-    if (pib < a.len) {
-      const int64_t pos = a.p0 + pib;
-      const int64_t i = a.perm ? a.perm[pos] : a.begin + pos;
-      h.q0 = X.indptr[i];
-      h.m = (int)(X.indptr[i + 1] - h.q0);
-      h.m_tot = h.m + M.n_aug;
-      h.y = dev::target_of(X.y[i], M.task);
-      h.sg = a.single + a.toff[pos];
-    }
-    return h;
-  };
-  struct Ent {
-    int j, f;
-    double x, w;
-  };
-  auto load_ent = [&](const Hdr& h) {
-    Ent e{0, 0, 0.0, 0.0};
-    dev::row_entry(X, h.q0, h.m, h.m_tot, lane, e.j, e.x);
-    if (lane < h.m_tot) e.f = (int)h.sg[lane];
-    if (lane < h.m) e.w = M.w[e.j];
-    return e;
-  };
-
-  int pib = blockIdx.x * kWavesPerBlock + wv;
-  Hdr h = load_hdr(pib);
-  Ent en = load_ent(h);
-#pragma unroll 1
-  while (pib < a.len) {  // wave-uniform
-    const int pib_n = pib + n_waves;
-    const Hdr hn = load_hdr(pib_n);  // issued before this sample's row loads
-    double2 prow[NQ];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const int jj = lane_bcast_i<SPLIT>(en.j, u, slot);
-      prow[u] = *reinterpret_cast<const double2*>(M.P + (size_t)jj * M.Kp + 2 * l);
-    }
-    const Ent nx = load_ent(hn);  // in flight behind the rows, consumed in the next iteration
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- forward ----
-    double part = lane < h.m ? (sw * en.w) * en.x : 0.0;
-    double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const double xx = lane_bcast_d<SPLIT>(en.x, u, slot);
-      const double tx = xx * (sP * prow[u].x), ty = xx * (sP * prow[u].y);
-      a1.x += tx;
-      a1.y += ty;
-      a2.x += tx * tx;
-      a2.y += ty * ty;
-    }
-#pragma unroll
-    for (int s = L; s < kWave; s <<= 1) {
-      a1.x += dev::shfl_xor_d(a1.x, s);
-      a1.y += dev::shfl_xor_d(a1.y, s);
-      a2.x += dev::shfl_xor_d(a2.x, s);
-      a2.y += dev::shfl_xor_d(a2.y, s);
-    }
-    if (slot == 0) {
-      *reinterpret_cast<double2*>(a.Abuf + (size_t)pib * a.TA * M.Kp + 2 * l) = a1;
-      part += (a1.x * a1.x - a2.x) / 2 + (a1.y * a1.y - a2.y) / 2;
-    }
-#pragma unroll
-    for (int s = 1; s < kWave; s <<= 1) part += dev::shfl_xor_d(part, s);
-    // ---- loss, step sizes ----
-    const double yh = b0 + part;
-    const double dL = dev::loss_grad(O.loss, O.loss_param, h.y, yh);
-    const double it = it_base + (double)pib;
-    const double etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
-    const double etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
-    if (lane == 0) {
-      a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
-      w_loss += dev::loss_value(O.loss, O.loss_param, h.y, yh);
-      if (M.fit_intercept) {
-        const double eta0 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
-        w_acc0 += eta0 * dL;
-        w_acc1 += eta0;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- singles: updated from the rows still in registers ----
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      if ((u & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // keep the broadcasts next to their use
-      const int f = lane_bcast_i<SPLIT>(en.f, u, slot);  // read with every lane active
-      const int j = lane_bcast_i<SPLIT>(en.j, u, slot);
-      const double xv = lane_bcast_d<SPLIT>(en.x, u, slot);
-      if (f) {
-        double2 st = prow[u];
-        const double px = sP * st.x, py = sP * st.y;
-        const double ax = etaP * (dL * (xv * (a1.x - px * xv)));
-        const double ay = etaP * (dL * (xv * (a1.y - py * xv)));
-        w_viol += fabs(ax + etaP * O.beta * px) + fabs(ay + etaP * O.beta * py);
-        st.x = st.x - ax * rsPn;
-        st.y = st.y - ay * rsPn;
-        *reinterpret_cast<double2*>(M.P + (size_t)j * M.Kp + 2 * l) = st;
-      }
-    }
-    if (en.f && M.fit_linear && lane < h.m) {  // the linear term, one entry per lane
-      const double wj = sw * en.w;
-      const double a0 = etaw * (dL * en.x);
-      w_viol += fabs(a0 + etaw * O.alpha * wj);
-      M.w[en.j] = en.w - a0 / swn;
-    }
-    h = hn;
-    en = nx;
-    pib = pib_n;
-  }
-  w_viol = dev::wave_sum(w_viol);
-  if (lane == 0) {
-    s_red[wv][0] = w_loss;
-    s_red[wv][1] = w_viol;
-    s_red[wv][2] = w_acc0;
-    s_red[wv][3] = w_acc1;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    PartA p{0.0, 0.0, 0.0, 0.0};
-    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) {
-      p.loss += s_red[w_][0];
-      p.viol += s_red[w_][1];
-      p.acc0 += s_red[w_][2];
-      p.acc1 += s_red[w_][3];
-    }
-    a.parts[blockIdx.x] = p;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // column phase (+ batch close in workgroup 0)
 // ------------------------------------------------------------------------------------------------
 struct ColArgs {
@@ -1395,19 +1231,8 @@ static void launch_row(hipStream_t st, const RowArgs& ra, int mode, int n_cu, in
   *n_blocks = nA;
   constexpr bool CAN_HOLD = !GEN && held_entries<L, SPLIT>() > 0;
   constexpr bool CAN_REG = CAN_HOLD && OPT == OPT_SGD && L * SPLIT == kWave;
-  if (CAN_REG && mode == 2) {
-    // NFM_REG_PERSIST=1: persistent wavefronts with the next sample's CSR row prefetched (k_row_phase_reg).
-    // Off by default: the compiler does not fit the loop into 256 registers (200 spilled: 197 vs 110 us)
-    static const bool persist = getenv("NFM_REG_PERSIST") && atoi(getenv("NFM_REG_PERSIST")) != 0;
-    static const int wg_per_cu = getenv("NFM_REG_WG") ? atoi(getenv("NFM_REG_WG")) : 2;
-    if (persist) {
-      const int grid = nA < n_cu * wg_per_cu ? nA : n_cu * wg_per_cu;
-      hipLaunchKernelGGL((k_row_phase_reg<(CAN_REG ? L : 32), (CAN_REG ? SPLIT : 2)>), dim3(grid), dim3(kBlock), 0, st, ra);
-      *n_blocks = grid;
-    } else {
-      hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 2 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
-    }
-  }
+  if (CAN_REG && mode == 2)
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 2 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
   else if (CAN_HOLD && mode == 3)
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_HOLD ? 3 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
   else if (CAN_HOLD && mode >= 1)
