@@ -292,6 +292,12 @@ __device__ __forceinline__ int lane_bcast_i(int v, int u, int slot) {
   }
   return r;
 }
+// a value every lane of the wavefront holds identically, moved to scalar registers (one sample per
+// wavefront: the sample's target, step sizes, loss derivative ... need not occupy 64 lanes each)
+__device__ __forceinline__ double wave_uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 template <int SPLIT>
 __device__ __forceinline__ double lane_bcast_d(double v, int u, int slot) {
   const int lo = lane_bcast_i<SPLIT>(__double2loint(v), u, slot), hi = lane_bcast_i<SPLIT>(__double2hiint(v), u, slot);
@@ -316,8 +322,11 @@ constexpr int held_entries() {  // E: entries per lane; 0 = no held mode for thi
   return LPS >= kWave ? 1 : (LPS >= 8 ? (kWave / LPS > 4 ? 4 : kWave / LPS) : 0);
 }
 
+// MODE 2 at k = 64 needs 170 registers as written; three wavefronts per SIMD allow 168.  Asking for
+// three costs 4 spilled registers and gains 7 % (107 -> 100 us on the headline shape); with the target,
+// step sizes and loss derivative still in vector registers (180) the same request spilled 68 and lost.
 #ifndef NFM_REG_MINW
-#define NFM_REG_MINW 1
+#define NFM_REG_MINW 3
 #endif
 template <int L, int SPLIT, int OPT, bool GEN, int MODE, bool SING>
 __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_phase(RowArgs a) {
@@ -337,7 +346,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   const int sidx = lane / LPS, slot = (lane / L) % SPLIT, l = lane % L;
   const int sib = wv * SPW + sidx;  // sample inside the block
-  const int pib = blockIdx.x * SPB + sib;
+  // one sample per wavefront: the sample index is wave-uniform, and so is everything read through it
+  // (CSR header, target: scalar loads, scalar registers)
+  const int pib = SPW == 1 ? __builtin_amdgcn_readfirstlane(blockIdx.x * SPB + sib) : blockIdx.x * SPB + sib;
   const bool valid = pib < a.len;
   int64_t i = 0, q0 = 0;
   int m = 0, m_tot = 0;
@@ -349,6 +360,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
     m = (int)(X.indptr[i + 1] - q0);
     m_tot = m + M.n_aug;
     y = dev::target_of(X.y[i], M.task);
+    if (SPW == 1) y = wave_uniform(y);
   }
   double* Arow = a.Abuf + (size_t)(valid ? pib : 0) * a.TA * M.Kp;
   double b0 = M.sc[SC_INTERCEPT];
@@ -367,9 +379,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
   double etaP = 0.0, etaw = 0.0, eta_b = 0.0;
   if (SPW == 1 && NFM_WAVE_STAGE2 && OPT == OPT_SGD) {
     const double it = (a.it0p[0] + a.it_b) + (double)pib;
-    etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
-    etaw = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
-    if (M.fit_intercept) eta_b = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it);
+    etaP = wave_uniform(dev::get_eta(O.sched, O.eta0, O.power, O.beta, it));
+    etaw = wave_uniform(dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it));
+    if (M.fit_intercept) eta_b = wave_uniform(dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it));
   }
   // ---- 1. forward: yhat of every sample of the block ----
   // ---- held entries: a chunk of CAP = E * LPS entries of the row in one round trip (index, value, single
@@ -406,6 +418,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
       const int o = __shfl_xor(m_max, s, kWave);
       m_max = o > m_max ? o : m_max;
     }
+    m_max = __builtin_amdgcn_readfirstlane(m_max);
     // MODE 2: the first chunk's parameter rows stay in registers (prow); further chunks and MODE 1
     // stream the rows in groups of U, addressed from the held entries: one round trip per group
     constexpr int U = RPS < dev::kFwdUnroll ? RPS : dev::kFwdUnroll;
@@ -501,9 +514,9 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
     // ---- 2'. one sample per wavefront (k > 32): every wavefront finishes its own sample, no
     // workgroup barrier between the forward pass and the singles update, so the four wavefronts of a
     // workgroup drift apart and their load and store phases overlap ----
-    const double yh = b0 + part;
+    const double yh = wave_uniform(b0 + part);
     yh_w = yh;
-    dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
+    dL = wave_uniform(dev::loss_grad(O.loss, O.loss_param, y, yh));
     double r_acc0 = 0.0, r_acc1 = 0.0;
     if (OPT == OPT_SGD) {
       if (M.fit_intercept) {
