@@ -1113,7 +1113,10 @@ __global__ __launch_bounds__(kBlock) void k_singles(ColArgs a) {
   }
 }
 
-template <int L, int OPT, bool GEN, int TU>
+// STRIDED: the feature workgroups loop over the features (capped grid); otherwise one lane group = one
+// feature and no loop -- the loop costs registers (94 vs 80: 5 instead of 6 wavefronts per SIMD), which
+// the dense regime (cfg2) pays for without needing it
+template <int L, int OPT, bool GEN, int TU, bool STRIDED>
 __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
   constexpr int R = kWave / L;
   __shared__ double red[5][kBlock];
@@ -1128,7 +1131,8 @@ __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
   // resident set of wavefronts (host: run_batches), so no wavefront waits for a slot and the
   // per-workgroup launch cost is paid once per ~8 features instead of once per feature
   const int64_t stride = (int64_t)(gridDim.x - 1) * kWavesPerBlock * R;
-  for (int64_t u = closer ? a.u1 : a.u0 + ((int64_t)fb * kWavesPerBlock + wv) * R + g; u < a.u1; u += stride) {
+  for (int64_t u = closer ? a.u1 : a.u0 + ((int64_t)fb * kWavesPerBlock + wv) * R + g; u < a.u1;
+       u = STRIDED ? u + stride : a.u1) {
     // heavy features of degree-2 models are summed by k_heavy_partial / k_heavy_apply
     if (!GEN && a.uptr[u + 1] - a.uptr[u] > kHeavyTouches) continue;
     const int64_t j = a.ucol[u];
@@ -1330,7 +1334,9 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     // Fewer, longer wavefronts (cfg2: 12.5k wavefronts of 8 features x 10 touches) balance better
     // when the hardware hands out workgroups one by one (capped: 46 us, uncapped: 38 us).
     static const int col_wg_per_cu = getenv("NFM_COL_WG") ? atoi(getenv("NFM_COL_WG")) : 8;
-    if (col_wg_per_cu > 0 && nB > 4 * ctx->n_cu * col_wg_per_cu) nB = ctx->n_cu * col_wg_per_cu;
+    // the tuning variants TU = 1 / 4 (NFM_TU) are not strided
+    const bool nB_capped = tu == 2 && col_wg_per_cu > 0 && nB > 4 * ctx->n_cu * col_wg_per_cu;
+    if (nB_capped) nB = ctx->n_cu * col_wg_per_cu;
     nB += 1;  // + the closing workgroup
     const int nS = singles_in_col ? (len + kWavesPerBlock - 1) / kWavesPerBlock : 0;
     // the singles kernel writes parts[0, nS), the column phase parts[nS, nS + nB)
@@ -1350,12 +1356,15 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
         hipLaunchKernelGGL((k_singles<L, OPT>), dim3(nS), dim3(kBlock), 0, st, ca);
       }
       TimedLaunch tl(ctx, "col_phase");
+      const bool strided = nB_capped;
       if (tu == 1)
-        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 1>), dim3(nB), dim3(kBlock), 0, st, ca);
+        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 1, false>), dim3(nB), dim3(kBlock), 0, st, ca);
       else if (tu == 4)
-        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 4>), dim3(nB), dim3(kBlock), 0, st, ca);
+        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 4, false>), dim3(nB), dim3(kBlock), 0, st, ca);
+      else if (strided)
+        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 2, true>), dim3(nB), dim3(kBlock), 0, st, ca);
       else
-        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 2>), dim3(nB), dim3(kBlock), 0, st, ca);
+        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 2, false>), dim3(nB), dim3(kBlock), 0, st, ca);
     }
     int nH = 0;
     if (!GEN && P.bat_hoff[b + 1] > P.bat_hoff[b]) {
