@@ -16,6 +16,7 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/nimfm_hip.h"
@@ -58,8 +59,18 @@ class CSRDataset {
     check(nfm_dataset_create_csr(default_context(), nSamples, nFeatures, indptr.data(), indices.data(), data.data(), nullptr,
                                  0, nullptr, &h_));
   }
+  // a dataset made by one of the loaders below (the handle is adopted)
+  explicit CSRDataset(nfm_dataset* h) : h_(h) {
+    int64_t nnz = 0, nf = 0;
+    check(nfm_dataset_shape(h_, &n_, &d_, &nnz, &nf));
+  }
   CSRDataset(const CSRDataset&) = delete;
   ~CSRDataset() { nfm_dataset_destroy(h_); }
+  std::vector<double> targets() const {  // the loaders' y
+    std::vector<double> y((size_t)n_);
+    check(nfm_dataset_get_targets(h_, y.data()));
+    return y;
+  }
   int64_t nSamples() const { return n_; }
   int64_t nFeatures() const { return d_; }
   nfm_dataset* handle() const { return h_; }
@@ -68,6 +79,21 @@ class CSRDataset {
   nfm_dataset* h_ = nullptr;
   int64_t n_, d_;
 };
+
+// loadSVMLightFile (dataset.nim:616-632): the text is parsed on the GPU, y comes back with the dataset
+inline std::unique_ptr<CSRDataset> loadSVMLightFile(const std::string& f, std::vector<double>& y, int64_t nFeatures = -1) {
+  nfm_dataset* h = nullptr;
+  check(nfm_dataset_load_svmlight(default_context(), f.c_str(), nFeatures, &h));
+  std::unique_ptr<CSRDataset> X(new CSRDataset(h));
+  y = X->targets();
+  return X;
+}
+// newStreamCSRDataset + loadStreamLabel (dataset.nim:170-174, 1007-1014): the whole file becomes resident
+inline std::unique_ptr<CSRDataset> newStreamCSRDataset(const std::string& f, const std::string& fY = "") {
+  nfm_dataset* h = nullptr;
+  check(nfm_dataset_load_stream(default_context(), f.c_str(), fY.empty() ? nullptr : fY.c_str(), &h));
+  return std::unique_ptr<CSRDataset>(new CSRDataset(h));
+}
 
 class FactorizationMachine {
  public:
@@ -131,15 +157,14 @@ class FactorizationMachine {
     for (size_t i = 0; i < y.size(); ++i) r[i] = (y[i] > 0) - (y[i] < 0);
     return r;
   }
-  double score(const CSRDataset& X, const std::vector<double>& y) {  // fm_base.nim:39-48
-    auto p = decisionFunction(X);
-    double acc = 0.0;
-    if (task == regression) {
-      for (size_t i = 0; i < y.size(); ++i) acc += (p[i] - y[i]) * (p[i] - y[i]);
-      return std::sqrt(acc / (double)y.size());
-    }
-    for (size_t i = 0; i < y.size(); ++i) acc += ((y[i] > 0) - (y[i] < 0)) == ((p[i] > 0) - (p[i] < 0));
-    return acc / (double)y.size();
+  double score(const CSRDataset& X, const std::vector<double>& y) {  // fm_base.nim:39-48, reduced on the device
+    if (!isInitialized) throw NotFittedError("Factorization machines is not fitted.");
+    if (X.nFeatures() != d_) throw std::invalid_argument("Invalid nFeatures.");
+    if ((int64_t)y.size() != X.nSamples()) throw std::invalid_argument("len(y) != nSamples");
+    check(nfm_dataset_set_targets(X.handle(), y.data()));
+    double out = 0.0;
+    check(nfm_score(push(), X.handle(), &out));
+    return out;
   }
 
   nfm_model* push() {  // device copy of the host parameters

@@ -85,6 +85,34 @@ int main() {
     a5.fit(X, y, e2);
     for (size_t e = 0; e < c.P.size(); ++e) CHECK(std::fabs(c.P[e] - e2.P[e]) < 1e-8);
   }
+  {  // loader: dump a small svmlight file (1-based, dumpSVMLightFile's layout), load it on the GPU, same scores
+    const char* path = "/tmp/nimfm_host_mirror_test.svm";
+    FILE* f = std::fopen(path, "w");
+    const int64_t nn = 6;
+    const double yy[6] = {1.0, -1.0, 0.5, 2.0, -0.25, 0.0};
+    const int64_t ip[7] = {0, 2, 3, 3, 5, 6, 8};
+    const int64_t ix[8] = {0, 3, 1, 2, 4, 0, 1, 4};
+    const double xv[8] = {0.5, -1.25, 2.0, 0.1, 0.30000000000000004, 1e-3, -7.0, 3.5};
+    for (int64_t i = 0; i < nn; ++i) {
+      std::fprintf(f, "%.17g", yy[i]);
+      for (int64_t q = ip[i]; q < ip[i + 1]; ++q) std::fprintf(f, " %lld:%.17g", (long long)ix[q] + 1, xv[q]);
+      if (i + 1 != nn) std::fprintf(f, "\n");
+    }
+    std::fclose(f);
+    std::vector<double> yl;
+    auto Xl = loadSVMLightFile(path, yl);
+    CHECK(Xl->nSamples() == nn && Xl->nFeatures() == 5);
+    for (int64_t i = 0; i < nn; ++i) CHECK(yl[i] == yy[i]);
+    CSRDataset Xh(std::vector<double>(xv, xv + 8), std::vector<int64_t>(ix, ix + 8), std::vector<int64_t>(ip, ip + 7), nn, 5);
+    FactorizationMachine fm(regression, 2, 3, explicit_, true, true, true);
+    fm.init(Xh);
+    auto a = fm.decisionFunction(Xh), b = fm.decisionFunction(*Xl);
+    for (int64_t i = 0; i < nn; ++i) CHECK(a[i] == b[i]);
+    double acc = 0.0;  // score on the device == rmse by hand (metrics.nim:5-13)
+    for (int64_t i = 0; i < nn; ++i) acc += (a[i] - yy[i]) * (a[i] - yy[i]);
+    CHECK(std::fabs(fm.score(*Xl, yl) - std::sqrt(acc / nn)) < 1e-14);
+    std::remove(path);
+  }
   std::printf(fails ? "FAILED (%d)\n" : "host mirror ok\n", fails);
   return fails ? 1 : 0;
 }
