@@ -115,9 +115,11 @@ struct TimedLaunch {
 };
 int timing_flush(nfm_ctx* ctx);
 
-struct DevBuf {  // owned device allocation
+struct DevBuf {  // owned device allocation (blocks are recycled through a cache, util.hip)
   void* p = nullptr;
-  size_t bytes = 0;
+  size_t bytes = 0;  // what was asked for
+  size_t cap = 0;    // what the block holds
+  int device = 0;
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
@@ -129,8 +131,11 @@ struct DevBuf {  // owned device allocation
     release();
     p = o.p;
     bytes = o.bytes;
+    cap = o.cap;
+    device = o.device;
     o.p = nullptr;
     o.bytes = 0;
+    o.cap = 0;
   }
   template <class T>
   T* as() const { return reinterpret_cast<T*>(p); }

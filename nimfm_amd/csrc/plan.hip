@@ -329,8 +329,7 @@ int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_ho
     }
   }
   if (use_singles || want_tq) {  // the row phase finds a sample's per-nnz slots at toff[pos] + q
-    P.toff.p = toff.p; P.toff.bytes = toff.bytes;
-    toff.p = nullptr; toff.bytes = 0;
+    P.toff.take(toff);
   }
   return NFM_OK;  // temporaries are released by their destructors
 }
