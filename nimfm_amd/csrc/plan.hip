@@ -83,7 +83,7 @@ __global__ void k_expand(CsrView X, const int64_t* __restrict__ perm, int64_t be
 // per sorted touch r: is its feature touched exactly once in the batch (single), and is r the
 // first touch of a feature with >= 2 touches (head)?
 __global__ void k_classify(int64_t T, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, int use_singles,
-                           uint8_t* __restrict__ single_un, int64_t* __restrict__ multi, int64_t* __restrict__ head) {
+                           uint8_t* __restrict__ single_un, int32_t* __restrict__ multi, int32_t* __restrict__ head) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= T; r += (int64_t)gridDim.x * blockDim.x) {
     if (r == T) {
       multi[r] = 0;
@@ -101,7 +101,7 @@ __global__ void k_classify(int64_t T, const uint64_t* __restrict__ keys, const u
 }
 
 __global__ void k_compact(int64_t T, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                          const int64_t* __restrict__ mpos, const int64_t* __restrict__ uidx, int fbits,
+                          const int32_t* __restrict__ mpos, const int32_t* __restrict__ uidx, int fbits,
                           const int32_t* __restrict__ tpos_un, const double* __restrict__ tx_un,
                           const int64_t* __restrict__ tq_un, int32_t* __restrict__ tpos, double* __restrict__ tx,
                           int64_t* __restrict__ tq, int32_t* __restrict__ ucol, int64_t* __restrict__ uptr,
@@ -248,19 +248,23 @@ int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_ho
   //    to the column phase.  Their touches are compacted, payload in sorted order.
   DevBuf multi, mpos, head, uidx;
   if (use_singles) NFM_TRY(P.single.alloc(sizeof(uint8_t) * T));
-  NFM_TRY(multi.alloc(sizeof(int64_t) * (T + 1))); NFM_TRY(mpos.alloc(sizeof(int64_t) * (T + 1)));
-  NFM_TRY(head.alloc(sizeof(int64_t) * (T + 1))); NFM_TRY(uidx.alloc(sizeof(int64_t) * (T + 1)));
+  // flags and their scans in 32 bits (T < 2^31 is checked above): half the traffic of these passes
+  NFM_TRY(multi.alloc(sizeof(int32_t) * (T + 1))); NFM_TRY(mpos.alloc(sizeof(int32_t) * (T + 1)));
+  NFM_TRY(head.alloc(sizeof(int32_t) * (T + 1))); NFM_TRY(uidx.alloc(sizeof(int32_t) * (T + 1)));
   hipLaunchKernelGGL(k_classify, dim3(grid1d(T + 1)), dim3(kBlock), 0, st, T, keys, vals, use_singles ? 1 : 0,
-                     use_singles ? P.single.as<uint8_t>() : nullptr, multi.as<int64_t>(), head.as<int64_t>());
+                     use_singles ? P.single.as<uint8_t>() : nullptr, multi.as<int32_t>(), head.as<int32_t>());
   tmp_bytes = 0;
-  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, head.as<int64_t>(), uidx.as<int64_t>(), (int)(T + 1), st));
+  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, head.as<int32_t>(), uidx.as<int32_t>(), (int)(T + 1), st));
   NFM_TRY(tmp.alloc(tmp_bytes));
-  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, head.as<int64_t>(), uidx.as<int64_t>(), (int)(T + 1), st));
-  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, multi.as<int64_t>(), mpos.as<int64_t>(), (int)(T + 1), st));
+  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, head.as<int32_t>(), uidx.as<int32_t>(), (int)(T + 1), st));
+  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, multi.as<int32_t>(), mpos.as<int32_t>(), (int)(T + 1), st));
   int64_t U = 0, TM = 0;
-  NFM_HIP_CHECK(hipMemcpyAsync(&U, uidx.as<int64_t>() + T, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-  NFM_HIP_CHECK(hipMemcpyAsync(&TM, mpos.as<int64_t>() + T, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  int32_t U32 = 0, TM32 = 0;
+  NFM_HIP_CHECK(hipMemcpyAsync(&U32, uidx.as<int32_t>() + T, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipMemcpyAsync(&TM32, mpos.as<int32_t>() + T, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   NFM_HIP_CHECK(hipStreamSynchronize(st));
+  U = U32;
+  TM = TM32;
   P.U = U;
   P.TM = TM;
   NFM_TRY(P.tpos.alloc(sizeof(int32_t) * TM)); NFM_TRY(P.tx.alloc(sizeof(double) * TM));
@@ -272,7 +276,7 @@ int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_ho
   NFM_TRY(ubatch.alloc(sizeof(int64_t) * (U + 1)));
   const int64_t none = INT64_MAX;
   hipLaunchKernelGGL(k_set_i64, dim3(grid1d(P.n_batches)), dim3(kBlock), 0, st, bfu.as<int64_t>(), P.n_batches, none);
-  hipLaunchKernelGGL(k_compact, dim3(grid1d(T)), dim3(kBlock), 0, st, T, keys, vals, mpos.as<int64_t>(), uidx.as<int64_t>(),
+  hipLaunchKernelGGL(k_compact, dim3(grid1d(T)), dim3(kBlock), 0, st, T, keys, vals, mpos.as<int32_t>(), uidx.as<int32_t>(),
                      fbits, tpos_un.as<int32_t>(), tx_un.as<double>(), want_tq ? tq_un.as<int64_t>() : nullptr,
                      P.tpos.as<int32_t>(), P.tx.as<double>(), want_tq ? P.tq.as<int64_t>() : nullptr, P.ucol.as<int32_t>(),
                      P.uptr.as<int64_t>(), ubatch.as<int64_t>());
