@@ -44,10 +44,13 @@ def exchange(tensors, dist, world, rule, prevs=None, force=False):
         avg = dist.get_backend() == "nccl"  # RCCL averages inside the collective; gloo has no AVG
         for t in tensors:
             if avg:
-                dist.all_reduce(t, op=dist.ReduceOp.AVG)
-            else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                t.div_(world)
+                try:
+                    dist.all_reduce(t, op=dist.ReduceOp.AVG)
+                    continue
+                except RuntimeError:  # a build without ncclAvg for this dtype: sum, then scale
+                    avg = False
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t.div_(world)
     elif rule == "sum_deltas":
         for t, p in zip(tensors, prevs):
             t.sub_(p)
