@@ -893,42 +893,67 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
       }
     }
   } else {
-    for (int64_t t = t0; t < t1; ++t) {
-      const int pib = a.tpos[t];
-      const double x = a.tx[t];
-      const SampleRec r = a.rec[pib];
-      const double* Ar = a.Abuf + ((size_t)pib * a.TA + slot) * M.Kp + 2 * l;
-      double Ax[dev::kMaxDeg - 1], Ay[dev::kMaxDeg - 1];
+    // degree >= 3: the same walk (touches fetched LG at a time by the feature's lanes, records and A rows
+    // of two touches requested together); a touch needs the sample's deg - 1 A rows of this order
+    constexpr int TG = 2;
+    const int gbase = (int)(threadIdx.x & (kWave - 1)) - l;
+    for (int64_t tb = t0; tb < t1; tb += LG) {
+      const int64_t tl = tb + l;
+      const int pib_l = tl < t1 ? a.tpos[tl] : 0;
+      const double x_l = tl < t1 ? a.tx[tl] : 0.0;
+      const int cnt = (int)(t1 - tb < LG ? t1 - tb : LG);
+      for (int ub = 0; ub < cnt; ub += TG) {
+        int pib[TG];
+        double x[TG];
+        SampleRec r[TG];
+        double2 Av[TG][dev::kMaxDeg - 1];
 #pragma unroll
-      for (int tt = 0; tt < dev::kMaxDeg - 1; ++tt) {
-        Ax[tt] = 0.0;
-        Ay[tt] = 0.0;
-        if (tt < deg - 1) {
-          const double2 v = *reinterpret_cast<const double2*>(Ar + (size_t)tt * M.Kp);
-          Ax[tt] = v.x;
-          Ay[tt] = v.y;
+        for (int u = 0; u < TG; ++u) {
+          const int src = gbase + ((ub + u) < LG ? (ub + u) : 0);
+          pib[u] = __shfl(pib_l, src, kWave);
+          x[u] = dev::shfl_d(x_l, src);
         }
-      }
-      const double dAx = dev::anova_grad(deg, x, p.x, Ax);
-      const double dAy = dev::anova_grad(deg, x, p.y, Ay);
-      if (OPT == OPT_SGD) {
-        acc.x += r.etaP * (r.dL * dAx);
-        acc.y += r.etaP * (r.dL * dAy);
-        seta += r.etaP;
-        if (do_w) {
-          wacc.a0 += r.etaw * (r.dL * x);
-          wacc.a1 += r.etaw;
+#pragma unroll
+        for (int u = 0; u < TG; ++u) {
+          r[u] = a.rec[pib[u]];
+          const double* Ar = a.Abuf + ((size_t)pib[u] * a.TA + slot) * M.Kp + 2 * l;
+#pragma unroll
+          for (int tt = 0; tt < dev::kMaxDeg - 1; ++tt) {
+            Av[u][tt] = {0.0, 0.0};
+            if (tt < deg - 1) Av[u][tt] = *reinterpret_cast<const double2*>(Ar + (size_t)tt * M.Kp);
+          }
         }
-      } else {
-        const double gx = r.dL * dAx, gy = r.dL * dAy;
-        acc.x += gx;
-        acc.y += gy;
-        accn.x += gx * gx;
-        accn.y += gy * gy;
-        if (do_w) {
-          const double gw = r.dL * x;
-          wacc.a0 += gw;
-          wacc.a1 += gw * gw;
+#pragma unroll
+        for (int u = 0; u < TG; ++u) {
+          if (ub + u >= cnt) continue;
+          double Ax[dev::kMaxDeg - 1], Ay[dev::kMaxDeg - 1];
+#pragma unroll
+          for (int tt = 0; tt < dev::kMaxDeg - 1; ++tt) {
+            Ax[tt] = Av[u][tt].x;
+            Ay[tt] = Av[u][tt].y;
+          }
+          const double dAx = dev::anova_grad(deg, x[u], p.x, Ax);
+          const double dAy = dev::anova_grad(deg, x[u], p.y, Ay);
+          if (OPT == OPT_SGD) {
+            acc.x += r[u].etaP * (r[u].dL * dAx);
+            acc.y += r[u].etaP * (r[u].dL * dAy);
+            seta += r[u].etaP;
+            if (do_w) {
+              wacc.a0 += r[u].etaw * (r[u].dL * x[u]);
+              wacc.a1 += r[u].etaw;
+            }
+          } else {
+            const double gx = r[u].dL * dAx, gy = r[u].dL * dAy;
+            acc.x += gx;
+            acc.y += gy;
+            accn.x += gx * gx;
+            accn.y += gy * gy;
+            if (do_w) {
+              const double gw = r[u].dL * x[u];
+              wacc.a0 += gw;
+              wacc.a1 += gw * gw;
+            }
+          }
         }
       }
     }
