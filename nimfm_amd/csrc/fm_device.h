@@ -206,6 +206,34 @@ __device__ __forceinline__ void anova_fwd_deg2(const PS& ps, const CsrView& X, i
   A2 = a2;
 }
 
+// partial results over the SPLIT slots' disjoint nnz subsets combine by truncated polynomial multiplication
+template <int L, int SPLIT>
+__device__ __forceinline__ void combine_slots_degn(double2 (&E)[kMaxDeg + 1], int deg, int lane) {
+#pragma unroll
+  for (int s = L; s < L * SPLIT; s <<= 1) {
+    double2 lo[kMaxDeg + 1], hi[kMaxDeg + 1];
+    const bool upper = (lane & s) != 0;
+#pragma unroll
+    for (int t = 0; t <= kMaxDeg; ++t) {
+      double2 o;
+      o.x = shfl_xor_d(E[t].x, s);
+      o.y = shfl_xor_d(E[t].y, s);
+      lo[t] = upper ? o : E[t];  // both partners form the same (lo, hi) pair
+      hi[t] = upper ? E[t] : o;
+    }
+#pragma unroll
+    for (int t = 1; t <= kMaxDeg; ++t) {
+      double2 acc = {0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u <= t; ++u) {
+        acc.x += lo[u].x * hi[t - u].x;
+        acc.y += lo[u].y * hi[t - u].y;
+      }
+      if (t <= deg) E[t] = acc;
+    }
+  }
+}
+
 // ---- ANOVA forward, degree 3..kMaxDeg: the DP of optimizer/sgd.nim:152-159 (kernels.nim:54-58),
 // A[t] += A[t-1] * p * x for t = deg..1 per nnz.  A[t] is the t-th elementary symmetric polynomial
 // of {p_j x_j}; partial results over the SPLIT slots' disjoint nnz subsets combine by truncated
@@ -230,29 +258,7 @@ __device__ __forceinline__ void anova_fwd_degn(const PS& ps, const CsrView& X, i
         E[t].y += E[t - 1].y * p.y * x;
       }
   }
-#pragma unroll
-  for (int s = L; s < L * SPLIT; s <<= 1) {
-    double2 lo[kMaxDeg + 1], hi[kMaxDeg + 1];
-    const bool upper = (lane & s) != 0;
-#pragma unroll
-    for (int t = 0; t <= kMaxDeg; ++t) {
-      double2 o;
-      o.x = shfl_xor_d(E[t].x, s);
-      o.y = shfl_xor_d(E[t].y, s);
-      lo[t] = upper ? o : E[t];  // both partners form the same (lo, hi) pair
-      hi[t] = upper ? E[t] : o;
-    }
-#pragma unroll
-    for (int t = 1; t <= kMaxDeg; ++t) {
-      double2 acc = {0.0, 0.0};
-#pragma unroll
-      for (int u = 0; u <= t; ++u) {
-        acc.x += lo[u].x * hi[t - u].x;
-        acc.y += lo[u].y * hi[t - u].y;
-      }
-      if (t <= deg) E[t] = acc;
-    }
-  }
+  combine_slots_degn<L, SPLIT>(E, deg, lane);
 }
 
 // value of a compile-time-unrolled array at a run-time index

@@ -332,7 +332,7 @@ template <int L, int SPLIT, int OPT, bool GEN, int MODE, bool SING>
 __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_phase(RowArgs a) {
   constexpr int LPS = L * SPLIT, SPW = kWave / LPS, SPB = kWavesPerBlock * SPW;  // samples per wave / block
   constexpr int E = held_entries<L, SPLIT>() > 0 ? held_entries<L, SPLIT>() : 1;
-  constexpr bool HELD = MODE >= 1 && !GEN && held_entries<L, SPLIT>() > 0;
+  constexpr bool HELD = MODE >= 1 && held_entries<L, SPLIT>() > 0;  // GEN models: MODE 1 / 3 only (host)
   constexpr bool REG = MODE == 2 && HELD && OPT == OPT_SGD && LPS == kWave;
   constexpr bool CHUNKED = MODE == 3;  // rows longer than one chunk of held entries
   constexpr int NQ = REG ? L : 1;       // row pieces per lane kept in registers
@@ -479,7 +479,86 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
       if (valid && slot == 0) *reinterpret_cast<double2*>(Arow + 2 * l) = A1;
       if (slot == 0) part += (a1.x * a1.x - a2.x) / 2 + (a1.y * a1.y - a2.y) / 2;
     };
-    if (OPT == OPT_SGD)
+    // models with several orders and / or degree >= 3: the held entries serve every order (one chunk) --
+    // the streamed kernel reads the CSR row again for each of them
+    auto held_forward_gen = [&](auto ps) {
+      int slot_a = 0;
+      for (int o = 0; o < M.nb; ++o) {
+        const size_t blk = (size_t)o * M.da * M.Kp;
+        const int deg = M.degree - o;
+        double2 E[dev::kMaxDeg + 1];
+#pragma unroll
+        for (int t = 0; t <= dev::kMaxDeg; ++t) E[t] = {0.0, 0.0};
+        E[0] = {1.0, 1.0};
+        double2 a2 = {0.0, 0.0};  // degree 2: sum of squares (E[1] is the plain sum)
+        for (int base = 0; base == 0 || (CHUNKED && base < m_max); base += CAP) {
+          if (CHUNKED || o == 0) load_chunk(base, o == 0);
+#pragma unroll
+          for (int u0 = 0; u0 < RPS; u0 += U) {
+            if (base + u0 * SPLIT >= m_max) break;
+            int jj[U];
+            double xx[U];
+            double2 pp[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int r = u0 + u, src = sbase + slot + (r % L) * SPLIT;
+              jj[u] = __shfl(jq[r / L], src, kWave);
+              xx[u] = dev::shfl_d(xq[r / L], src);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) pp[u] = ps.load(blk + (size_t)jj[u] * M.Kp + 2 * l);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const double tx = xx[u] * pp[u].x, ty = xx[u] * pp[u].y;
+              if (deg == 2) {
+                E[1].x += tx;
+                E[1].y += ty;
+                a2.x += tx * tx;
+                a2.y += ty * ty;
+              } else {  // the DP of optimizer/sgd.nim:152-159, entry by entry
+#pragma unroll
+                for (int t = dev::kMaxDeg; t >= 1; --t)
+                  if (t <= deg) {
+                    E[t].x += E[t - 1].x * pp[u].x * xx[u];  // the reference's order of the two products
+                    E[t].y += E[t - 1].y * pp[u].y * xx[u];
+                  }
+              }
+            }
+          }
+        }
+        double2 ker;
+        if (deg == 2) {
+#pragma unroll
+          for (int s = L; s < L * SPLIT; s <<= 1) {
+            E[1].x += dev::shfl_xor_d(E[1].x, s);
+            E[1].y += dev::shfl_xor_d(E[1].y, s);
+            a2.x += dev::shfl_xor_d(a2.x, s);
+            a2.y += dev::shfl_xor_d(a2.y, s);
+          }
+          ker.x = (E[1].x * E[1].x - a2.x) / 2;
+          ker.y = (E[1].y * E[1].y - a2.y) / 2;
+          if (valid && slot == 0) *reinterpret_cast<double2*>(Arow + (size_t)slot_a * M.Kp + 2 * l) = E[1];
+        } else {
+          dev::combine_slots_degn<L, SPLIT>(E, deg, lane);
+          ker = dev::pick(E, deg);
+          if (valid && slot == 0) {
+#pragma unroll
+            for (int t = 1; t < dev::kMaxDeg; ++t)
+              if (t < deg) *reinterpret_cast<double2*>(Arow + (size_t)(slot_a + t - 1) * M.Kp + 2 * l) = E[t];
+          }
+        }
+        slot_a += deg - 1;
+        if (slot == 0) part += ker.x + ker.y;
+      }
+    };
+    if (GEN) {
+      if (OPT == OPT_SGD)
+        held_forward_gen(dev::PlainParams{M.P, a.scales[0]});
+      else if (stored)
+        held_forward_gen(dev::PlainParams{M.P, 1.0});
+      else
+        held_forward_gen(dev::AdaParams{O.G, O.N, O.eta0, O.eta0 * itp * O.beta});
+    } else if (OPT == OPT_SGD)
       held_forward(dev::PlainParams{M.P, a.scales[0]});
     else if (stored)
       held_forward(dev::PlainParams{M.P, 1.0});
@@ -1271,8 +1350,8 @@ static void launch_row(hipStream_t st, const RowArgs& ra, int mode, int n_cu, in
   constexpr int SPW = kWave / (L * SPLIT);
   const int nA = (ra.len + kWavesPerBlock * SPW - 1) / (kWavesPerBlock * SPW);
   *n_blocks = nA;
-  constexpr bool CAN_HOLD = !GEN && held_entries<L, SPLIT>() > 0;
-  constexpr bool CAN_REG = CAN_HOLD && OPT == OPT_SGD && L * SPLIT == kWave;
+  constexpr bool CAN_HOLD = held_entries<L, SPLIT>() > 0;
+  constexpr bool CAN_REG = CAN_HOLD && !GEN && OPT == OPT_SGD && L * SPLIT == kWave;
   if (CAN_REG && mode == 2)
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 2 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
   else if (CAN_HOLD && mode == 3)
@@ -1329,9 +1408,9 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     auto mode_for = [&](int s_used) {
       static const bool held_on = !(getenv("NFM_HELD") && atoi(getenv("NFM_HELD")) == 0);
       static const bool reg_on = !(getenv("NFM_NQ") && atoi(getenv("NFM_NQ")) == 0);
-      if (GEN || !held_on || held_capacity(L, s_used) == 0) return 0;
+      if (!held_on || held_capacity(L, s_used) == 0) return 0;
       if (X.max_row + M.n_aug > held_capacity(L, s_used)) return 3;  // long rows: chunks of held entries
-      if (reg_on && OPT == OPT_SGD && singles_in_row && L * s_used == kWave) return 2;
+      if (!GEN && reg_on && OPT == OPT_SGD && singles_in_row && L * s_used == kWave) return 2;
       return 1;
     };
     int nA;
