@@ -2,7 +2,7 @@
 // path, so DESIGN.md can quote measured ceilings next to the 8 TB/s spec:
 //   stream read / copy, random gather of R-byte rows (16 B per lane, a row = R/16 consecutive lanes),
 //   random read-modify-write of distinct rows, and gather + RMW of a fraction of the same rows.
-// build: hipcc --offload-arch=gfx950 -O3 -o gpurun_out/membench tools/membench.hip
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/membench tools/membench.hip   (tools/bin/ is not tracked)
 // usage: membench [table_MB] [row_bytes] [rows_per_launch]
 #include <hip/hip_runtime.h>
 
