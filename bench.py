@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["ingest"])
     ap.add_argument("--batch", type=int, default=0, help="mini-batch size (default: per workload)")
-    ap.add_argument("--n", type=int, default=0, help="override samples per GPU")
+    ap.add_argument("--n", "--samples", dest="n", type=int, default=0, help="override samples per GPU (--samples under torchrun, whose parser claims --n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=1_000_000)
     args = ap.parse_args()
