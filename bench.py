@@ -36,6 +36,10 @@ WORKLOADS = {
     # cfg4: field-aware FM, 16 fields, one nnz per field (field f owns the indices [f d/F, (f+1) d/F),
     # tests/utils.nim:66-68), AdaGrad
     "cfg4": dict(n=1_000_000, d=100_000, m=16, k=8, degree=2, solver="adagrad", loss="squared", batch=32768, fields=16),
+    # cfg4 with three low-cardinality fields (2, 7 and 50 distinct features): their features are touched by a
+    # large share of every batch
+    "cfg4lc": dict(n=1_000_000, d=100_000, m=16, k=8, degree=2, solver="adagrad", loss="squared", batch=32768, fields=16,
+                   low_card=[2, 7, 50]),
     "tiny": dict(n=50_000, d=5_000, m=16, k=8, degree=2, solver="sgd", loss="logistic", batch=4096),
     # cfg2 with Zipf(1.1) feature popularity: a few features are touched by most samples of a batch
     "cfg2z": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768, zipf=1.1),
@@ -203,7 +207,11 @@ def main():
         g = torch.Generator(device=dev)
         g.manual_seed(42 + rank)
         per = d // F
-        idx = torch.randint(0, per, (n, F), device=dev, generator=g, dtype=torch.int64) + torch.arange(F, device=dev) * per
+        idx = torch.randint(0, per, (n, F), device=dev, generator=g, dtype=torch.int64)
+        if wl.get("low_card"):  # the first fields have only a handful of distinct features (gender, weekday ...)
+            for f_, card in enumerate(wl["low_card"]):
+                idx[:, f_] = torch.randint(0, card, (n,), device=dev, generator=g, dtype=torch.int64)
+        idx = idx + torch.arange(F, device=dev) * per
         indices = idx.reshape(-1).to(torch.int32)
         fields = torch.arange(F, device=dev, dtype=torch.int32).repeat(n)
         data = torch.rand((n * F,), device=dev, generator=g, dtype=torch.float64) * 2 - 1

@@ -356,6 +356,226 @@ struct FColArgs {
   int32_t use_stored, nA, n_prev;
 };
 
+// One work unit = (unique feature j, field f): MODE 0 walks the touches [t0, t1) and applies the update;
+// heavy features (more than kHeavyTouches touches in the batch -- in field-aware data the features of a
+// low-cardinality field are touched by a large share of every batch) are done in two steps: MODE 1 sums ONE
+// segment of the touches and stores the partial sums (no side effects), MODE 2 (one wavefront per unit) adds
+// the segments' partial sums -- lane group g takes segments g, g + R, ..., then a fixed xor-shuffle tree --
+// and applies.  A partial record is PW = 2 Kp + 4 doubles: [acc Kp][accn Kp][seta, a0, a1, -].
+template <int L, int OPT, int MODE>
+__device__ __forceinline__ double ffm_unit(const FColArgs& a, int64_t j, int f, int l, int64_t t0, int64_t t1, double c, double sP,
+                                           double sPn, double sw, double swn, double fP, double fw, double itp, double* hp,
+                                           int64_t nseg, int PW) {
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int F = M.nb;
+  double viol = 0.0;
+  const bool do_w = M.fit_linear && f == 0;
+  const size_t e = ((size_t)f * M.da + j) * M.Kp + 2 * l;
+  double2 st = {0.0, 0.0}, g2 = {0.0, 0.0}, n2 = {0.0, 0.0}, p = {0.0, 0.0};
+  if (MODE != 1) {
+    if (OPT == OPT_SGD) {
+      st = *reinterpret_cast<const double2*>(M.P + e);
+      p.x = sP * st.x; p.y = sP * st.y;
+    } else {
+      g2 = *reinterpret_cast<const double2*>(O.G + e);
+      n2 = *reinterpret_cast<const double2*>(O.N + e);
+      if (a.use_stored) {
+        p = *reinterpret_cast<const double2*>(M.P + e);
+      } else {
+        const double tmp = O.eta0 * itp * O.beta;
+        p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmp);
+        p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmp);
+        if (O.track_viol) {
+          st = *reinterpret_cast<const double2*>(M.P + e);
+          viol += fabs(st.x - p.x) + fabs(st.y - p.y);
+          *reinterpret_cast<double2*>(M.P + e) = p;  // idempotent: every lane group of a MODE 2 wavefront writes the same
+        }
+      }
+    }
+  }
+  double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
+  double seta = 0.0, a0 = 0.0, a1 = 0.0;
+  if (MODE == 2) {
+    constexpr int RG = kWave / L;
+    const int g_ = (int)(threadIdx.x & (kWave - 1)) / L;
+    for (int64_t sg = g_; sg < nseg; sg += RG) {
+      const double* rec_ = hp + (size_t)sg * F * PW;  // consecutive segments of one feature are F records apart
+      const double2 pa = *reinterpret_cast<const double2*>(rec_ + 2 * l);
+      const double2 pn = *reinterpret_cast<const double2*>(rec_ + M.Kp + 2 * l);
+      acc.x += pa.x; acc.y += pa.y;
+      accn.x += pn.x; accn.y += pn.y;
+      seta += rec_[2 * M.Kp];
+      a0 += rec_[2 * M.Kp + 1];
+      a1 += rec_[2 * M.Kp + 2];
+    }
+#pragma unroll
+    for (int sh = L; sh < kWave; sh <<= 1) {
+      acc.x += dev::shfl_xor_d(acc.x, sh);
+      acc.y += dev::shfl_xor_d(acc.y, sh);
+      accn.x += dev::shfl_xor_d(accn.x, sh);
+      accn.y += dev::shfl_xor_d(accn.y, sh);
+      seta += dev::shfl_xor_d(seta, sh);
+      a0 += dev::shfl_xor_d(a0, sh);
+      a1 += dev::shfl_xor_d(a1, sh);
+    }
+    if (g_ != 0) return 0.0;
+  } else {
+    constexpr int TU = 4;  // touches requested together
+    for (int64_t tb = t0; tb < t1; tb += TU) {
+      int pib[TU];
+      int64_t tq[TU];
+      double x[TU];
+      SampleRec r[TU];
+      double2 v[TU];
+#pragma unroll
+      for (int q = 0; q < TU; ++q) {
+        const int64_t t = tb + q < t1 ? tb + q : t1 - 1;
+        pib[q] = a.tpos[t];
+        tq[q] = a.tq[t];
+        x[q] = do_w ? a.tx[t] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < TU; ++q) {
+        r[q] = a.rec[pib[q]];
+        v[q] = *reinterpret_cast<const double2*>(a.contrib + ((size_t)(tq[q] - a.t_base) * F + f) * M.Kp + 2 * l);
+      }
+#pragma unroll
+      for (int q = 0; q < TU; ++q) {
+        if (tb + q >= t1) break;
+        if (OPT == OPT_SGD) {
+          acc.x += r[q].etaP * (r[q].dL * v[q].x);
+          acc.y += r[q].etaP * (r[q].dL * v[q].y);
+          seta += r[q].etaP;
+          if (do_w) { a0 += r[q].etaw * (r[q].dL * x[q]); a1 += r[q].etaw; }
+        } else {
+          const double gx = r[q].dL * v[q].x, gy = r[q].dL * v[q].y;
+          acc.x += gx; acc.y += gy;
+          accn.x += gx * gx; accn.y += gy * gy;
+          if (do_w) { const double gw = r[q].dL * x[q]; a0 += gw; a1 += gw * gw; }
+        }
+      }
+    }
+  }
+  if (MODE == 1) {
+    *reinterpret_cast<double2*>(hp + 2 * l) = acc;
+    *reinterpret_cast<double2*>(hp + M.Kp + 2 * l) = accn;
+    if (l == 0) {
+      hp[2 * M.Kp] = seta;
+      hp[2 * M.Kp + 1] = a0;
+      hp[2 * M.Kp + 2] = a1;
+      hp[2 * M.Kp + 3] = 0.0;
+    }
+    return 0.0;
+  }
+  if (OPT == OPT_SGD) {
+    viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
+    st.x = st.x * fP - (acc.x / c) / sPn;
+    st.y = st.y * fP - (acc.y / c) / sPn;
+    *reinterpret_cast<double2*>(M.P + e) = st;
+  } else {
+    g2.x += acc.x; g2.y += acc.y; n2.x += accn.x; n2.y += accn.y;
+    *reinterpret_cast<double2*>(O.G + e) = g2;
+    *reinterpret_cast<double2*>(O.N + e) = n2;
+  }
+  if (do_w && l == 0) {
+    const double wt = M.w[j];
+    if (OPT == OPT_SGD) {
+      const double wj = sw * wt;
+      viol += fabs((a0 + a1 * O.alpha * wj) / c);
+      M.w[j] = wt * fw - (a0 / c) / swn;
+    } else {
+      const double gw = O.Gw[j], nw = O.Nw[j];
+      if (!a.use_stored) {
+        const double wj = -O.eta0 * gw / (itp * O.eta0 * O.alpha + sqrt(nw));
+        viol += fabs(wt - wj);
+        M.w[j] = wj;
+      }
+      O.Gw[j] = gw + a0;
+      O.Nw[j] = nw + a1;
+    }
+  }
+  return viol;
+}
+
+// decay corrections of a coordinate touched c times (as mb_fm.hip's touch_factors)
+__device__ __forceinline__ void ffm_touch_factors(const FColArgs& a, int64_t ci, double& fP, double& fw) {
+  fP = 1.0;
+  fw = 1.0;
+  if (ci > 1) {
+    const double c = (double)ci;
+    if (ci <= kFtab) { fP = a.Ftab_b[ci - 1]; fw = a.Ftab_b[kFtab + ci - 1]; }
+    else { fP = pow(a.Dtab_b[0], 1.0 / c) / a.Dtab_b[0]; fw = pow(a.Dtab_b[1], 1.0 / c) / a.Dtab_b[1]; }
+  }
+}
+
+struct FHeavyArgs {
+  const int64_t* hv_u;     // heavy feature -> index into ucol / uptr
+  const int64_t* hv_seg0;  // heavy feature -> its first segment
+  int64_t h0, h1, s0, s1;  // this batch's heavy features / segments
+  double* hpart;           // [(s1 - s0) * F][PW]
+  double* parts;           // per-block viol partials of the apply kernel
+  int32_t PW, pad_;
+};
+
+template <int L, int OPT>
+__global__ __launch_bounds__(kBlock) void k_ffm_heavy_partial(FColArgs a, FHeavyArgs hv) {
+  constexpr int R = kWave / L;
+  const ModelView& M = a.M;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int F = M.nb;
+  const int64_t unit = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;  // (segment, field)
+  const int64_t gs = hv.s0 + unit / F;
+  const int f = (int)(unit % F);
+  if (gs >= hv.s1) return;
+  int64_t lo = hv.h0, hi = hv.h1 - 1;  // last heavy feature whose first segment is <= gs
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (hv.hv_seg0[mid] <= gs) lo = mid; else hi = mid - 1;
+  }
+  const int64_t u = hv.hv_u[lo];
+  const int64_t j = a.ucol[u];
+  const int64_t t0 = a.uptr[u] + (gs - hv.hv_seg0[lo]) * kHeavySegment;
+  const int64_t t1 = min(t0 + (int64_t)kHeavySegment, a.uptr[u + 1]);
+  ffm_unit<L, OPT, 1>(a, j, f, l, t0, t1, 0.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0,
+                      hv.hpart + ((size_t)(gs - hv.s0) * F + f) * hv.PW, 0, hv.PW);
+}
+
+template <int L, int OPT>
+__global__ __launch_bounds__(kBlock) void k_ffm_heavy_apply(FColArgs a, FHeavyArgs hv) {
+  __shared__ double red[kWavesPerBlock];
+  const ModelView& M = a.M;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int l = lane % L;
+  const int F = M.nb;
+  const int64_t wid = (int64_t)blockIdx.x * kWavesPerBlock + wv;  // one wavefront per (heavy feature, field)
+  const int64_t h = hv.h0 + wid / F;
+  const int f = (int)(wid % F);
+  double viol = 0.0;
+  if (h < hv.h1) {
+    const int64_t u = hv.hv_u[h];
+    const int64_t j = a.ucol[u];
+    const int64_t c = a.uptr[u + 1] - a.uptr[u];
+    double sP = 1.0, sPn = 1.0, sw = 1.0, swn = 1.0, fP = 1.0, fw = 1.0;
+    if (OPT == OPT_SGD) {
+      sP = a.scales_b[0]; sw = a.scales_b[1]; sPn = a.scales_n[0]; swn = a.scales_n[1];
+      ffm_touch_factors(a, c, fP, fw);
+    }
+    const int64_t sg0 = hv.hv_seg0[h], nseg = hv.hv_seg0[h + 1] - sg0;
+    viol = ffm_unit<L, OPT, 2>(a, j, f, l, 0, 0, (double)c, sP, sPn, sw, swn, fP, fw, (a.it0p[0] + a.it_b) - 1.0,
+                               hv.hpart + ((size_t)(sg0 - hv.s0) * F + f) * hv.PW, nseg, hv.PW);
+  }
+  viol = dev::wave_sum(viol);
+  if (lane == 0) red[wv] = viol;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) v += red[w_];
+    hv.parts[blockIdx.x] = v;
+  }
+}
+
 template <int L, int OPT>
 __global__ __launch_bounds__(kBlock) void k_ffm_col_phase(FColArgs a) {
   constexpr int R = kWave / L;
@@ -386,94 +606,8 @@ __global__ __launch_bounds__(kBlock) void k_ffm_col_phase(FColArgs a) {
         else { fP = pow(a.Dtab_b[0], 1.0 / c) / a.Dtab_b[0]; fw = pow(a.Dtab_b[1], 1.0 / c) / a.Dtab_b[1]; }
       }
     }
-    const bool do_w = M.fit_linear && f == 0;
-    {
-      const size_t e = ((size_t)f * M.da + j) * M.Kp + 2 * l;
-      double2 st = {0.0, 0.0}, g2 = {0.0, 0.0}, n2 = {0.0, 0.0}, p;
-      if (OPT == OPT_SGD) {
-        st = *reinterpret_cast<const double2*>(M.P + e);
-        p.x = sP * st.x; p.y = sP * st.y;
-      } else {
-        g2 = *reinterpret_cast<const double2*>(O.G + e);
-        n2 = *reinterpret_cast<const double2*>(O.N + e);
-        if (a.use_stored) {
-          p = *reinterpret_cast<const double2*>(M.P + e);
-        } else {
-          const double tmp = O.eta0 * itp * O.beta;
-          p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmp);
-          p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmp);
-          if (O.track_viol) {
-            st = *reinterpret_cast<const double2*>(M.P + e);
-            viol += fabs(st.x - p.x) + fabs(st.y - p.y);
-            *reinterpret_cast<double2*>(M.P + e) = p;
-          }
-        }
-      }
-      double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
-      double seta = 0.0, a0 = 0.0, a1 = 0.0;
-      constexpr int TU = 4;  // touches requested together
-      for (int64_t tb = t0; tb < t1; tb += TU) {
-        int pib[TU];
-        int64_t tq[TU];
-        double x[TU];
-        SampleRec r[TU];
-        double2 v[TU];
-#pragma unroll
-        for (int q = 0; q < TU; ++q) {
-          const int64_t t = tb + q < t1 ? tb + q : t1 - 1;
-          pib[q] = a.tpos[t];
-          tq[q] = a.tq[t];
-          x[q] = do_w ? a.tx[t] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < TU; ++q) {
-          r[q] = a.rec[pib[q]];
-          v[q] = *reinterpret_cast<const double2*>(a.contrib + ((size_t)(tq[q] - a.t_base) * F + f) * M.Kp + 2 * l);
-        }
-#pragma unroll
-        for (int q = 0; q < TU; ++q) {
-          if (tb + q >= t1) break;
-          if (OPT == OPT_SGD) {
-            acc.x += r[q].etaP * (r[q].dL * v[q].x);
-            acc.y += r[q].etaP * (r[q].dL * v[q].y);
-            seta += r[q].etaP;
-            if (do_w) { a0 += r[q].etaw * (r[q].dL * x[q]); a1 += r[q].etaw; }
-          } else {
-            const double gx = r[q].dL * v[q].x, gy = r[q].dL * v[q].y;
-            acc.x += gx; acc.y += gy;
-            accn.x += gx * gx; accn.y += gy * gy;
-            if (do_w) { const double gw = r[q].dL * x[q]; a0 += gw; a1 += gw * gw; }
-          }
-        }
-      }
-      if (OPT == OPT_SGD) {
-        viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
-        st.x = st.x * fP - (acc.x / c) / sPn;
-        st.y = st.y * fP - (acc.y / c) / sPn;
-        *reinterpret_cast<double2*>(M.P + e) = st;
-      } else {
-        g2.x += acc.x; g2.y += acc.y; n2.x += accn.x; n2.y += accn.y;
-        *reinterpret_cast<double2*>(O.G + e) = g2;
-        *reinterpret_cast<double2*>(O.N + e) = n2;
-      }
-      if (do_w && l == 0) {
-        const double wt = M.w[j];
-        if (OPT == OPT_SGD) {
-          const double wj = sw * wt;
-          viol += fabs((a0 + a1 * O.alpha * wj) / c);
-          M.w[j] = wt * fw - (a0 / c) / swn;
-        } else {
-          const double gw = O.Gw[j], nw = O.Nw[j];
-          if (!a.use_stored) {
-            const double wj = -O.eta0 * gw / (itp * O.eta0 * O.alpha + sqrt(nw));
-            viol += fabs(wt - wj);
-            M.w[j] = wj;
-          }
-          O.Gw[j] = gw + a0;
-          O.Nw[j] = nw + a1;
-        }
-      }
-    }
+    if (t1 - t0 <= kHeavyTouches)  // heavy features: k_ffm_heavy_partial / k_ffm_heavy_apply
+      viol += ffm_unit<L, OPT, 0>(a, j, f, l, t0, t1, c, sP, sPn, sw, swn, fP, fw, itp, nullptr, 0, 0);
   }
   viol = dev::wave_sum(viol);
   if (lane == 0) red[0][wv] = viol;
@@ -570,10 +704,27 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
                   W.rec.as<SampleRec>(), W.partsB.as<double>() + (b & 1) * half, W.partsA.as<PartA>(),
                   W.partsB.as<double>() + ((b + 1) & 1) * half, W.out_acc.as<double>(), (double)p0, (double)len, it0p,
                   use_stored, nA, n_prev};
-      TimedLaunch tl(ctx, "col_phase");
-      hipLaunchKernelGGL((k_ffm_col_phase<L, OPT>), dim3(nB), dim3(kBlock), 0, st, ca);
+      {
+        TimedLaunch tl(ctx, "col_phase");
+        hipLaunchKernelGGL((k_ffm_col_phase<L, OPT>), dim3(nB), dim3(kBlock), 0, st, ca);
+      }
+      int nH = 0;
+      if (P.bat_hoff[b + 1] > P.bat_hoff[b]) {  // features with more than kHeavyTouches touches in this batch
+        const int PW = 2 * M.Kp + 4;
+        FHeavyArgs ha{P.hv_u.as<int64_t>(), P.hv_seg0.as<int64_t>(), P.bat_hoff[b], P.bat_hoff[b + 1], P.bat_soff[b],
+                      P.bat_soff[b + 1], W.hpart.as<double>(), W.partsB.as<double>() + (b & 1) * half + nB, PW, 0};
+        const int64_t units = (ha.s1 - ha.s0) * M.nb;
+        const int nsb = (int)((units + per_block - 1) / per_block);
+        nH = (int)(((ha.h1 - ha.h0) * M.nb + kWavesPerBlock - 1) / kWavesPerBlock);  // one wavefront per (feature, field)
+        {
+          TimedLaunch tl(ctx, "heavy_partial");
+          hipLaunchKernelGGL((k_ffm_heavy_partial<L, OPT>), dim3(nsb), dim3(kBlock), 0, st, ca, ha);
+        }
+        TimedLaunch tl(ctx, "heavy_apply");
+        hipLaunchKernelGGL((k_ffm_heavy_apply<L, OPT>), dim3(nH), dim3(kBlock), 0, st, ca, ha);
+      }
+      n_prev = nB + nH;
     }
-    n_prev = nB;
   }
   if (P.n_batches > 0)
     hipLaunchKernelGGL(k_epoch_close, dim3(1), dim3(kBlock), 0, st, W.partsB.as<double>() + ((P.n_batches - 1) & 1) * half,
@@ -600,7 +751,8 @@ int mb_ffm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& 
   NFM_TRY(W.contrib.ensure(sizeof(double) * (size_t)max_t * M.nb * M.Kp));
   NFM_TRY(W.rec.ensure(sizeof(SampleRec) * (size_t)std::max<int64_t>(P.max_batch, 1)));
   NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch / kWavesPerBlock + 1)));
-  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique * M.nb / kWavesPerBlock + 2)));
+  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique * M.nb / kWavesPerBlock + P.max_heavy * M.nb / kWavesPerBlock + 4)));
+  NFM_TRY(W.hpart.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_segs, 1) * M.nb * (2 * M.Kp + 4)));
   NFM_TRY(W.Dtab.ensure(sizeof(double) * 4 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Stab.ensure(sizeof(double) * 2 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Ftab.ensure(sizeof(double) * 2 * kFtab * (size_t)(P.n_batches + 1)));

@@ -274,6 +274,53 @@ def test_ffm_minibatch_vs_mb_oracle(k, F, batch):
     assert_close([h[0] for h in ada.history], hist, 1e-9, 1e-12, "viol")
 
 
+@pytest.mark.parametrize("k,batch", [(4, 700), (8, 257)])
+def test_ffm_low_cardinality_fields(k, batch):
+    """Field-aware data where some fields have only a few distinct features (each touched by a large share of every
+    batch): those features go through k_ffm_heavy_partial / k_ffm_heavy_apply (segments of 64 touches, then one
+    wavefront per (feature, field)); the rest through the ordinary column phase.  SGD and AdaGrad vs the oracle."""
+    from common import init_ffm
+    from gpu_common import gpu_ffm
+    rng = np.random.default_rng(k)
+    n, F, per = 1500, 4, 10
+    cards = [2, 3, 10, 10]
+    d = F * per
+    idx = np.stack([f * per + rng.integers(0, cards[f], size=n) for f in range(F)], axis=1)
+    val = rng.uniform(-1, 1, size=(n, F))
+    Xo = O.Dataset(np.arange(n + 1) * F, idx.ravel(), val.ravel(), n, d, fields=np.tile(np.arange(F), n), n_fields=F)
+    y = rng.standard_normal(n)
+    P0, w0, b0 = init_ffm(d, F, k, scale=0.05)
+    perms = make_perms(n, 2)
+    X = to_gpu(Xo)
+    P, w, b, it = P0.copy(), w0.copy(), b0, 1
+    hist = []
+    for e in range(2):
+        b, it, ls, vs = O.ffm_sgd_epoch_mb(Xo, y, P, w, b, O.sgd_cfg(eta0=0.01), batch, perm=perms[e], it=it)
+        hist.append((vs, ls / n))
+    ffm = gpu_ffm("regression", k, True, True, P0, w0, b0)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, eta0=0.01, mode="minibatch", batch=batch)
+    sgd.fit(X, y, ffm, perms=perms)
+    assert abs(ffm.intercept - b) < 1e-11
+    assert_close(ffm.w, w, RTOL, ATOL, "w")
+    assert_close(ffm.P, P, RTOL, ATOL, "P")
+    assert_close([h[0] for h in sgd.history], [h[0] for h in hist], 1e-9, 1e-12, "viol")
+    cfg = O.adagrad_cfg()
+    P, w, b, it = P0.copy(), w0.copy(), b0, 1
+    st = O.AdaState(F, d, k, d)
+    hist = []
+    for e in range(2):
+        b, it, ls, vs = O.ffm_adagrad_epoch_mb(Xo, y, P, w, b, cfg, batch, st, perm=perms[e], it=it)
+        hist.append(vs)
+    b = O.ffm_adagrad_finalize(P, w, b, cfg, it, st)
+    ffm = gpu_ffm("regression", k, True, True, P0, w0, b0)
+    ada = nf.newAdaGrad(maxIter=2, verbose=0, tol=0, mode="minibatch", batch=batch)
+    ada.fit(X, y, ffm, perms=perms)
+    assert abs(ffm.intercept - b) < 1e-11
+    assert_close(ffm.w, w, RTOL, ATOL, "w")
+    assert_close(ffm.P, P, RTOL, ATOL, "P")
+    assert_close([h[0] for h in ada.history], hist, 1e-9, 1e-12, "viol")
+
+
 @pytest.mark.parametrize("solver,k", [("sgd", 4), ("sgd", 16), ("adagrad", 8)])
 def test_heavy_features(solver, k):
     """Features touched by (almost) every sample of a batch -- Zipf heads, dummy features -- have their touch
