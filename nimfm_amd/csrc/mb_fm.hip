@@ -856,7 +856,7 @@ struct WAcc {  // linear-term accumulators of one feature
 template <int OPT, bool GEN, int TU, int LG, int MODE>
 __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg, int slot, int l, int64_t t0, int64_t t1,
                                             double sP, double sPn, double fP, bool do_w, WAcc& wacc, double c_total = 0.0,
-                                            double* hp = nullptr, int64_t nseg = 0, int PW = 0) {
+                                            double* hp = nullptr, int64_t nseg = 0, int PW = 0, int seg_stride = 0) {
   const ModelView& M = a.M;
   const OptView& O = a.O;
   double viol = 0.0;
@@ -890,7 +890,7 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
     const int g_ = (int)(threadIdx.x & (kWave - 1)) / LG;
 #pragma unroll 4
     for (int64_t sg = g_; sg < nseg; sg += RG) {
-      const double* rec_ = hp + (size_t)sg * PW;
+      const double* rec_ = hp + (size_t)sg * (seg_stride ? seg_stride : PW);
       const double2 pa = *reinterpret_cast<const double2*>(rec_);
       const double2 pn = *reinterpret_cast<const double2*>(rec_ + M.Kp);
       acc.x += pa.x;
@@ -1120,7 +1120,7 @@ struct HeavyArgs {
   int32_t PW, pad_;
 };
 
-template <int L, int OPT>
+template <int L, int OPT, bool GEN>
 __global__ __launch_bounds__(kBlock) void k_heavy_partial(ColArgs a, HeavyArgs hv) {
   constexpr int R = kWave / L;
   const ModelView& M = a.M;
@@ -1139,12 +1139,17 @@ __global__ __launch_bounds__(kBlock) void k_heavy_partial(ColArgs a, HeavyArgs h
   const int64_t t1 = min(t0 + (int64_t)kHeavySegment, a.uptr[u + 1]);
   const double sP = OPT == OPT_SGD ? a.scales_b[0] : 1.0;
   const bool has_w = M.fit_linear && j < M.d;
-  WAcc wacc;
-  col_block<OPT, false, 2, L, 1>(a, (size_t)j * M.Kp + 2 * l, 2, 0, l, t0, t1, sP, 1.0, 1.0, has_w, wacc, 0.0,
-                                 hv.hpart + (size_t)(gs - hv.s0) * hv.PW + 2 * l, 0, hv.PW);
+  int slot = 0;
+  for (int o = 0; o < M.nb; ++o) {  // one partial record per (segment, order)
+    WAcc wacc;
+    const int deg = M.degree - o;
+    col_block<OPT, GEN, 2, L, 1>(a, ((size_t)o * M.da + j) * M.Kp + 2 * l, deg, slot, l, t0, t1, sP, 1.0, 1.0, has_w && o == 0, wacc,
+                                 0.0, hv.hpart + ((size_t)(gs - hv.s0) * M.nb + o) * hv.PW + 2 * l, 0, hv.PW);
+    slot += deg - 1;
+  }
 }
 
-template <int L, int OPT>
+template <int L, int OPT, bool GEN>
 __global__ __launch_bounds__(kBlock) void k_heavy_apply(ColArgs a, HeavyArgs hv) {
   constexpr int R = kWave / L;
   __shared__ double red[kWavesPerBlock];
@@ -1169,8 +1174,16 @@ __global__ __launch_bounds__(kBlock) void k_heavy_apply(ColArgs a, HeavyArgs hv)
     const bool has_w = M.fit_linear && j < M.d;
     WAcc wacc;
     const int64_t sg0 = hv.hv_seg0[h], nseg = hv.hv_seg0[h + 1] - sg0;
-    viol += col_block<OPT, false, 2, L, 2>(a, (size_t)j * M.Kp + 2 * l, 2, 0, l, 0, 0, sP, sPn, fP, has_w, wacc, (double)c,
-                                           hv.hpart + (size_t)(sg0 - hv.s0) * hv.PW + 2 * l, nseg, hv.PW);
+    int slot = 0;
+    for (int o = 0; o < M.nb; ++o) {
+      WAcc wo;
+      const int deg = M.degree - o;
+      viol += col_block<OPT, GEN, 2, L, 2>(a, ((size_t)o * M.da + j) * M.Kp + 2 * l, deg, slot, l, 0, 0, sP, sPn, fP, has_w && o == 0,
+                                           wo, (double)c, hv.hpart + ((size_t)(sg0 - hv.s0) * M.nb + o) * hv.PW + 2 * l, nseg,
+                                           hv.PW, M.nb * hv.PW);
+      if (o == 0) wacc = wo;
+      slot += deg - 1;
+    }
     if (has_w && g == 0) viol += w_epilogue<OPT>(a, j, l, (double)c, sw, swn, fw, wacc);
   }
   viol = dev::wave_sum(viol);
@@ -1237,8 +1250,9 @@ __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
   const int64_t stride = (int64_t)(gridDim.x - 1) * kWavesPerBlock * R;
   for (int64_t u = closer ? a.u1 : a.u0 + ((int64_t)fb * kWavesPerBlock + wv) * R + g; u < a.u1;
        u = STRIDED ? u + stride : a.u1) {
-    // heavy features of degree-2 models are summed by k_heavy_partial / k_heavy_apply
-    if (!GEN && a.uptr[u + 1] - a.uptr[u] > kHeavyTouches) continue;
+    // heavy features are summed by k_heavy_partial / k_heavy_apply (degree-1 models have no parameter block
+    // to walk them with and keep them here)
+    if (M.nb > 0 && a.uptr[u + 1] - a.uptr[u] > kHeavyTouches) continue;
     const int64_t j = a.ucol[u];
     const int64_t t0 = a.uptr[u], t1 = a.uptr[u + 1];
     double sP = 1.0, sPn = 1.0, sw = 1.0, swn = 1.0, fP = 1.0, fw = 1.0;
@@ -1408,7 +1422,7 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     auto mode_for = [&](int s_used) {
       static const bool held_on = !(getenv("NFM_HELD") && atoi(getenv("NFM_HELD")) == 0);
       static const bool reg_on = !(getenv("NFM_NQ") && atoi(getenv("NFM_NQ")) == 0);
-      if (!held_on || held_capacity(L, s_used) == 0) return 0;
+      if (!held_on || held_capacity(L, s_used) == 0 || M.nb == 0) return 0;  // degree-1 models: linear term only, streamed
       if (X.max_row + M.n_aug > held_capacity(L, s_used)) return 3;  // long rows: chunks of held entries
       if (!GEN && reg_on && OPT == OPT_SGD && singles_in_row && L * s_used == kWave) return 2;
       return 1;
@@ -1471,7 +1485,7 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
         hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 2, false>), dim3(nB), dim3(kBlock), 0, st, ca);
     }
     int nH = 0;
-    if (!GEN && P.bat_hoff[b + 1] > P.bat_hoff[b]) {
+    if (M.nb > 0 && P.bat_hoff[b + 1] > P.bat_hoff[b]) {
       const int PW = 2 * M.Kp + 4;
       HeavyArgs ha{P.hv_u.as<int64_t>(), P.hv_seg0.as<int64_t>(), P.bat_hoff[b], P.bat_hoff[b + 1], P.bat_soff[b],
                    P.bat_soff[b + 1], W.hpart.as<double>(), parts_cur + nS + nB, PW, 0};
@@ -1486,10 +1500,10 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
       nH = (int)((ha.h1 - ha.h0 + kWavesPerBlock - 1) / kWavesPerBlock);  // one wavefront per heavy feature
       {
         TimedLaunch tl(ctx, "heavy_partial");
-        hipLaunchKernelGGL((k_heavy_partial<L, OPT>), dim3(nsb), dim3(kBlock), 0, st, ca, ha);
+        hipLaunchKernelGGL((k_heavy_partial<L, OPT, GEN>), dim3(nsb), dim3(kBlock), 0, st, ca, ha);
       }
       TimedLaunch tl(ctx, "heavy_apply");
-      hipLaunchKernelGGL((k_heavy_apply<L, OPT>), dim3(nH), dim3(kBlock), 0, st, ca, ha);
+      hipLaunchKernelGGL((k_heavy_apply<L, OPT, GEN>), dim3(nH), dim3(kBlock), 0, st, ca, ha);
     }
     n_prev = nB + nS + nH;
   }
@@ -1560,7 +1574,7 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   NFM_TRY(W.rec.ensure(sizeof(SampleRec) * (size_t)std::max<int64_t>(P.max_batch, 1)));
   NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch / kWavesPerBlock + 1)));
   NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique / kMinGroupsPerBlock + P.max_batch / kWavesPerBlock + P.max_heavy / kWavesPerBlock + 6)));
-  NFM_TRY(W.hpart.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_segs, 1) * (2 * M.Kp + 4)));
+  NFM_TRY(W.hpart.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_segs, 1) * std::max(M.nb, 1) * (2 * M.Kp + 4)));
   NFM_TRY(W.Dtab.ensure(sizeof(double) * 4 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Stab.ensure(sizeof(double) * 2 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Ftab.ensure(sizeof(double) * 2 * kFtab * (size_t)(P.n_batches + 1)));

@@ -321,6 +321,40 @@ def test_ffm_low_cardinality_fields(k, batch):
     assert_close([h[0] for h in ada.history], hist, 1e-9, 1e-12, "viol")
 
 
+@pytest.mark.parametrize("degree,fit_lower,fit_linear", [(3, "augment", True), (4, "augment", False), (3, "explicit", True),
+                                                         (1, "explicit", True)])
+def test_heavy_features_higher_degree(degree, fit_lower, fit_linear):
+    """Dummy features of fitLower=augment are touched by EVERY sample of a batch; with degree >= 3 (or several orders)
+    they and other heavy columns go through the segmented kernels too (one partial record per (segment, order))."""
+    n, d, k, batch = 900, 12, 4, 400
+    Xo = random_csr(n, d, 6, seed=11)
+    rng = np.random.default_rng(degree)
+    y = rng.standard_normal(n)
+    n_ord, n_aug = O.n_orders(degree, fit_lower), O.n_augments(degree, fit_lower, fit_linear)
+    P0, w0 = rng.standard_normal((n_ord, k, d + n_aug)) * 0.1, np.zeros(d)
+    perms = make_perms(n, 2)
+    cfg = O.sgd_cfg(fit_linear=fit_linear)
+    P, w, b, it, hist = run_oracle_sgd_mb(Xo, y, degree, P0, w0, 0.0, cfg, batch, n_aug, perms, 2)
+    fm = gpu_fm("regression", degree, k, fit_lower, fit_linear, True, P0, w0, 0.0)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, mode="minibatch", batch=batch)
+    sgd.fit(to_gpu(Xo), y, fm, perms=perms)
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
+    assert_close([h[0] for h in sgd.history], [h[0] for h in hist], 1e-9, 1e-12, "viol")
+    acfg = O.adagrad_cfg(fit_linear=fit_linear)
+    P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
+    st = O.AdaState(n_ord, d + n_aug, k, d)
+    for e in range(2):
+        b, it, ls, vs = O.fm_adagrad_epoch_mb(Xo, y, degree, P, w, b, acfg, batch, st, n_aug, perm=perms[e], it=it)
+    b = O.fm_adagrad_finalize(degree, P, w, b, acfg, it, st, n_aug)
+    fm = gpu_fm("regression", degree, k, fit_lower, fit_linear, True, P0, w0, 0.0)
+    nf.newAdaGrad(maxIter=2, verbose=0, tol=0, mode="minibatch", batch=batch).fit(to_gpu(Xo), y, fm, perms=perms)
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
+
+
 @pytest.mark.parametrize("solver,k", [("sgd", 4), ("sgd", 16), ("adagrad", 8)])
 def test_heavy_features(solver, k):
     """Features touched by (almost) every sample of a batch -- Zipf heads, dummy features -- have their touch
