@@ -40,6 +40,9 @@ WORKLOADS = {
     # large share of every batch
     "cfg4lc": dict(n=1_000_000, d=100_000, m=16, k=8, degree=2, solver="adagrad", loss="squared", batch=32768, fields=16,
                    low_card=[2, 7, 50]),
+    # the shape of click-through data: 39 fields, one entry per field, k = 4, 13 low-cardinality fields
+    "ffm39": dict(n=500_000, d=39 * 25641, m=39, k=4, degree=2, solver="adagrad", loss="logistic", batch=32768, fields=39,
+                  low_card=[16] * 13),
     "tiny": dict(n=50_000, d=5_000, m=16, k=8, degree=2, solver="sgd", loss="logistic", batch=4096),
     # cfg2 with Zipf(1.1) feature popularity: a few features are touched by most samples of a batch
     "cfg2z": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768, zipf=1.1),

@@ -172,11 +172,13 @@ __global__ __launch_bounds__(kBlock) void k_ffm_row_phase(FRowArgs a) {
 //      in ascending q' (the reference's accumulation order, sgd_ffm.nim:24-30), written to the
 //      contribution buffer; yhat's pair sum = 1/2 sum <P[f][j_q], dA[q][f]>
 // ------------------------------------------------------------------------------------------------
-template <int L, int OPT>
-__global__ __launch_bounds__(kBlock) void k_ffm_row_phase_lds(FRowArgs a, int m_cap) {
+// WPB wavefronts per workgroup: 4, or 1 when a sample's m*F rows need more than a quarter of the LDS
+// (e.g. 39 fields x 39 entries at k = 4: 49 KiB per sample -> three single-wavefront workgroups per CU)
+template <int L, int OPT, int WPB>
+__global__ __launch_bounds__(kWave * WPB) void k_ffm_row_phase_lds(FRowArgs a, int m_cap) {
   constexpr int R = kWave / L;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  __shared__ double red[kWavesPerBlock][4];
+  __shared__ double red[WPB][4];
   const CsrView& X = a.X;
   const ModelView& M = a.M;
   const OptView& O = a.O;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void k_ffm_row_phase_lds(FRowArgs a, int m_
   double* xs = reinterpret_cast<double*>(base + (size_t)m_cap * F * Kp * 8 + (size_t)F * 8);
   int* js = reinterpret_cast<int*>(xs + m_cap);
   int* fs = js + m_cap;
-  const int pib = blockIdx.x * kWavesPerBlock + wv;
+  const int pib = blockIdx.x * WPB + wv;
   const bool valid = pib < a.len;
   int64_t q0 = 0;
   int m = 0;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void k_ffm_row_phase_lds(FRowArgs a, int m_
   }
   // 2. gather the m * F rows
   const int n_out = m * F;
-  constexpr int U = 8;
+  constexpr int U = 8;  // (16 in flight for rows of 16-64 B measured no faster)
   for (int ob = 0; ob < n_out; ob += R * U) {
     double2 r0[U], r1[U];
     int oo[U];
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_ffm_row_phase_lds(FRowArgs a, int m_
   __syncthreads();
   if (threadIdx.x == 0) {
     PartA p{0.0, 0.0, 0.0, 0.0};
-    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) {
+    for (int w_ = 0; w_ < WPB; ++w_) {
       p.loss += red[w_][0];
       p.acc0 += red[w_][2];
       p.acc1 += red[w_][3];
@@ -670,26 +672,40 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
   static const bool lds_on = !(getenv("NFM_FFM_LDS") && atoi(getenv("NFM_FFM_LDS")) == 0);
   const int m_cap = (int)std::max<int64_t>(X.max_row, 1);
   size_t lds_bytes = 0;
+  int lds_wpb = 4;
   if (lds_on && X.max_row <= kWave && M.nb <= kWave) {
     size_t per_wave = (size_t)m_cap * M.nb * M.Kp * 8 + (size_t)M.nb * 8 + (size_t)m_cap * 16;
     per_wave = (per_wave + 15) / 16 * 16;
-    if (per_wave * kWavesPerBlock <= 150 * 1024) lds_bytes = per_wave * kWavesPerBlock;
+    if (per_wave * 4 <= 150 * 1024) {
+      lds_bytes = per_wave * 4;
+    } else if (per_wave <= 150 * 1024) {
+      lds_bytes = per_wave;
+      lds_wpb = 1;
+    }
   }
-  if (lds_bytes > 64 * 1024)
-    NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffm_row_phase_lds<L, OPT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  if (lds_bytes > 64 * 1024) {
+    if (lds_wpb == 4)
+      NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffm_row_phase_lds<L, OPT, 4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    else
+      NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffm_row_phase_lds<L, OPT, 1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  }
   for (int64_t b = 0; b < P.n_batches; ++b) {
     const int64_t p0 = P.bat_pos[b];
     const int len = (int)(P.bat_pos[b + 1] - p0);
     const int use_stored = (OPT == OPT_ADAGRAD && P.first_singleton && b == 0) ? 1 : 0;
-    const int nA = (len + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int wpb = lds_bytes > 0 ? lds_wpb : kWavesPerBlock;
+    const int nA = (len + wpb - 1) / wpb;
     {
       FRowArgs ra{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, P.toff.as<int64_t>(), P.begin, p0, t_base[b], len,
                   use_stored, (double)p0, it0p, OPT == OPT_SGD ? Stab + 2 * b : M.sc, W.contrib.as<double>(),
                   W.rec.as<SampleRec>(), W.partsA.as<PartA>()};
       TimedLaunch tl(ctx, "row_phase");
-      if (lds_bytes > 0)
-        hipLaunchKernelGGL((k_ffm_row_phase_lds<L, OPT>), dim3(nA), dim3(kBlock), lds_bytes, st, ra, m_cap);
+      if (lds_bytes > 0 && lds_wpb == 4)
+        hipLaunchKernelGGL((k_ffm_row_phase_lds<L, OPT, 4>), dim3(nA), dim3(kBlock), lds_bytes, st, ra, m_cap);
+      else if (lds_bytes > 0)
+        hipLaunchKernelGGL((k_ffm_row_phase_lds<L, OPT, 1>), dim3(nA), dim3(kWave), lds_bytes, st, ra, m_cap);
       else
         hipLaunchKernelGGL((k_ffm_row_phase<L, OPT>), dim3(nA), dim3(kBlock), 0, st, ra);
     }
@@ -750,7 +766,7 @@ int mb_ffm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& 
   for (int64_t b = 0; b < P.n_batches; ++b) max_t = std::max(max_t, t_base[b + 1] - t_base[b]);
   NFM_TRY(W.contrib.ensure(sizeof(double) * (size_t)max_t * M.nb * M.Kp));
   NFM_TRY(W.rec.ensure(sizeof(SampleRec) * (size_t)std::max<int64_t>(P.max_batch, 1)));
-  NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch / kWavesPerBlock + 1)));
+  NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch + 1)));  // one partial per workgroup, workgroups of >= 1 wavefront
   NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique * M.nb / kWavesPerBlock + P.max_heavy * M.nb / kWavesPerBlock + 4)));
   NFM_TRY(W.hpart.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_segs, 1) * M.nb * (2 * M.Kp + 4)));
   NFM_TRY(W.Dtab.ensure(sizeof(double) * 4 * (size_t)(P.n_batches + 1)));

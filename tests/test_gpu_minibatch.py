@@ -228,12 +228,13 @@ def test_register_resident_rows(k, fit_linear, max_m):
     assert_close([h[0] for h in sgd.history], [h[0] for h in hist], 1e-9, 1e-12, "viol")
 
 
-@pytest.mark.parametrize("k,F,batch", [(4, 5, 1), (4, 5, 7), (8, 16, 64), (30, 3, 80), (4, 4, 16), (8, 2, 32)])
+@pytest.mark.parametrize("k,F,batch", [(4, 5, 1), (4, 5, 7), (8, 16, 64), (30, 3, 80), (4, 4, 16), (8, 2, 32), (16, 16, 40)])
 def test_ffm_minibatch_vs_mb_oracle(k, F, batch):
     """FieldAwareFactorizationMachine through the mini-batch kernels (mb_ffm.hip), SGD and AdaGrad."""
     from common import init_ffm, make_ffm_dataset
     from gpu_common import gpu_ffm
-    # d divisible by F (tests/utils.nim:66-68); F = 4: rows of ~80 entries (> 64: the generic row kernel),
+    # d divisible by F (tests/utils.nim:66-68); (16, 16): a sample's m*F rows need > 1/4 of the LDS (one wavefront per
+    # workgroup); F = 4: rows of ~80 entries (> 64: the generic row kernel),
     # F = 2: rows that fit the LDS-resident kernel with many entries per field
     n, d = 120, {5: 60, 16: 48, 3: 48, 4: 200, 2: 64}[F]
     Xo, Xd, field_of, y = make_ffm_dataset(n, d, F, k, 42, threshold=0.6)
