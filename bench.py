@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="mini-batch size (default: per workload)")
     ap.add_argument("--n", "--samples", dest="n", type=int, default=0, help="override samples per GPU (--samples under torchrun, whose parser claims --n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-viol", action="store_true",
+                    help="AdaGrad without the reference's viol = sum|P_old - P_new| (no stored copy of P is read or "
+                         "written; the stopping criterion is then unavailable) -- an information run, not the metric")
     ap.add_argument("--cpu-samples", type=int, default=1_000_000)
     args = ap.parse_args()
 
@@ -243,7 +246,7 @@ def main():
         opt = nf.newSGD(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch", batch=args.batch)
     else:
         opt = nf.newAdaGrad(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch",
-                            batch=args.batch)
+                            batch=args.batch, trackViol=not args.no_viol)
     X.set_targets(y)
     opt._handle(fm, ctx, "minibatch")
     import ctypes as C
