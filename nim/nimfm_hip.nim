@@ -99,6 +99,33 @@ proc toDevice(X: CSRDataset): NfmDataset =
                                cast[ptr int64](addr indptr[0]), cast[ptr int64](addr indices[0]),
                                addr data[0], nil, 0, nil, addr result)
 
+type
+  HipCSRDataset* = ref object
+    ## a dataset that lives in HBM only: made by the GPU loaders below, consumed by hipFit / hipDecisionFunction
+    ## overloads that take the handle instead of uploading a CSRDataset
+    handle*: NfmDataset
+    nSamples*, nFeatures*, nnz*, nFields*: int
+
+proc hipLoadSVMLightFile*(f: string, dataset: var HipCSRDataset, y: var seq[float64], nFeatures: int = -1) =
+  ## dataset.nim:616-632 loadSVMLightFile: the text is parsed on the GPU, the CSR never exists on the host
+  new(dataset)
+  check nfm_dataset_load_svmlight(ctx(), f.cstring, nFeatures.int64, addr dataset.handle)
+  var n, d, nnz, nf: int64
+  check nfm_dataset_shape(dataset.handle, addr n, addr d, addr nnz, addr nf)
+  (dataset.nSamples, dataset.nFeatures, dataset.nnz, dataset.nFields) = (n.int, d.int, nnz.int, nf.int)
+  y = newSeq[float64](n.int)
+  if n > 0: check nfm_dataset_get_targets(dataset.handle, addr y[0])
+
+proc hipLoadFFMFile*(f: string, dataset: var HipCSRDataset, y: var seq[float64], nFeatures: int = -1, nFields: int = -1) =
+  ## dataset.nim:768-790 loadFFMFile
+  new(dataset)
+  check nfm_dataset_load_ffm(ctx(), f.cstring, nFeatures.int64, nFields.int64, addr dataset.handle)
+  var n, d, nnz, nf: int64
+  check nfm_dataset_shape(dataset.handle, addr n, addr d, addr nnz, addr nf)
+  (dataset.nSamples, dataset.nFeatures, dataset.nnz, dataset.nFields) = (n.int, d.int, nnz.int, nf.int)
+  y = newSeq[float64](n.int)
+  if n > 0: check nfm_dataset_get_targets(dataset.handle, addr y[0])
+
 proc lossId[L](loss: L): int32 =
   when L is Squared: 0 elif L is SquaredHinge: 1 elif L is Logistic: 2 else: 3
 
