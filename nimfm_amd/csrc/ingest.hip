@@ -21,6 +21,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -619,9 +620,26 @@ static int read_whole(const char* path, std::vector<unsigned char>* buf) {
 
 int ingest_stream(nfm_ctx* ctx, const char* x_path, const char* y_path, IngestResult* out) {
   hipStream_t st = ctx->stream;
-  std::vector<unsigned char> raw;
-  NFM_TRY(read_whole(x_path, &raw));
-  const int64_t len = (int64_t)raw.size();
+  // the bytes go to the device through the reader threads of upload_file; the host walks the row headers
+  // through a read-only mapping of the same file
+  DevBuf dev_raw;
+  int64_t len = 0;
+  NFM_TRY(upload_file(ctx, x_path, &dev_raw, &len));
+  struct Mapping {
+    const unsigned char* p = nullptr;
+    size_t n = 0;
+    ~Mapping() { if (p) munmap(const_cast<unsigned char*>(p), n); }
+    const unsigned char* data() const { return p; }
+  } raw;
+  if (len > 0) {
+    const int fd = open(x_path, O_RDONLY);
+    NFM_CHECK(fd >= 0, NFM_ERR_INVALID, "%s cannot be opened.", x_path);
+    void* mp = mmap(nullptr, (size_t)len, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    NFM_CHECK(mp != MAP_FAILED, NFM_ERR_INVALID, "%s cannot be mapped.", x_path);
+    raw.p = static_cast<const unsigned char*>(mp);
+    raw.n = (size_t)len;
+  }
   bool with_fields = false;
   int64_t base = 0;
   if (len >= 14 && !memcmp(raw.data(), "STREAMCSRFIELD", 14)) {
@@ -654,9 +672,7 @@ int ingest_stream(nfm_ctx* ctx, const char* x_path, const char* y_path, IngestRe
     max_row = std::max(max_row, r);
   }
   NFM_CHECK(acc == nnz, NFM_ERR_INVALID, "%s: rows hold %lld entries, header says %lld", x_path, (long long)acc, (long long)nnz);
-  DevBuf dev_raw, status;
-  NFM_TRY(dev_raw.alloc((size_t)len + 64));
-  NFM_HIP_CHECK(hipMemcpyAsync(dev_raw.p, raw.data(), (size_t)len, hipMemcpyHostToDevice, st));
+  DevBuf status;
   NFM_TRY(out->indptr.alloc(sizeof(int64_t) * (n + 1)));
   NFM_HIP_CHECK(hipMemcpyAsync(out->indptr.p, indptr.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
   NFM_TRY(out->indices.alloc(sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
