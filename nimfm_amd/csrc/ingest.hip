@@ -6,7 +6,7 @@
 // negative index = ValueError), nFeatures = maxIndex + 1 - offset (nFields likewise, :733-734, with the
 // reference's initial maxFieldIndex = 1).
 //
-// The file goes to HBM as bytes (pinned double buffer); everything after that is data-parallel:
+// The file goes to HBM as bytes (four reader threads, pinned buffers); everything after that is data-parallel:
 //   1. count per 16-KiB tile, scan, then list the positions of '\n' and ':' (16-byte loads, exact byte masks)
 //   2. one thread per LINE: its span, the colons inside it (binary search) -> row length and, because
 //      entries appear in file order, indptr[i] = (#colons before the line) / colons-per-entry; the
