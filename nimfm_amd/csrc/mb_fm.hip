@@ -421,7 +421,10 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
     m_max = __builtin_amdgcn_readfirstlane(m_max);
     // MODE 2: the first chunk's parameter rows stay in registers (prow); further chunks and MODE 1
     // stream the rows in groups of U, addressed from the held entries: one round trip per group
-    constexpr int U = RPS < dev::kFwdUnroll ? RPS : dev::kFwdUnroll;
+    // rows requested together per lane: 4 for one order of degree 2 (8 costs a wavefront of occupancy: cfg2 26.4 ->
+    // 25.1 us, AdaGrad k = 64 314 -> 295 us), 8 for the multi-order walk
+    constexpr int UW = GEN ? dev::kFwdUnroll : 4;
+    constexpr int U = RPS < UW ? RPS : UW;
     auto held_forward = [&](auto ps) {
       double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
       for (int base = 0; base == 0 || (CHUNKED && base < m_max); base += CAP) {
