@@ -781,7 +781,9 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         const double lambda = (double)o->batch * ((double)ds->v.nnz / (double)std::max<int64_t>(ds->v.n, 1)) / (double)m->d;
         bool use_singles = m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2 && (o->batch == 1 || lambda <= 1.4);
         if (const char* env = getenv("NFM_SINGLES")) use_singles = use_singles && atoi(env) != 0;  // tuning override
-        NFM_TRY(plan_build(ctx, ds->v, m->n_aug, perm, begin, end, o->batch, first_singleton, want_tq, use_singles, o->plan.get()));
+        const bool sort_by_count = m->Kp * (int)sizeof(double) >= 128;  // rows of at least one 128-byte line (plan.hip)
+        NFM_TRY(plan_build(ctx, ds->v, m->n_aug, perm, begin, end, o->batch, first_singleton, want_tq, use_singles, sort_by_count,
+                           o->plan.get()));
         o->plan->ds = ds;
       }
       if (m->cfg.kind == NFM_KIND_FM)

@@ -339,6 +339,9 @@ struct FColArgs {
   OptView O;
   const int32_t* ucol;
   const int64_t* uptr;
+  const int32_t* ucol_s;  // unique features by descending touch count (plan.h): what the column phase walks
+  const int64_t* ubeg_s;
+  const int32_t* ucnt_s;
   const int32_t* tpos;
   const double* tx;
   const int64_t* tq;  // sample-order touch index of every sorted touch
@@ -596,8 +599,8 @@ __global__ __launch_bounds__(kBlock) void k_ffm_col_phase(FColArgs a) {
   const double itp = (a.it0p[0] + a.it_b) - 1.0;
   double viol = 0.0;
   if (u < a.u1) {
-    const int64_t j = a.ucol[u];
-    const int64_t t0 = a.uptr[u], t1 = a.uptr[u + 1];
+    const int64_t j = a.ucol_s[u];
+    const int64_t t0 = a.ubeg_s[u], t1 = t0 + a.ucnt_s[u];
     const double c = (double)(t1 - t0);
     double sP = 1.0, sPn = 1.0, sw = 1.0, swn = 1.0, fP = 1.0, fw = 1.0;
     if (OPT == OPT_SGD) {
@@ -713,7 +716,8 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
     const int per_block = kWavesPerBlock * R;
     const int nB = (int)(((u1 - u0) * M.nb + per_block - 1) / per_block) + 1;  // units = (feature, field)
     {
-      FColArgs ca{M, O, P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(),
+      FColArgs ca{M, O, P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.ucol_s.as<int32_t>(), P.ubeg_s.as<int64_t>(),
+                  P.ucnt_s.as<int32_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(),
                   P.tq.as<int64_t>(), u0, u1, t_base[b], OPT == OPT_SGD ? Stab + 2 * b : M.sc,
                   OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc, OPT == OPT_SGD ? Dtab + 4 * b : nullptr,
                   OPT == OPT_SGD ? W.Ftab.as<double>() + (size_t)b * 2 * kFtab : nullptr, W.contrib.as<double>(),

@@ -827,6 +827,9 @@ struct ColArgs {
   int32_t len_i, nS;
   const int32_t* ucol;
   const int64_t* uptr;
+  const int32_t* ucol_s;  // the batch's unique features by descending touch count (plan.h): what k_col_phase walks
+  const int64_t* ubeg_s;
+  const int32_t* ucnt_s;
   const int32_t* tpos;
   const double* tx;
   int64_t u0, u1;
@@ -1255,9 +1258,10 @@ __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
        u = STRIDED ? u + stride : a.u1) {
     // heavy features are summed by k_heavy_partial / k_heavy_apply (degree-1 models have no parameter block
     // to walk them with and keep them here)
-    if (M.nb > 0 && a.uptr[u + 1] - a.uptr[u] > kHeavyTouches) continue;
-    const int64_t j = a.ucol[u];
-    const int64_t t0 = a.uptr[u], t1 = a.uptr[u + 1];
+    const int64_t cnt_u = a.ucnt_s[u];
+    if (M.nb > 0 && cnt_u > kHeavyTouches) continue;
+    const int64_t j = a.ucol_s[u];
+    const int64_t t0 = a.ubeg_s[u], t1 = t0 + cnt_u;
     double sP = 1.0, sPn = 1.0, sw = 1.0, swn = 1.0, fP = 1.0, fw = 1.0;
     if (OPT == OPT_SGD) {
       sP = a.scales_b[0];
@@ -1466,7 +1470,8 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     {
       ColArgs ca{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, singles_in_col ? P.toff.as<int64_t>() : nullptr,
                  singles_in_col ? P.single.as<uint8_t>() : nullptr, P.begin, p0, len, nS,
-                 P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(), u0, u1,
+                 P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.ucol_s.as<int32_t>(), P.ubeg_s.as<int64_t>(), P.ucnt_s.as<int32_t>(),
+                 P.tpos.as<int32_t>(), P.tx.as<double>(), u0, u1,
                  OPT == OPT_SGD ? Stab + 2 * b : M.sc, OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc,
                  OPT == OPT_SGD ? Dtab + 4 * b : nullptr,
                  OPT == OPT_SGD ? W.Ftab.as<double>() + (size_t)b * 2 * kFtab : nullptr, W.Abuf.as<double>(),
@@ -1493,7 +1498,8 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
       HeavyArgs ha{P.hv_u.as<int64_t>(), P.hv_seg0.as<int64_t>(), P.bat_hoff[b], P.bat_hoff[b + 1], P.bat_soff[b],
                    P.bat_soff[b + 1], W.hpart.as<double>(), parts_cur + nS + nB, PW, 0};
       ColArgs ca{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, nullptr, nullptr, P.begin, p0, len, nS,
-                 P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(), u0, u1,
+                 P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), P.ucol_s.as<int32_t>(), P.ubeg_s.as<int64_t>(), P.ucnt_s.as<int32_t>(),
+                 P.tpos.as<int32_t>(), P.tx.as<double>(), u0, u1,
                  OPT == OPT_SGD ? Stab + 2 * b : M.sc, OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc,
                  OPT == OPT_SGD ? Dtab + 4 * b : nullptr,
                  OPT == OPT_SGD ? W.Ftab.as<double>() + (size_t)b * 2 * kFtab : nullptr, W.Abuf.as<double>(),

@@ -25,6 +25,12 @@ struct Plan {
   DevBuf bat_pos_dev;             // int64[n_batches + 1]
   DevBuf ucol;                    // int32[U]
   DevBuf uptr;                    // int64[U + 1]
+  // the same unique features, inside every batch ordered by DESCENDING touch count: the lane groups of a
+  // wavefront walk their features' touch lists in lock step, so a wavefront lasts as long as its longest list --
+  // neighbours of equal length waste nothing (cfg2: the longest of 8 Poisson(10.5) lists is 15)
+  DevBuf ucol_s;                  // int32[U] feature
+  DevBuf ubeg_s;                  // int64[U] first touch
+  DevBuf ucnt_s;                  // int32[U] touches
   DevBuf tpos;                    // int32[TM]
   DevBuf tx;                      // double[TM]
   DevBuf tq;                      // int64[TM] (only when want_tq)
@@ -50,6 +56,6 @@ constexpr int kHeavyTouches = 128;
 constexpr int kHeavySegment = 64;
 
 int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
-               int64_t batch, bool first_singleton, bool want_tq, bool use_singles, Plan* out);
+               int64_t batch, bool first_singleton, bool want_tq, bool use_singles, bool sort_by_count, Plan* out);
 
 }  // namespace nfm

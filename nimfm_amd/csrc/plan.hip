@@ -7,6 +7,8 @@
 // with shuffle off the plan is reused by every epoch.
 #include <hipcub/hipcub.hpp>
 
+#include <stdlib.h>
+
 #include "plan.h"
 
 namespace nfm {
@@ -16,6 +18,9 @@ void Plan::release() {
   bat_pos_dev.release();
   ucol.release();
   uptr.release();
+  ucol_s.release();
+  ubeg_s.release();
+  ucnt_s.release();
   tpos.release();
   tx.release();
   tq.release();
@@ -124,6 +129,26 @@ __global__ void k_compact(int64_t T, const uint64_t* __restrict__ keys, const ui
   }
 }
 
+// (batch, descending touch count) keys of the unique features, and the gather into the sorted tables
+__global__ void k_ukeys(int64_t U, const int64_t* __restrict__ ubatch, const int64_t* __restrict__ uptr, int bucket,
+                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = uptr[u + 1] - uptr[u];
+    keys[u] = ((uint64_t)ubatch[u] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(c / bucket));
+    vals[u] = (uint32_t)u;
+  }
+}
+__global__ void k_usorted(int64_t U, const uint32_t* __restrict__ vals, const int32_t* __restrict__ ucol,
+                          const int64_t* __restrict__ uptr, int32_t* __restrict__ ucol_s, int64_t* __restrict__ ubeg_s,
+                          int32_t* __restrict__ ucnt_s) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < U; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t u = vals[i];
+    ucol_s[i] = ucol[u];
+    ubeg_s[i] = uptr[u];
+    ucnt_s[i] = (int32_t)(uptr[u + 1] - uptr[u]);
+  }
+}
+
 // first unique feature of every batch that has one
 __global__ void k_batch_first(int64_t U, const int64_t* __restrict__ ubatch, int64_t* __restrict__ bat_first_u) {
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x)
@@ -168,7 +193,7 @@ static inline unsigned grid1d(int64_t n) {
 }
 
 int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
-               int64_t batch, bool first_singleton, bool want_tq, bool use_singles, Plan* out) {
+               int64_t batch, bool first_singleton, bool want_tq, bool use_singles, bool sort_by_count, Plan* out) {
   static uint64_t g_serial = 0;
   Plan& P = *out;
   P.release();
@@ -284,6 +309,33 @@ int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_ho
     hipLaunchKernelGGL(k_batch_first, dim3(grid1d(U)), dim3(kBlock), 0, st, U, ubatch.as<int64_t>(), bfu.as<int64_t>());
   NFM_HIP_CHECK(hipGetLastError());
   NFM_HIP_CHECK(hipMemcpyAsync(P.uptr.as<int64_t>() + U, &TM, sizeof(int64_t), hipMemcpyHostToDevice, st));
+  // the per-batch order by descending touch count (the batch ranges [bat_uoff[b], bat_uoff[b+1]) are unchanged)
+  NFM_TRY(P.ucol_s.alloc(sizeof(int32_t) * std::max<int64_t>(U, 1)));
+  NFM_TRY(P.ubeg_s.alloc(sizeof(int64_t) * std::max<int64_t>(U, 1)));
+  NFM_TRY(P.ucnt_s.alloc(sizeof(int32_t) * std::max<int64_t>(U, 1)));
+  if (U > 0) {
+    NFM_CHECK(P.n_batches < ((int64_t)1 << 31), NFM_ERR_UNSUPPORTED, "too many batches");
+    DevBuf uk0, uk1, uv0, uv1, utmp;
+    NFM_TRY(uk0.alloc(sizeof(uint64_t) * U)); NFM_TRY(uk1.alloc(sizeof(uint64_t) * U));
+    NFM_TRY(uv0.alloc(sizeof(uint32_t) * U)); NFM_TRY(uv1.alloc(sizeof(uint32_t) * U));
+    static const int cnt_bucket = getenv("NFM_CNT_BUCKET") && atoi(getenv("NFM_CNT_BUCKET")) > 0 ? atoi(getenv("NFM_CNT_BUCKET")) : 1;
+    hipLaunchKernelGGL(k_ukeys, dim3(grid1d(U)), dim3(kBlock), 0, st, U, ubatch.as<int64_t>(), P.uptr.as<int64_t>(), cnt_bucket,
+                       uk0.as<uint64_t>(), uv0.as<uint32_t>());
+    hipcub::DoubleBuffer<uint64_t> udk(uk0.as<uint64_t>(), uk1.as<uint64_t>());
+    hipcub::DoubleBuffer<uint32_t> udv(uv0.as<uint32_t>(), uv1.as<uint32_t>());
+    // Parameter rows shorter than a 128-byte line (k <= 8) keep the feature order: neighbours in the list are
+    // neighbours in memory and share their lines, which is worth more than balanced wavefronts (cfg5, k = 8:
+    // column phase 59 us in feature order, 64 us by count; cfg2, k = 16: 38 vs 35 us)
+    if (sort_by_count) {
+      size_t ub = 0;
+      NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, ub, udk, udv, (int)U, 0, 32 + bbits, st));
+      NFM_TRY(utmp.alloc(ub));
+      NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(utmp.p, ub, udk, udv, (int)U, 0, 32 + bbits, st));
+    }
+    hipLaunchKernelGGL(k_usorted, dim3(grid1d(U)), dim3(kBlock), 0, st, U, udv.Current(), P.ucol.as<int32_t>(),
+                       P.uptr.as<int64_t>(), P.ucol_s.as<int32_t>(), P.ubeg_s.as<int64_t>(), P.ucnt_s.as<int32_t>());
+    NFM_HIP_CHECK(hipStreamSynchronize(st));  // the sort's temporaries go out of scope
+  }
   std::vector<int64_t> first(P.n_batches);
   NFM_HIP_CHECK(hipMemcpyAsync(first.data(), bfu.p, sizeof(int64_t) * P.n_batches, hipMemcpyDeviceToHost, st));
   NFM_HIP_CHECK(hipStreamSynchronize(st));
