@@ -19,7 +19,7 @@ LOWER = {"explicit": 0, "augment": 1, "none": 2}
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("nimfm_oracle.c", "nimfm_slow.c", "nimfm_mb.c", "nimfm_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("nimfm_oracle.c", "nimfm_slow.c", "nimfm_mb.c", "nimfm_psgd.c", "nimfm_ingest.c", "nimfm_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -42,6 +42,13 @@ class AdaCfg(C.Structure):
                 ("fit_linear", C.c_int32), ("fit_intercept", C.c_int32), ("pad_", C.c_int32)]
 
 
+class PSGDCfg(C.Structure):
+    _fields_ = [("eta0", C.c_double), ("alpha0", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
+                ("gamma", C.c_double), ("power", C.c_double), ("loss_param", C.c_double), ("loss", C.c_int32),
+                ("scheduling", C.c_int32), ("fit_linear", C.c_int32), ("fit_intercept", C.c_int32),
+                ("reg", C.c_int32), ("reg_transpose", C.c_int32)]
+
+
 _lib = None
 
 
@@ -51,7 +58,7 @@ def lib():
         build()
         _lib = C.CDLL(_SO)
         for name in ("orc_loss", "orc_dloss", "orc_get_eta", "orc_expit", "orc_rmse", "orc_accuracy_sign",
-                     "orc_regularization", "slow_anova"):
+                     "orc_regularization", "slow_anova", "orc_reg_eval"):
             getattr(_lib, name).restype = C.c_double
         _lib.orc_loss.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double]
         _lib.orc_dloss.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double]
@@ -380,3 +387,63 @@ def svmlight_load_c(text):
     L.orc_svmlight_fill.restype = None
     L.orc_svmlight_fill(text, C.c_int64(len(text)), off, _p(indptr), _p(indices), _p(data), _p(y))
     return dict(indptr=indptr, indices=indices, data=data, y=y, n_features=d.value, offset=off.value)
+
+
+# ---- mini-batch proximal SGD, SURVEY.md 8(f) rank 3 (nimfm_psgd.c) ----
+REG = {"l1": 0, "l21": 1, "squaredl12": 2, "squaredl21": 3}
+
+
+def psgd_cfg(eta0=0.1, alpha0=1e-6, alpha=1e-3, beta=1e-4, gamma=1e-4, loss="squared", reg="squaredl12",
+             transpose=None, scheduling="optimal", power=1.0, fit_linear=True, fit_intercept=True, loss_param=1.0):
+    """newMBPSGD's defaults (optimizer/minibatch_psgd.nim:24-29); transpose defaults as the regularizers'
+    constructors do (squaredl12.nim:85: true, squaredl21.nim:15: false)"""
+    if transpose is None:
+        transpose = reg == "squaredl12"
+    return PSGDCfg(eta0, alpha0, alpha, beta, gamma, power, loss_param, LOSS[loss], SCHED[scheduling], int(fit_linear),
+                   int(fit_intercept), REG[reg], int(transpose))
+
+
+def prox_squaredl12(p, lam, seed=1):
+    p = np.array(p, dtype=np.float64)
+    rng = C.c_uint64(seed)
+    lib().orc_prox_squaredl12(_p(p), C.c_int64(len(p)), C.c_double(lam), C.byref(rng))
+    return p
+
+
+def prox_squaredl12_slow(p, lam):
+    p = np.array(p, dtype=np.float64)
+    lib().orc_prox_squaredl12_slow(_p(p), C.c_int64(len(p)), C.c_double(lam))
+    return p
+
+
+def prox(reg, Pt, lam, transpose=None, seed=1):
+    """matrix prox on one order in the training layout [da][k]; returns a new array"""
+    if transpose is None:
+        transpose = reg == "squaredl12"
+    Pt = np.array(Pt, dtype=np.float64, order="C")
+    rng = C.c_uint64(seed)
+    lib().orc_prox(REG[reg], int(transpose), _p(Pt), C.c_int64(Pt.shape[0]), int(Pt.shape[1]), C.c_double(lam),
+                   C.byref(rng))
+    return Pt
+
+
+def reg_eval(reg, Pt, transpose=None):
+    if transpose is None:
+        transpose = reg == "squaredl12"
+    Pt = np.ascontiguousarray(Pt, dtype=np.float64)
+    return lib().orc_reg_eval(REG[reg], int(transpose), _p(Pt), C.c_int64(Pt.shape[0]), int(Pt.shape[1]))
+
+
+def fm_mbpsgd_epoch(X, y, degree, P, w, intercept, cfg, stream, batch, n_aug=0, it=1, seed=1):
+    """one outer iteration (minibatch_psgd.nim:87-122) in place on P (model layout) and w;
+    returns (intercept, it, loss_sum)"""
+    O, k, da = P.shape
+    assert P.dtype == np.float64 and P.flags.c_contiguous and w.flags.c_contiguous
+    y = f64(y)
+    stream = i64(stream)
+    b, itc, ls, rng = C.c_double(intercept), C.c_int64(it), C.c_double(0), C.c_uint64(seed)
+    rc = lib().orc_fm_mbpsgd_epoch(C.byref(X.c), _p(y), degree, k, O, n_aug, _p(P), _p(w), C.byref(b), C.byref(cfg),
+                                   _p(stream), C.c_int64(len(stream)), C.c_int64(batch), C.byref(itc), C.byref(rng),
+                                   C.byref(ls))
+    assert rc == 0
+    return b.value, itc.value, ls.value

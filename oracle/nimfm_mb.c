@@ -345,3 +345,6 @@ int orc_fm_adagrad_finalize(int degree, int k, int n_orders, int n_aug, int64_t 
   free(Pt);
   return 0;
 }
+
+/* mini-batch proximal SGD shares predict_with_grad with the above */
+#include "nimfm_psgd.c"

@@ -188,6 +188,25 @@ int orc_fm_adagrad_finalize(int degree, int k, int n_orders, int n_aug, int64_t 
                             double* gsum_P, double* gnorm_P, double* gsum_w, double* gnorm_w,
                             double* gsum_b, double* gnorm_b);
 
+/* ---- mini-batch proximal SGD, SURVEY.md 8(f) rank 3 (nimfm_psgd.c) ---- */
+enum { ORC_REG_L1 = 0, ORC_REG_L21 = 1, ORC_REG_SQUAREDL12 = 2, ORC_REG_SQUAREDL21 = 3 };
+typedef struct orc_psgd_cfg {
+  double eta0, alpha0, alpha, beta, gamma, power, loss_param;
+  int32_t loss, scheduling, fit_linear, fit_intercept, reg, reg_transpose;
+} orc_psgd_cfg;
+/* regularizer/squaredl12.nim:16-69 and its brute-force twin tests/regularizer/squaredl12_slow.nim:10-25 */
+void orc_prox_squaredl12(double* p, int64_t n, double lam, uint64_t* rng);
+void orc_prox_squaredl12_slow(double* p, int64_t n, double lam);
+/* the matrix prox of l1.nim:35-39, l21.nim:23-34, squaredl12.nim:147-162, squaredl21.nim:46-54 on one
+ * order in the training layout [da][k] */
+void orc_prox(int reg, int transpose, double* Po, int64_t da, int k, double lam, uint64_t* rng);
+double orc_reg_eval(int reg, int transpose, const double* Po, int64_t da, int k);
+/* optimizer/minibatch_psgd.nim:87-122 (one outer iteration over an explicit index stream) */
+int orc_fm_mbpsgd_epoch(const orc_csr* X, const double* y, int degree, int k, int n_orders, int n_aug,
+                        double* P, double* w, double* intercept, const orc_psgd_cfg* cfg,
+                        const int64_t* stream, int64_t n_stream, int64_t batch, int64_t* it,
+                        uint64_t* rng, double* loss_sum);
+
 #ifdef __cplusplus
 }
 #endif
