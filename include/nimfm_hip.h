@@ -60,6 +60,9 @@ enum { NFM_SCHED_CONSTANT = 0, NFM_SCHED_OPTIMAL = 1, NFM_SCHED_INVSCALING = 2, 
  *   (optimizer/sgd_multi.nim:40-120, adagrad_multi.nim:39-115); equals the
  *   sequential rule at batch == 1. */
 enum { NFM_MODE_SEQUENTIAL = 0, NFM_MODE_MINIBATCH = 1 };
+/* sparsity-inducing regularisers with a matrix proximal operator (regularizer/l1.nim, l21.nim,
+ * squaredl12.nim, squaredl21.nim); OmegaTI / OmegaCS have none and cannot drive MBPSGD */
+enum { NFM_REG_L1 = 0, NFM_REG_L21 = 1, NFM_REG_SQUAREDL12 = 2, NFM_REG_SQUAREDL21 = 3 };
 
 const char* nfm_last_error(void);
 int32_t nfm_version(void);
@@ -209,8 +212,25 @@ typedef struct nfm_adagrad_cfg { /* newAdaGrad, optimizer/adagrad.nim:20-44 */
   int64_t batch;
 } nfm_adagrad_cfg;
 
+/* newMBPSGD (optimizer/minibatch_psgd.nim:24-65): the reference's own mini-batch rule --
+ * the gradient of `batch` samples averaged (updateGradient, :67-84), one step on ALL parameters
+ * (Params.step, model/params.nim:90-98), then the regulariser's prox per order with
+ * gamma * eta_P / (1 + eta_P * beta) (:112-120).  FactorizationMachine only.  SquaredL12 / SquaredL21 need
+ * degree 2 (their initSGD raises, squaredl12.nim:103-105); reg_transpose: SquaredL12 column-wise (1, the
+ * reference default) or row-wise (0); SquaredL21 only 0 (its default).
+ * nfm_opt_epoch on such an optimizer runs (end - begin) / batch mini-batches over perm[begin..end) -- the
+ * stream of sample indices the reference's inner loops consume (indices[ii], wrap-arounds included), so
+ * end may exceed nSamples when perm is given and (end - begin) must be a multiple of batch; `it` advances
+ * once per mini-batch (:121); viol_sum is 0 (the solver has none). */
+typedef struct nfm_mbpsgd_cfg {
+  double eta0, alpha0, alpha, beta, gamma, power, loss_param;
+  int32_t loss, scheduling, reg /* NFM_REG_* */, reg_transpose;
+  int64_t batch; /* miniBatchSize >= 1 */
+} nfm_mbpsgd_cfg;
+
 int32_t nfm_sgd_create(nfm_model* m, const nfm_sgd_cfg* cfg, nfm_opt** out);
 int32_t nfm_adagrad_create(nfm_model* m, const nfm_adagrad_cfg* cfg, nfm_opt** out);
+int32_t nfm_mbpsgd_create(nfm_model* m, const nfm_mbpsgd_cfg* cfg, nfm_opt** out);
 /* the optimizer's `it` (optimizer/sgd.nim:18,55-56; adagrad.nim:14,50): starts
  * at 1, +1 per sample; set to 1 to mimic a non-warm-start fit. */
 int32_t nfm_opt_set_it(nfm_opt* o, int64_t it);

@@ -22,6 +22,7 @@ LOWER = {"explicit": 0, "augment": 1, "none": 2}
 LOSS = {"squared": 0, "squared_hinge": 1, "logistic": 2, "huber": 3}
 SCHED = {"constant": 0, "optimal": 1, "invscaling": 2, "pegasos": 3}
 MODE = {"sequential": 0, "minibatch": 1}
+REG = {"l1": 0, "l21": 1, "squaredl12": 2, "squaredl21": 3}
 
 # every symbol include/nimfm_hip.h declares (tests/test_abi.py checks header <-> library <-> this list)
 SYMBOLS = [
@@ -35,7 +36,7 @@ SYMBOLS = [
     "nfm_model_create", "nfm_model_shape", "nfm_model_set_params", "nfm_model_get_params",
     "nfm_decision_function", "nfm_decision_function_device", "nfm_score", "nfm_metrics", "nfm_model_sqnorms", "nfm_model_device_buffers",
     "nfm_model_destroy",
-    "nfm_sgd_create", "nfm_adagrad_create", "nfm_opt_set_it", "nfm_opt_get_it", "nfm_opt_get_state",
+    "nfm_sgd_create", "nfm_adagrad_create", "nfm_mbpsgd_create", "nfm_opt_set_it", "nfm_opt_get_it", "nfm_opt_get_state",
     "nfm_opt_set_state", "nfm_opt_epoch", "nfm_opt_finalize", "nfm_opt_device_state", "nfm_opt_destroy",
 ]
 
@@ -50,6 +51,12 @@ class SGDCfg(C.Structure):
     _fields_ = [("eta0", C.c_double), ("alpha0", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
                 ("power", C.c_double), ("loss_param", C.c_double), ("loss", C.c_int32), ("scheduling", C.c_int32),
                 ("mode", C.c_int32), ("reserved", C.c_int32), ("batch", C.c_int64)]
+
+
+class MBPSGDCfg(C.Structure):
+    _fields_ = [("eta0", C.c_double), ("alpha0", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
+                ("gamma", C.c_double), ("power", C.c_double), ("loss_param", C.c_double), ("loss", C.c_int32),
+                ("scheduling", C.c_int32), ("reg", C.c_int32), ("reg_transpose", C.c_int32), ("batch", C.c_int64)]
 
 
 class AdaGradCfg(C.Structure):
@@ -137,6 +144,7 @@ def lib():
         "nfm_model_destroy": [vp],
         "nfm_sgd_create": [vp, C.POINTER(SGDCfg), pp],
         "nfm_adagrad_create": [vp, C.POINTER(AdaGradCfg), pp],
+        "nfm_mbpsgd_create": [vp, C.POINTER(MBPSGDCfg), pp],
         "nfm_opt_set_it": [vp, i64],
         "nfm_opt_get_it": [vp, C.POINTER(i64)],
         "nfm_opt_get_state": [vp, vp, vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl)],

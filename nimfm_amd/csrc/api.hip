@@ -637,9 +637,33 @@ int32_t nfm_adagrad_create(nfm_model* m, const nfm_adagrad_cfg* c, nfm_opt** out
   return NFM_OK;
 }
 
+int32_t nfm_mbpsgd_create(nfm_model* m, const nfm_mbpsgd_cfg* c, nfm_opt** out) {
+  NFM_CHECK(c && out, NFM_ERR_INVALID, "null argument");
+  NFM_TRY(check_common(m, c->loss, NFM_MODE_MINIBATCH, c->batch));
+  NFM_CHECK(c->scheduling >= 0 && c->scheduling <= 3, NFM_ERR_INVALID, "bad scheduling id");
+  NFM_CHECK(c->reg >= NFM_REG_L1 && c->reg <= NFM_REG_SQUAREDL21, NFM_ERR_INVALID, "bad regularizer id");
+  NFM_CHECK(m->cfg.kind == NFM_KIND_FM, NFM_ERR_UNSUPPORTED, "MBPSGD fits a FactorizationMachine (minibatch_psgd.nim:125-126)");
+  if (c->reg == NFM_REG_SQUAREDL12)  // squaredl12.nim:103-105
+    NFM_CHECK(m->cfg.degree == 2, NFM_ERR_INVALID, "SquaredL12 supports only degree=2.");
+  if (c->reg == NFM_REG_SQUAREDL21) {  // squaredl21.nim:27-28
+    NFM_CHECK(m->cfg.degree == 2, NFM_ERR_INVALID, "SquaredL21 supports only degree=2.");
+    NFM_CHECK(!c->reg_transpose, NFM_ERR_UNSUPPORTED, "SquaredL21 with transpose=true is not supported");
+  }
+  std::unique_ptr<nfm_opt> o(new nfm_opt());
+  o->ctx = m->ctx; o->m = m; o->kind = OPT_PSGD; o->mode = NFM_MODE_MINIBATCH; o->batch = c->batch; o->it = 1;
+  o->o.eta0 = c->eta0; o->o.alpha0 = c->alpha0; o->o.alpha = c->alpha; o->o.beta = c->beta; o->o.power = c->power;
+  o->o.eps = 0.0; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = c->scheduling; o->o.track_viol = 0;
+  o->o.gamma = c->gamma; o->o.bsize = (double)c->batch; o->o.reg = c->reg; o->o.reg_transpose = c->reg_transpose ? 1 : 0;
+  NFM_TRY(use_device(m->ctx));
+  NFM_TRY(o->out2.alloc(sizeof(double) * 2));
+  *out = o.release();
+  return NFM_OK;
+}
+
 int32_t nfm_opt_set_it(nfm_opt* o, int64_t it) {
   NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
-  NFM_CHECK(it >= 1, NFM_ERR_INVALID, "it must be >= 1");
+  // newMBPSGD starts at it = 0 and a warm-started fit keeps it (minibatch_psgd.nim:63,153-154)
+  NFM_CHECK(it >= (o->kind == OPT_PSGD ? 0 : 1), NFM_ERR_INVALID, "it must be >= 1");
   o->it = it;
   return NFM_OK;
 }
@@ -741,8 +765,12 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
   NFM_CHECK(ds->ctx == ctx, NFM_ERR_INVALID, "optimizer and dataset belong to different contexts");
   NFM_TRY(check_predict_shapes(m, ds));
   NFM_CHECK(ds->has_y, NFM_ERR_INVALID, "dataset has no targets");
-  NFM_CHECK(begin >= 0 && begin <= end && end <= ds->v.n, NFM_ERR_INVALID, "bad sample range [%lld,%lld)", (long long)begin,
-            (long long)end);
+  // MBPSGD consumes a stream of sample indices that may wrap past the end of the data (minibatch_psgd.nim:104-108)
+  NFM_CHECK(begin >= 0 && begin <= end && (end <= ds->v.n || (o->kind == OPT_PSGD && perm)), NFM_ERR_INVALID,
+            "bad sample range [%lld,%lld)", (long long)begin, (long long)end);
+  if (o->kind == OPT_PSGD)
+    NFM_CHECK((end - begin) % o->batch == 0, NFM_ERR_INVALID, "MBPSGD: %lld samples are not a whole number of mini-batches of %lld",
+              (long long)(end - begin), (long long)o->batch);
   if (perm)
     for (int64_t p = begin; p < end; ++p)
       NFM_CHECK(perm[p] >= 0 && perm[p] < ds->v.n, NFM_ERR_INVALID, "perm[%lld] = %lld out of range", (long long)p, (long long)perm[p]);
@@ -750,6 +778,8 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
   hipStream_t st = ctx->stream;
   if (o->kind == OPT_ADAGRAD) {
     if (o->it == 1 || !o->state_ready) NFM_TRY(adagrad_reset_state(o));
+    NFM_TRY(ensure_unit_scale(m));
+  } else if (o->kind == OPT_PSGD) {
     NFM_TRY(ensure_unit_scale(m));
   }
   double out2[2] = {0.0, 0.0};
@@ -779,7 +809,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         // second visit of the row only when they are a sizeable share of the touches.  With a touch
         // rate lambda = batch * nnz_per_row / d per feature that share is about exp(-lambda).
         const double lambda = (double)o->batch * ((double)ds->v.nnz / (double)std::max<int64_t>(ds->v.n, 1)) / (double)m->d;
-        bool use_singles = m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2 && (o->batch == 1 || lambda <= 1.4);
+        bool use_singles = o->kind != OPT_PSGD && m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2 && (o->batch == 1 || lambda <= 1.4);
         if (const char* env = getenv("NFM_SINGLES")) use_singles = use_singles && atoi(env) != 0;  // tuning override
         const bool sort_by_count = m->Kp * (int)sizeof(double) >= 128;  // rows of at least one 128-byte line (plan.hip)
         NFM_TRY(plan_build(ctx, ds->v, m->n_aug, perm, begin, end, o->batch, first_singleton, want_tq, use_singles, sort_by_count,
@@ -791,7 +821,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       else
         NFM_TRY(mb_ffm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2));
     }
-    o->it += ns;
+    o->it += o->kind == OPT_PSGD ? ns / o->batch : ns;
     if (o->kind == OPT_SGD) {  // resetScaling, sgd.nim:116-131
       double sc[SC_COUNT];
       NFM_HIP_CHECK(hipMemcpyAsync(sc, m->sc.p, sizeof(sc), hipMemcpyDeviceToHost, st));
@@ -810,6 +840,8 @@ int32_t nfm_opt_finalize(nfm_opt* o) {
   NFM_TRY(use_device(m->ctx));
   if (o->kind == OPT_SGD) {
     NFM_TRY(launch_rescale(m->ctx, m->view()));
+  } else if (o->kind == OPT_PSGD) {
+    // pgd.finalize (optimizer/pgd.nim:45-51) only copies the parameters back
   } else if (o->state_ready) {
     NFM_TRY(launch_adagrad_finalize(m->ctx, m->view(), o->o, o->it));
   }

@@ -18,6 +18,7 @@ struct MbWork {
   DevBuf contrib;  // FFM: per-touch gradient rows
   DevBuf itbuf;    // device scalar: `it` at the start of the epoch call
   DevBuf hpart;    // heavy features: per-segment partial sums
+  DevBuf prox;     // MBPSGD: row norms [nb][da] + thresholds [nb][Kp] of the coupled prox operators
   // hipGraph of one epoch call over a reusable plan
   bool use_graph = true;
   void* graph_exec = nullptr;

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
       if (q < m) {
         wq[e] = M.w[jq[e]];
         double wj = sw * wq[e];
-        if (OPT == OPT_ADAGRAD && M.fit_linear) {
+        if (OPT == OPT_ADAGRAD && M.fit_linear && (!stored || a.single != nullptr)) {
           gwq[e] = O.Gw[jq[e]];
           nwq[e] = O.Nw[jq[e]];
           if (!stored) wj = -O.eta0 * gwq[e] / (denw + sqrt(nwq[e]));
@@ -871,6 +871,9 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
     stored = dev::ld_stream(M.P + e);
     p.x = sP * stored.x;
     p.y = sP * stored.y;
+  } else if (OPT == OPT_PSGD) {  // minibatch_psgd.nim:72: the parameters as they stand, no lazy scale
+    stored = dev::ld_stream(M.P + e);
+    p = stored;
   } else {
     g2 = dev::ld_stream(O.G + e);
     n2 = dev::ld_stream(O.N + e);
@@ -961,6 +964,11 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
                 wacc.a0 += r[u].etaw * (r[u].dL * x[u]);
                 wacc.a1 += r[u].etaw;
               }
+            } else if (OPT == OPT_PSGD) {  // minibatch_psgd.nim:75-84: coef = dloss / miniBatchSize
+              const double cf = r[u].dL / O.bsize;
+              acc.x += cf * dAx;
+              acc.y += cf * dAy;
+              if (do_w) wacc.a0 += cf * x[u];
             } else {  // adagrad.nim:122-124
               const double gx = r[u].dL * dAx, gy = r[u].dL * dAy;
               acc.x += gx;
@@ -1027,6 +1035,11 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
               wacc.a0 += r[u].etaw * (r[u].dL * x[u]);
               wacc.a1 += r[u].etaw;
             }
+          } else if (OPT == OPT_PSGD) {
+            const double cf = r[u].dL / O.bsize;
+            acc.x += cf * dAx;
+            acc.y += cf * dAy;
+            if (do_w) wacc.a0 += cf * x[u];
           } else {
             const double gx = r[u].dL * dAx, gy = r[u].dL * dAy;
             acc.x += gx;
@@ -1061,6 +1074,10 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
     stored.x = stored.x * fP - (acc.x / c) / sPn;
     stored.y = stored.y * fP - (acc.y / c) / sPn;
     dev::st_stream(M.P + e, stored);
+  } else if (OPT == OPT_PSGD) {  // Params.add with -eta_P (model/params.nim:33-41,97); sPn carries eta_P here
+    stored.x += -sPn * acc.x;
+    stored.y += -sPn * acc.y;
+    dev::st_stream(M.P + e, stored);
   } else {
     g2.x += acc.x;
     g2.y += acc.y;
@@ -1086,6 +1103,8 @@ __device__ __forceinline__ double w_epilogue(const ColArgs& a, int64_t j, int l,
       viol += fabs((wacc.a0 + wacc.a1 * O.alpha * wj) / c);
       M.w[j] = wt * fw - (wacc.a0 / c) / swn;
     }
+  } else if (OPT == OPT_PSGD) {  // model/params.nim:43-45; swn carries eta_w
+    if (l == 0) M.w[j] = wt + -swn * wacc.a0;
   } else {
     const double gw = O.Gw[j], nw = O.Nw[j];
     if (l == 0) {
@@ -1176,6 +1195,11 @@ __global__ __launch_bounds__(kBlock) void k_heavy_apply(ColArgs a, HeavyArgs hv)
       sPn = a.scales_n[0];
       swn = a.scales_n[1];
       touch_factors(a, c, fP, fw);
+    } else if (OPT == OPT_PSGD) {  // this mini-batch's step sizes (minibatch_psgd.nim:112-113) ride in sPn / swn
+      const OptView& O = a.O;
+      const double it = a.it0p[0] + a.it_b;
+      sPn = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+      swn = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
     }
     const bool has_w = M.fit_linear && j < M.d;
     WAcc wacc;
@@ -1269,6 +1293,10 @@ __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
       sPn = a.scales_n[0];
       swn = a.scales_n[1];
       touch_factors(a, t1 - t0, fP, fw);
+    } else if (OPT == OPT_PSGD) {
+      const double it = a.it0p[0] + a.it_b;
+      sPn = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+      swn = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it);
     }
     const bool has_w = M.fit_linear && j < M.d;  // dummy features have no w
     WAcc wacc;
@@ -1287,6 +1315,8 @@ __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
           if (OPT == OPT_SGD) {
             wacc.a0 += r.etaw * (r.dL * x);
             wacc.a1 += r.etaw;
+          } else if (OPT == OPT_PSGD) {
+            wacc.a0 += (r.dL / O.bsize) * x;
           } else {
             wacc.a0 += r.dL * x;
             wacc.a1 += (r.dL * x) * (r.dL * x);
@@ -1331,6 +1361,10 @@ __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
         const double b0 = M.sc[SC_INTERCEPT], f0 = a.Dtab_b[3];
         v += fabs((red[2][0] + red[3][0] * O.alpha0 * b0) / a.len);
         M.sc[SC_INTERCEPT] = f0 * b0 - red[2][0] / a.len;
+      } else if (OPT == OPT_PSGD) {
+        // model/params.nim:47 gates the intercept's step on grad.fitLinear -- kept as the reference has it
+        if (M.fit_linear)
+          M.sc[SC_INTERCEPT] += -dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, a.it0p[0] + a.it_b) * (red[2][0] / O.bsize);
       } else {
         if (!a.use_stored) {  // adagrad.nim:102-106
           const double old = M.sc[SC_INTERCEPT];
@@ -1360,6 +1394,210 @@ __global__ __launch_bounds__(kBlock) void k_epoch_close(const double* __restrict
     __syncthreads();
   }
   if (threadIdx.x == 0) out_acc[1] += red[0];
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// MBPSGD (optimizer/minibatch_psgd.nim:87-122): after the column phase has added
+// -eta * (batch gradient) to the touched rows, EVERY parameter shrinks by 1 / (1 + eta * reg)
+// (Params.step = add then scale, model/params.nim:60-65,90-98) and every order goes through the
+// regulariser's proximal operator with lam = gamma * eta_P / (1 + eta_P * beta) (:118-120).  The solver is
+// dense by construction: one pass over P per mini-batch is its roofline (16 B per parameter).
+//   L1 (l1.nim:35-39), L21 (l21.nim:23-34), row-wise SquaredL12 (squaredl12.nim:161-162): fused into the pass.
+//   column-wise SquaredL12 (the default, :150-159) and SquaredL21 (squaredl21.nim:46-54) couple a whole
+//   column / all row norms through one threshold tau = 2 lam S, S = sum_{|p_i| > tau} |p_i| / (1 + 2 lam theta)
+//   (squaredl12.nim:16-69 finds theta by randomised pivoting).  Here tau is the fixed point of
+//   tau <- 2 lam sum_{|p_i| > tau} |p_i| / (1 + 2 lam #{|p_i| > tau}) started at 0: the map is the Newton step
+//   of a concave increasing piecewise-linear function, so the active set only shrinks and the iteration ends
+//   after finitely many passes at the same theta the pivoting finds (no random numbers, fixed summation order).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double softthreshold(double x, double alpha) {  // regularizer/utils.nim:4-5
+  const double t = fmax(fabs(x) - alpha, 0.0);
+  return x > 0 ? t : (x < 0 ? -t : 0.0 * t);
+}
+
+struct ProxArgs {
+  ModelView M;
+  OptView O;
+  const double* it0p;
+  double it_b;
+  double* norms;  // [nb][da]   (SquaredL21)
+  double* tau;    // [nb][Kp]   thresholds of the coupled operators
+};
+
+__device__ __forceinline__ double psgd_lam(const OptView& O, double etaP) { return O.gamma * etaP / (1.0 + etaP * O.beta); }
+
+// sum over the L lanes of one row (fixed xor tree)
+template <int L>
+__device__ __forceinline__ double row_sum(double v) {
+#pragma unroll
+  for (int s = 1; s < L; s <<= 1) v += dev::shfl_xor_d(v, s);
+  return v;
+}
+
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_psgd_dense(ProxArgs a) {
+  constexpr int R = kWave / L;
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int64_t rows = (int64_t)M.nb * M.da;
+  const int64_t r = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  const double it = a.it0p[0] + a.it_b;
+  const double etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+  const double invP = 1.0 / (1.0 + etaP * O.beta), lam = psgd_lam(O, etaP);
+  const bool act = r < rows;  // inactive lanes keep taking part in the shuffles
+  double2 p = {0.0, 0.0};
+  const size_t e = (size_t)(act ? r : 0) * M.Kp + 2 * l;
+  if (act) p = *reinterpret_cast<const double2*>(M.P + e);
+  p.x *= invP;
+  p.y *= invP;
+  if (O.reg == NFM_REG_L1) {
+    p.x = softthreshold(p.x, lam);
+    p.y = softthreshold(p.y, lam);
+  } else if (O.reg == NFM_REG_L21 || O.reg == NFM_REG_SQUAREDL21) {
+    const double nrm = sqrt(row_sum<L>(p.x * p.x + p.y * p.y));
+    if (O.reg == NFM_REG_L21) {
+      const double f = nrm > lam ? 1.0 - lam / nrm : 0.0;
+      p.x = nrm > lam ? p.x * f : 0.0;
+      p.y = nrm > lam ? p.y * f : 0.0;
+    } else if (act && l == 0) {
+      a.norms[r] = nrm;
+    }
+  } else if (O.reg == NFM_REG_SQUAREDL12 && !O.reg_transpose) {
+    // the vector operator on the row's k components
+    const double ax = fabs(p.x), ay = fabs(p.y);
+    double tau = 0.0;
+    int cnt_prev = -1;
+    for (int pass = 0; pass < 2 * L + 2; ++pass) {
+      const double S = row_sum<L>((ax > tau ? ax : 0.0) + (ay > tau ? ay : 0.0));
+      const int c = (int)row_sum<L>((double)((ax > tau) + (ay > tau)));
+      if (c == cnt_prev || c == 0) break;  // uniform over the row's lanes; rows of one wavefront may differ:
+      cnt_prev = c;                        // a finished row keeps its tau (the map is idempotent at the fixed point)
+      tau = 2 * lam * (S / (1.0 + 2.0 * lam * (double)c));
+    }
+    p.x = softthreshold(p.x, tau);
+    p.y = softthreshold(p.y, tau);
+  }
+  if (act) *reinterpret_cast<double2*>(M.P + e) = p;
+}
+
+// linear term and intercept: scale only (model/params.nim:60-65)
+__global__ __launch_bounds__(kBlock) void k_psgd_linear(ProxArgs a) {
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const double it = a.it0p[0] + a.it_b;
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (M.fit_linear && j < M.d) M.w[j] *= 1.0 / (1.0 + dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it) * O.alpha);
+  if (M.fit_intercept && j == 0)
+    M.sc[SC_INTERCEPT] *= 1.0 / (1.0 + dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it) * O.alpha0);
+}
+
+// threshold of one coupled vector: v(i) = |x[i * stride]|, i < n.  One workgroup, fixed-order sums.
+constexpr int kProxBlock = 1024;
+__device__ __forceinline__ double prox_threshold(const double* __restrict__ x, int64_t n, int64_t stride, double lam) {
+  __shared__ double sS[kProxBlock / kWave];
+  __shared__ double sC[kProxBlock / kWave];
+  __shared__ double s_tau;
+  __shared__ int s_done;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  double tau = 0.0, cnt_prev = -1.0;
+  for (;;) {
+    double S = 0.0, c = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += kProxBlock) {
+      const double v = fabs(x[i * stride]);
+      if (v > tau) {
+        S += v;
+        c += 1.0;
+      }
+    }
+    S = dev::wave_sum(S);
+    c = dev::wave_sum(c);
+    if (lane == 0) {
+      sS[wv] = S;
+      sC[wv] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double St = 0.0, ct = 0.0;
+      for (int w_ = 0; w_ < kProxBlock / kWave; ++w_) {
+        St += sS[w_];
+        ct += sC[w_];
+      }
+      s_done = (ct == cnt_prev || ct == 0.0) ? 1 : 0;
+      if (!s_done) s_tau = 2 * lam * (St / (1.0 + 2.0 * lam * ct));
+      sC[0] = ct;
+    }
+    __syncthreads();
+    const int done = s_done;
+    const double ct = sC[0];
+    if (!done) tau = s_tau;
+    __syncthreads();
+    if (done) break;
+    cnt_prev = ct;
+  }
+  return tau;
+}
+
+// column-wise SquaredL12 (squaredl12.nim:150-159): workgroup (s, o) owns component s of order o
+__global__ __launch_bounds__(kProxBlock) void k_psgd_prox_columns(ProxArgs a) {
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int s = blockIdx.x, o = blockIdx.y;
+  const double lam = psgd_lam(O, dev::get_eta(O.sched, O.eta0, O.power, O.beta, a.it0p[0] + a.it_b));
+  double* col = M.P + (size_t)o * M.da * M.Kp + s;
+  const double tau = prox_threshold(col, M.da, M.Kp, lam);
+  for (int64_t j = threadIdx.x; j < M.da; j += kProxBlock) col[j * M.Kp] = softthreshold(col[j * M.Kp], tau);
+}
+
+// SquaredL21 (squaredl21.nim:46-54): the vector operator on the row norms of order o ...
+__global__ __launch_bounds__(kProxBlock) void k_psgd_prox_norms(ProxArgs a) {
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int o = blockIdx.x;
+  const double lam = psgd_lam(O, dev::get_eta(O.sched, O.eta0, O.power, O.beta, a.it0p[0] + a.it_b));
+  const double tau = prox_threshold(a.norms + (size_t)o * M.da, M.da, 1, lam);
+  if (threadIdx.x == 0) a.tau[o] = tau;
+}
+
+// ... then every row is rescaled from its old norm to the thresholded one: P[i] /= n; P[i] *= n'
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_psgd_rescale_rows(ProxArgs a) {
+  constexpr int R = kWave / L;
+  const ModelView& M = a.M;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int64_t r = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  if (r >= (int64_t)M.nb * M.da) return;
+  const double n_old = a.norms[r], n_new = softthreshold(n_old, a.tau[r / M.da]);
+  const size_t e = (size_t)r * M.Kp + 2 * l;
+  double2 p = *reinterpret_cast<const double2*>(M.P + e);
+  if (n_old != 0) {
+    p.x /= n_old;
+    p.y /= n_old;
+  }
+  p.x *= n_new;
+  p.y *= n_new;
+  *reinterpret_cast<double2*>(M.P + e) = p;
+}
+
+template <int L>
+static void launch_psgd_step(nfm_ctx* ctx, const ModelView& M, const OptView& O, MbWork& W, const double* it0p, double it_b) {
+  constexpr int R = kWave / L;
+  hipStream_t st = ctx->stream;
+  ProxArgs pa{M, O, it0p, it_b, W.prox.as<double>(), W.prox.as<double>() + (size_t)M.nb * M.da};
+  const int64_t rows = (int64_t)M.nb * M.da;
+  const unsigned row_blocks = (unsigned)((rows + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
+  TimedLaunch tl(ctx, "psgd_step");
+  if (rows > 0) hipLaunchKernelGGL((k_psgd_dense<L>), dim3(row_blocks), dim3(kBlock), 0, st, pa);
+  hipLaunchKernelGGL(k_psgd_linear, dim3((unsigned)((std::max<int64_t>(M.d, 1) + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pa);
+  if (rows > 0 && O.reg == NFM_REG_SQUAREDL12 && O.reg_transpose) {
+    hipLaunchKernelGGL(k_psgd_prox_columns, dim3((unsigned)M.k, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+  } else if (rows > 0 && O.reg == NFM_REG_SQUAREDL21) {
+    hipLaunchKernelGGL(k_psgd_prox_norms, dim3((unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    hipLaunchKernelGGL((k_psgd_rescale_rows<L>), dim3(row_blocks), dim3(kBlock), 0, st, pa);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1418,8 +1656,11 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
   for (int64_t b = 0; b < P.n_batches; ++b) {
     const int64_t p0 = P.bat_pos[b];
     const int len = (int)(P.bat_pos[b + 1] - p0);
-    const int use_stored = (OPT == OPT_ADAGRAD && P.first_singleton && b == 0) ? 1 : 0;
-    const double it_b = (double)p0;
+    // MBPSGD: the forward pass is AdaGrad's row phase reading the stored parameters (its record carries the
+    // raw dloss); the optimizer's `it` advances once per mini-batch (minibatch_psgd.nim:121), not per sample
+    const int use_stored = (OPT == OPT_PSGD || (OPT == OPT_ADAGRAD && P.first_singleton && b == 0)) ? 1 : 0;
+    const double it_b = OPT == OPT_PSGD ? (double)b : (double)p0;
+    constexpr int ROPT = OPT == OPT_PSGD ? OPT_ADAGRAD : OPT;
     const int split = choose_split(L, len, avg_row, ctx->n_cu);
     // row-phase mode (k_row_phase): 2 = held entries + register-resident rows (SGD, one sample per
     // wavefront, a batch with singles: 106 vs 141 us per batch on the headline shape), 1 = held entries,
@@ -1443,11 +1684,11 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
                  W.partsA.as<PartA>()};
       TimedLaunch tl(ctx, "row_phase");
       int s_used;
-      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), OPT, GEN>(st, ra, mode_for(R >= 16 ? 16 : R), ctx->n_cu, &nA); s_used = R >= 16 ? 16 : R; }
-      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), OPT, GEN>(st, ra, mode_for(R >= 8 ? 8 : R), ctx->n_cu, &nA); s_used = R >= 8 ? 8 : R; }
-      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), OPT, GEN>(st, ra, mode_for(R >= 4 ? 4 : R), ctx->n_cu, &nA); s_used = R >= 4 ? 4 : R; }
-      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), OPT, GEN>(st, ra, mode_for(R >= 2 ? 2 : R), ctx->n_cu, &nA); s_used = R >= 2 ? 2 : R; }
-      else { launch_row<L, 1, OPT, GEN>(st, ra, mode_for(1), ctx->n_cu, &nA); s_used = 1; }
+      if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), ROPT, GEN>(st, ra, mode_for(R >= 16 ? 16 : R), ctx->n_cu, &nA); s_used = R >= 16 ? 16 : R; }
+      else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), ROPT, GEN>(st, ra, mode_for(R >= 8 ? 8 : R), ctx->n_cu, &nA); s_used = R >= 8 ? 8 : R; }
+      else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), ROPT, GEN>(st, ra, mode_for(R >= 4 ? 4 : R), ctx->n_cu, &nA); s_used = R >= 4 ? 4 : R; }
+      else if (R >= 2 && split >= 2) { launch_row<L, (R >= 2 ? 2 : R), ROPT, GEN>(st, ra, mode_for(R >= 2 ? 2 : R), ctx->n_cu, &nA); s_used = R >= 2 ? 2 : R; }
+      else { launch_row<L, 1, ROPT, GEN>(st, ra, mode_for(1), ctx->n_cu, &nA); s_used = 1; }
       (void)s_used;  // nA = workgroups launched (their per-workgroup partials are what the closer adds up)
     }
     const int64_t u0 = P.bat_uoff[b], u1 = P.bat_uoff[b + 1];
@@ -1483,10 +1724,10 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
       }
       TimedLaunch tl(ctx, "col_phase");
       const bool strided = nB_capped;
-      if (tu == 1)
-        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 1, false>), dim3(nB), dim3(kBlock), 0, st, ca);
-      else if (tu == 4)
-        hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 4, false>), dim3(nB), dim3(kBlock), 0, st, ca);
+      if (tu == 1 && OPT != OPT_PSGD)  // the tuning variants are not instantiated for MBPSGD
+        hipLaunchKernelGGL((k_col_phase<L, (OPT == OPT_PSGD ? OPT_SGD : OPT), GEN, 1, false>), dim3(nB), dim3(kBlock), 0, st, ca);
+      else if (tu == 4 && OPT != OPT_PSGD)
+        hipLaunchKernelGGL((k_col_phase<L, (OPT == OPT_PSGD ? OPT_SGD : OPT), GEN, 4, false>), dim3(nB), dim3(kBlock), 0, st, ca);
       else if (strided)
         hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 2, true>), dim3(nB), dim3(kBlock), 0, st, ca);
       else
@@ -1515,6 +1756,7 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
       hipLaunchKernelGGL((k_heavy_apply<L, OPT, GEN>), dim3(nH), dim3(kBlock), 0, st, ca, ha);
     }
     n_prev = nB + nS + nH;
+    if (OPT == OPT_PSGD) launch_psgd_step<L>(ctx, M, O, W, it0p, it_b);
   }
   if (P.n_batches > 0) {
     const double* parts_last = W.partsB.as<double>() + ((P.n_batches - 1) & 1) * partsB_half;
@@ -1543,6 +1785,9 @@ static int enqueue_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const Mod
   NFM_CHECK(!gen || !P.use_singles, NFM_ERR_INVALID, "a plan with singles needs the degree-2 kernels");
 #define NFM_RUN(LL)                                                                     \
   case LL:                                                                              \
+    if (opt_kind == OPT_PSGD)                                                           \
+      return gen ? run_batches<LL, OPT_PSGD, true>(ctx, X, M, O, P, W, TA)              \
+                 : run_batches<LL, OPT_PSGD, false>(ctx, X, M, O, P, W, TA);            \
     if (gen)                                                                            \
       return opt_kind == OPT_SGD ? run_batches<LL, OPT_SGD, true>(ctx, X, M, O, P, W, TA)  \
                                  : run_batches<LL, OPT_ADAGRAD, true>(ctx, X, M, O, P, W, TA); \
@@ -1578,7 +1823,7 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   int TA = 0;
   for (int o = 0; o < M.nb; ++o) TA += M.degree - o - 1;
   constexpr int kMinGroupsPerBlock = kWavesPerBlock;  // L = 64
-  const void* before[] = {W.Abuf.p, W.rec.p, W.partsA.p, W.partsB.p, W.Dtab.p, W.Stab.p, W.Ftab.p, W.out_acc.p, W.itbuf.p, W.hpart.p};
+  const void* before[] = {W.Abuf.p, W.rec.p, W.partsA.p, W.partsB.p, W.Dtab.p, W.Stab.p, W.Ftab.p, W.out_acc.p, W.itbuf.p, W.hpart.p, W.prox.p};
   NFM_TRY(W.Abuf.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_batch, 1) * std::max(TA, 1) * M.Kp));
   NFM_TRY(W.rec.ensure(sizeof(SampleRec) * (size_t)std::max<int64_t>(P.max_batch, 1)));
   NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch / kWavesPerBlock + 1)));
@@ -1589,7 +1834,8 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   NFM_TRY(W.Ftab.ensure(sizeof(double) * 2 * kFtab * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.out_acc.ensure(sizeof(double) * 2));
   NFM_TRY(W.itbuf.ensure(sizeof(double)));
-  const void* after[] = {W.Abuf.p, W.rec.p, W.partsA.p, W.partsB.p, W.Dtab.p, W.Stab.p, W.Ftab.p, W.out_acc.p, W.itbuf.p, W.hpart.p};
+  if (opt_kind == OPT_PSGD) NFM_TRY(W.prox.ensure(sizeof(double) * ((size_t)M.nb * M.da + (size_t)std::max(M.nb, 1) * M.Kp)));
+  const void* after[] = {W.Abuf.p, W.rec.p, W.partsA.p, W.partsB.p, W.Dtab.p, W.Stab.p, W.Ftab.p, W.out_acc.p, W.itbuf.p, W.hpart.p, W.prox.p};
   for (size_t q = 0; q < sizeof(before) / sizeof(before[0]); ++q)
     if (before[q] != after[q]) W.drop_graph();
   hipLaunchKernelGGL(k_set_double, dim3(1), dim3(1), 0, st, W.itbuf.as<double>(), (double)it0);

@@ -4,7 +4,8 @@
 
 namespace nfm {
 
-enum { OPT_SGD = 0, OPT_ADAGRAD = 1 };
+// OPT_PSGD: the reference's mini-batch proximal SGD (optimizer/minibatch_psgd.nim)
+enum { OPT_SGD = 0, OPT_ADAGRAD = 1, OPT_PSGD = 2 };
 
 struct OptView {
   // hyper-parameters (newSGD optimizer/sgd.nim:23-52, newAdaGrad optimizer/adagrad.nim:20-44)
@@ -17,6 +18,9 @@ struct OptView {
   double* Gw;
   double* Nw;
   double* gsc;
+  // MBPSGD (newMBPSGD, optimizer/minibatch_psgd.nim:24-65): gamma, miniBatchSize as a double, NFM_REG_*
+  double gamma, bsize;
+  int32_t reg, reg_transpose;
 };
 
 // ---- seq.hip ----

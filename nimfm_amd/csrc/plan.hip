@@ -200,7 +200,8 @@ int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_ho
   P.serial = ++g_serial;
   hipStream_t st = ctx->stream;
   const int64_t ns = end - begin;
-  NFM_CHECK(ns >= 0 && begin >= 0 && end <= X.n, NFM_ERR_INVALID, "epoch range [%lld,%lld) outside [0,%lld)",
+  // with an explicit permutation the range counts positions of the index stream, which may be longer than the data (MBPSGD)
+  NFM_CHECK(ns >= 0 && begin >= 0 && (end <= X.n || perm_host), NFM_ERR_INVALID, "epoch range [%lld,%lld) outside [0,%lld)",
             (long long)begin, (long long)end, (long long)X.n);
   NFM_CHECK(batch >= 1, NFM_ERR_INVALID, "batch must be >= 1");
   P.begin = begin; P.end = end; P.batch = batch; P.n_aug = n_aug;

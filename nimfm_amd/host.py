@@ -790,3 +790,190 @@ def newSGD(maxIter=100, eta0=0.01, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squ
 def newAdaGrad(maxIter=100, eta0=0.1, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squared", eps=1e-10, verbose=1,
                tol=1e-3, shuffle=True, nCalls=-1, **gpu):
     return AdaGrad(maxIter, eta0, alpha0, alpha, beta, loss, eps, verbose, tol, shuffle, nCalls, **gpu)
+
+
+# ------------------------------------------------------------------------------------------------
+# mini-batch proximal SGD
+# ------------------------------------------------------------------------------------------------
+class _Regularizer:
+    """regularizer/*.nim: the sparsity-inducing penalties that have a matrix proximal operator.
+    eval (for the verbose line, minibatch_psgd.nim:196-199) runs on the host copy of one order, [d+a][k]."""
+    name = None
+
+    def __init__(self, transpose=False):
+        self.transpose = bool(transpose)
+
+
+class L1(_Regularizer):
+    name = "l1"
+
+    def eval(self, Pt, degree=2):  # l1.nim:19-22
+        return float(np.abs(Pt).sum())
+
+
+class L21(_Regularizer):
+    name = "l21"
+
+    def eval(self, Pt, degree=2):  # l21.nim:17-20
+        return float(np.sqrt((Pt * Pt).sum(1)).sum())
+
+
+class SquaredL12(_Regularizer):
+    name = "squaredl12"
+
+    def __init__(self, transpose=True):  # squaredl12.nim:85-88
+        super().__init__(transpose)
+
+    def eval(self, Pt, degree=2):  # squaredl12.nim:72-82
+        if degree > 2:
+            raise ValueError("SquaredL12 supports only degree=2.")
+        return float((np.abs(Pt).sum(0 if self.transpose else 1) ** 2).sum())
+
+
+class SquaredL21(_Regularizer):
+    name = "squaredl21"
+
+    def __init__(self, transpose=False):  # squaredl21.nim:15-17
+        super().__init__(transpose)
+
+    def eval(self, Pt, degree=2):  # squaredl21.nim:21-29
+        if degree != 2:
+            raise ValueError("SquaredL21 supports only degree=2.")
+        return float(np.sqrt((Pt * Pt).sum(0 if self.transpose else 1)).sum() ** 2)
+
+
+def newL1():
+    return L1()
+
+
+def newL21():
+    return L21()
+
+
+def newSquaredL12(transpose=True):
+    return SquaredL12(transpose)
+
+
+def newSquaredL21(transpose=False):
+    return SquaredL21(transpose)
+
+
+class MBPSGD(_OptimizerBase):
+    """optimizer/minibatch_psgd.nim:11-65,125-210: newMBPSGD(...).fit(X, y, sfm).  The gradient of a mini-batch,
+    the step on all parameters and the proximal operator run on the device (nfm_mbpsgd_create / nfm_opt_epoch);
+    the outer loop, the index stream (indices[ii] with wrap-around and reshuffle, :98-108), the stopping rule
+    (:201-204) and the verbose lines run here where the reference has them."""
+
+    def __init__(self, maxIter=100, eta0=0.1, alpha0=1e-6, alpha=1e-3, beta=1e-4, gamma=1e-4, loss="squared", reg=None,
+                 miniBatchSize=-1, maxIterInner=-1, scheduling="optimal", power=1.0, verbose=1, tol=1e-6, shuffle=True,
+                 nCalls=-1, lossParam=1.0):
+        super().__init__(maxIter, alpha0, alpha, beta, loss, verbose, tol, shuffle, nCalls, "minibatch", 1, lossParam)
+        if scheduling not in capi.SCHED:
+            raise ValueError("unknown scheduling %r" % (scheduling,))
+        self.reg = reg if reg is not None else newSquaredL12()
+        if not isinstance(self.reg, _Regularizer):
+            raise ValueError("reg must be one of newL1(), newL21(), newSquaredL12(), newSquaredL21()")
+        self.gamma, self.eta0, self.scheduling, self.power = float(gamma), float(eta0), scheduling, float(power)
+        self.miniBatchSize, self.maxIterInner = int(miniBatchSize), int(maxIterInner)
+        self.it = 0  # :63
+
+    def _create(self, mh, mode):
+        cfg = capi.MBPSGDCfg(self.eta0, self.alpha0, self.alpha, self.beta, self.gamma, self.power, self.lossParam,
+                             capi.LOSS[self.loss], capi.SCHED[self.scheduling], capi.REG[self.reg.name],
+                             int(self.reg.transpose), self.batch)
+        capi.check(capi.lib().nfm_mbpsgd_create(mh, C.byref(cfg), C.byref(self._h)))
+
+    def fit(self, X, y, sfm, callback=None, stream=None):
+        """stream (optional): the sample indices in the order the inner loops consume them, at least
+        maxIter * miniBatchSize * maxIterInner of them -- replaces the internal shuffle (Nim's global RNG in the
+        reference, :107,170), which a Nim host passes in here."""
+        if not isinstance(sfm, FactorizationMachine):
+            raise ValueError("MBPSGD fits a FactorizationMachine")
+        sfm.init(X)
+        y = _f64(y)
+        if len(y) != X.nSamples:
+            raise ValueError("len(y) != nSamples")
+        X.set_targets(y)
+        n, d = X.nSamples, X.nFeatures
+        if not sfm.warmStart:
+            self.it = 1  # :153-154
+        B = self.miniBatchSize
+        if B <= 0:  # :160-163
+            B = max((d * n) // max(X.nnz, 1), 1)
+        inner = self.maxIterInner
+        if inner <= 0:  # :164-167
+            inner = max((n - 1) // B + 1, 1)
+        if self.reg.name in ("squaredl12", "squaredl21") and sfm.degree != 2:  # initSGD, squaredl12.nim:103-105
+            raise ValueError("%s supports only degree=2." % type(self.reg).__name__)
+        self.batch = B
+        self._handle(sfm, X.ctx, "minibatch")
+        if sfm._dirty:
+            sfm._push(X.ctx)
+        capi.check(capi.lib().nfm_opt_set_it(self._h, self.it))
+        rng = getattr(sfm, "_rng", None) or np.random.default_rng(getattr(sfm, "randomState", 1))
+        indices = np.arange(n, dtype=np.int64)
+        ii = 0
+        if stream is None and self.shuffle:
+            rng.shuffle(indices)  # :169-170
+        if stream is not None:
+            stream = _i64(stream)
+        if self.verbose > 0:
+            print("Minibatch size: %d" % B)
+            print("Number of inner iteration: %d" % inner)
+            print("%s   %s   Regularization" % ("Epoch".ljust(len(str(self.maxIter))), "Loss".ljust(10)), flush=True)
+        oldLossVal = float("inf")
+        isConverged = False
+        self.history = []
+        need = B * inner
+        for it in range(self.maxIter):
+            if stream is not None:
+                chunk = stream[it * need:(it + 1) * need]
+                if len(chunk) != need:
+                    raise ValueError("stream holds fewer than maxIter * miniBatchSize * maxIterInner indices")
+            else:  # :98-108: indices[ii], ii wraps and reshuffles
+                chunk = np.empty(need, dtype=np.int64)
+                got = 0
+                while got < need:
+                    take = min(need - got, n - ii)
+                    chunk[got:got + take] = indices[ii:ii + take]
+                    got += take
+                    ii += take
+                    if ii >= n:
+                        ii = 0
+                        if self.shuffle:
+                            rng.shuffle(indices)
+            ls, _ = self._epoch(X, chunk, 0, need)
+            self.it += inner
+            runningLoss = ls / float(B * inner)  # :122
+            self.history.append((0.0, runningLoss))
+            if callback is not None:  # :185-187
+                self._finalize_into(sfm)
+                callback(self, sfm)
+            if math.isnan(runningLoss):  # :189-191
+                print("Loss is NaN. Use smaller learning rate.")
+                break
+            if self.verbose > 0:  # :193-199
+                self._finalize_into(sfm)
+                regVal = 0.5 * self.alpha0 * sfm.intercept ** 2 + 0.5 * self.alpha * float((sfm.w ** 2).sum()) \
+                    + 0.5 * self.beta * float((sfm.P ** 2).sum())
+                for order in range(sfm.P.shape[0]):
+                    regVal += self.gamma * self.reg.eval(np.ascontiguousarray(sfm.P[order].T), sfm.degree - order)
+                print("%s   %-10.4e   %-10.4e" % (str(it + 1).ljust(max(5, len(str(self.maxIter)))), runningLoss, regVal),
+                      flush=True)
+            if abs(oldLossVal - runningLoss) < self.tol:  # :201-204
+                if self.verbose > 0:
+                    print("Converged at epoch %d." % (it + 1))
+                isConverged = True
+                break
+            oldLossVal = runningLoss
+        if not isConverged and self.verbose > 0:
+            print("Objective did not converge. Increase maxIter.")
+        self._finalize_into(sfm)
+        return self
+
+
+def newMBPSGD(maxIter=100, eta0=0.1, alpha0=1e-6, alpha=1e-3, beta=1e-4, gamma=1e-4, loss="squared", reg=None,
+              miniBatchSize=-1, maxIterInner=-1, scheduling="optimal", power=1.0, verbose=1, tol=1e-6, shuffle=True,
+              nCalls=-1, **gpu):
+    return MBPSGD(maxIter, eta0, alpha0, alpha, beta, gamma, loss, reg, miniBatchSize, maxIterInner, scheduling, power,
+                  verbose, tol, shuffle, nCalls, **gpu)
