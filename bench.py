@@ -156,12 +156,97 @@ def ingest_leg(args):
         os.rmdir(tmp)
 
 
+def psgd_leg(args):
+    """--workload psgd: mini-batch proximal SGD on a matrix of the shape of the reference's own
+    benchmark for this solver (benchmarks/ml100k/sparse_fm_mbpsgd.nim: ml-100k user x item x side features, d = 2703,
+    squared loss, SquaredL12, nComponents = 30, default mini-batch = d n / nnz).  One step = one outer iteration
+    (maxIterInner mini-batches: gradient, step on all parameters, prox).  cpu_baseline = oracle/nimfm_psgd.c."""
+    import torch
+
+    import nimfm_amd as nf
+
+    n, d, m, k = args.n or 90_570, 2_703, 24, 30
+    dev = torch.device("cuda", 0)
+    ctx = nf.Context(0)
+    nf.set_default_context(ctx)
+    indptr, indices, data = gen_shard(torch, dev, n, d, m, 42)
+    X = nf.CSRDataset.from_device(ctx, n, d, n * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(),
+                                  keep=(indptr, indices, data))
+    rng = np.random.default_rng(1234)
+    planted = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True)
+    planted.set_params(rng.standard_normal((1, k, d)) * 0.1, rng.standard_normal(d) * 0.1, 0.0)
+    y = planted.decisionFunction(X)
+    del planted
+    B = args.batch or max((d * n) // (n * m), 1)
+    inner = (n - 1) // B + 1
+    need = B * inner
+    fm = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True, randomState=1)
+    fm.init(X)
+    opt = nf.newMBPSGD(maxIter=1, beta=1e-5, alpha0=1e-10, alpha=1e-10, gamma=1e-5, miniBatchSize=B, verbose=0)
+    opt.batch, opt.it = B, 1
+    X.set_targets(y)
+    opt._handle(fm, ctx, "minibatch")
+    stream = np.concatenate([np.arange(n, dtype=np.int64), np.arange(need - n, dtype=np.int64)])
+
+    def step():
+        ls, _ = opt._epoch(X, stream, 0, need)
+        opt.it += inner
+        return ls
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    fams = ("plan_build", "row_phase", "col_phase", "heavy_partial", "heavy_apply", "psgd_step")
+    ctx.timing_reset()
+    ctx.timing_enable(True)
+    step()
+    ctx.synchronize()
+    fam = {f: ctx.timing_get(f) for f in fams}
+    ctx.timing_enable(False)
+    da = d
+    Kp = 2 * max(1, 1 << (((k + 1) // 2) - 1).bit_length())
+    dense_bytes = 16 * da * Kp + (16 * da * Kp)  # scale pass + column prox pass, read + write each
+    step_ms = fam["psgd_step"][1] / max(fam["psgd_step"][0], 1)
+    roof = {"bound": "hbm", "kernel": "psgd_step (k_psgd_dense + k_psgd_linear + k_psgd_prox_columns): all parameters, once per mini-batch",
+            "achieved": round(dense_bytes / (step_ms * 1e-3) / 1e9, 2) if step_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(dense_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if step_ms else None, "traffic": None,
+            "algorithmic_bytes_per_minibatch": dense_bytes,
+            "note": "%d x %d parameters = %.2f MB: the whole model sits in L2 and every kernel is launch-latency bound" % (da, Kp, 8e-6 * da * Kp),
+            "avg_ms": {f: round(fam[f][1] / fam[f][0], 5) if fam[f][0] else 0.0 for f in fams},
+            "launches_per_step": {f: fam[f][0] for f in fams}}
+    cpu = None
+    if not args.no_cpu_baseline:
+        import oracle as O
+
+        Xo = O.Dataset(indptr.cpu().numpy(), indices.cpu().numpy().astype(np.int64), data.cpu().numpy(), n, d)
+        P0 = np.random.default_rng(1).standard_normal((1, k, d)) * 0.01
+        inner_c = max(1, min(inner, 250))
+        cfg = O.psgd_cfg(beta=1e-5, alpha0=1e-10, alpha=1e-10, gamma=1e-5)
+        tc = time.perf_counter()
+        O.fm_mbpsgd_epoch(Xo, y, 2, P0, np.zeros(d), 0.0, cfg, stream[:B * inner_c], B)
+        tc = time.perf_counter() - tc
+        cpu = {"value": round(B * inner_c / tc, 1), "unit": "samples/s", "cores": 1, "kind": "port",
+               "sample": "the first %d mini-batches of the same outer iteration, oracle/nimfm_psgd.c (minibatch_psgd.nim:87-122), "
+                         "-O2, 1 thread" % inner_c}
+    print(json.dumps({"metric": "MBPSGD training samples/sec/outer iteration", "value": round(need / dt, 1), "unit": "samples/s",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3),
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": "psgd: synthetic CSR %dx%d, %d nnz/row, k=%d, MBPSGD squared loss, SquaredL12, "
+                                             "mini-batch %d x %d per outer iteration" % (n, d, m, k, B, inner)},
+                      "last_step": {"mean_loss": last / need}, "roofline": roof, "cpu_baseline": cpu}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["ingest"])
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["ingest", "psgd"])
     ap.add_argument("--batch", type=int, default=0, help="mini-batch size (default: per workload)")
     ap.add_argument("--n", "--samples", dest="n", type=int, default=0, help="override samples per GPU (--samples under torchrun, whose parser claims --n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -173,6 +258,8 @@ def main():
 
     if args.workload == "ingest":
         return ingest_leg(args)
+    if args.workload == "psgd":
+        return psgd_leg(args)
     import torch
 
     import nimfm_amd as nf

@@ -1497,13 +1497,11 @@ __global__ __launch_bounds__(kBlock) void k_psgd_linear(ProxArgs a) {
 // threshold of one coupled vector: v(i) = |x[i * stride]|, i < n.  One workgroup, fixed-order sums.
 constexpr int kProxBlock = 1024;
 __device__ __forceinline__ double prox_threshold(const double* __restrict__ x, int64_t n, int64_t stride, double lam) {
-  __shared__ double sS[kProxBlock / kWave];
-  __shared__ double sC[kProxBlock / kWave];
-  __shared__ double s_tau;
-  __shared__ int s_done;
+  __shared__ double sS[2][kProxBlock / kWave];
+  __shared__ double sC[2][kProxBlock / kWave];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   double tau = 0.0, cnt_prev = -1.0;
-  for (;;) {
+  for (int pass = 0;; ++pass) {
     double S = 0.0, c = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += kProxBlock) {
       const double v = fabs(x[i * stride]);
@@ -1514,27 +1512,23 @@ __device__ __forceinline__ double prox_threshold(const double* __restrict__ x, i
     }
     S = dev::wave_sum(S);
     c = dev::wave_sum(c);
+    // one barrier per pass: the per-wavefront sums alternate between two buffers, every thread adds them up in
+    // the same fixed order (a writer of pass p + 2 has passed the barrier of pass p + 1, after all reads of pass p)
+    double* bS = sS[pass & 1];
+    double* bC = sC[pass & 1];
     if (lane == 0) {
-      sS[wv] = S;
-      sC[wv] = c;
+      bS[wv] = S;
+      bC[wv] = c;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      double St = 0.0, ct = 0.0;
-      for (int w_ = 0; w_ < kProxBlock / kWave; ++w_) {
-        St += sS[w_];
-        ct += sC[w_];
-      }
-      s_done = (ct == cnt_prev || ct == 0.0) ? 1 : 0;
-      if (!s_done) s_tau = 2 * lam * (St / (1.0 + 2.0 * lam * ct));
-      sC[0] = ct;
+    double St = 0.0, ct = 0.0;
+#pragma unroll
+    for (int w_ = 0; w_ < kProxBlock / kWave; ++w_) {
+      St += bS[w_];
+      ct += bC[w_];
     }
-    __syncthreads();
-    const int done = s_done;
-    const double ct = sC[0];
-    if (!done) tau = s_tau;
-    __syncthreads();
-    if (done) break;
+    if (ct == cnt_prev || ct == 0.0) break;
+    tau = 2 * lam * (St / (1.0 + 2.0 * lam * ct));
     cnt_prev = ct;
   }
   return tau;
@@ -1549,6 +1543,76 @@ __global__ __launch_bounds__(kProxBlock) void k_psgd_prox_columns(ProxArgs a) {
   double* col = M.P + (size_t)o * M.da * M.Kp + s;
   const double tau = prox_threshold(col, M.da, M.Kp, lam);
   for (int64_t j = threadIdx.x; j < M.da; j += kProxBlock) col[j * M.Kp] = softthreshold(col[j * M.Kp], tau);
+}
+
+// The same for models of at most VPT * 1024 features, and the whole step of such a model in ONE launch: the
+// workgroup reads its column once (VPT values per thread, in registers), applies the shrink 1 / (1 + eta_P beta)
+// of Params.step itself (the padding components s >= k are zero and need none), runs the threshold passes on
+// the registers -- a pass is one workgroup reduction, no memory traffic -- and writes the column once.  The
+// workgroups s >= k of order 0 shrink the linear term and the intercept (k_psgd_linear's work).
+template <int VPT>
+__global__ __launch_bounds__(kProxBlock) void k_psgd_step_columns(ProxArgs a) {
+  __shared__ double sS[2][kProxBlock / kWave];
+  __shared__ double sC[2][kProxBlock / kWave];
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int s = blockIdx.x, o = blockIdx.y;
+  const double it = a.it0p[0] + a.it_b;
+  if (s >= M.k) {
+    if (o != 0) return;
+    const int64_t j = (int64_t)(s - M.k) * kProxBlock + threadIdx.x;
+    if (M.fit_linear && j < M.d) M.w[j] *= 1.0 / (1.0 + dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it) * O.alpha);
+    if (M.fit_intercept && j == 0)
+      M.sc[SC_INTERCEPT] *= 1.0 / (1.0 + dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it) * O.alpha0);
+    return;
+  }
+  const double etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+  const double invP = 1.0 / (1.0 + etaP * O.beta), lam = psgd_lam(O, etaP);
+  double* col = M.P + (size_t)o * M.da * M.Kp + s;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  double v[VPT];
+#pragma unroll
+  for (int q = 0; q < VPT; ++q) {
+    const int64_t j = (int64_t)q * kProxBlock + threadIdx.x;
+    v[q] = j < M.da ? col[j * M.Kp] * invP : 0.0;
+  }
+  double tau = 0.0, cnt_prev = -1.0;
+  for (int pass = 0;; ++pass) {
+    double S = 0.0, c = 0.0;
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+      const double av = fabs(v[q]);
+      if (av > tau) {
+        S += av;
+        c += 1.0;
+      }
+    }
+    S = dev::wave_sum(S);
+    c = dev::wave_sum(c);
+    // one barrier per pass: the per-wavefront sums alternate between two buffers, every thread adds them up in
+    // the same fixed order (a writer of pass p + 2 has passed the barrier of pass p + 1, after all reads of pass p)
+    double* bS = sS[pass & 1];
+    double* bC = sC[pass & 1];
+    if (lane == 0) {
+      bS[wv] = S;
+      bC[wv] = c;
+    }
+    __syncthreads();
+    double St = 0.0, ct = 0.0;
+#pragma unroll
+    for (int w_ = 0; w_ < kProxBlock / kWave; ++w_) {
+      St += bS[w_];
+      ct += bC[w_];
+    }
+    if (ct == cnt_prev || ct == 0.0) break;
+    tau = 2 * lam * (St / (1.0 + 2.0 * lam * ct));
+    cnt_prev = ct;
+  }
+#pragma unroll
+  for (int q = 0; q < VPT; ++q) {
+    const int64_t j = (int64_t)q * kProxBlock + threadIdx.x;
+    if (j < M.da) col[j * M.Kp] = softthreshold(v[q], tau);
+  }
 }
 
 // SquaredL21 (squaredl21.nim:46-54): the vector operator on the row norms of order o ...
@@ -1590,6 +1654,16 @@ static void launch_psgd_step(nfm_ctx* ctx, const ModelView& M, const OptView& O,
   const int64_t rows = (int64_t)M.nb * M.da;
   const unsigned row_blocks = (unsigned)((rows + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
   TimedLaunch tl(ctx, "psgd_step");
+  if (rows > 0 && O.reg == NFM_REG_SQUAREDL12 && O.reg_transpose && M.da <= 16 * kProxBlock) {  // the one-launch step
+    const unsigned gx = (unsigned)(M.k + (std::max<int64_t>(M.d, 1) + kProxBlock - 1) / kProxBlock);
+    const int vpt = (int)((M.da + kProxBlock - 1) / kProxBlock);
+    if (vpt <= 1) hipLaunchKernelGGL((k_psgd_step_columns<1>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    else if (vpt <= 2) hipLaunchKernelGGL((k_psgd_step_columns<2>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    else if (vpt <= 4) hipLaunchKernelGGL((k_psgd_step_columns<4>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    else if (vpt <= 8) hipLaunchKernelGGL((k_psgd_step_columns<8>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    else hipLaunchKernelGGL((k_psgd_step_columns<16>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    return;
+  }
   if (rows > 0) hipLaunchKernelGGL((k_psgd_dense<L>), dim3(row_blocks), dim3(kBlock), 0, st, pa);
   hipLaunchKernelGGL(k_psgd_linear, dim3((unsigned)((std::max<int64_t>(M.d, 1) + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pa);
   if (rows > 0 && O.reg == NFM_REG_SQUAREDL12 && O.reg_transpose) {

@@ -113,6 +113,16 @@ def test_heavy_features_and_many_rows():
         check(Xo, y, "regression", 2, "explicit", k, P0, w0, 0.0, n_aug, B, 2, reg, gamma=0.01, eta0=0.1)
 
 
+@pytest.mark.parametrize("reg", ["squaredl12", "squaredl21"])
+def test_more_features_than_the_register_resident_step_holds(reg):
+    """d > 16384: the coupled threshold runs its passes over memory (k_psgd_prox_columns / k_psgd_prox_norms)"""
+    n, d, k, B = 64, 20000, 2, 16
+    Xo = random_csr(n, d, 40, 6)
+    y = np.random.default_rng(2).normal(size=n)
+    P0, w0, b0, n_aug = init_fm(d, 2, k, "explicit", True, scale=0.3)
+    check(Xo, y, "regression", 2, "explicit", k, P0, w0, 0.0, n_aug, B, 2, reg, gamma=1e-4)
+
+
 def test_ragged_rows_and_default_batch():
     """empty rows, rows longer than a wavefront; miniBatchSize / maxIterInner defaults (minibatch_psgd.nim:160-167)"""
     n, d, k = 150, 300, 4
