@@ -33,6 +33,10 @@ type
     eta0, alpha0, alpha, beta, eps, lossParam: float64
     loss, mode, trackViol, reserved: int32
     batch: int64
+  NfmMbpsgdCfg {.bycopy.} = object
+    eta0, alpha0, alpha, beta, gamma, power, lossParam: float64
+    loss, scheduling, reg, regTranspose: int32
+    batch: int64
 
 {.push importc, cdecl, dynlib: libnfm.}
 proc nfm_last_error(): cstring
@@ -54,6 +58,7 @@ proc nfm_model_sqnorms(m: NfmModel, pSq, wSq: ptr float64): int32
 proc nfm_model_destroy(m: NfmModel): int32
 proc nfm_sgd_create(m: NfmModel, cfg: ptr NfmSgdCfg, outp: ptr NfmOpt): int32
 proc nfm_adagrad_create(m: NfmModel, cfg: ptr NfmAdaGradCfg, outp: ptr NfmOpt): int32
+proc nfm_mbpsgd_create(m: NfmModel, cfg: ptr NfmMbpsgdCfg, outp: ptr NfmOpt): int32
 proc nfm_opt_set_it(o: NfmOpt, it: int64): int32
 proc nfm_opt_epoch(o: NfmOpt, ds: NfmDataset, perm: ptr int64, first, last: int64,
                    lossSum, violSum: ptr float64): int32
@@ -223,4 +228,66 @@ proc hipFit*[L](self: AdaGrad[L], X: CSRDataset, y: seq[float64], fm: Factorizat
   check nfm_adagrad_create(m, addr cfg, addr o)
   runFit(o, m, ds, fm, X.nSamples, self.maxIter, self.verbose, self.tol, self.alpha0, self.alpha, self.beta,
          self.shuffle, self.it)
+  discard nfm_opt_destroy(o); discard nfm_model_destroy(m); discard nfm_dataset_destroy(ds)
+
+# ---- mini-batch proximal SGD (optimizer/minibatch_psgd.nim; SURVEY 8f rank 3) ----
+# MBPSGD keeps eta0 / scheduling / power / miniBatchSize / maxIterInner / shuffle / it private
+# (minibatch_psgd.nim:13-22), so a binding outside that module takes them as arguments; inside the module
+# this is `proc hipFit*[L, R](self: MBPSGD[L, R], X, y, sfm)` reading the fields.
+proc regId(reg: L1): int32 = 0
+proc regId(reg: L21): int32 = 1
+proc regId(reg: SquaredL12): int32 = 2
+proc regId(reg: SquaredL21): int32 = 3
+
+proc hipFitMBPSGD*[L, R](X: CSRDataset, y: seq[float64], sfm: FactorizationMachine, loss: L, reg: R,
+                         regTranspose: bool, maxIter = 100, eta0 = 0.1, alpha0 = 1e-6, alpha = 1e-3, beta = 1e-4,
+                         gamma = 1e-4, miniBatchSize = -1, maxIterInner = -1, scheduling = optimal, power = 1.0,
+                         verbose = 1, tol = 1e-6, shuffleOn = true, it: var int) =
+  sfm.init(X)
+  if not sfm.warmStart: it = 1                                  # minibatch_psgd.nim:153-154
+  let nSamples = X.nSamples
+  var B = miniBatchSize
+  if B <= 0: B = max((X.nFeatures * nSamples) div X.nnz, 1)     # :160-163
+  var inner = maxIterInner
+  if inner <= 0: inner = max((nSamples-1) div B + 1, 1)         # :164-167
+  let ds = toDevice(X)
+  var yy = y
+  check nfm_dataset_set_targets(ds, addr yy[0])
+  let m = modelHandle(sfm, X.nFeatures)
+  var cfg = NfmMbpsgdCfg(eta0: eta0, alpha0: alpha0, alpha: alpha, beta: beta, gamma: gamma, power: power,
+                         lossParam: 1.0, loss: lossId(loss), scheduling: ord(scheduling).int32,
+                         reg: regId(reg), regTranspose: regTranspose.int32, batch: B.int64)
+  var o: NfmOpt
+  check nfm_mbpsgd_create(m, addr cfg, addr o)                  # ValueError for SquaredL12/21 with degree != 2
+  check nfm_opt_set_it(o, it.int64)
+  var indices = toSeq(0..<nSamples)
+  var stream = newSeq[int](B * inner)
+  var ii = 0
+  if shuffleOn: shuffle(indices)                                # :169-170
+  var oldLossVal = Inf
+  var isConverged = false
+  for epoch in 0..<maxIter:
+    for q in 0..<stream.len:                                    # :98-108: indices[ii], wrap and reshuffle
+      stream[q] = indices[ii]
+      inc(ii)
+      if ii >= nSamples:
+        ii = 0
+        if shuffleOn: shuffle(indices)
+    var lossSum, viol: float64
+    check nfm_opt_epoch(o, ds, cast[ptr int64](addr stream[0]), 0, stream.len.int64, addr lossSum, addr viol)
+    it += inner
+    let runningLoss = lossSum / float(B * inner)                # :122
+    if runningLoss.classify == fcNan:
+      echo("Loss is NaN. Use smaller learning rate.")
+      break
+    if verbose > 0: echo fmt"{epoch+1:<5}   {runningLoss:<10.4e}"
+    if abs(oldLossVal - runningLoss) < tol:                     # :201-204
+      if verbose > 0: echo("Converged at epoch ", epoch+1, ".")
+      isConverged = true
+      break
+    oldLossVal = runningLoss
+  if not isConverged and verbose > 0:
+    echo("Objective did not converge. Increase maxIter.")
+  check nfm_opt_finalize(o)
+  pull(sfm, m)                                                  # pgd.finalize, optimizer/pgd.nim:45-51
   discard nfm_opt_destroy(o); discard nfm_model_destroy(m); discard nfm_dataset_destroy(ds)

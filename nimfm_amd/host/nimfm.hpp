@@ -307,4 +307,92 @@ class AdaGrad {
   nfm_opt* o_ = nullptr; nfm_model* m_ = nullptr; int md_ = -1;
 };
 
+// regularizer/{l1,l21,squaredl12,squaredl21}.nim: the penalties with a matrix proximal operator
+struct L1 { static constexpr int id = NFM_REG_L1; bool transpose = false; };
+struct L21 { static constexpr int id = NFM_REG_L21; bool transpose = false; };
+struct SquaredL12 { static constexpr int id = NFM_REG_SQUAREDL12; bool transpose = true; /* squaredl12.nim:85 */ };
+struct SquaredL21 { static constexpr int id = NFM_REG_SQUAREDL21; bool transpose = false; /* squaredl21.nim:15 */ };
+
+// MBPSGD[L, R], optimizer/minibatch_psgd.nim:11-65,125-210
+template <class L = Squared, class R = SquaredL12>
+class MBPSGD {
+ public:
+  int maxIter; double eta0, alpha0, alpha, beta, gamma; L loss; R reg; int64_t miniBatchSize, maxIterInner;
+  SchedulingKind scheduling; double power; int verbose; double tol; bool shuffle; int64_t it = 0;
+  explicit MBPSGD(int maxIter_ = 100, double eta0_ = 0.1, double alpha0_ = 1e-6, double alpha_ = 1e-3, double beta_ = 1e-4,
+                  double gamma_ = 1e-4, L loss_ = L(), R reg_ = R(), int64_t miniBatchSize_ = -1, int64_t maxIterInner_ = -1,
+                  SchedulingKind scheduling_ = optimal, double power_ = 1.0, int verbose_ = 1, double tol_ = 1e-6,
+                  bool shuffle_ = true)
+      : maxIter(maxIter_), eta0(eta0_), alpha0(alpha0_), alpha(alpha_), beta(beta_), gamma(gamma_), loss(loss_), reg(reg_),
+        miniBatchSize(miniBatchSize_), maxIterInner(maxIterInner_), scheduling(scheduling_), power(power_),
+        verbose(verbose_), tol(tol_), shuffle(shuffle_) {}
+  ~MBPSGD() { if (o_) nfm_opt_destroy(o_); }
+  void fit(const CSRDataset& X, const std::vector<double>& y, FactorizationMachine& sfm,
+           std::function<void(MBPSGD&, FactorizationMachine&)> callback = nullptr) {
+    sfm.init(X);
+    if ((int64_t)y.size() != X.nSamples()) throw std::invalid_argument("len(y) != nSamples");
+    check(nfm_dataset_set_targets(X.handle(), y.data()));
+    if (!sfm.warmStart) it = 1;  // :153-154
+    const int64_t n = X.nSamples();
+    int64_t nnz = 0;
+    check(nfm_dataset_shape(X.handle(), nullptr, nullptr, &nnz, nullptr));
+    int64_t B = miniBatchSize;
+    if (B <= 0) B = std::max<int64_t>((X.nFeatures() * n) / std::max<int64_t>(nnz, 1), 1);  // :160-163
+    int64_t inner = maxIterInner;
+    if (inner <= 0) inner = std::max<int64_t>((n - 1) / B + 1, 1);  // :164-167
+    nfm_model* m = sfm.push();
+    if (!o_ || m_ != m || B_ != B) {
+      if (o_) nfm_opt_destroy(o_);
+      o_ = nullptr;
+      nfm_mbpsgd_cfg c{eta0, alpha0, alpha, beta, gamma, power, loss.param, L::id, (int32_t)scheduling, R::id,
+                       reg.transpose ? 1 : 0, B};
+      check(nfm_mbpsgd_create(m, &c, &o_));
+      m_ = m; B_ = B;
+    }
+    check(nfm_opt_set_it(o_, it));
+    std::vector<int64_t> indices(n), chunk((size_t)(B * inner));
+    std::iota(indices.begin(), indices.end(), 0);
+    int64_t ii = 0;
+    if (shuffle) std::shuffle(indices.begin(), indices.end(), sfm.rng());  // :169-170
+    if (verbose > 0) {
+      std::printf("Minibatch size: %lld\nNumber of inner iteration: %lld\n", (long long)B, (long long)inner);
+      std::printf("Epoch   Loss         Regularization\n");
+    }
+    double oldLossVal = INFINITY;
+    bool isConverged = false;
+    for (int t = 0; t < maxIter; ++t) {
+      for (size_t q = 0; q < chunk.size(); ++q) {  // :98-108: indices[ii], ii wraps and reshuffles
+        chunk[q] = indices[ii++];
+        if (ii >= n) {
+          ii = 0;
+          if (shuffle) std::shuffle(indices.begin(), indices.end(), sfm.rng());
+        }
+      }
+      double ls = 0.0, viol = 0.0;
+      check(nfm_opt_epoch(o_, X.handle(), chunk.data(), 0, (int64_t)chunk.size(), &ls, &viol));
+      it += inner;
+      const double runningLoss = ls / (double)(B * inner);  // :122
+      if (callback) {
+        check(nfm_opt_finalize(o_));
+        sfm.pull();
+        callback(*this, sfm);
+      }
+      if (std::isnan(runningLoss)) { std::printf("Loss is NaN. Use smaller learning rate.\n"); break; }
+      if (verbose > 0) std::printf("%-5d   %-10.4e\n", t + 1, runningLoss);
+      if (std::fabs(oldLossVal - runningLoss) < tol) {  // :201-204
+        if (verbose > 0) std::printf("Converged at epoch %d.\n", t + 1);
+        isConverged = true;
+        break;
+      }
+      oldLossVal = runningLoss;
+    }
+    if (!isConverged && verbose > 0) std::printf("Objective did not converge. Increase maxIter.\n");
+    check(nfm_opt_finalize(o_));
+    sfm.pull();
+  }
+
+ private:
+  nfm_opt* o_ = nullptr; nfm_model* m_ = nullptr; int64_t B_ = -1;
+};
+
 }  // namespace nimfm

@@ -85,6 +85,23 @@ int main() {
     a5.fit(X, y, e2);
     for (size_t e = 0; e < c.P.size(); ++e) CHECK(std::fabs(c.P[e] - e2.P[e]) < 1e-8);
   }
+  {  // MBPSGD (optimizer/minibatch_psgd.nim): the loss goes down, a strong L1 penalty empties P, degree 3 is refused
+    FactorizationMachine fm(regression, 2, k);
+    MBPSGD<Squared, SquaredL12> opt(30, 0.05, 1e-6, 1e-3, 1e-4, 1e-4, Squared(), SquaredL12(), 16, -1, optimal, 1.0, 0, -1.0, false);
+    const double before = fm.score(X, y);
+    opt.fit(X, y, fm);
+    CHECK(fm.score(X, y) < before);
+    CHECK(opt.it == 1 + 30 * ((n - 1) / 16 + 1));
+    FactorizationMachine z(regression, 2, k);
+    MBPSGD<Squared, L1> hard(3, 0.05, 1e-6, 1e-3, 1e-4, 1e3, Squared(), L1(), 16, -1, optimal, 1.0, 0, -1.0, false);
+    hard.fit(X, y, z);
+    for (double v : z.P) CHECK(v == 0.0);
+    FactorizationMachine cubic(regression, 3, k);
+    MBPSGD<Squared, SquaredL12> refuse(1, 0.05, 1e-6, 1e-3, 1e-4, 1e-4, Squared(), SquaredL12(), 16, -1, optimal, 1.0, 0);
+    bool threw = false;
+    try { refuse.fit(X, y, cubic); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+  }
   {  // loader: dump a small svmlight file (1-based, dumpSVMLightFile's layout), load it on the GPU, same scores
     const char* path = "/tmp/nimfm_host_mirror_test.svm";
     FILE* f = std::fopen(path, "w");
