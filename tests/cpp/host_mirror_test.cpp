@@ -88,6 +88,7 @@ int main() {
   {  // MBPSGD (optimizer/minibatch_psgd.nim): the loss goes down, a strong L1 penalty empties P, degree 3 is refused
     FactorizationMachine fm(regression, 2, k);
     MBPSGD<Squared, SquaredL12> opt(30, 0.05, 1e-6, 1e-3, 1e-4, 1e-4, Squared(), SquaredL12(), 16, -1, optimal, 1.0, 0, -1.0, false);
+    fm.init(X);
     const double before = fm.score(X, y);
     opt.fit(X, y, fm);
     CHECK(fm.score(X, y) < before);
