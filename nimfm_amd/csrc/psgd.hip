@@ -1,0 +1,315 @@
+// nimfm_amd/csrc/psgd.hip -- the step + proximal stage of MBPSGD; the batch gradient itself
+// runs through the mini-batch row / column phase (mb_fm.hip, OPT_PSGD).
+#include "fm_device.h"
+#include "mb.h"
+
+namespace nfm {
+// ------------------------------------------------------------------------------------------------
+// MBPSGD (optimizer/minibatch_psgd.nim:87-122): after the column phase has added
+// -eta * (batch gradient) to the touched rows, EVERY parameter shrinks by 1 / (1 + eta * reg)
+// (Params.step = add then scale, model/params.nim:60-65,90-98) and every order goes through the
+// regulariser's proximal operator with lam = gamma * eta_P / (1 + eta_P * beta) (:118-120).  The solver is
+// dense by construction: one pass over P per mini-batch is its roofline (16 B per parameter).
+//   L1 (l1.nim:35-39), L21 (l21.nim:23-34), row-wise SquaredL12 (squaredl12.nim:161-162): fused into the pass.
+//   column-wise SquaredL12 (the default, :150-159) and SquaredL21 (squaredl21.nim:46-54) couple a whole
+//   column / all row norms through one threshold tau = 2 lam S, S = sum_{|p_i| > tau} |p_i| / (1 + 2 lam theta)
+//   (squaredl12.nim:16-69 finds theta by randomised pivoting).  Here tau is the fixed point of
+//   tau <- 2 lam sum_{|p_i| > tau} |p_i| / (1 + 2 lam #{|p_i| > tau}) started at 0: the map is the Newton step
+//   of a concave increasing piecewise-linear function, so the active set only shrinks and the iteration ends
+//   after finitely many passes at the same theta the pivoting finds (no random numbers, fixed summation order).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double softthreshold(double x, double alpha) {  // regularizer/utils.nim:4-5
+  const double t = fmax(fabs(x) - alpha, 0.0);
+  return x > 0 ? t : (x < 0 ? -t : 0.0 * t);
+}
+
+// Sum over the wavefront with the first four levels on DPP (quad permutes and row mirrors: no LDS-pipe traffic) and
+// the last two on ds_bpermute.  Every lane adds the same two group sums at every level, so all lanes end with the
+// same bits.  (16 wavefronts per workgroup run two of these per threshold pass.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_d<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_d<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_d<0x141>(v);  // row_half_mirror
+  v += dpp_d<0x140>(v);  // row_mirror
+  v += dev::shfl_xor_d(v, 16);
+  v += dev::shfl_xor_d(v, 32);
+  return v;
+}
+
+struct ProxArgs {
+  ModelView M;
+  OptView O;
+  const double* it0p;
+  double it_b;
+  double* norms;  // [nb][da]   (SquaredL21)
+  double* tau;    // [nb][Kp]   thresholds of the coupled operators
+};
+
+__device__ __forceinline__ double psgd_lam(const OptView& O, double etaP) { return O.gamma * etaP / (1.0 + etaP * O.beta); }
+
+// sum over the L lanes of one row (fixed xor tree)
+template <int L>
+__device__ __forceinline__ double row_sum(double v) {
+#pragma unroll
+  for (int s = 1; s < L; s <<= 1) v += dev::shfl_xor_d(v, s);
+  return v;
+}
+
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_psgd_dense(ProxArgs a) {
+  constexpr int R = kWave / L;
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int64_t rows = (int64_t)M.nb * M.da;
+  const int64_t r = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  const double it = a.it0p[0] + a.it_b;
+  const double etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+  const double invP = 1.0 / (1.0 + etaP * O.beta), lam = psgd_lam(O, etaP);
+  const bool act = r < rows;  // inactive lanes keep taking part in the shuffles
+  double2 p = {0.0, 0.0};
+  const size_t e = (size_t)(act ? r : 0) * M.Kp + 2 * l;
+  if (act) p = *reinterpret_cast<const double2*>(M.P + e);
+  p.x *= invP;
+  p.y *= invP;
+  if (O.reg == NFM_REG_L1) {
+    p.x = softthreshold(p.x, lam);
+    p.y = softthreshold(p.y, lam);
+  } else if (O.reg == NFM_REG_L21 || O.reg == NFM_REG_SQUAREDL21) {
+    const double nrm = sqrt(row_sum<L>(p.x * p.x + p.y * p.y));
+    if (O.reg == NFM_REG_L21) {
+      const double f = nrm > lam ? 1.0 - lam / nrm : 0.0;
+      p.x = nrm > lam ? p.x * f : 0.0;
+      p.y = nrm > lam ? p.y * f : 0.0;
+    } else if (act && l == 0) {
+      a.norms[r] = nrm;
+    }
+  } else if (O.reg == NFM_REG_SQUAREDL12 && !O.reg_transpose) {
+    // the vector operator on the row's k components
+    const double ax = fabs(p.x), ay = fabs(p.y);
+    double tau = 0.0;
+    int cnt_prev = -1;
+    for (int pass = 0; pass < 2 * L + 2; ++pass) {
+      const double S = row_sum<L>((ax > tau ? ax : 0.0) + (ay > tau ? ay : 0.0));
+      const int c = (int)row_sum<L>((double)((ax > tau) + (ay > tau)));
+      if (c == cnt_prev || c == 0) break;  // uniform over the row's lanes; rows of one wavefront may differ:
+      cnt_prev = c;                        // a finished row keeps its tau (the map is idempotent at the fixed point)
+      tau = 2 * lam * (S / (1.0 + 2.0 * lam * (double)c));
+    }
+    p.x = softthreshold(p.x, tau);
+    p.y = softthreshold(p.y, tau);
+  }
+  if (act) *reinterpret_cast<double2*>(M.P + e) = p;
+}
+
+// linear term and intercept: scale only (model/params.nim:60-65)
+__global__ __launch_bounds__(kBlock) void k_psgd_linear(ProxArgs a) {
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const double it = a.it0p[0] + a.it_b;
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (M.fit_linear && j < M.d) M.w[j] *= 1.0 / (1.0 + dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it) * O.alpha);
+  if (M.fit_intercept && j == 0)
+    M.sc[SC_INTERCEPT] *= 1.0 / (1.0 + dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it) * O.alpha0);
+}
+
+// threshold of one coupled vector: v(i) = |x[i * stride]|, i < n.  One workgroup, fixed-order sums.
+constexpr int kProxBlock = 1024;
+__device__ __forceinline__ double prox_threshold(const double* __restrict__ x, int64_t n, int64_t stride, double lam) {
+  __shared__ double sS[2][kProxBlock / kWave];
+  __shared__ double sC[2][kProxBlock / kWave];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  double tau = 0.0, cnt_prev = -1.0;
+  for (int pass = 0;; ++pass) {
+    double S = 0.0, c = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += kProxBlock) {
+      const double v = fabs(x[i * stride]);
+      if (v > tau) {
+        S += v;
+        c += 1.0;
+      }
+    }
+    S = wave_sum_dpp(S);
+    c = wave_sum_dpp(c);
+    // one barrier per pass: the per-wavefront sums alternate between two buffers, every thread adds them up in
+    // the same fixed order (a writer of pass p + 2 has passed the barrier of pass p + 1, after all reads of pass p)
+    double* bS = sS[pass & 1];
+    double* bC = sC[pass & 1];
+    if (lane == 0) {
+      bS[wv] = S;
+      bC[wv] = c;
+    }
+    __syncthreads();
+    double St = 0.0, ct = 0.0;
+#pragma unroll
+    for (int w_ = 0; w_ < kProxBlock / kWave; ++w_) {
+      St += bS[w_];
+      ct += bC[w_];
+    }
+    if (ct == cnt_prev || ct == 0.0) break;
+    tau = 2 * lam * (St / (1.0 + 2.0 * lam * ct));
+    cnt_prev = ct;
+  }
+  return tau;
+}
+
+// column-wise SquaredL12 (squaredl12.nim:150-159): workgroup (s, o) owns component s of order o
+__global__ __launch_bounds__(kProxBlock) void k_psgd_prox_columns(ProxArgs a) {
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int s = blockIdx.x, o = blockIdx.y;
+  const double lam = psgd_lam(O, dev::get_eta(O.sched, O.eta0, O.power, O.beta, a.it0p[0] + a.it_b));
+  double* col = M.P + (size_t)o * M.da * M.Kp + s;
+  const double tau = prox_threshold(col, M.da, M.Kp, lam);
+  for (int64_t j = threadIdx.x; j < M.da; j += kProxBlock) col[j * M.Kp] = softthreshold(col[j * M.Kp], tau);
+}
+
+// The same for models of at most VPT * 1024 features, and the whole step of such a model in ONE launch: the
+// workgroup reads its column once (VPT values per thread, in registers), applies the shrink 1 / (1 + eta_P beta)
+// of Params.step itself (the padding components s >= k are zero and need none), runs the threshold passes on
+// the registers -- a pass is one workgroup reduction, no memory traffic -- and writes the column once.  The
+// workgroups s >= k of order 0 shrink the linear term and the intercept (k_psgd_linear's work).
+template <int VPT>
+__global__ __launch_bounds__(kProxBlock) void k_psgd_step_columns(ProxArgs a) {
+  __shared__ double sS[2][kProxBlock / kWave];
+  __shared__ double sC[2][kProxBlock / kWave];
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int s = blockIdx.x, o = blockIdx.y;
+  const double it = a.it0p[0] + a.it_b;
+  if (s >= M.k) {
+    if (o != 0) return;
+    const int64_t j = (int64_t)(s - M.k) * kProxBlock + threadIdx.x;
+    if (M.fit_linear && j < M.d) M.w[j] *= 1.0 / (1.0 + dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it) * O.alpha);
+    if (M.fit_intercept && j == 0)
+      M.sc[SC_INTERCEPT] *= 1.0 / (1.0 + dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it) * O.alpha0);
+    return;
+  }
+  const double etaP = dev::get_eta(O.sched, O.eta0, O.power, O.beta, it);
+  const double invP = 1.0 / (1.0 + etaP * O.beta), lam = psgd_lam(O, etaP);
+  double* col = M.P + (size_t)o * M.da * M.Kp + s;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  double v[VPT];
+#pragma unroll
+  for (int q = 0; q < VPT; ++q) {
+    const int64_t j = (int64_t)q * kProxBlock + threadIdx.x;
+    v[q] = j < M.da ? col[j * M.Kp] * invP : 0.0;
+  }
+  double tau = 0.0, cnt_prev = -1.0;
+  for (int pass = 0;; ++pass) {
+    double S = 0.0, c = 0.0;
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+      const double av = fabs(v[q]);
+      if (av > tau) {
+        S += av;
+        c += 1.0;
+      }
+    }
+    S = wave_sum_dpp(S);
+    c = wave_sum_dpp(c);
+    // one barrier per pass: the per-wavefront sums alternate between two buffers, every thread adds them up in
+    // the same fixed order (a writer of pass p + 2 has passed the barrier of pass p + 1, after all reads of pass p)
+    double* bS = sS[pass & 1];
+    double* bC = sC[pass & 1];
+    if (lane == 0) {
+      bS[wv] = S;
+      bC[wv] = c;
+    }
+    __syncthreads();
+    double St = 0.0, ct = 0.0;
+#pragma unroll
+    for (int w_ = 0; w_ < kProxBlock / kWave; ++w_) {
+      St += bS[w_];
+      ct += bC[w_];
+    }
+    if (ct == cnt_prev || ct == 0.0) break;
+    tau = 2 * lam * (St / (1.0 + 2.0 * lam * ct));
+    cnt_prev = ct;
+  }
+#pragma unroll
+  for (int q = 0; q < VPT; ++q) {
+    const int64_t j = (int64_t)q * kProxBlock + threadIdx.x;
+    if (j < M.da) col[j * M.Kp] = softthreshold(v[q], tau);
+  }
+}
+
+// SquaredL21 (squaredl21.nim:46-54): the vector operator on the row norms of order o ...
+__global__ __launch_bounds__(kProxBlock) void k_psgd_prox_norms(ProxArgs a) {
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int o = blockIdx.x;
+  const double lam = psgd_lam(O, dev::get_eta(O.sched, O.eta0, O.power, O.beta, a.it0p[0] + a.it_b));
+  const double tau = prox_threshold(a.norms + (size_t)o * M.da, M.da, 1, lam);
+  if (threadIdx.x == 0) a.tau[o] = tau;
+}
+
+// ... then every row is rescaled from its old norm to the thresholded one: P[i] /= n; P[i] *= n'
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_psgd_rescale_rows(ProxArgs a) {
+  constexpr int R = kWave / L;
+  const ModelView& M = a.M;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int64_t r = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  if (r >= (int64_t)M.nb * M.da) return;
+  const double n_old = a.norms[r], n_new = softthreshold(n_old, a.tau[r / M.da]);
+  const size_t e = (size_t)r * M.Kp + 2 * l;
+  double2 p = *reinterpret_cast<const double2*>(M.P + e);
+  if (n_old != 0) {
+    p.x /= n_old;
+    p.y /= n_old;
+  }
+  p.x *= n_new;
+  p.y *= n_new;
+  *reinterpret_cast<double2*>(M.P + e) = p;
+}
+
+template <int L>
+static void launch_psgd_step_t(nfm_ctx* ctx, const ModelView& M, const OptView& O, MbWork& W, const double* it0p, double it_b) {
+  constexpr int R = kWave / L;
+  hipStream_t st = ctx->stream;
+  ProxArgs pa{M, O, it0p, it_b, W.prox.as<double>(), W.prox.as<double>() + (size_t)M.nb * M.da};
+  const int64_t rows = (int64_t)M.nb * M.da;
+  const unsigned row_blocks = (unsigned)((rows + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
+  TimedLaunch tl(ctx, "psgd_step");
+  if (rows > 0 && O.reg == NFM_REG_SQUAREDL12 && O.reg_transpose && M.da <= 16 * kProxBlock) {  // the one-launch step
+    const unsigned gx = (unsigned)(M.k + (std::max<int64_t>(M.d, 1) + kProxBlock - 1) / kProxBlock);
+    const int vpt = (int)((M.da + kProxBlock - 1) / kProxBlock);
+    if (vpt <= 1) hipLaunchKernelGGL((k_psgd_step_columns<1>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    else if (vpt <= 2) hipLaunchKernelGGL((k_psgd_step_columns<2>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    else if (vpt <= 4) hipLaunchKernelGGL((k_psgd_step_columns<4>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    else if (vpt <= 8) hipLaunchKernelGGL((k_psgd_step_columns<8>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    else hipLaunchKernelGGL((k_psgd_step_columns<16>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    return;
+  }
+  if (rows > 0) hipLaunchKernelGGL((k_psgd_dense<L>), dim3(row_blocks), dim3(kBlock), 0, st, pa);
+  hipLaunchKernelGGL(k_psgd_linear, dim3((unsigned)((std::max<int64_t>(M.d, 1) + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pa);
+  if (rows > 0 && O.reg == NFM_REG_SQUAREDL12 && O.reg_transpose) {
+    hipLaunchKernelGGL(k_psgd_prox_columns, dim3((unsigned)M.k, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+  } else if (rows > 0 && O.reg == NFM_REG_SQUAREDL21) {
+    hipLaunchKernelGGL(k_psgd_prox_norms, dim3((unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    hipLaunchKernelGGL((k_psgd_rescale_rows<L>), dim3(row_blocks), dim3(kBlock), 0, st, pa);
+  }
+}
+
+void launch_psgd_step(nfm_ctx* ctx, const ModelView& M, const OptView& O, MbWork& W, const double* it0p, double it_b) {
+  switch (M.L) {
+    case 1: return launch_psgd_step_t<1>(ctx, M, O, W, it0p, it_b);
+    case 2: return launch_psgd_step_t<2>(ctx, M, O, W, it0p, it_b);
+    case 4: return launch_psgd_step_t<4>(ctx, M, O, W, it0p, it_b);
+    case 8: return launch_psgd_step_t<8>(ctx, M, O, W, it0p, it_b);
+    case 16: return launch_psgd_step_t<16>(ctx, M, O, W, it0p, it_b);
+    case 32: return launch_psgd_step_t<32>(ctx, M, O, W, it0p, it_b);
+    default: return launch_psgd_step_t<64>(ctx, M, O, W, it0p, it_b);
+  }
+}
+
+}  // namespace nfm
