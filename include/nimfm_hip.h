@@ -231,6 +231,13 @@ typedef struct nfm_mbpsgd_cfg {
 int32_t nfm_sgd_create(nfm_model* m, const nfm_sgd_cfg* cfg, nfm_opt** out);
 int32_t nfm_adagrad_create(nfm_model* m, const nfm_adagrad_cfg* cfg, nfm_opt** out);
 int32_t nfm_mbpsgd_create(nfm_model* m, const nfm_mbpsgd_cfg* cfg, nfm_opt** out);
+/* predictAllWithGrad (optimizer/pgd.nim:70-103), the full-batch half of the proximal solvers, on an optimizer made
+ * by nfm_mbpsgd_create (its loss is used; its state and `it` are untouched): y_pred[n] = the model's output on every
+ * sample, dL[n] = dloss(y_i, y_pred_i), and the gradient of the MEAN loss -- grad_P in the training layout
+ * [nOrders][d + nAugments][k] (the reference's grads.P), grad_w[d] (zeros unless fitLinear), *grad_b (0 unless
+ * fitIntercept), *loss_sum = sum_i loss(y_i, y_pred_i).  Any output pointer may be NULL. */
+int32_t nfm_opt_predict_all_with_grad(nfm_opt* o, nfm_dataset* ds, double* y_pred, double* dL,
+                                      double* grad_P, double* grad_w, double* grad_b, double* loss_sum);
 /* the optimizer's `it` (optimizer/sgd.nim:18,55-56; adagrad.nim:14,50): starts
  * at 1, +1 per sample; set to 1 to mimic a non-warm-start fit. */
 int32_t nfm_opt_set_it(nfm_opt* o, int64_t it);

@@ -59,6 +59,7 @@ proc nfm_model_destroy(m: NfmModel): int32
 proc nfm_sgd_create(m: NfmModel, cfg: ptr NfmSgdCfg, outp: ptr NfmOpt): int32
 proc nfm_adagrad_create(m: NfmModel, cfg: ptr NfmAdaGradCfg, outp: ptr NfmOpt): int32
 proc nfm_mbpsgd_create(m: NfmModel, cfg: ptr NfmMbpsgdCfg, outp: ptr NfmOpt): int32
+proc nfm_opt_predict_all_with_grad(o: NfmOpt, ds: NfmDataset, yPred, dL, gradP, gradW, gradB, lossSum: ptr float64): int32
 proc nfm_opt_set_it(o: NfmOpt, it: int64): int32
 proc nfm_opt_epoch(o: NfmOpt, ds: NfmDataset, perm: ptr int64, first, last: int64,
                    lossSum, violSum: ptr float64): int32

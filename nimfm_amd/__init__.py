@@ -7,7 +7,7 @@ Layout:
   dp.py      one-process-per-GPU data parallelism over torch.distributed (RCCL)
 """
 from ._capi import NfmError, NotFittedError, build, lib  # noqa: F401
-from .host import (L1, L21, MBPSGD, SquaredL12, SquaredL21, newL1, newL21, newMBPSGD, newSquaredL12, newSquaredL21,  # noqa: F401
+from .host import (L1, L21, MBPSGD, SquaredL12, SquaredL21, newL1, newL21, newMBPSGD, predictAllWithGrad, newSquaredL12, newSquaredL21,  # noqa: F401
                    AdaGrad, Context, CSRDataset, FactorizationMachine, FieldAwareFactorizationMachine, SGD,  # noqa: F401
                    accuracy, convertSVMLightFile, default_context, expit, load, loadFFMFile, loadSVMLightFile, newAdaGrad, newCSRDataset, newCSRFieldDataset,
                    newFactorizationMachine, newFieldAwareFactorizationMachine, newSGD, newStreamCSRDataset, parseText, rmse,

@@ -36,7 +36,7 @@ SYMBOLS = [
     "nfm_model_create", "nfm_model_shape", "nfm_model_set_params", "nfm_model_get_params",
     "nfm_decision_function", "nfm_decision_function_device", "nfm_score", "nfm_metrics", "nfm_model_sqnorms", "nfm_model_device_buffers",
     "nfm_model_destroy",
-    "nfm_sgd_create", "nfm_adagrad_create", "nfm_mbpsgd_create", "nfm_opt_set_it", "nfm_opt_get_it", "nfm_opt_get_state",
+    "nfm_sgd_create", "nfm_adagrad_create", "nfm_mbpsgd_create", "nfm_opt_predict_all_with_grad", "nfm_opt_set_it", "nfm_opt_get_it", "nfm_opt_get_state",
     "nfm_opt_set_state", "nfm_opt_epoch", "nfm_opt_finalize", "nfm_opt_device_state", "nfm_opt_destroy",
 ]
 
@@ -145,6 +145,7 @@ def lib():
         "nfm_sgd_create": [vp, C.POINTER(SGDCfg), pp],
         "nfm_adagrad_create": [vp, C.POINTER(AdaGradCfg), pp],
         "nfm_mbpsgd_create": [vp, C.POINTER(MBPSGDCfg), pp],
+        "nfm_opt_predict_all_with_grad": [vp, vp, vp, vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl)],
         "nfm_opt_set_it": [vp, i64],
         "nfm_opt_get_it": [vp, C.POINTER(i64)],
         "nfm_opt_get_state": [vp, vp, vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl)],

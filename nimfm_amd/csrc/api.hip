@@ -834,6 +834,55 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
   return NFM_OK;
 }
 
+int32_t nfm_opt_predict_all_with_grad(nfm_opt* o, nfm_dataset* ds, double* y_pred, double* dL, double* grad_P, double* grad_w,
+                                      double* grad_b, double* loss_sum) {
+  NFM_CHECK(o && ds, NFM_ERR_INVALID, "null argument");
+  NFM_CHECK(o->kind == OPT_PSGD, NFM_ERR_INVALID, "predictAllWithGrad needs an optimizer made by nfm_mbpsgd_create");
+  nfm_model* m = o->m;
+  nfm_ctx* ctx = m->ctx;
+  NFM_CHECK(ds->ctx == ctx, NFM_ERR_INVALID, "optimizer and dataset belong to different contexts");
+  NFM_TRY(check_predict_shapes(m, ds));
+  NFM_CHECK(ds->has_y, NFM_ERR_INVALID, "dataset has no targets");
+  NFM_TRY(use_device(ctx));
+  NFM_TRY(ensure_unit_scale(m));
+  hipStream_t st = ctx->stream;
+  const int64_t n = ds->v.n;
+  const ModelView M = m->view();
+  const size_t bP = pad256(sizeof(double) * std::max<int64_t>(m->nP(), 2)), bw = pad256(sizeof(double) * std::max<int64_t>(m->d, 1));
+  DevBuf g, rec2;
+  NFM_TRY(g.alloc(bP + bw + 256));
+  NFM_HIP_CHECK(hipMemsetAsync(g.p, 0, g.bytes, st));  // features no sample touches keep a zero gradient
+  double out2[2] = {0.0, 0.0};
+  if (n > 0) {
+    OptView O = o->o;
+    O.bsize = (double)n;  // one mini-batch holding every sample: coef = dloss / nSamples (pgd.nim:102)
+    O.gradP = g.as<double>();
+    O.gradw = reinterpret_cast<double*>(g.as<char>() + bP);
+    O.gradb = reinterpret_cast<double*>(g.as<char>() + bP + bw);
+    Plan plan;
+    MbWork W;
+    W.use_graph = false;
+    const bool sort_by_count = m->Kp * (int)sizeof(double) >= 128;
+    NFM_TRY(plan_build(ctx, ds->v, m->n_aug, nullptr, 0, n, n, false, false, false, sort_by_count, &plan));
+    NFM_TRY(mb_fm_epoch(ctx, OPT_PSGD, ds->v, M, O, plan, W, o->it, out2));
+    if (y_pred || dL) {
+      NFM_TRY(rec2.alloc(sizeof(double) * 2 * (size_t)n));
+      NFM_TRY(mb_fm_records(ctx, W, n, rec2.as<double>(), rec2.as<double>() + n));
+      if (y_pred) NFM_HIP_CHECK(hipMemcpyAsync(y_pred, rec2.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+      if (dL) NFM_HIP_CHECK(hipMemcpyAsync(dL, rec2.as<double>() + n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    }
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  if (grad_P && m->nP() > 0)  // device rows of Kp doubles -> the training layout's rows of k
+    NFM_HIP_CHECK(hipMemcpy2DAsync(grad_P, sizeof(double) * m->cfg.n_components, g.p, sizeof(double) * m->Kp,
+                                   sizeof(double) * m->cfg.n_components, (size_t)m->nb * m->da, hipMemcpyDeviceToHost, st));
+  if (grad_w) NFM_HIP_CHECK(hipMemcpyAsync(grad_w, g.as<char>() + bP, sizeof(double) * m->d, hipMemcpyDeviceToHost, st));
+  if (grad_b) NFM_HIP_CHECK(hipMemcpyAsync(grad_b, g.as<char>() + bP + bw, sizeof(double), hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  if (loss_sum) *loss_sum = out2[0];
+  return NFM_OK;
+}
+
 int32_t nfm_opt_finalize(nfm_opt* o) {
   NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
   nfm_model* m = o->m;

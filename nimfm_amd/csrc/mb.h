@@ -32,6 +32,8 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
                 int64_t it0, double* out2_host);
 // psgd.hip: Params.step's shrink + the regulariser's prox after one mini-batch of MBPSGD (it = it0p[0] + it_b)
 void launch_psgd_step(nfm_ctx* ctx, const ModelView& M, const OptView& O, MbWork& W, const double* it0p, double it_b);
+// yhat / dloss of the samples of the last epoch call's batch (a single batch: pgd.predictAllWithGrad), device arrays
+int mb_fm_records(nfm_ctx* ctx, MbWork& W, int64_t n, double* yhat_dev, double* dL_dev);
 int mb_ffm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
                  int64_t it0, double* out2_host);
 

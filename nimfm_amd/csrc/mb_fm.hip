@@ -34,7 +34,7 @@ namespace nfm {
 #endif
 
 struct SampleRec {
-  double dL, etaP, etaw, pad;
+  double dL, etaP, etaw, yhat;  // yhat: the sample's prediction (read back by predictAllWithGrad)
 };
 struct PartA {
   double loss, viol, acc0, acc1;
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
       r_acc1 = dL * dL;
     }
     if (lane == 0) {
-      if (valid) a.rec[pib] = SampleRec{dL, etaP, etaw, 0.0};
+      if (valid) a.rec[pib] = SampleRec{dL, etaP, etaw, yh};
       s_dL[sib] = valid ? r_acc0 : 0.0;
       s_etaP[sib] = valid ? r_acc1 : 0.0;
     }  // the loss VALUE (log / exp) waits until the rows are written back, see below
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
           r_acc0 += dL;
           r_acc1 += dL * dL;
         }
-        a.rec[pt] = SampleRec{dL, etaP, etaw, 0.0};
+        a.rec[pt] = SampleRec{dL, etaP, etaw, yh};
         s_dL[t] = dL;
         s_etaP[t] = etaP;
         s_etaw[t] = etaw;
@@ -1075,9 +1075,13 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
     stored.y = stored.y * fP - (acc.y / c) / sPn;
     dev::st_stream(M.P + e, stored);
   } else if (OPT == OPT_PSGD) {  // Params.add with -eta_P (model/params.nim:33-41,97); sPn carries eta_P here
-    stored.x += -sPn * acc.x;
-    stored.y += -sPn * acc.y;
-    dev::st_stream(M.P + e, stored);
+    if (O.gradP != nullptr) {  // predictAllWithGrad: the gradient is the product
+      *reinterpret_cast<double2*>(O.gradP + e) = acc;
+    } else {
+      stored.x += -sPn * acc.x;
+      stored.y += -sPn * acc.y;
+      dev::st_stream(M.P + e, stored);
+    }
   } else {
     g2.x += acc.x;
     g2.y += acc.y;
@@ -1104,7 +1108,10 @@ __device__ __forceinline__ double w_epilogue(const ColArgs& a, int64_t j, int l,
       M.w[j] = wt * fw - (wacc.a0 / c) / swn;
     }
   } else if (OPT == OPT_PSGD) {  // model/params.nim:43-45; swn carries eta_w
-    if (l == 0) M.w[j] = wt + -swn * wacc.a0;
+    if (l == 0) {
+      if (O.gradw != nullptr) O.gradw[j] = wacc.a0;
+      else M.w[j] = wt + -swn * wacc.a0;
+    }
   } else {
     const double gw = O.Gw[j], nw = O.Nw[j];
     if (l == 0) {
@@ -1363,7 +1370,9 @@ __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
         M.sc[SC_INTERCEPT] = f0 * b0 - red[2][0] / a.len;
       } else if (OPT == OPT_PSGD) {
         // model/params.nim:47 gates the intercept's step on grad.fitLinear -- kept as the reference has it
-        if (M.fit_linear)
+        if (O.gradb != nullptr)
+          O.gradb[0] = red[2][0] / O.bsize;
+        else if (M.fit_linear)
           M.sc[SC_INTERCEPT] += -dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, a.it0p[0] + a.it_b) * (red[2][0] / O.bsize);
       } else {
         if (!a.use_stored) {  // adagrad.nim:102-106
@@ -1553,7 +1562,7 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
       hipLaunchKernelGGL((k_heavy_apply<L, OPT, GEN>), dim3(nH), dim3(kBlock), 0, st, ca, ha);
     }
     n_prev = nB + nS + nH;
-    if (OPT == OPT_PSGD) launch_psgd_step(ctx, M, O, W, it0p, it_b);
+    if (OPT == OPT_PSGD && O.gradP == nullptr) launch_psgd_step(ctx, M, O, W, it0p, it_b);
   }
   if (P.n_batches > 0) {
     const double* parts_last = W.partsB.as<double>() + ((P.n_batches - 1) & 1) * partsB_half;
@@ -1666,6 +1675,24 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   }
   NFM_HIP_CHECK(hipMemcpyAsync(out2_host, W.out_acc.p, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
   NFM_HIP_CHECK(hipStreamSynchronize(st));
+  return NFM_OK;
+}
+
+// predictAllWithGrad: the records of the (single) batch the last epoch call ran, unpacked
+__global__ void k_unpack_rec(const SampleRec* __restrict__ rec, int64_t n, double* __restrict__ yhat, double* __restrict__ dL) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const SampleRec r = rec[i];
+  if (yhat) yhat[i] = r.yhat;
+  if (dL) dL[i] = r.dL;
+}
+
+int mb_fm_records(nfm_ctx* ctx, MbWork& W, int64_t n, double* yhat_dev, double* dL_dev) {
+  NFM_CHECK(W.rec.p && W.rec.bytes >= sizeof(SampleRec) * (size_t)n, NFM_ERR_INVALID, "no records of %lld samples", (long long)n);
+  if (n > 0)
+    hipLaunchKernelGGL(k_unpack_rec, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, W.rec.as<SampleRec>(), n,
+                       yhat_dev, dL_dev);
+  NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }
 

@@ -21,6 +21,11 @@ struct OptView {
   // MBPSGD (newMBPSGD, optimizer/minibatch_psgd.nim:24-65): gamma, miniBatchSize as a double, NFM_REG_*
   double gamma, bsize;
   int32_t reg, reg_transpose;
+  // pgd.predictAllWithGrad (optimizer/pgd.nim:70-103): when set, the column phase of OPT_PSGD stores the batch
+  // gradient here (device layout of P, [d], one scalar) instead of stepping the parameters
+  double* gradP;
+  double* gradw;
+  double* gradb;
 };
 
 // ---- seq.hip ----

@@ -972,6 +972,29 @@ class MBPSGD(_OptimizerBase):
         return self
 
 
+def predictAllWithGrad(X, y, sfm, loss="squared", lossParam=1.0):
+    """optimizer/pgd.nim:70-103 on the device: -> (yPred, dL, grads) with grads = {"P": [nOrders][d+a][k] (the training
+    layout of the reference's grads.P), "w": [d], "intercept": float, "loss": mean loss} -- the gradient of the mean
+    loss at sfm's current parameters (sfm must be initialised; classification targets are sign()-ed)."""
+    sfm.checkInitialized()
+    y = _f64(y)
+    if len(y) != X.nSamples:
+        raise ValueError("len(y) != nSamples")
+    X.set_targets(y)
+    opt = MBPSGD(maxIter=1, loss=loss, reg=newL1(), miniBatchSize=1, verbose=0, lossParam=lossParam)
+    opt._handle(sfm, X.ctx, "minibatch")
+    if sfm._dirty:
+        sfm._push(X.ctx)
+    n, d = X.nSamples, X.nFeatures
+    nb, k, da = sfm._P.shape
+    yp, dL = np.zeros(n), np.zeros(n)
+    gP, gw = np.zeros((nb, da, k)), np.zeros(d)
+    gb, ls = C.c_double(0.0), C.c_double(0.0)
+    capi.check(capi.lib().nfm_opt_predict_all_with_grad(opt._h, X.h, _vp(yp), _vp(dL), _vp(gP), _vp(gw), C.byref(gb),
+                                                        C.byref(ls)))
+    return yp, dL, {"P": gP, "w": gw, "intercept": gb.value, "loss": ls.value / max(n, 1)}
+
+
 def newMBPSGD(maxIter=100, eta0=0.1, alpha0=1e-6, alpha=1e-3, beta=1e-4, gamma=1e-4, loss="squared", reg=None,
               miniBatchSize=-1, maxIterInner=-1, scheduling="optimal", power=1.0, verbose=1, tol=1e-6, shuffle=True,
               nCalls=-1, **gpu):

@@ -447,3 +447,18 @@ def fm_mbpsgd_epoch(X, y, degree, P, w, intercept, cfg, stream, batch, n_aug=0, 
                                    C.byref(ls))
     assert rc == 0
     return b.value, itc.value, ls.value
+
+
+def fm_predict_all_with_grad(X, y, degree, P, w, intercept, loss="squared", n_aug=0, fit_linear=True, fit_intercept=True,
+                             loss_param=1.0):
+    """pgd.nim:70-103 -> (yPred, dL, gP [O][d+a][k], gw, gb)"""
+    O_, k, da = P.shape
+    y = f64(y)
+    yp, dL = np.zeros(X.n), np.zeros(X.n)
+    gP, gw, gb = np.zeros((O_, da, k)), np.zeros(X.d), C.c_double(0)
+    rc = lib().orc_fm_predict_all_with_grad(C.byref(X.c), _p(y), degree, k, O_, n_aug, _p(np.ascontiguousarray(P)),
+                                            _p(np.ascontiguousarray(w)), C.c_double(intercept), LOSS[loss],
+                                            C.c_double(loss_param), int(fit_linear), int(fit_intercept), _p(yp), _p(dL),
+                                            _p(gP), _p(gw), C.byref(gb))
+    assert rc == 0
+    return yp, dL, gP, gw, gb.value

@@ -206,6 +206,11 @@ int orc_fm_mbpsgd_epoch(const orc_csr* X, const double* y, int degree, int k, in
                         double* P, double* w, double* intercept, const orc_psgd_cfg* cfg,
                         const int64_t* stream, int64_t n_stream, int64_t batch, int64_t* it,
                         uint64_t* rng, double* loss_sum);
+/* optimizer/pgd.nim:70-103 predictAllWithGrad (gP in the training layout [O][d+a][k]) */
+int orc_fm_predict_all_with_grad(const orc_csr* X, const double* y, int degree, int k, int n_orders, int n_aug,
+                                 const double* P, const double* w, double intercept, int loss, double loss_param,
+                                 int fit_linear, int fit_intercept, double* y_pred, double* dL, double* gP,
+                                 double* gw, double* gb);
 
 #ifdef __cplusplus
 }

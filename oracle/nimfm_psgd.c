@@ -254,3 +254,60 @@ double orc_reg_eval(int reg, int transpose, const double* Po, int64_t da, int k)
   }
   return r;
 }
+
+/* optimizer/pgd.nim:70-103 predictAllWithGrad: yPred, dL and the gradient of the MEAN loss at the given
+ * parameters (the other function SURVEY 8(f) rank 3 names).  P in the model layout [O][k][d+a]; gP is returned in
+ * the TRAINING layout [O][d+a][k] like the reference's grads.P. */
+int orc_fm_predict_all_with_grad(const orc_csr* X, const double* y, int degree, int k, int n_orders, int n_aug,
+                                 const double* P, const double* w, double intercept, int loss, double loss_param,
+                                 int fit_linear, int fit_intercept, double* y_pred, double* dL, double* gP,
+                                 double* gw, double* gb) {
+  const int64_t d = X->d, da = d + n_aug, n = X->n;
+  const size_t nP = (size_t)n_orders * da * k;
+  double* Pt = (double*)calloc(nP ? nP : 1, sizeof(double));
+  double* dA = (double*)calloc(nP ? nP : 1, sizeof(double));
+  double* A = (double*)calloc((size_t)k * (degree + 1), sizeof(double));
+  to_train_layout(Pt, P, n_orders, k, da);
+  memset(gP, 0, sizeof(double) * nP); /* grads.P <- 0.0, :76 */
+  for (int64_t j = 0; j < d; j++) gw[j] = 0.0;
+  *gb = 0.0;
+  for (int64_t i = 0; i < n; i++) {
+    row_view r = get_row(X, i);
+    /* :79-88: mvmul(X, w) + intercept, then per order computeAnova + derivative -- predict_with_grad's sum in
+     * the order linear, intercept, orders; the reference adds intercept after the linear term (:80-81) */
+    double yp = 0.0;
+    for (int64_t q = 0; q < r.m; q++) yp += w[r.idx[q]] * r.val[q];
+    yp += intercept;
+    for (int o = 0; o < n_orders; o++) {
+      const double* Po = Pt + (size_t)o * da * k;
+      yp += compute_anova(Po, r, d, n_aug, k, degree - o, A, degree + 1);
+      compute_anova_derivative(Po, r, d, n_aug, k, degree - o, A, degree + 1, dA + (size_t)o * da * k);
+    }
+    y_pred[i] = yp;
+    dL[i] = orc_dloss(loss, loss_param, y[i], yp); /* :90 */
+    for (int o = 0; o < n_orders; o++)
+      for (int64_t q = 0; q < r.m + n_aug; q++) {
+        const int64_t j = ROW_J(r, q, d);
+        for (int s = 0; s < k; s++) gP[((size_t)o * da + j) * k + s] += dL[i] * dA[((size_t)o * da + j) * k + s];
+      }
+  }
+  if (fit_linear) /* vmmul(dL, X, grads.w), :96-97 */
+    for (int64_t i = 0; i < n; i++) {
+      row_view r = get_row(X, i);
+      for (int64_t q = 0; q < r.m; q++) gw[r.idx[q]] += dL[i] * r.val[q];
+    }
+  if (fit_intercept) { /* :98-99 */
+    double sm = 0.0;
+    for (int64_t i = 0; i < n; i++) sm += dL[i];
+    *gb = sm;
+  }
+  { /* grads /= float(nSamples), :102 = scale(1.0 / n): P always, w / intercept when fitted (params.nim:60-65) */
+    const double sc = 1.0 / (double)n;
+    for (size_t e = 0; e < nP; e++) gP[e] *= sc;
+    if (fit_linear)
+      for (int64_t j = 0; j < d; j++) gw[j] *= sc;
+    if (fit_intercept) *gb *= sc;
+  }
+  free(Pt); free(dA); free(A);
+  return 0;
+}

@@ -160,6 +160,31 @@ def test_internal_shuffle_stopping_and_verbose(capsys):
     assert np.isfinite(fm.P).all()
 
 
+@pytest.mark.parametrize("degree,fit_lower,loss,fit_linear,fit_intercept", [
+    (2, "explicit", "squared", True, True), (3, "explicit", "logistic", True, True), (3, "augment", "squared", True, False),
+    (2, "none", "squared_hinge", False, True), (4, "explicit", "huber", True, True)])
+def test_predict_all_with_grad(degree, fit_lower, loss, fit_linear, fit_intercept):
+    """pgd.predictAllWithGrad (optimizer/pgd.nim:70-103) through nfm_opt_predict_all_with_grad vs its restatement"""
+    n, d, k = 300, 40, 5  # every feature is touched by ~100 samples of the single batch: heavy and light paths
+    Xo, Xd, y = make_fm_dataset(n, d, degree, k, 21, fit_lower, fit_linear, fit_intercept, threshold=0.6)
+    Xo2 = random_csr(n, d, 3, 5)
+    task = "regression" if loss in ("squared", "huber") else "classification"
+    for X_ in (Xo, Xo2):
+        yo = y if task == "regression" else np.sign(y)
+        P0, w0, b0, n_aug = init_fm(d, degree, k, fit_lower, fit_linear, scale=0.3)
+        w0 = np.random.default_rng(3).normal(size=d) * (0.1 if fit_linear else 0.0)
+        b0 = 0.25 if fit_intercept else 0.0
+        yp, dL, gP, gw, gb = O.fm_predict_all_with_grad(X_, yo, degree, P0, w0, b0, loss, n_aug, fit_linear, fit_intercept)
+        fm = gpu_fm(task, degree, k, fit_lower, fit_linear, fit_intercept, P0, w0, b0)
+        yp_g, dL_g, g = nf.predictAllWithGrad(to_gpu(X_), yo, fm, loss=loss)
+        assert_close(yp_g, yp, 1e-11, 1e-13, "yPred")
+        assert_close(dL_g, dL, 1e-10, 1e-13, "dL")
+        assert_close(g["P"], gP, 1e-9, 1e-13, "grad P")
+        assert_close(g["w"], gw, 1e-9, 1e-13, "grad w")
+        assert abs(g["intercept"] - gb) < 1e-12
+        assert np.array_equal(fm.P, P0) and fm.intercept == b0  # the parameters are not stepped
+
+
 def test_errors():
     n, d, k = 20, 6, 2
     Xo, Xd, y = make_fm_dataset(n, d, 3, k, 1, "explicit", threshold=0.3)

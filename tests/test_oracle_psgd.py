@@ -150,3 +150,38 @@ def test_intercept_step_gated_on_fit_linear():
     b, it, ls = O.fm_mbpsgd_epoch(X, y, 2, P, w, 2.0, cfg, np.arange(12), B, n_aug, it=1)
     assert abs(b - 2.0 / (1 + 0.1 * 0.5) ** 3) < 1e-14
     assert np.all(w == w0)
+
+
+@pytest.mark.parametrize("degree,fit_lower,loss", [(2, "explicit", "squared"), (3, "explicit", "logistic"),
+                                                   (3, "augment", "squared"), (2, "none", "squared_hinge")])
+def test_predict_all_with_grad_is_the_gradient_of_the_mean_loss(degree, fit_lower, loss):
+    """pgd.nim:70-103 against central differences of the brute-force model's mean loss"""
+    n, d, k = 15, 5, 2
+    X, Xd, y = make_fm_dataset(n, d, degree, k, 4, fit_lower, threshold=0.3)
+    if loss != "squared":  # (Huber is left out: the reference's dloss for it, loss.nim:90-93, is not the derivative of its loss)
+        y = np.sign(y)
+    P, w, b, n_aug = init_fm(d, degree, k, fit_lower, True, scale=0.4)
+    w = np.random.default_rng(2).normal(size=d) * 0.1
+    b = 0.3
+    yp, dL, gP, gw, gb = O.fm_predict_all_with_grad(X, y, degree, P, w, b, loss, n_aug)
+    assert_close(yp, O.slow_fm_decision_function(Xd, degree, P, w, b, n_aug), rtol=1e-10, atol=1e-12)
+    lid = O.LOSS[loss]
+
+    def mean_loss(Pm, wm, bm):
+        f = O.slow_fm_decision_function(Xd, degree, Pm, wm, bm, n_aug)
+        return np.mean([O.lib().orc_loss(lid, 1.0, y[i], f[i]) for i in range(n)])
+
+    h = 1e-6
+    tol = 1e-6 if loss in ("squared", "logistic") else 1e-4  # the squared hinge's derivative has a kink: central differences lose an order
+    for o, s, j in itertools.product(range(P.shape[0]), range(k), range(P.shape[2])):
+        Pp, Pm = P.copy(), P.copy()
+        Pp[o, s, j] += h
+        Pm[o, s, j] -= h
+        assert abs(gP[o, j, s] - (mean_loss(Pp, w, b) - mean_loss(Pm, w, b)) / (2 * h)) < tol
+    for j in range(d):
+        wp, wm = w.copy(), w.copy()
+        wp[j] += h
+        wm[j] -= h
+        assert abs(gw[j] - (mean_loss(P, wp, b) - mean_loss(P, wm, b)) / (2 * h)) < tol
+    assert abs(gb - (mean_loss(P, w, b + h) - mean_loss(P, w, b - h)) / (2 * h)) < tol
+    assert abs(gb - dL.mean()) < 1e-14
