@@ -192,7 +192,8 @@ int32_t nfm_metrics(nfm_model* m, nfm_dataset* ds, double* rmse, double* accurac
 int32_t nfm_model_sqnorms(nfm_model* m, double* P_sq, double* w_sq);
 /* device views for the data-parallel exchange: pointers to
  * the device-layout parameter buffers and their lengths in doubles. scalars
- * holds {scale_P, scale_w, intercept, 5 unused}. The three buffers are pieces of
+ * holds {scale_P, scale_w, intercept, 5 unused}. (Device layout: FM [nOrders][d+nAug][Kp], FFM [d][nFields][Kp]
+ * with Kp >= k zero-padded -- opaque to an element-wise exchange.) The three buffers are pieces of
  * ONE allocation in the order [P | w | scalars] (gaps are zero padding), so a
  * single collective over [P_dev, scalars_dev + n_scalars) reconciles a replica. */
 int32_t nfm_model_device_buffers(nfm_model* m, double** P_dev, int64_t* n_P, double** w_dev,

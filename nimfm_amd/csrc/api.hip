@@ -45,6 +45,7 @@ struct nfm_model {
     ModelView m{};
     m.P = P.as<double>(); m.w = w.as<double>(); m.sc = sc.as<double>(); m.lams = lams.as<double>();
     m.d = d; m.da = da; m.nb = nb; m.k = k; m.Kp = Kp; m.L = L;
+    if (cfg.kind == NFM_KIND_FFM) { m.bs = 1; m.rs = nb; } else { m.bs = da; m.rs = 1; }
     m.degree = cfg.kind == NFM_KIND_FFM ? 2 : cfg.degree;
     m.n_aug = n_aug; m.kind = cfg.kind; m.fit_linear = cfg.fit_linear; m.fit_intercept = cfg.fit_intercept;
     m.task = cfg.task;
@@ -463,7 +464,7 @@ int32_t nfm_model_set_params(nfm_model* m, const double* P, const double* w, dou
     if (m->cfg.kind == NFM_KIND_FM)
       NFM_TRY(launch_fm_to_device(ctx, tmp.as<double>(), m->P.as<double>(), m->nb, m->k, m->Kp, m->da));
     else
-      NFM_TRY(launch_rows_to_device(ctx, tmp.as<double>(), m->P.as<double>(), (int64_t)m->nb * m->da, m->k, m->Kp, 0.0));
+      NFM_TRY(launch_rows_to_device(ctx, tmp.as<double>(), m->P.as<double>(), (int64_t)m->nb * m->da, m->k, m->Kp, 0.0, m->nb));
     NFM_HIP_CHECK(hipStreamSynchronize(st));
   }
   NFM_HIP_CHECK(hipMemcpyAsync(m->w.p, w, sizeof(double) * m->d, hipMemcpyHostToDevice, st));
@@ -493,7 +494,7 @@ int32_t nfm_model_get_params(nfm_model* m, double* P, double* w, double* interce
       NFM_TRY(launch_fm_from_device(ctx, m->P.as<double>(), tmp.as<double>(), m->nb, m->k, m->Kp, m->da, m->sc.as<double>() + SC_SCALE_P));
     else
       NFM_TRY(launch_rows_from_device(ctx, m->P.as<double>(), tmp.as<double>(), (int64_t)m->nb * m->da, m->k, m->Kp,
-                                      m->sc.as<double>() + SC_SCALE_P));
+                                      m->sc.as<double>() + SC_SCALE_P, m->nb));
     NFM_HIP_CHECK(hipMemcpyAsync(P, tmp.p, sizeof(double) * n_ref, hipMemcpyDeviceToHost, st));
     NFM_HIP_CHECK(hipStreamSynchronize(st));
   }
@@ -697,12 +698,13 @@ int32_t nfm_opt_get_state(nfm_opt* o, double* gsum_P, double* gnorm_P, double* g
   NFM_TRY(use_device(ctx));
   if (!o->state_ready) NFM_TRY(adagrad_reset_state(o));
   const int64_t rows = (int64_t)m->nb * m->da, n_ref = rows * m->k;
+  const int major = m->cfg.kind == NFM_KIND_FFM ? m->nb : 0;  // the state shares the parameters' device layout
   DevBuf tmp;
   NFM_TRY(tmp.alloc(sizeof(double) * std::max<int64_t>(n_ref, 1)));
   for (int which = 0; which < 2; ++which) {
     double* dst = which ? gnorm_P : gsum_P;
     if (!dst || n_ref == 0) continue;
-    NFM_TRY(launch_rows_from_device(ctx, which ? o->N.as<double>() : o->G.as<double>(), tmp.as<double>(), rows, m->k, m->Kp, nullptr));
+    NFM_TRY(launch_rows_from_device(ctx, which ? o->N.as<double>() : o->G.as<double>(), tmp.as<double>(), rows, m->k, m->Kp, nullptr, major));
     NFM_HIP_CHECK(hipMemcpyAsync(dst, tmp.p, sizeof(double) * n_ref, hipMemcpyDeviceToHost, ctx->stream));
     NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   }
@@ -724,16 +726,17 @@ int32_t nfm_opt_set_state(nfm_opt* o, const double* gsum_P, const double* gnorm_
   nfm_ctx* ctx = m->ctx;
   NFM_TRY(use_device(ctx));
   const int64_t rows = (int64_t)m->nb * m->da, n_ref = rows * m->k;
+  const int major = m->cfg.kind == NFM_KIND_FFM ? m->nb : 0;  // the state shares the parameters' device layout
   NFM_CHECK(n_ref == 0 || (gsum_P && gnorm_P), NFM_ERR_INVALID, "null state");
   NFM_CHECK(gsum_w && gnorm_w, NFM_ERR_INVALID, "null state");
   DevBuf tmp;
   NFM_TRY(tmp.alloc(sizeof(double) * std::max<int64_t>(n_ref, 1)));
   if (n_ref > 0) {
     NFM_HIP_CHECK(hipMemcpyAsync(tmp.p, gsum_P, sizeof(double) * n_ref, hipMemcpyHostToDevice, ctx->stream));
-    NFM_TRY(launch_rows_to_device(ctx, tmp.as<double>(), o->G.as<double>(), rows, m->k, m->Kp, 0.0));
+    NFM_TRY(launch_rows_to_device(ctx, tmp.as<double>(), o->G.as<double>(), rows, m->k, m->Kp, 0.0, major));
     NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     NFM_HIP_CHECK(hipMemcpyAsync(tmp.p, gnorm_P, sizeof(double) * n_ref, hipMemcpyHostToDevice, ctx->stream));
-    NFM_TRY(launch_rows_to_device(ctx, tmp.as<double>(), o->N.as<double>(), rows, m->k, m->Kp, o->o.eps));
+    NFM_TRY(launch_rows_to_device(ctx, tmp.as<double>(), o->N.as<double>(), rows, m->k, m->Kp, o->o.eps, major));
     NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   }
   NFM_HIP_CHECK(hipMemcpyAsync(o->Gw.p, gsum_w, sizeof(double) * m->d, hipMemcpyHostToDevice, ctx->stream));

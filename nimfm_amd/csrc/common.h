@@ -42,7 +42,8 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 // ---------------------------------------------------------------------------------------------
 // Device data layout
 //   CSR:    indptr int64[n+1], indices int32[nnz], data f64[nnz], fields int32[nnz]?, y f64[n]?
-//   params: P  f64[nb][da][Kp]   nb = nOrders (FM) | nFields (FFM), da = d + nAug,
+//   params: P  f64[nb][da][Kp]   FM: nb = nOrders, da = d + nAug.  FFM: f64[d][nFields][Kp] (feature-major,
+//                                ModelView::row); the reference's [nFields][d][k] is converted at the C ABI.
 //                                Kp = 2*L >= k, L = lanes per row (power of two); row = Kp*8 bytes,
 //                                16-byte aligned; padding s >= k is kept at exactly 0.
 //           w  f64[d]
@@ -70,6 +71,12 @@ struct ModelView {
   const double* lams;  // [Kp], zero padded
   int64_t d, da;
   int32_t nb, k, Kp, L, degree, n_aug, kind, fit_linear, fit_intercept, task;
+  // parameter row (block b, feature j) starts at (b * bs + j * rs) * Kp.  FM: order-major (bs = da, rs = 1; the
+  // FM kernels index it as such).  FFM: FEATURE-major (bs = 1, rs = nb): the nb field rows of one feature -- what
+  // a sample reads and, in the reference's update, writes together -- are one contiguous run of nb * Kp doubles
+  // instead of nb pieces of Kp * 8 bytes a whole table apart.
+  int64_t bs, rs;
+  __host__ __device__ size_t row(int64_t b, int64_t j) const { return (size_t)(b * bs + j * rs); }
 };
 
 struct LossCfg {
@@ -175,8 +182,9 @@ int launch_fill(nfm_ctx* ctx, double* p, int64_t n, double v);
 // reference FM layout [nb][k][da] <-> device [nb][da][Kp]; FFM reference [nb][da][k] <-> device
 int launch_fm_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int nb, int k, int Kp, int64_t da);
 int launch_fm_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int nb, int k, int Kp, int64_t da, const double* scale_dev);
-int launch_rows_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int64_t rows, int k, int Kp, double pad_value);
-int launch_rows_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int64_t rows, int k, int Kp, const double* scale_dev);
+// nb_major > 0: the reference tensor is [nb_major][rows / nb_major][k], the device tensor feature-major (ModelView::row)
+int launch_rows_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int64_t rows, int k, int Kp, double pad_value, int nb_major = 0);
+int launch_rows_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int64_t rows, int k, int Kp, const double* scale_dev, int nb_major = 0);
 // P *= sc[SC_SCALE_P], w *= sc[SC_SCALE_W] (if fit_linear), scales := 1  (sgd.nim:99-113)
 int launch_rescale(nfm_ctx* ctx, const ModelView& M);
 int launch_sqnorms(nfm_ctx* ctx, const ModelView& M, double* out2_dev /*{P_sq,w_sq}*/);

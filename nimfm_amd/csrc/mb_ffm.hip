@@ -110,14 +110,14 @@ __global__ __launch_bounds__(kBlock) void k_ffm_row_phase(FRowArgs a) {
           const int j2 = X.indices[q0 + q2];
           if (j2 == jq) continue;
           const double x2 = X.data[q0 + q2];
-          const double2 p = load_p(((size_t)fq * M.da + j2) * M.Kp + 2 * l);
+          const double2 p = load_p(M.row(fq, j2) * M.Kp + 2 * l);
           // sgd_ffm.nim:29-30: dA += val1 * val2 * P  (left to right)
           v.x += xq * x2 * p.x;
           v.y += xq * x2 * p.y;
         }
         *reinterpret_cast<double2*>(C + ((size_t)q * F + f) * M.Kp + 2 * l) = v;
         if (v.x != 0.0 || v.y != 0.0) {
-          const double2 pf = load_p(((size_t)f * M.da + jq) * M.Kp + 2 * l);
+          const double2 pf = load_p(M.row(f, jq) * M.Kp + 2 * l);
           part += 0.5 * (pf.x * v.x + pf.y * v.y);
         }
       }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kWave * WPB) void k_ffm_row_phase_lds(FRowArgs a, i
       oo[u] = o < n_out ? o : -1;
       const int q = o < n_out ? o / F : 0, f = o < n_out ? o % F : 0;
       const int jq = __shfl(jt, q, kWave);
-      const size_t e = ((size_t)f * M.da + jq) * Kp + 2 * l;
+      const size_t e = M.row(f, jq) * Kp + 2 * l;
       r0[u] = r1[u] = {0.0, 0.0};
       if (oo[u] >= 0) {
         if (OPT == OPT_SGD || stored) {
@@ -376,7 +376,7 @@ __device__ __forceinline__ double ffm_unit(const FColArgs& a, int64_t j, int f, 
   const int F = M.nb;
   double viol = 0.0;
   const bool do_w = M.fit_linear && f == 0;
-  const size_t e = ((size_t)f * M.da + j) * M.Kp + 2 * l;
+  const size_t e = M.row(f, j) * M.Kp + 2 * l;
   double2 st = {0.0, 0.0}, g2 = {0.0, 0.0}, n2 = {0.0, 0.0}, p = {0.0, 0.0};
   if (MODE != 1) {
     if (OPT == OPT_SGD) {

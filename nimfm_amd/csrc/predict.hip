@@ -82,8 +82,8 @@ __global__ __launch_bounds__(kBlock) void k_ffm_predict(CsrView X, ModelView M, 
         const int j1 = X.indices[q0 + a], j2 = X.indices[q0 + c2];
         if (j1 < j2) {
           const int f1 = X.fields[q0 + a], f2 = X.fields[q0 + c2];
-          const double2 u = ps.load(((size_t)f2 * M.da + j1) * M.Kp + 2 * l);
-          const double2 v = ps.load(((size_t)f1 * M.da + j2) * M.Kp + 2 * l);
+          const double2 u = ps.load(M.row(f2, j1) * M.Kp + 2 * l);
+          const double2 v = ps.load(M.row(f1, j2) * M.Kp + 2 * l);
           acc += (X.data[q0 + a] * X.data[q0 + c2]) * (u.x * v.x + u.y * v.y);
         }
       }

@@ -91,7 +91,7 @@ __global__ void k_sequential(SeqArgs a) {
         for (int blk = 0; blk < nb; ++blk)
           for (int q = 0; q < m_tot; ++q) {
             const int64_t j = STAGE ? jl[q] : (q < m ? X.indices[q0 + q] : X.d + (q - m));
-            const size_t e = ((size_t)blk * M.da + j) * Kp + tid;
+            const size_t e = M.row(blk, j) * Kp + tid;
             const double old = M.P[e];
             const double nw = dev::adagrad_param(O.G[e], O.N[e], O.eta0, tmp);
             viol_acc += fabs(old - nw);
@@ -124,11 +124,11 @@ __global__ void k_sequential(SeqArgs a) {
         for (; q + 4 <= m_tot; q += 4) {  // four independent loads in flight
           double t4[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) t4[u] = M.P[((size_t)blk * M.da + jl[q + u]) * Kp + tid];
+          for (int u = 0; u < 4; ++u) t4[u] = M.P[M.row(blk, jl[q + u]) * Kp + tid];
 #pragma unroll
           for (int u = 0; u < 4; ++u) Pl[((size_t)blk * a.m_cap + q + u) * T + tid] = t4[u];
         }
-        for (; q < m_tot; ++q) Pl[((size_t)blk * a.m_cap + q) * T + tid] = M.P[((size_t)blk * M.da + jl[q]) * Kp + tid];
+        for (; q < m_tot; ++q) Pl[((size_t)blk * a.m_cap + q) * T + tid] = M.P[M.row(blk, jl[q]) * Kp + tid];
       }
     }
 
@@ -210,8 +210,8 @@ __global__ void k_sequential(SeqArgs a) {
             if (j1 < j2) {
               const int f1 = X.fields[q0 + q1], f2 = X.fields[q0 + q2];
               const double v12 = X.data[q0 + q1] * X.data[q0 + q2];
-              const double pa = sP * M.P[((size_t)f2 * M.da + j1) * Kp + tid];
-              const double pb = sP * M.P[((size_t)f1 * M.da + j2) * Kp + tid];
+              const double pa = sP * M.P[M.row(f2, j1) * Kp + tid];
+              const double pb = sP * M.P[M.row(f1, j2) * Kp + tid];
               part += (pa * pb) * v12;
               dA[((size_t)f2 * a.m_cap + q1) * T + tid] += v12 * pb;
               dA[((size_t)f1 * a.m_cap + q2) * T + tid] += v12 * pa;
@@ -238,7 +238,7 @@ __global__ void k_sequential(SeqArgs a) {
         for (int blk = 0; blk < nb; ++blk)
           for (int q = 0; q < m_tot; ++q) {
             const int64_t j = STAGE ? jl[q] : (q < m ? (int64_t)X.indices[q0 + q] : X.d + (q - m));
-            const size_t e = ((size_t)blk * M.da + j) * Kp + tid;
+            const size_t e = M.row(blk, j) * Kp + tid;
             const double p = sP * (STAGE ? Pl[((size_t)blk * a.m_cap + q) * T + tid] : M.P[e]);
             const double update = eta_P * (dL * dA[((size_t)blk * a.m_cap + q) * T + tid] + O.beta * p);
             viol_acc += fabs(update);
@@ -279,7 +279,7 @@ __global__ void k_sequential(SeqArgs a) {
         for (int blk = 0; blk < nb; ++blk)
           for (int q = 0; q < m_tot; ++q) {
             const int64_t j = STAGE ? jl[q] : (q < m ? (int64_t)X.indices[q0 + q] : X.d + (q - m));
-            const size_t e = ((size_t)blk * M.da + j) * Kp + tid;
+            const size_t e = M.row(blk, j) * Kp + tid;
             const double grad = dL * dA[((size_t)blk * a.m_cap + q) * T + tid];
             O.G[e] += grad;
             O.N[e] += grad * grad;

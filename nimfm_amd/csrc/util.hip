@@ -223,35 +223,38 @@ int launch_fm_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, 
 }
 
 // [rows][k] <-> [rows][Kp] (FFM parameters and every AdaGrad state tensor)
+// nb > 0: device row j * nb + b holds reference row b * (rows / nb) + j (feature-major FFM layout, common.h)
 __global__ void k_rows_to_device(const double* __restrict__ src, double* __restrict__ dst, int64_t rows, int k, int Kp,
-                                 double pad) {
-  const int64_t total = rows * Kp;
+                                 double pad, int nb) {
+  const int64_t total = rows * Kp, da = nb > 0 ? rows / nb : 0;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / Kp;
     const int s = (int)(e % Kp);
-    dst[e] = s < k ? src[r * k + s] : pad;
+    const int64_t rr = nb > 0 ? (r % nb) * da + r / nb : r;
+    dst[e] = s < k ? src[rr * k + s] : pad;
   }
 }
-int launch_rows_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int64_t rows, int k, int Kp, double pad) {
+int launch_rows_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int64_t rows, int k, int Kp, double pad, int nb_major) {
   if (rows == 0) return NFM_OK;
-  hipLaunchKernelGGL(k_rows_to_device, dim3(grid_for(rows * Kp)), dim3(kBlock), 0, ctx->stream, src_ref, dst_dev, rows, k, Kp, pad);
+  hipLaunchKernelGGL(k_rows_to_device, dim3(grid_for(rows * Kp)), dim3(kBlock), 0, ctx->stream, src_ref, dst_dev, rows, k, Kp, pad, nb_major);
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }
 __global__ void k_rows_from_device(const double* __restrict__ src, double* __restrict__ dst, int64_t rows, int k, int Kp,
-                                   const double* __restrict__ scale) {
+                                   const double* __restrict__ scale, int nb) {
   const double sc = scale ? *scale : 1.0;
-  const int64_t total = rows * k;
+  const int64_t total = rows * k, da = nb > 0 ? rows / nb : 0;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = e / k;
+    const int64_t r = e / k;  // reference row b * da + j
     const int s = (int)(e % k);
-    dst[e] = src[r * Kp + s] * sc;
+    const int64_t rr = nb > 0 ? (r % da) * nb + r / da : r;
+    dst[e] = src[rr * Kp + s] * sc;
   }
 }
 int launch_rows_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int64_t rows, int k, int Kp,
-                            const double* scale_dev) {
+                            const double* scale_dev, int nb_major) {
   if (rows == 0) return NFM_OK;
-  hipLaunchKernelGGL(k_rows_from_device, dim3(grid_for(rows * k)), dim3(kBlock), 0, ctx->stream, src_dev, dst_ref, rows, k, Kp, scale_dev);
+  hipLaunchKernelGGL(k_rows_from_device, dim3(grid_for(rows * k)), dim3(kBlock), 0, ctx->stream, src_dev, dst_ref, rows, k, Kp, scale_dev, nb_major);
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }
