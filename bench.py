@@ -166,6 +166,8 @@ def psgd_leg(args):
     import nimfm_amd as nf
 
     n, d, m, k = args.n or 90_570, 2_703, 24, 30
+    if args.psgd_shape:  # "d,m,k": other model sizes (the one-launch step holds up to 16384 features)
+        d, m, k = (int(v) for v in args.psgd_shape.split(","))
     dev = torch.device("cuda", 0)
     ctx = nf.Context(0)
     nf.set_default_context(ctx)
@@ -254,6 +256,7 @@ def main():
                     help="AdaGrad without the reference's viol = sum|P_old - P_new| (no stored copy of P is read or "
                          "written; the stopping criterion is then unavailable) -- an information run, not the metric")
     ap.add_argument("--cpu-samples", type=int, default=1_000_000)
+    ap.add_argument("--psgd-shape", default="", help="--workload psgd: d,m,k instead of the ml-100k shape")
     args = ap.parse_args()
 
     if args.workload == "ingest":

@@ -1640,7 +1640,9 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   NFM_TRY(W.Ftab.ensure(sizeof(double) * 2 * kFtab * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.out_acc.ensure(sizeof(double) * 2));
   NFM_TRY(W.itbuf.ensure(sizeof(double)));
-  if (opt_kind == OPT_PSGD) NFM_TRY(W.prox.ensure(sizeof(double) * ((size_t)M.nb * M.da + (size_t)std::max(M.nb, 1) * M.Kp)));
+  // MBPSGD scratch: row norms [nb][da] | per-component pass state 3 x [nb][Kp] + counter | per-workgroup partials [nb][1024][2 Kp]
+  if (opt_kind == OPT_PSGD)
+    NFM_TRY(W.prox.ensure(sizeof(double) * ((size_t)M.nb * M.da + (size_t)std::max(M.nb, 1) * M.Kp * (3 + 2 * 1024) + 8)));
   const void* after[] = {W.Abuf.p, W.rec.p, W.partsA.p, W.partsB.p, W.Dtab.p, W.Stab.p, W.Ftab.p, W.out_acc.p, W.itbuf.p, W.hpart.p, W.prox.p};
   for (size_t q = 0; q < sizeof(before) / sizeof(before[0]); ++q)
     if (before[q] != after[q]) W.drop_graph();

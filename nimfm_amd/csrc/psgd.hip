@@ -122,11 +122,12 @@ __global__ __launch_bounds__(kBlock) void k_psgd_linear(ProxArgs a) {
 
 // threshold of one coupled vector: v(i) = |x[i * stride]|, i < n.  One workgroup, fixed-order sums.
 constexpr int kProxBlock = 1024;
-__device__ __forceinline__ double prox_threshold(const double* __restrict__ x, int64_t n, int64_t stride, double lam) {
+__device__ __forceinline__ double prox_threshold(const double* __restrict__ x, int64_t n, int64_t stride, double lam,
+                                                 double tau0 = 0.0, double cnt0 = -1.0) {
   __shared__ double sS[2][kProxBlock / kWave];
   __shared__ double sC[2][kProxBlock / kWave];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-  double tau = 0.0, cnt_prev = -1.0;
+  double tau = tau0, cnt_prev = cnt0;
   for (int pass = 0;; ++pass) {
     double S = 0.0, c = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += kProxBlock) {
@@ -272,6 +273,131 @@ __global__ __launch_bounds__(kBlock) void k_psgd_rescale_rows(ProxArgs a) {
   *reinterpret_cast<double2*>(M.P + e) = p;
 }
 
+
+// ---- column-wise SquaredL12 for models too large for k_psgd_step_columns: the threshold passes run ROW-parallel ----
+// One workgroup per column walks da values a 256-byte stride apart per pass (637 us per mini-batch at d = 1e5,
+// k = 16).  Here a pass is two launches over the whole matrix with coalesced reads (L lanes per row as everywhere):
+// k_prox_pass_partial leaves per-workgroup sums {S, count} per component, k_prox_pass_combine adds them in workgroup
+// order and advances every component's threshold.  A dependent launch costs ~2 us, so kPasses passes are enqueued
+// blindly; finished components are frozen, a finished matrix makes the remaining launches return at once.  Components
+// still open after kPasses (never observed: the pass count grows with lam, 3 at 1e-6, 10 at 1) are finished by the
+// one-workgroup-per-column loop, so the result never depends on kPasses.
+constexpr int kPasses = 10;
+constexpr int kPassBlocks = 1024;
+
+struct PassArgs {
+  ProxArgs a;
+  double* tau;    // [nb][Kp]
+  double* cntp;   // [nb][Kp] active count of the previous pass
+  int* done;      // [nb][Kp]
+  int* ndone;     // components finished (of nb * Kp)
+  double* partial;  // [nb][G][4][L]
+  int G;
+};
+
+__global__ void k_prox_init(PassArgs p) {
+  const int C = p.a.M.nb * p.a.M.Kp;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    p.tau[c] = 0.0;
+    p.cntp[c] = -1.0;
+    p.done[c] = 0;
+  }
+  if (threadIdx.x == 0) *p.ndone = 0;
+}
+
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_prox_pass_partial(PassArgs p) {
+  constexpr int R = kWave / L;
+  __shared__ double red[4][kBlock];
+  const ModelView& M = p.a.M;
+  if (*p.ndone >= M.nb * M.Kp) return;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L, o = blockIdx.y;
+  const double tx = p.tau[o * M.Kp + 2 * l], ty = p.tau[o * M.Kp + 2 * l + 1];
+  double Sx = 0.0, Sy = 0.0, cx = 0.0, cy = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * R;
+  const double* base = M.P + (size_t)o * M.da * M.Kp + 2 * l;
+  for (int64_t r = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g; r < M.da; r += stride) {
+    const double2 v = *reinterpret_cast<const double2*>(base + (size_t)r * M.Kp);
+    const double ax = fabs(v.x), ay = fabs(v.y);
+    if (ax > tx) { Sx += ax; cx += 1.0; }
+    if (ay > ty) { Sy += ay; cy += 1.0; }
+  }
+  red[0][threadIdx.x] = Sx;
+  red[1][threadIdx.x] = Sy;
+  red[2][threadIdx.x] = cx;
+  red[3][threadIdx.x] = cy;
+  __syncthreads();
+  // thread (c, t), t < L: the workgroup's lane groups hold factor pair t at threads q * L + t, added in q order
+  for (int u = threadIdx.x; u < 4 * L; u += kBlock) {
+    const int c = u / L, t = u % L;
+    double acc = 0.0;
+    for (int q = 0; q < kBlock / L; ++q) acc += red[c][q * L + t];
+    p.partial[(((size_t)o * p.G + blockIdx.x) * 4 + c) * L + t] = acc;
+  }
+}
+
+// workgroup (t, o): factor pair t of order o -- adds the G partial sums in workgroup order (fixed tree)
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_prox_pass_combine(PassArgs p) {
+  __shared__ double red[4][kBlock];
+  const ModelView& M = p.a.M;
+  const OptView& O = p.a.O;
+  if (*p.ndone >= M.nb * M.Kp) return;
+  const int t = blockIdx.x, o = blockIdx.y;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < p.G; b += kBlock)
+    for (int c = 0; c < 4; ++c) acc[c] += p.partial[(((size_t)o * p.G + b) * 4 + c) * L + t];
+  for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = acc[c];
+  __syncthreads();
+  for (int st = kBlock / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st)
+      for (int c = 0; c < 4; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x < 2) {  // component 2t (x) and 2t + 1 (y)
+    const int comp = o * M.Kp + 2 * t + threadIdx.x;
+    if (!p.done[comp]) {
+      const double S = red[threadIdx.x][0], ct = red[2 + threadIdx.x][0];
+      const double lam = psgd_lam(O, dev::get_eta(O.sched, O.eta0, O.power, O.beta, p.a.it0p[0] + p.a.it_b));
+      if (ct == p.cntp[comp] || ct == 0.0) {
+        p.done[comp] = 1;
+        atomicAdd(p.ndone, 1);
+      } else {
+        p.tau[comp] = 2 * lam * (S / (1.0 + 2.0 * lam * ct));
+        p.cntp[comp] = ct;
+      }
+    }
+  }
+}
+
+// components the blind passes left open: the one-workgroup loop, resumed from their state
+__global__ __launch_bounds__(kProxBlock) void k_prox_finish(PassArgs p) {
+  const ModelView& M = p.a.M;
+  const OptView& O = p.a.O;
+  const int s = blockIdx.x, o = blockIdx.y, comp = o * M.Kp + s;
+  if (p.done[comp]) return;
+  const double lam = psgd_lam(O, dev::get_eta(O.sched, O.eta0, O.power, O.beta, p.a.it0p[0] + p.a.it_b));
+  const double tau = prox_threshold(M.P + (size_t)o * M.da * M.Kp + s, M.da, M.Kp, lam, p.tau[comp], p.cntp[comp]);
+  if (threadIdx.x == 0) p.tau[comp] = tau;
+}
+
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_prox_apply(PassArgs p) {
+  constexpr int R = kWave / L;
+  const ModelView& M = p.a.M;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int64_t r = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  if (r >= (int64_t)M.nb * M.da) return;
+  const int o = (int)(r / M.da);
+  const size_t e = (size_t)r * M.Kp + 2 * l;
+  double2 v = *reinterpret_cast<const double2*>(M.P + e);
+  v.x = softthreshold(v.x, p.tau[o * M.Kp + 2 * l]);
+  v.y = softthreshold(v.y, p.tau[o * M.Kp + 2 * l + 1]);
+  *reinterpret_cast<double2*>(M.P + e) = v;
+}
+
 template <int L>
 static void launch_psgd_step_t(nfm_ctx* ctx, const ModelView& M, const OptView& O, MbWork& W, const double* it0p, double it_b) {
   constexpr int R = kWave / L;
@@ -293,7 +419,22 @@ static void launch_psgd_step_t(nfm_ctx* ctx, const ModelView& M, const OptView& 
   if (rows > 0) hipLaunchKernelGGL((k_psgd_dense<L>), dim3(row_blocks), dim3(kBlock), 0, st, pa);
   hipLaunchKernelGGL(k_psgd_linear, dim3((unsigned)((std::max<int64_t>(M.d, 1) + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pa);
   if (rows > 0 && O.reg == NFM_REG_SQUAREDL12 && O.reg_transpose) {
-    hipLaunchKernelGGL(k_psgd_prox_columns, dim3((unsigned)M.k, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    static const bool by_column = getenv("NFM_PROX_COLUMNS") && atoi(getenv("NFM_PROX_COLUMNS")) != 0;  // the old path (tuning)
+    if (by_column) {
+      hipLaunchKernelGGL(k_psgd_prox_columns, dim3((unsigned)M.k, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+      return;
+    }
+    const int C = M.nb * M.Kp;
+    double* sbase = W.prox.as<double>() + (size_t)M.nb * M.da;  // scratch behind the norms: state, then partials
+    const int G = (int)std::min<int64_t>(kPassBlocks, (M.da + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
+    PassArgs ps{pa, sbase, sbase + C, reinterpret_cast<int*>(sbase + 2 * C), reinterpret_cast<int*>(sbase + 3 * C), sbase + 3 * C + 2, G};
+    hipLaunchKernelGGL(k_prox_init, dim3(1), dim3(kBlock), 0, st, ps);
+    for (int pass = 0; pass < kPasses; ++pass) {
+      hipLaunchKernelGGL((k_prox_pass_partial<L>), dim3((unsigned)G, (unsigned)M.nb), dim3(kBlock), 0, st, ps);
+      hipLaunchKernelGGL((k_prox_pass_combine<L>), dim3((unsigned)L, (unsigned)M.nb), dim3(kBlock), 0, st, ps);
+    }
+    hipLaunchKernelGGL(k_prox_finish, dim3((unsigned)M.Kp, (unsigned)M.nb), dim3(kProxBlock), 0, st, ps);
+    hipLaunchKernelGGL((k_prox_apply<L>), dim3(row_blocks), dim3(kBlock), 0, st, ps);
   } else if (rows > 0 && O.reg == NFM_REG_SQUAREDL21) {
     hipLaunchKernelGGL(k_psgd_prox_norms, dim3((unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
     hipLaunchKernelGGL((k_psgd_rescale_rows<L>), dim3(row_blocks), dim3(kBlock), 0, st, pa);

@@ -113,14 +113,17 @@ def test_heavy_features_and_many_rows():
         check(Xo, y, "regression", 2, "explicit", k, P0, w0, 0.0, n_aug, B, 2, reg, gamma=0.01, eta0=0.1)
 
 
-@pytest.mark.parametrize("reg", ["squaredl12", "squaredl21"])
-def test_more_features_than_the_register_resident_step_holds(reg):
-    """d > 16384: the coupled threshold runs its passes over memory (k_psgd_prox_columns / k_psgd_prox_norms)"""
-    n, d, k, B = 64, 20000, 2, 16
+@pytest.mark.parametrize("reg,k,gamma", [("squaredl12", 2, 1e-4), ("squaredl21", 2, 1e-4), ("squaredl12", 5, 1e-2),
+                                         ("squaredl12", 3, 30.0), ("squaredl12", 16, 1.0)])
+def test_more_features_than_the_register_resident_step_holds(reg, k, gamma):
+    """d > 16384: the coupled threshold runs row-parallel passes over memory (k_prox_pass_*; a large gamma needs more
+    passes than are enqueued blindly and ends in k_prox_finish) / k_psgd_prox_norms"""
+    n, d, B = 64, 20000, 16
     Xo = random_csr(n, d, 40, 6)
     y = np.random.default_rng(2).normal(size=n)
     P0, w0, b0, n_aug = init_fm(d, 2, k, "explicit", True, scale=0.3)
-    check(Xo, y, "regression", 2, "explicit", k, P0, w0, 0.0, n_aug, B, 2, reg, gamma=1e-4)
+    fm, P = check(Xo, y, "regression", 2, "explicit", k, P0, w0, 0.0, n_aug, B, 2, reg, gamma=gamma)
+    assert np.array_equal(fm.P == 0.0, P == 0.0)
 
 
 def test_ragged_rows_and_default_batch():
