@@ -5,7 +5,8 @@
  *   decisionFunction, SGD.fit, AdaGrad.fit for FactorizationMachine and
  *   FieldAwareFactorizationMachine, plus the brute-force "slow" models the
  *   reference's own unit tests compare against, plus a CPU restatement of
- *   this repository's deterministic mini-batch rule.
+ *   this repository's deterministic mini-batch rule, plus (nimfm_psgd.c)
+ *   mini-batch proximal SGD, the matrix proximal operators and pgd.predictAllWithGrad.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product path (nimfm_amd/, libnimfm_hip.so) never
