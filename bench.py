@@ -31,6 +31,7 @@ WORKLOADS = {
     "cfg2": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768),
     "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="logistic", batch=8192),
     "cfg3": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="squared", batch=8192),
+    "cfg3l": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="logistic", batch=8192),
     # cfg5: higher-order FM, degree 3 with fitLower=explicit -> two parameter blocks (ANOVA degree 3 and 2)
     "cfg5": dict(n=1_000_000, d=100_000, m=32, k=8, degree=3, solver="sgd", loss="squared", batch=32768),
     # cfg4: field-aware FM, 16 fields, one nnz per field (field f owns the indices [f d/F, (f+1) d/F),
