@@ -188,6 +188,29 @@ def test_predict_all_with_grad(degree, fit_lower, loss, fit_linear, fit_intercep
         assert np.array_equal(fm.P, P0) and fm.intercept == b0  # the parameters are not stepped
 
 
+@pytest.mark.parametrize("d,reg", [(3000, "squaredl12"), (20000, "squaredl12"), (3000, "squaredl21"), (3000, "l21")])
+def test_bitwise_reproducible(d, reg):
+    """no atomics, fixed summation orders, no random pivots: two fits from the same start give the same bits"""
+    n, k, B = 900, 8, 300
+    rng = np.random.default_rng(8)
+    Xo = random_csr(n, 12, 5, 1)
+    idx = Xo.indices.reshape(n, 5).copy()
+    idx[:, 4] = rng.integers(12, d, size=n)
+    Xo = O.Dataset(Xo.indptr, idx.reshape(-1), Xo.data, n, d)
+    y = rng.normal(size=n)
+    P0, w0, b0, n_aug = init_fm(d, 2, k, "explicit", True, scale=0.2)
+    stream = make_stream(n, 3 * n, 4)
+    out = []
+    for _ in range(2):
+        fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, b0)
+        opt = nf.newMBPSGD(maxIter=3, eta0=0.1, gamma=0.01, reg=REGS[reg](), miniBatchSize=B, verbose=0, tol=-1.0)
+        opt.it = 1
+        opt.fit(to_gpu(Xo), y, fm, stream=stream)
+        out.append((fm.P.copy(), fm.w.copy(), fm.intercept))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    assert (out[0][0] != P0).any()
+
+
 def test_errors():
     n, d, k = 20, 6, 2
     Xo, Xd, y = make_fm_dataset(n, d, 3, k, 1, "explicit", threshold=0.3)
