@@ -1,5 +1,5 @@
 """`python -m nimfm_amd train|test ...` -- the reference's end-user commands (`nimfm train`, `nimfm test`,
-/root/reference/src/nimfm.nim:72-134) for the solvers that run on the MI355X path (`--solver sgd|adagrad`):
+/root/reference/src/nimfm.nim:72-134) for the solvers that run on the MI355X path (`--solver sgd|adagrad`, plus `mbpsgd` from `nimfm_sparsefm`):
 svmlight files are parsed on the GPU (ingest.hip), training runs in libnimfm_hip.so, the test score is
 reduced on the device, models are written/read in the reference's text format (`dump`/`load`,
 model/factorization_machine.nim:142-220).  Option names follow the reference's proc parameters (cligen
@@ -45,7 +45,13 @@ def _parser():
     tr.add_argument(*_both("fitIntercept"), dest="fitIntercept", default="true")
     tr.add_argument("--scale", type=float, default=0.1)
     tr.add_argument(*_both("randomState"), dest="randomState", type=int, default=1)
-    tr.add_argument("--solver", default="sgd", help="sgd or adagrad (cd / als stay with the reference)")
+    tr.add_argument("--solver", default="sgd",
+                    help="sgd or adagrad; mbpsgd = the mini-batch proximal solver of the reference's nimfm_sparsefm CLI "
+                         "(src/nimfm_sparsefm.nim:58-63); cd / als stay with the reference")
+    # nimfm_sparsefm train's extra options (src/nimfm_sparsefm.nim:160-170), used by --solver mbpsgd
+    tr.add_argument("--gamma", type=float, default=1e-5)
+    tr.add_argument("--reg", default="squaredl12", help="l1, l21, squaredl12 or squaredl21")
+    tr.add_argument(*_both("miniBatchSize"), dest="miniBatchSize", type=int, default=-1)
     tr.add_argument(*_both("maxIter"), dest="maxIter", type=int, default=100)
     tr.add_argument("--tol", type=float, default=1e-5)
     tr.add_argument("--eta0", type=float, default=0.1)
@@ -101,8 +107,8 @@ def main(argv=None):
         if args.dump:
             fm.dump(args.dump)
         return 0
-    if args.solver not in ("sgd", "adagrad"):
-        raise ValueError("Solver %s is not supported on this path (sgd, adagrad; cd / als stay with the reference)" % args.solver)
+    if args.solver not in ("sgd", "adagrad", "mbpsgd"):
+        raise ValueError("Solver %s is not supported on this path (sgd, adagrad, mbpsgd; cd / als stay with the reference)" % args.solver)
     if args.load:
         fm = nf.load(args.load, True)
     else:
@@ -115,7 +121,15 @@ def main(argv=None):
     common = dict(maxIter=args.maxIter, eta0=args.eta0, alpha0=args.alpha0, alpha=args.alpha, beta=args.beta,
                   loss=args.loss, verbose=args.verbose, tol=args.tol, shuffle=_flag(args.shuffle), mode=args.mode,
                   batch=args.batch, lossParam=args.threshold)
-    if args.solver == "sgd":
+    if args.solver == "mbpsgd":
+        regs = {"l1": nf.newL1, "l21": nf.newL21, "squaredl12": nf.newSquaredL12, "squaredl21": nf.newSquaredL21}
+        if args.reg not in regs:
+            raise ValueError("reg %s is not supported (l1, l21, squaredl12, squaredl21)" % args.reg)
+        opt = nf.newMBPSGD(maxIter=args.maxIter, eta0=args.eta0, alpha0=args.alpha0, alpha=args.alpha, beta=args.beta,
+                           gamma=args.gamma, loss=args.loss, reg=regs[args.reg](), miniBatchSize=args.miniBatchSize,
+                           scheduling=args.scheduling, power=args.power, verbose=args.verbose, tol=args.tol,
+                           shuffle=_flag(args.shuffle), lossParam=args.threshold)
+    elif args.solver == "sgd":
         opt = nf.newSGD(scheduling=args.scheduling, power=args.power, **common)
     else:
         opt = nf.newAdaGrad(**common)

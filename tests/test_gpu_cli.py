@@ -72,6 +72,25 @@ def test_train_dump_test(tmp_path, task, solver):
     assert float(out2.strip().split(": ")[1]) == cli_score
 
 
+def test_train_mbpsgd(tmp_path):
+    """--solver mbpsgd (the reference's nimfm_sparsefm CLI offers it, src/nimfm_sparsefm.nim:58-63): ingest -> fit -> dump"""
+    (train, test), d = make_files(tmp_path, "r")
+    model = str(tmp_path / "sparse.txt")
+    out = run("train", "--task", "r", "--train", train, "--test", test, "--solver", "mbpsgd", "--n-components", "4",
+              "--maxIter", "5", "--eta0", "0.05", "--shuffle", "false", "--dump", model, "--nFeatures", str(d), "--verbose", "1",
+              "--reg", "l1", "--gamma", "1e-3", "--miniBatchSize", "50", "--tol", "-1")
+    assert "Minibatch size: 50" in out and "Number of inner iteration: 6" in out
+    cli_score = float([ln for ln in out.splitlines() if ln.startswith("Test RMSE: ")][0][len("Test RMSE: "):])
+    X, y = nf.loadSVMLightFile(train, d)
+    fm = nf.newFactorizationMachine("regression", nComponents=4, scale=0.1)
+    nf.newMBPSGD(maxIter=5, eta0=0.05, alpha0=1e-7, alpha=1e-5, beta=1e-3, gamma=1e-3, reg=nf.newL1(), miniBatchSize=50,
+                 verbose=0, tol=-1.0, shuffle=False, lossParam=0.1).fit(X, y, fm)
+    Xt, yt = nf.loadSVMLightFile(test, d)
+    assert fm.score(Xt, yt) == cli_score
+    g = nf.load(model, False)
+    assert np.array_equal(g.P, fm.P) and np.array_equal(g.w, fm.w) and g.intercept == fm.intercept
+
+
 def test_unsupported_solver(tmp_path):
     (train, _), d = make_files(tmp_path, "r")
     env = dict(os.environ, PYTHONPATH=ROOT)
