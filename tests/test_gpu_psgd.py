@@ -73,6 +73,26 @@ def test_mbpsgd_vs_oracle(reg, degree, fit_lower):
         assert np.array_equal(fm.P == 0.0, P == 0.0)
 
 
+def test_degree_one_model():
+    """degree = 1: no interaction block at all (nOrders = 0) -- only the linear term and the intercept are stepped"""
+    n, d, B = 90, 12, 16
+    Xo, Xd, y = make_fm_dataset(n, d, 2, 2, 7, "explicit", threshold=0.4)
+    P0 = np.zeros((0, 3, d))
+    w0 = np.random.default_rng(1).normal(size=d) * 0.1
+    inner = (n - 1) // B + 1
+    stream = make_stream(n, B * inner * 2, 2)
+    cfg = O.psgd_cfg(eta0=0.1, reg="l1", alpha=1e-2, alpha0=1e-2)
+    P, w, b, it, losses = run_oracle(Xo, y, 1, P0, w0, 0.2, cfg, stream, B, inner, 2, 0)
+    fm = nf.newFactorizationMachine("regression", degree=1, nComponents=3, warmStart=True)
+    fm.set_params(P0, w0, 0.2)
+    opt = nf.newMBPSGD(maxIter=2, eta0=0.1, alpha=1e-2, alpha0=1e-2, reg=nf.newL1(), miniBatchSize=B, verbose=0, tol=-1.0)
+    opt.it = 1
+    opt.fit(to_gpu(Xo), y, fm, stream=stream)
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close([h[1] for h in opt.history], losses, 1e-10, 1e-13, "loss")
+
+
 @pytest.mark.parametrize("loss,fit_linear,fit_intercept,scheduling", [
     ("logistic", True, True, "constant"), ("squared_hinge", False, True, "invscaling"), ("huber", True, False, "optimal"),
     ("squared", False, False, "constant")])
