@@ -876,9 +876,14 @@ int32_t nfm_opt_predict_all_with_grad(nfm_opt* o, nfm_dataset* ds, double* y_pre
     }
     NFM_HIP_CHECK(hipStreamSynchronize(st));
   }
-  if (grad_P && m->nP() > 0)  // device rows of Kp doubles -> the training layout's rows of k
-    NFM_HIP_CHECK(hipMemcpy2DAsync(grad_P, sizeof(double) * m->cfg.n_components, g.p, sizeof(double) * m->Kp,
-                                   sizeof(double) * m->cfg.n_components, (size_t)m->nb * m->da, hipMemcpyDeviceToHost, st));
+  if (grad_P && m->nP() > 0) {  // device [nb][da][Kp] -> the training layout [nb][da][k]
+    const int64_t rows = (int64_t)m->nb * m->da;
+    DevBuf tmp;
+    NFM_TRY(tmp.alloc(sizeof(double) * rows * m->k));
+    NFM_TRY(launch_rows_from_device(ctx, g.as<double>(), tmp.as<double>(), rows, m->k, m->Kp, nullptr, 0));
+    NFM_HIP_CHECK(hipMemcpyAsync(grad_P, tmp.p, sizeof(double) * rows * m->k, hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+  }
   if (grad_w) NFM_HIP_CHECK(hipMemcpyAsync(grad_w, g.as<char>() + bP, sizeof(double) * m->d, hipMemcpyDeviceToHost, st));
   if (grad_b) NFM_HIP_CHECK(hipMemcpyAsync(grad_b, g.as<char>() + bP + bw, sizeof(double), hipMemcpyDeviceToHost, st));
   NFM_HIP_CHECK(hipStreamSynchronize(st));

@@ -142,18 +142,19 @@ __device__ __forceinline__ double row_forward(const PS& ps, const CsrView& X, co
   double part = 0.0;
   int slot_a = 0;
   for (int o = 0; o < M.nb; ++o) {
-    const size_t blk = (size_t)o * M.da * M.Kp;
+    const size_t blk = M.row(o, 0) * M.Kp;
+    const int rstride = (int)M.rs * M.Kp;
     const int deg = M.degree - o;
     double2 ker;
     if (deg == 2) {
       double2 A1, A2;
-      dev::anova_fwd_deg2<L, SPLIT>(ps, X, q0, m, m_tot, blk, M.Kp, slot, l, A1, A2);
+      dev::anova_fwd_deg2<L, SPLIT>(ps, X, q0, m, m_tot, blk, rstride, slot, l, A1, A2);
       ker.x = (A1.x * A1.x - A2.x) / 2;
       ker.y = (A1.y * A1.y - A2.y) / 2;
       if (valid && slot == 0) *reinterpret_cast<double2*>(Arow + (size_t)slot_a * M.Kp + 2 * l) = A1;
     } else {
       double2 E[dev::kMaxDeg + 1];
-      dev::anova_fwd_degn<L, SPLIT>(ps, X, q0, m, m_tot, blk, M.Kp, slot, l, lane, deg, E);
+      dev::anova_fwd_degn<L, SPLIT>(ps, X, q0, m, m_tot, blk, rstride, slot, l, lane, deg, E);
       ker = dev::pick(E, deg);
       if (valid && slot == 0) {
 #pragma unroll
@@ -487,7 +488,8 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
     auto held_forward_gen = [&](auto ps) {
       int slot_a = 0;
       for (int o = 0; o < M.nb; ++o) {
-        const size_t blk = (size_t)o * M.da * M.Kp;
+        const size_t blk = M.row(o, 0) * M.Kp;
+        const size_t rstride = (size_t)M.rs * M.Kp;
         const int deg = M.degree - o;
         double2 E[dev::kMaxDeg + 1];
 #pragma unroll
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
               xx[u] = dev::shfl_d(xq[r / L], src);
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) pp[u] = ps.load(blk + (size_t)jj[u] * M.Kp + 2 * l);
+            for (int u = 0; u < U; ++u) pp[u] = ps.load(blk + (size_t)jj[u] * rstride + 2 * l);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
               const double tx = xx[u] * pp[u].x, ty = xx[u] * pp[u].y;
@@ -1175,7 +1177,7 @@ __global__ __launch_bounds__(kBlock) void k_heavy_partial(ColArgs a, HeavyArgs h
   for (int o = 0; o < M.nb; ++o) {  // one partial record per (segment, order)
     WAcc wacc;
     const int deg = M.degree - o;
-    col_block<OPT, GEN, 2, L, 1>(a, ((size_t)o * M.da + j) * M.Kp + 2 * l, deg, slot, l, t0, t1, sP, 1.0, 1.0, has_w && o == 0, wacc,
+    col_block<OPT, GEN, 2, L, 1>(a, M.row(o, j) * M.Kp + 2 * l, deg, slot, l, t0, t1, sP, 1.0, 1.0, has_w && o == 0, wacc,
                                  0.0, hv.hpart + ((size_t)(gs - hv.s0) * M.nb + o) * hv.PW + 2 * l, 0, hv.PW);
     slot += deg - 1;
   }
@@ -1215,7 +1217,7 @@ __global__ __launch_bounds__(kBlock) void k_heavy_apply(ColArgs a, HeavyArgs hv)
     for (int o = 0; o < M.nb; ++o) {
       WAcc wo;
       const int deg = M.degree - o;
-      viol += col_block<OPT, GEN, 2, L, 2>(a, ((size_t)o * M.da + j) * M.Kp + 2 * l, deg, slot, l, 0, 0, sP, sPn, fP, has_w && o == 0,
+      viol += col_block<OPT, GEN, 2, L, 2>(a, M.row(o, j) * M.Kp + 2 * l, deg, slot, l, 0, 0, sP, sPn, fP, has_w && o == 0,
                                            wo, (double)c, hv.hpart + ((size_t)(sg0 - hv.s0) * M.nb + o) * hv.PW + 2 * l, nseg,
                                            hv.PW, M.nb * hv.PW);
       if (o == 0) wacc = wo;
@@ -1309,7 +1311,7 @@ __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
     WAcc wacc;
     int slot = 0;
     for (int o = 0; o < M.nb; ++o) {
-      const size_t e = ((size_t)o * M.da + j) * M.Kp + 2 * l;
+      const size_t e = M.row(o, j) * M.Kp + 2 * l;
       const int deg = M.degree - o;
       viol += col_block<OPT, GEN, TU, L, 0>(a, e, deg, slot, l, t0, t1, sP, sPn, fP, has_w && o == 0, wacc);
       slot += deg - 1;

@@ -31,17 +31,18 @@ __global__ __launch_bounds__(kBlock) void k_fm_predict(CsrView X, ModelView M, d
     double part = 0.0;
     for (int q = slot * L + l; q < m; q += LPS) part += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
     for (int o = 0; o < M.nb; ++o) {
-      const size_t blk = (size_t)o * M.da * M.Kp;
+      const size_t blk = M.row(o, 0) * M.Kp;
+      const int rstride = (int)M.rs * M.Kp;  // doubles between consecutive features' rows of this order
       const int deg = M.degree - o;
       double2 ker;
       if (deg == 2) {
         double2 A1, A2;
-        dev::anova_fwd_deg2<L, SPLIT>(ps, X, q0, m, m_tot, blk, M.Kp, slot, l, A1, A2);
+        dev::anova_fwd_deg2<L, SPLIT>(ps, X, q0, m, m_tot, blk, rstride, slot, l, A1, A2);
         ker.x = (A1.x * A1.x - A2.x) / 2.0;
         ker.y = (A1.y * A1.y - A2.y) / 2.0;
       } else {
         double2 E[dev::kMaxDeg + 1];
-        dev::anova_fwd_degn<L, SPLIT>(ps, X, q0, m, m_tot, blk, M.Kp, slot, l, lane, deg, E);
+        dev::anova_fwd_degn<L, SPLIT>(ps, X, q0, m, m_tot, blk, rstride, slot, l, lane, deg, E);
         ker = dev::pick(E, deg);
       }
       if (slot == 0) part += ker.x * lam0 + ker.y * lam1;  // every slot holds the same totals

@@ -144,7 +144,7 @@ __global__ void k_sequential(SeqArgs a) {
         const int deg = M.degree - o;
         double A[kSeqMaxDeg + 1];
         double kv = 0.0;
-        const size_t blk = (size_t)o * M.da * Kp;
+        const size_t blk = M.row(o, 0) * Kp, rstride = (size_t)M.rs * Kp;
         if (act) {
           if (deg != 2) {  // sgd.nim:152-159
             A[0] = 1.0;
@@ -153,7 +153,7 @@ __global__ void k_sequential(SeqArgs a) {
             for (int q = 0; q < m_tot; ++q) {
               const int64_t j = STAGE ? 0 : (q < m ? (int64_t)X.indices[q0 + q] : X.d + (q - m));
               const double val = STAGE ? vl[q] : (q < m ? X.data[q0 + q] : 1.0);
-              const double p = sP * (STAGE ? Pl[((size_t)o * a.m_cap + q) * T + tid] : M.P[blk + (size_t)j * Kp + tid]);
+              const double p = sP * (STAGE ? Pl[((size_t)o * a.m_cap + q) * T + tid] : M.P[blk + (size_t)j * rstride + tid]);
 #pragma unroll
               for (int t = kSeqMaxDeg; t >= 1; --t)
                 if (t <= deg) A[t] += A[t - 1] * p * val;
@@ -167,7 +167,7 @@ __global__ void k_sequential(SeqArgs a) {
             for (int q = 0; q < m_tot; ++q) {
               const int64_t j = STAGE ? 0 : (q < m ? (int64_t)X.indices[q0 + q] : X.d + (q - m));
               const double val = STAGE ? vl[q] : (q < m ? X.data[q0 + q] : 1.0);
-              const double p = sP * (STAGE ? Pl[((size_t)o * a.m_cap + q) * T + tid] : M.P[blk + (size_t)j * Kp + tid]);
+              const double p = sP * (STAGE ? Pl[((size_t)o * a.m_cap + q) * T + tid] : M.P[blk + (size_t)j * rstride + tid]);
               a1 += val * p;
               a2 += (val * p) * (val * p);
             }
@@ -179,7 +179,7 @@ __global__ void k_sequential(SeqArgs a) {
           for (int q = 0; q < m_tot; ++q) {
             const int64_t j = STAGE ? 0 : (q < m ? (int64_t)X.indices[q0 + q] : X.d + (q - m));
             const double val = STAGE ? vl[q] : (q < m ? X.data[q0 + q] : 1.0);
-            const double p = sP * (STAGE ? Pl[((size_t)o * a.m_cap + q) * T + tid] : M.P[blk + (size_t)j * Kp + tid]);
+            const double p = sP * (STAGE ? Pl[((size_t)o * a.m_cap + q) * T + tid] : M.P[blk + (size_t)j * rstride + tid]);
             double d_;
             if (deg != 2) {
               d_ = val;
