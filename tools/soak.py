@@ -25,3 +25,14 @@ for solver in ("sgd", "adagrad"):
     print("%s: 60 shuffled epochs in %.2f s, loss %.4f -> %.4f, accuracy %.4f, device memory delta %.1f MB" % (
         solver, dt, losses[0], losses[-1], fm.score(X, y), (free0 - free1) / 1e6), flush=True)
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+# MBPSGD: shuffled stream with wrap-around, both step paths (d > 16384: row-parallel passes)
+fm = nf.newFactorizationMachine("classification", nComponents=k, randomState=1)
+opt = nf.newMBPSGD(maxIter=20, eta0=0.5, gamma=1e-6, loss="logistic", miniBatchSize=4096, verbose=0, tol=-1.0)
+t0 = time.perf_counter()
+opt.fit(X, y, fm)
+dt = time.perf_counter() - t0
+losses = [h[1] for h in opt.history]
+free1 = torch.cuda.mem_get_info()[0]
+print("mbpsgd: 20 outer iterations (74 mini-batches of 4096 each) in %.2f s, loss %.4f -> %.4f, accuracy %.4f, zeros in P %.1f %%, "
+      "device memory delta %.1f MB" % (dt, losses[0], losses[-1], fm.score(X, y), 100.0 * (fm.P == 0).mean(), (free0 - free1) / 1e6), flush=True)
+assert np.isfinite(losses).all() and losses[-1] < losses[0]
