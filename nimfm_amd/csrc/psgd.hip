@@ -41,6 +41,16 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
   v += dev::shfl_xor_d(v, 32);
   return v;
 }
+constexpr int kProxBlock = 1024;  // threads of the one-workgroup-per-column kernels
+// total of lanes 0..15 (the first DPP row), handed to every lane of the wavefront
+__device__ __forceinline__ double row16_total(double v) {
+  static_assert(kProxBlock / kWave == 16, "one DPP row holds the workgroup's wavefront sums");
+  v += dpp_d<0xB1>(v);
+  v += dpp_d<0x4E>(v);
+  v += dpp_d<0x141>(v);
+  v += dpp_d<0x140>(v);
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 
 struct ProxArgs {
   ModelView M;
@@ -121,7 +131,6 @@ __global__ __launch_bounds__(kBlock) void k_psgd_linear(ProxArgs a) {
 }
 
 // threshold of one coupled vector: v(i) = |x[i * stride]|, i < n.  One workgroup, fixed-order sums.
-constexpr int kProxBlock = 1024;
 __device__ __forceinline__ double prox_threshold(const double* __restrict__ x, int64_t n, int64_t stride, double lam,
                                                  double tau0 = 0.0, double cnt0 = -1.0) {
   __shared__ double sS[2][kProxBlock / kWave];
@@ -148,12 +157,11 @@ __device__ __forceinline__ double prox_threshold(const double* __restrict__ x, i
       bC[wv] = c;
     }
     __syncthreads();
-    double St = 0.0, ct = 0.0;
-#pragma unroll
-    for (int w_ = 0; w_ < kProxBlock / kWave; ++w_) {
-      St += bS[w_];
-      ct += bC[w_];
-    }
+    // lanes 0..15 pick up the 16 wavefronts' sums and add them on DPP (one row of 16 lanes: no LDS-pipe traffic --
+    // every thread reading all 32 values was 256 KB of LDS reads per pass, ~0.85 us); every wavefront runs the same
+    // tree on the same numbers, so all threads hold the same bits
+    const double St = row16_total(lane < kProxBlock / kWave ? bS[lane] : 0.0);
+    const double ct = row16_total(lane < kProxBlock / kWave ? bC[lane] : 0.0);
     if (ct == cnt_prev || ct == 0.0) break;
     tau = 2 * lam * (St / (1.0 + 2.0 * lam * ct));
     cnt_prev = ct;
@@ -225,12 +233,11 @@ __global__ __launch_bounds__(kProxBlock) void k_psgd_step_columns(ProxArgs a) {
       bC[wv] = c;
     }
     __syncthreads();
-    double St = 0.0, ct = 0.0;
-#pragma unroll
-    for (int w_ = 0; w_ < kProxBlock / kWave; ++w_) {
-      St += bS[w_];
-      ct += bC[w_];
-    }
+    // lanes 0..15 pick up the 16 wavefronts' sums and add them on DPP (one row of 16 lanes: no LDS-pipe traffic --
+    // every thread reading all 32 values was 256 KB of LDS reads per pass, ~0.85 us); every wavefront runs the same
+    // tree on the same numbers, so all threads hold the same bits
+    const double St = row16_total(lane < kProxBlock / kWave ? bS[lane] : 0.0);
+    const double ct = row16_total(lane < kProxBlock / kWave ? bC[lane] : 0.0);
     if (ct == cnt_prev || ct == 0.0) break;
     tau = 2 * lam * (St / (1.0 + 2.0 * lam * ct));
     cnt_prev = ct;
