@@ -42,13 +42,16 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
   return v;
 }
 constexpr int kProxBlock = 1024;  // threads of the one-workgroup-per-column kernels
-// total of lanes 0..15 (the first DPP row), handed to every lane of the wavefront
+// total of lanes 0..NW-1 (NW = 4 or 16 lanes of the first DPP row), handed to every lane of the wavefront
+template <int NW = 16>
 __device__ __forceinline__ double row16_total(double v) {
-  static_assert(kProxBlock / kWave == 16, "one DPP row holds the workgroup's wavefront sums");
+  static_assert(NW == 4 || NW == 16, "wavefront sums of a workgroup of 4 or 16 wavefronts");
   v += dpp_d<0xB1>(v);
   v += dpp_d<0x4E>(v);
-  v += dpp_d<0x141>(v);
-  v += dpp_d<0x140>(v);
+  if (NW == 16) {
+    v += dpp_d<0x141>(v);
+    v += dpp_d<0x140>(v);
+  }
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
@@ -138,16 +141,17 @@ __device__ __forceinline__ double prox_threshold(const double* __restrict__ x, i
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   double tau = tau0, cnt_prev = cnt0;
   for (int pass = 0;; ++pass) {
-    double S = 0.0, c = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += kProxBlock) {
-      const double v = fabs(x[i * stride]);
-      if (v > tau) {
-        S += v;
-        c += 1.0;
-      }
+    double S = 0.0;
+    int cw = 0;
+    for (int64_t i0 = 0; i0 < n; i0 += kProxBlock) {  // uniform trip count: the ballot needs every lane
+      const int64_t i = i0 + threadIdx.x;
+      const double v = i < n ? fabs(x[i * stride]) : 0.0;
+      const bool on = i < n && v > tau;
+      cw += __popcll(__ballot(on));
+      if (on) S += v;
     }
     S = wave_sum_dpp(S);
-    c = wave_sum_dpp(c);
+    const double c = (double)cw;
     // one barrier per pass: the per-wavefront sums alternate between two buffers, every thread adds them up in
     // the same fixed order (a writer of pass p + 2 has passed the barrier of pass p + 1, after all reads of pass p)
     double* bS = sS[pass & 1];
@@ -157,9 +161,8 @@ __device__ __forceinline__ double prox_threshold(const double* __restrict__ x, i
       bC[wv] = c;
     }
     __syncthreads();
-    // lanes 0..15 pick up the 16 wavefronts' sums and add them on DPP (one row of 16 lanes: no LDS-pipe traffic --
-    // every thread reading all 32 values was 256 KB of LDS reads per pass, ~0.85 us); every wavefront runs the same
-    // tree on the same numbers, so all threads hold the same bits
+    // lanes 0..15 pick up the 16 wavefronts' sums and add them on DPP (one row of 16 lanes); every wavefront runs
+    // the same tree on the same numbers, so all threads hold the same bits
     const double St = row16_total(lane < kProxBlock / kWave ? bS[lane] : 0.0);
     const double ct = row16_total(lane < kProxBlock / kWave ? bC[lane] : 0.0);
     if (ct == cnt_prev || ct == 0.0) break;
@@ -185,17 +188,17 @@ __global__ __launch_bounds__(kProxBlock) void k_psgd_prox_columns(ProxArgs a) {
 // of Params.step itself (the padding components s >= k are zero and need none), runs the threshold passes on
 // the registers -- a pass is one workgroup reduction, no memory traffic -- and writes the column once.  The
 // workgroups s >= k of order 0 shrink the linear term and the intercept (k_psgd_linear's work).
-template <int VPT>
-__global__ __launch_bounds__(kProxBlock) void k_psgd_step_columns(ProxArgs a) {
-  __shared__ double sS[2][kProxBlock / kWave];
-  __shared__ double sC[2][kProxBlock / kWave];
+template <int VPT, int TB>
+__global__ __launch_bounds__(TB) void k_psgd_step_columns(ProxArgs a) {
+  __shared__ double sS[2][TB / kWave];
+  __shared__ double sC[2][TB / kWave];
   const ModelView& M = a.M;
   const OptView& O = a.O;
   const int s = blockIdx.x, o = blockIdx.y;
   const double it = a.it0p[0] + a.it_b;
   if (s >= M.k) {
     if (o != 0) return;
-    const int64_t j = (int64_t)(s - M.k) * kProxBlock + threadIdx.x;
+    const int64_t j = (int64_t)(s - M.k) * TB + threadIdx.x;
     if (M.fit_linear && j < M.d) M.w[j] *= 1.0 / (1.0 + dev::get_eta(O.sched, O.eta0, O.power, O.alpha, it) * O.alpha);
     if (M.fit_intercept && j == 0)
       M.sc[SC_INTERCEPT] *= 1.0 / (1.0 + dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, it) * O.alpha0);
@@ -208,22 +211,22 @@ __global__ __launch_bounds__(kProxBlock) void k_psgd_step_columns(ProxArgs a) {
   double v[VPT];
 #pragma unroll
   for (int q = 0; q < VPT; ++q) {
-    const int64_t j = (int64_t)q * kProxBlock + threadIdx.x;
+    const int64_t j = (int64_t)q * TB + threadIdx.x;
     v[q] = j < M.da ? col[j * M.Kp] * invP : 0.0;
   }
   double tau = 0.0, cnt_prev = -1.0;
   for (int pass = 0;; ++pass) {
-    double S = 0.0, c = 0.0;
+    double S = 0.0;
+    int cw = 0;  // the wavefront's active count comes from ballots: no second reduction tree
 #pragma unroll
     for (int q = 0; q < VPT; ++q) {
       const double av = fabs(v[q]);
-      if (av > tau) {
-        S += av;
-        c += 1.0;
-      }
+      const bool on = av > tau;
+      cw += __popcll(__ballot(on));
+      if (on) S += av;
     }
     S = wave_sum_dpp(S);
-    c = wave_sum_dpp(c);
+    const double c = (double)cw;
     // one barrier per pass: the per-wavefront sums alternate between two buffers, every thread adds them up in
     // the same fixed order (a writer of pass p + 2 has passed the barrier of pass p + 1, after all reads of pass p)
     double* bS = sS[pass & 1];
@@ -233,18 +236,17 @@ __global__ __launch_bounds__(kProxBlock) void k_psgd_step_columns(ProxArgs a) {
       bC[wv] = c;
     }
     __syncthreads();
-    // lanes 0..15 pick up the 16 wavefronts' sums and add them on DPP (one row of 16 lanes: no LDS-pipe traffic --
-    // every thread reading all 32 values was 256 KB of LDS reads per pass, ~0.85 us); every wavefront runs the same
-    // tree on the same numbers, so all threads hold the same bits
-    const double St = row16_total(lane < kProxBlock / kWave ? bS[lane] : 0.0);
-    const double ct = row16_total(lane < kProxBlock / kWave ? bC[lane] : 0.0);
+    // lanes 0..15 pick up the 16 wavefronts' sums and add them on DPP (one row of 16 lanes); every wavefront runs
+    // the same tree on the same numbers, so all threads hold the same bits
+    const double St = row16_total<TB / kWave>(lane < TB / kWave ? bS[lane] : 0.0);
+    const double ct = row16_total<TB / kWave>(lane < TB / kWave ? bC[lane] : 0.0);
     if (ct == cnt_prev || ct == 0.0) break;
     tau = 2 * lam * (St / (1.0 + 2.0 * lam * ct));
     cnt_prev = ct;
   }
 #pragma unroll
   for (int q = 0; q < VPT; ++q) {
-    const int64_t j = (int64_t)q * kProxBlock + threadIdx.x;
+    const int64_t j = (int64_t)q * TB + threadIdx.x;
     if (j < M.da) col[j * M.Kp] = softthreshold(v[q], tau);
   }
 }
@@ -414,13 +416,19 @@ static void launch_psgd_step_t(nfm_ctx* ctx, const ModelView& M, const OptView& 
   const unsigned row_blocks = (unsigned)((rows + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
   TimedLaunch tl(ctx, "psgd_step");
   if (rows > 0 && O.reg == NFM_REG_SQUAREDL12 && O.reg_transpose && M.da <= 16 * kProxBlock) {  // the one-launch step
-    const unsigned gx = (unsigned)(M.k + (std::max<int64_t>(M.d, 1) + kProxBlock - 1) / kProxBlock);
-    const int vpt = (int)((M.da + kProxBlock - 1) / kProxBlock);
-    if (vpt <= 1) hipLaunchKernelGGL((k_psgd_step_columns<1>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
-    else if (vpt <= 2) hipLaunchKernelGGL((k_psgd_step_columns<2>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
-    else if (vpt <= 4) hipLaunchKernelGGL((k_psgd_step_columns<4>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
-    else if (vpt <= 8) hipLaunchKernelGGL((k_psgd_step_columns<8>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
-    else hipLaunchKernelGGL((k_psgd_step_columns<16>), dim3(gx, (unsigned)M.nb), dim3(kProxBlock), 0, st, pa);
+    // 1024 threads per column: 256 threads with four times the values per thread measured 15.2 vs 13.8 us (the
+    // strided column loads and stores want the memory parallelism)
+    constexpr int tb = kProxBlock;
+    const unsigned gx = (unsigned)(M.k + (std::max<int64_t>(M.d, 1) + tb - 1) / tb);
+    const int vpt = (int)((M.da + tb - 1) / tb);
+    const dim3 grid(gx, (unsigned)M.nb);
+#define NFM_STEP(V, T) hipLaunchKernelGGL((k_psgd_step_columns<V, T>), grid, dim3(T), 0, st, pa)
+    if (vpt <= 1) NFM_STEP(1, 1024);
+    else if (vpt <= 2) NFM_STEP(2, 1024);
+    else if (vpt <= 4) NFM_STEP(4, 1024);
+    else if (vpt <= 8) NFM_STEP(8, 1024);
+    else NFM_STEP(16, 1024);
+#undef NFM_STEP
     return;
   }
   if (rows > 0) hipLaunchKernelGGL((k_psgd_dense<L>), dim3(row_blocks), dim3(kBlock), 0, st, pa);
