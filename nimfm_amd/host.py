@@ -635,12 +635,17 @@ class _OptimizerBase:
 
     def _handle(self, fm, ctx, mode):
         mh = fm._push(ctx)
-        if self._h is None or self._model is not fm or self._mode_built != (mode, self.batch) or self._mh != mh.value:
+        key = (mode, self.batch) + self._cfg_key()  # a changed hyper-parameter needs a new device optimizer
+        if self._h is None or self._model is not fm or self._mode_built != key or self._mh != mh.value:
             self._release()
             self._h = C.c_void_p()
             self._create(mh, mode)
-            self._model, self._mode_built, self._mh = fm, (mode, self.batch), mh.value
+            self._model, self._mode_built, self._mh = fm, key, mh.value
         return self._h
+
+    def _cfg_key(self):
+        """what _create bakes into the device optimizer (the common part; subclasses extend it)"""
+        return (self.alpha0, self.alpha, self.beta, self.loss, self.lossParam)
 
     def _epoch(self, X, perm, begin, end):
         ls, vs = C.c_double(0.0), C.c_double(0.0)
@@ -751,6 +756,9 @@ class SGD(_OptimizerBase):
                           capi.LOSS[self.loss], capi.SCHED[self.scheduling], capi.MODE[mode], 0, self.batch)
         capi.check(capi.lib().nfm_sgd_create(mh, C.byref(cfg), C.byref(self._h)))
 
+    def _cfg_key(self):
+        return super()._cfg_key() + (self.eta0, self.scheduling, self.power)
+
     def _per_epoch_callback(self, callback):
         return callback is not None and (self.nCalls <= 0 or self.mode != "sequential")  # sgd.nim:312
 
@@ -766,6 +774,9 @@ class AdaGrad(_OptimizerBase):
         cfg = capi.AdaGradCfg(self.eta0, self.alpha0, self.alpha, self.beta, self.eps, self.lossParam,
                               capi.LOSS[self.loss], capi.MODE[mode], int(self.trackViol), 0, self.batch)
         capi.check(capi.lib().nfm_adagrad_create(mh, C.byref(cfg), C.byref(self._h)))
+
+    def _cfg_key(self):
+        return super()._cfg_key() + (self.eta0, self.eps, self.trackViol)
 
     def _per_epoch_callback(self, callback):
         return callback is not None  # adagrad.nim:188-191
@@ -882,6 +893,9 @@ class MBPSGD(_OptimizerBase):
                              capi.LOSS[self.loss], capi.SCHED[self.scheduling], capi.REG[self.reg.name],
                              int(self.reg.transpose), self.batch)
         capi.check(capi.lib().nfm_mbpsgd_create(mh, C.byref(cfg), C.byref(self._h)))
+
+    def _cfg_key(self):
+        return super()._cfg_key() + (self.eta0, self.gamma, self.scheduling, self.power, self.reg.name, self.reg.transpose)
 
     def fit(self, X, y, sfm, callback=None, stream=None):
         """stream (optional): the sample indices in the order the inner loops consume them, at least

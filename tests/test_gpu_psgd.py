@@ -231,6 +231,25 @@ def test_bitwise_reproducible(d, reg):
     assert (out[0][0] != P0).any()
 
 
+def test_changed_hyperparameters_rebuild_the_device_optimizer():
+    """the same MBPSGD object fitted with another gamma / regulariser must not reuse the cached device handle"""
+    n, d, k, B = 64, 10, 3, 16
+    Xo, Xd, y = make_fm_dataset(n, d, 2, k, 3, "explicit", threshold=0.3)
+    P0, w0, b0, n_aug = init_fm(d, 2, k, "explicit", True, scale=0.3)
+    stream = make_stream(n, 2 * n, 1)
+    opt = nf.newMBPSGD(maxIter=2, eta0=0.2, gamma=1e-3, reg=nf.newL1(), miniBatchSize=B, verbose=0, tol=-1.0)
+    got = []
+    for gamma, reg in ((1e-3, nf.newL1()), (0.5, nf.newL1()), (0.5, nf.newL21())):
+        opt.gamma, opt.reg, opt.it = gamma, reg, 1
+        fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, b0)
+        opt.fit(to_gpu(Xo), y, fm, stream=stream)
+        cfg = O.psgd_cfg(eta0=0.2, gamma=gamma, reg=reg.name)
+        P, w, b, it, _ = run_oracle(Xo, y, 2, P0, w0, b0, cfg, stream, B, 4, 2, n_aug)
+        assert_close(fm.P, P, RTOL, ATOL, "P gamma=%g %s" % (gamma, reg.name))
+        got.append(fm.P.copy())
+    assert not np.array_equal(got[0], got[1]) and not np.array_equal(got[1], got[2])
+
+
 def test_errors():
     n, d, k = 20, 6, 2
     Xo, Xd, y = make_fm_dataset(n, d, 3, k, 1, "explicit", threshold=0.3)
