@@ -504,6 +504,7 @@ def main():
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()  # rank 0 ran the predict / roofline legs after the timed region: leave together
         dist.destroy_process_group()
 
 
