@@ -395,4 +395,29 @@ class MBPSGD {
   nfm_opt* o_ = nullptr; nfm_model* m_ = nullptr; int64_t B_ = -1;
 };
 
+// predictAllWithGrad, optimizer/pgd.nim:70-103: yPred, dL and the gradient of the mean loss at sfm's parameters;
+// gradP in the reference's training layout [nOrders][d + nAugments][k]
+struct Grads { std::vector<double> P, w; double intercept = 0.0, loss = 0.0; };
+template <class L = Squared>
+inline Grads predictAllWithGrad(const CSRDataset& X, const std::vector<double>& y, FactorizationMachine& sfm,
+                                std::vector<double>& yPred, std::vector<double>& dL, L loss = L()) {
+  if (!sfm.isInitialized) throw NotFittedError("Factorization machines is not fitted.");
+  if ((int64_t)y.size() != X.nSamples()) throw std::invalid_argument("len(y) != nSamples");
+  check(nfm_dataset_set_targets(X.handle(), y.data()));
+  nfm_model* m = sfm.push();
+  nfm_mbpsgd_cfg c{0.1, 1e-6, 1e-3, 1e-4, 1e-4, 1.0, loss.param, L::id, (int32_t)optimal, NFM_REG_L1, 0, 1};
+  nfm_opt* o = nullptr;
+  check(nfm_mbpsgd_create(m, &c, &o));
+  Grads g;
+  g.P.assign(sfm.P.size(), 0.0);
+  g.w.assign((size_t)X.nFeatures(), 0.0);
+  yPred.assign((size_t)X.nSamples(), 0.0);
+  dL.assign((size_t)X.nSamples(), 0.0);
+  const int32_t rc = nfm_opt_predict_all_with_grad(o, X.handle(), yPred.data(), dL.data(), g.P.data(), g.w.data(), &g.intercept, &g.loss);
+  nfm_opt_destroy(o);
+  check(rc);
+  g.loss /= (double)std::max<int64_t>(X.nSamples(), 1);
+  return g;
+}
+
 }  // namespace nimfm

@@ -103,6 +103,23 @@ int main() {
     try { refuse.fit(X, y, cubic); } catch (const std::invalid_argument&) { threw = true; }
     CHECK(threw);
   }
+  {  // predictAllWithGrad (optimizer/pgd.nim:70-103): yPred is decisionFunction, the intercept's gradient is mean(dL)
+    FactorizationMachine fm(regression, 2, k);
+    fm.init(X);
+    std::vector<double> yp, dl;
+    Grads g = predictAllWithGrad(X, y, fm, yp, dl);
+    const std::vector<double> ref = fm.decisionFunction(X);
+    double mean_dl = 0.0, mean_loss = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+      CHECK(std::fabs(yp[i] - ref[i]) < 1e-12);
+      CHECK(std::fabs(dl[i] - (yp[i] - y[i])) < 1e-12);  // Squared.dloss = p - y (loss.nim:21)
+      mean_dl += dl[i];
+      mean_loss += 0.5 * (y[i] - yp[i]) * (y[i] - yp[i]);
+    }
+    CHECK(std::fabs(g.intercept - mean_dl / n) < 1e-12);
+    CHECK(std::fabs(g.loss - mean_loss / n) < 1e-10);
+    CHECK(g.P.size() == fm.P.size() && g.w.size() == (size_t)d);
+  }
   {  // loader: dump a small svmlight file (1-based, dumpSVMLightFile's layout), load it on the GPU, same scores
     const char* path = "/tmp/nimfm_host_mirror_test.svm";
     FILE* f = std::fopen(path, "w");
