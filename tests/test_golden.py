@@ -74,3 +74,43 @@ def test_gpu_ffm_vs_golden():
         opt.fit(X, y, ffm)
         assert_close(ffm.P, G["ffm_%s_P" % key]); assert_close(ffm.w, G["ffm_%s_w" % key])
         assert abs(ffm.intercept - G["ffm_%s_b" % key]) < 1e-7
+
+
+# ---- mini-batch proximal SGD (tests/golden/psgd_golden.npz, provenance in tests/golden/make_psgd_golden.py: a dense
+# numpy statement of minibatch_psgd.nim with sort-based proximal operators) ----
+GP = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "psgd_golden.npz"))
+PSGD_REGS = ["l1", "l21", "squaredl12", "squaredl21"]
+
+
+@pytest.mark.parametrize("reg", PSGD_REGS)
+def test_oracle_psgd_vs_golden(reg):
+    Xd, y, P0, w0, stream = GP["X"], GP["y"], GP["P0"], GP["w0"], GP["stream"]
+    eta0, alpha0, alpha, beta, gamma = GP["hyper"]
+    B, outer = int(GP["batch"]), int(GP["outer"])
+    Xo = O.Dataset.from_dense(Xd)
+    cfg = O.psgd_cfg(eta0=eta0, alpha0=alpha0, alpha=alpha, beta=beta, gamma=gamma, reg=reg)
+    P, w, b, it = P0.copy(), w0.copy(), float(GP["b0"]), 1
+    need = len(stream) // outer
+    for t in range(outer):
+        b, it, ls = O.fm_mbpsgd_epoch(Xo, y, 2, P, w, b, cfg, stream[t * need:(t + 1) * need], B, 0, it=it)
+        assert abs(ls / need - GP[reg + "_loss"][t]) < 1e-9
+    assert_close(P, GP[reg + "_P"]); assert_close(w, GP[reg + "_w"]); assert abs(b - GP[reg + "_b"]) < 1e-9
+    assert np.array_equal(P == 0.0, GP[reg + "_P"] == 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reg", PSGD_REGS)
+def test_gpu_psgd_vs_golden(reg):
+    import nimfm_amd as nf
+    from gpu_common import gpu_fm, to_gpu
+    Xd, y, P0, w0, stream = GP["X"], GP["y"], GP["P0"], GP["w0"], GP["stream"]
+    eta0, alpha0, alpha, beta, gamma = GP["hyper"]
+    regs = {"l1": nf.newL1, "l21": nf.newL21, "squaredl12": nf.newSquaredL12, "squaredl21": nf.newSquaredL21}
+    fm = gpu_fm("regression", 2, P0.shape[1], "explicit", True, True, P0, w0, float(GP["b0"]))
+    opt = nf.newMBPSGD(maxIter=int(GP["outer"]), eta0=eta0, alpha0=alpha0, alpha=alpha, beta=beta, gamma=gamma,
+                       reg=regs[reg](), miniBatchSize=int(GP["batch"]), verbose=0, tol=-1.0)
+    opt.it = 1
+    opt.fit(to_gpu(O.Dataset.from_dense(Xd)), y, fm, stream=stream)
+    assert_close(fm.P, GP[reg + "_P"]); assert_close(fm.w, GP[reg + "_w"]); assert abs(fm.intercept - GP[reg + "_b"]) < 1e-9
+    assert_close([h[1] for h in opt.history], GP[reg + "_loss"], 1e-9, 1e-12)
+    assert np.array_equal(fm.P == 0.0, GP[reg + "_P"] == 0.0)
