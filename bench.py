@@ -213,9 +213,10 @@ def psgd_leg(args):
     ctx.timing_enable(False)
     da = d
     Kp = 2 * max(1, 1 << (((k + 1) // 2) - 1).bit_length())
-    dense_bytes = 16 * da * Kp + (16 * da * Kp)  # scale pass + column prox pass, read + write each
+    dense_bytes = 16 * da * Kp  # every parameter read and written once per mini-batch (shrink + prox)
     step_ms = fam["psgd_step"][1] / max(fam["psgd_step"][0], 1)
-    roof = {"bound": "hbm", "kernel": "psgd_step (k_psgd_dense + k_psgd_linear + k_psgd_prox_columns): all parameters, once per mini-batch",
+    roof = {"bound": "hbm", "kernel": "psgd_step: k_psgd_step_columns (one launch, models of <= 16384 features) or k_psgd_dense + k_prox_pass_* -- "
+                      "all parameters, once per mini-batch",
             "achieved": round(dense_bytes / (step_ms * 1e-3) / 1e9, 2) if step_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(dense_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if step_ms else None, "traffic": None,
             "algorithmic_bytes_per_minibatch": dense_bytes,
