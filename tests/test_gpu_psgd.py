@@ -264,3 +264,45 @@ def test_errors():
     fm2 = nf.newFactorizationMachine("regression", nComponents=k)
     with pytest.raises(ValueError, match="stream holds fewer"):
         nf.newMBPSGD(verbose=0, maxIter=3, miniBatchSize=8).fit(to_gpu(Xo), y, fm2, stream=np.arange(10))
+
+
+def test_abi_error_paths():
+    """the C entry points themselves (nimfm_hip.h): bad regulariser id, batch < 1, a stream that is not a whole number of
+    mini-batches, predictAllWithGrad on an SGD optimizer"""
+    import ctypes as C
+
+    from nimfm_amd import _capi as capi
+
+    n, d, k = 20, 6, 2
+    Xo, Xd, y = make_fm_dataset(n, d, 2, k, 1, "explicit", threshold=0.3)
+    X = to_gpu(Xo)
+    X.set_targets(y)
+    fm = nf.newFactorizationMachine("regression", nComponents=k)
+    fm.init(X)
+    mh = fm._push(X.ctx)
+    L = capi.lib()
+
+    def create(reg=0, batch=4, transpose=0):
+        h = C.c_void_p()
+        cfg = capi.MBPSGDCfg(0.1, 1e-6, 1e-3, 1e-4, 1e-4, 1.0, 1.0, 0, 1, reg, transpose, batch)
+        return L.nfm_mbpsgd_create(mh, C.byref(cfg), C.byref(h)), h
+
+    assert create(reg=7)[0] == capi.ERR_INVALID
+    assert create(batch=0)[0] == capi.ERR_INVALID
+    assert create(reg=capi.REG["squaredl21"], transpose=1)[0] != 0
+    rc, h = create()
+    assert rc == 0
+    ls, vs = C.c_double(), C.c_double()
+    perm = np.arange(10, dtype=np.int64)
+    assert L.nfm_opt_epoch(h, X.h, perm.ctypes.data_as(C.c_void_p), 0, 10, C.byref(ls), C.byref(vs)) == capi.ERR_INVALID  # 10 % 4
+    assert b"whole number of mini-batches" in L.nfm_last_error()
+    assert L.nfm_opt_epoch(h, X.h, None, 0, 40, C.byref(ls), C.byref(vs)) == capi.ERR_INVALID  # past the data without a stream
+    assert L.nfm_opt_epoch(h, X.h, perm.ctypes.data_as(C.c_void_p), 0, 8, C.byref(ls), C.byref(vs)) == 0
+    it = C.c_int64()
+    L.nfm_opt_get_it(h, C.byref(it))
+    assert it.value == 3  # two mini-batches
+    L.nfm_opt_destroy(h)
+    sgd = nf.newSGD(verbose=0)
+    sgd._handle(fm, X.ctx, "sequential")
+    gb = C.c_double()
+    assert L.nfm_opt_predict_all_with_grad(sgd._h, X.h, None, None, None, None, C.byref(gb), None) == capi.ERR_INVALID
