@@ -146,6 +146,17 @@ def test_more_features_than_the_register_resident_step_holds(reg, k, gamma):
     assert np.array_equal(fm.P == 0.0, P == 0.0)
 
 
+@pytest.mark.parametrize("degree,fit_lower", [(3, "augment"), (2, "augment"), (4, "explicit")])
+def test_dummy_features_through_the_segment_path(degree, fit_lower):
+    """fitLower = augment: the dummy features are touched by every sample of a mini-batch of 300 (> 128 touches: the
+    column phase's segment path, for models with several orders too)"""
+    n, d, k, B = 600, 30, 4, 300
+    Xo, Xd, y = make_fm_dataset(n, d, degree, k, 9, fit_lower, threshold=0.7)
+    P0, w0, b0, n_aug = init_fm(d, degree, k, fit_lower, True, scale=0.2)
+    check(Xo, y, "regression", degree, fit_lower, k, P0, w0, 0.05, n_aug, B, 2, "l1", gamma=1e-3, eta0=0.05)
+    check(Xo, y, "regression", degree, fit_lower, k, P0, w0, 0.05, n_aug, B, 2, "l21", gamma=1e-3, eta0=0.05)
+
+
 def test_ragged_rows_and_default_batch():
     """empty rows, rows longer than a wavefront; miniBatchSize / maxIterInner defaults (minibatch_psgd.nim:160-167)"""
     n, d, k = 150, 300, 4
