@@ -21,7 +21,14 @@ def means(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             name = r["Kernel_Name"]
-            key = "row_phase" if "k_row_phase" in name else "col_phase" if "k_col_phase" in name else None
+            key = None
+            for pat, k_ in (("k_row_phase", "row_phase"), ("k_ffm_row_phase", "row_phase"), ("k_col_phase", "col_phase"),
+                            ("k_ffm_col_phase", "col_phase"), ("k_heavy_partial", "heavy_partial"), ("k_heavy_apply", "heavy_apply"),
+                            ("k_ffm_heavy_partial", "heavy_partial"), ("k_ffm_heavy_apply", "heavy_apply"),
+                            ("k_singles", "singles"), ("k_psgd_", "psgd_step"), ("k_prox_", "psgd_step")):
+                if pat in name:
+                    key = k_
+                    break
             if key:
                 acc[key].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
@@ -31,9 +38,12 @@ def main():
     fetch_csv, write_csv, workload, batch, tag = sys.argv[1:6]
     f, nf = means(fetch_csv, "FETCH_SIZE")
     w, nw = means(write_csv, "WRITE_SIZE")
-    per_kernel = {k: {"FETCH_SIZE_KiB_raw": f[k], "FETCH_bytes_corrected": 2 * f[k] * 1024, "WRITE_SIZE_KiB": w[k],
-                      "WRITE_bytes": w[k] * 1024, "launches_sampled": nf[k]} for k in f}
-    total = sum(v["FETCH_bytes_corrected"] + v["WRITE_bytes"] for v in per_kernel.values())
+    per_kernel = {k: {"FETCH_SIZE_KiB_raw": f[k], "FETCH_bytes_corrected": 2 * f[k] * 1024, "WRITE_SIZE_KiB": w.get(k, 0.0),
+                      "WRITE_bytes": w.get(k, 0.0) * 1024, "launches_sampled": nf[k]} for k in f}
+    # one mini-batch = one launch of the row and of the column phase; the heavy kernels run once per batch that has
+    # heavy features -- weight every family by its launches relative to the row phase
+    base = max(nf.get("row_phase", 1), 1)
+    total = sum((v["FETCH_bytes_corrected"] + v["WRITE_bytes"]) * nf[k] / base for k, v in per_kernel.items())
     out = {"workload": workload, "batch": int(batch), "per_kernel": per_kernel, "hbm_bytes_per_minibatch": total,
            "note": "FETCH_SIZE doubled (gfx950, 16 B/lane reads), WRITE_SIZE exact; separate --pmc passes"}
     path = "profiles/%s_pmc_traffic.json" % tag
