@@ -73,3 +73,13 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), os.path.join(dirpath, f)
                 assert "nimfm_oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_library_resolves_every_symbol_eagerly():
+    """dlopen with RTLD_NOW: a kernel's host stub left undefined by a split translation unit shows up here, on CPU"""
+    import ctypes
+
+    from nimfm_amd import _capi as capi
+
+    path = os.environ.get("NIMFM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(capi.__file__)), "lib", "libnimfm_hip.so")
+    ctypes.CDLL(path, mode=os.RTLD_NOW)
