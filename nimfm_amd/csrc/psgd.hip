@@ -444,7 +444,11 @@ static void launch_psgd_step_t(nfm_ctx* ctx, const ModelView& M, const OptView& 
     const int G = (int)std::min<int64_t>(kPassBlocks, (M.da + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
     PassArgs ps{pa, sbase, sbase + C, reinterpret_cast<int*>(sbase + 2 * C), reinterpret_cast<int*>(sbase + 3 * C), sbase + 3 * C + 2, G};
     hipLaunchKernelGGL(k_prox_init, dim3(1), dim3(kBlock), 0, st, ps);
-    for (int pass = 0; pass < kPasses; ++pass) {
+    // passes grow with lam (3 at 1e-6, 4 at 1e-4, 8 at 1e-2, 10 at 1 on N(0, 0.01) columns): enqueue what the largest
+    // lam of the schedule needs (eta <= eta0 except for pegasos); k_prox_finish covers any shortfall
+    const double lam_max = O.gamma * O.eta0 / (1.0 + O.eta0 * O.beta);
+    const int passes = O.sched == NFM_SCHED_PEGASOS ? kPasses : (lam_max < 1e-5 ? 4 : (lam_max < 1e-3 ? 6 : kPasses));
+    for (int pass = 0; pass < passes; ++pass) {
       hipLaunchKernelGGL((k_prox_pass_partial<L>), dim3((unsigned)G, (unsigned)M.nb), dim3(kBlock), 0, st, ps);
       hipLaunchKernelGGL((k_prox_pass_combine<L>), dim3((unsigned)L, (unsigned)M.nb), dim3(kBlock), 0, st, ps);
     }
