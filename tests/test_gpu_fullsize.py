@@ -60,6 +60,28 @@ def test_cfg2_fullsize_vs_mb_oracle(problem):
     assert sgd.history[1][1] < sgd.history[0][1] < np.log(2.0)  # the loss goes down
 
 
+def test_cfg2_fullsize_mbpsgd_vs_oracle(problem):
+    """SURVEY 8(f) rank 3 at cfg2's size: one outer iteration of MBPSGD (default mini-batch d n / nnz = 3125 -> 320
+    mini-batches, SquaredL12: the row-parallel threshold passes, d > 16384) against the C restatement"""
+    Xo, X, y, P0, w0 = problem
+    Bp = (D * N) // (N * M)
+    inner = (N - 1) // Bp + 1
+    stream = np.concatenate([np.arange(N, dtype=np.int64), np.arange(Bp * inner - N, dtype=np.int64)])
+    cfg = O.psgd_cfg(eta0=0.5, gamma=1e-4, loss="logistic")
+    P, w = P0.copy(), w0.copy()
+    b, it, ls = O.fm_mbpsgd_epoch(Xo, y, 2, P, w, 0.0, cfg, stream, Bp, it=1)
+    fm = gpu_fm("classification", 2, K, "explicit", True, True, P0, w0, 0.0)
+    opt = nf.newMBPSGD(maxIter=1, eta0=0.5, gamma=1e-4, loss="logistic", verbose=0, tol=-1.0)
+    opt.it = 1
+    opt.fit(X, y, fm, stream=stream)
+    assert opt.batch == Bp and opt.it == it == 1 + inner
+    assert abs(opt.history[0][1] - ls / (Bp * inner)) < 1e-11
+    assert abs(fm.intercept - b) < 1e-10
+    assert_close(fm.w, w, 1e-8, 1e-13, "w")
+    assert_close(fm.P, P, 1e-8, 1e-13, "P")
+    assert np.array_equal(fm.P == 0.0, P == 0.0) and (P == 0.0).any() and (P != 0.0).any()
+
+
 def test_determinism_and_composition(problem):
     Xo, X, y, P0, w0 = problem
     runs = []
