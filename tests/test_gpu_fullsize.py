@@ -82,6 +82,20 @@ def test_cfg2_fullsize_mbpsgd_vs_oracle(problem):
     assert np.array_equal(fm.P == 0.0, P == 0.0) and (P == 0.0).any() and (P != 0.0).any()
 
 
+def test_cfg2_fullsize_predict_all_with_grad(problem):
+    """pgd.predictAllWithGrad over the whole shard as ONE batch (every feature is touched ~320 times: the segment path)"""
+    Xo, X, y, P0, w0 = problem
+    wq = np.random.default_rng(5).standard_normal(D) * 0.05
+    yp, dL, gP, gw, gb = O.fm_predict_all_with_grad(Xo, y, 2, P0 * 10, wq, 0.1, "logistic")
+    fm = gpu_fm("classification", 2, K, "explicit", True, True, P0 * 10, wq, 0.1)
+    yp_g, dL_g, g = nf.predictAllWithGrad(X, y, fm, loss="logistic")
+    assert_close(yp_g, yp, 1e-10, 1e-13, "yPred")
+    assert_close(dL_g, dL, 1e-9, 1e-13, "dL")
+    assert_close(g["P"], gP, 1e-8, 1e-15, "grad P")
+    assert_close(g["w"], gw, 1e-8, 1e-15, "grad w")
+    assert abs(g["intercept"] - gb) < 1e-12
+
+
 def test_determinism_and_composition(problem):
     Xo, X, y, P0, w0 = problem
     runs = []
