@@ -66,6 +66,10 @@ struct nfm_opt {
   bool state_ready = false;
   MbWork W;
   std::unique_ptr<Plan> plan;
+  // predictAllWithGrad: the one-batch plan of a dataset and its scratch, kept between calls (PGD-style solvers ask for
+  // the full gradient of the same data once per iteration)
+  MbWork Wg;
+  std::unique_ptr<Plan> grad_plan;
 };
 
 static int use_device(nfm_ctx* ctx) {
@@ -862,11 +866,15 @@ int32_t nfm_opt_predict_all_with_grad(nfm_opt* o, nfm_dataset* ds, double* y_pre
     O.gradP = g.as<double>();
     O.gradw = reinterpret_cast<double*>(g.as<char>() + bP);
     O.gradb = reinterpret_cast<double*>(g.as<char>() + bP + bw);
-    Plan plan;
-    MbWork W;
+    MbWork& W = o->Wg;
     W.use_graph = false;
-    const bool sort_by_count = m->Kp * (int)sizeof(double) >= 128;
-    NFM_TRY(plan_build(ctx, ds->v, m->n_aug, nullptr, 0, n, n, false, false, false, sort_by_count, &plan));
+    if (!o->grad_plan || o->grad_plan->ds != (const void*)ds || o->grad_plan->end != n || o->grad_plan->n_aug != m->n_aug) {
+      if (!o->grad_plan) o->grad_plan.reset(new Plan());
+      const bool sort_by_count = m->Kp * (int)sizeof(double) >= 128;
+      NFM_TRY(plan_build(ctx, ds->v, m->n_aug, nullptr, 0, n, n, false, false, false, sort_by_count, o->grad_plan.get()));
+      o->grad_plan->ds = ds;
+    }
+    const Plan& plan = *o->grad_plan;
     NFM_TRY(mb_fm_epoch(ctx, OPT_PSGD, ds->v, M, O, plan, W, o->it, out2));
     if (y_pred || dL) {
       NFM_TRY(rec2.alloc(sizeof(double) * 2 * (size_t)n));

@@ -995,7 +995,13 @@ def predictAllWithGrad(X, y, sfm, loss="squared", lossParam=1.0):
     if len(y) != X.nSamples:
         raise ValueError("len(y) != nSamples")
     X.set_targets(y)
-    opt = MBPSGD(maxIter=1, loss=loss, reg=newL1(), miniBatchSize=1, verbose=0, lossParam=lossParam)
+    # the device optimizer (and with it the one-batch plan of X, nfm_opt_predict_all_with_grad) is kept on the model:
+    # PGD-style solvers ask for the full gradient of the same data once per iteration
+    opt = getattr(sfm, "_grad_opt", None)
+    if opt is None or opt._grad_key != (loss, float(lossParam)):
+        opt = MBPSGD(maxIter=1, loss=loss, reg=newL1(), miniBatchSize=1, verbose=0, lossParam=lossParam)
+        opt._grad_key = (loss, float(lossParam))
+        sfm._grad_opt = opt
     opt._handle(sfm, X.ctx, "minibatch")
     if sfm._dirty:
         sfm._push(X.ctx)
