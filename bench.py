@@ -2,11 +2,14 @@
 """bench.py -- SGD training samples/s per epoch on synthetic CSR (BASELINE.json metric).
 
 One "step" = one pass of the hot path (nfm_opt_epoch, mini-batch mode) over the rank's whole
-synthetic shard, inputs already resident in HBM.  N = 1 runs BASELINE.json configs[1]
-("cfg2": synthetic CSR 1e6 x 1e5, 32 nnz/row, k = 16, SGD, Logistic loss, 1 MI355X).
+synthetic shard, inputs already resident in HBM.  N = 1 runs the north-star headline workload of
+BASELINE.json (synthetic CSR 1e7 x 1e6, 64 nnz/row, k = 64, SGD, Logistic loss, mini-batch 8192, 1 MI355X)
+and, as `extra.cfg2`, BASELINE.json configs[1] (1e6 x 1e5, 32 nnz/row, k = 16).
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank trains on its own
 shard of the same size (weak scaling) and the replicas are averaged with one all-reduce of P / w /
-intercept per step; there is no collective inside the epoch.
+intercept per step; there is no collective inside the epoch.  `--gpus N` without
+torchrun's environment starts the N ranks itself (a torch.distributed.run child; this parent process
+never touches a GPU).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), carrying
   roofline     achieved algorithmic bytes/s of the per-batch kernel pair vs the 8 TB/s HBM peak,
@@ -245,60 +248,28 @@ def psgd_leg(args):
                       "last_step": {"mean_loss": last / need}, "roofline": roof, "cpu_baseline": cpu}))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["ingest", "psgd"])
-    ap.add_argument("--batch", type=int, default=0, help="mini-batch size (default: per workload)")
-    ap.add_argument("--n", "--samples", dest="n", type=int, default=0, help="override samples per GPU (--samples under torchrun, whose parser claims --n)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-viol", action="store_true",
-                    help="AdaGrad without the reference's viol = sum|P_old - P_new| (no stored copy of P is read or "
-                         "written; the stopping criterion is then unavailable) -- an information run, not the metric")
-    ap.add_argument("--cpu-samples", type=int, default=1_000_000)
-    ap.add_argument("--psgd-shape", default="", help="--workload psgd: d,m,k instead of the ml-100k shape")
-    args = ap.parse_args()
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a torch.distributed.run child and leave
+    with its exit code.  This parent imports neither torch nor the library and makes no HIP call (a process that has
+    initialised the GPU must not fork / exec workers on this pool)."""
+    import socket
+    import subprocess
 
-    if args.workload == "ingest":
-        return ingest_leg(args)
-    if args.workload == "psgd":
-        return psgd_leg(args)
-    import torch
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    raise SystemExit(subprocess.call(cmd, env=env))
 
-    import nimfm_amd as nf
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: libnimfm_hip has no CPU fallback")
-    # one process per GPU; NIMFM_BENCH_BACKEND=gloo rehearses the multi-process path on fewer GPUs than
-    # ranks (ranks then share devices; RCCL needs one GPU per rank)
-    backend = os.environ.get("NIMFM_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    wl = dict(WORKLOADS[args.workload])
-    if args.n:
-        wl["n"] = args.n
-    n, d, m, k = wl["n"], wl["d"], wl["m"], wl["k"]
-    n_orders = wl["degree"] - 1  # fitLower=explicit (model/factorization_machine.nim:81-97)
-    if not args.batch:
-        args.batch = wl["batch"]
-
-    ctx = nf.Context(dev_index)
-    nf.set_default_context(ctx)
-    # ---- synthetic shard, generated on the device (data seed 42 + rank; model seed 1) ----
+def make_dataset(torch, nf, ctx, dev, wl, n, rank):
+    """the rank's synthetic shard, generated on the device (data seed 42 + rank), adopted without a copy"""
+    d, m = wl["d"], wl["m"]
     F = wl.get("fields", 0)
     fields = None
     if F:
@@ -320,6 +291,77 @@ def main():
     X = nf.CSRDataset.from_device(ctx, n, d, n * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(),
                                   fields_ptr=fields.data_ptr() if F else None, nFields=F,
                                   keep=(indptr, indices, data, fields))
+    return X, indptr, indices, data
+
+
+def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, cheap=False):
+    """the reference-faithful CPU port (oracle/, test infrastructure used here as the reported baseline) on a bounded
+    prefix of the same shard: built -O3 -march=native on this host (oracle/Makefile `timing`), one warm-up epoch, the
+    median of the next three; Hogwild (optimizer/sgd_multi.nim semantics) at T = 4 (the reference
+    benchmarks' value), this GPU's share of the host's cores, and twice that (the reference's default maxThreads)."""
+    import oracle as O
+
+    epochs = 2 if cheap else 4
+    nc = min(n, args.cpu_samples, max(10_000, int((0.6e9 if cheap else 1.6e9) / (n_orders * m * k * epochs))))
+    ip = indptr[: nc + 1].cpu().numpy()
+    ix = indices[: nc * m].cpu().numpy().astype(np.int64)
+    dv = data[: nc * m].cpu().numpy()
+    Xo = O.Dataset(ip, ix, dv, nc, d)
+    P0 = np.random.default_rng(1).standard_normal((n_orders, k, d)) * 0.01
+    w0 = np.zeros(d)
+    sgd = wl["solver"] == "sgd"
+    cfg = O.sgd_cfg(loss=wl["loss"]) if sgd else O.adagrad_cfg(loss=wl["loss"])
+
+    def med(threads):
+        if sgd:
+            O.fm_sgd_fit(Xo, y[:nc], wl["degree"], P0, w0, 0.0, cfg, epochs, hogwild_threads=threads)
+        else:
+            O.fm_adagrad_fit(Xo, y[:nc], wl["degree"], P0, w0, 0.0, cfg, epochs)
+        return float(np.median(O.epoch_seconds(epochs)[1:]))  # epoch 0 is the warm-up
+
+    with O.variant("timing"):
+        t1 = med(0)
+        threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
+        th = None
+        sweep = []
+        if sgd:
+            for T_ in sorted({min(4, threads), threads} if cheap else {min(4, threads), threads, 2 * threads}):
+                tt_ = med(T_)
+                sweep.append({"threads": T_, "value": round(nc / tt_, 1)})
+                if T_ == threads:
+                    th = tt_
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": round(nc / t1, 1), "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": "the first %d samples of the same shard (same d, nnz/row, k); C restatement of optimizer/%s semantics, "
+                      "flat arrays, gcc -O3 -march=native on this host, 1 thread, 1 warm-up epoch then the median of %d; "
+                      "epoch loop only (the per-fit layout transposes, sgd.nim:292,328, are outside)"
+                      % (nc, "sgd.nim:261-328" if sgd else "adagrad.nim:137-203", epochs - 1),
+            "hogwild": None if th is None else {"value": round(nc / th, 1), "threads": threads,
+                                                "note": "optimizer/sgd_multi.nim semantics (racy), same port and build",
+                                                "sweep": sweep},
+            "host": {"cpu": cpu_model, "logical_cpus": os.cpu_count()}}
+
+
+def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
+    """one workload on this rank's GPU -> (dict of the JSON fields that depend on the workload)"""
+    import ctypes as C
+
+    from nimfm_amd import _capi as capi
+
+    wl = dict(WORKLOADS[name])
+    if args.n and primary:
+        wl["n"] = args.n
+    n, d, m, k = wl["n"], wl["d"], wl["m"], wl["k"]
+    n_orders = wl["degree"] - 1  # fitLower=explicit (model/factorization_machine.nim:81-97)
+    batch = args.batch if (args.batch and primary) else wl["batch"]
+    steps, warmup = (args.steps, args.warmup) if primary else (min(args.steps, 10), min(args.warmup, 3))
+    F = wl.get("fields", 0)
+    X, indptr, indices, data = make_dataset(torch, nf, ctx, dev, wl, n, rank)
     # labels from a planted FM (k, scale 0.1), like tests/utils.nim:29-47; classification -> sign
     rng = np.random.default_rng(1234)
     planted = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True)
@@ -333,33 +375,26 @@ def main():
         fm = nf.newFieldAwareFactorizationMachine(task, nComponents=k, warmStart=True, randomState=1)
     else:
         fm = nf.newFactorizationMachine(task, degree=wl["degree"], nComponents=k, warmStart=True, randomState=1)
-    fm.init(X)  # w = 0, P ~ N(0, 0.01^2), intercept = 0 (model/factorization_machine.nim:125-139)
+    fm.init(X)  # w = 0, P ~ N(0, 0.01^2) (Box-Muller pairs in fill order), intercept = 0 (factorization_machine.nim:125-139)
     if wl["solver"] == "sgd":
-        opt = nf.newSGD(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch", batch=args.batch)
+        opt = nf.newSGD(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch", batch=batch)
     else:
         opt = nf.newAdaGrad(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch",
-                            batch=args.batch, trackViol=not args.no_viol)
+                            batch=batch, trackViol=not args.no_viol)
     X.set_targets(y)
     opt._handle(fm, ctx, "minibatch")
-    import ctypes as C
-
-    from nimfm_amd import _capi as capi
-
     views = None
     if world > 1:
         from nimfm_amd import dp
 
         views = dp.ParamViews(torch, dev, fm, opt)
 
-    def step():
-        ls, vs = opt._epoch(X, None, 0, n)
+    def step(perm=None):
+        ls, vs = opt._epoch(X, perm, 0, n)
         opt.it += n
         if world > 1:
             views.average(dist, world)
         return ls, vs
-
-    for _ in range(args.warmup):
-        step()
 
     def fence():
         ctx.synchronize()
@@ -368,19 +403,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    ms_per_step = dt / args.steps * 1e3
-    value = n * world / (dt / args.steps)
+    def timed(k_steps, perms=None):
+        fence()
+        t0 = time.perf_counter()
+        last = None
+        for e in range(k_steps):
+            last = step(None if perms is None else perms[e])
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, last
+
+    for _ in range(warmup):
+        step()
+    dt, last = timed(steps)
+    ms_per_step = dt / steps * 1e3
+    value = n * world / (dt / steps)
+
+    # ---- the reference's default shuffle = true (optimizer/sgd.nim:297): every epoch gets a FRESH permutation, so the
+    # batch plan is rebuilt inside the timed region (permutation upload, plan build, un-graphed launches all counted;
+    # drawing the permutation is the host's job -- Nim's shuffle in the reference -- and is not) ----
+    ks = max(1, min(3, steps))
+    perms = [np.random.default_rng(7 + rank * 131 + e).permutation(n).astype(np.int64) for e in range(ks + 1)]
+    step(perms[ks])  # warm-up of the un-cached path (allocator pools sized)
+    dts, _ = timed(ks, perms)
+    value_shuffled = n * world / (dts / ks)
+    del perms
 
     # ---- predict samples/s (the metric's second half): decisionFunction over the shard, output on device ----
     pred = None
@@ -409,6 +460,7 @@ def main():
         pred = {"value": round(n / tp, 1), "unit": "samples/s", "ms": round(tp * 1e3, 4),
                 "roofline_frac": round(pbytes * n / tp / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": pbytes,
                 "score": {"value": round(n / ts, 1), "unit": "samples/s", "ms": round(ts * 1e3, 4), "result": sc.value}}
+        del out_dev
 
     # ---- roofline leg: per-kernel durations from HIP events on the library's stream ----
     roof = None
@@ -429,80 +481,110 @@ def main():
         bps = algorithmic_bytes_per_sample(wl["solver"], m, k, n_orders, F)
         units = n / n_batches
         achieved = bps * units / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
-        # HBM-side bytes per mini-batch from the last committed PMC run of this workload/batch
-        # (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes, tools/pmc_traffic.py); null otherwise
-        traffic = None
+        # HBM-side bytes per mini-batch are NOT measured in this run (PMC counters need their own rocprofv3 --pmc
+        # passes): the figure of the newest committed PMC run of this workload / batch is quoted and labelled, else null
+        traffic, traffic_src = None, None
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
             t = json.load(open(path))
-            if t.get("workload") == args.workload and t.get("batch") == args.batch:
-                traffic = t["hbm_bytes_per_minibatch"]
+            if t.get("workload") == name and t.get("batch") == batch:
+                traffic, traffic_src = t["hbm_bytes_per_minibatch"], "profiles/" + os.path.basename(path)
         roof = {"bound": "hbm", "kernel": "k_row_phase (+ k_singles in the sparse regime) + k_col_phase: one mini-batch = one launch of each",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": (traffic_src + " (a separate rocprofv3 --pmc run of this workload, not this run)") if traffic_src else None,
                 "algorithmic_bytes_per_minibatch": bps * units,
                 "bytes_per_sample": bps, "samples_per_launch": units,
                 "avg_ms": {f: round(per_batch_ms[f], 5) for f in per_batch_ms},
                 "launches_per_step": {f: fam[f][0] / reps for f in fam}}
 
-    # ---- CPU baseline: reference-faithful port, single thread, same workload (rank 0, N = 1) ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not F:
-        import oracle as O
+        cpu = cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, cheap=not primary)
 
-        cpu_epochs = 5
-        # bounded sample: ~10-30 s of single-thread work whatever the row size (cfg2: 1e6 samples x 5 epochs)
-        nc = min(n, args.cpu_samples, max(10_000, int(2.56e9 / (n_orders * m * k * cpu_epochs))))
-        ip = indptr[: nc + 1].cpu().numpy()
-        ix = indices[: nc * m].cpu().numpy().astype(np.int64)
-        dv = data[: nc * m].cpu().numpy()
-        Xo = O.Dataset(ip, ix, dv, nc, d)
-        P0 = np.random.default_rng(1).standard_normal((n_orders, k, d)) * 0.01
-        cfg = O.sgd_cfg(loss=wl["loss"]) if wl["solver"] == "sgd" else O.adagrad_cfg(loss=wl["loss"])
-        tc = time.perf_counter()
-        if wl["solver"] == "sgd":
-            O.fm_sgd_fit(Xo, y[:nc], wl["degree"], P0, np.zeros(d), 0.0, cfg, cpu_epochs)
+    return {"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "steps": steps, "warmup": warmup,
+            "value_shuffled": round(value_shuffled, 1),
+            "shuffled_note": "%d epochs, each with a fresh host-drawn permutation: permutation upload, batch-plan build and "
+                             "un-graphed launches inside the timed region" % ks,
+            "config": {"workload": "%s: synthetic CSR %dx%d, %d nnz/row, k=%d, %s %s loss, mini-batch %d, "
+                                   "mode=minibatch" % (name, n, d, m, k, wl["solver"].upper(), wl["loss"], batch),
+                       "update_rule": "this library's deterministic mini-batch rule (per-coordinate mean of the batch's "
+                                      "per-sample steps, DESIGN.md section 4) -- NOT the reference's sample-by-sample order, "
+                                      "which NFM_MODE_SEQUENTIAL reproduces at ~1e5 samples/s",
+                       "samples_per_gpu": n, "batch": batch,
+                       "parallelism": "replicas=%d, parameter average per step" % world if world > 1 else "1 GPU"},
+            "last_step": {"mean_loss": last[0] / n, "viol": last[1]}, "predict": pred,
+            "roofline": roof, "cpu_baseline": cpu}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS) + ["ingest", "psgd"])
+    ap.add_argument("--batch", type=int, default=0, help="mini-batch size (default: per workload)")
+    ap.add_argument("--n", "--samples", dest="n", type=int, default=0, help="override samples per GPU (--samples under torchrun, whose parser claims --n)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra.cfg2 leg of the default (headline) run")
+    ap.add_argument("--no-viol", action="store_true",
+                    help="AdaGrad without the reference's viol = sum|P_old - P_new| (no stored copy of P is read or "
+                         "written; the stopping criterion is then unavailable) -- an information run, not the metric")
+    ap.add_argument("--cpu-samples", type=int, default=1_000_000)
+    ap.add_argument("--psgd-shape", default="", help="--workload psgd: d,m,k instead of the ml-100k shape")
+    args = ap.parse_args()
+
+    if args.workload == "ingest":
+        return ingest_leg(args)
+    if args.workload == "psgd":
+        return psgd_leg(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)  # before anything that could touch a GPU
+    import torch
+
+    import nimfm_amd as nf
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libnimfm_hip has no CPU fallback")
+    # one process per GPU; NIMFM_BENCH_BACKEND=gloo rehearses the multi-process path on fewer GPUs than
+    # ranks (ranks then share devices; RCCL needs one GPU per rank)
+    backend = os.environ.get("NIMFM_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (one rank per GPU over RCCL); "
+                         "NIMFM_BENCH_BACKEND=gloo rehearses the multi-process path on fewer GPUs" % (world, torch.cuda.device_count()))
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
         else:
-            O.fm_adagrad_fit(Xo, y[:nc], wl["degree"], P0, np.zeros(d), 0.0, cfg, cpu_epochs)
-        t1 = (time.perf_counter() - tc) / cpu_epochs
-        threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
-        th = None
-        sweep = []
-        if wl["solver"] == "sgd":
-            # T in {4 (the reference benchmarks' value), the cores of this GPU's share, 2 x that (the
-            # reference's default maxThreads, sgd_multi.nim:15)}
-            for T_ in sorted({min(4, threads), threads, 2 * threads}):
-                tc = time.perf_counter()
-                O.fm_sgd_fit(Xo, y[:nc], wl["degree"], P0, np.zeros(d), 0.0, cfg, cpu_epochs, hogwild_threads=T_)
-                tt_ = (time.perf_counter() - tc) / cpu_epochs
-                sweep.append({"threads": T_, "value": round(nc / tt_, 1)})
-                if T_ == threads:
-                    th = tt_
-        cpu_model = ""
-        try:
-            with open("/proc/cpuinfo") as f:
-                cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
-        except OSError:
-            pass
-        cpu = {"value": round(nc / t1, 1), "unit": "samples/s", "cores": 1, "kind": "port",
-               "sample": "%d sequential epochs (optimizer/sgd.nim:261-328 semantics) over the first %d samples of "
-                         "the same shard, C restatement -O2, 1 thread" % (cpu_epochs, nc),
-               "hogwild": None if th is None else {"value": round(nc / th, 1), "threads": threads,
-                                                   "note": "optimizer/sgd_multi.nim semantics (racy), same port",
-                                                   "sweep": sweep},
-               "host": {"cpu": cpu_model, "logical_cpus": os.cpu_count()}}
+            dist.init_process_group(backend)
+    ctx = nf.Context(dev_index)
+    nf.set_default_context(ctx)
 
+    res = run_training(args, args.workload, torch, nf, dist, rank, world, dev, ctx, primary=True)
+    extra = None
+    if args.workload == "headline" and world == 1 and not args.no_extra and not args.n:
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        c2 = run_training(args, "cfg2", torch, nf, dist, rank, world, dev, ctx, primary=False)
+        extra = {"cfg2": {"metric": "SGD training samples/sec/epoch", "unit": "samples/s", **c2}}
     if rank == 0:
-        out = {"metric": "SGD training samples/sec/epoch", "value": round(value, 1), "unit": "samples/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        out = {"metric": "SGD training samples/sec/epoch", "value": res["value"], "unit": "samples/s",
+               "n_gpus": world, "steps": res["steps"], "warmup": res["warmup"], "ms_per_step": res["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "%s: synthetic CSR %dx%d, %d nnz/row, k=%d, %s %s loss, mini-batch %d, "
-                                      "mode=minibatch" % (args.workload, n, d, m, k, wl["solver"].upper(),
-                                                          wl["loss"], args.batch),
-                          "samples_per_gpu": n, "batch": args.batch,
-                          "parallelism": "replicas=%d, parameter average per step" % world if world > 1 else "1 GPU"},
-               "last_step": {"mean_loss": last[0] / n, "viol": last[1]}, "predict": pred,
-               "roofline": roof, "cpu_baseline": cpu}
+               "config": res["config"], "value_shuffled": res["value_shuffled"], "shuffled_note": res["shuffled_note"],
+               "last_step": res["last_step"], "predict": res["predict"], "roofline": res["roofline"],
+               "cpu_baseline": res["cpu_baseline"], "extra": extra}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()  # rank 0 ran the predict / roofline legs after the timed region: leave together

@@ -87,7 +87,14 @@ int32_t nfm_ctx_timing_get(nfm_ctx* ctx, const char* family, int64_t* launches, 
  * dataset.nim:10-13,182-231 (row iterators incl. dummy features, which the
  * kernels generate on the fly) as the thing `fit`/`decisionFunction` iterate.
  * indices/fields are narrowed to int32 on the device.  y may be NULL for
- * predict-only datasets.  Indices inside one row must be distinct. */
+ * predict-only datasets.  Rows may be stored in any order (dataset.nim:597-612),
+ * but the column ids inside one row must be DISTINCT: a repeated id is
+ * NFM_ERR_UNSUPPORTED at creation (here, in the *_device variant and in every
+ * loader).  The reference does not forbid repeats, but what it computes for
+ * them is an accident of its scratch layout (the later entry overwrites the
+ * earlier one's derivative dA[j], optimizer/sgd.nim:176-188, and the row's
+ * parameters are then stepped once per entry with it, :217-223); merge
+ * repeated entries before handing a matrix over. */
 int32_t nfm_dataset_create_csr(nfm_ctx* ctx, int64_t n_samples, int64_t n_features,
                                const int64_t* indptr /*n+1*/, const int64_t* indices /*nnz*/,
                                const double* data /*nnz*/, const int64_t* fields /*nnz or NULL*/,
@@ -267,6 +274,20 @@ int32_t nfm_opt_device_state(nfm_opt* o, double** gsum_P, double** gnorm_P, int6
                              double** gsum_w, double** gnorm_w, int64_t* n_w,
                              double** gscalars /* {gsum_b, gnorm_b} */);
 int32_t nfm_opt_destroy(nfm_opt* o);
+
+/* ---- host-side random numbers (no device work) ----
+ * FactorizationMachine.init draws P with randomNormal (model/factorization_machine.nim:125-139,
+ * tensor/tensor.nim:561-580: Box-Muller over rand(1.0); z = sqrt(-2 ln(1-x)) cos(2 pi y) and the sine twin go
+ * to CONSECUTIVE elements of the row-major fill [nOrders][nComponents][nFeatures+nAugments] (FFM:
+ * [nFields][nFeatures][nComponents]), an odd count leaves the twin unused) after randomize(randomState);
+ * fit shuffles the sample order with the same global generator (optimizer/sgd.nim:297).  A Nim host keeps
+ * calling Nim's own procs; these entry points give hosts in other languages the same procedures.  state is the
+ * generator's two 64-bit words.  The generator (Nim 1.0 lib/pure/random.nim, xoroshiro128+) is outside the
+ * reference tree and restated from memory: the PROCEDURE (pairing, fill order, shuffle loop) follows the
+ * reference, the bit stream is unverified. */
+int32_t nfm_rng_randomize(int64_t seed, uint64_t* state /*[2]*/);
+int32_t nfm_rng_random_normal(uint64_t* state, int64_t n, double loc, double scale, double* out /*n*/);
+int32_t nfm_rng_shuffle(uint64_t* state, int64_t* x, int64_t n);
 
 #ifdef __cplusplus
 }

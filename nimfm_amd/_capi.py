@@ -38,6 +38,7 @@ SYMBOLS = [
     "nfm_model_destroy",
     "nfm_sgd_create", "nfm_adagrad_create", "nfm_mbpsgd_create", "nfm_opt_predict_all_with_grad", "nfm_opt_set_it", "nfm_opt_get_it", "nfm_opt_get_state",
     "nfm_opt_set_state", "nfm_opt_epoch", "nfm_opt_finalize", "nfm_opt_device_state", "nfm_opt_destroy",
+    "nfm_rng_randomize", "nfm_rng_random_normal", "nfm_rng_shuffle",
 ]
 
 
@@ -154,6 +155,9 @@ def lib():
         "nfm_opt_finalize": [vp],
         "nfm_opt_device_state": [vp, pp, pp, C.POINTER(i64), pp, pp, C.POINTER(i64), pp],
         "nfm_opt_destroy": [vp],
+        "nfm_rng_randomize": [i64, vp],
+        "nfm_rng_random_normal": [vp, i64, dbl, dbl, vp],
+        "nfm_rng_shuffle": [vp, vp, i64],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

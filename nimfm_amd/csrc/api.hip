@@ -1,9 +1,13 @@
 // nimfm_amd/csrc/api.hip -- the C ABI of include/nimfm_hip.h over the HIP kernels.
 // Host-side bookkeeping only (allocation, layout conversion launches, plan cache, epoch driver);
 // every entry point validates shapes on the host before any kernel is launched.
+#include <math.h>
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <map>
+#include <mutex>
 #include <memory>
 #include <vector>
 
@@ -20,8 +24,15 @@ struct nfm_dataset {
   int max_row = 0;
   int64_t ingest_bytes = 0;  // set by the text loaders (ingest.hip)
   double ingest_upload_ms = 0.0, ingest_parse_ms = 0.0;
-  uint64_t serial = 0;  // bumps when targets change (plans do not depend on y; kept for clarity)
+  // Cache keys.  uid: process-unique, never reused -- what a Plan is keyed by (a raw nfm_dataset* can be handed out
+  // again by `new` after a `delete`, for a dataset of the same shape and different structure).  serial: bumps whenever
+  // one of the v.* device pointers changes (nfm_dataset_set_targets) -- a captured hipGraph holds those pointers.
+  uint64_t uid = 0, serial = 0;
 };
+static uint64_t next_dataset_uid() {
+  static std::atomic<uint64_t> g{0};
+  return ++g;
+}
 
 struct Span {  // a piece of an arena allocation
   void* p = nullptr;
@@ -32,6 +43,7 @@ struct Span {  // a piece of an arena allocation
 static size_t pad256(size_t b) { return (b + 255) / 256 * 256; }
 
 struct nfm_model {
+  uint64_t uid = 0;  // process-unique; optimizers refer to their model by it (an address can be handed out again)
   nfm_ctx* ctx = nullptr;
   nfm_model_cfg cfg{};
   int nb = 0, n_aug = 0, k = 0, Kp = 0, L = 0;
@@ -56,7 +68,8 @@ struct nfm_model {
 
 struct nfm_opt {
   nfm_ctx* ctx = nullptr;  // kept separately: the optimizer may outlive its model handle
-  nfm_model* m = nullptr;
+  nfm_model* m = nullptr;  // valid only while model_of(o) finds m_uid among the live models
+  uint64_t m_uid = 0;
   int kind = OPT_SGD, mode = NFM_MODE_SEQUENTIAL;
   int64_t batch = 1, it = 1;
   OptView o{};
@@ -71,6 +84,30 @@ struct nfm_opt {
   MbWork Wg;
   std::unique_ptr<Plan> grad_plan;
 };
+
+// live models by uid: an optimizer whose model was destroyed (and whose address may since belong to a model of
+// another shape) is refused instead of writing through a stale pointer
+static std::mutex g_models_mu;
+static std::map<uint64_t, nfm_model*> g_models;
+static uint64_t register_model(nfm_model* m) {
+  static uint64_t next = 0;
+  std::lock_guard<std::mutex> lk(g_models_mu);
+  g_models[++next] = m;
+  return next;
+}
+static void unregister_model(uint64_t uid) {
+  std::lock_guard<std::mutex> lk(g_models_mu);
+  g_models.erase(uid);
+}
+static int model_of(nfm_opt* o, nfm_model** out) {
+  NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
+  std::lock_guard<std::mutex> lk(g_models_mu);
+  auto it = g_models.find(o->m_uid);
+  NFM_CHECK(it != g_models.end() && it->second == o->m, NFM_ERR_INVALID,
+            "the optimizer's model was destroyed; create the optimizer again for the new model");
+  *out = it->second;
+  return NFM_OK;
+}
 
 static int use_device(nfm_ctx* ctx) {
   NFM_HIP_CHECK(hipSetDevice(ctx->device));
@@ -191,6 +228,7 @@ int32_t nfm_dataset_create_csr(nfm_ctx* ctx, int64_t n, int64_t d, const int64_t
   NFM_CHECK(nnz == 0 || data, NFM_ERR_INVALID, "null data");
   std::unique_ptr<nfm_dataset> ds(new nfm_dataset());
   ds->ctx = ctx;
+  ds->uid = next_dataset_uid();
   ds->max_row = max_row;
   hipStream_t st = ctx->stream;
   NFM_TRY(ds->indptr.alloc(sizeof(int64_t) * (n + 1)));
@@ -223,6 +261,7 @@ int32_t nfm_dataset_create_csr(nfm_ctx* ctx, int64_t n, int64_t d, const int64_t
   ds->v.y = ds->has_y ? ds->y.as<double>() : nullptr;
   ds->v.n = n; ds->v.d = d; ds->v.nnz = nnz; ds->v.n_fields = fields ? (int32_t)n_fields : 0;
   ds->v.max_row = max_row;
+  NFM_TRY(check_rows_distinct(ctx, ds->v));
   *out = ds.release();
   return NFM_OK;
 }
@@ -247,11 +286,13 @@ int32_t nfm_dataset_create_csr_device(nfm_ctx* ctx, int64_t n, int64_t d, int64_
   }
   std::unique_ptr<nfm_dataset> ds(new nfm_dataset());
   ds->ctx = ctx;
+  ds->uid = next_dataset_uid();
   ds->max_row = (int)mr;
   ds->has_y = y_dev != nullptr;
   ds->v.indptr = indptr_dev; ds->v.indices = indices_dev; ds->v.data = data_dev; ds->v.fields = fields_dev;
   ds->v.y = y_dev; ds->v.n = n; ds->v.d = d; ds->v.nnz = nnz; ds->v.n_fields = fields_dev ? (int32_t)n_fields : 0;
   ds->v.max_row = (int32_t)mr;
+  NFM_TRY(check_rows_distinct(ctx, ds->v));
   *out = ds.release();
   return NFM_OK;
 }
@@ -263,8 +304,8 @@ int32_t nfm_dataset_set_targets(nfm_dataset* ds, const double* y) {
   NFM_HIP_CHECK(hipMemcpyAsync(ds->y.p, y, sizeof(double) * ds->v.n, hipMemcpyHostToDevice, ds->ctx->stream));
   NFM_HIP_CHECK(hipStreamSynchronize(ds->ctx->stream));
   ds->has_y = true;
+  if (ds->v.y != ds->y.as<double>()) ds->serial++;  // a captured epoch graph holds the old pointer
   ds->v.y = ds->y.as<double>();
-  ds->serial++;
   return NFM_OK;
 }
 
@@ -281,6 +322,7 @@ static int dataset_from_ingest(nfm_ctx* ctx, IngestResult& r, bool with_fields, 
                      (long long)r.n_fields);
   std::unique_ptr<nfm_dataset> ds(new nfm_dataset());
   ds->ctx = ctx;
+  ds->uid = next_dataset_uid();
   ds->max_row = r.max_row;
   ds->indptr.take(r.indptr);
   ds->indices.take(r.indices);
@@ -301,6 +343,7 @@ static int dataset_from_ingest(nfm_ctx* ctx, IngestResult& r, bool with_fields, 
   ds->ingest_bytes = r.bytes;
   ds->ingest_upload_ms = r.upload_ms;
   ds->ingest_parse_ms = r.parse_ms;
+  NFM_TRY(check_rows_distinct(ctx, ds->v));
   *out = ds.release();
   return NFM_OK;
 }
@@ -443,6 +486,7 @@ int32_t nfm_model_create(nfm_ctx* ctx, const nfm_model_cfg* cfg, nfm_model** out
   double sc[SC_COUNT] = {1.0, 1.0, 0.0, 0, 0, 0, 0, 0};
   NFM_HIP_CHECK(hipMemcpyAsync(m->sc.p, sc, sizeof(sc), hipMemcpyHostToDevice, ctx->stream));
   NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  m->uid = register_model(m.get());
   *out = m.release();
   return NFM_OK;
 }
@@ -587,6 +631,7 @@ int32_t nfm_model_device_buffers(nfm_model* m, double** P_dev, int64_t* n_P, dou
 
 int32_t nfm_model_destroy(nfm_model* m) {
   if (!m) return NFM_OK;
+  unregister_model(m->uid);
   (void)hipSetDevice(m->ctx->device);
   (void)hipStreamSynchronize(m->ctx->stream);
   delete m;
@@ -607,7 +652,7 @@ int32_t nfm_sgd_create(nfm_model* m, const nfm_sgd_cfg* c, nfm_opt** out) {
   NFM_TRY(check_common(m, c->loss, c->mode, c->batch));
   NFM_CHECK(c->scheduling >= 0 && c->scheduling <= 3, NFM_ERR_INVALID, "bad scheduling id");
   std::unique_ptr<nfm_opt> o(new nfm_opt());
-  o->ctx = m->ctx; o->m = m; o->kind = OPT_SGD; o->mode = c->mode; o->batch = c->mode == NFM_MODE_MINIBATCH ? c->batch : 1; o->it = 1;
+  o->ctx = m->ctx; o->m = m; o->m_uid = m->uid; o->kind = OPT_SGD; o->mode = c->mode; o->batch = c->mode == NFM_MODE_MINIBATCH ? c->batch : 1; o->it = 1;
   o->o.eta0 = c->eta0; o->o.alpha0 = c->alpha0; o->o.alpha = c->alpha; o->o.beta = c->beta; o->o.power = c->power;
   o->o.eps = 0.0; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = c->scheduling; o->o.track_viol = 1;
   NFM_TRY(use_device(m->ctx));
@@ -620,7 +665,7 @@ int32_t nfm_adagrad_create(nfm_model* m, const nfm_adagrad_cfg* c, nfm_opt** out
   NFM_CHECK(c && out, NFM_ERR_INVALID, "null argument");
   NFM_TRY(check_common(m, c->loss, c->mode, c->batch));
   std::unique_ptr<nfm_opt> o(new nfm_opt());
-  o->ctx = m->ctx; o->m = m; o->kind = OPT_ADAGRAD; o->mode = c->mode; o->batch = c->mode == NFM_MODE_MINIBATCH ? c->batch : 1; o->it = 1;
+  o->ctx = m->ctx; o->m = m; o->m_uid = m->uid; o->kind = OPT_ADAGRAD; o->mode = c->mode; o->batch = c->mode == NFM_MODE_MINIBATCH ? c->batch : 1; o->it = 1;
   o->o.eta0 = c->eta0; o->o.alpha0 = c->alpha0; o->o.alpha = c->alpha; o->o.beta = c->beta; o->o.power = 1.0;
   o->o.eps = c->eps; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = 0; o->o.track_viol = c->track_viol;
   NFM_TRY(use_device(m->ctx));
@@ -655,7 +700,7 @@ int32_t nfm_mbpsgd_create(nfm_model* m, const nfm_mbpsgd_cfg* c, nfm_opt** out) 
     NFM_CHECK(!c->reg_transpose, NFM_ERR_UNSUPPORTED, "SquaredL21 with transpose=true is not supported");
   }
   std::unique_ptr<nfm_opt> o(new nfm_opt());
-  o->ctx = m->ctx; o->m = m; o->kind = OPT_PSGD; o->mode = NFM_MODE_MINIBATCH; o->batch = c->batch; o->it = 1;
+  o->ctx = m->ctx; o->m = m; o->m_uid = m->uid; o->kind = OPT_PSGD; o->mode = NFM_MODE_MINIBATCH; o->batch = c->batch; o->it = 1;
   o->o.eta0 = c->eta0; o->o.alpha0 = c->alpha0; o->o.alpha = c->alpha; o->o.beta = c->beta; o->o.power = c->power;
   o->o.eps = 0.0; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = c->scheduling; o->o.track_viol = 0;
   o->o.gamma = c->gamma; o->o.bsize = (double)c->batch; o->o.reg = c->reg; o->o.reg_transpose = c->reg_transpose ? 1 : 0;
@@ -680,7 +725,8 @@ int32_t nfm_opt_get_it(nfm_opt* o, int64_t* it) {
 
 // adagrad.nim:52-55: g_sum = 0, g_norm = eps when it == 1
 static int adagrad_reset_state(nfm_opt* o) {
-  nfm_model* m = o->m;
+  nfm_model* m = nullptr;
+  NFM_TRY(model_of(o, &m));
   nfm_ctx* ctx = m->ctx;
   NFM_HIP_CHECK(hipMemsetAsync(o->G.p, 0, o->G.bytes, ctx->stream));
   NFM_HIP_CHECK(hipMemsetAsync(o->Gw.p, 0, o->Gw.bytes, ctx->stream));
@@ -697,7 +743,8 @@ int32_t nfm_opt_get_state(nfm_opt* o, double* gsum_P, double* gnorm_P, double* g
                           double* gnorm_b) {
   NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
   NFM_CHECK(o->kind == OPT_ADAGRAD, NFM_ERR_INVALID, "only AdaGrad carries state");
-  nfm_model* m = o->m;
+  nfm_model* m = nullptr;
+  NFM_TRY(model_of(o, &m));
   nfm_ctx* ctx = m->ctx;
   NFM_TRY(use_device(ctx));
   if (!o->state_ready) NFM_TRY(adagrad_reset_state(o));
@@ -726,7 +773,8 @@ int32_t nfm_opt_set_state(nfm_opt* o, const double* gsum_P, const double* gnorm_
                           const double* gnorm_w, double gsum_b, double gnorm_b) {
   NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
   NFM_CHECK(o->kind == OPT_ADAGRAD, NFM_ERR_INVALID, "only AdaGrad carries state");
-  nfm_model* m = o->m;
+  nfm_model* m = nullptr;
+  NFM_TRY(model_of(o, &m));
   nfm_ctx* ctx = m->ctx;
   NFM_TRY(use_device(ctx));
   const int64_t rows = (int64_t)m->nb * m->da, n_ref = rows * m->k;
@@ -767,7 +815,8 @@ static int ensure_unit_scale(nfm_model* m) {
 int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t begin, int64_t end, double* loss_sum,
                       double* viol_sum) {
   NFM_CHECK(o && ds, NFM_ERR_INVALID, "null argument");
-  nfm_model* m = o->m;
+  nfm_model* m = nullptr;
+  NFM_TRY(model_of(o, &m));
   nfm_ctx* ctx = m->ctx;
   NFM_CHECK(ds->ctx == ctx, NFM_ERR_INVALID, "optimizer and dataset belong to different contexts");
   NFM_TRY(check_predict_shapes(m, ds));
@@ -806,7 +855,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
     } else {
       const bool first_singleton = o->kind == OPT_ADAGRAD && o->it == 1;
       const bool want_tq = m->cfg.kind == NFM_KIND_FFM;
-      const bool reuse = o->plan && !perm && !o->plan->has_perm && o->plan->ds == (const void*)ds && o->plan->begin == begin &&
+      const bool reuse = o->plan && !perm && !o->plan->has_perm && o->plan->ds_uid == ds->uid && o->plan->ds_nnz == ds->v.nnz && o->plan->begin == begin &&
                          o->plan->end == end && o->plan->batch == o->batch && o->plan->first_singleton == first_singleton &&
                          o->plan->n_aug == m->n_aug;
       if (!reuse) {
@@ -821,10 +870,11 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         const bool sort_by_count = m->Kp * (int)sizeof(double) >= 128;  // rows of at least one 128-byte line (plan.hip)
         NFM_TRY(plan_build(ctx, ds->v, m->n_aug, perm, begin, end, o->batch, first_singleton, want_tq, use_singles, sort_by_count,
                            o->plan.get()));
-        o->plan->ds = ds;
+        o->plan->ds_uid = ds->uid;
+        o->plan->ds_nnz = ds->v.nnz;
       }
       if (m->cfg.kind == NFM_KIND_FM)
-        NFM_TRY(mb_fm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2));
+        NFM_TRY(mb_fm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2, (ds->uid << 20) ^ ds->serial));
       else
         NFM_TRY(mb_ffm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2));
     }
@@ -845,7 +895,8 @@ int32_t nfm_opt_predict_all_with_grad(nfm_opt* o, nfm_dataset* ds, double* y_pre
                                       double* grad_b, double* loss_sum) {
   NFM_CHECK(o && ds, NFM_ERR_INVALID, "null argument");
   NFM_CHECK(o->kind == OPT_PSGD, NFM_ERR_INVALID, "predictAllWithGrad needs an optimizer made by nfm_mbpsgd_create");
-  nfm_model* m = o->m;
+  nfm_model* m = nullptr;
+  NFM_TRY(model_of(o, &m));
   nfm_ctx* ctx = m->ctx;
   NFM_CHECK(ds->ctx == ctx, NFM_ERR_INVALID, "optimizer and dataset belong to different contexts");
   NFM_TRY(check_predict_shapes(m, ds));
@@ -868,11 +919,13 @@ int32_t nfm_opt_predict_all_with_grad(nfm_opt* o, nfm_dataset* ds, double* y_pre
     O.gradb = reinterpret_cast<double*>(g.as<char>() + bP + bw);
     MbWork& W = o->Wg;
     W.use_graph = false;
-    if (!o->grad_plan || o->grad_plan->ds != (const void*)ds || o->grad_plan->end != n || o->grad_plan->n_aug != m->n_aug) {
+    if (!o->grad_plan || o->grad_plan->ds_uid != ds->uid || o->grad_plan->ds_nnz != ds->v.nnz || o->grad_plan->end != n ||
+        o->grad_plan->n_aug != m->n_aug) {
       if (!o->grad_plan) o->grad_plan.reset(new Plan());
       const bool sort_by_count = m->Kp * (int)sizeof(double) >= 128;
       NFM_TRY(plan_build(ctx, ds->v, m->n_aug, nullptr, 0, n, n, false, false, false, sort_by_count, o->grad_plan.get()));
-      o->grad_plan->ds = ds;
+      o->grad_plan->ds_uid = ds->uid;
+      o->grad_plan->ds_nnz = ds->v.nnz;
     }
     const Plan& plan = *o->grad_plan;
     NFM_TRY(mb_fm_epoch(ctx, OPT_PSGD, ds->v, M, O, plan, W, o->it, out2));
@@ -901,7 +954,8 @@ int32_t nfm_opt_predict_all_with_grad(nfm_opt* o, nfm_dataset* ds, double* y_pre
 
 int32_t nfm_opt_finalize(nfm_opt* o) {
   NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
-  nfm_model* m = o->m;
+  nfm_model* m = nullptr;
+  NFM_TRY(model_of(o, &m));
   NFM_TRY(use_device(m->ctx));
   if (o->kind == OPT_SGD) {
     NFM_TRY(launch_rescale(m->ctx, m->view()));
@@ -918,17 +972,90 @@ int32_t nfm_opt_device_state(nfm_opt* o, double** gsum_P, double** gnorm_P, int6
                              int64_t* n_w, double** gscalars) {
   NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
   NFM_CHECK(o->kind == OPT_ADAGRAD, NFM_ERR_INVALID, "only AdaGrad carries state");
+  nfm_model* m = nullptr;
+  NFM_TRY(model_of(o, &m));
   if (!o->state_ready) {
-    NFM_TRY(use_device(o->m->ctx));
+    NFM_TRY(use_device(m->ctx));
     NFM_TRY(adagrad_reset_state(o));
   }
   if (gsum_P) *gsum_P = o->G.as<double>();
   if (gnorm_P) *gnorm_P = o->N.as<double>();
-  if (n_P) *n_P = o->m->nP();
+  if (n_P) *n_P = m->nP();
   if (gsum_w) *gsum_w = o->Gw.as<double>();
   if (gnorm_w) *gnorm_w = o->Nw.as<double>();
-  if (n_w) *n_w = o->m->d;
+  if (n_w) *n_w = m->d;
   if (gscalars) *gscalars = o->gsc.as<double>();
+  return NFM_OK;
+}
+
+// ------------------------------------------------------------------ host-side random numbers
+// The reference draws P (tensor/tensor.nim:561-580) and shuffles the sample order (optimizer/sgd.nim:297) on the host
+// with Nim's global generator.  A Nim host keeps doing exactly that; hosts in other languages (nimfm_amd/host.py,
+// nimfm_amd/host/nimfm.hpp) get the same procedures here.  The generator is Nim 1.0's lib/pure/random.nim
+// (xoroshiro128+), which is NOT part of the reference tree: restated from memory, unverified.
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static inline uint64_t nim_next(uint64_t* st) {
+  const uint64_t s0 = st[0];
+  uint64_t s1 = st[1];
+  const uint64_t r = s0 + s1;
+  s1 ^= s0;
+  st[0] = rotl64(s0, 55) ^ s1 ^ (s1 << 14);
+  st[1] = rotl64(s1, 36);
+  return r;
+}
+static inline double nim_rand1(uint64_t* st) {  // rand(1.0): 52 random mantissa bits in [1, 2) minus 1
+  const uint64_t u = (0x3FFull << 52) | (nim_next(st) >> 12);
+  double f;
+  memcpy(&f, &u, sizeof(f));
+  return f - 1.0;
+}
+
+int32_t nfm_rng_randomize(int64_t seed, uint64_t* state) {  // randomize(seed) = initRand(seed)
+  NFM_CHECK(state, NFM_ERR_INVALID, "null state");
+  state[0] = (uint64_t)seed >> 16;
+  state[1] = (uint64_t)seed & 0xffffull;
+  (void)nim_next(state);
+  return NFM_OK;
+}
+
+int32_t nfm_rng_random_normal(uint64_t* state, int64_t n, double loc, double scale, double* out) {
+  NFM_CHECK(state && n >= 0 && (out || n == 0), NFM_ERR_INVALID, "null argument");
+  // tensor/tensor.nim:561-580: Box-Muller, the two values of one (x, y) draw go to CONSECUTIVE elements of the
+  // row-major fill (the pairing runs on across rows and blocks); an odd count leaves the sine half unused
+  double x = 0.0, y = 0.0;
+  bool has = false;
+  const double two_pi = 2 * 3.14159265358979323846;
+  for (int64_t t = 0; t < n; ++t) {
+    double z;
+    if (!has) {
+      x = nim_rand1(state);
+      y = nim_rand1(state);
+      z = sqrt(-2 * log(1.0 - x)) * cos(two_pi * y);
+      has = true;
+    } else {
+      z = sqrt(-2 * log(1.0 - x)) * sin(two_pi * y);
+      has = false;
+    }
+    out[t] = loc + z * scale;
+  }
+  return NFM_OK;
+}
+
+int32_t nfm_rng_shuffle(uint64_t* state, int64_t* x, int64_t n) {
+  NFM_CHECK(state && n >= 0 && (x || n == 0), NFM_ERR_INVALID, "null argument");
+  // shuffle: for i in countdown(high, 1): swap(x[i], x[rand(i)]); rand(max: int) rejects the top sliver of the
+  // 64-bit range and reduces modulo max + 1
+  const uint64_t rand_max = ~0ull;
+  for (int64_t i = n - 1; i >= 1; --i) {
+    uint64_t r;
+    do {
+      r = nim_next(state);
+    } while (r > rand_max - (rand_max % (uint64_t)i));
+    const int64_t j = (int64_t)(r % ((uint64_t)i + 1ull));
+    const int64_t t = x[i];
+    x[i] = x[j];
+    x[j] = t;
+  }
   return NFM_OK;
 }
 

@@ -583,6 +583,7 @@ __device__ __forceinline__ int64_t load_i64_unaligned(const unsigned char* p) {
 }
 
 __global__ void k_stream_split(const unsigned char* __restrict__ raw, int64_t base, int esize, int with_fields, int64_t n_rows,
+                               int64_t n_cols, int64_t n_fields,
                                const int64_t* __restrict__ indptr, int64_t nnz, int32_t* __restrict__ indices,
                                double* __restrict__ data, int32_t* __restrict__ fields, long long* __restrict__ st) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
@@ -601,7 +602,8 @@ __global__ void k_stream_split(const unsigned char* __restrict__ raw, int64_t ba
     data[e] = __longlong_as_double(vb);
     indices[e] = (int32_t)id;
     if (with_fields) fields[e] = (int32_t)f;
-    if (id < 0 || id > 2147483000ll || f < 0 || f > 2147483000ll) atomicAdd((unsigned long long*)&st[ST_MALFORMED], 1ull);
+    // an id / field beyond the header's nCols / nFields would index the parameter tables out of bounds later
+    if (id < 0 || id >= n_cols || f < 0 || (with_fields && f >= n_fields)) atomicAdd((unsigned long long*)&st[ST_MALFORMED], 1ull);
   }
 }
 
@@ -657,7 +659,13 @@ int ingest_stream(nfm_ctx* ctx, const char* x_path, const char* y_path, IngestRe
   memcpy(hdr, raw.data() + (with_fields ? 14 : 9), with_fields ? 32 : 24);
   const int64_t n = hdr[0], d = hdr[1], nnz = hdr[2], nf = with_fields ? hdr[3] : 0;
   NFM_CHECK(n >= 0 && d >= 0 && nnz >= 0 && d < (int64_t)2147483647 - 64, NFM_ERR_INVALID, "%s: bad header", x_path);
+  NFM_CHECK(!with_fields || (nf >= 0 && nf < (int64_t)2147483647), NFM_ERR_INVALID, "%s: bad nFields in the header", x_path);
   const int esize = with_fields ? 24 : 16;
+  // every row costs at least its 8-byte length word and every entry esize bytes: a header promising more than the
+  // file can hold is refused before anything is sized by it
+  NFM_CHECK(n <= (len - base) / 8 && nnz <= (len - base) / esize, NFM_ERR_INVALID,
+            "%s: the header promises %lld rows / %lld entries, the file holds %lld bytes", x_path, (long long)n, (long long)nnz,
+            (long long)len);
   std::vector<int64_t> indptr((size_t)n + 1);
   int64_t pos = base, acc = 0, max_row = 0;
   indptr[0] = 0;
@@ -665,7 +673,7 @@ int ingest_stream(nfm_ctx* ctx, const char* x_path, const char* y_path, IngestRe
     NFM_CHECK(pos + 8 <= len, NFM_ERR_INVALID, "%s: truncated at row %lld", x_path, (long long)i);
     int64_t r;
     memcpy(&r, raw.data() + pos, 8);
-    NFM_CHECK(r >= 0 && pos + 8 + r * esize <= len, NFM_ERR_INVALID, "%s: row %lld overruns the file", x_path, (long long)i);
+    NFM_CHECK(r >= 0 && r <= (len - pos - 8) / esize, NFM_ERR_INVALID, "%s: row %lld overruns the file", x_path, (long long)i);
     pos += 8 + r * esize;
     acc += r;
     indptr[i + 1] = acc;
@@ -684,12 +692,13 @@ int ingest_stream(nfm_ctx* ctx, const char* x_path, const char* y_path, IngestRe
   NFM_HIP_CHECK(hipMemcpyAsync(status.p, h_st, sizeof(h_st), hipMemcpyHostToDevice, st));
   if (nnz)
     hipLaunchKernelGGL(k_stream_split, dim3(grid_for(nnz)), dim3(kBlock), 0, st, dev_raw.as<unsigned char>(), base, esize,
-                       with_fields ? 1 : 0, n, out->indptr.as<int64_t>(), nnz, out->indices.as<int32_t>(),
+                       with_fields ? 1 : 0, n, d, nf, out->indptr.as<int64_t>(), nnz, out->indices.as<int32_t>(),
                        out->data.as<double>(), with_fields ? out->fields.as<int32_t>() : nullptr, status.as<long long>());
   NFM_HIP_CHECK(hipGetLastError());
   NFM_HIP_CHECK(hipMemcpyAsync(h_st, status.p, sizeof(h_st), hipMemcpyDeviceToHost, st));
   NFM_HIP_CHECK(hipStreamSynchronize(st));
-  NFM_CHECK(h_st[ST_MALFORMED] == 0, NFM_ERR_INVALID, "%s: %lld entries with an id or field outside int32", x_path, h_st[ST_MALFORMED]);
+  NFM_CHECK(h_st[ST_MALFORMED] == 0, NFM_ERR_INVALID, "%s: %lld entries with an id outside [0, nCols) or a field outside [0, nFields) of the header", x_path,
+            h_st[ST_MALFORMED]);
   NFM_TRY(out->y.alloc(sizeof(double) * std::max<int64_t>(n, 1)));
   if (y_path) {  // loadStreamLabel (dataset.nim:1007-1014): raw float64, one per sample
     std::vector<unsigned char> yraw;

@@ -23,13 +23,15 @@ struct MbWork {
   bool use_graph = true;
   void* graph_exec = nullptr;
   uint64_t graph_plan_serial = 0;
+  uint64_t graph_data_serial = 0;  // nfm_dataset::uid ^ serial mix the graph's captured dataset pointers belong to
   int graph_opt = -1;
   void drop_graph();
   ~MbWork();
 };
 
+// data_serial: changes whenever one of X's device pointers does (a captured graph holds them)
 int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
-                int64_t it0, double* out2_host);
+                int64_t it0, double* out2_host, uint64_t data_serial = 0);
 // psgd.hip: Params.step's shrink + the regulariser's prox after one mini-batch of MBPSGD (it = it0p[0] + it_b)
 void launch_psgd_step(nfm_ctx* ctx, const ModelView& M, const OptView& O, MbWork& W, const double* it0p, double it_b);
 // yhat / dloss of the samples of the last epoch call's batch (a single batch: pgd.predictAllWithGrad), device arrays

@@ -148,7 +148,7 @@ void MbWork::drop_graph() {
 MbWork::~MbWork() { drop_graph(); }
 
 int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
-                int64_t it0, double* out2_host) {
+                int64_t it0, double* out2_host, uint64_t data_serial) {
   NFM_CHECK(M.kind == NFM_KIND_FM, NFM_ERR_UNSUPPORTED, "mb_fm_epoch: FM only");
   NFM_CHECK(M.degree <= dev::kMaxDeg, NFM_ERR_UNSUPPORTED, "mini-batch mode supports degree <= %d", dev::kMaxDeg);
   NFM_CHECK(M.Kp == 2 * M.L && M.Kp <= 128, NFM_ERR_UNSUPPORTED, "mini-batch mode supports n_components <= 128");
@@ -179,7 +179,7 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   // (explicit permutations) launch directly.
   const bool want_graph = W.use_graph && !ctx->timing.enabled && !P.has_perm && P.n_batches >= 8;
   if (want_graph) {
-    if (!W.graph_exec || W.graph_plan_serial != P.serial || W.graph_opt != opt_kind) {
+    if (!W.graph_exec || W.graph_plan_serial != P.serial || W.graph_opt != opt_kind || W.graph_data_serial != data_serial) {
       W.drop_graph();
       hipGraph_t graph = nullptr;
       NFM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -196,6 +196,7 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
       NFM_HIP_CHECK(e2);
       W.graph_exec = exec;
       W.graph_plan_serial = P.serial;
+      W.graph_data_serial = data_serial;
       W.graph_opt = opt_kind;
     }
     NFM_HIP_CHECK(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(W.graph_exec), st));

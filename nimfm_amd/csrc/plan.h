@@ -13,7 +13,8 @@ namespace nfm {
 struct Plan {
   // identity (cache key)
   uint64_t serial = 0;  // unique per build
-  const void* ds = nullptr;
+  uint64_t ds_uid = 0;  // nfm_dataset::uid of the dataset the plan was built from (0 = none), and its nnz
+  int64_t ds_nnz = -1;
   int64_t begin = 0, end = 0, batch = 0;
   int n_aug = 0;
   bool first_singleton = false, has_perm = false, use_singles = false;
@@ -54,6 +55,11 @@ struct Plan {
 // many small segments make the per-feature sum of partials the new tail.)
 constexpr int kHeavyTouches = 128;
 constexpr int kHeavySegment = 64;
+
+// NFM_ERR_UNSUPPORTED when a row of X holds a column id twice (every training and predict kernel assumes distinct
+// ids per row; the reference's behaviour for repeats is an accident of its lazy scaling, optimizer/sgd.nim:134-143,
+// 176-188: the second entry overwrites the first one's derivative and the row's parameters are stepped twice with it)
+int check_rows_distinct(nfm_ctx* ctx, const CsrView& X);
 
 int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
                int64_t batch, bool first_singleton, bool want_tq, bool use_singles, bool sort_by_count, Plan* out);

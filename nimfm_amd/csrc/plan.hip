@@ -185,6 +185,76 @@ __global__ void k_set_i64(int64_t* p, int64_t n, int64_t v) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// ---- distinct column ids inside every row (include/nimfm_hip.h, nfm_dataset_create_csr) ----
+// one wavefront per row.  SORTED = false: counts the positions whose id is not larger than its predecessor's (0 = every
+// row is strictly increasing, hence distinct -- the common case, one pass over the ids).  SORTED = true (ids is a copy
+// sorted inside every row): counts equal neighbours = duplicates.
+template <bool SORTED>
+__global__ void k_row_order(int64_t n, const int64_t* __restrict__ indptr, const int32_t* __restrict__ ids,
+                            unsigned long long* __restrict__ count, long long* __restrict__ first_row) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  unsigned long long bad = 0;
+  for (int64_t r = wave0; r < n; r += nwaves) {
+    const int64_t q0 = indptr[r], q1 = indptr[r + 1];
+    bool row_bad = false;
+    for (int64_t q = q0 + 1 + lane; q < q1; q += kWave) {
+      const int32_t a = ids[q - 1], b = ids[q];
+      if (SORTED ? a == b : b <= a) {
+        ++bad;
+        row_bad = true;
+      }
+    }
+    if (row_bad) atomicMin(first_row, (long long)r);
+  }
+  if (bad) atomicAdd(count, bad);
+}
+
+int check_rows_distinct(nfm_ctx* ctx, const CsrView& X) {
+  if (X.n == 0 || X.nnz < 2 || X.max_row < 2) return NFM_OK;
+  hipStream_t st = ctx->stream;
+  DevBuf stat;
+  NFM_TRY(stat.alloc(16));
+  long long h[2] = {0, INT64_MAX};
+  auto run = [&](bool sorted, const int32_t* ids) -> int {
+    h[0] = 0;
+    h[1] = INT64_MAX;
+    NFM_HIP_CHECK(hipMemcpyAsync(stat.p, h, sizeof(h), hipMemcpyHostToDevice, st));
+    int64_t blocks = (X.n + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (sorted)
+      hipLaunchKernelGGL(k_row_order<true>, dim3((unsigned)blocks), dim3(kBlock), 0, st, X.n, X.indptr, ids,
+                         stat.as<unsigned long long>(), stat.as<long long>() + 1);
+    else
+      hipLaunchKernelGGL(k_row_order<false>, dim3((unsigned)blocks), dim3(kBlock), 0, st, X.n, X.indptr, ids,
+                         stat.as<unsigned long long>(), stat.as<long long>() + 1);
+    NFM_HIP_CHECK(hipGetLastError());
+    NFM_HIP_CHECK(hipMemcpyAsync(h, stat.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+    return NFM_OK;
+  };
+  NFM_TRY(run(false, X.indices));
+  if (h[0] == 0) return NFM_OK;  // every row strictly increasing
+  // some row is stored out of order (allowed, dataset.nim:597-612): sort a copy of the ids inside every row
+  NFM_CHECK(X.nnz < (int64_t)2147483647, NFM_ERR_UNSUPPORTED, "more than 2^31-1 nnz with unsorted rows");
+  DevBuf k0, k1, tmp;
+  NFM_TRY(k0.alloc(sizeof(int32_t) * X.nnz));
+  NFM_TRY(k1.alloc(sizeof(int32_t) * X.nnz));
+  NFM_HIP_CHECK(hipMemcpyAsync(k0.p, X.indices, sizeof(int32_t) * X.nnz, hipMemcpyDeviceToDevice, st));
+  hipcub::DoubleBuffer<int32_t> dk(k0.as<int32_t>(), k1.as<int32_t>());
+  size_t bytes = 0;
+  NFM_HIP_CHECK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, dk, (int)X.nnz, (int)X.n, X.indptr, X.indptr + 1, 0, 32, st));
+  NFM_TRY(tmp.alloc(bytes));
+  NFM_HIP_CHECK(hipcub::DeviceSegmentedRadixSort::SortKeys(tmp.p, bytes, dk, (int)X.nnz, (int)X.n, X.indptr, X.indptr + 1, 0, 32, st));
+  NFM_TRY(run(true, dk.Current()));
+  NFM_CHECK(h[0] == 0, NFM_ERR_UNSUPPORTED,
+            "%lld repeated column ids inside rows (first in row %lld): the ids of one row must be distinct -- merge "
+            "repeated entries before creating the dataset",
+            h[0], h[1]);
+  return NFM_OK;
+}
+
 static inline unsigned grid1d(int64_t n) {
   int64_t b = (n + kBlock - 1) / kBlock;
   if (b < 1) b = 1;

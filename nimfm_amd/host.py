@@ -175,6 +175,64 @@ def newCSRFieldDataset(data, indices, indptr, fields, nSamples, nFeatures, nFiel
     return CSRDataset(data, indices, indptr, nSamples, nFeatures, fields=fields, nFields=nFields, ctx=ctx)
 
 
+# ------------------------------------------------------------------------------------------------
+# Nim's global random number generator, as the reference uses it: randomize(seed) in init
+# (model/factorization_machine.nim:131), randomNormal for P (tensor/tensor.nim:561-580), shuffle(indices) in fit
+# (optimizer/sgd.nim:297).  The procedures live in the library (nfm_rng_*, host code); the generator itself is
+# outside the reference tree and restated from memory (unverified, include/nimfm_hip.h).
+# ------------------------------------------------------------------------------------------------
+class NimRand:
+    def __init__(self, seed=None):
+        self.state = (C.c_uint64 * 2)(0x69B4C98CB8530805, 0xFED1DD3004688D68)  # Nim's default global state
+        if seed is not None:
+            self.randomize(seed)
+
+    def randomize(self, seed):
+        capi.check(capi.lib().nfm_rng_randomize(int(seed), self.state))
+
+    def randomNormal(self, shape, loc=0.0, scale=1.0):
+        """tensor/tensor.nim:561-580: row-major fill, the cosine / sine halves of one draw on consecutive elements"""
+        out = np.empty(int(np.prod(shape)), dtype=np.float64)
+        capi.check(capi.lib().nfm_rng_random_normal(self.state, out.size, float(loc), float(scale), _vp(out)))
+        return out.reshape(shape)
+
+    def shuffle(self, x):
+        """in place, Nim's shuffle: for i in countdown(high, 1): swap(x[i], x[rand(i)])"""
+        assert x.dtype == np.int64 and x.flags["C_CONTIGUOUS"]
+        capi.check(capi.lib().nfm_rng_shuffle(self.state, _vp(x), len(x)))
+
+
+_global_rng = None
+
+
+def globalRand():
+    global _global_rng
+    if _global_rng is None:
+        _global_rng = NimRand()
+    return _global_rng
+
+
+def randomize(seed):
+    globalRand().randomize(seed)
+
+
+def randomNormal(shape, loc=0.0, scale=1.0, uniform=None):
+    """tensor/tensor.nim:561-580.  uniform: an explicit stream of rand(1.0) draws (array, 2 per pair of elements)
+    instead of the global generator -- the same pairing and fill order, vectorised."""
+    if uniform is None:
+        return globalRand().randomNormal(shape, loc, scale)
+    n = int(np.prod(shape))
+    u = _f64(uniform)[: 2 * ((n + 1) // 2)]
+    if len(u) < 2 * ((n + 1) // 2):
+        raise ValueError("randomNormal needs %d uniform draws" % (2 * ((n + 1) // 2)))
+    x, y = u[0::2], u[1::2]
+    r = np.sqrt(-2 * np.log(1.0 - x))
+    z = np.empty(2 * len(x))
+    z[0::2] = r * np.cos(2 * math.pi * y)
+    z[1::2] = r * np.sin(2 * math.pi * y)
+    return (loc + z[:n] * scale).reshape(shape)
+
+
 def expit(x):
     """utils.nim:33"""
     x = np.asarray(x, dtype=np.float64)
@@ -202,6 +260,7 @@ class _ModelBase:
 
     def __init__(self):
         self._h = None
+        self._gen = 0  # bumps whenever the device model is released: optimizers built on it are stale then
         self._ctx = None
         self._dirty = True
         self._P = None
@@ -267,8 +326,10 @@ class _ModelBase:
         self._dirty = False
 
     def _release(self):
-        if self._h is not None and capi.alive:
-            capi.lib().nfm_model_destroy(self._h)
+        if self._h is not None:
+            self._gen += 1
+            if capi.alive:
+                capi.lib().nfm_model_destroy(self._h)
         self._h = None
 
     def __del__(self):
@@ -368,18 +429,17 @@ class FactorizationMachine(_ModelBase):
             raise ValueError("Invalid nFeatures.")
 
     def init(self, X, force=False):
-        """model/factorization_machine.nim:125-139.  The reference draws P with Nim's stdlib RNG
-        (Box-Muller over xoroshiro128+), which is not part of the reference tree; numpy's generator
-        seeded with randomState is used instead (RNG parity is unpinned)."""
+        """model/factorization_machine.nim:125-139: randomize(randomState); w = 0; P = randomNormal([nOrders,
+        nComponents, nFeatures + nAugments], scale) -- Box-Muller pairs along the row-major fill -- intercept = 0.
+        (The generator behind randomize / rand is Nim's stdlib, restated unverified: see NimRand.)"""
         if force or not (self.warmStart and self.isInitialized):
             d = X.nFeatures
-            rng = np.random.default_rng(self.randomState)
-            self._rng = rng
+            randomize(self.randomState)
             if self._d != d:
                 self._release()
             self._d = d
             self.w = np.zeros(d)
-            self.P = rng.standard_normal((self.nOrders, self.nComponents, d + self.nAugments)) * self.scale
+            self.P = randomNormal((self.nOrders, self.nComponents, d + self.nAugments), scale=self.scale)
             self.intercept = 0.0
         self.isInitialized = True
 
@@ -504,13 +564,12 @@ class FieldAwareFactorizationMachine(_ModelBase):
         """model/field_aware_factorization_machine.nim:79-92"""
         if force or not (self.warmStart and self.isInitialized):
             d, F = X.nFeatures, X.nFields
-            rng = np.random.default_rng(self.randomState)
-            self._rng = rng
+            randomize(self.randomState)
             if (self._d, self._F) != (d, F):
                 self._release()
             self._d, self._F = d, F
             self.w = np.zeros(d)
-            self.P = rng.standard_normal((F, d, self.nComponents)) * self.scale
+            self.P = randomNormal((F, d, self.nComponents), scale=self.scale)
             self.intercept = 0.0
         self.isInitialized = True
 
@@ -636,11 +695,13 @@ class _OptimizerBase:
     def _handle(self, fm, ctx, mode):
         mh = fm._push(ctx)
         key = (mode, self.batch) + self._cfg_key()  # a changed hyper-parameter needs a new device optimizer
-        if self._h is None or self._model is not fm or self._mode_built != key or self._mh != mh.value:
+        # the device optimizer belongs to ONE device model: a model that was released and created again (init /
+        # set_params with another nFeatures) may sit at the same address -- compared by generation, not by pointer
+        if self._h is None or self._model is not fm or self._mode_built != key or self._mh != (mh.value, fm._gen):
             self._release()
             self._h = C.c_void_p()
             self._create(mh, mode)
-            self._model, self._mode_built, self._mh = fm, key, mh.value
+            self._model, self._mode_built, self._mh = fm, key, (mh.value, fm._gen)
         return self._h
 
     def _cfg_key(self):
@@ -683,7 +744,7 @@ class _OptimizerBase:
         if self.verbose > 0:
             _echo_header(self.maxIter)
         n = X.nSamples
-        rng = getattr(fm, "_rng", None) or np.random.default_rng(getattr(fm, "randomState", 1))
+        rng = globalRand()  # the reference shuffles with Nim's global generator, seeded by fm.init (sgd.nim:297)
         indices = np.arange(n, dtype=np.int64)
         isConverged = False
         per_epoch_cb = self._per_epoch_callback(callback)
@@ -924,7 +985,7 @@ class MBPSGD(_OptimizerBase):
         if sfm._dirty:
             sfm._push(X.ctx)
         capi.check(capi.lib().nfm_opt_set_it(self._h, self.it))
-        rng = getattr(sfm, "_rng", None) or np.random.default_rng(getattr(sfm, "randomState", 1))
+        rng = globalRand()
         indices = np.arange(n, dtype=np.int64)
         ii = 0
         if stream is None and self.shuffle:

@@ -50,6 +50,53 @@ class PSGDCfg(C.Structure):
 
 
 _lib = None
+_libs = {}
+
+
+def _load(path):
+    L = C.CDLL(path)
+    for name in ("orc_loss", "orc_dloss", "orc_get_eta", "orc_expit", "orc_rmse", "orc_accuracy_sign",
+                 "orc_regularization", "slow_anova", "orc_reg_eval"):
+        getattr(L, name).restype = C.c_double
+    L.orc_loss.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double]
+    L.orc_dloss.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double]
+    L.orc_get_eta.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int64]
+    L.orc_expit.argtypes = [C.c_double]
+    return L
+
+
+class variant:
+    """`with oracle.variant("timing"):` -- the same C sources built -O3 -march=native on THIS machine (oracle/Makefile
+    target `timing`), for bench.py's cpu_baseline leg only; parity tests use the default -O2 -ffp-contract=off build."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _lib
+        self.prev = _lib
+        if self.name == "timing":
+            if "timing" not in _libs:
+                so = os.path.join(_HERE, "_build", "libnimfm_oracle_timing.so")
+                if os.path.exists(so):
+                    os.remove(so)  # -march=native: never reuse a build made on another host
+                subprocess.check_call(["make", "-C", _HERE, "-s", "timing"])
+                _libs["timing"] = _load(so)
+            _lib = _libs["timing"]
+        else:
+            _lib = None
+            lib()
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+
+
+def epoch_seconds(n):
+    """wall-clock seconds of the first n epochs of the last *_fit call of the active build"""
+    arr = (C.c_double * 64).in_dll(lib(), "orc_epoch_seconds")
+    return [arr[i] for i in range(min(n, 64))]
 
 
 def lib():

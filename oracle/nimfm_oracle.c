@@ -6,12 +6,24 @@
  * loop nests, same operation order, same lazy-scaling bookkeeping, on flat
  * arrays instead of Nim's jagged seq-of-seq.  Citations: /root/reference/.
  */
+#define _POSIX_C_SOURCE 200809L /* clock_gettime under -std=c99 */
 #include "nimfm_oracle.h"
 
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+/* wall-clock seconds of every epoch of the last *_fit call (bench.py's cpu_baseline leg reads them: the layout
+ * transposes around the epoch loop, optimizer/sgd.nim:292,328, are per fit, not per epoch) */
+#define ORC_MAX_TIMED_EPOCHS 64
+double orc_epoch_seconds[ORC_MAX_TIMED_EPOCHS];
+static double orc_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 /* ------------------------------------------------------------------ */
 /* losses: loss.nim:15-102                                             */
@@ -436,11 +448,13 @@ int orc_fm_sgd_fit(const orc_csr* X, const double* y, int degree, int k, int n_o
   int is_converged = 0, epochs = 0;
   for (int epoch = 0; epoch < max_iter; epoch++) {
     double viol = 0.0, running_loss = 0.0;
+    const double t_epoch = orc_now();
     for (int64_t ii = 0; ii < n; ii++) {
       const int64_t i = perms ? perms[(size_t)epoch * n + ii] : ii;
       fm_sgd_step(&S, X, i, y[i], degree, n_aug, A, dA, &running_loss, &viol);
       S.it++; /* sgd.nim:308 */
     }
+    if (epoch < ORC_MAX_TIMED_EPOCHS) orc_epoch_seconds[epoch] = orc_now() - t_epoch;
     running_loss /= (double)n;
     if (epoch_loss) epoch_loss[epoch] = running_loss;
     if (epoch_viol) epoch_viol[epoch] = viol;
@@ -502,6 +516,7 @@ int orc_fm_sgd_fit_hogwild(const orc_csr* X, const double* y, int degree, int k,
   int is_converged = 0, epochs = 0;
   for (int epoch = 0; epoch < max_iter; epoch++) {
     double viol = 0.0, running_loss = 0.0;
+    const double t_epoch = orc_now();
     /* in-memory CSR: nCached == nSamples, one pass of the while loop (sgd_multi.nim:83-101) */
     borders[0] = 0;
     for (int t = 0; t < n_threads; t++) borders[t + 1] = borders[t] + n / n_threads;
@@ -518,6 +533,7 @@ int orc_fm_sgd_fit_hogwild(const orc_csr* X, const double* y, int degree, int k,
       running_loss += args[t].loss;
       viol += args[t].viol;
     }
+    if (epoch < ORC_MAX_TIMED_EPOCHS) orc_epoch_seconds[epoch] = orc_now() - t_epoch;
     running_loss /= (double)n;
     if (epoch_loss) epoch_loss[epoch] = running_loss;
     if (epoch_viol) epoch_viol[epoch] = viol;
@@ -667,6 +683,7 @@ int orc_fm_adagrad_fit(const orc_csr* X, const double* y, int degree, int k, int
   int is_converged = 0, epochs = 0;
   for (int epoch = 0; epoch < max_iter; epoch++) {
     double viol = 0.0, running_loss = 0.0;
+    const double t_epoch = orc_now();
     for (int64_t ii = 0; ii < n; ii++) {
       const int64_t i = perms ? perms[(size_t)epoch * n + ii] : ii;
       row_view r = get_row(X, i);
@@ -677,6 +694,7 @@ int orc_fm_adagrad_fit(const orc_csr* X, const double* y, int degree, int k, int
       ada_update_g(&S, r, n_aug, dA, y[i], y_pred);
       S.it++;
     }
+    if (epoch < ORC_MAX_TIMED_EPOCHS) orc_epoch_seconds[epoch] = orc_now() - t_epoch;
     running_loss /= (double)n;
     if (epoch_loss) epoch_loss[epoch] = running_loss;
     if (epoch_viol) epoch_viol[epoch] = viol;

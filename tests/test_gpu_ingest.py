@@ -173,3 +173,17 @@ def test_stream_files(tmp_path):
     (tmp_path / "junk.bin").write_bytes(b"hello world, not a matrix")
     with pytest.raises(ValueError, match="not a StreamCSR"):
         nf.newStreamCSRDataset(str(tmp_path / "junk.bin"))
+    # a header whose nCols is smaller than the ids the rows hold (they would index P / w out of bounds), whose nFields
+    # is smaller than the fields, or whose nRows the file cannot hold
+    import struct
+    n_, d_, nnz_ = struct.unpack_from("<qqq", xb, 9)
+    (tmp_path / "cols.bin").write_bytes(xb[:9] + struct.pack("<qqq", n_, max(1, d_ // 2), nnz_) + xb[33:])
+    with pytest.raises(ValueError, match="outside"):
+        nf.newStreamCSRDataset(str(tmp_path / "cols.bin"))
+    (tmp_path / "rows.bin").write_bytes(xb[:9] + struct.pack("<qqq", 1 << 60, d_, nnz_) + xb[33:])
+    with pytest.raises(ValueError, match="promises"):
+        nf.newStreamCSRDataset(str(tmp_path / "rows.bin"))
+    nF = struct.unpack_from("<q", fb, 14 + 24)[0]
+    (tmp_path / "nf.bin").write_bytes(bytes(fb[:14 + 24]) + struct.pack("<q", nF - 1) + bytes(fb[14 + 32:]))
+    with pytest.raises(ValueError, match="outside"):
+        nf.newStreamCSRDataset(str(tmp_path / "nf.bin"))

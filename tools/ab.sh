@@ -5,7 +5,7 @@ set -e
 read WL N B <<< "$1"; shift
 mkdir -p gpurun_out
 for L in "$@"; do
-  NIMFM_HIP_LIB=$(pwd)/nimfm_amd/lib/$L python3 bench.py --workload $WL --n $N --batch $B --no-cpu-baseline > gpurun_out/ab_tmp.json
+  NIMFM_HIP_LIB=$(pwd)/nimfm_amd/lib/$L python3 bench.py --workload $WL --n $N --batch $B --no-cpu-baseline --no-extra > gpurun_out/ab_tmp.json
   python3 - "$L" "$WL" "$B" <<'PY'
 import json, sys
 j = json.load(open("gpurun_out/ab_tmp.json"))
