@@ -101,7 +101,7 @@ def write_svmlight_file(path, n, d, m, seed):
     with open(path, "w") as f:
         for lo in range(0, n, 50_000):
             hi = min(n, lo + 50_000)
-            idx = np.sort(rng.integers(1, d + 1, size=(hi - lo, m)), axis=1)
+            idx = 1 + np.arange(m) * (d // m) + rng.integers(0, d // m, size=(hi - lo, m))  # distinct inside a row
             val = rng.uniform(-1, 1, size=(hi - lo, m))
             y = np.sign(rng.standard_normal(hi - lo))
             f.write("".join(

@@ -188,6 +188,7 @@ def test_plan_cache_is_keyed_by_dataset_identity_not_address():
         Xo = random_csr(n, d, m, seed=seed)
         X = to_gpu(Xo)
         fm.set_params(P0, w0, 0.0)
+        sgd.it = 1  # a warm-started model keeps the optimizer's step count (sgd.nim:288-289)
         sgd.fit(X, y, fm)
         P, w = P0.copy(), w0.copy()
         b, *_ = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, 0.0, O.sgd_cfg(), B, it=1)
