@@ -14,6 +14,9 @@ namespace nfm {
 #ifndef NFM_COL_MINW
 #define NFM_COL_MINW 1
 #endif
+#ifndef NFM_ADA2_MINW
+#define NFM_ADA2_MINW 2
+#endif
 
 struct SampleRec {
   double dL, etaP, etaw, yhat;  // yhat: the sample's prediction (read back by predictAllWithGrad)
@@ -35,7 +38,7 @@ struct RowArgs {
   OptView O;
   const int64_t* perm;  // relative to begin, or null
   int64_t begin, p0;    // first sample of the batch = begin + p0 (position), identity when perm null
-  int32_t len, use_stored, TA, pad_;
+  int32_t len, use_stored, TA, nt;  // nt: parameter / state rows are streamed (tables far larger than the caches)
   double it_b;            // batch start relative to the epoch call; the absolute step is it0p[0] + it_b
   const double* it0p;     // device scalar: the optimizer's `it` at the start of the epoch call
   const double* scales;  // {scale_P, scale_w} at the batch start
@@ -47,6 +50,30 @@ struct RowArgs {
   PartA* parts;          // [gridDim.x]
 };
 
+// Rows that a batch reads once and writes at most once (tables far larger than L2 / the Infinity Cache) are moved with
+// the non-temporal hint: they stop evicting the samples' A rows and records the column phase gathers from L2, and
+// dirty lines no longer queue behind reads.  Measured on the cfg3 shape (AdaGrad, d = 1e6, k = 64, B = 8192):
+// stores 264 -> 249 us row phase and 94.7 -> 90.8 us column phase, loads as well 249 -> 238 us.
+__device__ __forceinline__ void st_nt(double* p, double2 v) {
+  dev::v2d_t w;
+  w.x = v.x;
+  w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<dev::v2d_t*>(p));
+}
+__device__ __forceinline__ double2 ld_nt(const double* p) {
+  const dev::v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const dev::v2d_t*>(p));
+  return double2{v.x, v.y};
+}
+template <bool NT>
+__device__ __forceinline__ void st_row(double* p, double2 v) {
+  if (NT) st_nt(p, v);
+  else *reinterpret_cast<double2*>(p) = v;
+}
+template <bool NT>
+__device__ __forceinline__ double2 ld_row(const double* p) {
+  if (NT) return ld_nt(p);
+  return *reinterpret_cast<const double2*>(p);
+}
 // forward over all orders; returns this lane's share of sum_o sum_s kernel (non-zero in slot 0
 // only) and stores the A rows the column phase needs.  GEN = false: the model is a single order of
 // degree 2 (the common case), whose A1 is also returned for the in-place update of singles.
@@ -240,6 +267,11 @@ __device__ __forceinline__ double lane_bcast_d(double v, int u, int slot) {
 //           the single-touch rows written once.
 //   MODE 3  MODE 1 for rows of any length: the row is taken in chunks of held_capacity entries (a
 //           separate instantiation: the chunk loop costs registers -- 38 vs 26 us on cfg2's row phase).
+//   MODE 4  MODE 2 with the single-touch rows written back non-temporally (tables far larger than the caches:
+//           the written rows are not read again before a later batch, and as ordinary stores they evict the A rows
+//           and records the column phase is about to gather -- headline shape: column phase 57.7 -> 56.0 us, row
+//           phase 98 -> 97 us; non-temporal LOADS of the same rows cost the column phase its Infinity-Cache hits
+//           on the multi-touch rows: 57.7 -> 64.8 us)
 template <int L, int SPLIT>
 constexpr int held_entries() {  // E: entries per lane; 0 = no held mode for this lane mapping
   constexpr int LPS = L * SPLIT;
@@ -253,11 +285,11 @@ constexpr int held_entries() {  // E: entries per lane; 0 = no held mode for thi
 #define NFM_REG_MINW 3
 #endif
 template <int L, int SPLIT, int OPT, bool GEN, int MODE, bool SING>
-__global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_phase(RowArgs a) {
+__global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 4 ? NFM_REG_MINW : 1)) void k_row_phase(RowArgs a) {
   constexpr int LPS = L * SPLIT, SPW = kWave / LPS, SPB = kWavesPerBlock * SPW;  // samples per wave / block
   constexpr int E = held_entries<L, SPLIT>() > 0 ? held_entries<L, SPLIT>() : 1;
   constexpr bool HELD = MODE >= 1 && held_entries<L, SPLIT>() > 0;  // GEN models: MODE 1 / 3 only (host)
-  constexpr bool REG = MODE == 2 && HELD && OPT == OPT_SGD && LPS == kWave;
+  constexpr bool REG = (MODE == 2 || MODE == 4) && HELD && OPT == OPT_SGD && LPS == kWave;
   constexpr bool CHUNKED = MODE == 3;  // rows longer than one chunk of held entries
   constexpr int NQ = REG ? L : 1;       // row pieces per lane kept in registers
   constexpr int RPS = E * L;            // rows per slot in held mode
@@ -617,7 +649,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
             r_viol += fabs((ax + etaP * O.beta * px) / 1.0) + fabs((ay + etaP * O.beta * py) / 1.0);
             st.x = st.x - ax * rsPn;
             st.y = st.y - ay * rsPn;
-            *reinterpret_cast<double2*>(M.P + (size_t)j * M.Kp + 2 * l) = st;
+            st_row<MODE == 4>(M.P + (size_t)j * M.Kp + 2 * l, st);
           }
         }
       } else {
@@ -731,6 +763,184 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 ? NFM_REG_MINW : 1)) void k_row_
       }
     } else {
       p = PartA{s_part[0], 0.0, s_part[2], s_part[3]};
+    }
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) p.viol += s_viol[w_];
+    a.parts[blockIdx.x] = p;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row phase, AdaGrad at 32 < k <= 64 (cfg3): TWO wavefronts per sample, state resident in registers
+// ------------------------------------------------------------------------------------------------
+// The parameters of AdaGrad are a function of (g_sum, g_norm, it) (optimizer/adagrad.nim:96-98), so the forward pass
+// reads BOTH state rows of every feature of the sample, and the in-place update of the single-touch features (about
+// 60 % of a batch's touches at the cfg3 shape) needs them again: k_row_phase<.., MODE 1> reads them a second time
+// (39 KB of the 182 KB a sample moves).  One wavefront cannot hold 64 rows x 2 tensors x 512 B (256 + 140 registers,
+// one wavefront per SIMD: measured slower).  Here a sample is split by FACTORS over the two
+// wavefronts of a pair: each holds the g_sum / g_norm HALF rows (32 factors = 256 B, 16 lanes x 16 B) of up to 64
+// entries in 128 registers, the pair exchanges one double through LDS (its share of the prediction), and the update
+// of the single-touch rows issues no state load at all.  Rows of at most 64 entries (incl. dummies), one order of
+// degree 2, singles updated in the row phase, not the stored-parameter batch (host: run_batches).
+template <int OPT, bool NT>  // NT: state / parameter rows streamed (tables far larger than the caches)
+__global__ __launch_bounds__(kBlock, NFM_ADA2_MINW) void k_row_phase_ada2(RowArgs a) {
+  static_assert(OPT == OPT_ADAGRAD, "AdaGrad only");
+  constexpr int SPLIT = 4, NU = 16, SPB = 2;  // row slots per wavefront, rows per slot, samples per workgroup
+  __shared__ double s_part[SPB][2], s_loss[SPB], s_acc0[SPB], s_acc1[SPB], s_viol[kWavesPerBlock];
+  const CsrView& X = a.X;
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int sib = wv >> 1, half = wv & 1;
+  const int slot = lane >> 4, l = lane & 15;
+  const int pib = __builtin_amdgcn_readfirstlane(blockIdx.x * SPB + sib);
+  const bool valid = pib < a.len;
+  int64_t q0 = 0;
+  int m = 0, m_tot = 0;
+  double y = 0.0;
+  if (valid) {
+    const int64_t pos = a.p0 + pib;
+    const int64_t i = a.perm ? a.perm[pos] : a.begin + pos;
+    q0 = X.indptr[i];
+    m = (int)(X.indptr[i + 1] - q0);
+    m_tot = m + M.n_aug;
+    y = wave_uniform(dev::target_of(X.y[i], M.task));
+  }
+  const double itp = (a.it0p[0] + a.it_b) - 1.0;  // it' = it_b - 1 (adagrad.nim:90)
+  const double tmpP = O.eta0 * itp * O.beta, denw = itp * O.eta0 * O.alpha;
+  const size_t eoff = (size_t)half * 32 + 2 * l;  // this lane's factor pair inside a parameter row
+  // the sample's entries, one per lane (entry q = lane; past the end: (row 0, x = 0), no flag)
+  int jq, fq;
+  double xq;
+  dev::row_entry(X, q0, m, m_tot, lane, jq, xq);
+  const uint8_t* sg = valid ? a.single + a.toff[a.p0 + pib] : nullptr;
+  fq = (sg != nullptr && lane < m_tot) ? (int)sg[lane] : 0;
+  // linear term and intercept: the first wavefront of the pair
+  double wq = 0.0, gwq = 0.0, nwq = 0.0, part = 0.0;
+  if (half == 0 && lane < m) {
+    wq = M.w[jq];
+    double wj = wq;
+    if (M.fit_linear) {
+      gwq = O.Gw[jq];
+      nwq = O.Nw[jq];
+      wj = -O.eta0 * gwq / (denw + sqrt(nwq));
+    }
+    part = wj * xq;
+  }
+  // ---- 1. all state half rows in flight at once, then the forward pass from registers ----
+  double2 G[NU], N[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int jj = lane_bcast_i<SPLIT>(jq, u, slot);
+    const size_t e = (size_t)jj * M.Kp + eoff;
+    G[u] = ld_row<NT>(O.G + e);
+    N[u] = ld_row<NT>(O.N + e);
+  }
+  double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const double xx = lane_bcast_d<SPLIT>(xq, u, slot);
+    const double px = dev::adagrad_param(G[u].x, N[u].x, O.eta0, tmpP), py = dev::adagrad_param(G[u].y, N[u].y, O.eta0, tmpP);
+    const double tx = xx * px, ty = xx * py;
+    a1.x += tx;
+    a1.y += ty;
+    a2.x += tx * tx;
+    a2.y += ty * ty;
+    // one row at a time: interleaving the sqrt / divide sequences of several rows costs dozens of registers next to
+    // the 128 that hold the state
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int s = 16; s < kWave; s <<= 1) {
+    a1.x += dev::shfl_xor_d(a1.x, s);
+    a1.y += dev::shfl_xor_d(a1.y, s);
+    a2.x += dev::shfl_xor_d(a2.x, s);
+    a2.y += dev::shfl_xor_d(a2.y, s);
+  }
+  if (valid && slot == 0) *reinterpret_cast<double2*>(a.Abuf + (size_t)pib * a.TA * M.Kp + eoff) = a1;
+  if (slot == 0) part += (a1.x * a1.x - a2.x) / 2 + (a1.y * a1.y - a2.y) / 2;
+  part = dev::wave_sum(part);
+  if (lane == 0) s_part[sib][half] = part;
+  __syncthreads();
+  // ---- 2. prediction, loss derivative (both wavefronts of the pair form the same values) ----
+  double b0 = M.sc[SC_INTERCEPT];
+  if (M.fit_intercept) b0 = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * itp * O.alpha0);
+  const double yh = wave_uniform(b0 + (s_part[sib][0] + s_part[sib][1]));
+  const double dL = wave_uniform(dev::loss_grad(O.loss, O.loss_param, y, yh));
+  if (half == 0 && lane == 0) {
+    if (valid) a.rec[pib] = SampleRec{dL, 0.0, 0.0, yh};
+    s_acc0[sib] = (valid && M.fit_intercept) ? dL : 0.0;
+    s_acc1[sib] = (valid && M.fit_intercept) ? dL * dL : 0.0;
+  }
+  // ---- 3. single-touch features: updated from the resident state, written once ----
+  // (the entries are made opaque here: otherwise the compiler keeps the 16 row addresses of the forward pass -- 96
+  // registers for the three tensors -- alive next to the state instead of re-deriving them from jq)
+  asm volatile("" : "+v"(jq), "+v"(fq), "+v"(xq));
+  double r_viol = 0.0;
+#ifndef NFM_ADA2_V
+#define NFM_ADA2_V 8
+#endif
+  constexpr int V = NFM_ADA2_V;  // stored-parameter rows requested together (one round trip per group)
+#pragma unroll
+  for (int u0 = 0; u0 < NU; u0 += V) {
+    int f[V], j[V];
+    double xv[V];
+    double2 po[V];
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      f[u] = lane_bcast_i<SPLIT>(fq, u0 + u, slot);
+      j[u] = lane_bcast_i<SPLIT>(jq, u0 + u, slot);
+      xv[u] = lane_bcast_d<SPLIT>(xq, u0 + u, slot);
+    }
+    if (O.track_viol) {  // adagrad.nim:99: sum |P_old - P_new| needs the parameters as last stored
+#pragma unroll
+      for (int u = 0; u < V; ++u) {
+        po[u] = {0.0, 0.0};
+        if (f[u]) po[u] = ld_row<NT>(M.P + (size_t)j[u] * M.Kp + eoff);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      if (!f[u]) continue;
+      const size_t e = (size_t)j[u] * M.Kp + eoff;
+      double2 g2 = G[u0 + u], n2 = N[u0 + u], p;
+      // recomputed, not carried over from the forward pass (the compiler would park 64 more values per lane in scratch)
+      asm volatile("" : "+v"(g2.x), "+v"(g2.y), "+v"(n2.x), "+v"(n2.y));
+      p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmpP);
+      p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmpP);
+      if (O.track_viol) {
+        r_viol += fabs(po[u].x - p.x) + fabs(po[u].y - p.y);
+        st_row<NT>(M.P + e, p);
+      }
+      const double gx = dL * (xv[u] * (a1.x - p.x * xv[u])), gy = dL * (xv[u] * (a1.y - p.y * xv[u]));
+      g2.x += gx;
+      g2.y += gy;
+      n2.x += gx * gx;
+      n2.y += gy * gy;
+      st_row<NT>(O.G + e, g2);
+      st_row<NT>(O.N + e, n2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (half == 0 && M.fit_linear && fq && lane < m) {  // fit_linear.nim:50-57, one entry per lane
+    const double wj = -O.eta0 * gwq / (denw + sqrt(nwq));
+    r_viol += fabs(wq - wj);
+    M.w[jq] = wj;
+    const double g = dL * xq;
+    O.Gw[jq] = gwq + g;
+    O.Nw[jq] = nwq + g * g;
+  }
+  r_viol = dev::wave_sum(r_viol);
+  if (lane == 0) {
+    s_viol[wv] = r_viol;
+    if (half == 0) s_loss[sib] = valid ? dev::loss_value(O.loss, O.loss_param, y, yh) : 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PartA p{0.0, 0.0, 0.0, 0.0};
+    for (int s_ = 0; s_ < SPB; ++s_) {
+      p.loss += s_loss[s_];
+      p.acc0 += s_acc0[s_];
+      p.acc1 += s_acc1[s_];
     }
     for (int w_ = 0; w_ < kWavesPerBlock; ++w_) p.viol += s_viol[w_];
     a.parts[blockIdx.x] = p;
@@ -1330,7 +1540,9 @@ static void launch_row(hipStream_t st, const RowArgs& ra, int mode, int n_cu, in
   *n_blocks = nA;
   constexpr bool CAN_HOLD = held_entries<L, SPLIT>() > 0;
   constexpr bool CAN_REG = CAN_HOLD && !GEN && OPT == OPT_SGD && L * SPLIT == kWave;
-  if (CAN_REG && mode == 2)
+  if (CAN_REG && mode == 2 && ra.nt)
+    hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 4 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
+  else if (CAN_REG && mode == 2)
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_REG ? 2 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
   else if (CAN_HOLD && mode == 3)
     hipLaunchKernelGGL((k_row_phase<L, SPLIT, OPT, GEN, (CAN_HOLD ? 3 : 0), false>), dim3(nA), dim3(kBlock), 0, st, ra);
@@ -1368,6 +1580,11 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
   // as extra workgroups of the column launch the sum of the times was conserved as well: the memory
   // system is the limit, not latency).
   const bool have_singles = !GEN && P.use_singles;
+  // tables far beyond the 256 MB Infinity Cache, batches that visit most rows once: stream them (st_nt / ld_nt above);
+  // NFM_STREAM=0|1 overrides
+  static const int stream_env = getenv("NFM_STREAM") ? atoi(getenv("NFM_STREAM")) : -1;
+  const size_t table_bytes = sizeof(double) * (size_t)M.nb * M.da * M.Kp * (OPT == OPT_ADAGRAD ? 3 : 1);
+  const bool stream_rows = stream_env >= 0 ? stream_env != 0 : (have_singles && table_bytes > ((size_t)384 << 20));
   static const bool env_kernel = getenv("NFM_SINGLES_KERNEL") && atoi(getenv("NFM_SINGLES_KERNEL")) != 0;
   const bool singles_in_row = have_singles && !env_kernel;
   const bool singles_in_col = have_singles && !singles_in_row;
@@ -1396,13 +1613,24 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     };
     int nA;
     {
-      RowArgs ra{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, P.begin, p0, len, use_stored, TA, 0, it_b, it0p,
+      RowArgs ra{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, P.begin, p0, len, use_stored, TA, stream_rows ? 1 : 0, it_b, it0p,
                  OPT == OPT_SGD ? Stab + 2 * b : M.sc, OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc,
                  singles_in_row ? P.toff.as<int64_t>() : nullptr,
                  singles_in_row ? P.single.as<uint8_t>() : nullptr, W.Abuf.as<double>(), W.rec.as<SampleRec>(),
                  W.partsA.as<PartA>()};
       TimedLaunch tl(ctx, "row_phase");
       int s_used;
+      // AdaGrad, 32 < k <= 64, rows of at most 64 entries, singles in the row phase: two wavefronts per sample with the
+      // state rows resident in registers (k_row_phase_ada2; NFM_ADA2=0 switches it off)
+      static const bool ada2_on = !(getenv("NFM_ADA2") && atoi(getenv("NFM_ADA2")) == 0);
+      if (OPT == OPT_ADAGRAD && !GEN && L == 32 && ada2_on && singles_in_row && !use_stored && X.max_row + M.n_aug <= 64) {
+        nA = (len + 1) / 2;
+        if (stream_rows)
+          hipLaunchKernelGGL((k_row_phase_ada2<OPT_ADAGRAD, true>), dim3(nA), dim3(kBlock), 0, st, ra);
+        else
+          hipLaunchKernelGGL((k_row_phase_ada2<OPT_ADAGRAD, false>), dim3(nA), dim3(kBlock), 0, st, ra);
+        s_used = 2;
+      } else
       if (R >= 16 && split >= 16) { launch_row<L, (R >= 16 ? 16 : R), ROPT, GEN>(st, ra, mode_for(R >= 16 ? 16 : R), ctx->n_cu, &nA); s_used = R >= 16 ? 16 : R; }
       else if (R >= 8 && split >= 8) { launch_row<L, (R >= 8 ? 8 : R), ROPT, GEN>(st, ra, mode_for(R >= 8 ? 8 : R), ctx->n_cu, &nA); s_used = R >= 8 ? 8 : R; }
       else if (R >= 4 && split >= 4) { launch_row<L, (R >= 4 ? 4 : R), ROPT, GEN>(st, ra, mode_for(R >= 4 ? 4 : R), ctx->n_cu, &nA); s_used = R >= 4 ? 4 : R; }
