@@ -383,17 +383,20 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                             batch=batch, trackViol=not args.no_viol)
     X.set_targets(y)
     opt._handle(fm, ctx, "minibatch")
-    views = None
+    sync_period = 0
     if world > 1:
-        from nimfm_amd import dp
-
-        views = dp.ParamViews(torch, dev, fm, opt)
+        # the exchange lives in the library (csrc/dp.hip): one RCCL communicator per rank, the replicas reconciled every
+        # sync_period mini-batches on a second stream beside the next period's mini-batches, exactly at the end of the
+        # epoch; torch.distributed only carried the group id (dp.Group.from_torch, in main)
+        sync_period = args.sync_period if args.sync_period >= 0 else (64 if n // batch >= 256 else 0)
+        opt.setDataParallel(run_training.group, sync_period, True)
 
     def step(perm=None):
-        ls, vs = opt._epoch(X, perm, 0, n)
-        opt.it += n
+        ls, vs = opt._epoch(X, perm, 0, n)  # with a group: the sums over all ranks
         if world > 1:
-            views.average(dist, world)
+            opt._sync_it()  # advanced by the samples of all ranks (the reference's threads share one counter)
+        else:
+            opt.it += n
         return ls, vs
 
     def fence():
@@ -412,7 +415,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt, last
@@ -462,8 +465,11 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                 "score": {"value": round(n / ts, 1), "unit": "samples/s", "ms": round(ts * 1e3, 4), "result": sc.value}}
         del out_dev
 
-    # ---- roofline leg: per-kernel durations from HIP events on the library's stream ----
+    # ---- roofline leg: per-kernel durations from HIP events on the library's stream (one replica, no exchange) ----
     roof = None
+    if world > 1:
+        dist.barrier()
+        opt.setDataParallel(None)
     if rank == 0:
         ctx.timing_reset()
         ctx.timing_enable(True)
@@ -512,8 +518,12 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                                       "per-sample steps, DESIGN.md section 4) -- NOT the reference's sample-by-sample order, "
                                       "which NFM_MODE_SEQUENTIAL reproduces at ~1e5 samples/s",
                        "samples_per_gpu": n, "batch": batch,
-                       "parallelism": "replicas=%d, parameter average per step" % world if world > 1 else "1 GPU"},
-            "last_step": {"mean_loss": last[0] / n, "viol": last[1]}, "predict": pred,
+                       "parallelism": ("%d ranks, one process per GPU, contiguous sample shards; replicas %s in the library over "
+                                       "RCCL every %s on a second stream + exactly at the end of every epoch"
+                                       % (world, "averaged" if wl["solver"] == "sgd" else "state-summed",
+                                          ("%d mini-batches" % sync_period) if sync_period else "epoch (no mid-epoch exchange)"))
+                       if world > 1 else "1 GPU"},
+            "last_step": {"mean_loss": last[0] / (n * world), "viol": last[1]}, "predict": pred,
             "roofline": roof, "cpu_baseline": cpu}
 
 
@@ -531,6 +541,9 @@ def main():
                     help="AdaGrad without the reference's viol = sum|P_old - P_new| (no stored copy of P is read or "
                          "written; the stopping criterion is then unavailable) -- an information run, not the metric")
     ap.add_argument("--cpu-samples", type=int, default=1_000_000)
+    ap.add_argument("--sync-period", type=int, default=-1,
+                    help="N > 1: mini-batches between exchanges (0 = only at the end of every epoch; default 64 for epochs "
+                         "of >= 256 mini-batches, else 0)")
     ap.add_argument("--psgd-shape", default="", help="--workload psgd: d,m,k instead of the ml-100k shape")
     args = ap.parse_args()
 
@@ -559,15 +572,21 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
+    ctx = nf.Context(dev_index)
+    nf.set_default_context(ctx)
     if world > 1:
         import torch.distributed as dist
 
+        from nimfm_amd import dp
+
+        # torch.distributed (gloo, host side) is only the bootstrap and the clock: it carries the group id and the
+        # barriers / MAX-over-ranks of the timing.  The exchange itself is the library's own RCCL communicator.
+        dist.init_process_group("gloo")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            run_training.group = dp.Group.from_torch(ctx, dist)
         else:
-            dist.init_process_group(backend)
-    ctx = nf.Context(dev_index)
-    nf.set_default_context(ctx)
+            raise SystemExit("NIMFM_BENCH_BACKEND=%s: the exchange is RCCL inside the library; rehearse the rule on the CPU "
+                             "with tests/test_dp_gloo.py or on one GPU with tests/test_gpu_dp.py" % backend)
 
     res = run_training(args, args.workload, torch, nf, dist, rank, world, dev, ctx, primary=True)
     extra = None

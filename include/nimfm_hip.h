@@ -275,6 +275,40 @@ int32_t nfm_opt_device_state(nfm_opt* o, double** gsum_P, double** gnorm_P, int6
                              double** gscalars /* {gsum_b, gnorm_b} */);
 int32_t nfm_opt_destroy(nfm_opt* o);
 
+/* ---- data-parallel groups: sample shards, replicated parameters, periodic exchange ----
+ * Replaces the reference's Hogwild drivers (optimizer/sgd_multi.nim:40-120, adagrad_multi.nim:39-115,
+ * sgd_ffm_multi.nim, adagrad_ffm_multi.nim: T threads, contiguous sample slices `nSamples div nThreads`,
+ * ONE shared unsynchronised model) across GPUs: rank r trains on its own contiguous slice, resident in its GPU's
+ * HBM (the host hands each rank its slice as that rank's nfm_dataset), the model is replicated, and nfm_opt_epoch
+ * reconciles the replicas every `sync_period` mini-batches and exactly at the end of the call:
+ *   SGD      replicas averaged;
+ *   AdaGrad  the replicas' g_sum / g_norm increments since the last exchange summed (the state ONE process would hold
+ *            after all shards' samples, optimizer/adagrad.nim:113-134).
+ * With overlap != 0 a mid-epoch exchange is delayed by one period: the collective runs on the group's own stream beside
+ * the next period's mini-batches and its result is folded in at the next sync point (a fixed point: results are
+ * reproducible).  All ranks of a group call nfm_opt_epoch together, with equal step counters at the call's start; the
+ * call returns the loss / viol sums over ALL ranks (sgd_multi.nim:98-101) and advances the step counter by the samples
+ * of all ranks (the reference's threads share one counter, sgd_multi.nim:37).  After the call all replicas hold the
+ * same bits.  NFM_MODE_MINIBATCH, SGD and AdaGrad (FM and FFM).
+ *
+ * nfm_dp_create: one PROCESS per GPU; the collective is ncclAllReduce(ncclDouble) of RCCL over xGMI on the single
+ * parameter / state arena.  Rank 0 obtains an id with nfm_dp_unique_id and the host distributes its
+ * NFM_DP_ID_BYTES bytes (file, environment, MPI, torch.distributed ...); nfm_dp_create is collective.
+ * nfm_dp_create_local: `world` ranks inside ONE process, one nfm_ctx (and one host thread) each -- several GPUs with
+ * peer access, or one GPU shared by all ranks; the collective is a rendezvous of the ranks' host threads and a
+ * rank-ordered device-side sum.  out receives `world` handles. */
+typedef struct nfm_dp nfm_dp;
+#define NFM_DP_ID_BYTES 128
+int32_t nfm_dp_unique_id(void* id /*[NFM_DP_ID_BYTES]*/);
+int32_t nfm_dp_create(nfm_ctx* ctx, const void* id /*[NFM_DP_ID_BYTES]*/, int32_t rank, int32_t world, nfm_dp** out);
+int32_t nfm_dp_create_local(nfm_ctx* const* ctxs /*[world]*/, int32_t world, nfm_dp** out /*[world]*/);
+/* rank / world of the group, collectives issued and bytes contributed so far (any pointer may be NULL) */
+int32_t nfm_dp_info(const nfm_dp* dp, int32_t* rank, int32_t* world, int64_t* n_collectives, int64_t* bytes);
+int32_t nfm_dp_destroy(nfm_dp* dp);
+/* attach (dp != NULL) or detach (dp == NULL) a group; sync_period: mini-batches between exchanges, 0 = only the exact
+ * exchange at the end of every nfm_opt_epoch call */
+int32_t nfm_opt_set_dp(nfm_opt* o, nfm_dp* dp, int64_t sync_period, int32_t overlap);
+
 /* ---- host-side random numbers (no device work) ----
  * FactorizationMachine.init draws P with randomNormal (model/factorization_machine.nim:125-139,
  * tensor/tensor.nim:561-580: Box-Muller over rand(1.0); z = sqrt(-2 ln(1-x)) cos(2 pi y) and the sine twin go

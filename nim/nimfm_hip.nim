@@ -39,6 +39,7 @@ type
   NfmDataset* = pointer
   NfmModel* = pointer
   NfmOpt* = pointer
+  NfmDp* = pointer
   NfmModelCfg* {.bycopy.} = object
     kind*, task*, degree*, nComponents*, fitLower*, fitIntercept*, fitLinear*, reserved*: int32
     nFeatures*, nFields*: int64
@@ -100,6 +101,13 @@ proc nfm_opt_epoch*(o: NfmOpt, ds: NfmDataset, perm: ptr int64, first, last: int
                     lossSum, violSum: ptr float64): int32
 proc nfm_opt_finalize*(o: NfmOpt): int32
 proc nfm_opt_destroy*(o: NfmOpt): int32
+# data-parallel groups: one process per GPU (RCCL over xGMI) or the ranks of one process (threads + peer access)
+proc nfm_dp_unique_id*(id: pointer): int32
+proc nfm_dp_create*(ctx: NfmCtx, id: pointer, rank, world: int32, outp: ptr NfmDp): int32
+proc nfm_dp_create_local*(ctxs: ptr NfmCtx, world: int32, outp: ptr NfmDp): int32
+proc nfm_dp_info*(dp: NfmDp, rank, world: ptr int32, nCollectives, bytes: ptr int64): int32
+proc nfm_dp_destroy*(dp: NfmDp): int32
+proc nfm_opt_set_dp*(o: NfmOpt, dp: NfmDp, syncPeriod: int64, overlap: int32): int32
 {.pop.}
 
 proc check*(rc: int32) =

@@ -39,6 +39,7 @@ SYMBOLS = [
     "nfm_sgd_create", "nfm_adagrad_create", "nfm_mbpsgd_create", "nfm_opt_predict_all_with_grad", "nfm_opt_set_it", "nfm_opt_get_it", "nfm_opt_get_state",
     "nfm_opt_set_state", "nfm_opt_epoch", "nfm_opt_finalize", "nfm_opt_device_state", "nfm_opt_destroy",
     "nfm_rng_randomize", "nfm_rng_random_normal", "nfm_rng_shuffle",
+    "nfm_dp_unique_id", "nfm_dp_create", "nfm_dp_create_local", "nfm_dp_info", "nfm_dp_destroy", "nfm_opt_set_dp",
 ]
 
 
@@ -158,6 +159,12 @@ def lib():
         "nfm_rng_randomize": [i64, vp],
         "nfm_rng_random_normal": [vp, i64, dbl, dbl, vp],
         "nfm_rng_shuffle": [vp, vp, i64],
+        "nfm_dp_unique_id": [vp],
+        "nfm_dp_create": [vp, vp, i32, i32, pp],
+        "nfm_dp_create_local": [vp, i32, vp],
+        "nfm_dp_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)],
+        "nfm_dp_destroy": [vp],
+        "nfm_opt_set_dp": [vp, vp, i64, i32],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

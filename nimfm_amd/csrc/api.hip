@@ -11,6 +11,7 @@
 #include <memory>
 #include <vector>
 
+#include "dp.h"
 #include "ingest.h"
 #include "mb.h"
 
@@ -83,6 +84,12 @@ struct nfm_opt {
   // the full gradient of the same data once per iteration)
   MbWork Wg;
   std::unique_ptr<Plan> grad_plan;
+  // data-parallel group (dp.h): when set, nfm_opt_epoch reconciles the replicas every dp_sync_period mini-batches
+  // (delayed by one period when dp_overlap) and exactly at the end of the call
+  nfm_dp* dp = nullptr;
+  int64_t dp_sync_period = 0;
+  bool dp_overlap = true;
+  DevBuf dp_sums;
 };
 
 // live models by uid: an optimizer whose model was destroyed (and whose address may since belong to a model of
@@ -843,6 +850,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
   if (ns > 0) {
     const ModelView M = m->view();
     if (o->mode == NFM_MODE_SEQUENTIAL) {
+      NFM_CHECK(!o->dp, NFM_ERR_UNSUPPORTED, "the data-parallel exchange needs NFM_MODE_MINIBATCH");
       const int64_t* perm_dev = nullptr;
       if (perm) {
         NFM_TRY(o->perm_dev.ensure(sizeof(int64_t) * ns));
@@ -873,13 +881,57 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         o->plan->ds_uid = ds->uid;
         o->plan->ds_nnz = ds->v.nnz;
       }
+      DpEpoch de;
+      if (o->dp) {
+        // the ranks of the group run this call together on their own shards (equal step counters at its start)
+        NFM_CHECK(o->kind != OPT_PSGD, NFM_ERR_UNSUPPORTED, "MBPSGD has no data-parallel mode");
+        de.dp = o->dp;
+        de.opt_kind = o->kind;
+        de.sync_period = o->dp_sync_period;
+        de.overlap = o->dp_overlap;
+        if (o->kind == OPT_SGD) {
+          de.arena = m->arena.as<double>();
+          de.n = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double)) + SC_COUNT;
+          de.skip_lo = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double)) + SC_SCALE_P;
+          de.skip_hi = de.skip_lo + 2;  // {scale_P, scale_w}
+        } else {
+          de.arena = o->state_arena.as<double>();
+          de.n = (int64_t)((o->gsc.as<char>() - o->state_arena.as<char>()) / sizeof(double)) + 2;
+        }
+        // leading mini-batches of the regular length (everything but a shorter tail) look alike on every rank
+        const Plan& PL = *o->plan;
+        int64_t regular = PL.n_batches;
+        if (PL.n_batches > 0 && PL.bat_pos[PL.n_batches] - PL.bat_pos[PL.n_batches - 1] < o->batch &&
+            !(PL.first_singleton && PL.n_batches == 1))
+          regular = PL.n_batches - 1;
+        NFM_TRY(dp_epoch_begin(de, regular, PL.n_batches));
+        o->W.after_batch = [&de](int64_t b) { return dp_after_batch(de, b); };
+      }
+      int rc_epoch;
       if (m->cfg.kind == NFM_KIND_FM)
-        NFM_TRY(mb_fm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2, (ds->uid << 20) ^ ds->serial));
+        rc_epoch = mb_fm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2, (ds->uid << 20) ^ ds->serial);
       else
-        NFM_TRY(mb_ffm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2));
+        rc_epoch = mb_ffm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2);
+      o->W.after_batch = nullptr;
+      NFM_TRY(rc_epoch);
+      if (o->dp) {
+        NFM_TRY(dp_fold_pending(de));
+        if (o->kind == OPT_SGD) NFM_TRY(launch_rescale(ctx, M));  // true values: the scales are 1 on every rank
+        NFM_TRY(o->dp_sums.ensure(sizeof(double) * 3));
+        double sums[3] = {out2[0], out2[1], (double)ns};
+        NFM_HIP_CHECK(hipMemcpyAsync(o->dp_sums.p, sums, sizeof(sums), hipMemcpyHostToDevice, st));
+        NFM_TRY(dp_epoch_end(de, o->dp_sums.as<double>()));
+        NFM_HIP_CHECK(hipMemcpyAsync(sums, o->dp_sums.p, sizeof(sums), hipMemcpyDeviceToHost, st));
+        NFM_HIP_CHECK(hipStreamSynchronize(st));
+        out2[0] = sums[0];
+        out2[1] = sums[1];
+        // the reference's threads share ONE step counter (sgd_multi.nim:37): after the call it has advanced by the
+        // samples of all ranks
+        o->it += (int64_t)(sums[2] + 0.5) - ns;
+      }
     }
     o->it += o->kind == OPT_PSGD ? ns / o->batch : ns;
-    if (o->kind == OPT_SGD) {  // resetScaling, sgd.nim:116-131
+    if (o->kind == OPT_SGD && !o->dp) {  // resetScaling, sgd.nim:116-131
       double sc[SC_COUNT];
       NFM_HIP_CHECK(hipMemcpyAsync(sc, m->sc.p, sizeof(sc), hipMemcpyDeviceToHost, st));
       NFM_HIP_CHECK(hipStreamSynchronize(st));
@@ -949,6 +1001,18 @@ int32_t nfm_opt_predict_all_with_grad(nfm_opt* o, nfm_dataset* ds, double* y_pre
   if (grad_b) NFM_HIP_CHECK(hipMemcpyAsync(grad_b, g.as<char>() + bP + bw, sizeof(double), hipMemcpyDeviceToHost, st));
   NFM_HIP_CHECK(hipStreamSynchronize(st));
   if (loss_sum) *loss_sum = out2[0];
+  return NFM_OK;
+}
+
+int32_t nfm_opt_set_dp(nfm_opt* o, nfm_dp* dp, int64_t sync_period, int32_t overlap) {
+  NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
+  NFM_CHECK(sync_period >= 0, NFM_ERR_INVALID, "sync_period must be >= 0");
+  NFM_CHECK(!dp || dp->ctx == o->ctx, NFM_ERR_INVALID, "optimizer and group belong to different contexts");
+  NFM_CHECK(!dp || o->mode == NFM_MODE_MINIBATCH, NFM_ERR_UNSUPPORTED, "the data-parallel exchange needs NFM_MODE_MINIBATCH");
+  NFM_CHECK(!dp || o->kind != OPT_PSGD, NFM_ERR_UNSUPPORTED, "MBPSGD has no data-parallel mode");
+  o->dp = dp;
+  o->dp_sync_period = sync_period;
+  o->dp_overlap = overlap != 0;
   return NFM_OK;
 }
 

@@ -1,0 +1,383 @@
+// nimfm_amd/csrc/dp.hip -- data-parallel groups: transports (RCCL over xGMI between processes; peer-to-peer sums between
+// the ranks of one process), the exchange rules of dp.h, and the nfm_dp_* entry points of include/nimfm_hip.h.
+#include "dp.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enumerators only: the library is opened at run time (no link dependency)
+#include <string.h>
+
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "opt_views.h"
+
+namespace nfm {
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, opened on first use.  torch ships its own librccl.so; whichever is already mapped under that soname is reused,
+// otherwise ROCm's.  One communicator per group and rank, one process per GPU.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+  void* h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string err;
+};
+Rccl& rccl() {
+  static Rccl* r = [] {
+    Rccl* x = new Rccl();
+    const char* names[] = {getenv("NFM_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      if (!n || !*n) continue;
+      x->h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (x->h) break;
+      x->err = dlerror();
+    }
+    if (!x->h) return x;
+    x->GetUniqueId = reinterpret_cast<decltype(&ncclGetUniqueId)>(dlsym(x->h, "ncclGetUniqueId"));
+    x->CommInitRank = reinterpret_cast<decltype(&ncclCommInitRank)>(dlsym(x->h, "ncclCommInitRank"));
+    x->CommDestroy = reinterpret_cast<decltype(&ncclCommDestroy)>(dlsym(x->h, "ncclCommDestroy"));
+    x->AllReduce = reinterpret_cast<decltype(&ncclAllReduce)>(dlsym(x->h, "ncclAllReduce"));
+    x->GetErrorString = reinterpret_cast<decltype(&ncclGetErrorString)>(dlsym(x->h, "ncclGetErrorString"));
+    if (!x->GetUniqueId || !x->CommInitRank || !x->CommDestroy || !x->AllReduce) {
+      x->err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
+      x->h = nullptr;
+    }
+    return x;
+  }();
+  return *r;
+}
+int rccl_ready() {
+  Rccl& r = rccl();
+  NFM_CHECK(r.h, NFM_ERR_HIP, "RCCL is not available: %s", r.err.c_str());
+  return NFM_OK;
+}
+#define NFM_NCCL_CHECK(expr)                                                                     \
+  do {                                                                                           \
+    ncclResult_t r_ = (expr);                                                                    \
+    if (r_ != ncclSuccess)                                                                       \
+      return set_error(NFM_ERR_HIP, "%s failed: %s", #expr,                                      \
+                       rccl().GetErrorString ? rccl().GetErrorString(r_) : "RCCL error");        \
+  } while (0)
+
+struct RcclTransport : DpTransport {
+  ncclComm_t comm = nullptr;
+  ~RcclTransport() override {
+    if (comm) (void)rccl().CommDestroy(comm);
+  }
+  int allreduce(const double* send, double* recv, int64_t n, int op, hipStream_t st) override {
+    NFM_NCCL_CHECK(rccl().AllReduce(send, recv, (size_t)n, ncclDouble, op == DP_MAX ? ncclMax : ncclSum, comm, st));
+    return NFM_OK;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the ranks of ONE process (one nfm_ctx each; several GPUs with peer access, or one GPU shared by all ranks -- the
+// way the exchange rules are exercised on a one-GPU box).  Every rank's host thread arrives with its buffers; each
+// rank then sums all ranks' send buffers in rank order into its own receive buffer: identical bits everywhere.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxLocalWorld = 16;
+struct LocalGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  int world = 0, arrived = 0;
+  uint64_t generation = 0;
+  const double* send[kMaxLocalWorld] = {};
+  hipEvent_t ready[kMaxLocalWorld] = {}, done[kMaxLocalWorld] = {};
+  int device[kMaxLocalWorld] = {};
+  bool broken = false;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t g = generation;
+    if (++arrived == world) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != g || broken; });
+    }
+  }
+};
+struct PeerPtrs {
+  const double* p[kMaxLocalWorld];
+};
+__global__ void k_sum_peers(PeerPtrs src, int world, double* __restrict__ dst, int64_t n, int op) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double v = src.p[0][i];
+    for (int q = 1; q < world; ++q) {
+      const double o = src.p[q][i];
+      v = op == DP_MAX ? (o > v ? o : v) : v + o;
+    }
+    dst[i] = v;
+  }
+}
+struct LocalTransport : DpTransport {
+  std::shared_ptr<LocalGroup> g;
+  int allreduce(const double* send, double* recv, int64_t n, int op, hipStream_t st) override {
+    LocalGroup& G = *g;
+    NFM_HIP_CHECK(hipEventRecord(G.ready[rank], st));
+    G.send[rank] = send;
+    G.barrier();  // every rank has published its buffer and recorded "ready"
+    PeerPtrs pp{};
+    for (int q = 0; q < world; ++q) {
+      pp.p[q] = G.send[q];
+      if (q != rank) NFM_HIP_CHECK(hipStreamWaitEvent(st, G.ready[q], 0));
+    }
+    int64_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)blocks), dim3(kBlock), 0, st, pp, world, recv, n, op);
+    NFM_HIP_CHECK(hipGetLastError());
+    NFM_HIP_CHECK(hipEventRecord(G.done[rank], st));
+    G.barrier();  // every rank has enqueued its sum
+    for (int q = 0; q < world; ++q)  // nobody's send buffer is overwritten before all readers are through
+      if (q != rank) NFM_HIP_CHECK(hipStreamWaitEvent(st, G.done[q], 0));
+    return NFM_OK;
+  }
+};
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// exchange kernels (all plain streaming passes over the arena)
+// ------------------------------------------------------------------------------------------------
+namespace {
+inline unsigned grid_stream(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b > 256 * 32) b = 256 * 32;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+// SGD, delayed: theta += R / W - S (stored units: the lazy L2 scale decays the late contribution like everything else)
+__global__ void k_sgd_fold(double* __restrict__ theta, const double* __restrict__ R, const double* __restrict__ S, int64_t n,
+                           double inv_w, int64_t skip_lo, int64_t skip_hi) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (i < skip_lo || i >= skip_hi) theta[i] += R[i] * inv_w - S[i];
+}
+// SGD, closing: theta = R / W
+__global__ void k_sgd_mean(double* __restrict__ theta, const double* __restrict__ R, int64_t n, double inv_w) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) theta[i] = R[i] * inv_w;
+}
+// AdaGrad: own = G - base
+__global__ void k_ada_own(const double* __restrict__ G, const double* __restrict__ base, double* __restrict__ own, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) own[i] = G[i] - base[i];
+}
+// AdaGrad, delayed: the other ranks' increments arrive: G += R - own, base += R
+__global__ void k_ada_fold(double* __restrict__ G, double* __restrict__ base, const double* __restrict__ R,
+                           const double* __restrict__ own, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double r = R[i];
+    G[i] += r - own[i];
+    base[i] += r;
+  }
+}
+// AdaGrad, closing: G = base + R (every rank forms the same sum), base = G
+__global__ void k_ada_close(double* __restrict__ G, double* __restrict__ base, const double* __restrict__ R, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double g = base[i] + R[i];
+    G[i] = g;
+    base[i] = g;
+  }
+}
+}  // namespace
+
+int dp_fold_pending(DpEpoch& e) {
+  nfm_dp* dp = e.dp;
+  if (!dp->pending) return NFM_OK;
+  hipStream_t st = dp->ctx->stream;
+  NFM_HIP_CHECK(hipStreamWaitEvent(st, dp->ev_done, 0));
+  const int64_t n = dp->pending_n;
+  if (e.opt_kind == OPT_SGD)
+    hipLaunchKernelGGL(k_sgd_fold, dim3(grid_stream(n)), dim3(kBlock), 0, st, e.arena, dp->recv.as<double>(), dp->snap.as<double>(), n,
+                       1.0 / (double)dp->t->world, e.skip_lo, e.skip_hi);
+  else
+    hipLaunchKernelGGL(k_ada_fold, dim3(grid_stream(n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(),
+                       dp->snap.as<double>(), n);
+  NFM_HIP_CHECK(hipGetLastError());
+  dp->pending = false;
+  return NFM_OK;
+}
+
+int dp_epoch_begin(DpEpoch& e, int64_t n_full_batches, int64_t n_batches) {
+  nfm_dp* dp = e.dp;
+  hipStream_t st = dp->ctx->stream;
+  NFM_CHECK(!dp->pending, NFM_ERR_INVALID, "a data-parallel exchange of an earlier call is still pending");
+  NFM_TRY(dp->snap.ensure(sizeof(double) * (size_t)e.n));
+  NFM_TRY(dp->recv.ensure(sizeof(double) * (size_t)e.n));
+  NFM_TRY(dp->scal.ensure(sizeof(double) * 8));
+  if (e.opt_kind == OPT_ADAGRAD) {
+    NFM_TRY(dp->base.ensure(sizeof(double) * (size_t)e.n));
+    NFM_HIP_CHECK(hipMemcpyAsync(dp->base.p, e.arena, sizeof(double) * (size_t)e.n, hipMemcpyDeviceToDevice, st));
+  }
+  // mid-epoch sync points lie after mini-batches S, 2S, ... that are FULL on every rank (identical step counters and
+  // L2 scales there) and strictly before this rank's -- hence every rank's -- last one
+  int64_t mine = 0;
+  if (e.sync_period > 0) {
+    mine = n_full_batches / e.sync_period;
+    if (mine * e.sync_period >= n_batches) mine = (n_batches - 1) / e.sync_period;
+    if (mine < 0) mine = 0;
+  }
+  double h[4] = {-(double)mine, 0.0, 0.0, 0.0};
+  NFM_HIP_CHECK(hipMemcpyAsync(dp->scal.p, h, sizeof(h), hipMemcpyHostToDevice, st));
+  NFM_TRY(dp->t->allreduce(dp->scal.as<double>(), dp->scal.as<double>() + 4, 4, DP_MAX, st));
+  NFM_HIP_CHECK(hipMemcpyAsync(h, dp->scal.as<double>() + 4, sizeof(h), hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  e.n_sync = (int64_t)(-h[0]);
+  return NFM_OK;
+}
+
+int dp_after_batch(DpEpoch& e, int64_t b) {
+  if (e.sync_period <= 0 || (b + 1) % e.sync_period != 0) return NFM_OK;
+  const int64_t k = (b + 1) / e.sync_period;  // 1-based sync point
+  if (k > e.n_sync) return NFM_OK;
+  nfm_dp* dp = e.dp;
+  hipStream_t st = dp->ctx->stream;
+  NFM_TRY(dp_fold_pending(e));  // the previous period's collective has had a whole period to finish
+  // what this rank contributes now
+  if (e.opt_kind == OPT_SGD)
+    NFM_HIP_CHECK(hipMemcpyAsync(dp->snap.p, e.arena, sizeof(double) * (size_t)e.n, hipMemcpyDeviceToDevice, st));
+  else
+    hipLaunchKernelGGL(k_ada_own, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->snap.as<double>(), e.n);
+  NFM_HIP_CHECK(hipGetLastError());
+  hipStream_t cs = e.overlap ? dp->comm : st;
+  if (e.overlap) {
+    NFM_HIP_CHECK(hipEventRecord(dp->ev_ready, st));
+    NFM_HIP_CHECK(hipStreamWaitEvent(cs, dp->ev_ready, 0));
+  }
+  NFM_TRY(dp->t->allreduce(dp->snap.as<double>(), dp->recv.as<double>(), e.n, DP_SUM, cs));
+  NFM_HIP_CHECK(hipEventRecord(dp->ev_done, cs));
+  dp->pending = true;
+  dp->pending_n = e.n;
+  dp->n_collectives++;
+  dp->bytes += (int64_t)sizeof(double) * e.n;
+  if (!e.overlap) NFM_TRY(dp_fold_pending(e));
+  return NFM_OK;
+}
+
+int dp_epoch_end(DpEpoch& e, double* sums_dev) {
+  nfm_dp* dp = e.dp;
+  hipStream_t st = dp->ctx->stream;
+  NFM_TRY(dp_fold_pending(e));
+  const double inv_w = 1.0 / (double)dp->t->world;
+  if (e.opt_kind == OPT_SGD) {
+    NFM_TRY(dp->t->allreduce(e.arena, dp->recv.as<double>(), e.n, DP_SUM, st));
+    hipLaunchKernelGGL(k_sgd_mean, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->recv.as<double>(), e.n, inv_w);
+  } else {
+    hipLaunchKernelGGL(k_ada_own, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->snap.as<double>(), e.n);
+    NFM_TRY(dp->t->allreduce(dp->snap.as<double>(), dp->recv.as<double>(), e.n, DP_SUM, st));
+    hipLaunchKernelGGL(k_ada_close, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(), e.n);
+  }
+  NFM_HIP_CHECK(hipGetLastError());
+  dp->n_collectives++;
+  dp->bytes += (int64_t)sizeof(double) * e.n;
+  // the running sums the reference adds up over its threads (sgd_multi.nim:98-101) and the samples all ranks saw
+  NFM_TRY(dp->t->allreduce(sums_dev, dp->scal.as<double>(), 3, DP_SUM, st));
+  NFM_HIP_CHECK(hipMemcpyAsync(sums_dev, dp->scal.p, sizeof(double) * 3, hipMemcpyDeviceToDevice, st));
+  return NFM_OK;
+}
+
+}  // namespace nfm
+
+using namespace nfm;
+
+static int dp_common_init(nfm_ctx* ctx, nfm_dp* dp) {
+  dp->ctx = ctx;
+  NFM_HIP_CHECK(hipSetDevice(ctx->device));
+  NFM_HIP_CHECK(hipStreamCreateWithFlags(&dp->comm, hipStreamNonBlocking));
+  NFM_HIP_CHECK(hipEventCreateWithFlags(&dp->ev_ready, hipEventDisableTiming));
+  NFM_HIP_CHECK(hipEventCreateWithFlags(&dp->ev_done, hipEventDisableTiming));
+  return NFM_OK;
+}
+
+extern "C" {
+
+int32_t nfm_dp_unique_id(void* id) {
+  NFM_CHECK(id, NFM_ERR_INVALID, "null id");
+  NFM_TRY(rccl_ready());
+  static_assert(sizeof(ncclUniqueId) == NFM_DP_ID_BYTES, "id size");
+  ncclUniqueId u;
+  NFM_NCCL_CHECK(rccl().GetUniqueId(&u));
+  memcpy(id, &u, sizeof(u));
+  return NFM_OK;
+}
+
+int32_t nfm_dp_create(nfm_ctx* ctx, const void* id, int32_t rank, int32_t world, nfm_dp** out) {
+  NFM_CHECK(ctx && id && out, NFM_ERR_INVALID, "null argument");
+  NFM_CHECK(world >= 1 && rank >= 0 && rank < world, NFM_ERR_INVALID, "bad rank %d of %d", rank, world);
+  NFM_TRY(rccl_ready());
+  std::unique_ptr<nfm_dp> dp(new nfm_dp());
+  NFM_TRY(dp_common_init(ctx, dp.get()));
+  std::unique_ptr<RcclTransport> t(new RcclTransport());
+  t->rank = rank;
+  t->world = world;
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  NFM_NCCL_CHECK(rccl().CommInitRank(&t->comm, world, u, rank));
+  dp->t = t.release();
+  *out = dp.release();
+  return NFM_OK;
+}
+
+int32_t nfm_dp_create_local(nfm_ctx* const* ctxs, int32_t world, nfm_dp** out) {
+  NFM_CHECK(ctxs && out, NFM_ERR_INVALID, "null argument");
+  NFM_CHECK(world >= 1 && world <= kMaxLocalWorld, NFM_ERR_INVALID, "world must be in [1,%d]", kMaxLocalWorld);
+  auto g = std::make_shared<LocalGroup>();
+  g->world = world;
+  for (int r = 0; r < world; ++r) {
+    NFM_CHECK(ctxs[r], NFM_ERR_INVALID, "null context %d", r);
+    g->device[r] = ctxs[r]->device;
+    NFM_HIP_CHECK(hipSetDevice(ctxs[r]->device));
+    NFM_HIP_CHECK(hipEventCreateWithFlags(&g->ready[r], hipEventDisableTiming));
+    NFM_HIP_CHECK(hipEventCreateWithFlags(&g->done[r], hipEventDisableTiming));
+    for (int q = 0; q < world; ++q)
+      if (ctxs[q]->device != ctxs[r]->device) {
+        const hipError_t e = hipDeviceEnablePeerAccess(ctxs[q]->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+          return set_error(NFM_ERR_HIP, "no peer access from device %d to %d: %s", ctxs[r]->device, ctxs[q]->device, hipGetErrorString(e));
+        (void)hipGetLastError();
+      }
+  }
+  std::vector<std::unique_ptr<nfm_dp>> made;
+  for (int r = 0; r < world; ++r) {
+    std::unique_ptr<nfm_dp> dp(new nfm_dp());
+    NFM_TRY(dp_common_init(ctxs[r], dp.get()));
+    LocalTransport* t = new LocalTransport();
+    t->rank = r;
+    t->world = world;
+    t->g = g;
+    dp->t = t;
+    made.push_back(std::move(dp));
+  }
+  for (int r = 0; r < world; ++r) out[r] = made[r].release();
+  return NFM_OK;
+}
+
+int32_t nfm_dp_info(const nfm_dp* dp, int32_t* rank, int32_t* world, int64_t* n_collectives, int64_t* bytes) {
+  NFM_CHECK(dp, NFM_ERR_INVALID, "null group");
+  if (rank) *rank = dp->t->rank;
+  if (world) *world = dp->t->world;
+  if (n_collectives) *n_collectives = dp->n_collectives;
+  if (bytes) *bytes = dp->bytes;
+  return NFM_OK;
+}
+
+int32_t nfm_dp_destroy(nfm_dp* dp) {
+  if (!dp) return NFM_OK;
+  (void)hipSetDevice(dp->ctx->device);
+  (void)hipStreamSynchronize(dp->ctx->stream);
+  if (dp->comm) {
+    (void)hipStreamSynchronize(dp->comm);
+    (void)hipStreamDestroy(dp->comm);
+  }
+  if (dp->ev_ready) (void)hipEventDestroy(dp->ev_ready);
+  if (dp->ev_done) (void)hipEventDestroy(dp->ev_done);
+  delete dp->t;
+  delete dp;
+  return NFM_OK;
+}
+
+}  // extern "C"

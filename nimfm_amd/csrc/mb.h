@@ -1,5 +1,7 @@
 // nimfm_amd/csrc/mb.h -- mini-batch mode: work buffers and entry points.
 #pragma once
+#include <functional>
+
 #include "opt_views.h"
 #include "plan.h"
 
@@ -25,6 +27,9 @@ struct MbWork {
   uint64_t graph_plan_serial = 0;
   uint64_t graph_data_serial = 0;  // nfm_dataset::uid ^ serial mix the graph's captured dataset pointers belong to
   int graph_opt = -1;
+  // data-parallel hook (dp.h): called after every mini-batch has been enqueued; set only for the duration of one
+  // nfm_opt_epoch call of an optimizer with a group attached (such an epoch is never replayed as a graph)
+  std::function<int(int64_t)> after_batch;
   void drop_graph();
   ~MbWork();
 };

@@ -745,6 +745,7 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
       }
       n_prev = nB + nH;
     }
+    if (W.after_batch) NFM_TRY(W.after_batch(b));
   }
   if (P.n_batches > 0)
     hipLaunchKernelGGL(k_epoch_close, dim3(1), dim3(kBlock), 0, st, W.partsB.as<double>() + ((P.n_batches - 1) & 1) * half,

@@ -159,7 +159,8 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   const void* before[] = {W.Abuf.p, W.rec.p, W.partsA.p, W.partsB.p, W.Dtab.p, W.Stab.p, W.Ftab.p, W.out_acc.p, W.itbuf.p, W.hpart.p, W.prox.p};
   NFM_TRY(W.Abuf.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_batch, 1) * std::max(TA, 1) * M.Kp));
   NFM_TRY(W.rec.ensure(sizeof(SampleRec) * (size_t)std::max<int64_t>(P.max_batch, 1)));
-  NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch / kWavesPerBlock + 1)));
+  // one partial per row-phase workgroup: >= 4 samples per workgroup, 2 in k_row_phase_ada2
+  NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch / 2 + 2)));
   NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique / kMinGroupsPerBlock + P.max_batch / kWavesPerBlock + P.max_heavy / kWavesPerBlock + 6)));
   NFM_TRY(W.hpart.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_segs, 1) * std::max(M.nb, 1) * (2 * M.Kp + 4)));
   NFM_TRY(W.Dtab.ensure(sizeof(double) * 4 * (size_t)(P.n_batches + 1)));
@@ -177,7 +178,7 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
   // A plan that is reused (shuffle off) is replayed as a hipGraph: two dependent launches per
   // batch make the epoch launch-bound on the host otherwise.  Timing mode and one-off plans
   // (explicit permutations) launch directly.
-  const bool want_graph = W.use_graph && !ctx->timing.enabled && !P.has_perm && P.n_batches >= 8;
+  const bool want_graph = W.use_graph && !W.after_batch && !ctx->timing.enabled && !P.has_perm && P.n_batches >= 8;
   if (want_graph) {
     if (!W.graph_exec || W.graph_plan_serial != P.serial || W.graph_opt != opt_kind || W.graph_data_serial != data_serial) {
       W.drop_graph();

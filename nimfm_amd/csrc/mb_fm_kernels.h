@@ -1704,6 +1704,7 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     }
     n_prev = nB + nS + nH;
     if (OPT == OPT_PSGD && O.gradP == nullptr) launch_psgd_step(ctx, M, O, W, it0p, it_b);
+    if (W.after_batch) NFM_TRY(W.after_batch(b));
   }
   if (P.n_batches > 0) {
     const double* parts_last = W.partsB.as<double>() + ((P.n_batches - 1) & 1) * partsB_half;

@@ -9,6 +9,8 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "plan.h"
 
 namespace nfm {
@@ -264,7 +266,7 @@ static inline unsigned grid1d(int64_t n) {
 
 int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
                int64_t batch, bool first_singleton, bool want_tq, bool use_singles, bool sort_by_count, Plan* out) {
-  static uint64_t g_serial = 0;
+  static std::atomic<uint64_t> g_serial{0};  // ranks of one process build plans concurrently (dp.h)
   Plan& P = *out;
   P.release();
   P.serial = ++g_serial;

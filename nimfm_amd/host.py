@@ -680,6 +680,7 @@ class _OptimizerBase:
         self._mode_built = None
         self._mh = None
         self.history = []  # (viol, mean loss) per epoch, what echoInfo prints
+        self._dp = None  # (dp.Group, sync_period, overlap): see setDataParallel
 
     def _release(self):
         if self._h is not None and capi.alive:
@@ -702,7 +703,30 @@ class _OptimizerBase:
             self._h = C.c_void_p()
             self._create(mh, mode)
             self._model, self._mode_built, self._mh = fm, key, (mh.value, fm._gen)
+            if self._dp is not None:
+                self._attach_dp()
         return self._h
+
+    def setDataParallel(self, group, syncPeriod=0, overlap=True):
+        """The maxThreads overloads across GPUs (optimizer/sgd_multi.nim:40-120 and twins): `group` is this rank's
+        dp.Group; X handed to fit is then this rank's contiguous slice of the samples (dp.shard_bounds), every rank
+        calls fit together, and the library reconciles the replicas every syncPeriod mini-batches (0: only at the end of
+        every epoch) -- averaged for SGD, state increments summed for AdaGrad.  The epoch's loss / viol and the step
+        counter `it` then cover the samples of ALL ranks."""
+        self._dp = None if group is None else (group, int(syncPeriod), bool(overlap))
+        if self._h is not None:
+            self._attach_dp()
+
+    def _attach_dp(self):
+        g = self._dp
+        capi.check(capi.lib().nfm_opt_set_dp(self._h, None if g is None else g[0].h, 0 if g is None else g[1],
+                                             1 if g is None or g[2] else 0))
+
+    def _sync_it(self):
+        """with a group attached the library advances `it` by the samples of all ranks"""
+        it = C.c_int64()
+        capi.check(capi.lib().nfm_opt_get_it(self._h, C.byref(it)))
+        self.it = it.value
 
     def _cfg_key(self):
         """what _create bakes into the device optimizer (the common part; subclasses extend it)"""
@@ -734,7 +758,7 @@ class _OptimizerBase:
         if len(y) != X.nSamples:
             raise ValueError("len(y) != nSamples")
         X.set_targets(y)  # checkTarget (fm_base.nim:29-36) is applied on the device from the model's task
-        mode = self.mode if maxThreads is None else "minibatch"
+        mode = self.mode if (maxThreads is None and self._dp is None) else "minibatch"
         if not fm.warmStart:
             self.it = 1  # sgd.nim:288-289, adagrad.nim:49-50
         self._handle(fm, X.ctx, mode)
@@ -775,7 +799,12 @@ class _OptimizerBase:
             else:
                 runningLoss, viol = self._epoch(X, perm, 0, n)
                 self.it += n
-            runningLoss /= float(n)
+            n_all = n
+            if self._dp is not None:  # sums and step counter cover all ranks' samples
+                it0 = self.it - n
+                self._sync_it()
+                n_all = self.it - it0
+            runningLoss /= float(n_all)
             if per_epoch_cb:
                 self._finalize_into(fm)
                 callback(self, fm)

@@ -1,8 +1,10 @@
-"""world_size-2 gloo test of the data-parallel exchange (nimfm_amd/dp.py) on CPU tensors.
+"""world_size-2 gloo test of the data-parallel exchange RULE (csrc/dp.hip, restated in tests/dp_rule.py) on CPU.
 
-Each rank trains its shard with the CPU oracle standing in for the GPU engine (the oracle is only
-the test's engine here, never the product's), the replicas are reconciled with dp.exchange over
-gloo, and the result is checked against a single-process restatement of the same rule."""
+Each process is one rank: it trains its contiguous shard (the reference's thread partition, optimizer/sgd_multi.nim:
+85-88) with the CPU oracle of the mini-batch rule standing in for the GPU engine (the oracle is only the test's engine
+here, never the product's) and reconciles with gloo all-reduces at the points the library would.  The result is held
+to the single-process lockstep simulation of the same rule: sync_period 0 (closing exchange only) and > 1, with the
+exchange delayed by one period (overlap) and immediate, shards of unequal size, SGD and AdaGrad."""
 import os
 import socket
 import sys
@@ -11,6 +13,8 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = [(0, True), (2, True), (3, False)]  # (sync_period, overlap)
+N, D, M, K, B = 403, 50, 6, 4, 32  # 403 samples over 2 ranks: 201 + 202 (13 batches each, tails of 9 and 10)
 
 
 def _free_port():
@@ -21,6 +25,63 @@ def _free_port():
     return p
 
 
+def _problem():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from common import random_csr
+
+    full = random_csr(N, D, M, seed=11)
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal(N)
+    P0, w0 = rng.standard_normal((1, K, D)) * 0.1, rng.standard_normal(D) * 0.01
+    return O, full, y, P0, w0
+
+
+def _shard(O, full, y, rank, world):
+    from nimfm_amd.dp import shard_bounds
+
+    lo, hi = shard_bounds(N, rank, world)
+    a, b = full.indptr[lo], full.indptr[hi]
+    return O.Dataset(full.indptr[lo:hi + 1] - a, full.indices[a:b], full.data[a:b], hi - lo, D), y[lo:hi]
+
+
+def _rank_gens(O, shard, ys, P0, w0, S, overlap, world):
+    """the SGD and the AdaGrad generator of one rank (two epochs each: the second starts from reconciled replicas)"""
+    import dp_rule as R
+
+    def sgd():
+        P, w, b, it = P0.copy(), w0.copy(), 0.25, 1
+        cfg = O.sgd_cfg(eta0=0.05)
+        out = []
+        for _ in range(2):
+            def ep(P_, w_, b_, lo, hi, it_):
+                b2, _, ls, vs = O.fm_sgd_epoch_mb(shard, ys, 2, P_, w_, b_, cfg, B, begin=lo, end=hi, it=it_)
+                return b2, ls, vs
+            P, w, b, ls, vs, it = yield from R.rank_sgd(ep, P, w, b, cfg, shard.n, B, S, it, overlap, world)
+            out.append((ls, vs, it))
+        return P, w, b, out
+
+    def ada():
+        cfg = O.adagrad_cfg()
+        P, w, it = P0.copy(), w0.copy(), 1
+        hold = [0.0]
+        st = O.AdaState(1, D, K, D)
+        st.gnorm_P[...] = cfg.eps
+        st.gnorm_w[...] = cfg.eps
+        st.gnorm_b.value = cfg.eps
+        out = []
+        for _ in range(2):
+            def ep(lo, hi, it_):
+                hold[0], _, ls, vs = O.fm_adagrad_epoch_mb(shard, ys, 2, P, w, hold[0], cfg, B, st, begin=lo, end=hi, it=it_)
+                return ls, vs
+            st, ls, vs, it = yield from R.rank_adagrad(ep, st, shard.n, B, S, it, overlap, world)
+            out.append((ls, vs, it))
+        return R._ada_flat(st), out
+
+    return sgd(), ada()
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -28,98 +89,61 @@ def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
 
-    import oracle as O
-    from common import random_csr
-    from nimfm_amd import dp
+    import dp_rule as R
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n, d, m, k, B = 400, 50, 6, 4, 32
-    full = random_csr(n, d, m, seed=11)
-    rng = np.random.default_rng(3)
-    y = rng.standard_normal(n)
-    P0, w0 = rng.standard_normal((1, k, d)) * 0.1, np.zeros(d)
-    lo, hi = rank * n // world, (rank + 1) * n // world  # contiguous shards, sgd_multi.nim:85-88
-    shard = O.Dataset(full.indptr[lo:hi + 1] - full.indptr[lo], full.indices[full.indptr[lo]:full.indptr[hi]],
-                      full.data[full.indptr[lo]:full.indptr[hi]], hi - lo, d)
-    # ---- SGD: replicas averaged after every epoch ----
-    P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
-    for _ in range(3):
-        b, it, _, _ = O.fm_sgd_epoch_mb(shard, y[lo:hi], 2, P, w, b, O.sgd_cfg(), B, it=it)
-        tb = torch.tensor([b], dtype=torch.float64)
-        tensors = [torch.from_numpy(P.reshape(-1)), torch.from_numpy(w), tb]
-        dp.exchange(tensors, dist, world, "average")
-        b = float(tb[0])
-    # ---- AdaGrad: state increments summed ----
-    cfg = O.adagrad_cfg()
-    Pa, wa, ba, ita = P0.copy(), w0.copy(), 0.0, 1
-    st = O.AdaState(1, d, k, d)
-    views = [torch.from_numpy(st.gsum_P.reshape(-1)), torch.from_numpy(st.gnorm_P.reshape(-1)),
-             torch.from_numpy(st.gsum_w), torch.from_numpy(st.gnorm_w)]
-    sb = torch.zeros(2, dtype=torch.float64)
-    ba, ita, _, _ = O.fm_adagrad_epoch_mb(shard, y[lo:hi], 2, Pa, wa, ba, cfg, B, st, it=ita)
-    sb[0], sb[1] = st.gsum_b.value, st.gnorm_b.value
-    prevs = [torch.zeros_like(v) for v in views] + [torch.zeros(2, dtype=torch.float64)]
-    prevs[1].fill_(cfg.eps); prevs[3].fill_(cfg.eps); prevs[4][1] = cfg.eps  # state before the epoch
-    dp.exchange(views + [sb], dist, world, "sum_deltas", prevs)
-    q.put((rank, P.copy(), w.copy(), b, st.gsum_P.copy(), st.gnorm_P.copy(), st.gsum_w.copy(), sb.numpy().copy()))
+    O, full, y, P0, w0 = _problem()
+    shard, ys = _shard(O, full, y, rank, world)
+    res = []
+    for S, overlap in CASES:
+        g_sgd, g_ada = _rank_gens(O, shard, ys, P0, w0, S, overlap, world)
+        res.append((R.drive_with_dist(g_sgd, dist, torch), R.drive_with_dist(g_ada, dist, torch)))
+    q.put((rank, res))
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-def test_exchange_world2():
+@pytest.mark.timeout(300)
+def test_exchange_rule_world2():
     import torch.multiprocessing as mp
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle as O
-    from common import random_csr
+    import dp_rule as R
 
-    O.build()
+    O, full, y, P0, w0 = _problem()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=150) for _ in procs], key=lambda t: t[0])
+    got = dict(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    # both ranks hold the same replicas after the exchange
-    for a, b in zip(res[0][1:], res[1][1:]):
-        assert np.array_equal(np.asarray(a), np.asarray(b))
-    # single-process restatement
-    n, d, m, k, B, world = 400, 50, 6, 4, 32, 2
-    full = random_csr(n, d, m, seed=11)
-    rng = np.random.default_rng(3)
-    y = rng.standard_normal(n)
-    P0, w0 = rng.standard_normal((1, k, d)) * 0.1, np.zeros(d)
-    shards = []
-    for r in range(world):
-        lo, hi = r * n // world, (r + 1) * n // world
-        shards.append((O.Dataset(full.indptr[lo:hi + 1] - full.indptr[lo], full.indices[full.indptr[lo]:full.indptr[hi]],
-                                 full.data[full.indptr[lo]:full.indptr[hi]], hi - lo, d), y[lo:hi]))
-    P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
-    for _ in range(3):
-        reps = []
-        for sh, ys in shards:
-            Pr, wr = P.copy(), w.copy()
-            br, itr, _, _ = O.fm_sgd_epoch_mb(sh, ys, 2, Pr, wr, b, O.sgd_cfg(), B, it=it)
-            reps.append((Pr, wr, br))
-        it = itr
-        P = (reps[0][0] + reps[1][0]) / world
-        w = (reps[0][1] + reps[1][1]) / world
-        b = (reps[0][2] + reps[1][2]) / world
-    assert np.allclose(res[0][1], P, rtol=1e-13, atol=1e-15) and np.allclose(res[0][2], w, rtol=1e-13, atol=1e-15)
-    assert abs(res[0][3] - b) < 1e-14
-    cfg = O.adagrad_cfg()
-    gs, gn, gw = np.zeros((1, d, k)), np.full((1, d, k), cfg.eps), np.zeros(d)
-    gb = np.array([0.0, cfg.eps])
-    for sh, ys in shards:
-        st = O.AdaState(1, d, k, d)
-        O.fm_adagrad_epoch_mb(sh, ys, 2, P0.copy(), w0.copy(), 0.0, cfg, B, st, it=1)
-        gs += st.gsum_P
-        gn += st.gnorm_P - cfg.eps
-        gw += st.gsum_w
-        gb += [st.gsum_b.value, st.gnorm_b.value - cfg.eps]
-    assert np.allclose(res[0][4], gs, rtol=1e-12, atol=1e-15) and np.allclose(res[0][5], gn, rtol=1e-12, atol=1e-18)
-    assert np.allclose(res[0][6], gw, rtol=1e-12, atol=1e-15) and np.allclose(res[0][7], gb, rtol=1e-12, atol=1e-15)
+    for ci, (S, overlap) in enumerate(CASES):
+        gens = [_rank_gens(O, *_shard(O, full, y, r, 2), P0, w0, S, overlap, 2) for r in range(2)]
+        want_sgd = R.simulate([g[0] for g in gens])
+        want_ada = R.simulate([g[1] for g in gens])
+        for r in range(2):
+            (P, w, b, hist), (st, hist_a) = got[r][ci]
+            Pw, ww, bw, histw = want_sgd[r]
+            # gloo adds in its own order: two ranks, so a + b == b + a bit for bit
+            assert np.array_equal(P, Pw) and np.array_equal(w, ww) and b == bw, (S, overlap, r)
+            assert hist == histw
+            assert np.array_equal(st, want_ada[r][0]) and hist_a == want_ada[r][1]
+        # all replicas leave an epoch identical, the step counter covers the samples of all ranks
+        assert np.array_equal(got[0][ci][0][0], got[1][ci][0][0]) and np.array_equal(got[0][ci][1][0], got[1][ci][1][0])
+        assert got[0][ci][0][3][-1][2] == 1 + 2 * N and got[0][ci][1][1][-1][2] == 1 + 2 * N
+    # the delayed exchange really differs from the immediate one and from no mid-epoch exchange (the rule is exercised)
+    assert not np.array_equal(got[0][0][0][0], got[0][1][0][0])
+
+
+def test_sync_point_agreement():
+    """sync points lie after regular mini-batches only and strictly before the last one"""
+    import dp_rule as R
+
+    assert R.n_sync_mine(R.batch_bounds(201, 32, False), 32, 2) == 3   # 7 batches (6 regular + tail of 9)
+    assert R.n_sync_mine(R.batch_bounds(192, 32, False), 32, 2) == 2   # 6 regular batches: not after the last
+    assert R.n_sync_mine(R.batch_bounds(192, 32, False), 32, 0) == 0
+    assert R.n_sync_mine(R.batch_bounds(20, 32, False), 32, 1) == 0
+    assert R.batch_bounds(70, 32, True) == [0, 1, 33, 65, 70]

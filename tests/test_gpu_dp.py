@@ -1,9 +1,15 @@
-"""-m gpu: the data-parallel plumbing on one MI355X -- torch tensors aliasing the library's device
-buffers (__cuda_array_interface__), an RCCL (backend "nccl") all-reduce over them with world_size 1,
-and training continuing correctly afterwards."""
+"""-m gpu: the data-parallel exchange inside the library (csrc/dp.hip, nfm_dp_* / nfm_opt_set_dp) on one MI355X.
+
+* groups of 2 and 3 ranks made by nfm_dp_create_local -- every rank has its own context, stream, dataset shard, model
+  replica, optimizer and host thread, all on the one GPU -- run nfm_opt_epoch together; the result is held to the CPU
+  restatement of the exchange rule (tests/dp_rule.py, itself checked across real processes in tests/test_dp_gloo.py):
+  sync_period 0 / 2 / 3, delayed (overlapped) and immediate exchange, shards of unequal size, SGD and AdaGrad, FM and
+  FFM; every replica ends bitwise identical; loss / viol / `it` cover all ranks.
+* the RCCL transport (nfm_dp_unique_id / nfm_dp_create, what one-process-per-GPU runs use) with world_size 1: the
+  collective really goes through ncclAllReduce and must leave a single replica's training unchanged."""
 import os
-import socket
 import sys
+import threading
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -11,78 +17,201 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np  # noqa: E402
 import pytest  # noqa: E402
 
+import dp_rule as R  # noqa: E402
+import nimfm_amd as nf  # noqa: E402
 import oracle as O  # noqa: E402
-from common import assert_close, random_csr
-from gpu_common import gpu_fm, to_gpu
+from common import assert_close, random_csr  # noqa: E402
+from gpu_common import gpu_ffm, gpu_fm  # noqa: E402
+from nimfm_amd import dp  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+N, D, M, K, B = 1003, 120, 8, 8, 64
 
 
-def test_alias_and_rccl_allreduce_world1():
-    """Runs in a fresh interpreter: torch must initialise its HIP runtime before libnimfm_hip.so is
-    loaded (as in bench.py); the other GPU tests of this process loaded the library first."""
-    import subprocess
-    import sys
-    out = subprocess.run([sys.executable, os.path.abspath(__file__)], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-    assert "dp world1 ok" in out.stdout
+def _shards(full, y, world):
+    out = []
+    for r in range(world):
+        lo, hi = dp.shard_bounds(full.n, r, world)
+        a, b = full.indptr[lo], full.indptr[hi]
+        out.append((O.Dataset(full.indptr[lo:hi + 1] - a, full.indices[a:b], full.data[a:b], hi - lo, full.d,
+                              None if full.fields is None else full.fields[a:b], full.n_fields), y[lo:hi]))
+    return out
 
 
-def _main():
-    import torch
-    import torch.distributed as dist
+def _run_ranks(world, make_rank):
+    """make_rank(r, ctx, group) -> result; one host thread per rank"""
+    ctxs = [nf.Context(0) for _ in range(world)]
+    groups = dp.Group.local(ctxs)
+    res, err = [None] * world, []
 
-    import nimfm_amd as nf
-    from nimfm_amd import dp
+    def body(r):
+        try:
+            res[r] = make_rank(r, ctxs[r], groups[r])
+        except BaseException as e:  # noqa: BLE001
+            err.append((r, e))
 
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
-    dev = torch.device("cuda", 0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    try:
-        n, d, m, k, B = 4000, 300, 8, 16, 256
-        Xo = random_csr(n, d, m, seed=4)
-        rng = np.random.default_rng(2)
-        y = rng.standard_normal(n)
-        P0, w0 = rng.standard_normal((1, k, d)) * 0.05, np.zeros(d)
-        X = to_gpu(Xo)
-        X.set_targets(y)
-        for solver in ("sgd", "adagrad"):
-            fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, 0.0)
-            opt = (nf.newSGD(maxIter=1, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B) if solver == "sgd"
-                   else nf.newAdaGrad(maxIter=1, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B))
-            opt._handle(fm, X.ctx, "minibatch")
-            views = dp.ParamViews(torch, dev, fm, opt)
-            # the alias really is the library's memory: P in the device layout [d][Kp], Kp = 16
-            fm._pull()
-            assert_close(views.params[0].cpu().numpy().reshape(d, k).T, fm.P[0], 0, 0)
-            for _ in range(3):
-                opt._epoch(X, None, 0, n)
-                opt.it += n
-                views.average(dist, 1, force=True)  # one replica: the exchange must be the identity
-            opt._finalize_into(fm)
-            if solver == "sgd":
-                P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
-                for _ in range(3):
-                    b, it, _, _ = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, b, O.sgd_cfg(), B, it=it)
-            else:
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not any(t.is_alive() for t in th), "a rank hangs in the exchange"
+    assert not err, err
+    info = [g.info() for g in groups]
+    for g in groups:
+        g.close()
+    return res, info
+
+
+@pytest.mark.parametrize("world,S,overlap", [(2, 0, True), (2, 2, True), (3, 3, True), (2, 3, False)])
+def test_local_group_sgd_and_adagrad_vs_rule(world, S, overlap):
+    full = random_csr(N, D, M, seed=21)
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal(N)
+    P0, w0, b0 = rng.standard_normal((1, K, D)) * 0.1, rng.standard_normal(D) * 0.01, 0.25
+    shards = _shards(full, y, world)
+    epochs = 2
+
+    # ---- the rule on the CPU ----
+    def gens():
+        gs, ga = [], []
+        for shard, ys in shards:
+            def sgd(shard=shard, ys=ys):
+                P, w, b, it = P0.copy(), w0.copy(), b0, 1
+                cfg = O.sgd_cfg(eta0=0.05)
+                hist = []
+                for _ in range(epochs):
+                    def ep(P_, w_, b_, lo, hi, it_):
+                        b2, _, ls, vs = O.fm_sgd_epoch_mb(shard, ys, 2, P_, w_, b_, cfg, B, begin=lo, end=hi, it=it_)
+                        return b2, ls, vs
+                    P, w, b, ls, vs, it = yield from R.rank_sgd(ep, P, w, b, cfg, shard.n, B, S, it, overlap, world)
+                    hist.append((vs, ls / N))
+                return P, w, b, hist, it
+
+            def ada(shard=shard, ys=ys):
                 cfg = O.adagrad_cfg()
-                P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
-                st = O.AdaState(1, d, k, d)
-                for _ in range(3):
-                    b, it, _, _ = O.fm_adagrad_epoch_mb(Xo, y, 2, P, w, b, cfg, B, st, it=it)
-                b = O.fm_adagrad_finalize(2, P, w, b, cfg, it, st)
-            assert abs(fm.intercept - b) < 1e-11
-            assert_close(fm.w, w, 1e-9, 1e-12, solver + " w")
-            assert_close(fm.P, P, 1e-9, 1e-12, solver + " P")
+                P, w, it = P0.copy(), w0.copy(), 1
+                hold = [b0]
+                st = O.AdaState(1, D, K, D)
+                st.gnorm_P[...] = cfg.eps
+                st.gnorm_w[...] = cfg.eps
+                st.gnorm_b.value = cfg.eps
+                hist = []
+                for _ in range(epochs):
+                    def ep(lo, hi, it_):
+                        hold[0], _, ls, vs = O.fm_adagrad_epoch_mb(shard, ys, 2, P, w, hold[0], cfg, B, st, begin=lo, end=hi, it=it_)
+                        return ls, vs
+                    st, ls, vs, it = yield from R.rank_adagrad(ep, st, shard.n, B, S, it, overlap, world)
+                    hist.append((vs, ls / N))
+                bb = O.fm_adagrad_finalize(2, P, w, hold[0], cfg, it, st)
+                return P, w, bb, hist, it
+
+            gs.append(sgd())
+            ga.append(ada())
+        return gs, ga
+
+    gs, ga = gens()
+    want = {"sgd": R.simulate(gs), "adagrad": R.simulate(ga)}
+
+    # ---- the library: one thread per rank ----
+    for solver in ("sgd", "adagrad"):
+        def make_rank(r, ctx, group, solver=solver):
+            shard, ys = shards[r]
+            X = nf.CSRDataset(shard.data, shard.indices, shard.indptr, shard.n, D, ctx=ctx)
+            fm = gpu_fm("regression", 2, K, "explicit", True, True, P0, w0, b0)
+            if solver == "sgd":
+                opt = nf.newSGD(maxIter=epochs, eta0=0.05, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B)
+            else:
+                opt = nf.newAdaGrad(maxIter=epochs, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B)
+            opt.setDataParallel(group, S, overlap)
+            opt.fit(X, ys, fm)
+            return fm.P.copy(), fm.w.copy(), fm.intercept, list(opt.history), opt.it
+
+        got, info = _run_ranks(world, make_rank)
+        for r in range(world):
+            Pw, ww, bw, histw, itw = want[solver][r]
+            P, w, b, hist, it = got[r]
+            assert it == itw == 1 + epochs * N
+            assert abs(b - bw) < 1e-11
+            assert_close(w, ww, 1e-9, 1e-13, "%s w rank %d" % (solver, r))
+            assert_close(P, Pw, 1e-9, 1e-13, "%s P rank %d" % (solver, r))
+            assert_close([h[1] for h in hist], [h[1] for h in histw], 1e-10, 0, "mean loss over all ranks")
+            assert_close([h[0] for h in hist], [h[0] for h in histw], 1e-8, 0, "viol over all ranks")
+            # every replica holds the same bits
+            assert np.array_equal(P, got[0][0]) and np.array_equal(w, got[0][1]) and b == got[0][2]
+        n_mid = min(R.n_sync_mine(R.batch_bounds(sh.n, B, False), B, S) for sh, _ in shards)
+        assert info[0]["world"] == world and info[0]["collectives"] >= epochs * (1 + (n_mid if solver == "sgd" else 0))
+
+
+def test_local_group_ffm():
+    from common import init_ffm
+    world, S, F = 2, 2, 4
+    rng = np.random.default_rng(8)
+    n, per = 600, 10
+    d = F * per
+    idx = np.stack([f * per + rng.integers(0, per, size=n) for f in range(F)], axis=1)
+    val = rng.uniform(-1, 1, size=(n, F))
+    full = O.Dataset(np.arange(n + 1) * F, idx.ravel(), val.ravel(), n, d, fields=np.tile(np.arange(F), n), n_fields=F)
+    y = rng.standard_normal(n)
+    P0, w0, b0 = init_ffm(d, F, 4, scale=0.05)
+    shards = _shards(full, y, world)
+    cfg = O.sgd_cfg(eta0=0.01)
+
+    def gen(shard, ys):
+        P, w = P0.copy(), w0.copy()
+
+        def ep(P_, w_, b_, lo, hi, it_):
+            b2, _, ls, vs = O.ffm_sgd_epoch_mb(shard, ys, P_, w_, b_, cfg, 32, begin=lo, end=hi, it=it_)
+            return b2, ls, vs
+        return (yield from R.rank_sgd(ep, P, w, b0, cfg, shard.n, 32, S, 1, True, world))
+
+    want = R.simulate([gen(*s) for s in shards])
+
+    def make_rank(r, ctx, group):
+        shard, ys = shards[r]
+        X = nf.CSRDataset(shard.data, shard.indices, shard.indptr, shard.n, d, fields=shard.fields, nFields=F, ctx=ctx)
+        ffm = gpu_ffm("regression", 4, True, True, P0, w0, b0)
+        opt = nf.newSGD(maxIter=1, eta0=0.01, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=32)
+        opt.setDataParallel(group, S, True)
+        opt.fit(X, ys, ffm)
+        return ffm.P.copy(), ffm.w.copy(), ffm.intercept, opt.it
+
+    got, _ = _run_ranks(world, make_rank)
+    for r in range(world):
+        assert got[r][3] == want[r][5] == 1 + n
+        assert abs(got[r][2] - want[r][2]) < 1e-11
+        assert_close(got[r][1], want[r][1], 1e-9, 1e-13, "w")
+        assert_close(got[r][0], want[r][0], 1e-9, 1e-13, "P")
+        assert np.array_equal(got[r][0], got[0][0])
+
+
+def test_rccl_group_world1():
+    """the RCCL transport end to end on one GPU: id -> communicator -> ncclAllReduce on the arena (mid-epoch and closing
+    exchanges); a single replica's result must be what it is without a group, up to the closing rescale"""
+    full = random_csr(N, D, M, seed=4)
+    rng = np.random.default_rng(2)
+    y = rng.standard_normal(N)
+    P0, w0 = rng.standard_normal((1, K, D)) * 0.05, np.zeros(D)
+    ctx = nf.default_context()
+    grp = dp.Group.rccl(ctx, dp.Group.unique_id(), 0, 1)
+    try:
+        X = nf.CSRDataset(full.data, full.indices, full.indptr, N, D, ctx=ctx)
+        for solver in ("sgd", "adagrad"):
+            res = []
+            for use_group in (False, True):
+                fm = gpu_fm("regression", 2, K, "explicit", True, True, P0, w0, 0.0)
+                opt = (nf.newSGD if solver == "sgd" else nf.newAdaGrad)(maxIter=3, verbose=0, tol=0, shuffle=False, mode="minibatch",
+                                                                         batch=B)
+                if use_group:
+                    opt.setDataParallel(grp, 2, True)
+                opt.fit(X, y, fm)
+                res.append((fm.P.copy(), fm.w.copy(), fm.intercept, list(opt.history), opt.it))
+            assert res[0][4] == res[1][4] == 1 + 3 * N
+            assert_close(res[1][0], res[0][0], 1e-12, 1e-15, solver + " P")
+            assert_close(res[1][1], res[0][1], 1e-12, 1e-15, solver + " w")
+            assert abs(res[1][2] - res[0][2]) < 1e-13
+            assert_close([h[1] for h in res[1][3]], [h[1] for h in res[0][3]], 1e-12, 0, "loss")
+        info = grp.info()
+        assert info["world"] == 1 and info["collectives"] >= 6 and info["bytes"] > 0
     finally:
-        dist.destroy_process_group()
-    print("dp world1 ok")
-
-
-if __name__ == "__main__":
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    sys.path.insert(0, os.path.dirname(here))
-    sys.path.insert(0, here)
-    _main()
+        grp.close()
