@@ -264,6 +264,15 @@ int32_t nfm_opt_set_state(nfm_opt* o, const double* gsum_P, const double* gnorm_
  * `viol`.  Classification targets are sign()-ed (fm_base.nim:32-34). */
 int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t begin,
                       int64_t end, double* loss_sum, double* viol_sum);
+/* shuffle = true on the device (NFM_MODE_MINIBATCH): with seed >= 0 every nfm_opt_epoch call WITHOUT an explicit
+ * permutation runs over a fresh random order of the samples [begin, end), drawn on the device from (seed, number of
+ * such calls so far) -- the reference shuffles `indices` on the host once per epoch (optimizer/sgd.nim:297, Nim's global
+ * generator, not reproduced: RNG parity is unpinned either way) -- and the batch plan of the NEXT such call is built on a
+ * second stream while the current epoch runs.  seed < 0 switches it off (the default: perm == NULL is the dataset's own
+ * order).  nfm_opt_get_perm: the n = end - begin sample ids of the most recent epoch call that ran in a permuted order
+ * (device-drawn or passed in), so that any run can be replayed sample for sample. */
+int32_t nfm_opt_set_shuffle(nfm_opt* o, int64_t seed);
+int32_t nfm_opt_get_perm(nfm_opt* o, int64_t* perm /*n*/, int64_t n);
 /* finalize (optimizer/sgd.nim:99-113; adagrad.nim:65-84): leaves the model's
  * parameters as the reference's fm.P/w/intercept after fit. Idempotent. */
 int32_t nfm_opt_finalize(nfm_opt* o);

@@ -99,6 +99,8 @@ proc nfm_opt_get_state*(o: NfmOpt, gsumP, gnormP, gsumW, gnormW, gsumB, gnormB: 
 proc nfm_opt_set_state*(o: NfmOpt, gsumP, gnormP, gsumW, gnormW: ptr float64, gsumB, gnormB: float64): int32
 proc nfm_opt_epoch*(o: NfmOpt, ds: NfmDataset, perm: ptr int64, first, last: int64,
                     lossSum, violSum: ptr float64): int32
+proc nfm_opt_set_shuffle*(o: NfmOpt, seed: int64): int32
+proc nfm_opt_get_perm*(o: NfmOpt, perm: ptr int64, n: int64): int32
 proc nfm_opt_finalize*(o: NfmOpt): int32
 proc nfm_opt_destroy*(o: NfmOpt): int32
 # data-parallel groups: one process per GPU (RCCL over xGMI) or the ranks of one process (threads + peer access)

@@ -29,6 +29,7 @@ struct nfm_dataset {
   // again by `new` after a `delete`, for a dataset of the same shape and different structure).  serial: bumps whenever
   // one of the v.* device pointers changes (nfm_dataset_set_targets) -- a captured hipGraph holds those pointers.
   uint64_t uid = 0, serial = 0;
+  CscIndex csc;  // column-major twin, built by the first plan that can use it (plan.hip)
 };
 static uint64_t next_dataset_uid() {
   static std::atomic<uint64_t> g{0};
@@ -86,6 +87,16 @@ struct nfm_opt {
   std::unique_ptr<Plan> grad_plan;
   // data-parallel group (dp.h): when set, nfm_opt_epoch reconciles the replicas every dp_sync_period mini-batches
   // (delayed by one period when dp_overlap) and exactly at the end of the call
+  // device-side shuffle (nfm_opt_set_shuffle): every epoch call without an explicit permutation draws a fresh order on
+  // the device; the plan of the NEXT epoch is built on a second stream while the current epoch runs
+  int64_t shuffle_seed = -1;
+  uint64_t shuffle_epoch = 0;
+  DevBuf perm_gen, perm_next;
+  std::unique_ptr<Plan> next_plan;
+  uint64_t next_plan_epoch = 0;
+  bool next_plan_ready = false;
+  hipStream_t plan_stream = nullptr;
+  double* out2_pinned = nullptr;
   nfm_dp* dp = nullptr;
   int64_t dp_sync_period = 0;
   bool dp_overlap = true;
@@ -866,18 +877,39 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       const bool reuse = o->plan && !perm && !o->plan->has_perm && o->plan->ds_uid == ds->uid && o->plan->ds_nnz == ds->v.nnz && o->plan->begin == begin &&
                          o->plan->end == end && o->plan->batch == o->batch && o->plan->first_singleton == first_singleton &&
                          o->plan->n_aug == m->n_aug;
-      if (!reuse) {
+      // Features touched once per batch are updated by the row phase itself ("singles"); worth the
+      // second visit of the row only when they are a sizeable share of the touches.  With a touch
+      // rate lambda = batch * nnz_per_row / d per feature that share is about exp(-lambda).
+      const double lambda = (double)o->batch * ((double)ds->v.nnz / (double)std::max<int64_t>(ds->v.n, 1)) / (double)m->d;
+      bool use_singles = o->kind != OPT_PSGD && m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2 && (o->batch == 1 || lambda <= 1.4);
+      if (const char* env = getenv("NFM_SINGLES")) use_singles = use_singles && atoi(env) != 0;  // tuning override
+      const bool sort_by_count = m->Kp * (int)sizeof(double) >= 128;  // rows of at least one 128-byte line (plan.hip)
+      const bool dev_shuffle = !perm && o->shuffle_seed >= 0 && o->kind != OPT_PSGD;
+      auto plan_matches = [&](const Plan& PL, bool fs) {
+        return PL.ds_uid == ds->uid && PL.ds_nnz == ds->v.nnz && PL.begin == begin && PL.end == end && PL.batch == o->batch &&
+               PL.first_singleton == fs && PL.n_aug == m->n_aug && PL.use_singles == use_singles;
+      };
+      if (dev_shuffle) {
+        // the order of this epoch is a function of (seed, shuffle_epoch); its plan may have been built beside the
+        // previous epoch
+        if (o->next_plan_ready && o->next_plan && o->next_plan_epoch == o->shuffle_epoch && plan_matches(*o->next_plan, first_singleton)) {
+          std::swap(o->plan, o->next_plan);
+          o->perm_gen.take(o->perm_next);
+        } else {
+          if (!o->plan) o->plan.reset(new Plan());
+          TimedLaunch tl(ctx, "plan_build");
+          NFM_TRY(gen_permutation(ctx, st, o->shuffle_seed, o->shuffle_epoch, begin, ns, &o->perm_gen));
+          NFM_TRY(plan_build(ctx, ds->v, m->n_aug, nullptr, begin, end, o->batch, first_singleton, want_tq, use_singles, sort_by_count,
+                             o->plan.get(), st, o->perm_gen.as<int64_t>(), &ds->csc));
+          o->plan->ds_uid = ds->uid;
+          o->plan->ds_nnz = ds->v.nnz;
+        }
+        o->next_plan_ready = false;
+      } else if (!reuse) {
         if (!o->plan) o->plan.reset(new Plan());
         TimedLaunch tl(ctx, "plan_build");
-        // Features touched once per batch are updated by the row phase itself ("singles"); worth the
-        // second visit of the row only when they are a sizeable share of the touches.  With a touch
-        // rate lambda = batch * nnz_per_row / d per feature that share is about exp(-lambda).
-        const double lambda = (double)o->batch * ((double)ds->v.nnz / (double)std::max<int64_t>(ds->v.n, 1)) / (double)m->d;
-        bool use_singles = o->kind != OPT_PSGD && m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2 && (o->batch == 1 || lambda <= 1.4);
-        if (const char* env = getenv("NFM_SINGLES")) use_singles = use_singles && atoi(env) != 0;  // tuning override
-        const bool sort_by_count = m->Kp * (int)sizeof(double) >= 128;  // rows of at least one 128-byte line (plan.hip)
         NFM_TRY(plan_build(ctx, ds->v, m->n_aug, perm, begin, end, o->batch, first_singleton, want_tq, use_singles, sort_by_count,
-                           o->plan.get()));
+                           o->plan.get(), nullptr, nullptr, perm ? &ds->csc : nullptr));
         o->plan->ds_uid = ds->uid;
         o->plan->ds_nnz = ds->v.nnz;
       }
@@ -908,11 +940,41 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         o->W.after_batch = [&de](int64_t b) { return dp_after_batch(de, b); };
       }
       int rc_epoch;
+      // device shuffle: the epoch is only ENQUEUED here; the next epoch's order and plan are then built on a second
+      // stream (its host-side waits block on that stream only) while this epoch runs
+      const bool prefetch = dev_shuffle && !ctx->timing.enabled;
+      double* out2_dst = out2;
+      if (prefetch) {
+        if (!o->out2_pinned) NFM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&o->out2_pinned), sizeof(double) * 2, hipHostMallocDefault));
+        if (!o->plan_stream) NFM_HIP_CHECK(hipStreamCreateWithFlags(&o->plan_stream, hipStreamNonBlocking));
+        out2_dst = o->out2_pinned;
+      }
       if (m->cfg.kind == NFM_KIND_FM)
-        rc_epoch = mb_fm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2, (ds->uid << 20) ^ ds->serial);
+        rc_epoch = mb_fm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2_dst, (ds->uid << 20) ^ ds->serial, prefetch);
       else
-        rc_epoch = mb_ffm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2);
+        rc_epoch = mb_ffm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2_dst, prefetch);
       o->W.after_batch = nullptr;
+      if (prefetch) {
+        int rc_next = NFM_OK;
+        if (rc_epoch == NFM_OK) {
+          if (!o->next_plan) o->next_plan.reset(new Plan());
+          rc_next = gen_permutation(ctx, o->plan_stream, o->shuffle_seed, o->shuffle_epoch + 1, begin, ns, &o->perm_next);
+          if (rc_next == NFM_OK)
+            rc_next = plan_build(ctx, ds->v, m->n_aug, nullptr, begin, end, o->batch, /*first_singleton=*/false, want_tq, use_singles,
+                                 sort_by_count, o->next_plan.get(), o->plan_stream, o->perm_next.as<int64_t>(), &ds->csc);
+          if (rc_next == NFM_OK) {
+            o->next_plan->ds_uid = ds->uid;
+            o->next_plan->ds_nnz = ds->v.nnz;
+            o->next_plan_epoch = o->shuffle_epoch + 1;
+            o->next_plan_ready = true;
+          }
+        }
+        NFM_HIP_CHECK(hipStreamSynchronize(st));
+        out2[0] = o->out2_pinned[0];
+        out2[1] = o->out2_pinned[1];
+        NFM_TRY(rc_next);
+      }
+      if (dev_shuffle) o->shuffle_epoch++;
       NFM_TRY(rc_epoch);
       if (o->dp) {
         NFM_TRY(dp_fold_pending(de));
@@ -1001,6 +1063,26 @@ int32_t nfm_opt_predict_all_with_grad(nfm_opt* o, nfm_dataset* ds, double* y_pre
   if (grad_b) NFM_HIP_CHECK(hipMemcpyAsync(grad_b, g.as<char>() + bP + bw, sizeof(double), hipMemcpyDeviceToHost, st));
   NFM_HIP_CHECK(hipStreamSynchronize(st));
   if (loss_sum) *loss_sum = out2[0];
+  return NFM_OK;
+}
+
+int32_t nfm_opt_set_shuffle(nfm_opt* o, int64_t seed) {
+  NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
+  NFM_CHECK(seed < 0 || o->mode == NFM_MODE_MINIBATCH, NFM_ERR_UNSUPPORTED, "the device-side shuffle needs NFM_MODE_MINIBATCH");
+  o->shuffle_seed = seed;
+  o->shuffle_epoch = 0;
+  o->next_plan_ready = false;
+  return NFM_OK;
+}
+
+int32_t nfm_opt_get_perm(nfm_opt* o, int64_t* perm, int64_t n) {
+  NFM_CHECK(o && (perm || n == 0), NFM_ERR_INVALID, "null argument");
+  NFM_CHECK(o->plan && o->plan->has_perm && o->plan->perm.p, NFM_ERR_INVALID, "the last epoch ran in the dataset's own order");
+  NFM_CHECK(n == o->plan->end - o->plan->begin, NFM_ERR_INVALID, "the last epoch covered %lld samples, not %lld",
+            (long long)(o->plan->end - o->plan->begin), (long long)n);
+  NFM_TRY(use_device(o->ctx));
+  NFM_HIP_CHECK(hipMemcpyAsync(perm, o->plan->perm.p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, o->ctx->stream));
+  NFM_HIP_CHECK(hipStreamSynchronize(o->ctx->stream));
   return NFM_OK;
 }
 
@@ -1127,6 +1209,11 @@ int32_t nfm_opt_destroy(nfm_opt* o) {
   if (!o) return NFM_OK;
   (void)hipSetDevice(o->ctx->device);
   (void)hipStreamSynchronize(o->ctx->stream);
+  if (o->plan_stream) {
+    (void)hipStreamSynchronize(o->plan_stream);
+    (void)hipStreamDestroy(o->plan_stream);
+  }
+  if (o->out2_pinned) (void)hipHostFree(o->out2_pinned);
   delete o;
   return NFM_OK;
 }

@@ -35,13 +35,15 @@ struct MbWork {
 };
 
 // data_serial: changes whenever one of X's device pointers does (a captured graph holds them)
+// defer_sync: return right after the epoch has been enqueued (out2_host must then be pinned memory; the caller
+// synchronises ctx->stream before reading it)
 int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
-                int64_t it0, double* out2_host, uint64_t data_serial = 0);
+                int64_t it0, double* out2_host, uint64_t data_serial = 0, bool defer_sync = false);
 // psgd.hip: Params.step's shrink + the regulariser's prox after one mini-batch of MBPSGD (it = it0p[0] + it_b)
 void launch_psgd_step(nfm_ctx* ctx, const ModelView& M, const OptView& O, MbWork& W, const double* it0p, double it_b);
 // yhat / dloss of the samples of the last epoch call's batch (a single batch: pgd.predictAllWithGrad), device arrays
 int mb_fm_records(nfm_ctx* ctx, MbWork& W, int64_t n, double* yhat_dev, double* dL_dev);
 int mb_ffm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
-                 int64_t it0, double* out2_host);
+                 int64_t it0, double* out2_host, bool defer_sync = false);
 
 }  // namespace nfm

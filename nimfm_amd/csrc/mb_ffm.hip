@@ -755,7 +755,7 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
 }
 
 int mb_ffm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
-                 int64_t it0, double* out2_host) {
+                 int64_t it0, double* out2_host, bool defer_sync) {
   NFM_CHECK(M.kind == NFM_KIND_FFM, NFM_ERR_UNSUPPORTED, "mb_ffm_epoch: FFM only");
   NFM_CHECK(M.Kp == 2 * M.L && M.Kp <= 128, NFM_ERR_UNSUPPORTED, "mini-batch mode supports n_components <= 128");
   NFM_CHECK(P.toff.p && (P.TM == 0 || P.tq.p), NFM_ERR_INVALID, "FFM plan lacks the touch tables");
@@ -799,7 +799,7 @@ int mb_ffm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& 
 #undef NFM_RUN
   NFM_TRY(rc);
   NFM_HIP_CHECK(hipMemcpyAsync(out2_host, W.out_acc.p, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
-  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  if (!defer_sync) NFM_HIP_CHECK(hipStreamSynchronize(st));
   return NFM_OK;
 }
 

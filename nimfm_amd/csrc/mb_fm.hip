@@ -148,7 +148,7 @@ void MbWork::drop_graph() {
 MbWork::~MbWork() { drop_graph(); }
 
 int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
-                int64_t it0, double* out2_host, uint64_t data_serial) {
+                int64_t it0, double* out2_host, uint64_t data_serial, bool defer_sync) {
   NFM_CHECK(M.kind == NFM_KIND_FM, NFM_ERR_UNSUPPORTED, "mb_fm_epoch: FM only");
   NFM_CHECK(M.degree <= dev::kMaxDeg, NFM_ERR_UNSUPPORTED, "mini-batch mode supports degree <= %d", dev::kMaxDeg);
   NFM_CHECK(M.Kp == 2 * M.L && M.Kp <= 128, NFM_ERR_UNSUPPORTED, "mini-batch mode supports n_components <= 128");
@@ -205,7 +205,7 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
     NFM_TRY(enqueue_epoch(ctx, opt_kind, X, M, O, P, W, TA));
   }
   NFM_HIP_CHECK(hipMemcpyAsync(out2_host, W.out_acc.p, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
-  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  if (!defer_sync) NFM_HIP_CHECK(hipStreamSynchronize(st));
   return NFM_OK;
 }
 

@@ -49,6 +49,17 @@ struct Plan {
   void release();
 };
 
+// The column-major twin of a dataset (plan.hip: plans for dense batches come from it), built once per dataset on the
+// first epoch that can use it: column j holds its entries [cptr[j], cptr[j+1]) in sample order.
+struct CscIndex {
+  bool built = false, usable = false;
+  int64_t max_col = 0;
+  DevBuf cptr;  // int64[d + 1]
+  DevBuf crow;  // int32[nnz] sample
+  DevBuf cval;  // double[nnz]
+  DevBuf cnz;   // uint32[nnz] index of the entry in the row-major arrays
+};
+
 // A lane group walks a feature's touches serially (~0.25 us per pair of touches, latency-bound): beyond
 // kHeavyTouches the list is cut into segments of kHeavySegment touches summed by separate lane groups.
 // (Measured on cfg2 with Zipf(1.1) popularity, B = 32768: 256/128 -> 245 us per batch, 48/32 -> 402 us: too
@@ -61,7 +72,13 @@ constexpr int kHeavySegment = 64;
 // 176-188: the second entry overwrites the first one's derivative and the row's parameters are stepped twice with it)
 int check_rows_distinct(nfm_ctx* ctx, const CsrView& X);
 
+// stream: where the build is enqueued and synchronised (default: the context's); perm_dev: the end - begin sample ids of
+// the epoch already on the device (instead of perm_host)
 int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
-               int64_t batch, bool first_singleton, bool want_tq, bool use_singles, bool sort_by_count, Plan* out);
+               int64_t batch, bool first_singleton, bool want_tq, bool use_singles, bool sort_by_count, Plan* out,
+               hipStream_t stream = nullptr, const int64_t* perm_dev = nullptr, CscIndex* csc = nullptr);
+
+// a random order of the samples begin .. begin+ns-1 drawn on the device from (seed, epoch): int64[ns] in *out
+int gen_permutation(nfm_ctx* ctx, hipStream_t st, int64_t seed, uint64_t epoch, int64_t begin, int64_t ns, DevBuf* out);
 
 }  // namespace nfm

@@ -665,7 +665,8 @@ def _echo_info(it, maxIter, viol, loss, regul):
 class _OptimizerBase:
     """optimizer/optimizer_base.nim:2-8 + the fit driver shared by SGD and AdaGrad."""
 
-    def __init__(self, maxIter, alpha0, alpha, beta, loss, verbose, tol, shuffle, nCalls, mode, batch, lossParam):
+    def __init__(self, maxIter, alpha0, alpha, beta, loss, verbose, tol, shuffle, nCalls, mode, batch, lossParam,
+                 deviceShuffle=False):
         if loss not in capi.LOSS:
             raise ValueError("unknown loss %r" % (loss,))
         if mode not in capi.MODE:
@@ -674,6 +675,9 @@ class _OptimizerBase:
         self.loss, self.lossParam = loss, float(lossParam)
         self.verbose, self.tol, self.shuffle, self.nCalls = int(verbose), float(tol), bool(shuffle), int(nCalls)
         self.mode, self.batch = mode, int(batch)
+        # deviceShuffle (mini-batch mode): shuffle = true draws each epoch's order on the device (nfm_opt_set_shuffle) and
+        # builds the next epoch's batch plan beside the current epoch, instead of shuffling `indices` on the host
+        self.deviceShuffle = bool(deviceShuffle)
         self.it = 1
         self._h = None
         self._model = None
@@ -737,6 +741,12 @@ class _OptimizerBase:
         capi.check(capi.lib().nfm_opt_epoch(self._h, X.h, _vp(perm), begin, end, C.byref(ls), C.byref(vs)))
         return ls.value, vs.value
 
+    def last_permutation(self, n):
+        """the sample order of the most recent permuted epoch call (nfm_opt_get_perm)"""
+        out = np.zeros(n, dtype=np.int64)
+        capi.check(capi.lib().nfm_opt_get_perm(self._h, _vp(out), n))
+        return out
+
     def _finalize_into(self, fm):
         capi.check(capi.lib().nfm_opt_finalize(self._h))
         fm._pull()
@@ -765,6 +775,8 @@ class _OptimizerBase:
         if fm._dirty:
             fm._push(X.ctx)
         capi.check(capi.lib().nfm_opt_set_it(self._h, self.it))
+        dev_shuffle = self.shuffle and self.deviceShuffle and mode == "minibatch" and perms is None
+        capi.check(capi.lib().nfm_opt_set_shuffle(self._h, int(getattr(fm, "randomState", 1)) if dev_shuffle else -1))
         if self.verbose > 0:
             _echo_header(self.maxIter)
         n = X.nSamples
@@ -778,7 +790,7 @@ class _OptimizerBase:
             perm = None
             if perms is not None:
                 perm = _i64(perms[epoch])
-            elif self.shuffle:
+            elif self.shuffle and not dev_shuffle:
                 rng.shuffle(indices)  # sgd.nim:297 (Nim's global RNG there)
                 perm = indices
             if callback is not None and self.nCalls > 0 and mode == "sequential":
@@ -835,8 +847,8 @@ class _OptimizerBase:
 class SGD(_OptimizerBase):
     def __init__(self, maxIter=100, eta0=0.01, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squared",
                  scheduling="optimal", power=1.0, verbose=1, tol=1e-3, shuffle=True, nCalls=-1, mode="sequential",
-                 batch=8192, lossParam=1.0):
-        super().__init__(maxIter, alpha0, alpha, beta, loss, verbose, tol, shuffle, nCalls, mode, batch, lossParam)
+                 batch=8192, lossParam=1.0, deviceShuffle=False):
+        super().__init__(maxIter, alpha0, alpha, beta, loss, verbose, tol, shuffle, nCalls, mode, batch, lossParam, deviceShuffle)
         if scheduling not in capi.SCHED:
             raise ValueError("unknown scheduling %r" % (scheduling,))
         self.eta0, self.scheduling, self.power = float(eta0), scheduling, float(power)
@@ -856,8 +868,8 @@ class SGD(_OptimizerBase):
 class AdaGrad(_OptimizerBase):
     def __init__(self, maxIter=100, eta0=0.1, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squared", eps=1e-10,
                  verbose=1, tol=1e-3, shuffle=True, nCalls=-1, mode="sequential", batch=8192, lossParam=1.0,
-                 trackViol=True):
-        super().__init__(maxIter, alpha0, alpha, beta, loss, verbose, tol, shuffle, nCalls, mode, batch, lossParam)
+                 trackViol=True, deviceShuffle=False):
+        super().__init__(maxIter, alpha0, alpha, beta, loss, verbose, tol, shuffle, nCalls, mode, batch, lossParam, deviceShuffle)
         self.eta0, self.eps, self.trackViol = float(eta0), float(eps), bool(trackViol)
 
     def _create(self, mh, mode):

@@ -398,3 +398,54 @@ def test_heavy_features(solver, k):
         assert_close(fm.w, w, RTOL, ATOL, "w")
         assert_close(fm.P, P, RTOL, ATOL, "P")
         assert_close([h[0] for h in opt.history], hv, 1e-9, 1e-12, "viol")
+
+
+@pytest.mark.parametrize("solver", ["sgd", "adagrad"])
+def test_device_shuffle_replays_on_the_oracle(solver):
+    """shuffle = true with the order drawn on the device (nfm_opt_set_shuffle): every epoch gets a fresh permutation, the
+    NEXT epoch's plan is built beside the current epoch on a second stream, and nfm_opt_get_perm hands back the order
+    that was used -- replayed on the CPU restatement of the mini-batch rule it must give the same parameters."""
+    n, d, m, k, B, epochs = 5000, 300, 8, 8, 512, 4
+    Xo = random_csr(n, d, m, seed=31)
+    rng = np.random.default_rng(6)
+    y = rng.standard_normal(n)
+    P0, w0 = rng.standard_normal((1, k, d)) * 0.05, np.zeros(d)
+    X = to_gpu(Xo)
+    fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, 0.0)
+    opt = (nf.newSGD if solver == "sgd" else nf.newAdaGrad)(maxIter=1, verbose=0, tol=0, shuffle=True, mode="minibatch", batch=B,
+                                                             deviceShuffle=True)
+    X.set_targets(y)
+    opt._handle(fm, X.ctx, "minibatch")
+    import ctypes as C
+    from nimfm_amd import _capi as capi
+    capi.check(capi.lib().nfm_opt_set_shuffle(opt._h, 7))
+    perms, hist = [], []
+    for e in range(epochs):
+        ls, vs = opt._epoch(X, None, 0, n)
+        opt.it += n
+        perms.append(opt.last_permutation(n))
+        hist.append((ls, vs))
+    opt._finalize_into(fm)
+    for p in perms:
+        assert np.array_equal(np.sort(p), np.arange(n))
+    assert not any(np.array_equal(perms[a], perms[b]) for a in range(epochs) for b in range(a))
+    assert abs(np.mean(perms[0][: n // 2]) - n / 2) < n / 10  # no obvious structure
+    P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
+    if solver == "sgd":
+        for e in range(epochs):
+            b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, b, O.sgd_cfg(), B, perm=perms[e], it=it)
+            assert_close([ls, vs], hist[e], 1e-9, 0, "loss / viol of epoch %d" % e)
+    else:
+        cfg = O.adagrad_cfg()
+        st = O.AdaState(1, d, k, d)
+        for e in range(epochs):
+            b, it, ls, vs = O.fm_adagrad_epoch_mb(Xo, y, 2, P, w, b, cfg, B, st, perm=perms[e], it=it)
+            assert_close([ls, vs], hist[e], 1e-9, 1e-12, "loss / viol of epoch %d" % e)
+        b = O.fm_adagrad_finalize(2, P, w, b, cfg, it, st)
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
+    # the same seed draws the same orders again; through fit() the seed is the model's randomState
+    capi.check(capi.lib().nfm_opt_set_shuffle(opt._h, 7))
+    opt._epoch(X, None, 0, n)
+    assert np.array_equal(opt.last_permutation(n), perms[0])
