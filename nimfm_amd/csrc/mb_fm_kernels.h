@@ -1402,6 +1402,58 @@ __global__ __launch_bounds__(kBlock) void k_singles(ColArgs a) {
   }
 }
 
+// the closing workgroup of a column-phase launch: fixed-order reductions of the row phase's and the previous batch's
+// partials, the intercept's update; it runs beside the feature workgroups
+template <int OPT>
+__device__ __forceinline__ void col_closer(const ColArgs& a, double (&red)[5][kBlock]) {
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  __syncthreads();
+  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < a.nA; i += kBlock) {
+    const PartA p = a.partsA[i];
+    s[0] += p.loss;
+    s[1] += p.viol;
+    s[2] += p.acc0;
+    s[3] += p.acc1;
+  }
+  for (int i = threadIdx.x; i < a.n_prev; i += kBlock) s[4] += a.parts_prev[i];
+  for (int c = 0; c < 5; ++c) red[c][threadIdx.x] = s[c];
+  __syncthreads();
+  for (int st = kBlock / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st)
+      for (int c = 0; c < 5; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double v = red[1][0] + red[4][0];
+    if (M.fit_intercept) {
+      if (OPT == OPT_SGD) {  // the intercept is touched by every sample of the batch: c = len
+        const double b0 = M.sc[SC_INTERCEPT], f0 = a.Dtab_b[3];
+        v += fabs((red[2][0] + red[3][0] * O.alpha0 * b0) / a.len);
+        M.sc[SC_INTERCEPT] = f0 * b0 - red[2][0] / a.len;
+      } else if (OPT == OPT_PSGD) {
+        // model/params.nim:47 gates the intercept's step on grad.fitLinear -- kept as the reference has it
+        if (O.gradb != nullptr)
+          O.gradb[0] = red[2][0] / O.bsize;
+        else if (M.fit_linear)
+          M.sc[SC_INTERCEPT] += -dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, a.it0p[0] + a.it_b) * (red[2][0] / O.bsize);
+      } else {
+        if (!a.use_stored) {  // adagrad.nim:102-106
+          const double old = M.sc[SC_INTERCEPT];
+          const double nb_ = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * ((a.it0p[0] + a.it_b) - 1.0) * O.alpha0);
+          v += fabs(old - nb_);
+          M.sc[SC_INTERCEPT] = nb_;
+        }
+        O.gsc[0] += red[2][0];
+        O.gsc[1] += red[3][0];
+      }
+    }
+    a.out_acc[0] += red[0][0];
+    a.out_acc[1] += v;
+  }
+}
+
 // STRIDED: the feature workgroups loop over the features (capped grid); otherwise one lane group = one
 // feature and no loop -- the loop costs registers (94 vs 80: 5 instead of 6 wavefronts per SIMD), which
 // the dense regime (cfg2) pays for without needing it
@@ -1477,52 +1529,216 @@ __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
     a.parts[a.nS + blockIdx.x] = v;  // the singles kernel owns parts[0, nS)
   }
   if (!closer) return;
-  // ---- the closing workgroup: fixed-order reductions, intercept update; it runs beside the
-  // feature workgroups (it needs only the row phase's and the previous batch's partials) ----
-  __syncthreads();
-  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < a.nA; i += kBlock) {
-    const PartA p = a.partsA[i];
-    s[0] += p.loss;
-    s[1] += p.viol;
-    s[2] += p.acc0;
-    s[3] += p.acc1;
+  col_closer<OPT>(a, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// column phase, sparse regime (one order of degree 2, SGD / AdaGrad): software-pipelined strided walk
+// ------------------------------------------------------------------------------------------------
+// In the sparse regime a batch has ~1e5 multi-touch features with two or three touches each: a feature costs three
+// DEPENDENT round trips (its header; its parameter row and touch list; the touching samples' records and A rows) and
+// almost no arithmetic, and the register count caps a CU at 16-20 wavefronts -- k_col_phase<.., STRIDED> is latency
+// bound (headline shape: 9 rounds of ~6 us).  Here a lane group keeps THREE features in flight: while the records and
+// A rows of feature u are gathered, the row, the touches, the decay factors and the linear weight of feature
+// u + stride are already requested, and so is the header of feature u + 2 stride.  Same arithmetic, same order of
+// every sum as col_block<.., MODE 0>.
+template <int OPT>
+struct ColStage {  // what the second round trip of a feature delivers
+  double2 st, g2, n2;  // SGD: stored row; AdaGrad: g_sum, g_norm (+ st = stored parameters when viol is tracked)
+  double x, fP, fw, wt, gw, nw;
+  int pib;
+};
+struct ColHdr {
+  int cnt, j;
+  int64_t t0;
+};
+
+template <int L, int OPT>
+__global__ __launch_bounds__(kBlock) void k_col_sparse(ColArgs a) {
+  static_assert(OPT == OPT_SGD || OPT == OPT_ADAGRAD, "SGD / AdaGrad");
+  constexpr int R = kWave / L, TU = 2;
+  __shared__ double red[5][kBlock];
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int gbase = lane - l;
+  const bool closer = blockIdx.x == gridDim.x - 1;
+  const int64_t stride = (int64_t)(gridDim.x - 1) * kWavesPerBlock * R;
+  double viol = 0.0;
+  double sP = 1.0, sPn = 1.0, sw = 1.0, swn = 1.0;
+  if (OPT == OPT_SGD) {
+    sP = a.scales_b[0];
+    sw = a.scales_b[1];
+    sPn = a.scales_n[0];
+    swn = a.scales_n[1];
   }
-  for (int i = threadIdx.x; i < a.n_prev; i += kBlock) s[4] += a.parts_prev[i];
-  for (int c = 0; c < 5; ++c) red[c][threadIdx.x] = s[c];
-  __syncthreads();
-  for (int st = kBlock / 2; st > 0; st >>= 1) {
-    if ((int)threadIdx.x < st)
-      for (int c = 0; c < 5; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + st];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    double v = red[1][0] + red[4][0];
-    if (M.fit_intercept) {
-      if (OPT == OPT_SGD) {  // the intercept is touched by every sample of the batch: c = len
-        const double b0 = M.sc[SC_INTERCEPT], f0 = a.Dtab_b[3];
-        v += fabs((red[2][0] + red[3][0] * O.alpha0 * b0) / a.len);
-        M.sc[SC_INTERCEPT] = f0 * b0 - red[2][0] / a.len;
-      } else if (OPT == OPT_PSGD) {
-        // model/params.nim:47 gates the intercept's step on grad.fitLinear -- kept as the reference has it
-        if (O.gradb != nullptr)
-          O.gradb[0] = red[2][0] / O.bsize;
-        else if (M.fit_linear)
-          M.sc[SC_INTERCEPT] += -dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, a.it0p[0] + a.it_b) * (red[2][0] / O.bsize);
+  const double itp = (a.it0p[0] + a.it_b) - 1.0;
+  const double tmpP = O.eta0 * itp * O.beta;
+  auto load_hdr = [&](int64_t uu) {
+    ColHdr h{0, 0, 0};
+    if (uu < a.u1) {
+      h.cnt = a.ucnt_s[uu];
+      h.j = a.ucol_s[uu];
+      h.t0 = a.ubeg_s[uu];
+      if (h.cnt > kHeavyTouches) h.cnt = 0;  // heavy features: k_heavy_partial / k_heavy_apply
+    }
+    return h;
+  };
+  auto load_stage = [&](const ColHdr& h) {
+    ColStage<OPT> s{};
+    if (h.cnt > 0) {
+      const size_t e = M.row(0, h.j) * M.Kp + 2 * l;
+      if (OPT == OPT_SGD) {
+        s.st = dev::ld_stream(M.P + e);
+        touch_factors(a, h.cnt, s.fP, s.fw);
       } else {
-        if (!a.use_stored) {  // adagrad.nim:102-106
-          const double old = M.sc[SC_INTERCEPT];
-          const double nb_ = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * ((a.it0p[0] + a.it_b) - 1.0) * O.alpha0);
-          v += fabs(old - nb_);
-          M.sc[SC_INTERCEPT] = nb_;
+        s.g2 = dev::ld_stream(O.G + e);
+        s.n2 = dev::ld_stream(O.N + e);
+        if (a.use_stored || O.track_viol) s.st = dev::ld_stream(M.P + e);
+      }
+      if (l < h.cnt) {
+        s.pib = a.tpos[h.t0 + l];
+        s.x = a.tx[h.t0 + l];
+      }
+      if (M.fit_linear && h.j < M.d) {
+        s.wt = M.w[h.j];
+        if (OPT == OPT_ADAGRAD) {
+          s.gw = O.Gw[h.j];
+          s.nw = O.Nw[h.j];
         }
-        O.gsc[0] += red[2][0];
-        O.gsc[1] += red[3][0];
       }
     }
-    a.out_acc[0] += red[0][0];
-    a.out_acc[1] += v;
+    return s;
+  };
+  int64_t u = closer ? a.u1 : a.u0 + ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  ColHdr h0 = load_hdr(u), h1 = load_hdr(u + stride);
+  ColStage<OPT> s0 = load_stage(h0);
+  for (; u < a.u1; u += stride) {
+    const ColHdr h2 = load_hdr(u + 2 * stride);
+    const ColStage<OPT> s1 = load_stage(h1);  // in flight while this feature's records and A rows are gathered
+    if (h0.cnt > 0) {
+      const int64_t j = h0.j;
+      const size_t e = M.row(0, j) * M.Kp + 2 * l;
+      const int64_t t0 = h0.t0, t1 = t0 + h0.cnt;
+      const bool do_w = M.fit_linear && j < M.d;
+      double2 stored = s0.st, g2 = s0.g2, n2 = s0.n2, p;
+      if (OPT == OPT_SGD) {
+        p.x = sP * stored.x;
+        p.y = sP * stored.y;
+      } else if (a.use_stored) {
+        p = stored;
+      } else {
+        p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmpP);
+        p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmpP);
+        if (O.track_viol) {  // adagrad.nim:96-99
+          viol += fabs(stored.x - p.x) + fabs(stored.y - p.y);
+          dev::st_stream(M.P + e, p);
+        }
+      }
+      double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
+      double seta = 0.0;
+      WAcc wacc;
+      for (int64_t tb = t0; tb < t1; tb += L) {
+        int pib_l = s0.pib;
+        double x_l = s0.x;
+        if (tb != t0) {  // lists longer than a lane group: further chunks are fetched here
+          const int64_t tl = tb + l;
+          pib_l = tl < t1 ? a.tpos[tl] : 0;
+          x_l = tl < t1 ? a.tx[tl] : 0.0;
+        }
+        const int cnt = (int)(t1 - tb < L ? t1 - tb : L);
+        for (int ub = 0; ub < cnt; ub += TU) {
+          int pib[TU];
+          double x[TU];
+          SampleRec r[TU];
+          double2 A1[TU];
+#pragma unroll
+          for (int q = 0; q < TU; ++q) {
+            const int src = gbase + ((ub + q) < L ? (ub + q) : 0);
+            pib[q] = __shfl(pib_l, src, kWave);
+            x[q] = dev::shfl_d(x_l, src);
+          }
+#pragma unroll
+          for (int q = 0; q < TU; ++q) {
+            if (ub + q >= cnt) pib[q] = pib[0];  // a valid record; its contribution is masked below
+            r[q] = a.rec[pib[q]];
+            A1[q] = *reinterpret_cast<const double2*>(a.Abuf + (size_t)pib[q] * a.TA * M.Kp + 2 * l);
+          }
+#pragma unroll
+          for (int q = 0; q < TU; ++q) {
+            if (ub + q < cnt) {
+              const double dAx = x[q] * (A1[q].x - p.x * x[q]);
+              const double dAy = x[q] * (A1[q].y - p.y * x[q]);
+              if (OPT == OPT_SGD) {  // sgd.nim:220-222, averaged per coordinate below
+                acc.x += r[q].etaP * (r[q].dL * dAx);
+                acc.y += r[q].etaP * (r[q].dL * dAy);
+                seta += r[q].etaP;
+                if (do_w) {
+                  wacc.a0 += r[q].etaw * (r[q].dL * x[q]);
+                  wacc.a1 += r[q].etaw;
+                }
+              } else {  // adagrad.nim:122-124
+                const double gx = r[q].dL * dAx, gy = r[q].dL * dAy;
+                acc.x += gx;
+                acc.y += gy;
+                accn.x += gx * gx;
+                accn.y += gy * gy;
+                if (do_w) {
+                  const double gw = r[q].dL * x[q];
+                  wacc.a0 += gw;
+                  wacc.a1 += gw * gw;
+                }
+              }
+            }
+          }
+        }
+      }
+      const double c = (double)(t1 - t0);
+      if (OPT == OPT_SGD) {
+        viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
+        stored.x = stored.x * s0.fP - (acc.x / c) / sPn;
+        stored.y = stored.y * s0.fP - (acc.y / c) / sPn;
+        dev::st_stream(M.P + e, stored);
+        if (do_w) {  // fit_linear.nim:41-47
+          const double wj = sw * s0.wt;
+          if (l == 0) {
+            viol += fabs((wacc.a0 + wacc.a1 * O.alpha * wj) / c);
+            M.w[j] = s0.wt * s0.fw - (wacc.a0 / c) / swn;
+          }
+        }
+      } else {
+        g2.x += acc.x;
+        g2.y += acc.y;
+        n2.x += accn.x;
+        n2.y += accn.y;
+        dev::st_stream(O.G + e, g2);
+        dev::st_stream(O.N + e, n2);
+        if (do_w && l == 0) {  // fit_linear.nim:50-57
+          if (!a.use_stored) {
+            const double wj = -O.eta0 * s0.gw / (itp * O.eta0 * O.alpha + sqrt(s0.nw));
+            viol += fabs(s0.wt - wj);
+            M.w[j] = wj;
+          }
+          O.Gw[j] = s0.gw + wacc.a0;
+          O.Nw[j] = s0.nw + wacc.a1;
+        }
+      }
+    }
+    h0 = h1;
+    h1 = h2;
+    s0 = s1;
   }
+  viol = dev::wave_sum(viol);
+  if (lane == 0) red[0][wv] = viol;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) v += red[0][w_];
+    a.parts[a.nS + blockIdx.x] = v;
+  }
+  if (!closer) return;
+  col_closer<OPT>(a, red);
 }
 
 // adds the last batch's per-block viol partials (every other batch's are folded in by the next batch's closing
@@ -1646,7 +1862,21 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     // 8 workgroups per CU and the workgroups stride over the features (headline shape: 70 -> 58 us).
     // Fewer, longer wavefronts (cfg2: 12.5k wavefronts of 8 features x 10 touches) balance better
     // when the hardware hands out workgroups one by one (capped: 46 us, uncapped: 38 us).
-    static const int col_wg_per_cu = getenv("NFM_COL_WG") ? atoi(getenv("NFM_COL_WG")) : 8;
+    // The capped grid is exactly ONE resident set: what the strided kernel's register count lets a CU hold (headline
+    // shape, SGD: 95 registers = 5 workgroups per CU: 8 per CU left three waiting for a slot, a second round with a long
+    // tail -- column phase 56.1 -> 50.9 us; 6 per CU: 64 us; 10: 53.8 us).  NFM_COL_WG overrides.
+    // one order of degree 2, SGD / AdaGrad: the software-pipelined walk (k_col_sparse); NFM_COL_PIPE=0 switches it off
+    static const bool col_pipe_env = !(getenv("NFM_COL_PIPE") && atoi(getenv("NFM_COL_PIPE")) == 0);
+    const bool col_pipe = col_pipe_env && !GEN && M.nb == 1 && OPT != OPT_PSGD;
+    static const int col_occ = [] {
+      int nb_ = 0, np_ = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, k_col_phase<L, OPT, GEN, 2, true>, kBlock, 0) != hipSuccess || nb_ < 1) nb_ = 8;
+      if (!GEN && OPT != OPT_PSGD && col_pipe_env &&
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&np_, k_col_sparse<L, (OPT == OPT_PSGD ? OPT_SGD : OPT)>, kBlock, 0) == hipSuccess && np_ >= 1)
+        nb_ = np_;
+      return nb_;
+    }();
+    static const int col_wg_per_cu = getenv("NFM_COL_WG") ? atoi(getenv("NFM_COL_WG")) : col_occ;
     // the tuning variants TU = 1 / 4 (NFM_TU) are not strided
     const bool nB_capped = tu == 2 && col_wg_per_cu > 0 && nB > 4 * ctx->n_cu * col_wg_per_cu;
     if (nB_capped) nB = ctx->n_cu * col_wg_per_cu;
@@ -1675,6 +1905,8 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
         hipLaunchKernelGGL((k_col_phase<L, (OPT == OPT_PSGD ? OPT_SGD : OPT), GEN, 1, false>), dim3(nB), dim3(kBlock), 0, st, ca);
       else if (tu == 4 && OPT != OPT_PSGD)
         hipLaunchKernelGGL((k_col_phase<L, (OPT == OPT_PSGD ? OPT_SGD : OPT), GEN, 4, false>), dim3(nB), dim3(kBlock), 0, st, ca);
+      else if (strided && col_pipe)
+        hipLaunchKernelGGL((k_col_sparse<L, (OPT == OPT_PSGD ? OPT_SGD : OPT)>), dim3(nB), dim3(kBlock), 0, st, ca);
       else if (strided)
         hipLaunchKernelGGL((k_col_phase<L, OPT, GEN, 2, true>), dim3(nB), dim3(kBlock), 0, st, ca);
       else
