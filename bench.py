@@ -441,7 +441,16 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     kh = max(1, min(3, steps))
     perms = [np.random.default_rng(7 + rank * 131 + e).permutation(n).astype(np.int64) for e in range(kh + 1)]
     step(perms[kh])  # warm-up of the un-cached path (allocator pools sized)
+    _step_plain = step
+
+    def step(perm=None, _seq=perms):  # noqa: F811 -- announces the next epoch's permutation, as the host loops do
+        k_ = next(i for i, p_ in enumerate(_seq) if p_ is perm)
+        if k_ + 1 < kh:
+            capi.check(capi.lib().nfm_opt_announce_perm(opt._h, _seq[k_ + 1].ctypes.data, 0, n))
+        return _step_plain(perm)
+
     dth, _ = timed(kh, perms)
+    step = _step_plain
     value_shuffled_host = n * world / (dth / kh)
     del perms
 

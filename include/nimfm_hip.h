@@ -272,6 +272,13 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
  * order).  nfm_opt_get_perm: the n = end - begin sample ids of the most recent epoch call that ran in a permuted order
  * (device-drawn or passed in), so that any run can be replayed sample for sample. */
 int32_t nfm_opt_set_shuffle(nfm_opt* o, int64_t seed);
+/* A host that shuffles itself (the Nim host: shuffle(indices), optimizer/sgd.nim:297) can tell the library the
+ * permutation of the NEXT epoch before it runs the current one: nfm_opt_announce_perm(o, perm_next, begin, end), then
+ * nfm_opt_epoch(o, ds, perm_current, begin, end, ...).  The plan for perm_next is built on a second stream beside the
+ * current epoch and used when the next nfm_opt_epoch call passes the SAME array (same pointer, same range); the array
+ * must stay alive and unchanged until that call returns (so the host alternates between two index arrays).  An
+ * announcement that is not followed up costs only the wasted build.  NFM_MODE_MINIBATCH; ignored otherwise. */
+int32_t nfm_opt_announce_perm(nfm_opt* o, const int64_t* perm_next, int64_t begin, int64_t end);
 int32_t nfm_opt_get_perm(nfm_opt* o, int64_t* perm /*n*/, int64_t n);
 /* finalize (optimizer/sgd.nim:99-113; adagrad.nim:65-84): leaves the model's
  * parameters as the reference's fm.P/w/intercept after fit. Idempotent. */

@@ -101,6 +101,7 @@ proc nfm_opt_epoch*(o: NfmOpt, ds: NfmDataset, perm: ptr int64, first, last: int
                     lossSum, violSum: ptr float64): int32
 proc nfm_opt_set_shuffle*(o: NfmOpt, seed: int64): int32
 proc nfm_opt_get_perm*(o: NfmOpt, perm: ptr int64, n: int64): int32
+proc nfm_opt_announce_perm*(o: NfmOpt, permNext: ptr int64, first, last: int64): int32
 proc nfm_opt_finalize*(o: NfmOpt): int32
 proc nfm_opt_destroy*(o: NfmOpt): int32
 # data-parallel groups: one process per GPU (RCCL over xGMI) or the ranks of one process (threads + peer access)
@@ -316,15 +317,25 @@ type HipFitCfg* = object
 
 proc hipEpochLoop*(o: NfmOpt, m: NfmModel, ds: NfmDataset, nSamples: int, c: HipFitCfg, it: var int,
                    pull: proc () {.closure.}, callback: proc () {.closure.}) =
-  var indices = toSeq(0..<nSamples)
+  # two index arrays: while epoch e runs over one, the other already holds epoch e+1's order (the same sequence of
+  # shuffles of the same array as the reference's, sgd.nim:297 -- drawn one epoch early) and is announced to the library,
+  # which builds its batch plan beside the running epoch
+  var idx = [toSeq(0..<nSamples), newSeq[int](0)]
   var isConverged = false
   check nfm_opt_set_it(o, it.int64)
+  let wholeEpochs = callback.isNil or c.nCalls <= 0 or c.minibatch
+  if c.shuffle: shuffle(idx[0])               # sgd.nim:297, Nim's global RNG exactly as in the reference
   for epoch in 0..<c.maxIter:
     var viol, runningLoss: float64
     var perm: ptr int64 = nil
+    template indices: untyped = idx[epoch mod 2]
     if c.shuffle:
-      shuffle(indices)                        # sgd.nim:297, Nim's global RNG exactly as in the reference
       perm = cast[ptr int64](addr indices[0])
+      if epoch + 1 < c.maxIter:
+        idx[(epoch + 1) mod 2] = indices      # a copy
+        shuffle(idx[(epoch + 1) mod 2])
+        if wholeEpochs and c.minibatch:
+          check nfm_opt_announce_perm(o, cast[ptr int64](addr idx[(epoch + 1) mod 2][0]), 0, nSamples.int64)
     if not callback.isNil and c.nCalls > 0 and not c.minibatch:
       # sgd.nim:303-308 / adagrad.nim:180-184: callback whenever it mod nCalls == 0 -- the epoch runs in pieces
       var pos = 0

@@ -40,7 +40,7 @@ SYMBOLS = [
     "nfm_opt_set_state", "nfm_opt_epoch", "nfm_opt_finalize", "nfm_opt_device_state", "nfm_opt_destroy",
     "nfm_rng_randomize", "nfm_rng_random_normal", "nfm_rng_shuffle",
     "nfm_dp_unique_id", "nfm_dp_create", "nfm_dp_create_local", "nfm_dp_info", "nfm_dp_destroy", "nfm_opt_set_dp",
-    "nfm_opt_set_shuffle", "nfm_opt_get_perm",
+    "nfm_opt_set_shuffle", "nfm_opt_get_perm", "nfm_opt_announce_perm",
 ]
 
 
@@ -168,6 +168,7 @@ def lib():
         "nfm_opt_set_dp": [vp, vp, i64, i32],
         "nfm_opt_set_shuffle": [vp, i64],
         "nfm_opt_get_perm": [vp, vp, i64],
+        "nfm_opt_announce_perm": [vp, vp, i64, i64],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

@@ -97,6 +97,12 @@ struct nfm_opt {
   bool next_plan_ready = false;
   hipStream_t plan_stream = nullptr;
   double* out2_pinned = nullptr;
+  // nfm_opt_announce_perm: the host's permutation for the NEXT epoch call (kept alive by the caller); its plan is
+  // built beside the current epoch like the device-drawn one's
+  const int64_t* announced = nullptr;
+  int64_t announced_begin = 0, announced_end = 0;
+  const int64_t* next_plan_perm = nullptr;  // the host array next_plan was built from
+  int64_t next_probe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   nfm_dp* dp = nullptr;
   int64_t dp_sync_period = 0;
   bool dp_overlap = true;
@@ -845,7 +851,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
   if (o->kind == OPT_PSGD)
     NFM_CHECK((end - begin) % o->batch == 0, NFM_ERR_INVALID, "MBPSGD: %lld samples are not a whole number of mini-batches of %lld",
               (long long)(end - begin), (long long)o->batch);
-  if (perm)
+  if (perm && o->mode == NFM_MODE_SEQUENTIAL)  // mini-batch mode checks the ids on the device (plan.hip)
     for (int64_t p = begin; p < end; ++p)
       NFM_CHECK(perm[p] >= 0 && perm[p] < ds->v.n, NFM_ERR_INVALID, "perm[%lld] = %lld out of range", (long long)p, (long long)perm[p]);
   NFM_TRY(use_device(ctx));
@@ -892,7 +898,8 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       if (dev_shuffle) {
         // the order of this epoch is a function of (seed, shuffle_epoch); its plan may have been built beside the
         // previous epoch
-        if (o->next_plan_ready && o->next_plan && o->next_plan_epoch == o->shuffle_epoch && plan_matches(*o->next_plan, first_singleton)) {
+        if (o->next_plan_ready && o->next_plan && !o->next_plan_perm && o->next_plan_epoch == o->shuffle_epoch &&
+            plan_matches(*o->next_plan, first_singleton)) {
           std::swap(o->plan, o->next_plan);
           o->perm_gen.take(o->perm_next);
         } else {
@@ -905,6 +912,14 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
           o->plan->ds_nnz = ds->v.nnz;
         }
         o->next_plan_ready = false;
+      } else if (perm && o->next_plan_ready && o->next_plan && o->next_plan_perm == perm && plan_matches(*o->next_plan, first_singleton) &&
+                 [&] {  // the array the plan was built from, unchanged as promised (a few probes)
+                   for (int q = 0; q < 8; ++q)
+                     if (perm[begin + (ns - 1) * q / 7] != o->next_probe[q]) return false;
+                   return true;
+                 }()) {
+        std::swap(o->plan, o->next_plan);
+        o->next_plan_ready = false;
       } else if (!reuse) {
         if (!o->plan) o->plan.reset(new Plan());
         TimedLaunch tl(ctx, "plan_build");
@@ -912,7 +927,12 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
                            o->plan.get(), nullptr, nullptr, perm ? &ds->csc : nullptr));
         o->plan->ds_uid = ds->uid;
         o->plan->ds_nnz = ds->v.nnz;
+        o->next_plan_ready = false;
       }
+      // an announced permutation for the next call over the same range: its plan is built beside this epoch
+      const int64_t* ann = (!dev_shuffle && o->announced && o->announced_begin == begin && o->announced_end == end && o->kind != OPT_PSGD)
+                               ? o->announced : nullptr;
+      o->announced = nullptr;
       DpEpoch de;
       if (o->dp) {
         // the ranks of the group run this call together on their own shards (equal step counters at its start)
@@ -942,7 +962,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       int rc_epoch;
       // device shuffle: the epoch is only ENQUEUED here; the next epoch's order and plan are then built on a second
       // stream (its host-side waits block on that stream only) while this epoch runs
-      const bool prefetch = dev_shuffle && !ctx->timing.enabled;
+      const bool prefetch = (dev_shuffle || ann != nullptr) && !ctx->timing.enabled;
       double* out2_dst = out2;
       if (prefetch) {
         if (!o->out2_pinned) NFM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&o->out2_pinned), sizeof(double) * 2, hipHostMallocDefault));
@@ -958,10 +978,20 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         int rc_next = NFM_OK;
         if (rc_epoch == NFM_OK) {
           if (!o->next_plan) o->next_plan.reset(new Plan());
-          rc_next = gen_permutation(ctx, o->plan_stream, o->shuffle_seed, o->shuffle_epoch + 1, begin, ns, &o->perm_next);
-          if (rc_next == NFM_OK)
-            rc_next = plan_build(ctx, ds->v, m->n_aug, nullptr, begin, end, o->batch, /*first_singleton=*/false, want_tq, use_singles,
-                                 sort_by_count, o->next_plan.get(), o->plan_stream, o->perm_next.as<int64_t>(), &ds->csc);
+          if (ann) {
+            rc_next = plan_build(ctx, ds->v, m->n_aug, ann, begin, end, o->batch, /*first_singleton=*/false, want_tq, use_singles,
+                                 sort_by_count, o->next_plan.get(), o->plan_stream, nullptr, &ds->csc);
+            if (rc_next == NFM_OK) {
+              o->next_plan_perm = ann;
+              for (int q = 0; q < 8; ++q) o->next_probe[q] = ann[begin + (ns - 1) * q / 7];
+            }
+          } else {
+            rc_next = gen_permutation(ctx, o->plan_stream, o->shuffle_seed, o->shuffle_epoch + 1, begin, ns, &o->perm_next);
+            if (rc_next == NFM_OK)
+              rc_next = plan_build(ctx, ds->v, m->n_aug, nullptr, begin, end, o->batch, /*first_singleton=*/false, want_tq, use_singles,
+                                   sort_by_count, o->next_plan.get(), o->plan_stream, o->perm_next.as<int64_t>(), &ds->csc);
+            if (rc_next == NFM_OK) o->next_plan_perm = nullptr;
+          }
           if (rc_next == NFM_OK) {
             o->next_plan->ds_uid = ds->uid;
             o->next_plan->ds_nnz = ds->v.nnz;
@@ -1072,6 +1102,15 @@ int32_t nfm_opt_set_shuffle(nfm_opt* o, int64_t seed) {
   o->shuffle_seed = seed;
   o->shuffle_epoch = 0;
   o->next_plan_ready = false;
+  return NFM_OK;
+}
+
+int32_t nfm_opt_announce_perm(nfm_opt* o, const int64_t* perm_next, int64_t begin, int64_t end) {
+  NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
+  NFM_CHECK(!perm_next || (begin >= 0 && begin < end), NFM_ERR_INVALID, "bad sample range [%lld,%lld)", (long long)begin, (long long)end);
+  o->announced = o->mode == NFM_MODE_MINIBATCH ? perm_next : nullptr;
+  o->announced_begin = begin;
+  o->announced_end = end;
   return NFM_OK;
 }
 

@@ -14,6 +14,9 @@ namespace nfm {
 #ifndef NFM_COL_MINW
 #define NFM_COL_MINW 1
 #endif
+#ifndef NFM_REG_NTSEL
+#define NFM_REG_NTSEL 0
+#endif
 #ifndef NFM_ADA2_MINW
 #define NFM_ADA2_MINW 2
 #endif
@@ -390,7 +393,15 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 4 ? NFM_REG_MINW : 1)
 #pragma unroll
           for (int u = 0; u < NQ; ++u) {
             const int jj = lane_bcast_i<SPLIT>(jq[0], u, slot);
+#if NFM_REG_NTSEL
+            // MODE 4: a single-touch row is read here and never again in this batch (streamed); a multi-touch row is
+            // read again by the column phase and should stay in the Infinity Cache
+            const int ff = MODE == 4 ? lane_bcast_i<SPLIT>(fq[0], u, slot) : 0;
+            if (ff) prow[u] = ld_nt(M.P + (size_t)jj * M.Kp + 2 * l);
+            else prow[u] = *reinterpret_cast<const double2*>(M.P + (size_t)jj * M.Kp + 2 * l);
+#else
             prow[u] = *reinterpret_cast<const double2*>(M.P + (size_t)jj * M.Kp + 2 * l);
+#endif
           }
 #pragma unroll
           for (int u = 0; u < NQ; ++u) {

@@ -47,6 +47,14 @@ __device__ __forceinline__ int64_t batch_start(int64_t b, int64_t batch, int fir
   return b * batch;
 }
 
+// sample ids of an order handed over by the host: all inside [0, n)?
+__global__ void k_perm_range(int64_t ns, const int64_t* __restrict__ perm, int64_t n, unsigned long long* __restrict__ bad) {
+  unsigned long long c = 0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ns; r += (int64_t)gridDim.x * blockDim.x)
+    c += (perm[r] < 0 || perm[r] >= n) ? 1 : 0;
+  if (c) atomicAdd(bad, c);
+}
+
 __global__ void k_row_len(CsrView X, const int64_t* __restrict__ perm, int64_t begin, int64_t ns, int n_aug,
                           int64_t* __restrict__ len) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= ns; r += (int64_t)gridDim.x * blockDim.x) {
@@ -511,6 +519,16 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
     else
       NFM_HIP_CHECK(hipMemcpyAsync(P.perm.p, perm_host + begin, sizeof(int64_t) * ns, hipMemcpyHostToDevice, st));
     perm_dev = P.perm.as<int64_t>();
+  }
+  DevBuf bad;
+  if (perm_host) {  // validated on the device (a host loop over 1e7 ids costs as much as a twentieth of the epoch)
+    NFM_TRY(bad.alloc(sizeof(unsigned long long)));
+    NFM_HIP_CHECK(hipMemsetAsync(bad.p, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_perm_range, dim3(256 * 4), dim3(kBlock), 0, st, ns, perm_dev, X.n, bad.as<unsigned long long>());
+    unsigned long long h_bad = 0;
+    NFM_HIP_CHECK(hipMemcpyAsync(&h_bad, bad.p, sizeof(h_bad), hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));  // before any kernel indexes the data with these ids
+    NFM_CHECK(h_bad == 0, NFM_ERR_INVALID, "%llu entries of the permutation are out of range [0,%lld)", h_bad, (long long)X.n);
   }
   // 1. row lengths -> touch offsets
   DevBuf len, toff, tmp;

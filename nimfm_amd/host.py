@@ -785,14 +785,30 @@ class _OptimizerBase:
         isConverged = False
         per_epoch_cb = self._per_epoch_callback(callback)
         self.history = []
+        # Host-side orders: epoch e+1's permutation is drawn while epoch e is still to run (the same sequence of shuffles
+        # of the same array as the reference's, one epoch early) and announced to the library, which builds its batch
+        # plan beside the running epoch (nfm_opt_announce_perm); two index arrays alternate.
+        host_shuffle = self.shuffle and not dev_shuffle and perms is None
+        order = [indices, None]
+        if host_shuffle:
+            rng.shuffle(order[0])  # sgd.nim:297 (Nim's global RNG there)
+        whole_epochs = not (callback is not None and self.nCalls > 0 and mode == "sequential")
+        if perms is not None:
+            perms = [_i64(p_) for p_ in perms]
         for epoch in range(self.maxIter):
             viol = runningLoss = 0.0
-            perm = None
+            perm = nxt = None
             if perms is not None:
-                perm = _i64(perms[epoch])
-            elif self.shuffle and not dev_shuffle:
-                rng.shuffle(indices)  # sgd.nim:297 (Nim's global RNG there)
-                perm = indices
+                perm = perms[epoch]
+                nxt = perms[epoch + 1] if epoch + 1 < len(perms) and epoch + 1 < self.maxIter else None
+            elif host_shuffle:
+                perm = order[epoch % 2]
+                if epoch + 1 < self.maxIter:
+                    order[(epoch + 1) % 2] = perm.copy()
+                    rng.shuffle(order[(epoch + 1) % 2])
+                    nxt = order[(epoch + 1) % 2]
+            if nxt is not None and whole_epochs and mode == "minibatch":
+                capi.check(capi.lib().nfm_opt_announce_perm(self._h, _vp(nxt), 0, n))
             if callback is not None and self.nCalls > 0 and mode == "sequential":
                 pos = 0
                 while pos < n:  # sgd.nim:303-308: callback whenever it mod nCalls == 0

@@ -449,3 +449,43 @@ def test_device_shuffle_replays_on_the_oracle(solver):
     capi.check(capi.lib().nfm_opt_set_shuffle(opt._h, 7))
     opt._epoch(X, None, 0, n)
     assert np.array_equal(opt.last_permutation(n), perms[0])
+
+
+def test_announced_permutation_is_only_a_hint():
+    """nfm_opt_announce_perm: the plan built beside the current epoch is used only when the next call passes the SAME
+    array; another array (or a changed one) is planned afresh -- results never depend on the announcement."""
+    from nimfm_amd import _capi as capi
+    n, d, m, k, B = 3000, 200, 8, 8, 256
+    Xo = random_csr(n, d, m, seed=17)
+    rng = np.random.default_rng(4)
+    y = rng.standard_normal(n)
+    P0, w0 = rng.standard_normal((1, k, d)) * 0.05, np.zeros(d)
+    perms = make_perms(n, 4, seed=3)
+    decoy = np.ascontiguousarray(perms[3][::-1])
+    X = to_gpu(Xo)
+    X.set_targets(y)
+    fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, 0.0)
+    sgd = nf.newSGD(maxIter=1, verbose=0, tol=0, mode="minibatch", batch=B)
+    sgd._handle(fm, X.ctx, "minibatch")
+    announce = lambda a: capi.check(capi.lib().nfm_opt_announce_perm(sgd._h, a.ctypes.data, 0, n))  # noqa: E731
+    announce(perms[1])
+    sgd._epoch(X, perms[0], 0, n)          # epoch 0; the plan of perms[1] is built beside it
+    sgd.it += n
+    sgd._epoch(X, perms[1], 0, n)          # ... and used here
+    sgd.it += n
+    announce(decoy)
+    sgd._epoch(X, perms[2], 0, n)          # the announcement is not followed up: planned afresh
+    sgd.it += n
+    changed = perms[3].copy()
+    announce(changed)
+    sgd._epoch(X, perms[2], 0, n)
+    sgd.it += n
+    changed[[0, -1]] = changed[[-1, 0]]    # the promised array was modified: the probes notice, planned afresh
+    sgd._epoch(X, changed, 0, n)
+    sgd._finalize_into(fm)
+    P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
+    for p in (perms[0], perms[1], perms[2], perms[2], changed):
+        b, it, _, _ = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, b, O.sgd_cfg(), B, perm=p, it=it)
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, RTOL, ATOL, "w")
+    assert_close(fm.P, P, RTOL, ATOL, "P")
