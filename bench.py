@@ -319,7 +319,17 @@ def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, c
             O.fm_adagrad_fit(Xo, y[:nc], wl["degree"], P0, w0, 0.0, cfg, epochs)
         return float(np.median(O.epoch_seconds(epochs)[1:]))  # epoch 0 is the warm-up
 
+    def med_jagged(threads_):
+        O.fm_sgd_fit_jagged(Xo, y[:nc], P0, w0, 0.0, cfg, epochs, threads=threads_)
+        return float(np.median(O.epoch_seconds(epochs)[1:]))
+
+    jag = None
     with O.variant("timing"):
+        if sgd and wl["degree"] == 2 and not cheap:  # the reference's own storage: one heap block per parameter row
+            jag = {"value": round(nc / med_jagged(1), 1), "cores": 1,
+                   "hogwild_4_threads": round(nc / med_jagged(min(4, os.cpu_count() or 1)), 1),
+                   "note": "the same epoch on jagged storage (seq-of-seq as tensor/tensor.nim:8-17: a malloc'd row with a seq header "
+                           "per feature behind a pointer table), oracle/nimfm_jagged.c, bit-identical results"}
         t1 = med(0)
         threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
         th = None
@@ -341,6 +351,7 @@ def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, c
                       "flat arrays, gcc -O3 -march=native on this host, 1 thread, 1 warm-up epoch then the median of %d; "
                       "epoch loop only (the per-fit layout transposes, sgd.nim:292,328, are outside)"
                       % (nc, "sgd.nim:261-328" if sgd else "adagrad.nim:137-203", epochs - 1),
+            "jagged": jag,
             "hogwild": None if th is None else {"value": round(nc / th, 1), "threads": threads,
                                                 "note": "optimizer/sgd_multi.nim semantics (racy), same port and build",
                                                 "sweep": sweep},

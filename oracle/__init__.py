@@ -19,7 +19,8 @@ LOWER = {"explicit": 0, "augment": 1, "none": 2}
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("nimfm_oracle.c", "nimfm_slow.c", "nimfm_mb.c", "nimfm_psgd.c", "nimfm_ingest.c", "nimfm_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("nimfm_oracle.c", "nimfm_slow.c", "nimfm_mb.c", "nimfm_psgd.c", "nimfm_ingest.c",
+                                             "nimfm_jagged.c", "nimfm_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -220,6 +221,21 @@ def fm_sgd_fit(X, y, degree, P, w, intercept, cfg, max_iter, n_aug=0, tol=0.0, p
                                   _p(ev), C.byref(nrun))
     assert rc == 0
     return P, w, b.value, itc.value, el, ev, nrun.value
+
+
+def fm_sgd_fit_jagged(X, y, P, w, intercept, cfg, max_iter, perms=None, it=1, threads=1):
+    """nimfm_jagged.c: the degree-2, one-order SGD fit on the reference's jagged (seq-of-seq) storage; threads > 1 = the
+    Hogwild driver.  Returns (P, w, intercept, it, epoch_loss, epoch_viol)."""
+    P, w, y = f64(P).copy(), f64(w).copy(), f64(y)
+    O, k, da = P.shape
+    assert O == 1 and da == X.d
+    b, itc = C.c_double(intercept), C.c_int64(it)
+    el, ev = np.zeros(max_iter), np.zeros(max_iter)
+    pm = _perms(perms)
+    rc = lib().orc_fm_sgd_fit_jagged(C.byref(X.c), _p(y), k, _p(P), _p(w), C.byref(b), C.byref(cfg), max_iter, _p(pm),
+                                     C.byref(itc), int(threads), _p(el), _p(ev))
+    assert rc == 0
+    return P, w, b.value, itc.value, el, ev
 
 
 def fm_adagrad_fit(X, y, degree, P, w, intercept, cfg, max_iter, n_aug=0, tol=0.0, perms=None, it=1, state=None):

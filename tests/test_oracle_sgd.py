@@ -123,3 +123,20 @@ def test_stopping_and_scaling_reset():
     Pf, wf, bf, *_ = O.fm_sgd_fit(X, y, degree, P0, w0, b0, cfg, 4, n_aug)
     assert_close(wf, ws, what="w")
     assert_close(Pf, Ps, what="P")
+
+
+def test_jagged_layout_restatement_is_bit_identical():
+    """oracle/nimfm_jagged.c (the reference's seq-of-seq storage, timed by bench.py's cpu_baseline) == the flat restatement"""
+    from common import make_perms, random_csr
+    n, d, m, k = 300, 40, 6, 5
+    X = random_csr(n, d, m, seed=2)
+    rng = np.random.default_rng(1)
+    y = rng.standard_normal(n)
+    P0, w0 = rng.standard_normal((1, k, d)) * 0.1, rng.standard_normal(d) * 0.01
+    perms = make_perms(n, 3)
+    for loss, sched, fl, fi in (("squared", "optimal", True, True), ("logistic", "invscaling", False, True), ("huber", "constant", True, False)):
+        cfg = O.sgd_cfg(loss=loss, scheduling=sched, fit_linear=fl, fit_intercept=fi, eta0=0.05)
+        P, w, b, it, el, ev, _ = O.fm_sgd_fit(X, y, 2, P0, w0, 0.1, cfg, 3, perms=perms)
+        Pj, wj, bj, itj, elj, evj = O.fm_sgd_fit_jagged(X, y, P0, w0, 0.1, cfg, 3, perms=perms)
+        assert np.array_equal(P, Pj) and np.array_equal(w, wj) and b == bj and it == itj
+        assert np.array_equal(el, elj) and np.array_equal(ev, evj)
