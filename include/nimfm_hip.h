@@ -133,6 +133,17 @@ int32_t nfm_dataset_parse_text(nfm_ctx* ctx, const char* text, int64_t len, int3
  * 1007-1014) or NULL.  A STREAMCSC file is NFM_ERR_UNSUPPORTED. */
 int32_t nfm_dataset_load_stream(nfm_ctx* ctx, const char* x_path, const char* y_path,
                                 nfm_dataset** out);
+/* The same files in row blocks, for matrices that do not fit the HBM left over: the reference's out-of-core epoch walks
+ * the file through a host-side cache of rows, block by block in file order, without shuffling
+ * (readCache, tensor/sparse_stream.nim:232-270; optimizer/sgd_multi.nim:83-97, sgd.nim:297 `if X.nCached ==
+ * X.nSamples and self.shuffle`).  nfm_stream_load_rows makes rows [row_begin, row_end) a resident dataset (targets from
+ * the label file's rows, zeros without one); the host runs nfm_opt_epoch over block after block -- the optimizer's step
+ * counter, scales and state simply continue -- and destroys each block's dataset when it is done with it. */
+typedef struct nfm_stream nfm_stream;
+int32_t nfm_stream_open(nfm_ctx* ctx, const char* x_path, const char* y_path /*or NULL*/, nfm_stream** out);
+int32_t nfm_stream_shape(const nfm_stream* s, int64_t* n_samples, int64_t* n_features, int64_t* nnz, int64_t* n_fields);
+int32_t nfm_stream_load_rows(nfm_stream* s, int64_t row_begin, int64_t row_end, nfm_dataset** out);
+int32_t nfm_stream_close(nfm_stream* s);
 /* convertSVMLightFile (dataset.nim:1017-1097): svmlight text -> STREAMCSR file +
  * raw float64 label file; the text is parsed on the GPU. */
 int32_t nfm_convert_svmlight(nfm_ctx* ctx, const char* f_in, const char* f_out_x,

@@ -40,6 +40,7 @@ type
   NfmModel* = pointer
   NfmOpt* = pointer
   NfmDp* = pointer
+  NfmStream* = pointer
   NfmModelCfg* {.bycopy.} = object
     kind*, task*, degree*, nComponents*, fitLower*, fitIntercept*, fitLinear*, reserved*: int32
     nFeatures*, nFields*: int64
@@ -74,6 +75,10 @@ proc nfm_dataset_create_csr*(ctx: NfmCtx, nSamples, nFeatures: int64, indptr, in
 proc nfm_dataset_load_svmlight*(ctx: NfmCtx, path: cstring, nFeatures: int64, outp: ptr NfmDataset): int32
 proc nfm_dataset_load_ffm*(ctx: NfmCtx, path: cstring, nFeatures, nFields: int64, outp: ptr NfmDataset): int32
 proc nfm_dataset_load_stream*(ctx: NfmCtx, xPath, yPath: cstring, outp: ptr NfmDataset): int32
+proc nfm_stream_open*(ctx: NfmCtx, xPath, yPath: cstring, outp: ptr NfmStream): int32
+proc nfm_stream_shape*(s: NfmStream, nSamples, nFeatures, nnz, nFields: ptr int64): int32
+proc nfm_stream_load_rows*(s: NfmStream, rowBegin, rowEnd: int64, outp: ptr NfmDataset): int32
+proc nfm_stream_close*(s: NfmStream): int32
 proc nfm_convert_svmlight*(ctx: NfmCtx, fIn, fOutX, fOutY: cstring): int32
 proc nfm_dataset_shape*(ds: NfmDataset, nSamples, nFeatures, nnz, nFields: ptr int64): int32
 proc nfm_dataset_get_targets*(ds: NfmDataset, y: ptr float64): int32

@@ -405,6 +405,42 @@ int32_t nfm_dataset_load_stream(nfm_ctx* ctx, const char* x_path, const char* y_
   return dataset_from_ingest(ctx, r, r.n_fields > 0, -1, -1, out);
 }
 
+struct nfm_stream {
+  nfm_ctx* ctx = nullptr;
+  StreamFile f;
+};
+
+int32_t nfm_stream_open(nfm_ctx* ctx, const char* x_path, const char* y_path, nfm_stream** out) {
+  NFM_CHECK(ctx && x_path && out, NFM_ERR_INVALID, "null argument");
+  std::unique_ptr<nfm_stream> s(new nfm_stream());
+  s->ctx = ctx;
+  NFM_TRY(StreamFile::open_file(x_path, y_path, &s->f));
+  *out = s.release();
+  return NFM_OK;
+}
+
+int32_t nfm_stream_shape(const nfm_stream* s, int64_t* n_samples, int64_t* n_features, int64_t* nnz, int64_t* n_fields) {
+  NFM_CHECK(s, NFM_ERR_INVALID, "null stream");
+  if (n_samples) *n_samples = s->f.n;
+  if (n_features) *n_features = s->f.d;
+  if (nnz) *nnz = s->f.nnz;
+  if (n_fields) *n_fields = s->f.nf;
+  return NFM_OK;
+}
+
+int32_t nfm_stream_load_rows(nfm_stream* s, int64_t row_begin, int64_t row_end, nfm_dataset** out) {
+  NFM_CHECK(s && out, NFM_ERR_INVALID, "null argument");
+  NFM_TRY(use_device(s->ctx));
+  IngestResult r;
+  NFM_TRY(s->f.load_rows(s->ctx, row_begin, row_end, &r));
+  return dataset_from_ingest(s->ctx, r, r.n_fields > 0, -1, -1, out);
+}
+
+int32_t nfm_stream_close(nfm_stream* s) {
+  delete s;
+  return NFM_OK;
+}
+
 int32_t nfm_convert_svmlight(nfm_ctx* ctx, const char* f_in, const char* f_out_x, const char* f_out_y) {
   NFM_CHECK(ctx && f_in && f_out_x && f_out_y, NFM_ERR_INVALID, "null argument");
   NFM_TRY(use_device(ctx));

@@ -2,6 +2,9 @@
 #pragma once
 #include "common.h"
 
+#include <string>
+#include <vector>
+
 namespace nfm {
 
 struct IngestResult {
@@ -19,6 +22,21 @@ int ingest_text(nfm_ctx* ctx, const char* path, const char* mem, int64_t mem_len
 
 // STREAMCSR / STREAMCSRFIELD binary files (tensor/sparse_stream.nim:3-33) -> CSR in HBM; y_path may be null
 int ingest_stream(nfm_ctx* ctx, const char* x_path, const char* y_path, IngestResult* out);
+// a STREAMCSR / STREAMCSRFIELD file opened for block-wise use (nfm_stream_*): header, a read-only mapping, and marks
+// (row -> byte offset) left behind by the walks over the per-row length words
+struct StreamFile {
+  std::string path, y_path;
+  const unsigned char* map = nullptr;
+  int64_t len = 0, base = 0, n = 0, d = 0, nnz = 0, nf = 0;
+  int esize = 16;
+  bool with_fields = false;
+  std::vector<int64_t> mark_row, mark_off;
+  ~StreamFile();
+  static int open_file(const char* x_path, const char* y_path, StreamFile* S);
+  int offset_of(int64_t r, int64_t* off_out);
+  int load_rows(nfm_ctx* ctx, int64_t r0, int64_t r1, IngestResult* out);  // rows [r0, r1) -> CSR in HBM
+};
+
 // convertSVMLightFile (dataset.nim:1017-1097): text -> STREAMCSR + raw float64 labels
 int convert_svmlight(nfm_ctx* ctx, const char* f_in, const char* f_out_x, const char* f_out_y);
 

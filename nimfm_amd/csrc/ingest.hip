@@ -719,6 +719,144 @@ int ingest_stream(nfm_ctx* ctx, const char* x_path, const char* y_path, IngestRe
   return NFM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// STREAMCSR files in row blocks: the reference's out-of-core epoch (readCache, tensor/sparse_stream.nim:232-270; loop
+// optimizer/sgd_multi.nim:83-97: `while nRest > 0: X.readCache(nSamples - nRest) ... dec(nRest, X.nCached)`) keeps a
+// cache of rows in host memory and walks the file block by block, in file order.  Here a block is made resident in HBM
+// (StreamFile::load_rows) and the epoch runs over it; for files that fit (288 GB) nfm_dataset_load_stream makes
+// everything resident at once.
+// ------------------------------------------------------------------------------------------------
+StreamFile::~StreamFile() {
+  if (map) munmap(const_cast<unsigned char*>(map), (size_t)len);
+}
+
+int StreamFile::open_file(const char* x_path, const char* y_path_, StreamFile* S) {
+  S->path = x_path;
+  S->y_path = y_path_ ? y_path_ : "";
+  const int fd = open(x_path, O_RDONLY);
+  NFM_CHECK(fd >= 0, NFM_ERR_INVALID, "%s cannot be opened.", x_path);
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); return set_error(NFM_ERR_INVALID, "%s cannot be opened.", x_path); }
+  S->len = (int64_t)sb.st_size;
+  void* mp = S->len > 0 ? mmap(nullptr, (size_t)S->len, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+  close(fd);
+  NFM_CHECK(mp != MAP_FAILED, NFM_ERR_INVALID, "%s cannot be mapped.", x_path);
+  S->map = static_cast<const unsigned char*>(mp);
+  if (S->len >= 14 && !memcmp(S->map, "STREAMCSRFIELD", 14)) {
+    S->with_fields = true;
+    S->base = 14 + 48;
+  } else if (S->len >= 9 && !memcmp(S->map, "STREAMCSR", 9)) {
+    S->base = 9 + 40;
+  } else if (S->len >= 9 && !memcmp(S->map, "STREAMCSC", 9)) {
+    return set_error(NFM_ERR_UNSUPPORTED, "%s is a column-major (STREAMCSC) file; the row-wise optimizers need STREAMCSR", x_path);
+  } else {
+    return set_error(NFM_ERR_INVALID, "%s is not a StreamCSR file.", x_path);
+  }
+  NFM_CHECK(S->len >= S->base, NFM_ERR_INVALID, "%s: truncated header", x_path);
+  int64_t hdr[4] = {0, 0, 0, 0};
+  memcpy(hdr, S->map + (S->with_fields ? 14 : 9), S->with_fields ? 32 : 24);
+  S->n = hdr[0]; S->d = hdr[1]; S->nnz = hdr[2]; S->nf = S->with_fields ? hdr[3] : 0;
+  S->esize = S->with_fields ? 24 : 16;
+  NFM_CHECK(S->n >= 0 && S->d >= 0 && S->nnz >= 0 && S->d < (int64_t)2147483647 - 64, NFM_ERR_INVALID, "%s: bad header", x_path);
+  NFM_CHECK(!S->with_fields || (S->nf >= 0 && S->nf < (int64_t)2147483647), NFM_ERR_INVALID, "%s: bad nFields in the header", x_path);
+  NFM_CHECK(S->n <= (S->len - S->base) / 8 && S->nnz <= (S->len - S->base) / S->esize, NFM_ERR_INVALID,
+            "%s: the header promises %lld rows / %lld entries, the file holds %lld bytes", x_path, (long long)S->n,
+            (long long)S->nnz, (long long)S->len);
+  S->mark_row.assign(1, 0);
+  S->mark_off.assign(1, S->base);
+  return NFM_OK;
+}
+
+// byte offset of row r: walked from the nearest mark at or before it (blocks are asked for in file order, so the walk
+// normally continues where the last one stopped); a mark is left every kMarkEvery rows
+int StreamFile::offset_of(int64_t r, int64_t* off_out) {
+  constexpr int64_t kMarkEvery = 65536;
+  size_t lo = 0, hi = mark_row.size() - 1;
+  while (lo < hi) {
+    const size_t mid = (lo + hi + 1) / 2;
+    if (mark_row[mid] <= r) lo = mid; else hi = mid - 1;
+  }
+  int64_t row = mark_row[lo], pos = mark_off[lo];
+  while (row < r) {
+    NFM_CHECK(pos + 8 <= len, NFM_ERR_INVALID, "%s: truncated at row %lld", path.c_str(), (long long)row);
+    int64_t c;
+    memcpy(&c, map + pos, 8);
+    NFM_CHECK(c >= 0 && c <= (len - pos - 8) / esize, NFM_ERR_INVALID, "%s: row %lld overruns the file", path.c_str(), (long long)row);
+    pos += 8 + c * esize;
+    ++row;
+    if (row % kMarkEvery == 0 && row > mark_row.back()) {
+      mark_row.push_back(row);
+      mark_off.push_back(pos);
+    }
+  }
+  *off_out = pos;
+  return NFM_OK;
+}
+
+int StreamFile::load_rows(nfm_ctx* ctx, int64_t r0, int64_t r1, IngestResult* out) {
+  NFM_CHECK(r0 >= 0 && r0 <= r1 && r1 <= n, NFM_ERR_INVALID, "rows [%lld,%lld) outside [0,%lld)", (long long)r0, (long long)r1, (long long)n);
+  hipStream_t st = ctx->stream;
+  const int64_t nr = r1 - r0;
+  int64_t off0 = 0;
+  NFM_TRY(offset_of(r0, &off0));
+  std::vector<int64_t> indptr((size_t)nr + 1);
+  int64_t pos = off0, acc = 0, max_row = 0;
+  indptr[0] = 0;
+  for (int64_t i = 0; i < nr; ++i) {
+    NFM_CHECK(pos + 8 <= len, NFM_ERR_INVALID, "%s: truncated at row %lld", path.c_str(), (long long)(r0 + i));
+    int64_t c;
+    memcpy(&c, map + pos, 8);
+    NFM_CHECK(c >= 0 && c <= (len - pos - 8) / esize, NFM_ERR_INVALID, "%s: row %lld overruns the file", path.c_str(), (long long)(r0 + i));
+    pos += 8 + c * esize;
+    acc += c;
+    indptr[i + 1] = acc;
+    max_row = std::max(max_row, c);
+  }
+  const int64_t nbytes = pos - off0, nz = acc;
+  DevBuf raw, status;
+  NFM_TRY(raw.alloc((size_t)nbytes + 64));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  if (nbytes) NFM_HIP_CHECK(hipMemcpy(raw.p, map + off0, (size_t)nbytes, hipMemcpyHostToDevice));
+  NFM_TRY(out->indptr.alloc(sizeof(int64_t) * (nr + 1)));
+  NFM_HIP_CHECK(hipMemcpyAsync(out->indptr.p, indptr.data(), sizeof(int64_t) * (nr + 1), hipMemcpyHostToDevice, st));
+  NFM_TRY(out->indices.alloc(sizeof(int32_t) * std::max<int64_t>(nz, 1)));
+  NFM_TRY(out->data.alloc(sizeof(double) * std::max<int64_t>(nz, 1)));
+  if (with_fields) NFM_TRY(out->fields.alloc(sizeof(int32_t) * std::max<int64_t>(nz, 1)));
+  long long h_st[ST_COUNT];
+  for (int i = 0; i < ST_COUNT; ++i) h_st[i] = 0;
+  NFM_TRY(status.alloc(sizeof(h_st)));
+  NFM_HIP_CHECK(hipMemcpyAsync(status.p, h_st, sizeof(h_st), hipMemcpyHostToDevice, st));
+  if (nz)
+    hipLaunchKernelGGL(k_stream_split, dim3(grid_for(nz)), dim3(kBlock), 0, st, raw.as<unsigned char>(), (int64_t)0, esize,
+                       with_fields ? 1 : 0, nr, d, nf, out->indptr.as<int64_t>(), nz, out->indices.as<int32_t>(),
+                       out->data.as<double>(), with_fields ? out->fields.as<int32_t>() : nullptr, status.as<long long>());
+  NFM_HIP_CHECK(hipGetLastError());
+  NFM_HIP_CHECK(hipMemcpyAsync(h_st, status.p, sizeof(h_st), hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  NFM_CHECK(h_st[ST_MALFORMED] == 0, NFM_ERR_INVALID, "%s: %lld entries with an id outside [0, nCols) or a field outside [0, nFields) of the header",
+            path.c_str(), h_st[ST_MALFORMED]);
+  NFM_TRY(out->y.alloc(sizeof(double) * std::max<int64_t>(nr, 1)));
+  if (!y_path.empty()) {  // loadStreamLabel (dataset.nim:1007-1014): raw float64, one per sample
+    FILE* f = fopen(y_path.c_str(), "rb");
+    NFM_CHECK(f, NFM_ERR_INVALID, "%s cannot be opened.", y_path.c_str());
+    std::vector<double> yb((size_t)nr);
+    const bool ok = fseeko(f, (off_t)(8 * r0), SEEK_SET) == 0 && (nr == 0 || fread(yb.data(), 8, (size_t)nr, f) == (size_t)nr);
+    fclose(f);
+    NFM_CHECK(ok, NFM_ERR_INVALID, "%s holds fewer than %lld labels", y_path.c_str(), (long long)r1);
+    if (nr) NFM_HIP_CHECK(hipMemcpy(out->y.p, yb.data(), (size_t)(8 * nr), hipMemcpyHostToDevice));
+  } else {
+    NFM_HIP_CHECK(hipMemsetAsync(out->y.p, 0, sizeof(double) * std::max<int64_t>(nr, 1), st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  out->n = nr;
+  out->d = d;
+  out->nnz = nz;
+  out->n_fields = nf;
+  out->max_row = (int)max_row;
+  out->bytes = nbytes;
+  return NFM_OK;
+}
+
 int convert_svmlight(nfm_ctx* ctx, const char* f_in, const char* f_out_x, const char* f_out_y) {
   IngestResult r;
   NFM_TRY(ingest_text(ctx, f_in, nullptr, 0, false, &r));

@@ -342,6 +342,8 @@ class _ModelBase:
         """model/factorization_machine.nim:100-122 / field_aware_factorization_machine.nim:52-76"""
         self.checkInitialized()
         self._check_shapes(X)
+        if isinstance(X, StreamCSRDataset):  # block by block
+            return np.concatenate([self.decisionFunction(X.load(r0, r1)) for r0, r1 in X.blocks()] or [np.zeros(0)])
         h = self._push(X.ctx)
         out = np.empty(X.nSamples, dtype=np.float64)
         capi.check(capi.lib().nfm_decision_function(h, X.h, _vp(out)))
@@ -617,11 +619,59 @@ def loadFFMFile(f, nFeatures=-1, nFields=-1, ctx=None):
     return ds, ds.targets()
 
 
-def newStreamCSRDataset(f, fY=None, ctx=None):
-    """dataset.nim:170-174 newStreamCSRDataset (+ loadStreamLabel, :1007-1014, when fY is given): the
-    STREAMCSR / STREAMCSRFIELD file is made resident in HBM instead of being streamed through a host cache.
-    -> (dataset, y)"""
+class StreamCSRDataset:
+    """A STREAMCSR / STREAMCSRFIELD file used in row blocks (dataset.nim:170-174 newStreamCSRDataset(f, cacheSize);
+    tensor/sparse_stream.nim:232-270 readCache): at most cacheRows rows are resident in HBM at a time.  fit walks the
+    blocks in file order without shuffling, as the reference does for a dataset that is not fully cached
+    (optimizer/sgd.nim:297, sgd_multi.nim:83-97)."""
+
+    def __init__(self, f, cacheRows, ctx=None, fY=None):
+        self.ctx = ctx or default_context()
+        self.h = C.c_void_p()
+        capi.check(capi.lib().nfm_stream_open(self.ctx.h, os.path.expanduser(f).encode(),
+                                              None if fY is None else os.path.expanduser(fY).encode(), C.byref(self.h)))
+        n, d, nnz, nf = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        capi.check(capi.lib().nfm_stream_shape(self.h, C.byref(n), C.byref(d), C.byref(nnz), C.byref(nf)))
+        self.nSamples, self._nFeatures, self.nnz, self.nFields = n.value, d.value, nnz.value, nf.value
+        self.cacheRows = max(1, int(cacheRows))
+
+    @property
+    def nFeatures(self):
+        return self._nFeatures
+
+    @property
+    def shape(self):
+        return [self.nSamples, self._nFeatures]
+
+    def blocks(self):
+        return [(r0, min(self.nSamples, r0 + self.cacheRows)) for r0 in range(0, self.nSamples, self.cacheRows)]
+
+    def load(self, r0, r1):
+        """rows [r0, r1) as a resident dataset"""
+        h = C.c_void_p()
+        capi.check(capi.lib().nfm_stream_load_rows(self.h, r0, r1, C.byref(h)))
+        return CSRDataset._from_loader(self.ctx, h)
+
+    def __del__(self):
+        try:
+            if capi.alive and getattr(self, "h", None):
+                capi.lib().nfm_stream_close(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def newStreamCSRDataset(f, fY=None, ctx=None, cacheRows=None):
+    """dataset.nim:170-174 newStreamCSRDataset (+ loadStreamLabel, :1007-1014, when fY is given).  cacheRows = None:
+    the STREAMCSR / STREAMCSRFIELD file is made resident in HBM as a whole; cacheRows = r: a StreamCSRDataset that
+    keeps at most r rows resident (the reference's cacheSize, in rows).  -> (dataset, y)"""
     ctx = ctx or default_context()
+    if cacheRows is not None:
+        ds = StreamCSRDataset(f, cacheRows, ctx, fY)
+        y = np.fromfile(os.path.expanduser(fY), dtype=np.float64) if fY is not None else np.zeros(ds.nSamples)
+        if len(y) != ds.nSamples:
+            raise ValueError("%s holds %d labels, the matrix has %d rows" % (fY, len(y), ds.nSamples))
+        return ds, y
     h = C.c_void_p()
     capi.check(capi.lib().nfm_dataset_load_stream(ctx.h, os.path.expanduser(f).encode(),
                                                   None if fY is None else os.path.expanduser(fY).encode(), C.byref(h)))
@@ -763,6 +813,8 @@ class _OptimizerBase:
         maxThreads (the reference's Hogwild overload) selects the data-parallel mini-batch mode.
         perms ([maxIter][n], optional) replaces the internal shuffle with explicit permutations: the
         reference shuffles with Nim's global RNG (sgd.nim:297), which a Nim host passes in here."""
+        if isinstance(X, StreamCSRDataset):
+            return self._fit_stream(X, y, fm, maxThreads, callback)
         fm.init(X)
         y = _f64(y)
         if len(y) != X.nSamples:
@@ -858,6 +910,67 @@ class _OptimizerBase:
             print("Objective did not converge. Increase maxIter.")
         self._finalize_into(fm)
         return self
+
+
+def _fit_stream(self, X, y, fm, maxThreads=None, callback=None):
+    """fit over a dataset that is resident one row block at a time (optimizer/sgd_multi.nim:83-97: `while nRest > 0:
+    X.readCache(...)`): blocks in file order, no shuffling (sgd.nim:297 shuffles only a fully cached dataset); the
+    optimizer's step counter, scales and state continue from block to block."""
+    fm.init(X)
+    y = _f64(y)
+    if len(y) != X.nSamples:
+        raise ValueError("len(y) != nSamples")
+    mode = self.mode if (maxThreads is None and self._dp is None) else "minibatch"
+    if not fm.warmStart:
+        self.it = 1
+    self._handle(fm, X.ctx, mode)
+    if fm._dirty:
+        fm._push(X.ctx)
+    capi.check(capi.lib().nfm_opt_set_it(self._h, self.it))
+    capi.check(capi.lib().nfm_opt_set_shuffle(self._h, -1))
+    if self.verbose > 0:
+        _echo_header(self.maxIter)
+    n = X.nSamples
+    isConverged = False
+    self.history = []
+    for epoch in range(self.maxIter):
+        viol = runningLoss = 0.0
+        for r0, r1 in X.blocks():
+            blk = X.load(r0, r1)
+            blk.set_targets(y[r0:r1])
+            ls, vs = self._epoch(blk, None, 0, r1 - r0)
+            runningLoss += ls
+            viol += vs
+            self.it += r1 - r0
+            del blk
+        runningLoss /= float(n)
+        if callback is not None:
+            self._finalize_into(fm)
+            callback(self, fm)
+        self.history.append((viol, runningLoss))
+        isContinue = True
+        if math.isnan(runningLoss):
+            print("Loss is NaN. Use smaller learning rate.")
+            isContinue = False
+        if self.verbose > 0:
+            b = C.c_double(0.0)
+            reg = self._regularization(fm)
+            capi.check(capi.lib().nfm_model_get_params(fm._h, None, None, C.byref(b)))
+            _echo_info(epoch + 1, self.maxIter, viol, runningLoss, reg + 0.5 * self.alpha0 * b.value ** 2)
+        if viol < self.tol:
+            if self.verbose > 0:
+                print("Converged at epoch %d." % epoch)
+            isConverged = True
+            isContinue = False
+        if not isContinue:
+            break
+    if not isConverged and self.verbose > 0:
+        print("Objective did not converge. Increase maxIter.")
+    self._finalize_into(fm)
+    return self
+
+
+_OptimizerBase._fit_stream = _fit_stream
 
 
 class SGD(_OptimizerBase):

@@ -186,3 +186,56 @@ def test_stream_files(tmp_path):
     (tmp_path / "nf.bin").write_bytes(bytes(fb[:14 + 24]) + struct.pack("<q", nF - 1) + bytes(fb[14 + 32:]))
     with pytest.raises(ValueError, match="outside"):
         nf.newStreamCSRDataset(str(tmp_path / "nf.bin"))
+
+
+def test_stream_file_in_row_blocks(tmp_path):
+    """newStreamCSRDataset(f, cacheRows): the out-of-core path (tensor/sparse_stream.nim:232-270 readCache; epoch loop
+    optimizer/sgd_multi.nim:83-97) -- at most cacheRows rows resident, blocks walked in file order, the optimizer's step
+    counter / scales / state continuing across blocks.  In the reference's sample order this must equal the fit over the
+    whole matrix; in mini-batch mode (cacheRows a multiple of the batch) likewise."""
+    import oracle as O
+    from common import assert_close
+    rng = np.random.default_rng(13)
+    n, d, k = 700, 120, 4
+    text = random_csr_text(rng, n, d, 0.08, wide=False)
+    xb, yb = ingest.convert_svmlight(text)
+    (tmp_path / "x.bin").write_bytes(xb)
+    (tmp_path / "y.bin").write_bytes(yb)
+    ref = ingest.read_stream(xb, yb)
+    Xo = O.Dataset(ref["indptr"], ref["indices"], ref["data"], len(ref["indptr"]) - 1, ref["n_features"])
+    dd = ref["n_features"]
+    y = ref["y"]
+    P0, w0 = rng.standard_normal((1, k, dd)) * 0.05, np.zeros(dd)
+    Xs, ys = nf.newStreamCSRDataset(str(tmp_path / "x.bin"), str(tmp_path / "y.bin"), cacheRows=256)
+    assert isinstance(Xs, nf.StreamCSRDataset) and Xs.nSamples == n and Xs.nFeatures == dd and np.array_equal(ys, y)
+    assert Xs.blocks() == [(0, 256), (256, 512), (512, 700)]
+    blk = Xs.load(256, 512)
+    ip, ix, dv, _ = blk.to_host()
+    a, b = ref["indptr"][256], ref["indptr"][512]
+    assert np.array_equal(ip, ref["indptr"][256:513] - a) and np.array_equal(ix, ref["indices"][a:b]) and np.array_equal(dv, ref["data"][a:b])
+    assert np.array_equal(blk.targets(), y[256:512])
+    # the reference's order (sequential mode), two epochs
+    fm = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True)
+    fm.set_params(P0, w0, 0.0)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=True, mode="sequential")  # shuffle is ignored for a streamed dataset
+    sgd.fit(Xs, y, fm)
+    P, w, b, it, el, ev, _ = O.fm_sgd_fit(Xo, y, 2, P0, w0, 0.0, O.sgd_cfg(), 2)
+    assert sgd.it == it
+    assert_close(fm.P, P, 1e-9, 1e-12, "P, sequential")
+    assert_close(fm.w, w, 1e-9, 1e-12, "w, sequential")
+    assert_close([h[1] for h in sgd.history], el, 1e-10, 1e-13, "mean loss per epoch")
+    assert_close(fm.decisionFunction(Xs), O.fm_decision_function(Xo, 2, P, w, b), 1e-10, 1e-13, "decisionFunction over blocks")
+    # mini-batch mode: blocks of 256 = 4 batches of 64
+    fm = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True)
+    fm.set_params(P0, w0, 0.0)
+    ada = nf.newAdaGrad(maxIter=2, verbose=0, tol=0, mode="minibatch", batch=64)
+    ada.fit(Xs, y, fm)
+    cfg = O.adagrad_cfg()
+    P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
+    st = O.AdaState(1, dd, k, dd)
+    for _ in range(2):
+        for r0, r1 in Xs.blocks():
+            b, it, _, _ = O.fm_adagrad_epoch_mb(Xo, y, 2, P, w, b, cfg, 64, st, begin=r0, end=r1, it=it)
+    b = O.fm_adagrad_finalize(2, P, w, b, cfg, it, st)
+    assert_close(fm.P, P, 1e-9, 1e-12, "P, mini-batch")
+    assert abs(fm.intercept - b) < 1e-11

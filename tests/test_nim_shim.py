@@ -15,7 +15,7 @@ C2N = {  # C parameter type (const dropped, spaces normalised) -> Nim spelling
     "nfm_ctx*": "NfmCtx", "nfm_dataset*": "NfmDataset", "nfm_model*": "NfmModel", "nfm_opt*": "NfmOpt",
     "nfm_ctx**": "ptr NfmCtx", "nfm_dataset**": "ptr NfmDataset", "nfm_model**": "ptr NfmModel", "nfm_opt**": "ptr NfmOpt",
     "nfm_model_cfg*": "ptr NfmModelCfg", "nfm_sgd_cfg*": "ptr NfmSgdCfg", "nfm_adagrad_cfg*": "ptr NfmAdaGradCfg",
-    "nfm_mbpsgd_cfg*": "ptr NfmMbpsgdCfg", "double**": "ptr ptr float64", "nfm_dp*": "NfmDp", "nfm_dp**": "ptr NfmDp",
+    "nfm_mbpsgd_cfg*": "ptr NfmMbpsgdCfg", "double**": "ptr ptr float64", "nfm_dp*": "NfmDp", "nfm_dp**": "ptr NfmDp", "nfm_stream*": "NfmStream", "nfm_stream**": "ptr NfmStream",
 }
 
 
