@@ -14,6 +14,9 @@ namespace nfm {
 #ifndef NFM_COL_MINW
 #define NFM_COL_MINW 1
 #endif
+#ifndef NFM_COL_D3
+#define NFM_COL_D3 1
+#endif
 #ifndef NFM_REG_NTSEL
 #define NFM_REG_NTSEL 0
 #endif
@@ -1239,6 +1242,130 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
   return viol;
 }
 
+// degree 3 with fitLower = explicit (cfg5): two parameter blocks -- order 0 of ANOVA degree 3 (A rows 0, 1 of the sample:
+// A[1], A[2]) and order 1 of degree 2 (A row 2).  col_block walks a feature's touch list once per block (touch positions,
+// values and the samples' records fetched twice); here BOTH blocks are handled in one walk: one record and the sample's
+// three A rows per touch.  Same arithmetic and the same order of every sum as two col_block<.., MODE 0> calls.
+template <int OPT, int LG>
+__device__ __forceinline__ double col_block_d3(const ColArgs& a, int64_t j, int l, int64_t t0, int64_t t1, double sP,
+                                               double sPn, double fP, bool do_w, WAcc& wacc) {
+  static_assert(OPT == OPT_SGD || OPT == OPT_ADAGRAD, "SGD / AdaGrad");
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const size_t e[2] = {M.row(0, j) * M.Kp + 2 * l, M.row(1, j) * M.Kp + 2 * l};
+  double viol = 0.0;
+  double2 stored[2], g2[2], n2[2], p[2];
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    stored[o] = g2[o] = n2[o] = {0.0, 0.0};
+    if (OPT == OPT_SGD) {
+      stored[o] = dev::ld_stream(M.P + e[o]);
+      p[o].x = sP * stored[o].x;
+      p[o].y = sP * stored[o].y;
+    } else {
+      g2[o] = dev::ld_stream(O.G + e[o]);
+      n2[o] = dev::ld_stream(O.N + e[o]);
+      if (a.use_stored) {
+        p[o] = dev::ld_stream(M.P + e[o]);
+      } else {
+        const double tmp = O.eta0 * ((a.it0p[0] + a.it_b) - 1.0) * O.beta;
+        p[o].x = dev::adagrad_param(g2[o].x, n2[o].x, O.eta0, tmp);
+        p[o].y = dev::adagrad_param(g2[o].y, n2[o].y, O.eta0, tmp);
+        if (O.track_viol) {
+          stored[o] = dev::ld_stream(M.P + e[o]);
+          viol += fabs(stored[o].x - p[o].x) + fabs(stored[o].y - p[o].y);
+          dev::st_stream(M.P + e[o], p[o]);
+        }
+      }
+    }
+  }
+  double2 acc[2] = {{0.0, 0.0}, {0.0, 0.0}}, accn[2] = {{0.0, 0.0}, {0.0, 0.0}};
+  double seta = 0.0;
+  constexpr int TG = 2;
+  const int gbase = (int)(threadIdx.x & (kWave - 1)) - l;
+  for (int64_t tb = t0; tb < t1; tb += LG) {
+    const int64_t tl = tb + l;
+    const int pib_l = tl < t1 ? a.tpos[tl] : 0;
+    const double x_l = tl < t1 ? a.tx[tl] : 0.0;
+    const int cnt = (int)(t1 - tb < LG ? t1 - tb : LG);
+    for (int ub = 0; ub < cnt; ub += TG) {
+      int pib[TG];
+      double x[TG];
+      SampleRec r[TG];
+      double2 Aa[TG], Ab[TG], Ac[TG];
+#pragma unroll
+      for (int u = 0; u < TG; ++u) {
+        const int src = gbase + ((ub + u) < LG ? (ub + u) : 0);
+        pib[u] = __shfl(pib_l, src, kWave);
+        x[u] = dev::shfl_d(x_l, src);
+      }
+#pragma unroll
+      for (int u = 0; u < TG; ++u) {
+        r[u] = a.rec[pib[u]];
+        const double* Ar = a.Abuf + (size_t)pib[u] * 3 * M.Kp + 2 * l;
+        Aa[u] = *reinterpret_cast<const double2*>(Ar);
+        Ab[u] = *reinterpret_cast<const double2*>(Ar + M.Kp);
+        Ac[u] = *reinterpret_cast<const double2*>(Ar + 2 * M.Kp);
+      }
+#pragma unroll
+      for (int u = 0; u < TG; ++u) {
+        if (ub + u >= cnt) continue;
+        const double xv = x[u];
+        // order 0, degree 3 (optimizer/sgd.nim:176-188): dA = x; dA = x (A[1] - p dA); dA = x (A[2] - p dA)
+        double d0x = xv * (Aa[u].x - p[0].x * xv), d0y = xv * (Aa[u].y - p[0].y * xv);
+        d0x = xv * (Ab[u].x - p[0].x * d0x);
+        d0y = xv * (Ab[u].y - p[0].y * d0y);
+        // order 1, degree 2
+        const double d1x = xv * (Ac[u].x - p[1].x * xv), d1y = xv * (Ac[u].y - p[1].y * xv);
+        if (OPT == OPT_SGD) {
+          acc[0].x += r[u].etaP * (r[u].dL * d0x);
+          acc[0].y += r[u].etaP * (r[u].dL * d0y);
+          acc[1].x += r[u].etaP * (r[u].dL * d1x);
+          acc[1].y += r[u].etaP * (r[u].dL * d1y);
+          seta += r[u].etaP;
+          if (do_w) {
+            wacc.a0 += r[u].etaw * (r[u].dL * xv);
+            wacc.a1 += r[u].etaw;
+          }
+        } else {
+          const double g0x = r[u].dL * d0x, g0y = r[u].dL * d0y, g1x = r[u].dL * d1x, g1y = r[u].dL * d1y;
+          acc[0].x += g0x;
+          acc[0].y += g0y;
+          accn[0].x += g0x * g0x;
+          accn[0].y += g0y * g0y;
+          acc[1].x += g1x;
+          acc[1].y += g1y;
+          accn[1].x += g1x * g1x;
+          accn[1].y += g1y * g1y;
+          if (do_w) {
+            const double gw = r[u].dL * xv;
+            wacc.a0 += gw;
+            wacc.a1 += gw * gw;
+          }
+        }
+      }
+    }
+  }
+  const double c = (double)(t1 - t0);
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    if (OPT == OPT_SGD) {
+      viol += fabs((acc[o].x + seta * O.beta * p[o].x) / c) + fabs((acc[o].y + seta * O.beta * p[o].y) / c);
+      stored[o].x = stored[o].x * fP - (acc[o].x / c) / sPn;
+      stored[o].y = stored[o].y * fP - (acc[o].y / c) / sPn;
+      dev::st_stream(M.P + e[o], stored[o]);
+    } else {
+      g2[o].x += acc[o].x;
+      g2[o].y += acc[o].y;
+      n2[o].x += accn[o].x;
+      n2[o].y += accn[o].y;
+      dev::st_stream(O.G + e[o], g2[o]);
+      dev::st_stream(O.N + e[o], n2[o]);
+    }
+  }
+  return viol;
+}
+
 // linear term of one feature (fit_linear.nim:41-57); every lane of the feature holds the same sums
 template <int OPT>
 __device__ __forceinline__ double w_epilogue(const ColArgs& a, int64_t j, int l, double c, double sw, double swn, double fw,
@@ -1506,6 +1633,10 @@ __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
     const bool has_w = M.fit_linear && j < M.d;  // dummy features have no w
     WAcc wacc;
     int slot = 0;
+    if (GEN && OPT != OPT_PSGD && NFM_COL_D3 && M.nb == 2 && M.degree == 3 && a.TA == 3) {
+      // degree 3, explicit lower orders (cfg5): both parameter blocks in one walk of the touch list
+      viol += col_block_d3<(OPT == OPT_PSGD ? OPT_SGD : OPT), L>(a, j, l, t0, t1, sP, sPn, fP, has_w, wacc);
+    } else
     for (int o = 0; o < M.nb; ++o) {
       const size_t e = M.row(o, j) * M.Kp + 2 * l;
       const int deg = M.degree - o;
