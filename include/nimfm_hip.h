@@ -334,7 +334,7 @@ int32_t nfm_dp_info(const nfm_dp* dp, int32_t* rank, int32_t* world, int64_t* n_
 int32_t nfm_dp_destroy(nfm_dp* dp);
 /* attach (dp != NULL) or detach (dp == NULL) a group; sync_period: mini-batches between exchanges, 0 = only the exact
  * exchange at the end of every nfm_opt_epoch call */
-int32_t nfm_opt_set_dp(nfm_opt* o, nfm_dp* dp, int64_t sync_period, int32_t overlap);
+int32_t nfm_opt_set_dp(nfm_opt* o, nfm_dp* dp, int64_t sync_period, int32_t overlap);  /* detach before nfm_dp_destroy */
 
 /* ---- host-side random numbers (no device work) ----
  * FactorizationMachine.init draws P with randomNormal (model/factorization_machine.nim:125-139,

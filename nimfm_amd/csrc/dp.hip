@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>  // types and enumerators only: the library is opened at run time (no link dependency)
 #include <string.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -92,16 +93,29 @@ struct LocalGroup {
   hipEvent_t ready[kMaxLocalWorld] = {}, done[kMaxLocalWorld] = {};
   int device[kMaxLocalWorld] = {};
   bool broken = false;
-  void barrier() {
+  ~LocalGroup() {
+    for (int r = 0; r < world; ++r) {
+      if (ready[r]) (void)hipEventDestroy(ready[r]);
+      if (done[r]) (void)hipEventDestroy(done[r]);
+    }
+  }
+  // false: a rank did not arrive within two minutes (it failed or never made the matching call) -- the group is
+  // marked broken and every waiting rank returns an error instead of hanging
+  bool barrier() {
     std::unique_lock<std::mutex> lk(mu);
+    if (broken) return false;
     const uint64_t g = generation;
     if (++arrived == world) {
       arrived = 0;
       ++generation;
       cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return generation != g || broken; });
+      return true;
     }
+    if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != g || broken; })) {
+      broken = true;
+      cv.notify_all();
+    }
+    return !broken;
   }
 };
 struct PeerPtrs {
@@ -123,7 +137,7 @@ struct LocalTransport : DpTransport {
     LocalGroup& G = *g;
     NFM_HIP_CHECK(hipEventRecord(G.ready[rank], st));
     G.send[rank] = send;
-    G.barrier();  // every rank has published its buffer and recorded "ready"
+    NFM_CHECK(G.barrier(), NFM_ERR_HIP, "a rank of the local group did not reach the collective");  // buffers published, "ready" recorded
     PeerPtrs pp{};
     for (int q = 0; q < world; ++q) {
       pp.p[q] = G.send[q];
@@ -135,7 +149,7 @@ struct LocalTransport : DpTransport {
     hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)blocks), dim3(kBlock), 0, st, pp, world, recv, n, op);
     NFM_HIP_CHECK(hipGetLastError());
     NFM_HIP_CHECK(hipEventRecord(G.done[rank], st));
-    G.barrier();  // every rank has enqueued its sum
+    NFM_CHECK(G.barrier(), NFM_ERR_HIP, "a rank of the local group did not reach the collective");  // every rank has enqueued its sum
     for (int q = 0; q < world; ++q)  // nobody's send buffer is overwritten before all readers are through
       if (q != rank) NFM_HIP_CHECK(hipStreamWaitEvent(st, G.done[q], 0));
     return NFM_OK;
