@@ -395,7 +395,8 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     X.set_targets(y)
     opt._handle(fm, ctx, "minibatch")
     sync_period = 0
-    if world > 1:
+    use_dp = world > 1 or getattr(run_training, "group", None) is not None
+    if use_dp:
         # the exchange lives in the library (csrc/dp.hip): one RCCL communicator per rank, the replicas reconciled every
         # sync_period mini-batches on a second stream beside the next period's mini-batches, exactly at the end of the
         # epoch; torch.distributed only carried the group id (dp.Group.from_torch, in main)
@@ -404,7 +405,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
 
     def step(perm=None):
         ls, vs = opt._epoch(X, perm, 0, n)  # with a group: the sums over all ranks
-        if world > 1:
+        if use_dp:
             opt._sync_it()  # advanced by the samples of all ranks (the reference's threads share one counter)
         else:
             opt.it += n
@@ -496,8 +497,9 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
 
     # ---- roofline leg: per-kernel durations from HIP events on the library's stream (one replica, no exchange) ----
     roof = None
-    if world > 1:
-        dist.barrier()
+    if use_dp:
+        if world > 1:
+            dist.barrier()
         opt.setDataParallel(None)
     if rank == 0:
         ctx.timing_reset()
@@ -554,7 +556,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                                        "RCCL every %s on a second stream + exactly at the end of every epoch"
                                        % (world, "averaged" if wl["solver"] == "sgd" else "state-summed",
                                           ("%d mini-batches" % sync_period) if sync_period else "epoch (no mid-epoch exchange)"))
-                       if world > 1 else "1 GPU"},
+                       if use_dp else "1 GPU"},
             "last_step": {"mean_loss": last[0] / (n * world), "viol": last[1]}, "predict": pred,
             "roofline": roof, "cpu_baseline": cpu}
 
@@ -606,17 +608,28 @@ def main():
     dist = None
     ctx = nf.Context(dev_index)
     nf.set_default_context(ctx)
-    if world > 1:
+    if world > 1 or os.environ.get("NIMFM_BENCH_FORCE_DP") == "1":  # FORCE_DP: the N > 1 plumbing with one rank (rehearsal)
         import torch.distributed as dist
 
         from nimfm_amd import dp
 
         # torch.distributed (gloo, host side) is only the bootstrap and the clock: it carries the group id and the
         # barriers / MAX-over-ranks of the timing.  The exchange itself is the library's own RCCL communicator.
-        dist.init_process_group("gloo")
-        if backend == "nccl":
-            run_training.group = dp.Group.from_torch(ctx, dist)
-        else:
+        # gloo and RCCL print banners ("[Gloo] Rank 0 is connected ...", "RCCL version : ...") on STDOUT when they come
+        # up; stdout carries exactly one JSON line, so file descriptor 1 points at stderr while the group is created
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            if backend == "nccl":
+                run_training.group = dp.Group.from_torch(ctx, dist)
+                dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
+        if backend != "nccl":
             raise SystemExit("NIMFM_BENCH_BACKEND=%s: the exchange is RCCL inside the library; rehearse the rule on the CPU "
                              "with tests/test_dp_gloo.py or on one GPU with tests/test_gpu_dp.py" % backend)
 
