@@ -1695,10 +1695,17 @@ struct ColHdr {
   int64_t t0;
 };
 
+#ifndef NFM_COL_NF
+#define NFM_COL_NF 1
+#endif
+#ifndef NFM_COL_SPARSE_MINW
+#define NFM_COL_SPARSE_MINW 1
+#endif
 template <int L, int OPT>
-__global__ __launch_bounds__(kBlock) void k_col_sparse(ColArgs a) {
+__global__ __launch_bounds__(kBlock, NFM_COL_SPARSE_MINW) void k_col_sparse(ColArgs a) {
   static_assert(OPT == OPT_SGD || OPT == OPT_ADAGRAD, "SGD / AdaGrad");
   constexpr int R = kWave / L, TU = 2;
+  constexpr int NF = NFM_COL_NF;  // features a lane group gathers for at the same time
   __shared__ double red[5][kBlock];
   const ModelView& M = a.M;
   const OptView& O = a.O;
@@ -1753,123 +1760,171 @@ __global__ __launch_bounds__(kBlock) void k_col_sparse(ColArgs a) {
     }
     return s;
   };
-  int64_t u = closer ? a.u1 : a.u0 + ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
-  ColHdr h0 = load_hdr(u), h1 = load_hdr(u + stride);
-  ColStage<OPT> s0 = load_stage(h0);
-  for (; u < a.u1; u += stride) {
-    const ColHdr h2 = load_hdr(u + 2 * stride);
-    const ColStage<OPT> s1 = load_stage(h1);  // in flight while this feature's records and A rows are gathered
-    if (h0.cnt > 0) {
-      const int64_t j = h0.j;
-      const size_t e = M.row(0, j) * M.Kp + 2 * l;
-      const int64_t t0 = h0.t0, t1 = t0 + h0.cnt;
-      const bool do_w = M.fit_linear && j < M.d;
-      double2 stored = s0.st, g2 = s0.g2, n2 = s0.n2, p;
-      if (OPT == OPT_SGD) {
-        p.x = sP * stored.x;
-        p.y = sP * stored.y;
-      } else if (a.use_stored) {
-        p = stored;
-      } else {
-        p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmpP);
-        p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmpP);
-        if (O.track_viol) {  // adagrad.nim:96-99
-          viol += fabs(stored.x - p.x) + fabs(stored.y - p.y);
-          dev::st_stream(M.P + e, p);
-        }
+  struct Gath {  // records and A rows of a feature's first TU touches
+    SampleRec r[TU];
+    double2 A1[TU];
+    double x[TU];
+  };
+  auto gather = [&](const ColHdr& h, const ColStage<OPT>& s) {
+    Gath G{};
+    if (h.cnt > 0) {
+#pragma unroll
+      for (int q = 0; q < TU; ++q) {
+        const int src = gbase + (q < h.cnt && q < L ? q : 0);
+        const int pib = __shfl(s.pib, src, kWave);
+        G.x[q] = dev::shfl_d(s.x, src);
+        G.r[q] = a.rec[pib];
+        G.A1[q] = *reinterpret_cast<const double2*>(a.Abuf + (size_t)pib * a.TA * M.Kp + 2 * l);
       }
-      double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
-      double seta = 0.0;
-      WAcc wacc;
+    }
+    return G;
+  };
+  // one touch into the feature's sums, in touch order: the arithmetic of col_block<.., MODE 0>
+  auto add_touch = [&](const SampleRec& r, double2 A1, double x, double2 p, bool do_w, double2& acc, double2& accn, double& seta,
+                       WAcc& wacc) {
+    const double dAx = x * (A1.x - p.x * x);
+    const double dAy = x * (A1.y - p.y * x);
+    if (OPT == OPT_SGD) {  // sgd.nim:220-222, averaged per coordinate below
+      acc.x += r.etaP * (r.dL * dAx);
+      acc.y += r.etaP * (r.dL * dAy);
+      seta += r.etaP;
+      if (do_w) {
+        wacc.a0 += r.etaw * (r.dL * x);
+        wacc.a1 += r.etaw;
+      }
+    } else {  // adagrad.nim:122-124
+      const double gx = r.dL * dAx, gy = r.dL * dAy;
+      acc.x += gx;
+      acc.y += gy;
+      accn.x += gx * gx;
+      accn.y += gy * gy;
+      if (do_w) {
+        const double gw = r.dL * x;
+        wacc.a0 += gw;
+        wacc.a1 += gw * gw;
+      }
+    }
+  };
+  auto finish = [&](const ColHdr& h, const ColStage<OPT>& s, const Gath& G) {
+    if (h.cnt <= 0) return;
+    const int64_t j = h.j;
+    const size_t e = M.row(0, j) * M.Kp + 2 * l;
+    const int64_t t0 = h.t0, t1 = t0 + h.cnt;
+    const bool do_w = M.fit_linear && j < M.d;
+    double2 stored = s.st, g2 = s.g2, n2 = s.n2, p;
+    if (OPT == OPT_SGD) {
+      p.x = sP * stored.x;
+      p.y = sP * stored.y;
+    } else if (a.use_stored) {
+      p = stored;
+    } else {
+      p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmpP);
+      p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmpP);
+      if (O.track_viol) {  // adagrad.nim:96-99
+        viol += fabs(stored.x - p.x) + fabs(stored.y - p.y);
+        dev::st_stream(M.P + e, p);
+      }
+    }
+    double2 acc = {0.0, 0.0}, accn = {0.0, 0.0};
+    double seta = 0.0;
+    WAcc wacc;
+#pragma unroll
+    for (int q = 0; q < TU; ++q)
+      if (q < h.cnt) add_touch(G.r[q], G.A1[q], G.x[q], p, do_w, acc, accn, seta, wacc);
+    if (h.cnt > TU) {  // longer lists (a minority in this regime): the rest is fetched here, TU touches at a time
       for (int64_t tb = t0; tb < t1; tb += L) {
-        int pib_l = s0.pib;
-        double x_l = s0.x;
-        if (tb != t0) {  // lists longer than a lane group: further chunks are fetched here
+        int pib_l = s.pib;
+        double x_l = s.x;
+        if (tb != t0) {
           const int64_t tl = tb + l;
           pib_l = tl < t1 ? a.tpos[tl] : 0;
           x_l = tl < t1 ? a.tx[tl] : 0.0;
         }
         const int cnt = (int)(t1 - tb < L ? t1 - tb : L);
-        for (int ub = 0; ub < cnt; ub += TU) {
+        for (int ub = tb == t0 ? TU : 0; ub < cnt; ub += TU) {
           int pib[TU];
           double x[TU];
           SampleRec r[TU];
           double2 A1[TU];
 #pragma unroll
           for (int q = 0; q < TU; ++q) {
-            const int src = gbase + ((ub + q) < L ? (ub + q) : 0);
+            const int src = gbase + ((ub + q) < cnt ? (ub + q) : ub);
             pib[q] = __shfl(pib_l, src, kWave);
             x[q] = dev::shfl_d(x_l, src);
           }
 #pragma unroll
           for (int q = 0; q < TU; ++q) {
-            if (ub + q >= cnt) pib[q] = pib[0];  // a valid record; its contribution is masked below
             r[q] = a.rec[pib[q]];
             A1[q] = *reinterpret_cast<const double2*>(a.Abuf + (size_t)pib[q] * a.TA * M.Kp + 2 * l);
           }
 #pragma unroll
-          for (int q = 0; q < TU; ++q) {
-            if (ub + q < cnt) {
-              const double dAx = x[q] * (A1[q].x - p.x * x[q]);
-              const double dAy = x[q] * (A1[q].y - p.y * x[q]);
-              if (OPT == OPT_SGD) {  // sgd.nim:220-222, averaged per coordinate below
-                acc.x += r[q].etaP * (r[q].dL * dAx);
-                acc.y += r[q].etaP * (r[q].dL * dAy);
-                seta += r[q].etaP;
-                if (do_w) {
-                  wacc.a0 += r[q].etaw * (r[q].dL * x[q]);
-                  wacc.a1 += r[q].etaw;
-                }
-              } else {  // adagrad.nim:122-124
-                const double gx = r[q].dL * dAx, gy = r[q].dL * dAy;
-                acc.x += gx;
-                acc.y += gy;
-                accn.x += gx * gx;
-                accn.y += gy * gy;
-                if (do_w) {
-                  const double gw = r[q].dL * x[q];
-                  wacc.a0 += gw;
-                  wacc.a1 += gw * gw;
-                }
-              }
-            }
-          }
-        }
-      }
-      const double c = (double)(t1 - t0);
-      if (OPT == OPT_SGD) {
-        viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
-        stored.x = stored.x * s0.fP - (acc.x / c) / sPn;
-        stored.y = stored.y * s0.fP - (acc.y / c) / sPn;
-        dev::st_stream(M.P + e, stored);
-        if (do_w) {  // fit_linear.nim:41-47
-          const double wj = sw * s0.wt;
-          if (l == 0) {
-            viol += fabs((wacc.a0 + wacc.a1 * O.alpha * wj) / c);
-            M.w[j] = s0.wt * s0.fw - (wacc.a0 / c) / swn;
-          }
-        }
-      } else {
-        g2.x += acc.x;
-        g2.y += acc.y;
-        n2.x += accn.x;
-        n2.y += accn.y;
-        dev::st_stream(O.G + e, g2);
-        dev::st_stream(O.N + e, n2);
-        if (do_w && l == 0) {  // fit_linear.nim:50-57
-          if (!a.use_stored) {
-            const double wj = -O.eta0 * s0.gw / (itp * O.eta0 * O.alpha + sqrt(s0.nw));
-            viol += fabs(s0.wt - wj);
-            M.w[j] = wj;
-          }
-          O.Gw[j] = s0.gw + wacc.a0;
-          O.Nw[j] = s0.nw + wacc.a1;
+          for (int q = 0; q < TU; ++q)
+            if (ub + q < cnt) add_touch(r[q], A1[q], x[q], p, do_w, acc, accn, seta, wacc);
         }
       }
     }
-    h0 = h1;
-    h1 = h2;
-    s0 = s1;
+    const double c = (double)(t1 - t0);
+    if (OPT == OPT_SGD) {
+      viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
+      stored.x = stored.x * s.fP - (acc.x / c) / sPn;
+      stored.y = stored.y * s.fP - (acc.y / c) / sPn;
+      dev::st_stream(M.P + e, stored);
+      if (do_w) {  // fit_linear.nim:41-47
+        const double wj = sw * s.wt;
+        if (l == 0) {
+          viol += fabs((wacc.a0 + wacc.a1 * O.alpha * wj) / c);
+          M.w[j] = s.wt * s.fw - (wacc.a0 / c) / swn;
+        }
+      }
+    } else {
+      g2.x += acc.x;
+      g2.y += acc.y;
+      n2.x += accn.x;
+      n2.y += accn.y;
+      dev::st_stream(O.G + e, g2);
+      dev::st_stream(O.N + e, n2);
+      if (do_w && l == 0) {  // fit_linear.nim:50-57
+        if (!a.use_stored) {
+          const double wj = -O.eta0 * s.gw / (itp * O.eta0 * O.alpha + sqrt(s.nw));
+          viol += fabs(s.wt - wj);
+          M.w[j] = wj;
+        }
+        O.Gw[j] = s.gw + wacc.a0;
+        O.Nw[j] = s.nw + wacc.a1;
+      }
+    }
+  };
+  // a lane group takes features u, u + stride, ...; NF of them per iteration: their records and A rows are gathered
+  // together, while the rows / touch lists of the next NF and the headers of the NF after those are requested
+  int64_t u = closer ? a.u1 : a.u0 + ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  ColHdr h0[NF], h1[NF];
+  ColStage<OPT> s0[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    h0[f] = load_hdr(u + f * stride);
+    h1[f] = load_hdr(u + (NF + f) * stride);
+  }
+#pragma unroll
+  for (int f = 0; f < NF; ++f) s0[f] = load_stage(h0[f]);
+  for (; u < a.u1; u += NF * stride) {
+    Gath G[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) G[f] = gather(h0[f], s0[f]);
+    ColHdr h2[NF];
+    ColStage<OPT> s1[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      h2[f] = load_hdr(u + (2 * NF + f) * stride);
+      s1[f] = load_stage(h1[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) finish(h0[f], s0[f], G[f]);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      h0[f] = h1[f];
+      h1[f] = h2[f];
+      s0[f] = s1[f];
+    }
   }
   viol = dev::wave_sum(viol);
   if (lane == 0) red[0][wv] = viol;
