@@ -998,7 +998,8 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       int rc_epoch;
       // device shuffle: the epoch is only ENQUEUED here; the next epoch's order and plan are then built on a second
       // stream (its host-side waits block on that stream only) while this epoch runs
-      const bool prefetch = (dev_shuffle || ann != nullptr) && !ctx->timing.enabled;
+      static const bool prefetch_on = !(getenv("NFM_PLAN_PREFETCH") && atoi(getenv("NFM_PLAN_PREFETCH")) == 0);  // 0: plans built in line (profiling)
+      const bool prefetch = (dev_shuffle || ann != nullptr) && !ctx->timing.enabled && prefetch_on;
       double* out2_dst = out2;
       if (prefetch) {
         if (!o->out2_pinned) NFM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&o->out2_pinned), sizeof(double) * 2, hipHostMallocDefault));

@@ -144,11 +144,12 @@ __global__ void k_compact(int64_t T, const KeyT* __restrict__ keys, const uint32
 }
 
 // (batch, descending touch count) keys of the unique features, and the gather into the sorted tables
-__global__ void k_ukeys(int64_t U, const int64_t* __restrict__ ubatch, const int64_t* __restrict__ uptr, int bucket,
-                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+__global__ void k_ukeys(int64_t U, const int64_t* __restrict__ ubatch, const int64_t* __restrict__ uptr, int bucket, int cbits,
+                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t cmax = (1u << cbits) - 1;  // counts beyond it share a key: they stay in feature order among themselves
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t c = uptr[u + 1] - uptr[u];
-    keys[u] = ((uint64_t)ubatch[u] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(c / bucket));
+    const int64_t c = (uptr[u + 1] - uptr[u]) / bucket;
+    keys[u] = ((uint32_t)ubatch[u] << cbits) | (cmax - (c < (int64_t)cmax ? (uint32_t)c : cmax));
     vals[u] = (uint32_t)u;
   }
 }
@@ -286,7 +287,7 @@ static inline unsigned grid1d(int64_t n) {
 // (k_csc_fill).  No pass over all touches but these two; cfg2 (32 M touches): ~0.8 ms instead of ~2.9 ms.
 // ------------------------------------------------------------------------------------------------
 constexpr int kCscMaxCol = 1024;      // longest column the ranking kernel takes (16 entries per lane)
-constexpr int kCscMaxBatches = 1024;  // per-wavefront LDS histogram + bucket starts (k_csc_fill: 4 x (2 x 1024 + 1 + 1024) ints = 48 KB)
+constexpr int kCscMaxBatches = 512;   // per-wavefront LDS: k_csc_fill 256 NE + 2 x 512 + 2 ints (NE = 16: 20.5 KB, two wavefronts per workgroup), k_csc_count 4 x 512 ints
 
 __global__ void k_iota_u32(int64_t n, uint32_t* __restrict__ v) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
@@ -368,24 +369,54 @@ __global__ void k_ipos(int64_t ns, const int64_t* __restrict__ perm, int64_t beg
   }
 }
 
-// one wavefront per feature: its touches per batch -> cnt[b * d + j]
+// 32-bit forms for the column path (positions and batch sizes below 2^31 there): a 64-bit divide is ~100 instructions
+__device__ __forceinline__ int batch_of32(int32_t rel, uint32_t batch, int first_singleton) {
+  if (first_singleton) return rel == 0 ? 0 : 1 + (int)((uint32_t)(rel - 1) / batch);
+  return (int)((uint32_t)rel / batch);
+}
+
+// one wavefront per kCntGroup consecutive features: their touches per batch -> cnt[b * d + j].  A column's row ids are
+// requested in one go (kCscMaxCol / 64 predicated loads per lane), then the positions of those rows; the counts of the
+// group leave as runs of kCntGroup consecutive ints per batch.
+constexpr int kCntGroup = 4;
 __global__ __launch_bounds__(kBlock) void k_csc_count(int64_t d, const int64_t* __restrict__ cptr, const int32_t* __restrict__ crow,
                                                       const int32_t* __restrict__ ipos, int64_t batch, int first_singleton,
                                                       int n_batches, int32_t* __restrict__ cnt, int32_t* __restrict__ rpos) {
-  extern __shared__ int s_hist[];  // [kWavesPerBlock][n_batches]
+  extern __shared__ int s_hist[];  // [kWavesPerBlock][kCntGroup][n_batches]
+  constexpr int NE = kCscMaxCol / kWave;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-  int* hist = s_hist + wv * n_batches;
-  for (int64_t j = (int64_t)blockIdx.x * kWavesPerBlock + wv; j < d; j += (int64_t)gridDim.x * kWavesPerBlock) {
-    for (int b = lane; b < n_batches; b += kWave) hist[b] = 0;
-    __builtin_amdgcn_wave_barrier();
-    const int64_t e0 = cptr[j], e1 = cptr[j + 1];
-    for (int64_t e = e0 + lane; e < e1; e += kWave) {
-      const int32_t r = ipos[crow[e]];  // a random 4-byte gather per touch: kept in column order for k_csc_fill
-      rpos[e] = r;
-      if (r >= 0) atomicAdd(&hist[batch_of(r, batch, first_singleton)], 1);
+  int* hist = s_hist + wv * kCntGroup * n_batches;
+  const uint32_t batch32 = (uint32_t)batch;
+  const int64_t n_groups = (d + kCntGroup - 1) / kCntGroup;
+  for (int i = lane; i < kCntGroup * n_batches; i += kWave) hist[i] = 0;
+  __builtin_amdgcn_wave_barrier();
+  for (int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + wv; g < n_groups; g += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int64_t j0 = g * kCntGroup;
+    for (int f = 0; f < kCntGroup && j0 + f < d; ++f) {
+      const int64_t e0 = cptr[j0 + f];
+      const int n_c = (int)(cptr[j0 + f + 1] - e0);
+      int32_t row[NE];
+#pragma unroll
+      for (int u = 0; u < NE; ++u) {
+        const int q = u * kWave + lane;
+        row[u] = q < n_c ? crow[e0 + q] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < NE; ++u) {
+        const int q = u * kWave + lane;
+        if (q < n_c) {
+          const int32_t r = ipos[row[u]];  // a random 4-byte gather per touch: kept in column order for k_csc_fill
+          rpos[e0 + q] = r;
+          if (r >= 0) atomicAdd(&hist[f * n_batches + batch_of32(r, batch32, first_singleton)], 1);
+        }
+      }
     }
     __builtin_amdgcn_wave_barrier();
-    for (int b = lane; b < n_batches; b += kWave) cnt[(size_t)b * d + j] = hist[b];
+    for (int i = lane; i < kCntGroup * n_batches; i += kWave) {
+      const int b = i / kCntGroup, f = i % kCntGroup;
+      if (j0 + f < d) cnt[(size_t)b * d + j0 + f] = hist[f * n_batches + b];
+      hist[f * n_batches + b] = 0;
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -409,34 +440,50 @@ __global__ void k_flag_pos(int64_t n, const int32_t* __restrict__ cnt, int32_t* 
 
 // one wavefront per feature: the column's touches are bucketed by batch in LDS (histogram -> scan -> slots handed out
 // by LDS atomics, in any order), then every touch finds its rank inside its (batch, feature) group -- the touches of
-// the same bucket at smaller positions, a dozen comparisons in the dense regime instead of the whole column -- and is
-// written to the group's place.  A column has at most kCscMaxCol entries.
+// the same bucket at smaller positions, a dozen comparisons in the dense regime instead of the whole column.  Bucket
+// start + rank is the touch's place in the column sorted by (batch, position); the touches are put there in LDS and
+// leave from there, lane after lane in sorted order: neighbouring lanes then write neighbouring slots of the same
+// (batch, feature) group (and read the same entry of the offset table) instead of 64 scattered 4- and 8-byte pieces --
+// the kernel was bound by the NUMBER of memory requests, not by bytes.  A column has at most 64 NE entries.
+template <int NE>
 __global__ __launch_bounds__(kBlock) void k_csc_fill(CsrView X, const int64_t* __restrict__ cptr, const int32_t* __restrict__ crow,
                                                      const double* __restrict__ cval, const uint32_t* __restrict__ cnz,
                                                      const int32_t* __restrict__ rpos, int64_t batch, int first_singleton,
                                                      int n_batches, const int32_t* __restrict__ off,
                                                      const int64_t* __restrict__ toff, int32_t* __restrict__ tpos,
                                                      double* __restrict__ tx, int64_t* __restrict__ tq) {
-  extern __shared__ int s_dyn[];  // per wavefront: hist[n_batches] | bstart[n_batches + 1] | bpos[kCscMaxCol]
-  constexpr int NE = kCscMaxCol / kWave;
+  // per wavefront: sx[64 NE] doubles | hist[n_batches] | bstart[n_batches + 1] | bpos[64 NE] | sq[64 NE]
+  extern __shared__ __align__(16) int s_dyn[];
+  constexpr int NC = NE * kWave;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-  const int per_wave = 2 * n_batches + 1 + kCscMaxCol;
-  int* hist = s_dyn + wv * per_wave;
+  const int per_wave = (2 * NC + 2 * n_batches + 1 + 2 * NC + 1) & ~1;
+  int* base = s_dyn + wv * per_wave;
+  double* sx = reinterpret_cast<double*>(base);
+  int* hist = base + 2 * NC;
   int* bstart = hist + n_batches;
-  int* bpos = bstart + n_batches + 1;
+  int* bpos = bstart + n_batches + 1;  // the bucket's positions while ranking, then the sorted column's positions
+  int* sq = bpos + NC;                 // sorted place -> entry of the column
   const int64_t d = X.d;
-  for (int64_t j = (int64_t)blockIdx.x * kWavesPerBlock + wv; j < d; j += (int64_t)gridDim.x * kWavesPerBlock) {
+  const uint32_t batch32 = (uint32_t)batch;
+  const int wpb = (int)(blockDim.x >> 6);  // wavefronts per workgroup (fewer for long columns: LDS)
+  for (int64_t j = (int64_t)blockIdx.x * wpb + wv; j < d; j += (int64_t)gridDim.x * wpb) {
     const int64_t e0 = cptr[j];
     const int n_c = (int)(cptr[j + 1] - e0);
+    const int nu = (n_c + kWave - 1) / kWave;  // live entries per lane (wave-uniform)
     for (int b = lane; b < n_batches; b += kWave) hist[b] = 0;
     __builtin_amdgcn_wave_barrier();
     int32_t r[NE];
     int bb[NE];
+    double xv[NE];
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
       const int q = u * kWave + lane;
       r[u] = q < n_c ? rpos[e0 + q] : -1;
-      bb[u] = r[u] >= 0 ? (int)batch_of(r[u], batch, first_singleton) : -1;
+      xv[u] = q < n_c ? cval[e0 + q] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      bb[u] = r[u] >= 0 ? batch_of32(r[u], batch32, first_singleton) : -1;
       if (bb[u] >= 0) atomicAdd(&hist[bb[u]], 1);
     }
     __builtin_amdgcn_wave_barrier();
@@ -457,26 +504,50 @@ __global__ __launch_bounds__(kBlock) void k_csc_fill(CsrView X, const int64_t* _
       carry += __shfl(incl, kWave - 1, kWave);
     }
     if (lane == 0) bstart[n_batches] = carry;
+    const int n_v = carry;  // touches of this column inside the epoch's range
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < NE; ++u)
       if (bb[u] >= 0) bpos[bstart[bb[u]] + atomicAdd(&hist[bb[u]], 1)] = r[u];
     __builtin_amdgcn_wave_barrier();
+    int place[NE];
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
-      if (u * kWave >= n_c) break;  // wave-uniform
+      place[u] = -1;
+      if (u >= nu) break;  // wave-uniform
       if (bb[u] < 0) continue;
-      const int q = u * kWave + lane;
       const int s0 = bstart[bb[u]], s1 = bstart[bb[u] + 1];
       int rank = 0;
       for (int t = s0; t < s1; ++t) rank += bpos[t] < r[u] ? 1 : 0;
-      const int64_t lo = batch_start(bb[u], batch, first_singleton);
-      const int64_t dst = (int64_t)off[(size_t)bb[u] * d + j] + rank;
-      tpos[dst] = (int32_t)(r[u] - lo);
-      tx[dst] = cval[e0 + q];
+      place[u] = s0 + rank;
+    }
+    __builtin_amdgcn_wave_barrier();  // every lane is done reading the buckets: bpos is reused
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      if (u >= nu) break;
+      if (place[u] < 0) continue;
+      bpos[place[u]] = r[u];
+      sx[place[u]] = xv[u];
+      sq[place[u]] = u * kWave + lane;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int p = u * kWave + lane;
+      if (u * kWave >= n_v) break;  // wave-uniform
+      if (p >= n_v) continue;
+      const int32_t rr = bpos[p];
+      const int b = batch_of32(rr, batch32, first_singleton);
+      int32_t lo;
+      if (first_singleton) lo = b == 0 ? 0 : 1 + (b - 1) * (int32_t)batch32;
+      else lo = b * (int32_t)batch32;
+      const int32_t dst = off[(size_t)b * d + j] + (p - bstart[b]);
+      tpos[dst] = rr - lo;
+      tx[dst] = sx[p];
       if (tq) {
+        const int q = sq[p];
         const int64_t i = crow[e0 + q];
-        tq[dst] = toff[r[u]] + ((int64_t)cnz[e0 + q] - X.indptr[i]);
+        tq[dst] = toff[rr] + ((int64_t)cnz[e0 + q] - X.indptr[i]);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -579,9 +650,10 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
     NFM_TRY(uidx.alloc(sizeof(int32_t) * (cells + 1)));
     NFM_HIP_CHECK(hipMemsetAsync(cnt.as<int32_t>() + cells, 0, sizeof(int32_t), st));
     {
-      int64_t blocks = (X.d + kWavesPerBlock - 1) / kWavesPerBlock;
+      const int64_t groups = (X.d + kCntGroup - 1) / kCntGroup;
+      int64_t blocks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
       if (blocks > 256 * 16) blocks = 256 * 16;
-      hipLaunchKernelGGL(k_csc_count, dim3((unsigned)blocks), dim3(kBlock), sizeof(int) * kWavesPerBlock * (size_t)P.n_batches, st, X.d,
+      hipLaunchKernelGGL(k_csc_count, dim3((unsigned)blocks), dim3(kBlock), sizeof(int) * kWavesPerBlock * kCntGroup * (size_t)P.n_batches, st, X.d,
                          csc->cptr.as<int64_t>(), csc->crow.as<int32_t>(), ipos.as<int32_t>(), batch, first_singleton ? 1 : 0,
                          (int)P.n_batches, cnt.as<int32_t>(), rpos.as<int32_t>());
     }
@@ -612,13 +684,20 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
       NFM_TRY(ubatch.alloc(sizeof(int64_t) * (U + 1)));
       hipLaunchKernelGGL(k_csc_units, dim3(grid1d(cells)), dim3(kBlock), 0, st, cells, X.d, cnt.as<int32_t>(), off.as<int32_t>(),
                          uidx.as<int32_t>(), P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), ubatch.as<int64_t>());
-      int64_t blocks = (X.d + kWavesPerBlock - 1) / kWavesPerBlock;
-      if (blocks > 256 * 16) blocks = 256 * 16;
-      hipLaunchKernelGGL(k_csc_fill, dim3((unsigned)blocks), dim3(kBlock),
-                         sizeof(int) * kWavesPerBlock * (size_t)(2 * P.n_batches + 1 + kCscMaxCol), st, X, csc->cptr.as<int64_t>(),
-                         csc->crow.as<int32_t>(), csc->cval.as<double>(), csc->cnz.as<uint32_t>(), rpos.as<int32_t>(), batch,
-                         first_singleton ? 1 : 0, (int)P.n_batches, off.as<int32_t>(), toff.as<int64_t>(), P.tpos.as<int32_t>(),
-                         P.tx.as<double>(), want_tq ? P.tq.as<int64_t>() : nullptr);
+      auto fill = [&](auto ne_tag) {
+        constexpr int NE = decltype(ne_tag)::value;
+        const size_t per_wave = (size_t)((4 * NE * kWave + 2 * P.n_batches + 2) & ~(int64_t)1);
+        const int wpb = NE > 8 ? 2 : kWavesPerBlock;  // at most 48 KB of LDS per workgroup
+        int64_t blocks = (X.d + wpb - 1) / wpb;
+        if (blocks > 256 * 16 * (kWavesPerBlock / wpb)) blocks = 256 * 16 * (kWavesPerBlock / wpb);
+        hipLaunchKernelGGL((k_csc_fill<NE>), dim3((unsigned)blocks), dim3(wpb * kWave), sizeof(int) * wpb * per_wave, st, X,
+                           csc->cptr.as<int64_t>(), csc->crow.as<int32_t>(), csc->cval.as<double>(), csc->cnz.as<uint32_t>(),
+                           rpos.as<int32_t>(), batch, first_singleton ? 1 : 0, (int)P.n_batches, off.as<int32_t>(),
+                           toff.as<int64_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(), want_tq ? P.tq.as<int64_t>() : nullptr);
+      };
+      if (csc->max_col <= 4 * kWave) fill(std::integral_constant<int, 4>{});
+      else if (csc->max_col <= 8 * kWave) fill(std::integral_constant<int, 8>{});
+      else fill(std::integral_constant<int, kCscMaxCol / kWave>{});
       if (U > 0)
         hipLaunchKernelGGL(k_batch_first, dim3(grid1d(U)), dim3(kBlock), 0, st, U, ubatch.as<int64_t>(), bfu.as<int64_t>());
       NFM_HIP_CHECK(hipGetLastError());
@@ -693,21 +772,26 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
   if (U > 0) {
     NFM_CHECK(P.n_batches < ((int64_t)1 << 31), NFM_ERR_UNSUPPORTED, "too many batches");
     DevBuf uk0, uk1, uv0, uv1, utmp;
-    NFM_TRY(uk0.alloc(sizeof(uint64_t) * U)); NFM_TRY(uk1.alloc(sizeof(uint64_t) * U));
+    NFM_TRY(uk0.alloc(sizeof(uint32_t) * U)); NFM_TRY(uk1.alloc(sizeof(uint32_t) * U));
     NFM_TRY(uv0.alloc(sizeof(uint32_t) * U)); NFM_TRY(uv1.alloc(sizeof(uint32_t) * U));
     static const int cnt_bucket = getenv("NFM_CNT_BUCKET") && atoi(getenv("NFM_CNT_BUCKET")) > 0 ? atoi(getenv("NFM_CNT_BUCKET")) : 1;
-    hipLaunchKernelGGL(k_ukeys, dim3(grid1d(U)), dim3(kBlock), 0, st, U, ubatch.as<int64_t>(), P.uptr.as<int64_t>(), cnt_bucket,
-                       uk0.as<uint64_t>(), uv0.as<uint32_t>());
-    hipcub::DoubleBuffer<uint64_t> udk(uk0.as<uint64_t>(), uk1.as<uint64_t>());
+    // (batch, descending touch count) in 32 bits, the count clamped to 8 bits (fewer when there are more than 2^24
+    // batches): two or three radix passes instead of the five to six of a 64-bit (batch << 32 | count) key
+    const int cbits = bbits <= 24 ? 8 : 32 - bbits;
+    hipcub::DoubleBuffer<uint32_t> udk(uk0.as<uint32_t>(), uk1.as<uint32_t>());
     hipcub::DoubleBuffer<uint32_t> udv(uv0.as<uint32_t>(), uv1.as<uint32_t>());
     // Parameter rows shorter than a 128-byte line (k <= 8) keep the feature order: neighbours in the list are
     // neighbours in memory and share their lines, which is worth more than balanced wavefronts (cfg5, k = 8:
     // column phase 59 us in feature order, 64 us by count; cfg2, k = 16: 38 vs 35 us)
-    if (sort_by_count) {
+    if (sort_by_count && cbits >= 1) {
+      hipLaunchKernelGGL(k_ukeys, dim3(grid1d(U)), dim3(kBlock), 0, st, U, ubatch.as<int64_t>(), P.uptr.as<int64_t>(), cnt_bucket, cbits,
+                         uk0.as<uint32_t>(), uv0.as<uint32_t>());
       size_t ub = 0;
-      NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, ub, udk, udv, (int)U, 0, 32 + bbits, st));
+      NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, ub, udk, udv, (int)U, 0, cbits + bbits, st));
       NFM_TRY(utmp.alloc(ub));
-      NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(utmp.p, ub, udk, udv, (int)U, 0, 32 + bbits, st));
+      NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(utmp.p, ub, udk, udv, (int)U, 0, cbits + bbits, st));
+    } else {
+      hipLaunchKernelGGL(k_iota_u32, dim3(grid1d(U)), dim3(kBlock), 0, st, U, uv0.as<uint32_t>());
     }
     hipLaunchKernelGGL(k_usorted, dim3(grid1d(U)), dim3(kBlock), 0, st, U, udv.Current(), P.ucol.as<int32_t>(),
                        P.uptr.as<int64_t>(), P.ucol_s.as<int32_t>(), P.ubeg_s.as<int64_t>(), P.ucnt_s.as<int32_t>());

@@ -10,7 +10,8 @@ for L in "$@"; do
 import json, sys
 j = json.load(open("gpurun_out/ab_tmp.json"))
 r = j["roofline"]
-print("%-24s %-9s B=%-6s %.4g samples/s frac %.4f  %s" % (sys.argv[1], sys.argv[2], sys.argv[3], j["value"], r["frac"],
+print("%-24s %-9s B=%-6s %.4g samples/s frac %.4f shuffled %.4g (%.2fx)  %s" % (sys.argv[1], sys.argv[2], sys.argv[3], j["value"], r["frac"],
+      j.get("value_shuffled") or 0.0, (j.get("value_shuffled") or 0.0) / j["value"],
       {k: round(v * 1e3, 1) for k, v in r["avg_ms"].items() if v}))
 PY
 done
