@@ -959,8 +959,8 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       } else if (!reuse) {
         if (!o->plan) o->plan.reset(new Plan());
         TimedLaunch tl(ctx, "plan_build");
-        NFM_TRY(plan_build(ctx, ds->v, m->n_aug, perm, begin, end, o->batch, first_singleton, want_tq, use_singles, sort_by_count,
-                           o->plan.get(), nullptr, nullptr, perm ? &ds->csc : nullptr));
+        NFM_TRY(plan_build(ctx, ds->v, m->n_aug, perm, begin, end, o->batch, first_singleton, want_tq, use_singles,
+                           sort_by_count, o->plan.get(), nullptr, nullptr, perm ? &ds->csc : nullptr));
         o->plan->ds_uid = ds->uid;
         o->plan->ds_nnz = ds->v.nnz;
         o->next_plan_ready = false;

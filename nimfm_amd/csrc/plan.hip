@@ -155,13 +155,17 @@ __global__ void k_ukeys(int64_t U, const int64_t* __restrict__ ubatch, const int
 }
 __global__ void k_usorted(int64_t U, const uint32_t* __restrict__ vals, const int32_t* __restrict__ ucol,
                           const int64_t* __restrict__ uptr, int32_t* __restrict__ ucol_s, int64_t* __restrict__ ubeg_s,
-                          int32_t* __restrict__ ucnt_s) {
+                          int32_t* __restrict__ ucnt_s, unsigned long long* __restrict__ n_heavy) {
+  unsigned long long heavy = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < U; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t u = vals[i];
+    const uint32_t u = vals ? vals[i] : (uint32_t)i;  // no order given: the features' own order
+    const int64_t c = uptr[u + 1] - uptr[u];
     ucol_s[i] = ucol[u];
     ubeg_s[i] = uptr[u];
-    ucnt_s[i] = (int32_t)(uptr[u + 1] - uptr[u]);
+    ucnt_s[i] = (int32_t)c;
+    heavy += c > kHeavyTouches ? 1 : 0;
   }
+  if (heavy) atomicAdd(n_heavy, heavy);  // most plans have none: the scans behind the heavy lists are skipped then
 }
 
 // first unique feature of every batch that has one
@@ -421,21 +425,22 @@ __global__ __launch_bounds__(kBlock) void k_csc_count(int64_t d, const int64_t* 
   }
 }
 
+// One scan over the (batch, feature) cells gives both prefix sums the plan needs: the touches before a cell (low word)
+// and the non-empty cells -- the batches' unique features -- before it (high word).  Both stay below 2^31.
+struct CellPack {
+  __host__ __device__ __forceinline__ uint64_t operator()(int32_t c) const { return (uint64_t)(uint32_t)c | ((uint64_t)(c > 0 ? 1 : 0) << 32); }
+};
 // the cells that hold touches, in (batch, feature) order: the batch's unique features
-__global__ void k_csc_units(int64_t cells, int64_t d, const int32_t* __restrict__ cnt, const int32_t* __restrict__ off,
-                            const int32_t* __restrict__ uidx, int32_t* __restrict__ ucol, int64_t* __restrict__ uptr,
-                            int64_t* __restrict__ ubatch) {
+__global__ void k_csc_units(int64_t cells, int64_t d, const int32_t* __restrict__ cnt, const uint64_t* __restrict__ ps,
+                            int32_t* __restrict__ ucol, int64_t* __restrict__ uptr, int64_t* __restrict__ ubatch) {
   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (int64_t)gridDim.x * blockDim.x)
     if (cnt[c] > 0) {
-      const int32_t u = uidx[c];
+      const uint64_t v = ps[c];
+      const int32_t u = (int32_t)(v >> 32);
       ucol[u] = (int32_t)(c % d);
-      uptr[u] = off[c];
+      uptr[u] = (int64_t)(uint32_t)v;
       ubatch[u] = c / d;
     }
-}
-__global__ void k_flag_pos(int64_t n, const int32_t* __restrict__ cnt, int32_t* __restrict__ flag) {
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c <= n; c += (int64_t)gridDim.x * blockDim.x)
-    flag[c] = (c < n && cnt[c] > 0) ? 1 : 0;
 }
 
 // one wavefront per feature: the column's touches are bucketed by batch in LDS (histogram -> scan -> slots handed out
@@ -449,7 +454,7 @@ template <int NE>
 __global__ __launch_bounds__(kBlock) void k_csc_fill(CsrView X, const int64_t* __restrict__ cptr, const int32_t* __restrict__ crow,
                                                      const double* __restrict__ cval, const uint32_t* __restrict__ cnz,
                                                      const int32_t* __restrict__ rpos, int64_t batch, int first_singleton,
-                                                     int n_batches, const int32_t* __restrict__ off,
+                                                     int n_batches, const uint64_t* __restrict__ ps,
                                                      const int64_t* __restrict__ toff, int32_t* __restrict__ tpos,
                                                      double* __restrict__ tx, int64_t* __restrict__ tq) {
   // per wavefront: sx[64 NE] doubles | hist[n_batches] | bstart[n_batches + 1] | bpos[64 NE] | sq[64 NE]
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void k_csc_fill(CsrView X, const int64_t* _
       int32_t lo;
       if (first_singleton) lo = b == 0 ? 0 : 1 + (b - 1) * (int32_t)batch32;
       else lo = b * (int32_t)batch32;
-      const int32_t dst = off[(size_t)b * d + j] + (p - bstart[b]);
+      const int32_t dst = (int32_t)(uint32_t)ps[(size_t)b * d + j] + (p - bstart[b]);
       tpos[dst] = rr - lo;
       tx[dst] = sx[p];
       if (tq) {
@@ -636,7 +641,7 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
   use_csc = use_csc && csc->usable;
   if (use_csc) {
     const int64_t cells = P.n_batches * X.d;
-    DevBuf ipos, clash, cnt, off, flag, uidx, rpos;
+    DevBuf ipos, clash, cnt, ps, rpos;
     NFM_TRY(rpos.alloc(sizeof(int32_t) * X.nnz));
     NFM_TRY(ipos.alloc(sizeof(int32_t) * X.n));
     NFM_TRY(clash.alloc(sizeof(unsigned long long)));
@@ -645,9 +650,7 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
     hipLaunchKernelGGL(k_ipos, dim3(grid1d(ns)), dim3(kBlock), 0, st, ns, perm_dev, begin, ipos.as<int32_t>(),
                        clash.as<unsigned long long>());
     NFM_TRY(cnt.alloc(sizeof(int32_t) * (cells + 1)));
-    NFM_TRY(off.alloc(sizeof(int32_t) * (cells + 1)));
-    NFM_TRY(flag.alloc(sizeof(int32_t) * (cells + 1)));
-    NFM_TRY(uidx.alloc(sizeof(int32_t) * (cells + 1)));
+    NFM_TRY(ps.alloc(sizeof(uint64_t) * (cells + 1)));
     NFM_HIP_CHECK(hipMemsetAsync(cnt.as<int32_t>() + cells, 0, sizeof(int32_t), st));
     {
       const int64_t groups = (X.d + kCntGroup - 1) / kCntGroup;
@@ -657,19 +660,18 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
                          csc->cptr.as<int64_t>(), csc->crow.as<int32_t>(), ipos.as<int32_t>(), batch, first_singleton ? 1 : 0,
                          (int)P.n_batches, cnt.as<int32_t>(), rpos.as<int32_t>());
     }
-    hipLaunchKernelGGL(k_flag_pos, dim3(grid1d(cells + 1)), dim3(kBlock), 0, st, cells, cnt.as<int32_t>(), flag.as<int32_t>());
     NFM_HIP_CHECK(hipGetLastError());
+    hipcub::TransformInputIterator<uint64_t, CellPack, const int32_t*> packed(cnt.as<int32_t>(), CellPack());
     tmp_bytes = 0;
-    NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt.as<int32_t>(), off.as<int32_t>(), (int)(cells + 1), st));
+    NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, packed, ps.as<uint64_t>(), (int)(cells + 1), st));
     NFM_TRY(tmp.alloc(tmp_bytes));
-    NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, cnt.as<int32_t>(), off.as<int32_t>(), (int)(cells + 1), st));
-    NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, flag.as<int32_t>(), uidx.as<int32_t>(), (int)(cells + 1), st));
-    int32_t U32 = 0, T32 = 0;
+    NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, packed, ps.as<uint64_t>(), (int)(cells + 1), st));
+    uint64_t h_tot = 0;
     unsigned long long h_clash = 0;
-    NFM_HIP_CHECK(hipMemcpyAsync(&U32, uidx.as<int32_t>() + cells, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    NFM_HIP_CHECK(hipMemcpyAsync(&T32, off.as<int32_t>() + cells, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipMemcpyAsync(&h_tot, ps.as<uint64_t>() + cells, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     NFM_HIP_CHECK(hipMemcpyAsync(&h_clash, clash.p, sizeof(h_clash), hipMemcpyDeviceToHost, st));
     NFM_HIP_CHECK(hipStreamSynchronize(st));
+    const int32_t U32 = (int32_t)(h_tot >> 32), T32 = (int32_t)(uint32_t)h_tot;
     if (h_clash != 0 || (int64_t)T32 != T) {
       use_csc = false;  // the order repeats a sample (an index stream, not a permutation): the general path below
     } else {
@@ -682,8 +684,8 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
       NFM_TRY(P.ucol.alloc(sizeof(int32_t) * U));
       NFM_TRY(P.uptr.alloc(sizeof(int64_t) * (U + 1)));
       NFM_TRY(ubatch.alloc(sizeof(int64_t) * (U + 1)));
-      hipLaunchKernelGGL(k_csc_units, dim3(grid1d(cells)), dim3(kBlock), 0, st, cells, X.d, cnt.as<int32_t>(), off.as<int32_t>(),
-                         uidx.as<int32_t>(), P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), ubatch.as<int64_t>());
+      hipLaunchKernelGGL(k_csc_units, dim3(grid1d(cells)), dim3(kBlock), 0, st, cells, X.d, cnt.as<int32_t>(), ps.as<uint64_t>(),
+                         P.ucol.as<int32_t>(), P.uptr.as<int64_t>(), ubatch.as<int64_t>());
       auto fill = [&](auto ne_tag) {
         constexpr int NE = decltype(ne_tag)::value;
         const size_t per_wave = (size_t)((4 * NE * kWave + 2 * P.n_batches + 2) & ~(int64_t)1);
@@ -692,7 +694,7 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
         if (blocks > 256 * 16 * (kWavesPerBlock / wpb)) blocks = 256 * 16 * (kWavesPerBlock / wpb);
         hipLaunchKernelGGL((k_csc_fill<NE>), dim3((unsigned)blocks), dim3(wpb * kWave), sizeof(int) * wpb * per_wave, st, X,
                            csc->cptr.as<int64_t>(), csc->crow.as<int32_t>(), csc->cval.as<double>(), csc->cnz.as<uint32_t>(),
-                           rpos.as<int32_t>(), batch, first_singleton ? 1 : 0, (int)P.n_batches, off.as<int32_t>(),
+                           rpos.as<int32_t>(), batch, first_singleton ? 1 : 0, (int)P.n_batches, ps.as<uint64_t>(),
                            toff.as<int64_t>(), P.tpos.as<int32_t>(), P.tx.as<double>(), want_tq ? P.tq.as<int64_t>() : nullptr);
       };
       if (csc->max_col <= 4 * kWave) fill(std::integral_constant<int, 4>{});
@@ -769,37 +771,42 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
   NFM_TRY(P.ucol_s.alloc(sizeof(int32_t) * std::max<int64_t>(U, 1)));
   NFM_TRY(P.ubeg_s.alloc(sizeof(int64_t) * std::max<int64_t>(U, 1)));
   NFM_TRY(P.ucnt_s.alloc(sizeof(int32_t) * std::max<int64_t>(U, 1)));
+  DevBuf n_heavy;
+  NFM_TRY(n_heavy.alloc(sizeof(unsigned long long)));
+  NFM_HIP_CHECK(hipMemsetAsync(n_heavy.p, 0, sizeof(unsigned long long), st));
+  DevBuf uk0, uk1, uv0, uv1, utmp;  // alive until the synchronisation below
   if (U > 0) {
     NFM_CHECK(P.n_batches < ((int64_t)1 << 31), NFM_ERR_UNSUPPORTED, "too many batches");
-    DevBuf uk0, uk1, uv0, uv1, utmp;
-    NFM_TRY(uk0.alloc(sizeof(uint32_t) * U)); NFM_TRY(uk1.alloc(sizeof(uint32_t) * U));
-    NFM_TRY(uv0.alloc(sizeof(uint32_t) * U)); NFM_TRY(uv1.alloc(sizeof(uint32_t) * U));
     static const int cnt_bucket = getenv("NFM_CNT_BUCKET") && atoi(getenv("NFM_CNT_BUCKET")) > 0 ? atoi(getenv("NFM_CNT_BUCKET")) : 1;
     // (batch, descending touch count) in 32 bits, the count clamped to 8 bits (fewer when there are more than 2^24
     // batches): two or three radix passes instead of the five to six of a 64-bit (batch << 32 | count) key
     const int cbits = bbits <= 24 ? 8 : 32 - bbits;
-    hipcub::DoubleBuffer<uint32_t> udk(uk0.as<uint32_t>(), uk1.as<uint32_t>());
-    hipcub::DoubleBuffer<uint32_t> udv(uv0.as<uint32_t>(), uv1.as<uint32_t>());
+    const uint32_t* order = nullptr;
     // Parameter rows shorter than a 128-byte line (k <= 8) keep the feature order: neighbours in the list are
     // neighbours in memory and share their lines, which is worth more than balanced wavefronts (cfg5, k = 8:
     // column phase 59 us in feature order, 64 us by count; cfg2, k = 16: 38 vs 35 us)
     if (sort_by_count && cbits >= 1) {
+      NFM_TRY(uk0.alloc(sizeof(uint32_t) * U)); NFM_TRY(uk1.alloc(sizeof(uint32_t) * U));
+      NFM_TRY(uv0.alloc(sizeof(uint32_t) * U)); NFM_TRY(uv1.alloc(sizeof(uint32_t) * U));
+      hipcub::DoubleBuffer<uint32_t> udk(uk0.as<uint32_t>(), uk1.as<uint32_t>());
+      hipcub::DoubleBuffer<uint32_t> udv(uv0.as<uint32_t>(), uv1.as<uint32_t>());
       hipLaunchKernelGGL(k_ukeys, dim3(grid1d(U)), dim3(kBlock), 0, st, U, ubatch.as<int64_t>(), P.uptr.as<int64_t>(), cnt_bucket, cbits,
                          uk0.as<uint32_t>(), uv0.as<uint32_t>());
       size_t ub = 0;
       NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, ub, udk, udv, (int)U, 0, cbits + bbits, st));
       NFM_TRY(utmp.alloc(ub));
       NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(utmp.p, ub, udk, udv, (int)U, 0, cbits + bbits, st));
-    } else {
-      hipLaunchKernelGGL(k_iota_u32, dim3(grid1d(U)), dim3(kBlock), 0, st, U, uv0.as<uint32_t>());
+      order = udv.Current();
     }
-    hipLaunchKernelGGL(k_usorted, dim3(grid1d(U)), dim3(kBlock), 0, st, U, udv.Current(), P.ucol.as<int32_t>(),
-                       P.uptr.as<int64_t>(), P.ucol_s.as<int32_t>(), P.ubeg_s.as<int64_t>(), P.ucnt_s.as<int32_t>());
-    NFM_HIP_CHECK(hipStreamSynchronize(st));  // the sort's temporaries go out of scope
+    hipLaunchKernelGGL(k_usorted, dim3(grid1d(U)), dim3(kBlock), 0, st, U, order, P.ucol.as<int32_t>(),
+                       P.uptr.as<int64_t>(), P.ucol_s.as<int32_t>(), P.ubeg_s.as<int64_t>(), P.ucnt_s.as<int32_t>(),
+                       n_heavy.as<unsigned long long>());
   }
   std::vector<int64_t> first(P.n_batches);
+  unsigned long long h_heavy = 0;
   NFM_HIP_CHECK(hipMemcpyAsync(first.data(), bfu.p, sizeof(int64_t) * P.n_batches, hipMemcpyDeviceToHost, st));
-  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  NFM_HIP_CHECK(hipMemcpyAsync(&h_heavy, n_heavy.p, sizeof(h_heavy), hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));  // also: the sort's temporaries may go
   P.bat_uoff[P.n_batches] = U;
   for (int64_t b = P.n_batches - 1; b >= 0; --b) P.bat_uoff[b] = first[b] != none ? first[b] : P.bat_uoff[b + 1];
   P.max_unique = 0;
@@ -807,7 +814,10 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
   // heavy features: flags -> scans -> compact lists + per-batch offsets
   P.bat_hoff.assign(P.n_batches + 1, 0);
   P.bat_soff.assign(P.n_batches + 1, 0);
-  if (U > 0) {
+  if (U > 0 && h_heavy == 0) {
+    NFM_TRY(P.hv_u.alloc(sizeof(int64_t)));
+    NFM_TRY(P.hv_seg0.alloc(sizeof(int64_t)));
+  } else if (U > 0) {
     DevBuf hflag, nseg, hidx, segoff, uoff_dev, hoff_dev, soff_dev;
     NFM_TRY(hflag.alloc(sizeof(int64_t) * (U + 1))); NFM_TRY(nseg.alloc(sizeof(int64_t) * (U + 1)));
     NFM_TRY(hidx.alloc(sizeof(int64_t) * (U + 1))); NFM_TRY(segoff.alloc(sizeof(int64_t) * (U + 1)));
@@ -852,40 +862,60 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
 }
 
 // ---- a fresh random order of the samples begin .. end-1, drawn on the device (nfm_opt_set_shuffle) ----
-// The reference shuffles `indices` on the host with Nim's global generator once per epoch (optimizer/sgd.nim:297).  Here:
-// key_i = mix(seed, epoch, i), a counter-based hash, and the samples sorted by key -- every permutation equally likely
-// up to key collisions, reproducible from (seed, epoch), no host work and no upload.
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+// The reference shuffles `indices` on the host with Nim's global generator once per epoch (optimizer/sgd.nim:297).  Here
+// the order is a keyed pseudo-random BIJECTION evaluated per position: a balanced Feistel network of kFeistelRounds
+// rounds over 2h bits (2^(2h) >= ns, < 4 ns), its round keys hashed from (seed, epoch), walked along its cycle until the
+// value falls below ns ("cycle walking": a bijection of [0, 2^(2h)) restricted that way is a bijection of [0, ns)).
+// No sort, no key collisions, reproducible from (seed, epoch), no host work and no upload; a radix sort of hashed
+// 64-bit keys, which this replaces, cost a tenth of a cfg2 epoch.
+constexpr int kFeistelRounds = 8;
+struct FeistelKey {
+  uint32_t k[kFeistelRounds];
+  uint32_t mask;
+  int h;
+};
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-__global__ void k_perm_keys(int64_t ns, int64_t begin, uint64_t seed, uint64_t epoch, uint64_t* __restrict__ keys,
-                            int64_t* __restrict__ vals) {
-  const uint64_t base = mix64(seed * 0x9E3779B97F4A7C15ull + epoch + 0x632BE59BD9B4E019ull);
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  return x ^ (x >> 16);
+}
+__device__ __forceinline__ uint64_t feistel(uint64_t x, const FeistelKey& K) {
+  uint32_t L = (uint32_t)(x >> K.h) & K.mask, R = (uint32_t)x & K.mask;
+#pragma unroll
+  for (int r = 0; r < kFeistelRounds; ++r) {
+    const uint32_t t = L ^ (mix32(R ^ K.k[r]) & K.mask);
+    L = R;
+    R = t;
+  }
+  return ((uint64_t)L << K.h) | R;
+}
+__global__ void k_perm_feistel(int64_t ns, int64_t begin, FeistelKey K, int64_t* __restrict__ perm) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (int64_t)gridDim.x * blockDim.x) {
-    keys[i] = mix64(base ^ ((uint64_t)i * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull));
-    vals[i] = begin + i;
+    uint64_t x = (uint64_t)i;
+    do x = feistel(x, K); while (x >= (uint64_t)ns);  // ends: x walks the cycle of i, which returns to i < ns
+    perm[i] = begin + (int64_t)x;
   }
 }
 int gen_permutation(nfm_ctx* ctx, hipStream_t st, int64_t seed, uint64_t epoch, int64_t begin, int64_t ns, DevBuf* out) {
   NFM_CHECK(ns < (int64_t)2147483647, NFM_ERR_UNSUPPORTED, "more than 2^31-1 samples in one shuffled epoch");
   NFM_TRY(out->ensure(sizeof(int64_t) * (size_t)std::max<int64_t>(ns, 1)));
   if (ns == 0) return NFM_OK;
-  DevBuf k0, k1, v0, tmp;
-  NFM_TRY(k0.alloc(sizeof(uint64_t) * ns));
-  NFM_TRY(k1.alloc(sizeof(uint64_t) * ns));
-  NFM_TRY(v0.alloc(sizeof(int64_t) * ns));
-  hipLaunchKernelGGL(k_perm_keys, dim3(grid1d(ns)), dim3(kBlock), 0, st, ns, begin, (uint64_t)seed, epoch, k0.as<uint64_t>(),
-                     v0.as<int64_t>());
+  FeistelKey K;
+  int bits = 1;
+  while (((int64_t)1 << bits) < ns) ++bits;
+  K.h = (bits + 1) / 2;
+  K.mask = (uint32_t)(((uint64_t)1 << K.h) - 1);
+  const uint64_t base = mix64((uint64_t)seed * 0x9E3779B97F4A7C15ull + epoch + 0x632BE59BD9B4E019ull);
+  for (int r = 0; r < kFeistelRounds; ++r) K.k[r] = (uint32_t)(mix64(base ^ ((uint64_t)(r + 1) * 0xD1342543DE82EF95ull)) >> 32);
+  hipLaunchKernelGGL(k_perm_feistel, dim3(grid1d(ns)), dim3(kBlock), 0, st, ns, begin, K, out->as<int64_t>());
   NFM_HIP_CHECK(hipGetLastError());
-  size_t bytes = 0;
-  NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<int64_t>(),
-                                                    out->as<int64_t>(), (int)ns, 0, 64, st));
-  NFM_TRY(tmp.alloc(bytes));
-  NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<int64_t>(),
-                                                    out->as<int64_t>(), (int)ns, 0, 64, st));
-  NFM_HIP_CHECK(hipStreamSynchronize(st));  // the temporaries go out of scope
   return NFM_OK;
 }
 

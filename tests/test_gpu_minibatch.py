@@ -451,6 +451,37 @@ def test_device_shuffle_replays_on_the_oracle(solver):
     assert np.array_equal(opt.last_permutation(n), perms[0])
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 64, 1000, 4097, 65537])
+def test_device_shuffle_is_a_permutation_at_awkward_sizes(n):
+    """the device order is a cycle-walked Feistel bijection over the next even power of two (csrc/plan.hip): it must be a
+    permutation of the range for every n (also 1, 2^k and 2^k + 1), spread positions evenly, and change with the epoch"""
+    d, m, k = 50, 4, 4
+    Xo = random_csr(n, d, m, seed=5)
+    X = to_gpu(Xo)
+    X.set_targets(np.zeros(n))
+    rng = np.random.default_rng(2)
+    fm = gpu_fm("regression", 2, k, "explicit", True, True, rng.standard_normal((1, k, d)) * 0.05, np.zeros(d), 0.0)
+    opt = nf.newSGD(maxIter=1, verbose=0, tol=0, shuffle=True, mode="minibatch", batch=32, deviceShuffle=True)
+    opt._handle(fm, X.ctx, "minibatch")
+    from nimfm_amd import _capi as capi
+    capi.check(capi.lib().nfm_opt_set_shuffle(opt._h, 11))
+    epochs = 24 if n <= 4097 else 3
+    perms = []
+    for e in range(epochs):
+        opt._epoch(X, None, 0, n)
+        opt.it += n
+        perms.append(opt.last_permutation(n))
+        assert np.array_equal(np.sort(perms[-1]), np.arange(n))
+    if n >= 1000:
+        assert not any(np.array_equal(perms[a], perms[b]) for a in range(epochs) for b in range(a))
+        pos = np.stack([np.argsort(p) for p in perms])  # position of every sample in every epoch
+        # the mean position of a sample over the epochs is n/2 +- n/sqrt(12 epochs); 6 sigma over all samples
+        assert np.max(np.abs(pos.mean(0) - (n - 1) / 2)) < 6 * n / np.sqrt(12 * epochs)
+        # neighbours in the data are not neighbours in the order more often than chance (2/n per pair)
+        adj = np.mean([np.mean(np.abs(np.diff(pp)) == 1) for pp in pos])
+        assert adj < 2.0 / n + 0.01
+
+
 def test_announced_permutation_is_only_a_hint():
     """nfm_opt_announce_perm: the plan built beside the current epoch is used only when the next call passes the SAME
     array; another array (or a changed one) is planned afresh -- results never depend on the announcement."""
