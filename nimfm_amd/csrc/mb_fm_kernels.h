@@ -2075,7 +2075,8 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     }();
     static const int col_wg_per_cu = getenv("NFM_COL_WG") ? atoi(getenv("NFM_COL_WG")) : col_occ;
     // the tuning variants TU = 1 / 4 (NFM_TU) are not strided
-    const bool nB_capped = tu == 2 && col_wg_per_cu > 0 && nB > 4 * ctx->n_cu * col_wg_per_cu;
+    static const int cap_sets = getenv("NFM_COL_CAP_SETS") ? atoi(getenv("NFM_COL_CAP_SETS")) : 4;  // tuning
+    const bool nB_capped = tu == 2 && col_wg_per_cu > 0 && nB > cap_sets * ctx->n_cu * col_wg_per_cu;
     if (nB_capped) nB = ctx->n_cu * col_wg_per_cu;
     nB += 1;  // + the closing workgroup
     const int nS = singles_in_col ? (len + kWavesPerBlock - 1) / kWavesPerBlock : 0;

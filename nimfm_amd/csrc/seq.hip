@@ -320,6 +320,505 @@ __global__ void k_sequential(SeqArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pipelined step (FactorizationMachine, degree 2, one order): the arithmetic of k_sequential<.., STAGE = true>, every
+// sum in the same order -- what changes is WHEN things are requested and WHO does the order-independent work.
+//
+// 1. A step of the staged kernel is a chain of dependent round trips (order -> indptr -> entries -> linear weights /
+//    parameter rows -> compute -> stores).  Here, while sample t is computed from LDS, the memory system works on the
+//    samples behind it:
+//        t+4: its id in the order      t+3: row bounds and target      t+2: its entries (registers, to LDS at the step's end)
+//        t+1: its parameter values (AdaGrad: state and last stored parameters) and linear terms -> registers
+//    Sample t+1 may share features with t, whose update lands after those values were requested.  Every thread therefore
+//    leaves what it writes for entry q (new stored value; AdaGrad: new g_sum and g_norm) in the LDS slot of q as well, and
+//    a map "entry of t+1 -> entry of t" (every thread looks one entry up in t's list) says which registers to refresh
+//    from there before t+1 uses them: a sample sees exactly the values of the one-at-a-time order.  A dense rescale
+//    (resetScaling, sgd.nim:116-131) reloads the registers instead.
+// 2. With one wavefront and thread = factor, a step was bound by the ~4500 instructions it ISSUES (32 divisions, three
+//    pow(), address arithmetic per entry), not by memory.  The workgroup is 256 threads = G groups x S factors: every
+//    group runs the per-factor sums over ALL entries (their order is the reference's; the groups agree bit for bit),
+//    but the work that is independent per entry -- requesting rows, the derivative, the update with its division, the
+//    AdaGrad parameter with its square root -- is split over the groups (entry c belongs to group c mod G).
+// 3. Only one barrier per step waits for memory (it stands where nothing but already-issued stores is outstanding); the
+//    others order LDS only: __syncthreads() waits for every outstanding global load and would put the hidden latency
+//    back on the critical path.  Loops read 8 LDS values at a time through clamped (not guarded) indices: a guarded
+//    load is a branch with a wait of its own.
+// ------------------------------------------------------------------------------------------------
+// LDS-only barrier: __syncthreads() also waits for every outstanding global load of the wavefront
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int kPipeThreads = 256;
+
+template <int OPT, int RC>  // RC: entries per thread (RC * G >= entries per sample incl. dummy features)
+__global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int S, int lgS) {
+  extern __shared__ double lds[];
+  const CsrView& X = a.X;
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  constexpr int T = kPipeThreads;
+  constexpr int CH = RC < 8 ? RC : 8;  // values requested together in the per-thread loops
+  constexpr int FH = 8;                // ... in the loops over all entries
+  const int tid = threadIdx.x;
+  const int G = T >> lgS, g = tid >> lgS, s = tid & (S - 1);
+  const int Kp = M.Kp, k = M.k, n_aug = M.n_aug;
+  const bool act = s < Kp;
+  const int mc = a.m_cap;
+  double* red = lds;                                    // [T]
+  double* dA = red + T;                                 // [mc][S] derivative, then what the step wrote for entry q
+  double* Pl = dA + (size_t)mc * S;                     // [mc][S] stored parameter values of the current sample (AdaGrad: then new g_norm)
+  double* vl = Pl + (size_t)mc * S;                     // [3][mc] values of samples t, t+1, t+2 (slot = step mod 3)
+  double* wl = vl + 3 * mc;                             // [mc] stored linear weights of the current sample
+  double* wp = wl + mc;                                 // [mc] written linear weight (AdaGrad: g_sum of the linear term)
+  double* wp2 = wp + mc;                                // [mc] AdaGrad: g_norm of the linear term
+  int64_t* jl = reinterpret_cast<int64_t*>(wp2 + mc);   // [3][mc] indices
+  int* rm = reinterpret_cast<int*>(jl + 3 * mc);        // [mc] entry of t+1 -> entry of t with the same feature, or -1
+  double sP = M.sc[SC_SCALE_P], sw = M.sc[SC_SCALE_W], b = M.sc[SC_INTERCEPT];
+  double gsb = 0.0, gnb = 0.0;
+  if (OPT == OPT_ADAGRAD) {
+    gsb = O.gsc[0];
+    gnb = O.gsc[1];
+  }
+  double loss_acc = 0.0, viol_acc = 0.0;
+  int64_t it = a.it0;
+
+  struct Desc {
+    int64_t q0;
+    int m;
+    double y;
+  };
+  auto sample_at = [&](int64_t pos) -> int64_t { return pos < a.end ? (a.perm ? a.perm[pos] : pos) : 0; };
+  auto load_desc = [&](int64_t pos, int64_t i) {
+    Desc d{0, 0, 0.0};
+    if (pos < a.end) {
+      d.q0 = X.indptr[i];
+      d.m = (int)(X.indptr[i + 1] - d.q0);
+      d.y = dev::target_of(X.y[i], M.task);
+    }
+    return d;
+  };
+  // entries of a sample: thread q holds entry q (m_cap <= T)
+  int64_t je = 0;
+  double ve = 0.0;
+  auto load_entries = [&](const Desc& d, bool live) {
+    je = 0;
+    ve = 0.0;
+    if (live && tid < d.m + n_aug) {
+      je = tid < d.m ? (int64_t)X.indices[d.q0 + tid] : X.d + (tid - d.m);
+      ve = tid < d.m ? X.data[d.q0 + tid] : 1.0;
+    }
+  };
+  auto store_entries = [&](int slot, const Desc& d, bool live) {
+    if (live && tid < d.m + n_aug) {
+      jl[slot * mc + tid] = je;
+      vl[slot * mc + tid] = ve;
+    }
+  };
+  // the row data of a sample, requested one step ahead: this thread's entries are c = u G + g
+  double Pr[RC], Gr[OPT == OPT_ADAGRAD ? RC : 1], Nr[OPT == OPT_ADAGRAD ? RC : 1];
+  double wr = 0.0, gwr = 0.0, nwr = 0.0;
+  auto load_rows = [&](int slot, const Desc& d, bool live) {
+    const int mt = live ? d.m + n_aug : 0;
+    if (act && g < mt) {
+      // straight-line code: entries past the end repeat this thread's first entry
+#pragma unroll
+      for (int ub = 0; ub < RC; ub += CH) {
+        int64_t j_[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int c = (ub + u) * G + g;
+          j_[u] = jl[slot * mc + (c < mt ? c : g)];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const size_t e = M.row(0, j_[u]) * Kp + s;
+          Pr[ub + u] = M.P[e];
+          if constexpr (OPT == OPT_ADAGRAD) {
+            Gr[ub + u] = O.G[e];
+            Nr[ub + u] = O.N[e];
+          }
+        }
+      }
+    }
+    wr = gwr = nwr = 0.0;
+    if (live && tid < d.m) {
+      const int64_t j = jl[slot * mc + tid];
+      wr = M.w[j];
+      if (OPT == OPT_ADAGRAD && M.fit_linear) {
+        gwr = O.Gw[j];
+        nwr = O.Nw[j];
+      }
+    }
+  };
+
+  // ---- prologue: descriptors of the first three samples, entries of the first two, rows of the first ----
+  Desc D0 = load_desc(a.begin, sample_at(a.begin));
+  Desc D1 = load_desc(a.begin + 1, sample_at(a.begin + 1));
+  Desc D2 = load_desc(a.begin + 2, sample_at(a.begin + 2));
+  int64_t i3 = sample_at(a.begin + 3);
+  load_entries(D0, true);
+  store_entries(0, D0, true);
+  load_entries(D1, a.begin + 1 < a.end);
+  store_entries(1, D1, a.begin + 1 < a.end);
+  for (int q = tid; q < mc; q += T) rm[q] = -1;
+  __syncthreads();
+  load_rows(0, D0, true);
+  bool fresh = true;  // the registers hold what memory holds now: nothing to refresh
+
+  for (int64_t pos = a.begin; pos < a.end; ++pos, ++it) {
+    const int s0 = (int)((pos - a.begin) % 3), s1 = (s0 + 1) % 3, s2 = (s0 + 2) % 3;
+    const int m = D0.m, m_tot = m + n_aug;
+    const double y = D0.y;
+    const double itf = (double)it;
+    const int64_t* jc = jl + s0 * mc;
+    const double* vc = vl + s0 * mc;
+    const bool live1 = pos + 1 < a.end, live2 = pos + 2 < a.end;
+    const bool mine = act && g < m_tot;  // this thread has entries of the current sample
+
+    // ---- 1. refresh what the previous step wrote, then the row goes to LDS ----
+    if (!fresh) {
+      if (mine) {
+#pragma unroll
+        for (int ub = 0; ub < RC; ub += CH) {
+          int r_[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int c = (ub + u) * G + g;
+            r_[u] = rm[c < m_tot ? c : g];
+          }
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int c = (ub + u) * G + g;
+            const int r = c < m_tot ? r_[u] : -1;
+            if (r >= 0) {  // rare: a feature shared by consecutive samples
+              if constexpr (OPT == OPT_ADAGRAD) {
+                Gr[ub + u] = dA[(size_t)r * S + s];
+                Nr[ub + u] = Pl[(size_t)r * S + s];
+              } else {
+                Pr[ub + u] = dA[(size_t)r * S + s];
+              }
+            }
+          }
+        }
+      }
+      if (tid < m) {
+        const int r = rm[tid];
+        if (r >= 0) {
+          if (OPT == OPT_ADAGRAD) {
+            wr = wl[r];  // what update() of the previous step stored for this feature
+            gwr = wp[r];
+            nwr = wp2[r];
+          } else {
+            wr = wp[r];
+          }
+        }
+      }
+      lds_barrier();  // every thread is done with the previous step's slots
+    }
+    fresh = false;
+    bool staged = false;
+    if constexpr (OPT == OPT_ADAGRAD) if (it != 1) {
+      staged = true;
+      // update(): optimizer/adagrad.nim:87-110, fit_linear.nim:50-57
+      const double itp = (double)(it - 1);
+      const double tmp = O.eta0 * itp * O.beta;
+      if (mine) {
+        // branch-free: the square root / division chains of several entries interleave; entries past the end repeat this
+        // thread's first entry -- the same value stored again, nothing added to viol
+#pragma unroll
+        for (int ub = 0; ub < RC; ub += CH) {
+          int64_t j_[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int c = (ub + u) * G + g;
+            j_[u] = jc[c < m_tot ? c : g];
+          }
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int c = (ub + u) * G + g;
+            const bool ok = c < m_tot;
+            const size_t e = M.row(0, j_[u]) * Kp + s;
+            const double nw = dev::adagrad_param(ok ? Gr[ub + u] : Gr[0], ok ? Nr[ub + u] : Nr[0], O.eta0, tmp);
+            const double dv = fabs((ok ? Pr[ub + u] : Pr[0]) - nw);
+            viol_acc = ok ? viol_acc + dv : viol_acc;
+            M.P[e] = nw;
+            Pl[(size_t)(ok ? c : g) * S + s] = nw;
+          }
+        }
+      }
+      if (M.fit_intercept) {
+        const double old = b;
+        const double denom = sqrt(gnb) + O.eta0 * itp * O.alpha0;
+        b = -O.eta0 * gsb / denom;
+        if (tid == 0) viol_acc += fabs(old - b);
+      }
+      if (tid < m) {
+        double nw = wr;
+        if (M.fit_linear) {
+          const double denom = itp * O.eta0 * O.alpha;
+          nw = -O.eta0 * gwr / (denom + sqrt(nwr));
+          M.w[jc[tid]] = nw;
+          viol_acc += fabs(wr - nw);
+        }
+        wl[tid] = nw;
+      }
+    }
+    if (!staged) {
+      if (mine) {
+#pragma unroll
+        for (int u = 0; u < RC; ++u) {
+          const int c = u * G + g;
+          Pl[(size_t)(c < m_tot ? c : g) * S + s] = c < m_tot ? Pr[u] : Pr[0];
+        }
+      }
+      if (tid < m) wl[tid] = wr;
+    }
+    // The ONE full barrier of a step (it also waits for this workgroup's outstanding memory operations): it stands where
+    // nothing but already-issued stores is outstanding.
+    __syncthreads();
+
+    // ---- 2. requests for the samples behind this one (after update()'s stores: a shared row is read as rewritten) ----
+    load_rows(s1, D1, live1);
+    load_entries(D2, live2);
+    const Desc D3 = load_desc(pos + 3, i3);
+    const int64_t i4 = sample_at(pos + 4);
+    // ---- 3. entry of the next sample -> entry of this one ----
+    {
+      const int mt1 = live1 ? D1.m + n_aug : 0;
+      const int64_t* jn = jl + s1 * mc;
+      if (tid < mt1) {
+        const int64_t j = jn[tid];
+        int r = -1;
+        for (int qb = 0; qb < m_tot; qb += FH) {
+          int64_t jj[FH];
+#pragma unroll
+          for (int u = 0; u < FH; ++u) jj[u] = jc[qb + u < m_tot ? qb + u : qb];
+#pragma unroll
+          for (int u = 0; u < FH; ++u) r = (qb + u < m_tot && jj[u] == j) ? qb + u : r;
+        }
+        rm[tid] = r;
+      }
+    }
+
+    // ---- 4. predictWithGrad (optimizer/sgd.nim:191-202): every group runs the sums over all entries ----
+    double yh = b;
+    for (int qb = 0; qb < m; qb += FH) {
+      double w_[FH], v_[FH];
+#pragma unroll
+      for (int u = 0; u < FH; ++u) {
+        w_[u] = wl[qb + u < m ? qb + u : qb];
+        v_[u] = vc[qb + u < m ? qb + u : qb];
+      }
+#pragma unroll
+      for (int u = 0; u < FH; ++u) yh = qb + u < m ? yh + (sw * w_[u]) * v_[u] : yh;
+    }
+    double a1 = 0.0, a2 = 0.0, kv = 0.0;
+    if (act) {
+      for (int qb = 0; qb < m_tot; qb += FH) {
+        double p_[FH], v_[FH];
+#pragma unroll
+        for (int u = 0; u < FH; ++u) {
+          v_[u] = vc[qb + u < m_tot ? qb + u : qb];
+          p_[u] = Pl[(size_t)(qb + u < m_tot ? qb + u : qb) * S + s];
+        }
+#pragma unroll
+        for (int u = 0; u < FH; ++u) {
+          const double p = sP * p_[u];
+          const bool ok = qb + u < m_tot;
+          a1 = ok ? a1 + v_[u] * p : a1;
+          a2 = ok ? a2 + (v_[u] * p) * (v_[u] * p) : a2;
+        }
+      }
+      kv = (a1 * a1 - a2) / 2;
+    }
+    if (mine) {  // computeAnovaDerivative (sgd.nim:176-188) of this thread's entries
+#pragma unroll
+      for (int u = 0; u < RC; ++u) {
+        const int c = u * G + g, cc = c < m_tot ? c : g;
+        const double val = vc[cc];
+        const double p = sP * Pl[(size_t)cc * S + s];
+        dA[(size_t)cc * S + s] = val * (a1 - p * val);
+      }
+    }
+    if (g == 0) red[s] = (act && s < k) ? kv : 0.0;
+    lds_barrier();
+    double tot = 0.0;
+    for (int sb = 0; sb < k; sb += FH) {  // sgd.nim:172-173, ascending s
+      double r_[FH];
+#pragma unroll
+      for (int u = 0; u < FH; ++u) r_[u] = red[sb + u < k ? sb + u : sb];
+#pragma unroll
+      for (int u = 0; u < FH; ++u) tot = sb + u < k ? tot + r_[u] : tot;
+    }
+    yh += tot;
+    lds_barrier();
+    if (tid == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
+    const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
+
+    // ---- 5. update; what is written for entry q is also left in q's LDS slot ----
+    if (OPT == OPT_SGD) {
+      const double eta_w = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, itf);
+      const double eta_P = dev::get_eta(O.sched, O.eta0, O.power, O.beta, itf);
+      const double sPn = sP * (1 - eta_P * O.beta);
+      if (mine) {
+#pragma unroll
+        for (int ub = 0; ub < RC; ub += CH) {
+          double p_[CH], d_[CH];
+          int64_t j_[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int c = (ub + u) * G + g, cc = c < m_tot ? c : g;
+            j_[u] = jc[cc];
+            p_[u] = Pl[(size_t)cc * S + s];
+            d_[u] = dA[(size_t)cc * S + s];
+          }
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {  // branch-free: the division chains interleave
+            const int c = (ub + u) * G + g;
+            const bool ok = c < m_tot;
+            const size_t e = M.row(0, j_[u]) * Kp + s;
+            const double p = sP * p_[u];
+            const double update = eta_P * (dL * d_[u] + O.beta * p);
+            viol_acc = ok ? viol_acc + fabs(update) : viol_acc;
+            const double nv = (p - update) / sPn;
+            M.P[e] = nv;
+            dA[(size_t)(ok ? c : g) * S + s] = nv;
+          }
+        }
+      }
+      sP = sPn;
+      if (M.fit_intercept) {
+        const double update = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf) * (dL + O.alpha0 * b);
+        if (tid == 0) viol_acc += fabs(update);
+        b -= update;
+      }
+      if (M.fit_linear) {
+        const double swn = sw * (1 - eta_w * O.alpha);
+        if (tid < m) {
+          const double wj = sw * wl[tid];
+          const double update = eta_w * (dL * vc[tid] + O.alpha * wj);
+          viol_acc += fabs(update);
+          const double nv = (wj - update) / swn;
+          M.w[jc[tid]] = nv;
+          wp[tid] = nv;
+        }
+        sw = swn;
+      } else if (tid < m) {
+        wp[tid] = wl[tid];
+      }
+      // resetScaling: sgd.nim:116-131 (rare; the requested rows are simply read again afterwards)
+      bool reset = false;
+      if (sP < 1e-9) {
+        __syncthreads();
+        if (act)
+          for (int64_t r = g; r < M.da; r += G) M.P[(size_t)r * Kp + s] *= sP;
+        sP = 1.0;
+        reset = true;
+      }
+      if (M.fit_linear && sw < 1e-9) {
+        __syncthreads();
+        for (int64_t j = tid; j < M.d; j += T) M.w[j] *= sw;
+        sw = 1.0;
+        reset = true;
+      }
+      if (reset) {
+        __syncthreads();
+        load_rows(s1, D1, live1);
+        fresh = true;
+      }
+    } else {
+      // updateG(): optimizer/adagrad.nim:113-134
+      if (mine) {
+#pragma unroll
+        for (int ub = 0; ub < RC; ub += CH) {
+          double d_[CH], g_[CH], n_[CH];
+          size_t e_[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int c = (ub + u) * G + g, cc = c < m_tot ? c : g;
+            e_[u] = M.row(0, jc[cc]) * Kp + s;
+            d_[u] = dA[(size_t)cc * S + s];
+          }
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {  // the state rows of CH entries requested together
+            g_[u] = O.G[e_[u]];
+            n_[u] = O.N[e_[u]];
+          }
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int c = (ub + u) * G + g, cc = c < m_tot ? c : g;
+            const double grad = dL * d_[u];
+            const double gn = g_[u] + grad, nn = n_[u] + grad * grad;
+            O.G[e_[u]] = gn;
+            O.N[e_[u]] = nn;
+            dA[(size_t)cc * S + s] = gn;
+            Pl[(size_t)cc * S + s] = nn;
+          }
+        }
+      }
+      if (M.fit_intercept) {
+        gsb += dL;
+        gnb += dL * dL;
+      }
+      if (tid < m && M.fit_linear) {
+        const int64_t j = jc[tid];
+        const double gg = dL * vc[tid];
+        const double gn = O.Gw[j] + gg, nn = O.Nw[j] + gg * gg;
+        O.Gw[j] = gn;
+        O.Nw[j] = nn;
+        wp[tid] = gn;
+        wp2[tid] = nn;
+      }
+    }
+    // ---- 6. the entries of t+2 go to their slot; the pipeline advances ----
+    store_entries(s2, D2, live2);
+    D0 = D1;
+    D1 = D2;
+    D2 = D3;
+    i3 = i4;
+    lds_barrier();
+  }
+
+  if (tid == 0) {
+    M.sc[SC_SCALE_P] = sP;
+    M.sc[SC_SCALE_W] = sw;
+    M.sc[SC_INTERCEPT] = b;
+    if (OPT == OPT_ADAGRAD) {
+      O.gsc[0] = gsb;
+      O.gsc[1] = gnb;
+    }
+  }
+  __syncthreads();
+  red[tid] = viol_acc;
+  __syncthreads();
+  if (tid == 0) {
+    double v = 0.0;
+    for (int t = 0; t < T; ++t) v += red[t];
+    a.out[0] = loss_acc;
+    a.out[1] = v;
+  }
+}
+
+template <int OPT, int RC>
+static int launch_seq_pipe_t(nfm_ctx* ctx, const SeqArgs& a, int S, int lgS, size_t lds_bytes) {
+  auto kern = k_sequential_pipe<OPT, RC>;
+  if (lds_bytes > 64 * 1024)
+    NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  TimedLaunch tl(ctx, "sequential");
+  hipLaunchKernelGGL(kern, dim3(1), dim3(kPipeThreads), lds_bytes, ctx->stream, a, S, lgS);
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+template <int OPT>
+static int launch_seq_pipe(nfm_ctx* ctx, const SeqArgs& a, int S, int lgS, int rc, size_t lds_bytes) {
+  if (rc <= 1) return launch_seq_pipe_t<OPT, 1>(ctx, a, S, lgS, lds_bytes);
+  if (rc <= 2) return launch_seq_pipe_t<OPT, 2>(ctx, a, S, lgS, lds_bytes);
+  if (rc <= 4) return launch_seq_pipe_t<OPT, 4>(ctx, a, S, lgS, lds_bytes);
+  if (rc <= 8) return launch_seq_pipe_t<OPT, 8>(ctx, a, S, lgS, lds_bytes);
+  if (rc <= 16) return launch_seq_pipe_t<OPT, 16>(ctx, a, S, lgS, lds_bytes);
+  if (rc <= 32) return launch_seq_pipe_t<OPT, 32>(ctx, a, S, lgS, lds_bytes);
+  return launch_seq_pipe_t<OPT, 64>(ctx, a, S, lgS, lds_bytes);
+}
+
 template <int KIND, int OPT, bool STAGE>
 static int launch_seq_t(nfm_ctx* ctx, const SeqArgs& a, int T, size_t lds_bytes) {
   auto kern = k_sequential<KIND, OPT, STAGE>;
@@ -348,6 +847,20 @@ int launch_sequential(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelV
     const size_t n_da = (size_t)(M.nb > 0 ? M.nb : 1) * m_cap * T;
     const size_t staged_bytes = lds_bytes + sizeof(double) * (n_da + 3 * (size_t)m_cap);
     static const bool stage_on = !(getenv("NFM_SEQ_STAGE") && atoi(getenv("NFM_SEQ_STAGE")) == 0);
+    // the pipelined step: degree 2 (one order), at most 256 factors and 256 entries per row, at most 64 entries per
+    // thread; NFM_SEQ_PIPE=0 switches it off
+    static const bool pipe_on = !(getenv("NFM_SEQ_PIPE") && atoi(getenv("NFM_SEQ_PIPE")) == 0);
+    int S = 2, lgS = 1;
+    while (S < M.Kp) { S <<= 1; ++lgS; }
+    const int G = S <= kPipeThreads ? kPipeThreads / S : 0;
+    const int rc = G > 0 ? (m_cap + G - 1) / G : 1 << 30;
+    const size_t pipe_bytes = sizeof(double) * ((size_t)kPipeThreads + 2 * (size_t)m_cap * S + 6 * (size_t)m_cap) +
+                              sizeof(int64_t) * 3 * (size_t)m_cap + sizeof(int) * (size_t)m_cap;
+    if (stage_on && pipe_on && M.nb == 1 && M.degree == 2 && G >= 1 && m_cap <= kPipeThreads && rc <= 64 && pipe_bytes <= 160 * 1024) {
+      SeqArgs ap = a;
+      if (opt_kind == OPT_SGD) return launch_seq_pipe<OPT_SGD>(ctx, ap, S, lgS, rc, pipe_bytes);
+      return launch_seq_pipe<OPT_ADAGRAD>(ctx, ap, S, lgS, rc, pipe_bytes);
+    }
     if (stage_on && M.nb > 0 && staged_bytes <= 160 * 1024) {
       if (opt_kind == OPT_SGD) return launch_seq_t<NFM_KIND_FM, OPT_SGD, true>(ctx, a, T, staged_bytes);
       return launch_seq_t<NFM_KIND_FM, OPT_ADAGRAD, true>(ctx, a, T, staged_bytes);
