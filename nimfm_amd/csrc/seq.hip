@@ -349,29 +349,36 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 constexpr int kPipeThreads = 256;
 
-template <int OPT, int RC>  // RC: entries per thread (RC * G >= entries per sample incl. dummy features)
+// KIND = FactorizationMachine (degree 2, one order): a sample's rows are its entries.  KIND = FieldAwareFactorizationMachine:
+// the reference's step reads and updates ALL nFields rows of every feature of the sample (sgd_ffm.nim:11-30 and the shared
+// update loops): the rows are "slots" c = field * m + q.  A slot belongs to group c mod G like an FM entry.
+template <int KIND, int OPT, int RC>  // RC: slots per thread (RC * G >= rows per sample)
 __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int S, int lgS) {
   extern __shared__ double lds[];
   const CsrView& X = a.X;
   const ModelView& M = a.M;
   const OptView& O = a.O;
   constexpr int T = kPipeThreads;
+  constexpr bool FFM = KIND == NFM_KIND_FFM;
   constexpr int CH = RC < 8 ? RC : 8;  // values requested together in the per-thread loops
   constexpr int FH = 8;                // ... in the loops over all entries
   const int tid = threadIdx.x;
   const int G = T >> lgS, g = tid >> lgS, s = tid & (S - 1);
-  const int Kp = M.Kp, k = M.k, n_aug = M.n_aug;
+  const int Kp = M.Kp, k = M.k, n_aug = FFM ? 0 : M.n_aug, nbk = FFM ? M.nb : 1;
   const bool act = s < Kp;
   const int mc = a.m_cap;
   double* red = lds;                                    // [T]
-  double* dA = red + T;                                 // [mc][S] derivative, then what the step wrote for entry q
-  double* Pl = dA + (size_t)mc * S;                     // [mc][S] stored parameter values of the current sample (AdaGrad: then new g_norm)
-  double* vl = Pl + (size_t)mc * S;                     // [3][mc] values of samples t, t+1, t+2 (slot = step mod 3)
+  double* dA = red + T;                                 // [nbk mc][S] derivative, then what the step wrote for the slot
+  double* Pl = dA + (size_t)nbk * mc * S;               // [nbk mc][S] stored parameter values of the current sample (AdaGrad: then new g_norm)
+  double* vl = Pl + (size_t)nbk * mc * S;               // [3][mc] values of samples t, t+1, t+2 (buffer = step mod 3)
   double* wl = vl + 3 * mc;                             // [mc] stored linear weights of the current sample
   double* wp = wl + mc;                                 // [mc] written linear weight (AdaGrad: g_sum of the linear term)
   double* wp2 = wp + mc;                                // [mc] AdaGrad: g_norm of the linear term
   int64_t* jl = reinterpret_cast<int64_t*>(wp2 + mc);   // [3][mc] indices
   int* rm = reinterpret_cast<int*>(jl + 3 * mc);        // [mc] entry of t+1 -> entry of t with the same feature, or -1
+  int* fl = rm + mc;                                    // FFM: [3][mc] fields
+  int* fcnt = fl + 3 * mc;                              // FFM: [nbk] entries of the current sample per field
+  int* fent = fcnt + nbk;                               // FFM: [nbk][mc] ... which ones, ascending
   double sP = M.sc[SC_SCALE_P], sw = M.sc[SC_SCALE_W], b = M.sc[SC_INTERCEPT];
   double gsb = 0.0, gnb = 0.0;
   if (OPT == OPT_ADAGRAD) {
@@ -399,38 +406,49 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
   // entries of a sample: thread q holds entry q (m_cap <= T)
   int64_t je = 0;
   double ve = 0.0;
+  int fe = 0;
   auto load_entries = [&](const Desc& d, bool live) {
     je = 0;
     ve = 0.0;
+    fe = 0;
     if (live && tid < d.m + n_aug) {
       je = tid < d.m ? (int64_t)X.indices[d.q0 + tid] : X.d + (tid - d.m);
       ve = tid < d.m ? X.data[d.q0 + tid] : 1.0;
+      if (FFM) fe = X.fields[d.q0 + tid];
     }
   };
-  auto store_entries = [&](int slot, const Desc& d, bool live) {
+  auto store_entries = [&](int buf, const Desc& d, bool live) {
     if (live && tid < d.m + n_aug) {
-      jl[slot * mc + tid] = je;
-      vl[slot * mc + tid] = ve;
+      jl[buf * mc + tid] = je;
+      vl[buf * mc + tid] = ve;
+      if (FFM) fl[buf * mc + tid] = fe;
     }
   };
-  // the row data of a sample, requested one step ahead: this thread's entries are c = u G + g
+  // the row data of a sample, requested one step ahead: this thread's slots are c = u G + g, c = blk * m_tot + q;
+  // (blk << 16 | q) of every slot is kept in a register (ns: of the sample being requested, cs: of the current one)
   double Pr[RC], Gr[OPT == OPT_ADAGRAD ? RC : 1], Nr[OPT == OPT_ADAGRAD ? RC : 1];
+  int cs[RC], ns[RC];
   double wr = 0.0, gwr = 0.0, nwr = 0.0;
-  auto load_rows = [&](int slot, const Desc& d, bool live) {
+  auto load_rows = [&](int buf, const Desc& d, bool live) {
     const int mt = live ? d.m + n_aug : 0;
-    if (act && g < mt) {
-      // straight-line code: entries past the end repeat this thread's first entry
+    const int nsl = nbk * mt;
+    if (act && g < nsl) {
+      // straight-line code: slots past the end repeat the first slot of their group of CH (past the end itself: the
+      // thread's first slot).  Repeating work is harmless as long as a repeat reads what the original read: all reads of
+      // a group of CH come before its writes, and the update loops leave at the first group that starts past the end.
 #pragma unroll
       for (int ub = 0; ub < RC; ub += CH) {
         int64_t j_[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-          const int c = (ub + u) * G + g;
-          j_[u] = jl[slot * mc + (c < mt ? c : g)];
+          const int c0 = (ub + u) * G + g, cf = ub * G + g, c = c0 < nsl ? c0 : (cf < nsl ? cf : g);
+          const int blk = FFM ? c / mt : 0, q = FFM ? c - blk * mt : c;
+          ns[ub + u] = (blk << 16) | q;
+          j_[u] = jl[buf * mc + q];
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-          const size_t e = M.row(0, j_[u]) * Kp + s;
+          const size_t e = M.row(ns[ub + u] >> 16, j_[u]) * Kp + s;
           Pr[ub + u] = M.P[e];
           if constexpr (OPT == OPT_ADAGRAD) {
             Gr[ub + u] = O.G[e];
@@ -441,7 +459,7 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
     }
     wr = gwr = nwr = 0.0;
     if (live && tid < d.m) {
-      const int64_t j = jl[slot * mc + tid];
+      const int64_t j = jl[buf * mc + tid];
       wr = M.w[j];
       if (OPT == OPT_ADAGRAD && M.fit_linear) {
         gwr = O.Gw[j];
@@ -463,38 +481,48 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
   __syncthreads();
   load_rows(0, D0, true);
   bool fresh = true;  // the registers hold what memory holds now: nothing to refresh
+  int m_prev = 0;     // entries (incl. dummies) of the previous sample: its slot (blk, r) is blk * m_prev + r
 
   for (int64_t pos = a.begin; pos < a.end; ++pos, ++it) {
     const int s0 = (int)((pos - a.begin) % 3), s1 = (s0 + 1) % 3, s2 = (s0 + 2) % 3;
-    const int m = D0.m, m_tot = m + n_aug;
+    const int m = D0.m, m_tot = m + n_aug, n_slots = nbk * m_tot;
     const double y = D0.y;
     const double itf = (double)it;
     const int64_t* jc = jl + s0 * mc;
     const double* vc = vl + s0 * mc;
+    const int* fc = fl + s0 * mc;
     const bool live1 = pos + 1 < a.end, live2 = pos + 2 < a.end;
-    const bool mine = act && g < m_tot;  // this thread has entries of the current sample
+    const bool mine = act && g < n_slots;  // this thread has rows of the current sample
+#pragma unroll
+    for (int u = 0; u < RC; ++u) cs[u] = ns[u];
+    // the slot of register u (past the end: this thread's first slot, whose work is then simply done again)
+    auto slot_of = [&](int u) {
+      const int c = u * G + g, cf = (u / CH * CH) * G + g;
+      return c < n_slots ? c : (cf < n_slots ? cf : g);
+    };
+    auto reg_of = [&](int u) {  // the register that holds slot_of(u)'s values
+      const int c = u * G + g, cf = (u / CH * CH) * G + g;
+      return c < n_slots ? u : (cf < n_slots ? u / CH * CH : 0);
+    };
 
-    // ---- 1. refresh what the previous step wrote, then the row goes to LDS ----
+    // ---- 1. refresh what the previous step wrote, then the rows go to LDS ----
     if (!fresh) {
       if (mine) {
 #pragma unroll
         for (int ub = 0; ub < RC; ub += CH) {
           int r_[CH];
 #pragma unroll
-          for (int u = 0; u < CH; ++u) {
-            const int c = (ub + u) * G + g;
-            r_[u] = rm[c < m_tot ? c : g];
-          }
+          for (int u = 0; u < CH; ++u) r_[u] = rm[cs[ub + u] & 0xFFFF];
 #pragma unroll
           for (int u = 0; u < CH; ++u) {
-            const int c = (ub + u) * G + g;
-            const int r = c < m_tot ? r_[u] : -1;
+            const int r = (ub + u) * G + g < n_slots ? r_[u] : -1;
             if (r >= 0) {  // rare: a feature shared by consecutive samples
+              const size_t src = ((size_t)(cs[ub + u] >> 16) * m_prev + r) * S + s;
               if constexpr (OPT == OPT_ADAGRAD) {
-                Gr[ub + u] = dA[(size_t)r * S + s];
-                Nr[ub + u] = Pl[(size_t)r * S + s];
+                Gr[ub + u] = dA[src];
+                Nr[ub + u] = Pl[src];
               } else {
-                Pr[ub + u] = dA[(size_t)r * S + s];
+                Pr[ub + u] = dA[src];
               }
             }
           }
@@ -522,26 +550,24 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
       const double itp = (double)(it - 1);
       const double tmp = O.eta0 * itp * O.beta;
       if (mine) {
-        // branch-free: the square root / division chains of several entries interleave; entries past the end repeat this
-        // thread's first entry -- the same value stored again, nothing added to viol
+        // branch-free: the square root / division chains of several rows interleave; slots past the end repeat this
+        // thread's first slot -- the same value stored again, nothing added to viol
 #pragma unroll
         for (int ub = 0; ub < RC; ub += CH) {
           int64_t j_[CH];
 #pragma unroll
-          for (int u = 0; u < CH; ++u) {
-            const int c = (ub + u) * G + g;
-            j_[u] = jc[c < m_tot ? c : g];
-          }
+          for (int u = 0; u < CH; ++u) j_[u] = jc[cs[ub + u] & 0xFFFF];
 #pragma unroll
           for (int u = 0; u < CH; ++u) {
-            const int c = (ub + u) * G + g;
-            const bool ok = c < m_tot;
-            const size_t e = M.row(0, j_[u]) * Kp + s;
-            const double nw = dev::adagrad_param(ok ? Gr[ub + u] : Gr[0], ok ? Nr[ub + u] : Nr[0], O.eta0, tmp);
-            const double dv = fabs((ok ? Pr[ub + u] : Pr[0]) - nw);
+            const bool ok = (ub + u) * G + g < n_slots;
+            const size_t e = M.row(cs[ub + u] >> 16, j_[u]) * Kp + s;
+            const int ru = reg_of(ub + u) == ub + u ? ub + u : (reg_of(ub + u) == ub ? ub : 0);  // static candidates only
+            const double nw = dev::adagrad_param(ru == ub + u ? Gr[ub + u] : (ru == ub ? Gr[ub] : Gr[0]),
+                                                 ru == ub + u ? Nr[ub + u] : (ru == ub ? Nr[ub] : Nr[0]), O.eta0, tmp);
+            const double dv = fabs((ru == ub + u ? Pr[ub + u] : (ru == ub ? Pr[ub] : Pr[0])) - nw);
             viol_acc = ok ? viol_acc + dv : viol_acc;
             M.P[e] = nw;
-            Pl[(size_t)(ok ? c : g) * S + s] = nw;
+            Pl[(size_t)slot_of(ub + u) * S + s] = nw;
           }
         }
       }
@@ -566,15 +592,35 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
       if (mine) {
 #pragma unroll
         for (int u = 0; u < RC; ++u) {
-          const int c = u * G + g;
-          Pl[(size_t)(c < m_tot ? c : g) * S + s] = c < m_tot ? Pr[u] : Pr[0];
+          const int ru = reg_of(u);
+          Pl[(size_t)slot_of(u) * S + s] = ru == u ? Pr[u] : (ru == u / CH * CH ? Pr[u / CH * CH] : Pr[0]);
         }
       }
       if (tid < m) wl[tid] = wr;
     }
+    if (FFM) {  // the current sample's entries by field, ascending (sgd_ffm.nim:24-30 walks a field's entries in this order)
+      for (int f = tid; f < nbk; f += T) fcnt[f] = 0;
+    }
     // The ONE full barrier of a step (it also waits for this workgroup's outstanding memory operations): it stands where
     // nothing but already-issued stores is outstanding.
     __syncthreads();
+    if (FFM && tid < m) {
+      const int f = fc[tid];
+      int before = 0, total = 0;
+      for (int qb = 0; qb < m; qb += FH) {
+        int f_[FH];
+#pragma unroll
+        for (int u = 0; u < FH; ++u) f_[u] = fc[qb + u < m ? qb + u : qb];
+#pragma unroll
+        for (int u = 0; u < FH; ++u) {
+          const bool same = qb + u < m && f_[u] == f;
+          total += same ? 1 : 0;
+          before += (same && qb + u < tid) ? 1 : 0;
+        }
+      }
+      fent[f * mc + before] = tid;
+      if (before == total - 1) fcnt[f] = total;
+    }
 
     // ---- 2. requests for the samples behind this one (after update()'s stores: a shared row is read as rewritten) ----
     load_rows(s1, D1, live1);
@@ -599,7 +645,7 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
       }
     }
 
-    // ---- 4. predictWithGrad (optimizer/sgd.nim:191-202): every group runs the sums over all entries ----
+    // ---- 4. predictWithGrad (optimizer/sgd.nim:191-202, sgd_ffm.nim:11-30) ----
     double yh = b;
     for (int qb = 0; qb < m; qb += FH) {
       double w_[FH], v_[FH];
@@ -611,32 +657,101 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
 #pragma unroll
       for (int u = 0; u < FH; ++u) yh = qb + u < m ? yh + (sw * w_[u]) * v_[u] : yh;
     }
-    double a1 = 0.0, a2 = 0.0, kv = 0.0;
-    if (act) {
-      for (int qb = 0; qb < m_tot; qb += FH) {
-        double p_[FH], v_[FH];
+    double kv = 0.0;
+    if constexpr (!FFM) {
+      // every group runs the per-factor sums over all entries; the derivative of a thread's own entries follows
+      double a1 = 0.0, a2 = 0.0;
+      if (act) {
+        for (int qb = 0; qb < m_tot; qb += FH) {
+          double p_[FH], v_[FH];
 #pragma unroll
-        for (int u = 0; u < FH; ++u) {
-          v_[u] = vc[qb + u < m_tot ? qb + u : qb];
-          p_[u] = Pl[(size_t)(qb + u < m_tot ? qb + u : qb) * S + s];
+          for (int u = 0; u < FH; ++u) {
+            v_[u] = vc[qb + u < m_tot ? qb + u : qb];
+            p_[u] = Pl[(size_t)(qb + u < m_tot ? qb + u : qb) * S + s];
+          }
+#pragma unroll
+          for (int u = 0; u < FH; ++u) {
+            const double p = sP * p_[u];
+            const bool ok = qb + u < m_tot;
+            a1 = ok ? a1 + v_[u] * p : a1;
+            a2 = ok ? a2 + (v_[u] * p) * (v_[u] * p) : a2;
+          }
         }
+        kv = (a1 * a1 - a2) / 2;
+      }
+      if (mine) {  // computeAnovaDerivative (sgd.nim:176-188) of this thread's entries
 #pragma unroll
-        for (int u = 0; u < FH; ++u) {
-          const double p = sP * p_[u];
-          const bool ok = qb + u < m_tot;
-          a1 = ok ? a1 + v_[u] * p : a1;
-          a2 = ok ? a2 + (v_[u] * p) * (v_[u] * p) : a2;
+        for (int u = 0; u < RC; ++u) {
+          const int cc = slot_of(u);
+          const double val = vc[cc];
+          const double p = sP * Pl[(size_t)cc * S + s];
+          dA[(size_t)cc * S + s] = val * (a1 - p * val);
         }
       }
-      kv = (a1 * a1 - a2) / 2;
-    }
-    if (mine) {  // computeAnovaDerivative (sgd.nim:176-188) of this thread's entries
+    } else {
+      lds_barrier();  // the field lists
+      // sgd_ffm.nim:18-30 visits the pairs (q1, q2), j_q1 < j_q2, q1 outer / q2 inner, and adds
+      //   part                 += (P[f2][j1] P[f1][j2]) x1 x2
+      //   dA[f2][q1]           += x1 x2 P[f1][j2]          dA[f1][q2] += x1 x2 P[f2][j1]
+      // A slot (f, q) therefore collects, over the entries q' of field f, x_q x_q' P[field(q)][j_q'] in the order
+      //   q' < q with j_q' < j_q   (visited as (q', q));   then all q' with j_q' > j_q   (visited as (q, q'));
+      //   then q' > q with j_q' < j_q   (visited as (q', q))
+      // -- the same additions in the same order, one slot at a time, so the slots can be split over the groups.
+      if (mine) {
 #pragma unroll
-      for (int u = 0; u < RC; ++u) {
-        const int c = u * G + g, cc = c < m_tot ? c : g;
-        const double val = vc[cc];
-        const double p = sP * Pl[(size_t)cc * S + s];
-        dA[(size_t)cc * S + s] = val * (a1 - p * val);
+        for (int u = 0; u < RC; ++u) {
+          const int f = cs[u] >> 16, q = cs[u] & 0xFFFF;
+          const int64_t j = jc[q];
+          const double xq = vc[q];
+          const int fq = fc[q], nf = fcnt[f];
+          const int* ent = fent + f * mc;
+          double acc = 0.0;
+          for (int ph = 0; ph < 3; ++ph)
+            for (int t = 0; t < nf; ++t) {
+              const int q2 = ent[t];
+              const int64_t j2 = jc[q2];
+              const bool take = ph == 0 ? (q2 < q && j2 < j) : ph == 1 ? (j2 > j) : (q2 > q && j2 < j);
+              if (take) {
+                const double v12 = (j2 < j) ? vc[q2] * xq : xq * vc[q2];
+                acc += v12 * (sP * Pl[((size_t)fq * m + q2) * S + s]);
+              }
+            }
+          dA[(size_t)slot_of(u) * S + s] = acc;
+        }
+      }
+      if (act) {  // the pair sum of the prediction, every group alike
+        double part = 0.0;
+        for (int q1 = 0; q1 < m; ++q1) {
+          const int64_t j1 = jc[q1];
+          const int f1 = fc[q1];
+          const double x1 = vc[q1];
+          for (int qb = 0; qb < m; qb += FH) {
+            int64_t j_[FH];
+            int f_[FH];
+            double x_[FH], pa_[FH], pb_[FH];
+#pragma unroll
+            for (int u = 0; u < FH; ++u) {
+              const int q2 = qb + u < m ? qb + u : qb;
+              j_[u] = jc[q2];
+              f_[u] = fc[q2];
+              x_[u] = vc[q2];
+            }
+#pragma unroll
+            for (int u = 0; u < FH; ++u) {
+              const int q2 = qb + u < m ? qb + u : qb;
+              pa_[u] = Pl[((size_t)f_[u] * m + q1) * S + s];
+              pb_[u] = Pl[((size_t)f1 * m + q2) * S + s];
+            }
+#pragma unroll
+            for (int u = 0; u < FH; ++u) {
+              const bool ok = qb + u < m && j1 < j_[u];
+              const double v12 = x1 * x_[u];
+              const double pa = sP * pa_[u], pb = sP * pb_[u];
+              part = ok ? part + (pa * pb) * v12 : part;
+            }
+          }
+        }
+        kv = part;
       }
     }
     if (g == 0) red[s] = (act && s < k) ? kv : 0.0;
@@ -654,7 +769,7 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
     if (tid == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
     const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
 
-    // ---- 5. update; what is written for entry q is also left in q's LDS slot ----
+    // ---- 5. update; what is written for a slot is also left in its LDS place ----
     if (OPT == OPT_SGD) {
       const double eta_w = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, itf);
       const double eta_P = dev::get_eta(O.sched, O.eta0, O.power, O.beta, itf);
@@ -662,26 +777,26 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
       if (mine) {
 #pragma unroll
         for (int ub = 0; ub < RC; ub += CH) {
+          if (ub * G + g >= n_slots) break;
           double p_[CH], d_[CH];
           int64_t j_[CH];
 #pragma unroll
           for (int u = 0; u < CH; ++u) {
-            const int c = (ub + u) * G + g, cc = c < m_tot ? c : g;
-            j_[u] = jc[cc];
+            const int cc = slot_of(ub + u);
+            j_[u] = jc[cs[ub + u] & 0xFFFF];
             p_[u] = Pl[(size_t)cc * S + s];
             d_[u] = dA[(size_t)cc * S + s];
           }
 #pragma unroll
           for (int u = 0; u < CH; ++u) {  // branch-free: the division chains interleave
-            const int c = (ub + u) * G + g;
-            const bool ok = c < m_tot;
-            const size_t e = M.row(0, j_[u]) * Kp + s;
+            const bool ok = (ub + u) * G + g < n_slots;
+            const size_t e = M.row(cs[ub + u] >> 16, j_[u]) * Kp + s;
             const double p = sP * p_[u];
             const double update = eta_P * (dL * d_[u] + O.beta * p);
             viol_acc = ok ? viol_acc + fabs(update) : viol_acc;
             const double nv = (p - update) / sPn;
             M.P[e] = nv;
-            dA[(size_t)(ok ? c : g) * S + s] = nv;
+            dA[(size_t)slot_of(ub + u) * S + s] = nv;
           }
         }
       }
@@ -710,7 +825,7 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
       if (sP < 1e-9) {
         __syncthreads();
         if (act)
-          for (int64_t r = g; r < M.da; r += G) M.P[(size_t)r * Kp + s] *= sP;
+          for (int64_t r = g; r < (int64_t)M.nb * M.da; r += G) M.P[(size_t)r * Kp + s] *= sP;
         sP = 1.0;
         reset = true;
       }
@@ -730,22 +845,22 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
       if (mine) {
 #pragma unroll
         for (int ub = 0; ub < RC; ub += CH) {
+          if (ub * G + g >= n_slots) break;
           double d_[CH], g_[CH], n_[CH];
           size_t e_[CH];
 #pragma unroll
           for (int u = 0; u < CH; ++u) {
-            const int c = (ub + u) * G + g, cc = c < m_tot ? c : g;
-            e_[u] = M.row(0, jc[cc]) * Kp + s;
-            d_[u] = dA[(size_t)cc * S + s];
+            e_[u] = M.row(cs[ub + u] >> 16, jc[cs[ub + u] & 0xFFFF]) * Kp + s;
+            d_[u] = dA[(size_t)slot_of(ub + u) * S + s];
           }
 #pragma unroll
-          for (int u = 0; u < CH; ++u) {  // the state rows of CH entries requested together
+          for (int u = 0; u < CH; ++u) {  // the state rows of CH slots requested together
             g_[u] = O.G[e_[u]];
             n_[u] = O.N[e_[u]];
           }
 #pragma unroll
           for (int u = 0; u < CH; ++u) {
-            const int c = (ub + u) * G + g, cc = c < m_tot ? c : g;
+            const int cc = slot_of(ub + u);
             const double grad = dL * d_[u];
             const double gn = g_[u] + grad, nn = n_[u] + grad * grad;
             O.G[e_[u]] = gn;
@@ -769,8 +884,9 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
         wp2[tid] = nn;
       }
     }
-    // ---- 6. the entries of t+2 go to their slot; the pipeline advances ----
+    // ---- 6. the entries of t+2 go to their buffer; the pipeline advances ----
     store_entries(s2, D2, live2);
+    m_prev = m_tot;
     D0 = D1;
     D1 = D2;
     D2 = D3;
@@ -798,9 +914,9 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
   }
 }
 
-template <int OPT, int RC>
+template <int KIND, int OPT, int RC>
 static int launch_seq_pipe_t(nfm_ctx* ctx, const SeqArgs& a, int S, int lgS, size_t lds_bytes) {
-  auto kern = k_sequential_pipe<OPT, RC>;
+  auto kern = k_sequential_pipe<KIND, OPT, RC>;
   if (lds_bytes > 64 * 1024)
     NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   TimedLaunch tl(ctx, "sequential");
@@ -808,15 +924,15 @@ static int launch_seq_pipe_t(nfm_ctx* ctx, const SeqArgs& a, int S, int lgS, siz
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }
-template <int OPT>
+template <int KIND, int OPT>
 static int launch_seq_pipe(nfm_ctx* ctx, const SeqArgs& a, int S, int lgS, int rc, size_t lds_bytes) {
-  if (rc <= 1) return launch_seq_pipe_t<OPT, 1>(ctx, a, S, lgS, lds_bytes);
-  if (rc <= 2) return launch_seq_pipe_t<OPT, 2>(ctx, a, S, lgS, lds_bytes);
-  if (rc <= 4) return launch_seq_pipe_t<OPT, 4>(ctx, a, S, lgS, lds_bytes);
-  if (rc <= 8) return launch_seq_pipe_t<OPT, 8>(ctx, a, S, lgS, lds_bytes);
-  if (rc <= 16) return launch_seq_pipe_t<OPT, 16>(ctx, a, S, lgS, lds_bytes);
-  if (rc <= 32) return launch_seq_pipe_t<OPT, 32>(ctx, a, S, lgS, lds_bytes);
-  return launch_seq_pipe_t<OPT, 64>(ctx, a, S, lgS, lds_bytes);
+  if (rc <= 1) return launch_seq_pipe_t<KIND, OPT, 1>(ctx, a, S, lgS, lds_bytes);
+  if (rc <= 2) return launch_seq_pipe_t<KIND, OPT, 2>(ctx, a, S, lgS, lds_bytes);
+  if (rc <= 4) return launch_seq_pipe_t<KIND, OPT, 4>(ctx, a, S, lgS, lds_bytes);
+  if (rc <= 8) return launch_seq_pipe_t<KIND, OPT, 8>(ctx, a, S, lgS, lds_bytes);
+  if (rc <= 16) return launch_seq_pipe_t<KIND, OPT, 16>(ctx, a, S, lgS, lds_bytes);
+  if (rc <= 32) return launch_seq_pipe_t<KIND, OPT, 32>(ctx, a, S, lgS, lds_bytes);
+  return launch_seq_pipe_t<KIND, OPT, 64>(ctx, a, S, lgS, lds_bytes);
 }
 
 template <int KIND, int OPT, bool STAGE>
@@ -837,30 +953,39 @@ int launch_sequential(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelV
   int T = ((M.Kp + kWave - 1) / kWave) * kWave;
   if (T < kWave) T = kWave;
   if (m_cap < 1) m_cap = 1;
+  SeqArgs a{X, M, O, perm_dev, begin, end, it0, out2_dev, m_cap};
+  // The pipelined step (k_sequential_pipe): degree-2 FMs with one order and field-aware models; at most 256 factors and
+  // 256 entries per row, at most 64 rows per thread, everything of a sample in LDS.  NFM_SEQ_PIPE=0 switches it off.
+  static const bool pipe_on = !(getenv("NFM_SEQ_PIPE") && atoi(getenv("NFM_SEQ_PIPE")) == 0);
+  const bool ffm = M.kind == NFM_KIND_FFM;
+  if (pipe_on && (ffm || (M.nb == 1 && M.degree == 2)) && M.nb >= 1 && M.nb < 32768 && m_cap <= kPipeThreads) {
+    int S = 2, lgS = 1;
+    while (S < M.Kp) { S <<= 1; ++lgS; }
+    const int nbk = ffm ? M.nb : 1;
+    const int G = S <= kPipeThreads ? kPipeThreads / S : 0;
+    const int64_t slots = (int64_t)nbk * m_cap;
+    const int64_t rc = G > 0 ? (slots + G - 1) / G : (int64_t)1 << 30;
+    const size_t pipe_bytes = sizeof(double) * ((size_t)kPipeThreads + 2 * (size_t)slots * S + 6 * (size_t)m_cap) +
+                              sizeof(int64_t) * 3 * (size_t)m_cap +
+                              sizeof(int) * ((size_t)m_cap + (ffm ? 3 * (size_t)m_cap + nbk + (size_t)nbk * m_cap : 0));
+    if (G >= 1 && rc <= 64 && pipe_bytes <= 160 * 1024) {
+      if (ffm) {
+        if (opt_kind == OPT_SGD) return launch_seq_pipe<NFM_KIND_FFM, OPT_SGD>(ctx, a, S, lgS, (int)rc, pipe_bytes);
+        return launch_seq_pipe<NFM_KIND_FFM, OPT_ADAGRAD>(ctx, a, S, lgS, (int)rc, pipe_bytes);
+      }
+      if (opt_kind == OPT_SGD) return launch_seq_pipe<NFM_KIND_FM, OPT_SGD>(ctx, a, S, lgS, (int)rc, pipe_bytes);
+      return launch_seq_pipe<NFM_KIND_FM, OPT_ADAGRAD>(ctx, a, S, lgS, (int)rc, pipe_bytes);
+    }
+  }
   const size_t lds_bytes = sizeof(double) * ((size_t)T + (size_t)(M.nb > 0 ? M.nb : 1) * m_cap * T);
   NFM_CHECK(lds_bytes <= 160 * 1024, NFM_ERR_UNSUPPORTED,
             "sequential mode needs %zu bytes of LDS for the per-sample gradient (n_blocks=%d, max row nnz=%d, Kp=%d)",
             lds_bytes, M.nb, m_cap, M.Kp);
-  SeqArgs a{X, M, O, perm_dev, begin, end, it0, out2_dev, m_cap};
   if (M.kind == NFM_KIND_FM) {
     // staged step (entries and parameter values in LDS) when the extra [nb][m_cap][T] + 2 [m_cap] doubles fit
     const size_t n_da = (size_t)(M.nb > 0 ? M.nb : 1) * m_cap * T;
     const size_t staged_bytes = lds_bytes + sizeof(double) * (n_da + 3 * (size_t)m_cap);
     static const bool stage_on = !(getenv("NFM_SEQ_STAGE") && atoi(getenv("NFM_SEQ_STAGE")) == 0);
-    // the pipelined step: degree 2 (one order), at most 256 factors and 256 entries per row, at most 64 entries per
-    // thread; NFM_SEQ_PIPE=0 switches it off
-    static const bool pipe_on = !(getenv("NFM_SEQ_PIPE") && atoi(getenv("NFM_SEQ_PIPE")) == 0);
-    int S = 2, lgS = 1;
-    while (S < M.Kp) { S <<= 1; ++lgS; }
-    const int G = S <= kPipeThreads ? kPipeThreads / S : 0;
-    const int rc = G > 0 ? (m_cap + G - 1) / G : 1 << 30;
-    const size_t pipe_bytes = sizeof(double) * ((size_t)kPipeThreads + 2 * (size_t)m_cap * S + 6 * (size_t)m_cap) +
-                              sizeof(int64_t) * 3 * (size_t)m_cap + sizeof(int) * (size_t)m_cap;
-    if (stage_on && pipe_on && M.nb == 1 && M.degree == 2 && G >= 1 && m_cap <= kPipeThreads && rc <= 64 && pipe_bytes <= 160 * 1024) {
-      SeqArgs ap = a;
-      if (opt_kind == OPT_SGD) return launch_seq_pipe<OPT_SGD>(ctx, ap, S, lgS, rc, pipe_bytes);
-      return launch_seq_pipe<OPT_ADAGRAD>(ctx, ap, S, lgS, rc, pipe_bytes);
-    }
     if (stage_on && M.nb > 0 && staged_bytes <= 160 * 1024) {
       if (opt_kind == OPT_SGD) return launch_seq_t<NFM_KIND_FM, OPT_SGD, true>(ctx, a, T, staged_bytes);
       return launch_seq_t<NFM_KIND_FM, OPT_ADAGRAD, true>(ctx, a, T, staged_bytes);

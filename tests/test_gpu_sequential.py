@@ -11,7 +11,7 @@ import pytest
 import nimfm_amd as nf
 import oracle as O
 from common import assert_close, init_ffm, init_fm, make_ffm_dataset, make_fm_dataset, make_perms
-from gpu_common import gpu_ffm, gpu_fm, to_gpu
+from gpu_common import gpu_ffm, gpu_fm, ragged_csr, to_gpu
 
 pytestmark = pytest.mark.gpu
 N, D, K = 80, 8, 4
@@ -183,3 +183,95 @@ def test_stopping_criterion_and_scale_reset():
     nf.newSGD(maxIter=4, verbose=0, tol=0, shuffle=False, **cfg).fit(X, y, fm)
     assert_close(fm.w, wf, 1e-7, 1e-11, "w")
     assert_close(fm.P, Pf, 1e-7, 1e-11, "P")
+
+
+@pytest.mark.parametrize("k,max_m,d", [(1, 5, 9), (3, 40, 60), (16, 100, 150), (50, 64, 90), (64, 30, 40), (100, 12, 30)])
+@pytest.mark.parametrize("solver", ["sgd", "adagrad"])
+def test_pipelined_step_shapes(solver, k, max_m, d):
+    """k_sequential_pipe (csrc/seq.hip): group counts G = 256 / S from 128 down to 2, 1 to 50 rows per thread, ragged and
+    empty rows, unsorted storage order, consecutive samples that share most of their features (d is small: nearly every
+    requested value is refreshed through LDS), a permuted order -- bit-level agreement with the one-sample-at-a-time
+    oracle is the tolerance of the reference grids"""
+    n = 120
+    Xo = ragged_csr(n, d, seed=k + max_m, max_m=max_m, empty_every=7)
+    rng = np.random.default_rng(k)
+    y = rng.standard_normal(n)
+    P0, w0 = rng.standard_normal((1, k, d)) * 0.05, rng.standard_normal(d) * 0.01
+    perms = make_perms(n, 3)
+    fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, 0.1)
+    if solver == "sgd":
+        Pf, wf, bf, it, el, ev, _ = O.fm_sgd_fit(Xo, y, 2, P0, w0, 0.1, O.sgd_cfg(eta0=0.02), 3, 0, perms=perms)
+        opt = nf.newSGD(maxIter=3, eta0=0.02, verbose=0, tol=0)
+    else:
+        Pf, wf, bf, it, el, ev, _, _ = O.fm_adagrad_fit(Xo, y, 2, P0, w0, 0.1, O.adagrad_cfg(), 3, 0, perms=perms)
+        opt = nf.newAdaGrad(maxIter=3, verbose=0, tol=0)
+    opt.fit(to_gpu(Xo), y, fm, perms=perms)
+    assert abs(fm.intercept - bf) < 1e-9
+    assert_close(fm.w, wf, RTOL, ATOL, "w")
+    assert_close(fm.P, Pf, RTOL, ATOL, "P")
+    assert_close([h[1] for h in opt.history], el, 1e-9, 1e-12, "loss")
+    assert_close([h[0] for h in opt.history], ev, 1e-8, 1e-11, "viol")
+
+
+@pytest.mark.parametrize("F,k,d", [(3, 2, 12), (16, 8, 64), (39, 4, 120), (7, 20, 30)])
+@pytest.mark.parametrize("solver", ["sgd", "adagrad"])
+def test_pipelined_step_ffm_shapes(solver, F, k, d):
+    """the field-aware step through the same kernel: fields with several entries, with one and with none in a sample,
+    storage order not sorted by index (the pair order of sgd_ffm.nim:18-30 depends on it)"""
+    n = 90
+    rng = np.random.default_rng(F * 100 + k)
+    field_of = rng.integers(0, F, size=d)
+    rows, vals, indptr = [], [], [0]
+    for i in range(n):
+        m = 0 if i % 11 == 5 else int(rng.integers(1, min(d, max(F, 6)) + 1))  # F = 39: 39 x 39 rows of a sample in LDS
+        idx = rng.choice(d, size=m, replace=False)
+        if i % 3:
+            idx = np.sort(idx)
+        rows.append(idx)
+        vals.append(rng.uniform(-1, 1, size=m))
+        indptr.append(indptr[-1] + m)
+    idx = np.concatenate(rows).astype(np.int64)
+    Xo = O.Dataset(np.array(indptr), idx, np.concatenate(vals), n, d, field_of[idx], F)
+    y = rng.standard_normal(n)
+    P0, w0, b0 = init_ffm(d, F, k)
+    X = to_gpu(Xo)
+    ffm = gpu_ffm("regression", k, True, True, P0, w0, b0)
+    if solver == "sgd":
+        Pf, wf, bf, it, el, ev, _ = O.ffm_sgd_fit(Xo, y, P0, w0, b0, O.sgd_cfg(eta0=0.05), 3)
+        opt = nf.newSGD(maxIter=3, eta0=0.05, verbose=0, tol=0, shuffle=False)
+    else:
+        Pf, wf, bf, it, el, ev, _, _ = O.ffm_adagrad_fit(Xo, y, P0, w0, b0, O.adagrad_cfg(), 3)
+        opt = nf.newAdaGrad(maxIter=3, verbose=0, tol=0, shuffle=False)
+    opt.fit(X, y, ffm)
+    assert abs(ffm.intercept - bf) < 1e-9
+    assert_close(ffm.w, wf, RTOL, ATOL, "w")
+    assert_close(ffm.P, Pf, RTOL, ATOL, "P")
+    assert_close([h[0] for h in opt.history], ev, 1e-8, 1e-11, "viol")
+
+
+@pytest.mark.parametrize("solver", ["sgd", "adagrad"])
+def test_sequential_mode_is_bit_exact_where_the_arithmetic_is_the_same(solver):
+    """The device code is built without fused multiply-adds (csrc/Makefile: the reference's generated C has none on
+    x86-64).  Where the step then performs the reference's operations in the reference's order -- AdaGrad, and SGD without
+    L2 decay (with decay the device keeps one global scale where the reference keeps per-feature snapshots) -- and the loss
+    needs no exp / log, the result is the oracle's BIT FOR BIT: division and square root are correctly rounded on both
+    sides.  viol is a sum over threads and stays within rounding."""
+    n, d, k = 200, 70, 8
+    Xo = ragged_csr(n, d, seed=11, max_m=30, empty_every=9)
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal(n) * 0.5
+    P0, w0 = rng.standard_normal((1, k, d)) * 0.05, rng.standard_normal(d) * 0.01
+    perms = make_perms(n, 3)
+    for loss in ("squared", "squared_hinge", "huber"):
+        yy = np.sign(y) if loss == "squared_hinge" else y
+        task = "classification" if loss == "squared_hinge" else "regression"
+        fm = gpu_fm(task, 2, k, "explicit", True, True, P0, w0, 0.1)
+        if solver == "sgd":
+            Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, yy, 2, P0, w0, 0.1, O.sgd_cfg(loss=loss, alpha=0.0, beta=0.0), 3, 0, perms=perms)
+            nf.newSGD(maxIter=3, loss=loss, alpha=0.0, beta=0.0, verbose=0, tol=0).fit(to_gpu(Xo), yy, fm, perms=perms)
+        else:
+            Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, yy, 2, P0, w0, 0.1, O.adagrad_cfg(loss=loss), 3, 0, perms=perms)
+            nf.newAdaGrad(maxIter=3, loss=loss, verbose=0, tol=0).fit(to_gpu(Xo), yy, fm, perms=perms)
+        assert fm.intercept == bf, loss
+        assert np.array_equal(fm.w, wf), loss
+        assert np.array_equal(fm.P, Pf), loss

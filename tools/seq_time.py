@@ -25,3 +25,20 @@ for name, n, d, m, k, solver in (("cfg2 shape", 40_000, 100_000, 32, 16, "sgd"),
     ctx.timing_enable(False)
     print("%-15s %-8s n=%d m=%d k=%d: kernel %.2f us per step (%.3g samples/s); fit() wall %.2f us per step, NFM_SEQ_PIPE=%s" %
           (name, solver, n, m, k, kt[1] / n * 1e3, n / (kt[1] * 1e-3), dt / n * 1e6, os.environ.get("NFM_SEQ_PIPE", "1")))
+
+# field-aware models (sgd_ffm.nim / adagrad_ffm.nim), cfg4's row shape: 16 fields, one entry per field, k = 8
+from bench import make_dataset
+for solver in ("sgd", "adagrad"):
+    n, d, F, k = 10_000, 100_000, 16, 8
+    X, *_keep = make_dataset(torch, nf, ctx, dev, dict(d=d, m=F, fields=F), n, 0)
+    y = np.random.default_rng(0).standard_normal(n)
+    fm = nf.newFieldAwareFactorizationMachine("regression", nComponents=k, randomState=1, warmStart=True)
+    fm.init(X)
+    mk = nf.newSGD if solver == "sgd" else nf.newAdaGrad
+    opt = mk(maxIter=1, loss="squared", verbose=0, tol=0, shuffle=False, mode="sequential")
+    opt.fit(X, y, fm)
+    ctx.timing_reset(); ctx.timing_enable(True)
+    opt.fit(X, y, fm)
+    kt = ctx.timing_get("sequential")
+    ctx.timing_enable(False)
+    print("FFM cfg4 shape  %-8s n=%d F=%d k=%d: kernel %.2f us per step (%.3g samples/s)" % (solver, n, F, k, kt[1] / n * 1e3, n / (kt[1] * 1e-3)))
