@@ -495,6 +495,31 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                 "score": {"value": round(n / ts, 1), "unit": "samples/s", "ms": round(ts * 1e3, 4), "result": sc.value}}
         del out_dev
 
+    # ---- the reference's own sample-by-sample order (NFM_MODE_SEQUENTIAL: one sample in flight, results equal to the
+    # reference-faithful CPU restatement) on a bounded prefix of the shard: the speed of the mode that reproduces the
+    # reference exactly, reported beside the mini-batch rule's ----
+    exact = None
+    if rank == 0 and world == 1 and not F:
+        ns_ = min(n, 20000)
+        Xs = nf.CSRDataset.from_device(ctx, ns_, d, ns_ * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(),
+                                       keep=(indptr, indices, data))
+        Xs.set_targets(np.ascontiguousarray(y[:ns_]))
+        fm_s = nf.newFactorizationMachine(task, degree=wl["degree"], nComponents=k, warmStart=True, randomState=1)
+        fm_s.init(Xs)
+        mk_ = nf.newSGD if wl["solver"] == "sgd" else nf.newAdaGrad
+        opt_s = mk_(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="sequential")
+        opt_s._handle(fm_s, ctx, "sequential")
+        opt_s._epoch(Xs, None, 0, ns_)
+        opt_s.it += ns_
+        ctx.synchronize()
+        t_s = time.perf_counter()
+        opt_s._epoch(Xs, None, 0, ns_)
+        ctx.synchronize()
+        t_s = time.perf_counter() - t_s
+        exact = {"value": round(ns_ / t_s, 1), "unit": "samples/s", "us_per_step": round(t_s / ns_ * 1e6, 2),
+                 "sample": "the first %d samples of the shard, storage order, mode=sequential (csrc/seq.hip)" % ns_}
+        del opt_s, fm_s, Xs
+
     # ---- roofline leg: per-kernel durations from HIP events on the library's stream (one replica, no exchange) ----
     roof = None
     if use_dp:
@@ -550,14 +575,14 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                                    "mode=minibatch" % (name, n, d, m, k, wl["solver"].upper(), wl["loss"], batch),
                        "update_rule": "this library's deterministic mini-batch rule (per-coordinate mean of the batch's "
                                       "per-sample steps, DESIGN.md section 4) -- NOT the reference's sample-by-sample order, "
-                                      "which NFM_MODE_SEQUENTIAL reproduces at ~1e5 samples/s",
+                                      "which NFM_MODE_SEQUENTIAL reproduces (exact_order: its samples/s on this shape)",
                        "samples_per_gpu": n, "batch": batch,
                        "parallelism": ("%d ranks, one process per GPU, contiguous sample shards; replicas %s in the library over "
                                        "RCCL every %s on a second stream + exactly at the end of every epoch"
                                        % (world, "averaged" if wl["solver"] == "sgd" else "state-summed",
                                           ("%d mini-batches" % sync_period) if sync_period else "epoch (no mid-epoch exchange)"))
                        if use_dp else "1 GPU"},
-            "last_step": {"mean_loss": last[0] / (n * world), "viol": last[1]}, "predict": pred,
+            "last_step": {"mean_loss": last[0] / (n * world), "viol": last[1]}, "predict": pred, "exact_order": exact,
             "roofline": roof, "cpu_baseline": cpu}
 
 
@@ -648,7 +673,8 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": res["config"], "value_shuffled": res["value_shuffled"],
                "value_shuffled_host_perm": res["value_shuffled_host_perm"], "shuffled_note": res["shuffled_note"],
-               "last_step": res["last_step"], "predict": res["predict"], "roofline": res["roofline"],
+               "last_step": res["last_step"], "predict": res["predict"], "exact_order": res["exact_order"],
+               "roofline": res["roofline"],
                "cpu_baseline": res["cpu_baseline"], "extra": extra}
         print(json.dumps(out))
     if world > 1:
