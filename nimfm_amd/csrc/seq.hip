@@ -348,6 +348,7 @@ __global__ void k_sequential(SeqArgs a) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int kPipeThreads = 256;
+constexpr int kPipePairCap = 4096;  // FFM: entries^2 of the per-pair table (32 KB)
 
 // KIND = FactorizationMachine (degree 2, one order): a sample's rows are its entries.  KIND = FieldAwareFactorizationMachine:
 // the reference's step reads and updates ALL nFields rows of every feature of the sample (sgd_ffm.nim:11-30 and the shared
@@ -374,7 +375,9 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
   double* wl = vl + 3 * mc;                             // [mc] stored linear weights of the current sample
   double* wp = wl + mc;                                 // [mc] written linear weight (AdaGrad: g_sum of the linear term)
   double* wp2 = wp + mc;                                // [mc] AdaGrad: g_norm of the linear term
-  int64_t* jl = reinterpret_cast<int64_t*>(wp2 + mc);   // [3][mc] indices
+  const bool by_pair = FFM && mc * mc <= kPipePairCap;  // FFM: one thread per ordered pair of entries (below)
+  double* pc = wp2 + mc;                                // FFM, by_pair: [mc][mc] a pair's term of the prediction
+  int64_t* jl = reinterpret_cast<int64_t*>(pc + (by_pair ? mc * mc : 0));  // [3][mc] indices
   int* rm = reinterpret_cast<int*>(jl + 3 * mc);        // [mc] entry of t+1 -> entry of t with the same feature, or -1
   int* fl = rm + mc;                                    // FFM: [3][mc] fields
   int* fcnt = fl + 3 * mc;                              // FFM: [nbk] entries of the current sample per field
@@ -719,7 +722,49 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
           dA[(size_t)slot_of(u) * S + s] = acc;
         }
       }
-      if (act) {  // the pair sum of the prediction, every group alike
+      if (by_pair) {
+        // The prediction exactly as sgd_ffm.nim:18-27 forms it: per pair ONE dot product over the factors, ascending s,
+        // times x1, times x2, added to the running prediction in the order the pairs are visited.  The dot products of
+        // different pairs are independent: thread p takes the ordered pair (q1, q2) = (p / m, p mod m).
+        for (int p = tid; p < m * m; p += T) {
+          const int q1 = p / m, q2 = p - q1 * m;
+          double c = 0.0;
+          if (jc[q1] < jc[q2]) {
+            const double* pa_ = Pl + ((size_t)fc[q2] * m + q1) * S;
+            const double* pb_ = Pl + ((size_t)fc[q1] * m + q2) * S;
+            double tmp = 0.0;
+            for (int sb = 0; sb < k; sb += FH) {
+              double a_[FH], b_[FH];
+#pragma unroll
+              for (int u = 0; u < FH; ++u) {
+                a_[u] = pa_[sb + u < k ? sb + u : sb];
+                b_[u] = pb_[sb + u < k ? sb + u : sb];
+              }
+#pragma unroll
+              for (int u = 0; u < FH; ++u) tmp = sb + u < k ? tmp + (sP * a_[u]) * (sP * b_[u]) : tmp;
+            }
+            c = tmp * vc[q1] * vc[q2];
+          }
+          pc[p] = c;
+        }
+        lds_barrier();
+        for (int q1 = 0; q1 < m; ++q1) {
+          const int64_t j1 = jc[q1];
+          for (int qb = 0; qb < m; qb += FH) {
+            int64_t j_[FH];
+            double c_[FH];
+#pragma unroll
+            for (int u = 0; u < FH; ++u) {
+              const int q2 = qb + u < m ? qb + u : qb;
+              j_[u] = jc[q2];
+              c_[u] = pc[q1 * m + q2];
+            }
+#pragma unroll
+            for (int u = 0; u < FH; ++u) yh = (qb + u < m && j1 < j_[u]) ? yh + c_[u] : yh;
+          }
+        }
+      } else if (act) {  // rows too long for a pair table: per-factor sums over the pairs, every group alike (the
+                         // prediction then differs from the reference's grouping by rounding)
         double part = 0.0;
         for (int q1 = 0; q1 < m; ++q1) {
           const int64_t j1 = jc[q1];
@@ -764,7 +809,7 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
 #pragma unroll
       for (int u = 0; u < FH; ++u) tot = sb + u < k ? tot + r_[u] : tot;
     }
-    yh += tot;
+    yh = by_pair ? yh : yh + tot;  // by_pair: the pair terms are in yh already
     lds_barrier();
     if (tid == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
     const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
@@ -965,7 +1010,8 @@ int launch_sequential(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelV
     const int G = S <= kPipeThreads ? kPipeThreads / S : 0;
     const int64_t slots = (int64_t)nbk * m_cap;
     const int64_t rc = G > 0 ? (slots + G - 1) / G : (int64_t)1 << 30;
-    const size_t pipe_bytes = sizeof(double) * ((size_t)kPipeThreads + 2 * (size_t)slots * S + 6 * (size_t)m_cap) +
+    const size_t pair_doubles = ffm && (int64_t)m_cap * m_cap <= kPipePairCap ? (size_t)m_cap * m_cap : 0;
+    const size_t pipe_bytes = sizeof(double) * ((size_t)kPipeThreads + 2 * (size_t)slots * S + 6 * (size_t)m_cap + pair_doubles) +
                               sizeof(int64_t) * 3 * (size_t)m_cap +
                               sizeof(int) * ((size_t)m_cap + (ffm ? 3 * (size_t)m_cap + nbk + (size_t)nbk * m_cap : 0));
     if (G >= 1 && rc <= 64 && pipe_bytes <= 160 * 1024) {

@@ -275,3 +275,21 @@ def test_sequential_mode_is_bit_exact_where_the_arithmetic_is_the_same(solver):
         assert fm.intercept == bf, loss
         assert np.array_equal(fm.w, wf), loss
         assert np.array_equal(fm.P, Pf), loss
+
+
+def test_sequential_ffm_adagrad_is_bit_exact():
+    """field-aware AdaGrad: the pipelined step forms the prediction as sgd_ffm.nim:18-27 does -- one dot product per
+    pair of entries, the pairs' terms added in visiting order -- so it equals the oracle bit for bit as well"""
+    n, d, F, k = 150, 50, 6, 8
+    rng = np.random.default_rng(9)
+    Xr = ragged_csr(n, d, seed=21, max_m=12, empty_every=8)
+    field_of = rng.integers(0, F, size=d)
+    Xo = O.Dataset(Xr.indptr, Xr.indices, Xr.data, n, d, field_of[Xr.indices], F)
+    y = rng.standard_normal(n) * 0.5
+    P0, w0, b0 = init_ffm(d, F, k)
+    Pf, wf, bf, *_ = O.ffm_adagrad_fit(Xo, y, P0, w0, b0, O.adagrad_cfg(), 3)
+    ffm = gpu_ffm("regression", k, True, True, P0, w0, b0)
+    nf.newAdaGrad(maxIter=3, verbose=0, tol=0, shuffle=False).fit(to_gpu(Xo), y, ffm)
+    assert ffm.intercept == bf
+    assert np.array_equal(ffm.w, wf)
+    assert np.array_equal(ffm.P, Pf)
