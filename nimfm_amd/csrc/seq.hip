@@ -348,18 +348,18 @@ __global__ void k_sequential(SeqArgs a) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int kPipeThreads = 256;
+constexpr int kPipeThreadsWide = 512;   // when a thread of 256 would hold 8 or more rows (1024 threads: 128 registers, spills: slower)
 constexpr int kPipePairCap = 4096;  // FFM: entries^2 of the per-pair table (32 KB)
 
 // KIND = FactorizationMachine (degree 2, one order): a sample's rows are its entries.  KIND = FieldAwareFactorizationMachine:
 // the reference's step reads and updates ALL nFields rows of every feature of the sample (sgd_ffm.nim:11-30 and the shared
 // update loops): the rows are "slots" c = field * m + q.  A slot belongs to group c mod G like an FM entry.
-template <int KIND, int OPT, int RC>  // RC: slots per thread (RC * G >= rows per sample)
-__global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int S, int lgS) {
+template <int KIND, int OPT, int RC, int T>  // RC: slots per thread (RC * G >= rows per sample), T: threads (256 or 1024)
+__global__ __launch_bounds__(T) void k_sequential_pipe(SeqArgs a, int S, int lgS, int split_terms) {
   extern __shared__ double lds[];
   const CsrView& X = a.X;
   const ModelView& M = a.M;
   const OptView& O = a.O;
-  constexpr int T = kPipeThreads;
   constexpr bool FFM = KIND == NFM_KIND_FFM;
   constexpr int CH = RC < 8 ? RC : 8;  // values requested together in the per-thread loops
   constexpr int FH = 8;                // ... in the loops over all entries
@@ -377,7 +377,9 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
   double* wp2 = wp + mc;                                // [mc] AdaGrad: g_norm of the linear term
   const bool by_pair = FFM && mc * mc <= kPipePairCap;  // FFM: one thread per ordered pair of entries (below)
   double* pc = wp2 + mc;                                // FFM, by_pair: [mc][mc] a pair's term of the prediction
-  int64_t* jl = reinterpret_cast<int64_t*>(pc + (by_pair ? mc * mc : 0));  // [3][mc] indices
+  double* yt = pc + (by_pair ? mc * mc : 0);            // [mc] terms of the linear part of the prediction
+  double* T1 = yt + mc;                                 // FM, split_terms: [mc][S] x_q p_qs, the terms of the per-factor sums
+  int64_t* jl = reinterpret_cast<int64_t*>(T1 + (!FFM && split_terms ? (size_t)mc * S : 0));  // [3][mc] indices
   int* rm = reinterpret_cast<int*>(jl + 3 * mc);        // [mc] entry of t+1 -> entry of t with the same feature, or -1
   int* fl = rm + mc;                                    // FFM: [3][mc] fields
   int* fcnt = fl + 3 * mc;                              // FFM: [nbk] entries of the current sample per field
@@ -546,6 +548,7 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
       lds_barrier();  // every thread is done with the previous step's slots
     }
     fresh = false;
+    if (tid < mc) rm[tid] = -1;  // refilled in step 3, read by the next step's refresh
     bool staged = false;
     if constexpr (OPT == OPT_ADAGRAD) if (it != 1) {
       staged = true;
@@ -630,41 +633,70 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
     load_entries(D2, live2);
     const Desc D3 = load_desc(pos + 3, i3);
     const int64_t i4 = sample_at(pos + 4);
-    // ---- 3. entry of the next sample -> entry of this one ----
+    // ---- 3. entry of the next sample -> entry of this one: the (entry, entry) comparisons are spread over all threads
+    // (ids are distinct inside a row: at most one match per entry, no write conflicts) ----
     {
       const int mt1 = live1 ? D1.m + n_aug : 0;
       const int64_t* jn = jl + s1 * mc;
-      if (tid < mt1) {
-        const int64_t j = jn[tid];
-        int r = -1;
-        for (int qb = 0; qb < m_tot; qb += FH) {
+      int lg = 0;
+      while ((1 << lg) < mt1) ++lg;
+      const int c = tid & ((1 << lg) - 1), part = tid >> lg, nparts = T >> lg;
+      const int len = (m_tot + nparts - 1) / nparts;
+      if (c < mt1) {
+        const int64_t j = jn[c];
+        const int q_lo = part * len, q_hi = q_lo + len < m_tot ? q_lo + len : m_tot;
+        for (int qb = q_lo; qb < q_hi; qb += FH) {
           int64_t jj[FH];
 #pragma unroll
-          for (int u = 0; u < FH; ++u) jj[u] = jc[qb + u < m_tot ? qb + u : qb];
+          for (int u = 0; u < FH; ++u) jj[u] = jc[qb + u < q_hi ? qb + u : qb];
+          int r = -1;
 #pragma unroll
-          for (int u = 0; u < FH; ++u) r = (qb + u < m_tot && jj[u] == j) ? qb + u : r;
+          for (int u = 0; u < FH; ++u) r = (qb + u < q_hi && jj[u] == j) ? qb + u : r;
+          if (r >= 0) rm[c] = r;
         }
-        rm[tid] = r;
       }
     }
+    // the terms of the linear part, one entry per thread; FM with split_terms: x_q p_qs of this thread's entries
+    if (tid < m) yt[tid] = (sw * wl[tid]) * vc[tid];
+    if constexpr (!FFM) {
+      if (split_terms && mine) {
+#pragma unroll
+        for (int u = 0; u < RC; ++u) {
+          const int cc = slot_of(u);
+          T1[(size_t)cc * S + s] = vc[cc] * (sP * Pl[(size_t)cc * S + s]);
+        }
+      }
+    }
+    lds_barrier();
 
     // ---- 4. predictWithGrad (optimizer/sgd.nim:191-202, sgd_ffm.nim:11-30) ----
+    // every sum below adds its terms in the reference's order; the products were formed above, in parallel
     double yh = b;
     for (int qb = 0; qb < m; qb += FH) {
-      double w_[FH], v_[FH];
+      double t_[FH];
 #pragma unroll
-      for (int u = 0; u < FH; ++u) {
-        w_[u] = wl[qb + u < m ? qb + u : qb];
-        v_[u] = vc[qb + u < m ? qb + u : qb];
-      }
+      for (int u = 0; u < FH; ++u) t_[u] = yt[qb + u < m ? qb + u : qb];
 #pragma unroll
-      for (int u = 0; u < FH; ++u) yh = qb + u < m ? yh + (sw * w_[u]) * v_[u] : yh;
+      for (int u = 0; u < FH; ++u) yh = qb + u < m ? yh + t_[u] : yh;
     }
     double kv = 0.0;
     if constexpr (!FFM) {
       // every group runs the per-factor sums over all entries; the derivative of a thread's own entries follows
       double a1 = 0.0, a2 = 0.0;
-      if (act) {
+      if (act && split_terms) {
+        for (int qb = 0; qb < m_tot; qb += FH) {
+          double t_[FH];
+#pragma unroll
+          for (int u = 0; u < FH; ++u) t_[u] = T1[(size_t)(qb + u < m_tot ? qb + u : qb) * S + s];
+#pragma unroll
+          for (int u = 0; u < FH; ++u) {
+            const bool ok = qb + u < m_tot;
+            a1 = ok ? a1 + t_[u] : a1;
+            a2 = ok ? a2 + t_[u] * t_[u] : a2;
+          }
+        }
+        kv = (a1 * a1 - a2) / 2;
+      } else if (act) {
         for (int qb = 0; qb < m_tot; qb += FH) {
           double p_[FH], v_[FH];
 #pragma unroll
@@ -959,25 +991,31 @@ __global__ __launch_bounds__(kPipeThreads) void k_sequential_pipe(SeqArgs a, int
   }
 }
 
-template <int KIND, int OPT, int RC>
-static int launch_seq_pipe_t(nfm_ctx* ctx, const SeqArgs& a, int S, int lgS, size_t lds_bytes) {
-  auto kern = k_sequential_pipe<KIND, OPT, RC>;
+template <int KIND, int OPT, int RC, int T>
+static int launch_seq_pipe_t(nfm_ctx* ctx, const SeqArgs& a, int S, int lgS, int split_terms, size_t lds_bytes) {
+  auto kern = k_sequential_pipe<KIND, OPT, RC, T>;
   if (lds_bytes > 64 * 1024)
     NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   TimedLaunch tl(ctx, "sequential");
-  hipLaunchKernelGGL(kern, dim3(1), dim3(kPipeThreads), lds_bytes, ctx->stream, a, S, lgS);
+  hipLaunchKernelGGL(kern, dim3(1), dim3(T), lds_bytes, ctx->stream, a, S, lgS, split_terms);
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }
 template <int KIND, int OPT>
-static int launch_seq_pipe(nfm_ctx* ctx, const SeqArgs& a, int S, int lgS, int rc, size_t lds_bytes) {
-  if (rc <= 1) return launch_seq_pipe_t<KIND, OPT, 1>(ctx, a, S, lgS, lds_bytes);
-  if (rc <= 2) return launch_seq_pipe_t<KIND, OPT, 2>(ctx, a, S, lgS, lds_bytes);
-  if (rc <= 4) return launch_seq_pipe_t<KIND, OPT, 4>(ctx, a, S, lgS, lds_bytes);
-  if (rc <= 8) return launch_seq_pipe_t<KIND, OPT, 8>(ctx, a, S, lgS, lds_bytes);
-  if (rc <= 16) return launch_seq_pipe_t<KIND, OPT, 16>(ctx, a, S, lgS, lds_bytes);
-  if (rc <= 32) return launch_seq_pipe_t<KIND, OPT, 32>(ctx, a, S, lgS, lds_bytes);
-  return launch_seq_pipe_t<KIND, OPT, 64>(ctx, a, S, lgS, lds_bytes);
+static int launch_seq_pipe(nfm_ctx* ctx, const SeqArgs& a, int S, int lgS, int rc, int threads, int split_terms, size_t lds_bytes) {
+  if (threads == kPipeThreadsWide) {  // rc <= 16
+    if (rc <= 2) return launch_seq_pipe_t<KIND, OPT, 2, kPipeThreadsWide>(ctx, a, S, lgS, split_terms, lds_bytes);
+    if (rc <= 4) return launch_seq_pipe_t<KIND, OPT, 4, kPipeThreadsWide>(ctx, a, S, lgS, split_terms, lds_bytes);
+    if (rc <= 8) return launch_seq_pipe_t<KIND, OPT, 8, kPipeThreadsWide>(ctx, a, S, lgS, split_terms, lds_bytes);
+    return launch_seq_pipe_t<KIND, OPT, 16, kPipeThreadsWide>(ctx, a, S, lgS, split_terms, lds_bytes);
+  }
+  if (rc <= 1) return launch_seq_pipe_t<KIND, OPT, 1, kPipeThreads>(ctx, a, S, lgS, split_terms, lds_bytes);
+  if (rc <= 2) return launch_seq_pipe_t<KIND, OPT, 2, kPipeThreads>(ctx, a, S, lgS, split_terms, lds_bytes);
+  if (rc <= 4) return launch_seq_pipe_t<KIND, OPT, 4, kPipeThreads>(ctx, a, S, lgS, split_terms, lds_bytes);
+  if (rc <= 8) return launch_seq_pipe_t<KIND, OPT, 8, kPipeThreads>(ctx, a, S, lgS, split_terms, lds_bytes);
+  if (rc <= 16) return launch_seq_pipe_t<KIND, OPT, 16, kPipeThreads>(ctx, a, S, lgS, split_terms, lds_bytes);
+  if (rc <= 32) return launch_seq_pipe_t<KIND, OPT, 32, kPipeThreads>(ctx, a, S, lgS, split_terms, lds_bytes);
+  return launch_seq_pipe_t<KIND, OPT, 64, kPipeThreads>(ctx, a, S, lgS, split_terms, lds_bytes);
 }
 
 template <int KIND, int OPT, bool STAGE>
@@ -1007,20 +1045,29 @@ int launch_sequential(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelV
     int S = 2, lgS = 1;
     while (S < M.Kp) { S <<= 1; ++lgS; }
     const int nbk = ffm ? M.nb : 1;
-    const int G = S <= kPipeThreads ? kPipeThreads / S : 0;
     const int64_t slots = (int64_t)nbk * m_cap;
-    const int64_t rc = G > 0 ? (slots + G - 1) / G : (int64_t)1 << 30;
+    int threads = kPipeThreads;
+    int G = S <= threads ? threads / S : 0;
+    int64_t rc = G > 0 ? (slots + G - 1) / G : (int64_t)1 << 30;
+    if (G > 0 && rc >= 8 && (slots + 2 * G - 1) / (2 * G) <= 16) {  // 8 wavefronts: half of the rows per thread
+      threads = kPipeThreadsWide;
+      G *= 2;
+      rc = (slots + G - 1) / G;
+    }
     const size_t pair_doubles = ffm && (int64_t)m_cap * m_cap <= kPipePairCap ? (size_t)m_cap * m_cap : 0;
-    const size_t pipe_bytes = sizeof(double) * ((size_t)kPipeThreads + 2 * (size_t)slots * S + 6 * (size_t)m_cap + pair_doubles) +
-                              sizeof(int64_t) * 3 * (size_t)m_cap +
+    // FM: the products of the per-factor sums are formed in parallel into one more [entries][S] table when it fits
+    const size_t base_doubles = (size_t)threads + 2 * (size_t)slots * S + 7 * (size_t)m_cap + pair_doubles;
+    const size_t tail_bytes = sizeof(int64_t) * 3 * (size_t)m_cap +
                               sizeof(int) * ((size_t)m_cap + (ffm ? 3 * (size_t)m_cap + nbk + (size_t)nbk * m_cap : 0));
+    const int split_terms = !ffm && sizeof(double) * (base_doubles + (size_t)m_cap * S) + tail_bytes <= 160 * 1024 ? 1 : 0;
+    const size_t pipe_bytes = sizeof(double) * (base_doubles + (split_terms ? (size_t)m_cap * S : 0)) + tail_bytes;
     if (G >= 1 && rc <= 64 && pipe_bytes <= 160 * 1024) {
       if (ffm) {
-        if (opt_kind == OPT_SGD) return launch_seq_pipe<NFM_KIND_FFM, OPT_SGD>(ctx, a, S, lgS, (int)rc, pipe_bytes);
-        return launch_seq_pipe<NFM_KIND_FFM, OPT_ADAGRAD>(ctx, a, S, lgS, (int)rc, pipe_bytes);
+        if (opt_kind == OPT_SGD) return launch_seq_pipe<NFM_KIND_FFM, OPT_SGD>(ctx, a, S, lgS, (int)rc, threads, split_terms, pipe_bytes);
+        return launch_seq_pipe<NFM_KIND_FFM, OPT_ADAGRAD>(ctx, a, S, lgS, (int)rc, threads, split_terms, pipe_bytes);
       }
-      if (opt_kind == OPT_SGD) return launch_seq_pipe<NFM_KIND_FM, OPT_SGD>(ctx, a, S, lgS, (int)rc, pipe_bytes);
-      return launch_seq_pipe<NFM_KIND_FM, OPT_ADAGRAD>(ctx, a, S, lgS, (int)rc, pipe_bytes);
+      if (opt_kind == OPT_SGD) return launch_seq_pipe<NFM_KIND_FM, OPT_SGD>(ctx, a, S, lgS, (int)rc, threads, split_terms, pipe_bytes);
+      return launch_seq_pipe<NFM_KIND_FM, OPT_ADAGRAD>(ctx, a, S, lgS, (int)rc, threads, split_terms, pipe_bytes);
     }
   }
   const size_t lds_bytes = sizeof(double) * ((size_t)T + (size_t)(M.nb > 0 ? M.nb : 1) * m_cap * T);
