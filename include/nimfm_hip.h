@@ -335,6 +335,14 @@ int32_t nfm_dp_destroy(nfm_dp* dp);
 /* attach (dp != NULL) or detach (dp == NULL) a group; sync_period: mini-batches between exchanges, 0 = only the exact
  * exchange at the end of every nfm_opt_epoch call */
 int32_t nfm_opt_set_dp(nfm_opt* o, nfm_dp* dp, int64_t sync_period, int32_t overlap);  /* detach before nfm_dp_destroy */
+/* How SGD combines the ranks' increments at an exchange (AdaGrad always adds its state increments up):
+ * NFM_DP_MEAN (default) -- the replicas' mean: local SGD, as stable as one rank, but the model moves as far as ONE rank's
+ * steps take it; NFM_DP_SUM -- every rank's steps land in the model, as every Hogwild thread's steps land in the
+ * reference's shared one (optimizer/sgd_multi.nim:83-101): the progress of all ranks' steps, at the price of a step size
+ * that is effectively multiplied by the number of ranks wherever their features overlap (keep sync_period small).
+ * DESIGN.md section 6 has the measurements. */
+enum { NFM_DP_MEAN = 0, NFM_DP_SUM = 1 };
+int32_t nfm_opt_set_dp_combine(nfm_opt* o, int32_t combine);
 
 /* ---- host-side random numbers (no device work) ----
  * FactorizationMachine.init draws P with randomNormal (model/factorization_machine.nim:125-139,

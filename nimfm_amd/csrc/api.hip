@@ -106,6 +106,7 @@ struct nfm_opt {
   nfm_dp* dp = nullptr;
   int64_t dp_sync_period = 0;
   bool dp_overlap = true;
+  int dp_combine = 0;  // NFM_DP_MEAN / NFM_DP_SUM (SGD)
   DevBuf dp_sums;
 };
 
@@ -977,11 +978,14 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         de.opt_kind = o->kind;
         de.sync_period = o->dp_sync_period;
         de.overlap = o->dp_overlap;
+        de.combine_w = (o->kind == OPT_SGD && o->dp_combine == NFM_DP_MEAN) ? 1.0 / (double)o->dp->t->world : 1.0;
         if (o->kind == OPT_SGD) {
           de.arena = m->arena.as<double>();
           de.n = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double)) + SC_COUNT;
           de.skip_lo = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double)) + SC_SCALE_P;
           de.skip_hi = de.skip_lo + 2;  // {scale_P, scale_w}
+          de.seg_w = (int64_t)((reinterpret_cast<char*>(M.w) - m->arena.as<char>()) / sizeof(double));
+          de.seg_sc = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double));
         } else {
           de.arena = o->state_arena.as<double>();
           de.n = (int64_t)((o->gsc.as<char>() - o->state_arena.as<char>()) / sizeof(double)) + 2;
@@ -1044,8 +1048,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       if (dev_shuffle) o->shuffle_epoch++;
       NFM_TRY(rc_epoch);
       if (o->dp) {
-        NFM_TRY(dp_fold_pending(de));
-        if (o->kind == OPT_SGD) NFM_TRY(launch_rescale(ctx, M));  // true values: the scales are 1 on every rank
+        NFM_TRY(dp_fold_pending(de));  // (SGD: the closing exchange itself brings the arena to true values, scales 1)
         NFM_TRY(o->dp_sums.ensure(sizeof(double) * 3));
         double sums[3] = {out2[0], out2[1], (double)ns};
         NFM_HIP_CHECK(hipMemcpyAsync(o->dp_sums.p, sums, sizeof(sums), hipMemcpyHostToDevice, st));
@@ -1171,6 +1174,13 @@ int32_t nfm_opt_set_dp(nfm_opt* o, nfm_dp* dp, int64_t sync_period, int32_t over
   o->dp = dp;
   o->dp_sync_period = sync_period;
   o->dp_overlap = overlap != 0;
+  return NFM_OK;
+}
+
+int32_t nfm_opt_set_dp_combine(nfm_opt* o, int32_t combine) {
+  NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
+  NFM_CHECK(combine == NFM_DP_MEAN || combine == NFM_DP_SUM, NFM_ERR_INVALID, "combine must be NFM_DP_MEAN or NFM_DP_SUM");
+  o->dp_combine = combine;
   return NFM_OK;
 }
 

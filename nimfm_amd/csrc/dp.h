@@ -4,9 +4,11 @@
 // (optimizer/sgd_multi.nim:83-101: every thread owns a slice, all threads share ONE model, nothing is
 // synchronised).  Across GPUs the slices become per-rank shards resident in each GPU's HBM and the shared model
 // becomes replicas that are reconciled every `sync_period` mini-batches:
-//   SGD      replicas are averaged (local SGD);
-//   AdaGrad  the replicas' state increments since the last exchange are summed (the state is additive over samples,
-//            optimizer/adagrad.nim:113-134), which is the state ONE process would hold after all shards' samples.
+//   Both optimizers exchange INCREMENTS since the last agreed state:
+//   SGD      the ranks' increments are averaged (default: local SGD, as stable as one rank) or summed (NFM_DP_SUM: every
+//            rank's steps land in the model, as every Hogwild thread's do in the reference's shared one) -- dp.hip;
+//   AdaGrad  the state is additive over samples (optimizer/adagrad.nim:113-134): the sum is the state ONE process would
+//            hold after all shards' samples.
 // A mid-epoch exchange is DELAYED by one period so that the collective (on its own stream) runs beside the next
 // period's mini-batches: at sync point k a rank snapshots what it contributes and starts the all-reduce; the result
 // is folded in at sync point k+1.  The fold-in point is fixed, so the result is deterministic.  The exchange that ends
@@ -49,10 +51,12 @@ struct DpEpoch {
   int opt_kind = 0;            // OPT_SGD / OPT_ADAGRAD
   double* arena = nullptr;     // SGD: [P | w | scalars]; AdaGrad: [G | N | Gw | Nw | gscalars]
   int64_t n = 0;               // doubles in the arena
-  int64_t skip_lo = 0, skip_hi = 0;  // SGD: the two scale slots (identical on all ranks; never exchanged mid-epoch)
+  int64_t skip_lo = 0, skip_hi = 0;  // SGD: the two scale slots (identical on all ranks at a sync point; never exchanged)
+  int64_t seg_w = 0, seg_sc = 0;     // SGD: the arena is [P: 0 .. seg_w | w: seg_w .. seg_sc | scalars]
   int64_t sync_period = 0;     // mini-batches between exchanges, 0 = only the closing exchange
   int64_t n_sync = 0;          // mid-epoch sync points every rank reaches (agreed at dp_epoch_begin)
   bool overlap = true;
+  double combine_w = 1.0;      // SGD: 1 / world (mean of the ranks' increments, the default) or 1 (their sum); AdaGrad: 1
 };
 
 // agree on the number of mid-epoch sync points: min over ranks of (full mini-batches / sync_period), strictly before
@@ -60,9 +64,10 @@ struct DpEpoch {
 int dp_epoch_begin(DpEpoch& e, int64_t n_full_batches, int64_t n_batches);
 // called after mini-batch b (0-based) has been enqueued on ctx->stream
 int dp_after_batch(DpEpoch& e, int64_t b);
-// folds a pending (delayed) exchange in; SGD: BEFORE the scales are brought to 1 -- what is folded in is in stored units
+// folds a pending (delayed) exchange in (SGD: stored units)
 int dp_fold_pending(DpEpoch& e);
-// closing exchange (exact, blocking).  SGD: the caller has brought the scales to 1 (launch_rescale) beforehand.
+// closing exchange (exact, blocking).  SGD: in true values under one agreed scale; leaves the arena in true values with
+// both scales 1 (no launch_rescale afterwards).
 // sums[3] = {loss_sum, viol_sum, samples} of this rank in, of all ranks out (device buffer of 3 doubles).
 int dp_epoch_end(DpEpoch& e, double* sums_dev);
 

@@ -166,36 +166,74 @@ inline unsigned grid_stream(int64_t n) {
   if (b > 256 * 32) b = 256 * 32;
   return (unsigned)(b < 1 ? 1 : b);
 }
-// SGD, delayed: theta += R / W - S (stored units: the lazy L2 scale decays the late contribution like everything else)
-__global__ void k_sgd_fold(double* __restrict__ theta, const double* __restrict__ R, const double* __restrict__ S, int64_t n,
-                           double inv_w, int64_t skip_lo, int64_t skip_hi) {
+// Both optimizers exchange INCREMENTS since the last agreed state (`base`).  AdaGrad's g_sum / g_norm are sums over
+// samples: the ranks' increments are added up.  SGD combines the ranks' increments by `cw` times their sum:
+//   cw = 1 / world  the replicas' MEAN (the default; local SGD).  Always as stable as one rank, but the model moves as far
+//                   as ONE rank's steps take it: after the same number of epochs a 4-rank run stands where a single rank
+//                   that saw a quarter of the steps stands (tests/test_gpu_dp.py::test_data_parallel_training_..., held-out
+//                   RMSE 0.87 against 0.27 for one rank over all samples).
+//   cw = 1          the SUM (NFM_DP_SUM): every rank's steps land in the model, as every Hogwild thread's steps land in
+//                   the reference's shared one (sgd_multi.nim:83-101) -- the progress of all ranks' steps, but steps that
+//                   were computed from the same stale point add up: with features shared by all ranks it acts like a step
+//                   size times world (same test: 0.45 with an exchange every 8 mini-batches, divergence with one per
+//                   epoch).
+// SGD's arena holds STORED values (true / lazy L2 scale); at a mid-epoch sync all ranks have taken the same steps, hence
+// have the same scales, and stored increments combine like true ones.  The two scale slots [skip_lo, skip_hi) are never
+// exchanged.
+// own = x - base
+__global__ void k_inc_own(const double* __restrict__ x, const double* __restrict__ base, double* __restrict__ own, int64_t n,
+                          int64_t skip_lo, int64_t skip_hi) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    if (i < skip_lo || i >= skip_hi) theta[i] += R[i] * inv_w - S[i];
+    own[i] = (i < skip_lo || i >= skip_hi) ? x[i] - base[i] : 0.0;
 }
-// SGD, closing: theta = R / W
-__global__ void k_sgd_mean(double* __restrict__ theta, const double* __restrict__ R, int64_t n, double inv_w) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) theta[i] = R[i] * inv_w;
+// delayed: the other ranks' increments arrive: x += R - own, base += R
+__global__ void k_inc_fold(double* __restrict__ x, double* __restrict__ base, const double* __restrict__ R,
+                           const double* __restrict__ own, int64_t n, int64_t skip_lo, int64_t skip_hi, double cw) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (i < skip_lo || i >= skip_hi) {
+      const double r = R[i] * cw;
+      x[i] += r - own[i];
+      base[i] += r;
+    }
 }
-// AdaGrad: own = G - base
-__global__ void k_ada_own(const double* __restrict__ G, const double* __restrict__ base, double* __restrict__ own, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) own[i] = G[i] - base[i];
-}
-// AdaGrad, delayed: the other ranks' increments arrive: G += R - own, base += R
-__global__ void k_ada_fold(double* __restrict__ G, double* __restrict__ base, const double* __restrict__ R,
-                           const double* __restrict__ own, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double r = R[i];
-    G[i] += r - own[i];
-    base[i] += r;
-  }
-}
-// AdaGrad, closing: G = base + R (every rank forms the same sum), base = G
-__global__ void k_ada_close(double* __restrict__ G, double* __restrict__ base, const double* __restrict__ R, int64_t n) {
+// closing: x = base + R (every rank forms the same sum), base = x
+__global__ void k_inc_close(double* __restrict__ x, double* __restrict__ base, const double* __restrict__ R, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const double g = base[i] + R[i];
-    G[i] = g;
+    x[i] = g;
     base[i] = g;
   }
+}
+// SGD, closing.  The ranks' tails may differ in length (shards of unequal size), so their scales do: the increments
+// travel as TRUE values, own = scale_rank * (stored - base), and are added to the base under ONE scale all ranks agree
+// on (the smallest: the rank that took the most steps).  The arena is left in true values with both scales 1.
+// sc = the rank's {scale_P, scale_w} (the arena's slots skip_lo, skip_lo + 1); segments: [0, seg_w) P, [seg_w, seg_sc) w.
+__global__ void k_sgd_close_own(const double* __restrict__ x, const double* __restrict__ base, double* __restrict__ own, int64_t n,
+                                int64_t seg_w, int64_t seg_sc, int64_t skip_lo, int64_t skip_hi) {
+  const double sP = x[skip_lo], sw = x[skip_lo + 1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double sc = i < seg_w ? sP : (i < seg_sc ? sw : 1.0);
+    own[i] = (i < skip_lo || i >= skip_hi) ? sc * (x[i] - base[i]) : 0.0;
+  }
+}
+__global__ void k_sgd_close_apply(double* __restrict__ x, const double* __restrict__ base, const double* __restrict__ R,
+                                  const double* __restrict__ neg_min_scales, int64_t n, int64_t seg_w, int64_t seg_sc,
+                                  int64_t skip_lo, int64_t skip_hi, double cw) {
+  const double sP = -neg_min_scales[0], sw = -neg_min_scales[1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i >= skip_lo && i < skip_hi) {
+      x[i] = 1.0;  // the arena now holds true values
+    } else {
+      const double sc = i < seg_w ? sP : (i < seg_sc ? sw : 1.0);
+      x[i] = sc * base[i] + R[i] * cw;
+    }
+  }
+}
+__global__ void k_neg_scales(const double* __restrict__ x, int64_t skip_lo, double* __restrict__ out) {
+  out[0] = -x[skip_lo];
+  out[1] = -x[skip_lo + 1];
+  out[2] = 0.0;
+  out[3] = 0.0;
 }
 }  // namespace
 
@@ -205,12 +243,8 @@ int dp_fold_pending(DpEpoch& e) {
   hipStream_t st = dp->ctx->stream;
   NFM_HIP_CHECK(hipStreamWaitEvent(st, dp->ev_done, 0));
   const int64_t n = dp->pending_n;
-  if (e.opt_kind == OPT_SGD)
-    hipLaunchKernelGGL(k_sgd_fold, dim3(grid_stream(n)), dim3(kBlock), 0, st, e.arena, dp->recv.as<double>(), dp->snap.as<double>(), n,
-                       1.0 / (double)dp->t->world, e.skip_lo, e.skip_hi);
-  else
-    hipLaunchKernelGGL(k_ada_fold, dim3(grid_stream(n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(),
-                       dp->snap.as<double>(), n);
+  hipLaunchKernelGGL(k_inc_fold, dim3(grid_stream(n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(),
+                     dp->snap.as<double>(), n, e.skip_lo, e.skip_hi, e.combine_w);
   NFM_HIP_CHECK(hipGetLastError());
   dp->pending = false;
   return NFM_OK;
@@ -223,10 +257,9 @@ int dp_epoch_begin(DpEpoch& e, int64_t n_full_batches, int64_t n_batches) {
   NFM_TRY(dp->snap.ensure(sizeof(double) * (size_t)e.n));
   NFM_TRY(dp->recv.ensure(sizeof(double) * (size_t)e.n));
   NFM_TRY(dp->scal.ensure(sizeof(double) * 8));
-  if (e.opt_kind == OPT_ADAGRAD) {
-    NFM_TRY(dp->base.ensure(sizeof(double) * (size_t)e.n));
-    NFM_HIP_CHECK(hipMemcpyAsync(dp->base.p, e.arena, sizeof(double) * (size_t)e.n, hipMemcpyDeviceToDevice, st));
-  }
+  // the state all ranks agree on (they enter the call with identical replicas; SGD: in true values, both scales 1)
+  NFM_TRY(dp->base.ensure(sizeof(double) * (size_t)e.n));
+  NFM_HIP_CHECK(hipMemcpyAsync(dp->base.p, e.arena, sizeof(double) * (size_t)e.n, hipMemcpyDeviceToDevice, st));
   // mid-epoch sync points lie after mini-batches S, 2S, ... that are FULL on every rank (identical step counters and
   // L2 scales there) and strictly before this rank's -- hence every rank's -- last one
   int64_t mine = 0;
@@ -252,10 +285,8 @@ int dp_after_batch(DpEpoch& e, int64_t b) {
   hipStream_t st = dp->ctx->stream;
   NFM_TRY(dp_fold_pending(e));  // the previous period's collective has had a whole period to finish
   // what this rank contributes now
-  if (e.opt_kind == OPT_SGD)
-    NFM_HIP_CHECK(hipMemcpyAsync(dp->snap.p, e.arena, sizeof(double) * (size_t)e.n, hipMemcpyDeviceToDevice, st));
-  else
-    hipLaunchKernelGGL(k_ada_own, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->snap.as<double>(), e.n);
+  hipLaunchKernelGGL(k_inc_own, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->snap.as<double>(), e.n,
+                     e.skip_lo, e.skip_hi);
   NFM_HIP_CHECK(hipGetLastError());
   hipStream_t cs = e.overlap ? dp->comm : st;
   if (e.overlap) {
@@ -276,14 +307,19 @@ int dp_epoch_end(DpEpoch& e, double* sums_dev) {
   nfm_dp* dp = e.dp;
   hipStream_t st = dp->ctx->stream;
   NFM_TRY(dp_fold_pending(e));
-  const double inv_w = 1.0 / (double)dp->t->world;
   if (e.opt_kind == OPT_SGD) {
-    NFM_TRY(dp->t->allreduce(e.arena, dp->recv.as<double>(), e.n, DP_SUM, st));
-    hipLaunchKernelGGL(k_sgd_mean, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->recv.as<double>(), e.n, inv_w);
-  } else {
-    hipLaunchKernelGGL(k_ada_own, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->snap.as<double>(), e.n);
+    hipLaunchKernelGGL(k_sgd_close_own, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->snap.as<double>(),
+                       e.n, e.seg_w, e.seg_sc, e.skip_lo, e.skip_hi);
+    hipLaunchKernelGGL(k_neg_scales, dim3(1), dim3(1), 0, st, e.arena, e.skip_lo, dp->scal.as<double>());
+    NFM_TRY(dp->t->allreduce(dp->scal.as<double>(), dp->scal.as<double>() + 4, 4, DP_MAX, st));
     NFM_TRY(dp->t->allreduce(dp->snap.as<double>(), dp->recv.as<double>(), e.n, DP_SUM, st));
-    hipLaunchKernelGGL(k_ada_close, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(), e.n);
+    hipLaunchKernelGGL(k_sgd_close_apply, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(),
+                       dp->scal.as<double>() + 4, e.n, e.seg_w, e.seg_sc, e.skip_lo, e.skip_hi, e.combine_w);
+  } else {
+    hipLaunchKernelGGL(k_inc_own, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->snap.as<double>(), e.n,
+                       (int64_t)0, (int64_t)0);
+    NFM_TRY(dp->t->allreduce(dp->snap.as<double>(), dp->recv.as<double>(), e.n, DP_SUM, st));
+    hipLaunchKernelGGL(k_inc_close, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(), e.n);
   }
   NFM_HIP_CHECK(hipGetLastError());
   dp->n_collectives++;

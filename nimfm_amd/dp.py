@@ -6,7 +6,7 @@ slices become per-rank shards (resident in each GPU's HBM) and the shared model 
 LIBRARY reconciles -- every `sync_period` mini-batches, overlapped with the next period's mini-batches on a
 second stream, and exactly at the end of every nfm_opt_epoch call (csrc/dp.hip):
 
-  SGD      replicas averaged                                            (local SGD / model averaging)
+  SGD      the replicas' increments averaged (default) or summed        (Optimizer.setDataParallel(..., combine=))
   AdaGrad  the replicas' g_sum / g_norm increments summed               (optimizer/adagrad.nim:113-134 is additive)
 
 One process per GPU: the collective is RCCL's ncclAllReduce over xGMI on the single parameter / state arena,

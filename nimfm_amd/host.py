@@ -761,13 +761,18 @@ class _OptimizerBase:
                 self._attach_dp()
         return self._h
 
-    def setDataParallel(self, group, syncPeriod=0, overlap=True):
+    def setDataParallel(self, group, syncPeriod=0, overlap=True, combine="mean"):
         """The maxThreads overloads across GPUs (optimizer/sgd_multi.nim:40-120 and twins): `group` is this rank's
         dp.Group; X handed to fit is then this rank's contiguous slice of the samples (dp.shard_bounds), every rank
         calls fit together, and the library reconciles the replicas every syncPeriod mini-batches (0: only at the end of
-        every epoch) -- averaged for SGD, state increments summed for AdaGrad.  The epoch's loss / viol and the step
+        every epoch).  AdaGrad's state increments are summed.  SGD: combine = "mean" (default) averages the ranks' increments
+        (local SGD: as stable as one rank, the model moves as far as ONE rank's steps take it), "sum" adds them up (every
+        rank's steps land in the model, as every Hogwild thread's steps do in the reference; acts like a step size times
+        the number of ranks where features overlap -- keep syncPeriod small).  The epoch's loss / viol and the step
         counter `it` then cover the samples of ALL ranks."""
-        self._dp = None if group is None else (group, int(syncPeriod), bool(overlap))
+        if combine not in ("mean", "sum"):
+            raise ValueError("combine must be 'mean' or 'sum'")
+        self._dp = None if group is None else (group, int(syncPeriod), bool(overlap), combine)
         if self._h is not None:
             self._attach_dp()
 
@@ -775,6 +780,7 @@ class _OptimizerBase:
         g = self._dp
         capi.check(capi.lib().nfm_opt_set_dp(self._h, None if g is None else g[0].h, 0 if g is None else g[1],
                                              1 if g is None or g[2] else 0))
+        capi.check(capi.lib().nfm_opt_set_dp_combine(self._h, 1 if g is not None and g[3] == "sum" else 0))
 
     def _sync_it(self):
         """with a group attached the library advances `it` by the samples of all ranks"""

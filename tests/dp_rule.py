@@ -5,12 +5,15 @@ A rank is a generator: it trains its shard with the CPU oracle of the mini-batch
 the ranks of a group in lockstep inside one process; tests/test_dp_gloo.py drives ONE rank per process with gloo
 all-reduces.  The GPU tests hold the library (groups made by nfm_dp_create_local, one host thread per rank) to it.
 
-Rule (true-value space; the library works on stored values = true / lazy-L2 scale, which is why its late fold-in needs
-no explicit decay factor):
+Rule (true-value space; the library works on stored values = true / lazy-L2 scale, in which an untouched value does not
+change while its true value decays -- the `dec` factors below are that decay):
   sync points after mini-batches S, 2S, ... that are regular on every rank and lie before every rank's last batch
-  SGD      at sync k a rank snapshots its parameters; the group's mean minus the snapshot is folded in at sync k+1
-           (overlap: the collective runs beside period k+1), decayed by the L2 factors of that period; without overlap
-           it is folded in at once.  Closing exchange: plain mean.
+  Both optimizers exchange INCREMENTS since the last agreed state (`base`) and add the ranks' increments up.
+  SGD      own = parameters - base (base decayed to now); the ranks' increments are combined to total = cw * sum with
+           cw = 1 / world (mean, the default) or 1 (sum); the others' share (total - own) is
+           folded in at sync k+1 (overlap: the collective runs beside period k+1), decayed by that period's factors, or at
+           once; base tracks the agreed state.  Closing exchange: increments in true values, the base under the smallest
+           decay factor of the ranks' (possibly unequal) tails.
   AdaGrad  own = state - base is summed over the ranks; the others' share (sum - own) is folded in at sync k+1 (or at
            once); base tracks the agreed state.  Closing exchange: state = base + sum of the remaining increments.
 """
@@ -49,13 +52,28 @@ def decay(cfg, reg, it_lo, it_hi):
     return d
 
 
-def rank_sgd(epoch_fn, P, w, b, cfg, n, B, S, it0, overlap, world):
+def rank_sgd(epoch_fn, P, w, b, cfg, n, B, S, it0, overlap, world, combine="mean"):
     """epoch_fn(P, w, b, begin, end, it) -> (b, loss, viol): the oracle's mini-batch epoch over [begin, end) in place"""
     bounds = batch_bounds(n, B, False)
     nb = len(bounds) - 1
     n_sync = int(-(yield ("max", np.array([-float(n_sync_mine(bounds, B, S))])))[0])
     loss = viol = 0.0
     pending = None
+    cw = 1.0 / world if combine == "mean" else 1.0  # the ranks' increments are averaged (default) or added up
+
+    def flat():
+        return np.concatenate([P.ravel(), w, [b]])
+
+    def dec(it_lo, it_hi):  # what an untouched value shrinks by over those steps (the intercept has no lazy scale)
+        dP = decay(cfg, cfg.beta, it_lo, it_hi)
+        dw = decay(cfg, cfg.alpha, it_lo, it_hi) if cfg.fit_linear else 1.0
+        return np.concatenate([np.full(P.size, dP), np.full(w.size, dw), [1.0]])
+
+    def put(f):
+        nonlocal b
+        P[...] = f[:P.size].reshape(P.shape)
+        w[...] = f[P.size:P.size + w.size]
+        b = f[-1]
 
     def run(b0, b1):
         nonlocal b, loss, viol
@@ -64,37 +82,37 @@ def rank_sgd(epoch_fn, P, w, b, cfg, n, B, S, it0, overlap, world):
             loss += ls
             viol += vs
 
-    def fold(b0, b1):
-        nonlocal b, pending
+    def fold(now_it):
+        nonlocal pending
         if pending is None:
             return
-        dP, dw, db = pending
-        P[...] += dP * decay(cfg, cfg.beta, it0 + bounds[b0], it0 + bounds[b1])
-        if cfg.fit_linear:
-            w[...] += dw * decay(cfg, cfg.alpha, it0 + bounds[b0], it0 + bounds[b1])
-        else:
-            w[...] += dw
-        b += db  # the intercept is stored as a true value: no lazy scale on it
+        others, then_it = pending
+        put(flat() + others * dec(then_it, now_it))
         pending = None
 
+    base, base_it = flat(), it0 + bounds[0]
     for k in range(1, n_sync + 1):
         run((k - 1) * S, k * S)
-        fold((k - 1) * S, k * S)
-        snap = np.concatenate([P.ravel(), w, [b]])
-        mean = (yield ("sum", snap.copy())) / world
-        d = mean - snap
-        pending = (d[:P.size].reshape(P.shape), d[P.size:P.size + w.size], d[-1])
+        now_it = it0 + bounds[k * S]
+        fold(now_it)
+        base_now = base * dec(base_it, now_it)
+        own = flat() - base_now
+        total = cw * (yield ("sum", own.copy()))
+        base, base_it = base_now + total, now_it  # what all ranks agree on at this point
+        pending = (total - own, now_it)           # the other ranks' steps: folded in one period later (overlap) or at once
         if not overlap:
-            P[...] += pending[0]
-            w[...] += pending[1]
-            b += pending[2]
-            pending = None
+            fold(now_it)
     run(n_sync * S, nb)
-    fold(n_sync * S, nb)
-    flat = (yield ("sum", np.concatenate([P.ravel(), w, [b]]))) / world
-    P[...] = flat[:P.size].reshape(P.shape)
-    w[...] = flat[P.size:P.size + w.size]
-    b = flat[-1]
+    end_it = it0 + bounds[nb]
+    fold(end_it)
+    # closing exchange: the ranks' tails may differ in length; increments in true values, the base under the smallest
+    # of the ranks' decay factors since the last agreed point
+    d_mine = dec(base_it, end_it)
+    own = flat() - base * d_mine
+    d_min = -(yield ("max", -np.array([d_mine[0], d_mine[P.size] if w.size else 1.0])))
+    total = cw * (yield ("sum", own.copy()))
+    d_vec = np.concatenate([np.full(P.size, d_min[0]), np.full(w.size, d_min[1]), [1.0]])
+    put(base * d_vec + total)
     sums = yield ("sum", np.array([loss, viol, float(n)]))
     return P, w, b, sums[0], sums[1], it0 + int(round(sums[2]))
 
