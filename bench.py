@@ -400,7 +400,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         # the exchange lives in the library (csrc/dp.hip): one RCCL communicator per rank, the replicas reconciled every
         # sync_period mini-batches on a second stream beside the next period's mini-batches, exactly at the end of the
         # epoch; torch.distributed only carried the group id (dp.Group.from_torch, in main)
-        sync_period = args.sync_period if args.sync_period >= 0 else (64 if n // batch >= 256 else 0)
+        sync_period = args.sync_period if args.sync_period >= 0 else (128 if n // batch >= 512 else (64 if n // batch >= 256 else 0))
         opt.setDataParallel(run_training.group, sync_period, True)
 
     def step(perm=None):
@@ -601,8 +601,8 @@ def main():
                          "written; the stopping criterion is then unavailable) -- an information run, not the metric")
     ap.add_argument("--cpu-samples", type=int, default=1_000_000)
     ap.add_argument("--sync-period", type=int, default=-1,
-                    help="N > 1: mini-batches between exchanges (0 = only at the end of every epoch; default 64 for epochs "
-                         "of >= 256 mini-batches, else 0)")
+                    help="N > 1: mini-batches between exchanges (0 = only at the end of every epoch; default 128 for epochs "
+                         "of >= 512 mini-batches, 64 for >= 256, else 0)")
     ap.add_argument("--psgd-shape", default="", help="--workload psgd: d,m,k instead of the ml-100k shape")
     args = ap.parse_args()
 
