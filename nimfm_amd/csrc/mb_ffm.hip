@@ -16,6 +16,40 @@
 //                 is written once.  One extra workgroup closes the batch (as in mb_fm.hip).
 #include "fm_device.h"
 #include "mb.h"
+// Streaming hints (bit mask; measured on cfg4: F = 16, k = 8, tables of 3 x 100 MB, mini-batch 32768):
+//   1  the per-touch contribution rows are WRITTEN once by the row phase   } non-temporal: row phase 411 -> 365 us,
+//   2  ... and READ once by the column phase                               } column phase 333 -> 317 us
+//   4  the column phase's writes of P / g_sum / g_norm rows (next read: the next batch's row phase, 300 MB later)
+//   8  the column phase's reads of those rows: column phase 317 -> 290 us, the next row phase 366 -> 377 us
+//  16  the row phase's reads of the state rows: row phase 377 -> 429 us (a feature is read by ~5 samples of a batch:
+//      these reads WANT the cache) -- off
+// 15: cfg4 4.25e7 -> 4.78e7 samples/s (roofline.frac 0.355 -> 0.40).
+#ifndef NFM_FFM_NT
+#define NFM_FFM_NT 15
+#endif
+namespace nfm {
+typedef double ffm_v2d __attribute__((ext_vector_type(2)));
+template <int BIT>
+__device__ __forceinline__ double2 ffm_ld(const double* p) {
+  if constexpr ((NFM_FFM_NT & BIT) != 0) {
+    const ffm_v2d w = __builtin_nontemporal_load(reinterpret_cast<const ffm_v2d*>(p));
+    return double2{w.x, w.y};
+  } else {
+    return *reinterpret_cast<const double2*>(p);
+  }
+}
+template <int BIT>
+__device__ __forceinline__ void ffm_st(double* p, double2 v) {
+  if constexpr ((NFM_FFM_NT & BIT) != 0) {
+    ffm_v2d w;
+    w.x = v.x;
+    w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<ffm_v2d*>(p));
+  } else {
+    *reinterpret_cast<double2*>(p) = v;
+  }
+}
+}  // namespace nfm
 
 namespace nfm {
 
@@ -246,10 +280,10 @@ __global__ __launch_bounds__(kWave * WPB) void k_ffm_row_phase_lds(FRowArgs a, i
       r0[u] = r1[u] = {0.0, 0.0};
       if (oo[u] >= 0) {
         if (OPT == OPT_SGD || stored) {
-          r0[u] = *reinterpret_cast<const double2*>(M.P + e);
+          r0[u] = ffm_ld<16>(M.P + e);
         } else {
-          r0[u] = *reinterpret_cast<const double2*>(O.G + e);
-          r1[u] = *reinterpret_cast<const double2*>(O.N + e);
+          r0[u] = ffm_ld<16>(O.G + e);
+          r1[u] = ffm_ld<16>(O.N + e);
         }
       }
     }
@@ -287,7 +321,17 @@ __global__ __launch_bounds__(kWave * WPB) void k_ffm_row_phase_lds(FRowArgs a, i
         v.x += xq * x2 * p.x;  // sgd_ffm.nim:29-30: dA += val1 * val2 * P  (left to right)
         v.y += xq * x2 * p.y;
       }
+#if NFM_FFM_NT & 1  // the contribution rows are written once here and read once by the column phase
+      {
+        typedef double v2d_ __attribute__((ext_vector_type(2)));
+        v2d_ w_;
+        w_.x = v.x;
+        w_.y = v.y;
+        __builtin_nontemporal_store(w_, reinterpret_cast<v2d_*>(C + (size_t)o * Kp + 2 * l));
+      }
+#else
       *reinterpret_cast<double2*>(C + (size_t)o * Kp + 2 * l) = v;
+#endif
       if (v.x != 0.0 || v.y != 0.0) {
         const double2 pf = *reinterpret_cast<const double2*>(rows + (size_t)o * Kp + 2 * l);
         part += 0.5 * (pf.x * v.x + pf.y * v.y);
@@ -380,21 +424,21 @@ __device__ __forceinline__ double ffm_unit(const FColArgs& a, int64_t j, int f, 
   double2 st = {0.0, 0.0}, g2 = {0.0, 0.0}, n2 = {0.0, 0.0}, p = {0.0, 0.0};
   if (MODE != 1) {
     if (OPT == OPT_SGD) {
-      st = *reinterpret_cast<const double2*>(M.P + e);
+      st = ffm_ld<8>(M.P + e);
       p.x = sP * st.x; p.y = sP * st.y;
     } else {
-      g2 = *reinterpret_cast<const double2*>(O.G + e);
-      n2 = *reinterpret_cast<const double2*>(O.N + e);
+      g2 = ffm_ld<8>(O.G + e);
+      n2 = ffm_ld<8>(O.N + e);
       if (a.use_stored) {
-        p = *reinterpret_cast<const double2*>(M.P + e);
+        p = ffm_ld<8>(M.P + e);
       } else {
         const double tmp = O.eta0 * itp * O.beta;
         p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmp);
         p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmp);
         if (O.track_viol) {
-          st = *reinterpret_cast<const double2*>(M.P + e);
+          st = ffm_ld<8>(M.P + e);
           viol += fabs(st.x - p.x) + fabs(st.y - p.y);
-          *reinterpret_cast<double2*>(M.P + e) = p;  // idempotent: every lane group of a MODE 2 wavefront writes the same
+          ffm_st<4>(M.P + e, p);  // idempotent: every lane group of a MODE 2 wavefront writes the same
         }
       }
     }
@@ -443,7 +487,15 @@ __device__ __forceinline__ double ffm_unit(const FColArgs& a, int64_t j, int f, 
 #pragma unroll
       for (int q = 0; q < TU; ++q) {
         r[q] = a.rec[pib[q]];
+#if NFM_FFM_NT & 2
+        {
+          typedef double v2d_ __attribute__((ext_vector_type(2)));
+          const v2d_ w_ = __builtin_nontemporal_load(reinterpret_cast<const v2d_*>(a.contrib + ((size_t)(tq[q] - a.t_base) * F + f) * M.Kp + 2 * l));
+          v[q] = double2{w_.x, w_.y};
+        }
+#else
         v[q] = *reinterpret_cast<const double2*>(a.contrib + ((size_t)(tq[q] - a.t_base) * F + f) * M.Kp + 2 * l);
+#endif
       }
 #pragma unroll
       for (int q = 0; q < TU; ++q) {
@@ -477,11 +529,11 @@ __device__ __forceinline__ double ffm_unit(const FColArgs& a, int64_t j, int f, 
     viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
     st.x = st.x * fP - (acc.x / c) / sPn;
     st.y = st.y * fP - (acc.y / c) / sPn;
-    *reinterpret_cast<double2*>(M.P + e) = st;
+    ffm_st<4>(M.P + e, st);
   } else {
     g2.x += acc.x; g2.y += acc.y; n2.x += accn.x; n2.y += accn.y;
-    *reinterpret_cast<double2*>(O.G + e) = g2;
-    *reinterpret_cast<double2*>(O.N + e) = n2;
+    ffm_st<4>(O.G + e, g2);
+    ffm_st<4>(O.N + e, n2);
   }
   if (do_w && l == 0) {
     const double wt = M.w[j];
