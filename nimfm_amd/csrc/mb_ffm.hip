@@ -206,9 +206,12 @@ __global__ __launch_bounds__(kBlock) void k_ffm_row_phase(FRowArgs a) {
 //      in ascending q' (the reference's accumulation order, sgd_ffm.nim:24-30), written to the
 //      contribution buffer; yhat's pair sum = 1/2 sum <P[f][j_q], dA[q][f]>
 // ------------------------------------------------------------------------------------------------
-// WPB wavefronts per workgroup: 4, or 1 when a sample's m*F rows need more than a quarter of the LDS
-// (e.g. 39 fields x 39 entries at k = 4: 49 KiB per sample -> three single-wavefront workgroups per CU)
-template <int L, int OPT, int WPB>
+// WPB wavefronts per workgroup.  COOP = false: one sample per wavefront (a sample's m*F rows fit a quarter of the
+// LDS share).  COOP = true: the WPB wavefronts work on ONE sample together -- for samples whose rows need more (39 fields
+// x 39 entries at k = 4: 49 KiB -> three workgroups per CU).  With one wavefront per such workgroup a CU ran three
+// wavefronts, each issuing ~10k instructions per sample (1521 rows x (address, square root, division), then 1521
+// outputs): the row phase was bound by instruction issue on three of four SIMDs' single wavefronts, not by memory.
+template <int L, int OPT, int WPB, bool COOP>
 __global__ __launch_bounds__(kWave * WPB) void k_ffm_row_phase_lds(FRowArgs a, int m_cap) {
   constexpr int R = kWave / L;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -221,13 +224,15 @@ __global__ __launch_bounds__(kWave * WPB) void k_ffm_row_phase_lds(FRowArgs a, i
   const int F = M.nb, Kp = M.Kp;
   // per-wavefront LDS: rows [m_cap * F][Kp] doubles, masks [F] u64, values [m_cap] doubles, indices/fields [m_cap] ints
   const size_t per_wave = ((size_t)m_cap * F * Kp * 8 + (size_t)F * 8 + (size_t)m_cap * 16 + 15) / 16 * 16;
-  unsigned char* base = lds_raw + (size_t)wv * per_wave;
+  unsigned char* base = lds_raw + (COOP ? (size_t)0 : (size_t)wv * per_wave);
+  constexpr int RW = COOP ? R * WPB : R;        // rows handled per step by the sample's lane groups
+  const int gg = COOP ? wv * R + g : g;         // this lane group among them
   double* rows = reinterpret_cast<double*>(base);
   unsigned long long* fmask = reinterpret_cast<unsigned long long*>(base + (size_t)m_cap * F * Kp * 8);
   double* xs = reinterpret_cast<double*>(base + (size_t)m_cap * F * Kp * 8 + (size_t)F * 8);
   int* js = reinterpret_cast<int*>(xs + m_cap);
   int* fs = js + m_cap;
-  const int pib = blockIdx.x * WPB + wv;
+  const int pib = COOP ? (int)blockIdx.x : (int)blockIdx.x * WPB + wv;
   const bool valid = pib < a.len;
   int64_t q0 = 0;
   int m = 0;
@@ -255,8 +260,8 @@ __global__ __launch_bounds__(kWave * WPB) void k_ffm_row_phase_lds(FRowArgs a, i
     xt = X.data[q0 + lane];
     double wj = sw * M.w[jt];
     if (OPT == OPT_ADAGRAD && !stored && M.fit_linear) wj = -O.eta0 * O.Gw[jt] / (denw + sqrt(O.Nw[jt]));
-    part += wj * xt;
-    xs[lane] = xt;
+    if (!COOP || wv == 0) part += wj * xt;
+    xs[lane] = xt;  // COOP: every wavefront writes the same values
     js[lane] = jt;
     fs[lane] = ft;
   }
@@ -267,12 +272,12 @@ __global__ __launch_bounds__(kWave * WPB) void k_ffm_row_phase_lds(FRowArgs a, i
   // 2. gather the m * F rows
   const int n_out = m * F;
   constexpr int U = 8;  // (16 in flight for rows of 16-64 B measured no faster)
-  for (int ob = 0; ob < n_out; ob += R * U) {
+  for (int ob = 0; ob < n_out; ob += RW * U) {
     double2 r0[U], r1[U];
     int oo[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int o = ob + u * R + g;
+      const int o = ob + u * RW + gg;
       oo[u] = o < n_out ? o : -1;
       const int q = o < n_out ? o / F : 0, f = o < n_out ? o % F : 0;
       const int jq = __shfl(jt, q, kWave);
@@ -304,8 +309,8 @@ __global__ __launch_bounds__(kWave * WPB) void k_ffm_row_phase_lds(FRowArgs a, i
   __syncthreads();
   // 3. outputs
   double* C = a.contrib + (size_t)(valid ? a.toff[pos] - a.t_base : 0) * F * Kp;
-  for (int ob = 0; ob < n_out; ob += R) {
-    const int o = ob + g;
+  for (int ob = 0; ob < n_out; ob += RW) {
+    const int o = ob + gg;
     if (o < n_out) {
       const int q = o / F, f = o % F;
       const int jq = js[q], fq = fs[q];
@@ -339,8 +344,15 @@ __global__ __launch_bounds__(kWave * WPB) void k_ffm_row_phase_lds(FRowArgs a, i
     }
   }
   part = dev::wave_sum(part);
+  if (COOP) {  // the wavefronts' shares of the prediction, added in wavefront order
+    if (lane == 0) red[wv][1] = part;
+    __syncthreads();
+    part = 0.0;
+    for (int w_ = 0; w_ < WPB; ++w_) part += red[w_][1];
+    __syncthreads();
+  }
   double r_loss = 0.0, r_acc0 = 0.0, r_acc1 = 0.0;
-  if (valid) {
+  if (valid && (!COOP || wv == 0)) {
     const double yh = b0 + part;
     const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
     r_loss = dev::loss_value(O.loss, O.loss_param, y, yh);
@@ -740,10 +752,10 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
   }
   if (lds_bytes > 64 * 1024) {
     if (lds_wpb == 4)
-      NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffm_row_phase_lds<L, OPT, 4>),
+      NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffm_row_phase_lds<L, OPT, 4, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     else
-      NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffm_row_phase_lds<L, OPT, 1>),
+      NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffm_row_phase_lds<L, OPT, 4, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   }
   for (int64_t b = 0; b < P.n_batches; ++b) {
@@ -758,9 +770,9 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
                   W.rec.as<SampleRec>(), W.partsA.as<PartA>()};
       TimedLaunch tl(ctx, "row_phase");
       if (lds_bytes > 0 && lds_wpb == 4)
-        hipLaunchKernelGGL((k_ffm_row_phase_lds<L, OPT, 4>), dim3(nA), dim3(kBlock), lds_bytes, st, ra, m_cap);
+        hipLaunchKernelGGL((k_ffm_row_phase_lds<L, OPT, 4, false>), dim3(nA), dim3(kBlock), lds_bytes, st, ra, m_cap);
       else if (lds_bytes > 0)
-        hipLaunchKernelGGL((k_ffm_row_phase_lds<L, OPT, 1>), dim3(nA), dim3(kWave), lds_bytes, st, ra, m_cap);
+        hipLaunchKernelGGL((k_ffm_row_phase_lds<L, OPT, 4, true>), dim3(nA), dim3(kBlock), lds_bytes, st, ra, m_cap);  // one sample per workgroup
       else
         hipLaunchKernelGGL((k_ffm_row_phase<L, OPT>), dim3(nA), dim3(kBlock), 0, st, ra);
     }
