@@ -534,12 +534,12 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
             opt._epoch(X, None, 0, n)
             opt.it += n
         ctx.synchronize()
-        fam = {f: ctx.timing_get(f) for f in ("row_phase", "singles", "col_phase", "heavy_partial", "heavy_apply", "schedule")}
+        fam = {f: ctx.timing_get(f) for f in ("row_phase", "singles", "col_phase", "heavy_partial", "heavy_apply", "refresh", "schedule")}
         ctx.timing_enable(False)
         n_batches = fam["row_phase"][0] / reps
         per_batch_ms = {f: (fam[f][1] / fam[f][0] if fam[f][0] else 0.0) for f in fam}
         pair_ms = (per_batch_ms["row_phase"] + per_batch_ms["singles"] + per_batch_ms["col_phase"]
-                   + (fam["heavy_partial"][1] + fam["heavy_apply"][1]) / max(fam["row_phase"][0], 1))
+                   + (fam["heavy_partial"][1] + fam["heavy_apply"][1] + fam["refresh"][1]) / max(fam["row_phase"][0], 1))
         bps = algorithmic_bytes_per_sample(wl["solver"], m, k, n_orders, F)
         units = n / n_batches
         achieved = bps * units / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0

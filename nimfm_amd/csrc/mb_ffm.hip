@@ -724,6 +724,61 @@ __global__ __launch_bounds__(kBlock) void k_ffm_col_phase(FColArgs a) {
   }
 }
 
+// AdaGrad, start of a mini-batch: update() (optimizer/adagrad.nim:87-110) of everything the batch touches, ONCE per
+// (feature, field) -- P = -eta0 g_sum / (eta0 it' beta + sqrt(g_norm)), viol += |stored - new|, stored = new; likewise the
+// linear weights of the batch's features and the intercept.  The row phase then reads the stored parameters (one row
+// per touch instead of the two state rows, and no square root / division per touch: a feature of cfg4 is read by ~5
+// samples of a batch, and the row phase was bound by instruction issue) and the column phase only adds to the state.
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_ffm_refresh(ModelView M, OptView O, const int32_t* __restrict__ ucol, int64_t u0,
+                                                        int64_t u1, const double* __restrict__ it0p, double it_b,
+                                                        double* __restrict__ parts) {
+  constexpr int R = kWave / L;
+  __shared__ double red[kWavesPerBlock];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int g = lane / L, l = lane % L;
+  const int F = M.nb;
+  const int64_t unit = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * R + g;
+  const int64_t u = u0 + unit / F;
+  const int f = (int)(unit % F);
+  const double itp = (it0p[0] + it_b) - 1.0;
+  double viol = 0.0;
+  if (u < u1) {
+    const int64_t j = ucol[u];
+    const size_t e = M.row(f, j) * M.Kp + 2 * l;
+    const double2 g2 = *reinterpret_cast<const double2*>(O.G + e), n2 = *reinterpret_cast<const double2*>(O.N + e);
+    const double tmp = O.eta0 * itp * O.beta;
+    double2 p;
+    p.x = dev::adagrad_param(g2.x, n2.x, O.eta0, tmp);
+    p.y = dev::adagrad_param(g2.y, n2.y, O.eta0, tmp);
+    if (O.track_viol) {
+      const double2 st = *reinterpret_cast<const double2*>(M.P + e);
+      viol += fabs(st.x - p.x) + fabs(st.y - p.y);
+    }
+    *reinterpret_cast<double2*>(M.P + e) = p;
+    if (f == 0 && l == 0 && M.fit_linear) {  // fit_linear.nim:50-57
+      const double wt = M.w[j];
+      const double wj = -O.eta0 * O.Gw[j] / (itp * O.eta0 * O.alpha + sqrt(O.Nw[j]));
+      viol += fabs(wt - wj);
+      M.w[j] = wj;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && M.fit_intercept) {
+    const double old = M.sc[SC_INTERCEPT];
+    const double nb_ = -O.eta0 * O.gsc[0] / (sqrt(O.gsc[1]) + O.eta0 * itp * O.alpha0);
+    viol += fabs(old - nb_);
+    M.sc[SC_INTERCEPT] = nb_;
+  }
+  viol = dev::wave_sum(viol);
+  if (lane == 0) red[wv] = viol;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0;
+    for (int w_ = 0; w_ < kWavesPerBlock; ++w_) v += red[w_];
+    parts[blockIdx.x] = v;
+  }
+}
+
 template <int L, int OPT>
 static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const OptView& O, const Plan& P, MbWork& W,
                    const std::vector<int64_t>& t_base) {
@@ -737,6 +792,8 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
   // LDS-resident neighbourhood (k_ffm_row_phase_lds): rows <= 64 entries, <= 64 fields, at most 64 KiB
   // per wavefront (2 workgroups per CU at 160 KiB); NFM_FFM_LDS=0 falls back to the generic kernel
   static const bool lds_on = !(getenv("NFM_FFM_LDS") && atoi(getenv("NFM_FFM_LDS")) == 0);
+  static const bool refresh_on = !(getenv("NFM_FFM_REFRESH") && atoi(getenv("NFM_FFM_REFRESH")) == 0);  // AdaGrad: k_ffm_refresh
+  static const bool refresh_force = getenv("NFM_FFM_REFRESH") && atoi(getenv("NFM_FFM_REFRESH")) == 2;
   const int m_cap = (int)std::max<int64_t>(X.max_row, 1);
   size_t lds_bytes = 0;
   int lds_wpb = 4;
@@ -761,9 +818,23 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
   for (int64_t b = 0; b < P.n_batches; ++b) {
     const int64_t p0 = P.bat_pos[b];
     const int len = (int)(P.bat_pos[b + 1] - p0);
-    const int use_stored = (OPT == OPT_ADAGRAD && P.first_singleton && b == 0) ? 1 : 0;
+    int use_stored = (OPT == OPT_ADAGRAD && P.first_singleton && b == 0) ? 1 : 0;
     const int wpb = lds_bytes > 0 ? lds_wpb : kWavesPerBlock;
     const int nA = (len + wpb - 1) / wpb;
+    int nR = 0;  // workgroups of the refresh pass: their viol partials sit in front of the column phase's
+    // worth its pass over the batch's (feature, field) units when a unit is read by several samples of the batch (cfg4:
+    // 5.2 touches per feature, 4.8e7 -> 5.1e7 samples/s; the 39-field shape: 2.7, 1.3e7 -> 1.16e7: not there)
+    const bool refresh = OPT == OPT_ADAGRAD && !use_stored && refresh_on &&
+                         (refresh_force || (double)(t_base[b + 1] - t_base[b]) >= 4.0 * (double)(P.bat_uoff[b + 1] - P.bat_uoff[b]));
+    if (refresh) {
+      const int64_t ur0 = P.bat_uoff[b], ur1 = P.bat_uoff[b + 1];
+      const int per_block_r = kWavesPerBlock * R;
+      nR = (int)std::max<int64_t>(1, ((ur1 - ur0) * M.nb + per_block_r - 1) / per_block_r);
+      TimedLaunch tl(ctx, "refresh");
+      hipLaunchKernelGGL((k_ffm_refresh<L>), dim3(nR), dim3(kBlock), 0, st, M, O, P.ucol.as<int32_t>(), ur0, ur1, it0p, (double)p0,
+                         W.partsB.as<double>() + (b & 1) * half);
+      use_stored = 1;  // row and column phase take the parameters as stored
+    }
     {
       FRowArgs ra{X, M, O, P.has_perm ? P.perm.as<int64_t>() : nullptr, P.toff.as<int64_t>(), P.begin, p0, t_base[b], len,
                   use_stored, (double)p0, it0p, OPT == OPT_SGD ? Stab + 2 * b : M.sc, W.contrib.as<double>(),
@@ -785,7 +856,7 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
                   P.tq.as<int64_t>(), u0, u1, t_base[b], OPT == OPT_SGD ? Stab + 2 * b : M.sc,
                   OPT == OPT_SGD ? Stab + 2 * (b + 1) : M.sc, OPT == OPT_SGD ? Dtab + 4 * b : nullptr,
                   OPT == OPT_SGD ? W.Ftab.as<double>() + (size_t)b * 2 * kFtab : nullptr, W.contrib.as<double>(),
-                  W.rec.as<SampleRec>(), W.partsB.as<double>() + (b & 1) * half, W.partsA.as<PartA>(),
+                  W.rec.as<SampleRec>(), W.partsB.as<double>() + (b & 1) * half + nR, W.partsA.as<PartA>(),
                   W.partsB.as<double>() + ((b + 1) & 1) * half, W.out_acc.as<double>(), (double)p0, (double)len, it0p,
                   use_stored, nA, n_prev};
       {
@@ -796,7 +867,7 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
       if (P.bat_hoff[b + 1] > P.bat_hoff[b]) {  // features with more than kHeavyTouches touches in this batch
         const int PW = 2 * M.Kp + 4;
         FHeavyArgs ha{P.hv_u.as<int64_t>(), P.hv_seg0.as<int64_t>(), P.bat_hoff[b], P.bat_hoff[b + 1], P.bat_soff[b],
-                      P.bat_soff[b + 1], W.hpart.as<double>(), W.partsB.as<double>() + (b & 1) * half + nB, PW, 0};
+                      P.bat_soff[b + 1], W.hpart.as<double>(), W.partsB.as<double>() + (b & 1) * half + nR + nB, PW, 0};
         const int64_t units = (ha.s1 - ha.s0) * M.nb;
         const int nsb = (int)((units + per_block - 1) / per_block);
         nH = (int)(((ha.h1 - ha.h0) * M.nb + kWavesPerBlock - 1) / kWavesPerBlock);  // one wavefront per (feature, field)
@@ -807,7 +878,7 @@ static int run_ffm(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const Opt
         TimedLaunch tl(ctx, "heavy_apply");
         hipLaunchKernelGGL((k_ffm_heavy_apply<L, OPT>), dim3(nH), dim3(kBlock), 0, st, ca, ha);
       }
-      n_prev = nB + nH;
+      n_prev = nR + nB + nH;
     }
     if (W.after_batch) NFM_TRY(W.after_batch(b));
   }
@@ -836,7 +907,7 @@ int mb_ffm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& 
   NFM_TRY(W.contrib.ensure(sizeof(double) * (size_t)max_t * M.nb * M.Kp));
   NFM_TRY(W.rec.ensure(sizeof(SampleRec) * (size_t)std::max<int64_t>(P.max_batch, 1)));
   NFM_TRY(W.partsA.ensure(sizeof(PartA) * (size_t)(P.max_batch + 1)));  // one partial per workgroup, workgroups of >= 1 wavefront
-  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(P.max_unique * M.nb / kWavesPerBlock + P.max_heavy * M.nb / kWavesPerBlock + 4)));
+  NFM_TRY(W.partsB.ensure(sizeof(double) * 2 * (size_t)(2 * (P.max_unique * M.nb / kWavesPerBlock) + P.max_heavy * M.nb / kWavesPerBlock + 8)));
   NFM_TRY(W.hpart.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_segs, 1) * M.nb * (2 * M.Kp + 4)));
   NFM_TRY(W.Dtab.ensure(sizeof(double) * 4 * (size_t)(P.n_batches + 1)));
   NFM_TRY(W.Stab.ensure(sizeof(double) * 2 * (size_t)(P.n_batches + 1)));
