@@ -23,7 +23,7 @@ def means(path, counter):
             name = r["Kernel_Name"]
             key = None
             for pat, k_ in (("k_row_phase", "row_phase"), ("k_ffm_row_phase", "row_phase"), ("k_col_phase", "col_phase"), ("k_col_sparse", "col_phase"),
-                            ("k_ffm_col_phase", "col_phase"), ("k_heavy_partial", "heavy_partial"), ("k_heavy_apply", "heavy_apply"),
+                            ("k_ffm_col_phase", "col_phase"), ("k_ffm_refresh", "refresh"), ("k_heavy_partial", "heavy_partial"), ("k_heavy_apply", "heavy_apply"),
                             ("k_ffm_heavy_partial", "heavy_partial"), ("k_ffm_heavy_apply", "heavy_apply"),
                             ("k_singles", "singles"), ("k_psgd_", "psgd_step"), ("k_prox_", "psgd_step")):
                 if pat in name:
