@@ -112,7 +112,8 @@ __global__ void k_classify(int64_t T, const KeyT* __restrict__ keys, const uint3
     const bool first = r == 0 || keys[r - 1] != key;
     const bool last = r + 1 == T || keys[r + 1] != key;
     const bool is_single = use_singles && first && last;
-    if (single_un) single_un[vals[r]] = is_single ? 1 : 0;
+    if (single_un && is_single) single_un[vals[r]] = 1;  // the table is zeroed beforehand: a scattered byte per SINGLE touch only
+                                                         // (this pass is bound by the number of scattered writes)
     multi[r] = is_single ? 0 : 1;
     head[r] = (!is_single && first) ? 1 : 0;
   }
@@ -733,7 +734,10 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
   //    by the row phase itself (flag per nnz in sample order); only features with >= 2 touches go
   //    to the column phase.  Their touches are compacted, payload in sorted order.
   DevBuf multi, mpos, head, uidx;
-  if (use_singles) NFM_TRY(P.single.alloc(sizeof(uint8_t) * T));
+  if (use_singles) {
+    NFM_TRY(P.single.alloc(sizeof(uint8_t) * T));
+    NFM_HIP_CHECK(hipMemsetAsync(P.single.p, 0, sizeof(uint8_t) * T, st));
+  }
   // flags and their scans in 32 bits (T < 2^31 is checked above): half the traffic of these passes
   NFM_TRY(multi.alloc(sizeof(int32_t) * (T + 1))); NFM_TRY(mpos.alloc(sizeof(int32_t) * (T + 1)));
   NFM_TRY(head.alloc(sizeof(int32_t) * (T + 1))); NFM_TRY(uidx.alloc(sizeof(int32_t) * (T + 1)));
