@@ -520,3 +520,40 @@ def test_announced_permutation_is_only_a_hint():
     assert abs(fm.intercept - b) < 1e-11
     assert_close(fm.w, w, RTOL, ATOL, "w")
     assert_close(fm.P, P, RTOL, ATOL, "P")
+
+
+@pytest.mark.parametrize("dense", [True, False])
+@pytest.mark.parametrize("with_perm", [False, True])
+def test_epoch_over_a_sub_range(dense, with_perm):
+    """nfm_opt_epoch over [begin, end) of the order (what the nCalls callbacks and the Hogwild-style slices use): a dense
+    shape takes its plan from the column-major twin -- the samples outside the range must drop out of every column's touch
+    list --, a sparse one from the sort; three consecutive ranges must equal the CPU restatement run over the same ranges."""
+    n, k, B = 3000, 8, 256
+    d, m = (100, 12) if dense else (20000, 12)
+    Xo = random_csr(n, d, m, seed=77)
+    rng = np.random.default_rng(8)
+    y = rng.standard_normal(n)
+    P0, w0 = rng.standard_normal((1, k, d)) * 0.05, np.zeros(d)
+    perm = rng.permutation(n).astype(np.int64) if with_perm else None
+    X = to_gpu(Xo)
+    X.set_targets(y)
+    for solver in ("sgd", "adagrad"):
+        fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, 0.0)
+        opt = (nf.newSGD if solver == "sgd" else nf.newAdaGrad)(maxIter=1, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B)
+        opt._handle(fm, X.ctx, "minibatch")
+        P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
+        st = O.AdaState(1, d, k, d)
+        for lo, hi in ((0, 700), (700, 2950), (2950, n)):
+            ls, vs = opt._epoch(X, perm, lo, hi)
+            opt.it += hi - lo
+            if solver == "sgd":
+                b, it, lw, vw = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, b, O.sgd_cfg(), B, perm=perm, begin=lo, end=hi, it=it)
+            else:
+                b, it, lw, vw = O.fm_adagrad_epoch_mb(Xo, y, 2, P, w, b, O.adagrad_cfg(), B, st, perm=perm, begin=lo, end=hi, it=it)
+            assert_close([ls, vs], [lw, vw], 1e-9, 1e-12, "%s loss / viol of [%d, %d)" % (solver, lo, hi))
+        opt._finalize_into(fm)
+        if solver == "adagrad":
+            b = O.fm_adagrad_finalize(2, P, w, b, O.adagrad_cfg(), it, st)
+        assert abs(fm.intercept - b) < 1e-11
+        assert_close(fm.w, w, RTOL, ATOL, solver + " w")
+        assert_close(fm.P, P, RTOL, ATOL, solver + " P")
