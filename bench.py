@@ -401,7 +401,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         # sync_period mini-batches on a second stream beside the next period's mini-batches, exactly at the end of the
         # epoch; torch.distributed only carried the group id (dp.Group.from_torch, in main)
         sync_period = args.sync_period if args.sync_period >= 0 else (128 if n // batch >= 512 else (64 if n // batch >= 256 else 0))
-        opt.setDataParallel(run_training.group, sync_period, True)
+        opt.setDataParallel(run_training.group, sync_period, True, args.combine)
 
     def step(perm=None):
         ls, vs = opt._epoch(X, perm, 0, n)  # with a group: the sums over all ranks
@@ -579,7 +579,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                        "samples_per_gpu": n, "batch": batch,
                        "parallelism": ("%d ranks, one process per GPU, contiguous sample shards; replicas %s in the library over "
                                        "RCCL every %s on a second stream + exactly at the end of every epoch"
-                                       % (world, "averaged" if wl["solver"] == "sgd" else "state-summed",
+                                       % (world, ("increments %s" % ("averaged" if args.combine == "mean" else "summed")) if wl["solver"] == "sgd" else "state-summed",
                                           ("%d mini-batches" % sync_period) if sync_period else "epoch (no mid-epoch exchange)"))
                        if use_dp else "1 GPU"},
             "last_step": {"mean_loss": last[0] / (n * world), "viol": last[1]}, "predict": pred, "exact_order": exact,
@@ -603,6 +603,8 @@ def main():
     ap.add_argument("--sync-period", type=int, default=-1,
                     help="N > 1: mini-batches between exchanges (0 = only at the end of every epoch; default 128 for epochs "
                          "of >= 512 mini-batches, 64 for >= 256, else 0)")
+    ap.add_argument("--combine", default="mean", choices=["mean", "sum"],
+                    help="N > 1, SGD: how the ranks' increments are combined at an exchange (DESIGN.md section 6)")
     ap.add_argument("--psgd-shape", default="", help="--workload psgd: d,m,k instead of the ml-100k shape")
     args = ap.parse_args()
 
