@@ -614,6 +614,8 @@ def main():
         return psgd_leg(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)  # before anything that could touch a GPU
+    if "WORLD_SIZE" in os.environ:  # a rank says so before the slow imports (tests/test_bench_spawn.py counts these lines)
+        print("[bench.py] rank %s of %s started" % (os.environ.get("RANK", "0"), os.environ["WORLD_SIZE"]), file=sys.stderr, flush=True)
     import torch
 
     import nimfm_amd as nf

@@ -239,3 +239,40 @@ def test_stream_file_in_row_blocks(tmp_path):
     b = O.fm_adagrad_finalize(2, P, w, b, cfg, it, st)
     assert_close(fm.P, P, 1e-9, 1e-12, "P, mini-batch")
     assert abs(fm.intercept - b) < 1e-11
+
+
+def test_reference_literal_dataset_through_the_device(tmp_path):
+    """The literal 4 x 6 matrix and targets of the reference's dataset suite (tests/test_dataset.nim:124-128, committed as
+    tests/golden/ref_dataset_literal.json) pushed through every loader of this path, as its tests do (:130-156):
+    dump -> GPU loadSVMLightFile -> compare with the literal; convertSVMLightFile on the GPU -> STREAMCSR + label files ->
+    nfm_dataset_load_stream -> compare; the same file in row blocks (cacheRows = 2: an empty row starts the second block)."""
+    from test_oracle_ingest import dense_of, literal_text, ref_literal
+    dense, y = ref_literal()
+    src = tmp_path / "testsample.svm"
+    src.write_text(literal_text(dense, y))
+
+    def as_dict(ds, yy):
+        indptr, indices, data, _ = ds.to_host()
+        return {"indptr": indptr, "indices": indices, "data": data, "n_features": ds.nFeatures, "y": yy}
+
+    ds, yg = nf.loadSVMLightFile(str(src))
+    assert ds.nSamples == 4 and ds.nFeatures == 6 and ds.nnz == 5
+    assert np.array_equal(dense_of(as_dict(ds, yg)), dense) and np.array_equal(yg, y)
+    nf.convertSVMLightFile(str(src), str(tmp_path / "testsample"), str(tmp_path / "testlabel"))
+    xb, yb = ingest.convert_svmlight(src.read_text())
+    assert (tmp_path / "testsample").read_bytes() == xb and (tmp_path / "testlabel").read_bytes() == yb
+    dss, ys = nf.newStreamCSRDataset(str(tmp_path / "testsample"), str(tmp_path / "testlabel"))
+    assert np.array_equal(dense_of(as_dict(dss, ys)), dense) and np.array_equal(ys, y)
+    Xs, ys2 = nf.newStreamCSRDataset(str(tmp_path / "testsample"), str(tmp_path / "testlabel"), cacheRows=2)
+    assert Xs.blocks() == [(0, 2), (2, 4)] and np.array_equal(ys2, y)
+    got = np.vstack([dense_of(as_dict(Xs.load(r0, r1), None)) if Xs.load(r0, r1).nnz else np.zeros((r1 - r0, 6)) for r0, r1 in Xs.blocks()])
+    assert np.array_equal(got, dense)
+    # and the loaded matrix scores like the literal: decisionFunction of a fixed model on both
+    import oracle as O
+    rng = np.random.default_rng(5)
+    P0, w0 = rng.standard_normal((1, 3, 6)), rng.standard_normal(6)
+    fm = nf.newFactorizationMachine("regression", nComponents=3, warmStart=True)
+    fm.set_params(P0, w0, 0.25)
+    want = O.slow_fm_decision_function(dense, 2, P0, w0, 0.25, 0)
+    assert np.allclose(fm.decisionFunction(ds), want, rtol=1e-12, atol=1e-12)
+    assert np.allclose(fm.decisionFunction(Xs), want, rtol=1e-12, atol=1e-12)

@@ -95,3 +95,43 @@ def test_stream_format_round_trip():
         for k in ("indptr", "indices", "data", "y", "n_features"):
             assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (name, k)
         assert b["max"] == a["data"].max() and b["min"] == a["data"].min() and b["nnz"] == len(a["data"])
+
+
+def ref_literal():
+    """the one literal dataset the reference's tests hold near this path (tests/test_dataset.nim:124-128)"""
+    import json
+    with open(os.path.join(GOLD, "ref_dataset_literal.json")) as f:
+        lit = json.load(f)
+    return np.array(lit["data"], dtype=np.float64), np.array(lit["yTrue"], dtype=np.float64)
+
+
+def dense_of(r):
+    n = len(r["indptr"]) - 1
+    out = np.zeros((n, r["n_features"]))
+    for i in range(n):
+        for q in range(r["indptr"][i], r["indptr"][i + 1]):
+            out[i, r["indices"][q]] = r["data"][q]
+    return out
+
+
+def literal_text(dense, y):
+    """dumpSVMLightFile(f, X: seq[seq[float64]], y) (dataset.nim:808-822): zeros skipped, 1-based, no final newline"""
+    rows, cols = np.nonzero(dense)
+    indptr = np.concatenate([[0], np.cumsum((dense != 0).sum(1))])
+    return ingest.dump_svmlight(indptr, cols, dense[rows, cols], y)
+
+
+def test_reference_literal_dataset():
+    """tests/test_dataset.nim:130-156 ('Test CSRDataset', 'Test streamLabel') on the restatement: dump -> load -> compare
+    with the literal (checkDenseCSR, :7-28), dump the loaded data again -> load -> compare, convert -> stream files."""
+    dense, y = ref_literal()
+    text = literal_text(dense, y)
+    assert text == "-1.0 3:1.0 5:-4.2\n2.0 1:-3.0\n-10.0\n5.2 4:-5.0 6:103.2"
+    r = ingest.load_svmlight(text)
+    assert r["n_features"] == 6 and len(r["y"]) == 4 and len(r["data"]) == int((dense != 0).sum())
+    assert np.array_equal(dense_of(r), dense) and np.array_equal(r["y"], y)
+    r2 = ingest.load_svmlight(ingest.dump_svmlight(r["indptr"], r["indices"], r["data"], r["y"]))
+    assert np.array_equal(dense_of(r2), dense)
+    xb, yb = ingest.convert_svmlight(text)
+    s = ingest.read_stream(xb, yb)
+    assert np.array_equal(dense_of(s), dense) and np.array_equal(s["y"], y)
