@@ -81,6 +81,7 @@ struct nfm_opt {
   bool state_ready = false;
   MbWork W;
   std::unique_ptr<Plan> plan;
+  std::unique_ptr<SeqWin> seqwin;  // NFM_MODE_SEQUENTIAL: dependency table and mailboxes of the window kernel (seqwin.hip)
   // predictAllWithGrad: the one-batch plan of a dataset and its scratch, kept between calls (PGD-style solvers ask for
   // the full gradient of the same data once per iteration)
   MbWork Wg;
@@ -911,7 +912,13 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         NFM_HIP_CHECK(hipMemcpyAsync(o->perm_dev.p, perm + begin, sizeof(int64_t) * ns, hipMemcpyHostToDevice, st));
         perm_dev = o->perm_dev.as<int64_t>() - begin;  // indexed by absolute position
       }
-      NFM_TRY(launch_sequential(ctx, o->kind, ds->v, M, o->o, perm_dev, begin, end, o->it, ds->max_row + m->n_aug, o->out2.as<double>()));
+      if (seq_window_supported(M, ds->max_row + m->n_aug, ns, ds->v.nnz, ctx->n_cu)) {
+        if (!o->seqwin) o->seqwin.reset(new SeqWin());
+        NFM_TRY(launch_sequential_window(ctx, o->kind, ds->v, M, o->o, perm_dev, begin, end, o->it, ds->max_row + m->n_aug,
+                                         o->out2.as<double>(), o->seqwin.get(), (ds->uid << 20) ^ ds->serial, perm != nullptr));
+      } else {
+        NFM_TRY(launch_sequential(ctx, o->kind, ds->v, M, o->o, perm_dev, begin, end, o->it, ds->max_row + m->n_aug, o->out2.as<double>()));
+      }
       NFM_HIP_CHECK(hipMemcpyAsync(out2, o->out2.p, sizeof(out2), hipMemcpyDeviceToHost, st));
       NFM_HIP_CHECK(hipStreamSynchronize(st));
     } else {

@@ -32,6 +32,18 @@ struct OptView {
 int launch_sequential(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O,
                       const int64_t* perm_dev, int64_t begin, int64_t end, int64_t it0, int m_cap,
                       double* out2_dev /*{loss_sum, viol_sum}*/);
+// ---- seqwin.hip: the same order as launch_sequential, run as a dependency window over the chip ----
+struct SeqWin {           // kept on the optimizer between calls
+  DevBuf prev;            // [nnz] per stored entry: previous position of the call with the same feature
+  DevBuf scales, mail, ctl;
+  bool valid = false, had_perm = false;
+  uint64_t ds_uid = 0;
+  int64_t begin = 0, end = 0, nnz = 0;
+};
+bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz, int n_cu);
+int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O,
+                             const int64_t* perm_dev, int64_t begin, int64_t end, int64_t it0, int m_cap,
+                             double* out2_dev /*{loss_sum, viol_sum}*/, SeqWin* sw, uint64_t ds_uid, bool perm_is_callers);
 // AdaGrad finalize (optimizer/adagrad.nim:65-84): all parameters from the state with it' = it-1
 int launch_adagrad_finalize(nfm_ctx* ctx, const ModelView& M, const OptView& O, int64_t it);
 

@@ -1,0 +1,803 @@
+// nimfm_amd/csrc/seqwin.hip -- NFM_MODE_SEQUENTIAL at throughput: the reference's one-sample-at-a-time order
+// (optimizer/sgd.nim:246-258,294-308; optimizer/adagrad.nim:169-184) run as a DEPENDENCY WINDOW over the whole chip.
+//
+// What the order really serialises.  Sample t of the order reads and rewrites (a) the parameter rows of its own
+// features, (b) the intercept (SGD) / the intercept's state (AdaGrad), (c) the step counter and, for SGD, the two lazy
+// L2 scales.  (c) does not depend on the data: a product of factors that are functions of `it` alone.  (b) is a scalar
+// chain  b_t -> yhat_t = ((b_t + w x ...) + ...) + anova -> dL_t -> b_{t+1}  that nothing can shorten without changing
+// the rounding.  (a) ties t only to the EARLIER samples that share a feature with it -- at d = 1e6, 64 entries per row,
+// two samples do with probability 0.4 %.  So:
+//
+//   * W worker wavefronts (one workgroup = one wavefront = one CU each) take the samples round-robin: worker s owns
+//     positions s, s + W, s + 2W ...  A worker waits until every earlier sample that shares a feature with its sample has
+//     written its rows (a per-entry "previous position with this feature" table, built once per order by one sort, and a
+//     completion counter per worker), gathers the rows, forms everything of predictWithGrad (sgd.nim:191-202) that does
+//     not need the intercept -- the per-factor sums in the reference's entry order, their sum over the factors in
+//     ascending order, the products w_j x_j -- and posts them to its mailbox.
+//   * ONE conductor workgroup walks the samples in order: a fetch wavefront collects the mailboxes (several loads in
+//     flight) into an LDS ring, a chain wavefront adds  b + w_1 x_1 + ... + w_m x_m + anova  in the reference's order,
+//     takes dloss, steps the intercept (or its AdaGrad state) and posts {dL, yhat} back.  This chain -- about m + 100
+//     dependent fp64 operations per sample -- is the one thing that runs at the speed of a single thread; everything else
+//     of the step is spread over the workers.
+//   * The worker then performs update() (sgd.nim:205-243 / adagrad.nim:113-134) for its rows, drains its stores and
+//     bumps its completion counter.
+//   * SGD's scale chain (scaling_P *= 1 - eta_P beta, sgd.nim:233-234) is produced ahead of the launch by one
+//     wavefront (k_win_scales: step sizes of 64 samples in parallel, the two products in order); it also finds the
+//     sample after which a scale drops below 1e-9 (resetScaling, sgd.nim:116-131): the launch ends there, the dense
+//     rescale runs, the next launch continues.
+//
+// Same arithmetic, same order of every sum as k_sequential_pipe (seq.hip): parameters, linear weights, intercept and
+// AdaGrad state come out BIT FOR BIT equal to the one-workgroup kernels (tests/test_gpu_seqwin.py); only the epoch's
+// loss / viol totals are associated differently (per worker, then in worker order).
+//
+// Cross-CU visibility (MI355X: per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by another
+// CU's stores): every byte that one workgroup writes and another reads during the launch -- parameter rows, linear
+// weights, AdaGrad state, mailboxes, counters -- is stored AND loaded with agent-scope relaxed atomics (global_load /
+// global_store ... sc1, 8 bytes), every signalling store follows an s_waitcnt vmcnt(0) of the wavefront that wrote the
+// data, and a consumer loads the data only after ITS OWN poll has seen the signal.  Mailbox words are self-validating
+// (a reserved signalling-NaN pattern means "not written yet"), so they need no separate flag.  One workgroup per CU
+// (LDS request), W + 1 <= number of CUs: all workgroups are resident, every wait is on a workgroup that is running.
+// Every spin has a wall-clock limit and watches an abort word: a launch always drains.
+#include <hipcub/hipcub.hpp>
+#include <stdlib.h>
+
+#include "fm_device.h"
+#include "opt_views.h"
+
+namespace nfm {
+
+typedef unsigned long long ull;
+constexpr ull kWinSentinel = 0x7FF4DEADBEEF0000ull;  // a signalling NaN no arithmetic produces (results are quiet NaNs)
+constexpr ull kWinQuietNaN = 0x7FF8000000000000ull;
+constexpr int kWinRing = 8;    // LDS ring slots between the conductor's fetch and chain wavefronts (power of two)
+constexpr int kWinDepth = 4;   // mailboxes the fetch wavefront has requested ahead (must stay < W, see below)
+constexpr int kWinHdr = 4;     // mailbox header: anova sum, target, eta(alpha0) | eta0 (it-1) alpha0, spare
+constexpr int kWinMaxNL = 5;   // 64-lane loads per mailbox: rows of up to 316 entries
+constexpr long long kWinTimeoutTicks = 400000000ll;  // 4 s of the 100 MHz wall clock without progress: abort
+
+struct WinArgs {
+  CsrView X;
+  ModelView M;
+  OptView O;
+  const int64_t* perm;    // absolute positions, or null
+  int64_t begin;          // first position of the call
+  int64_t seg0, n_seg;    // this launch: positions begin + seg0 ... begin + seg0 + n_seg - 1
+  int64_t it0;            // step counter of the launch's first sample
+  const int32_t* prev;    // [nnz] position (relative to `begin`) of the previous sample of the call with this feature, -1: none
+  const double* scales;   // SGD: [ns][2] {scale_P, scale_w} BEFORE each sample of the call
+  ull* fwd;               // [W][2][FW] worker -> conductor
+  ull* res;               // [W][2][2]  conductor -> worker {dL, yhat}
+  unsigned* completed;    // [W] samples of this launch a worker has finished
+  unsigned* ctrl;         // [0]: abort
+  double* partial;        // [W + 1][2] {loss, viol} per worker, last: the conductor's
+  int W, lgW, m_cap, FW, lgKp;
+};
+
+__device__ __forceinline__ ull ld_u64(const ull* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_u64(ull* p, ull v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ ull mail_bits(double v) {  // a value as a mailbox word: never the "empty" pattern
+  return v != v ? kWinQuietNaN : (ull)__double_as_longlong(v);
+}
+__device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// A spin that always ends: the abort word of the launch and a wall-clock limit, looked at every 64 rounds.
+struct Spin {
+  long long t0;
+  int n = 0;
+  __device__ Spin() : t0(wall_clock64()) {}
+  // true: give up (the launch is being aborted)
+  __device__ __forceinline__ bool wait(unsigned* ctrl) {
+    __builtin_amdgcn_s_sleep(2);
+    if ((++n & 63) != 0) return false;
+    if (ld_u32(ctrl) != 0u) return true;
+    if (wall_clock64() - t0 > kWinTimeoutTicks) {
+      st_u32(ctrl, 1u);
+      return true;
+    }
+    return false;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// worker: one wavefront, lanes (r, s) = (row slot, factor), Kp lanes per row, R = 64 / Kp rows per instruction
+// ------------------------------------------------------------------------------------------------------------------
+template <int OPT>
+__device__ void win_worker(const WinArgs& a, const int slot, double* lds) {
+  const CsrView& X = a.X;
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  constexpr bool ADA = OPT == OPT_ADAGRAD;
+  constexpr int U = 4;  // rows a lane requests together
+  const int lane = threadIdx.x;
+  const int Kp = M.Kp, lgK = a.lgKp, k = M.k, mc = a.m_cap;
+  const int R = kWave >> lgK, r = lane >> lgK, s = lane & (Kp - 1);
+  const int W = a.W, lgW = a.lgW;
+  double* Pl = lds;                                   // [mc][Kp] stored parameter values of the sample's rows
+  double* Tl = Pl + (size_t)mc * Kp;                  // [mc][Kp] x_q p_qs, then the derivative
+  double* Gl = Tl + (size_t)mc * Kp;                  // AdaGrad: [mc][Kp] g_sum
+  double* Nl = Gl + (ADA ? (size_t)mc * Kp : 0);      // AdaGrad: [mc][Kp] g_norm
+  double* red = Nl + (ADA ? (size_t)mc * Kp : 0);     // [64]
+  double* vl = red + kWave;                           // [mc] values
+  double* wl = vl + mc;                               // [mc] stored linear weights (AdaGrad: after update())
+  double* gwl = wl + mc;                              // AdaGrad: [mc] g_sum of the linear term
+  double* nwl = gwl + (ADA ? mc : 0);                 // AdaGrad: [mc] g_norm
+  int* jl = reinterpret_cast<int*>(nwl + (ADA ? mc : 0));  // [mc] feature ids
+  int* pl = jl + mc;                                       // [mc] previous position with the same feature
+  unsigned* cnt = reinterpret_cast<unsigned*>(pl + mc);    // [W] completion counters as last seen
+  for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
+  double loss_acc = 0.0, viol_acc = 0.0;
+
+  for (int64_t u = slot; u < a.n_seg; u += W) {
+    const int64_t pos = a.seg0 + u, pa = a.begin + pos;
+    const int64_t i = a.perm ? a.perm[pa] : pa;
+    const int64_t q0 = X.indptr[i];
+    const int m = (int)(X.indptr[i + 1] - q0);
+    const double y = dev::target_of(X.y[i], M.task);
+    const int64_t it = a.it0 + u;
+    const double itf = (double)it;
+    const int par = (int)((u >> lgW) & 1);
+    ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
+    ull* rp = a.res + (size_t)(slot * 2 + par) * 2;
+    for (int q = lane; q < m; q += kWave) {
+      jl[q] = X.indices[q0 + q];
+      vl[q] = X.data[q0 + q];
+      pl[q] = a.prev[q0 + q];
+    }
+    compiler_fence();
+
+    // ---- A. every earlier sample of this launch that shares a feature has written its rows ----
+    {
+      Spin sp;
+      bool first = true;
+      while (true) {
+        bool need = false;
+        for (int q = lane; q < m; q += kWave) {
+          const int64_t v = (int64_t)pl[q] - a.seg0;
+          if (v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW)) need = true;
+        }
+        if (!__any(need)) break;
+        if (!first && sp.wait(a.ctrl)) return;
+        first = false;
+        for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
+        compiler_fence();
+      }
+    }
+
+    // ---- B. rows -> LDS (AdaGrad: update(), adagrad.nim:87-110, for the sample's rows first) ----
+    double sP = 1.0, sw = 1.0;
+    if constexpr (!ADA) {
+      sP = a.scales[2 * pos];
+      sw = a.scales[2 * pos + 1];
+    }
+    const double itp = (double)(it - 1);
+    const double tmpP = O.eta0 * itp * O.beta;
+    for (int qb = 0; qb < m; qb += R * U) {
+      double v_[U], g_[ADA ? U : 1], n_[ADA ? U : 1];
+      int j_[U];
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        const int q = qb + t * R + r;
+        j_[t] = jl[q < m ? q : 0];
+      }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        const size_t e = (size_t)j_[t] * Kp + s;
+        v_[t] = ld_f64(M.P + e);
+        if constexpr (ADA) {
+          g_[t] = ld_f64(O.G + e);
+          n_[t] = ld_f64(O.N + e);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        const int q = qb + t * R + r;
+        if (q < m) {
+          double p = v_[t];
+          if constexpr (ADA) {
+            if (it != 1) {
+              p = dev::adagrad_param(g_[t], n_[t], O.eta0, tmpP);
+              viol_acc += fabs(v_[t] - p);
+              st_f64(M.P + (size_t)j_[t] * Kp + s, p);
+            }
+            Gl[(size_t)q * Kp + s] = g_[t];
+            Nl[(size_t)q * Kp + s] = n_[t];
+          }
+          Pl[(size_t)q * Kp + s] = p;
+          Tl[(size_t)q * Kp + s] = vl[q] * (sP * p);
+        }
+      }
+    }
+    for (int q = lane; q < m; q += kWave) {
+      const int j = jl[q];
+      double wv = ld_f64(M.w + j);
+      if constexpr (ADA) {
+        if (M.fit_linear) {
+          const double gw = ld_f64(O.Gw + j), nw_ = ld_f64(O.Nw + j);
+          gwl[q] = gw;
+          nwl[q] = nw_;
+          if (it != 1) {
+            const double denom = itp * O.eta0 * O.alpha;
+            const double nv = -O.eta0 * gw / (denom + sqrt(nw_));
+            viol_acc += fabs(wv - nv);
+            st_f64(M.w + j, nv);
+            wv = nv;
+          }
+        }
+      }
+      wl[q] = wv;
+    }
+    compiler_fence();
+
+    // ---- C. the per-factor sums over all entries in storage order (sgd.nim:160-170), their sum over the factors in
+    // ascending order (:172-173); every row slot runs them, so every lane ends with its factor's sums ----
+    double a1 = 0.0, a2 = 0.0;
+    for (int qb = 0; qb < m; qb += 8) {
+      double t_[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) t_[t] = Tl[(size_t)(qb + t < m ? qb + t : qb) * Kp + s];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const bool ok = qb + t < m;
+        a1 = ok ? a1 + t_[t] : a1;
+        a2 = ok ? a2 + t_[t] * t_[t] : a2;
+      }
+    }
+    const double kv = (a1 * a1 - a2) / 2;
+    if (r == 0) red[s] = s < k ? kv : 0.0;
+    compiler_fence();
+    double tot = 0.0;
+    for (int sb = 0; sb < k; sb += 8) {
+      double r_[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) r_[t] = red[sb + t < k ? sb + t : sb];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) tot = sb + t < k ? tot + r_[t] : tot;
+    }
+    // the mailbox: header, then the terms of the linear part; past the row's end -0.0, which changes no sum
+    const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
+    for (int e = lane; e < a.FW; e += kWave) {
+      double val;
+      if (e == 0) val = tot;
+      else if (e == 1) val = y;
+      else if (e == 2) val = h2;
+      else if (e == 3) val = 0.0;
+      else {
+        const int q = e - kWinHdr;
+        val = q < m ? (sw * wl[q]) * vl[q] : -0.0;
+      }
+      st_u64(mb + e, mail_bits(val));
+    }
+
+    // ---- D. while the conductor works: the derivative (sgd.nim:176-188) and the step sizes ----
+    for (int qb = 0; qb < m; qb += R * U) {
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        const int q = qb + t * R + r;
+        if (q < m) {
+          const double val = vl[q];
+          const double p = sP * Pl[(size_t)q * Kp + s];
+          Tl[(size_t)q * Kp + s] = val * (a1 - p * val);
+        }
+      }
+    }
+    double eta_w = 0.0, eta_P = 0.0, sPn = 1.0, swn = 1.0;
+    if constexpr (!ADA) {
+      eta_w = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, itf);
+      eta_P = dev::get_eta(O.sched, O.eta0, O.power, O.beta, itf);
+      sPn = sP * (1 - eta_P * O.beta);
+      swn = sw * (1 - eta_w * O.alpha);
+    }
+
+    // ---- E. {dL, yhat} from the conductor ----
+    double dL, yh;
+    {
+      Spin sp;
+      ull rv;
+      while (true) {
+        rv = ld_u64(rp + (lane & 1));
+        if (__all(rv != kWinSentinel)) break;
+        if (sp.wait(a.ctrl)) return;
+      }
+      const double rd = __longlong_as_double((long long)rv);
+      dL = dev::shfl_d(rd, 0);
+      yh = dev::shfl_d(rd, 1);
+    }
+    // both mailboxes back to "empty" for their next use, two samples of this worker from now: these stores have
+    // completed (vmcnt(0) below) before this worker posts its next sample, which the conductor consumes before it can
+    // look at these words again (kWinDepth < W)
+    for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);
+    if (lane < 2) st_u64(rp + lane, kWinSentinel);
+    if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
+
+    // ---- F. update(): sgd.nim:205-243 / updateG(): adagrad.nim:113-134 ----
+    for (int qb = 0; qb < m; qb += R * U) {
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        const int q = qb + t * R + r;
+        if (q < m) {
+          const size_t e = (size_t)jl[q] * Kp + s;
+          const double d_ = Tl[(size_t)q * Kp + s];
+          if constexpr (ADA) {
+            const double grad = dL * d_;
+            st_f64(O.G + e, Gl[(size_t)q * Kp + s] + grad);
+            st_f64(O.N + e, Nl[(size_t)q * Kp + s] + grad * grad);
+          } else {
+            const double p = sP * Pl[(size_t)q * Kp + s];
+            const double update = eta_P * (dL * d_ + O.beta * p);
+            viol_acc += fabs(update);
+            st_f64(M.P + e, (p - update) / sPn);
+          }
+        }
+      }
+    }
+    if (M.fit_linear) {
+      for (int q = lane; q < m; q += kWave) {
+        const int j = jl[q];
+        if constexpr (ADA) {
+          const double gg = dL * vl[q];
+          st_f64(O.Gw + j, gwl[q] + gg);
+          st_f64(O.Nw + j, nwl[q] + gg * gg);
+        } else {
+          const double wj = sw * wl[q];
+          const double update = eta_w * (dL * vl[q] + O.alpha * wj);
+          viol_acc += fabs(update);
+          st_f64(M.w + j, (wj - update) / swn);
+        }
+      }
+    }
+    // ---- G. rows written: tell the waiters ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
+  }
+  viol_acc = dev::wave_sum(viol_acc);
+  if (lane == 0) {
+    a.partial[2 * slot] = loss_acc;
+    a.partial[2 * slot + 1] = viol_acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conductor: wavefront 1 fetches the mailboxes in sample order into an LDS ring, wavefront 0 runs the scalar chain
+// ------------------------------------------------------------------------------------------------------------------
+// the conductor's three LDS words (ready, consumed, abort): volatile accesses in the LDS address space (ds_read / ds_write)
+typedef __attribute__((address_space(3))) unsigned lds_uint;
+__device__ __forceinline__ unsigned ldsv_load(unsigned* p) { return *(volatile lds_uint*)(lds_uint*)p; }
+__device__ __forceinline__ void ldsv_store(unsigned* p, unsigned v) { *(volatile lds_uint*)(lds_uint*)p = v; }
+
+template <int OPT>
+__device__ void win_conductor(const WinArgs& a, double* lds) {
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  constexpr bool ADA = OPT == OPT_ADAGRAD;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int FW = a.FW, W = a.W, lgW = a.lgW;
+  unsigned* c_ready = reinterpret_cast<unsigned*>(lds);  // samples the fetch wavefront has put into the ring
+  unsigned* c_consumed = c_ready + 1;                      // samples the chain wavefront is done with
+  unsigned* c_abort = c_ready + 2;
+  ull* ring = reinterpret_cast<ull*>(lds + 2);  // [kWinRing][FW]
+  if (threadIdx.x == 0) {
+    ldsv_store(c_ready, 0u);
+    ldsv_store(c_consumed, 0u);
+    ldsv_store(c_abort, 0u);
+  }
+  __syncthreads();
+  const int64_t n = a.n_seg;
+  if (wave == 1) {
+    // ---- fetch: kWinDepth mailboxes requested ahead; a word still "empty" means the worker has not posted yet ----
+    const int NL = (FW + kWave - 1) / kWave;
+    ull v[kWinDepth][kWinMaxNL];
+    auto issue = [&](int dd, int64_t u) {
+      const int slot = (int)(u & (W - 1)), par = (int)((u >> lgW) & 1);
+      const ull* mb = a.fwd + (size_t)(slot * 2 + par) * FW;
+#pragma unroll
+      for (int l = 0; l < kWinMaxNL; ++l) {
+        const int e = lane + kWave * l;
+        v[dd][l] = (l < NL && e < FW) ? ld_u64(mb + e) : 0ull;
+      }
+    };
+#pragma unroll
+    for (int dd = 0; dd < kWinDepth; ++dd)
+      if (dd < n) issue(dd, dd);
+    for (int64_t ub = 0; ub < n; ub += kWinDepth) {
+#pragma unroll
+      for (int dd = 0; dd < kWinDepth; ++dd) {
+        const int64_t u = ub + dd;
+        if (u >= n) break;
+        Spin sp;
+        while (true) {
+          bool bad = false;
+#pragma unroll
+          for (int l = 0; l < kWinMaxNL; ++l) bad = bad || v[dd][l] == kWinSentinel;
+          if (!__any(bad)) break;
+          if (sp.wait(a.ctrl)) {
+            ldsv_store(c_abort, 1u);
+            return;
+          }
+          issue(dd, u);
+        }
+        Spin sp2;
+        while ((int64_t)ldsv_load(c_consumed) + kWinRing <= u) {
+          if (sp2.wait(a.ctrl)) {
+            ldsv_store(c_abort, 1u);
+            return;
+          }
+        }
+        ull* dst = ring + (size_t)(u & (kWinRing - 1)) * FW;
+#pragma unroll
+        for (int l = 0; l < kWinMaxNL; ++l) {
+          const int e = lane + kWave * l;
+          if (l < NL && e < FW) dst[e] = v[dd][l];
+        }
+        lds_fence();  // LDS operations of a wavefront execute in order: data, then the counter
+        if (lane == 0) ldsv_store(c_ready, (unsigned)(u + 1));
+        if (u + kWinDepth < n) issue(dd, u + kWinDepth);
+      }
+    }
+    return;
+  }
+  // ---- chain ----
+  double b = M.sc[SC_INTERCEPT];
+  double gsb = 0.0, gnb = 0.0, viol_b = 0.0;
+  if (ADA) {
+    gsb = O.gsc[0];
+    gnb = O.gsc[1];
+  }
+  const int MC = FW - kWinHdr;  // a multiple of 8
+  for (int64_t u = 0; u < n; ++u) {
+    {
+      int spins = 0;
+      Spin sp;
+      while ((int64_t)ldsv_load(c_ready) <= u) {
+        if (ldsv_load(c_abort)) return;
+        if ((++spins & 1023) == 0 && sp.wait(a.ctrl)) return;
+      }
+    }
+    compiler_fence();
+    const double* sl = reinterpret_cast<const double*>(ring + (size_t)(u & (kWinRing - 1)) * FW);
+    const double tot = sl[0], y = sl[1], h2 = sl[2];
+    const int64_t it = a.it0 + u;
+    if (ADA && it != 1 && M.fit_intercept) {  // adagrad.nim:101-106
+      const double old = b;
+      const double denom = sqrt(gnb) + h2;
+      b = -O.eta0 * gsb / denom;
+      viol_b += fabs(old - b);
+    }
+    double yh = b;  // predictWithGrad, sgd.nim:193-196: intercept first, then the entries in storage order
+    for (int qb = 0; qb < MC; qb += 8) {
+      double t_[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) t_[t] = sl[kWinHdr + qb + t];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) yh += t_[t];
+    }
+    yh += tot;
+    const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
+    if (M.fit_intercept) {
+      if (ADA) {
+        gsb += dL;
+        gnb += dL * dL;
+      } else {
+        const double update = h2 * (dL + O.alpha0 * b);
+        viol_b += fabs(update);
+        b -= update;
+      }
+    }
+    const int slot = (int)(u & (W - 1)), par = (int)((u >> lgW) & 1);
+    ull* rp = a.res + (size_t)(slot * 2 + par) * 2;
+    if (lane < 2) st_u64(rp + lane, mail_bits(lane == 0 ? dL : yh));
+    lds_fence();  // the ring slot has been read
+    if (lane == 0) ldsv_store(c_consumed, (unsigned)(u + 1));
+  }
+  if (lane == 0) {
+    M.sc[SC_INTERCEPT] = b;
+    if (ADA) {
+      O.gsc[0] = gsb;
+      O.gsc[1] = gnb;
+    }
+    a.partial[2 * W] = 0.0;
+    a.partial[2 * W + 1] = viol_b;
+  }
+}
+
+template <int OPT>
+__global__ __launch_bounds__(128) void k_seq_window(WinArgs a) {
+  extern __shared__ double lds[];
+  if (blockIdx.x == 0) {
+    win_conductor<OPT>(a, lds);
+  } else {
+    if (threadIdx.x < kWave) win_worker<OPT>(a, (int)blockIdx.x - 1, lds);
+  }
+}
+
+// loss / viol of the launch: the workers' partial sums in worker order, then the conductor's
+__global__ void k_win_finish(const double* partial, int W, double* out) {
+  if (threadIdx.x == 0) {
+    double l = 0.0, v = 0.0;
+    for (int s = 0; s <= W; ++s) {
+      l += partial[2 * s];
+      v += partial[2 * s + 1];
+    }
+    out[0] += l;
+    out[1] += v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// SGD: the lazy-scaling chain (sgd.nim:233-234, 116-131) ahead of the launch.  One wavefront: the step sizes of 64
+// samples in parallel, the two products one sample after the other (lane 0: scale_P, lane 1: scale_w).
+//   scales[pos] = {scale_P, scale_w} before the sample at `pos`;  info[0] = last position of the stretch (the sample after
+//   which a scale falls below 1e-9, or the call's last), info[1] = 1: rescale P, 2: rescale w.  The model's two scale words
+//   get the values after that sample.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_win_scales(ModelView M, OptView O, int64_t it0, int64_t pos0, int64_t ns, double* scales,
+                                                   int64_t* info) {
+  __shared__ double f[2][kWave];
+  __shared__ double o[2][kWave];
+  __shared__ int stp[2];
+  const int lane = threadIdx.x;
+  double sc = lane == 0 ? M.sc[SC_SCALE_P] : M.sc[SC_SCALE_W];  // lane 0 carries scale_P, lane 1 scale_w
+  int64_t last = ns - 1;
+  int flags = 0;
+  for (int64_t base = pos0; base < ns; base += kWave) {
+    const int cnt = (int)(ns - base < kWave ? ns - base : kWave);
+    const double itf = (double)(it0 + (base - pos0) + lane);
+    f[0][lane] = 1 - dev::get_eta(O.sched, O.eta0, O.power, O.beta, itf) * O.beta;
+    // the linear scale moves only when the linear term is fitted (sgd.nim:229-234 as kept by k_sequential_pipe)
+    f[1][lane] = M.fit_linear ? 1 - dev::get_eta(O.sched, O.eta0, O.power, O.alpha, itf) * O.alpha : 1.0;
+    __syncthreads();
+    if (lane < 2) {
+      int stop = -1;
+      double c = sc;
+      const bool watch = lane == 0 || M.fit_linear;
+      for (int t = 0; t < cnt; ++t) {
+        o[lane][t] = c;
+        c = c * f[lane][t];
+        if (watch && c < 1e-9) {  // resetScaling after this sample (sgd.nim:116-131)
+          stop = t;
+          break;
+        }
+      }
+      sc = c;
+      stp[lane] = stop;
+    }
+    __syncthreads();
+    const int s0 = stp[0], s1 = stp[1];
+    const int stop = s0 >= 0 && (s1 < 0 || s0 <= s1) ? s0 : s1;
+    const int upto = stop >= 0 ? stop + 1 : cnt;
+    if (lane < upto) {
+      scales[2 * (base + lane)] = o[0][lane];
+      scales[2 * (base + lane) + 1] = o[1][lane];
+    }
+    if (stop >= 0) {
+      last = base + stop;
+      flags = (s0 == stop ? 1 : 0) | (s1 == stop ? 2 : 0);
+      if (lane < 2) sc = o[lane][stop] * f[lane][stop];  // both chains: the value after sample `stop`
+      break;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    M.sc[SC_SCALE_P] = sc;
+    info[0] = last;
+    info[1] = flags;
+  }
+  if (lane == 1) M.sc[SC_SCALE_W] = sc;
+}
+
+__global__ void k_win_fill(ull* p, int64_t n, ull v) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) p[e] = v;
+}
+
+__global__ void k_win_rescale(double* p, int64_t n, double* scale_word, const int64_t* info, int bit) {
+  if (!(info[1] & bit)) return;
+  const double sc = *scale_word;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) p[e] *= sc;
+}
+__global__ void k_win_rescale_done(double* sc, const int64_t* info) {
+  if (info[1] & 1) sc[SC_SCALE_P] = 1.0;
+  if (info[1] & 2) sc[SC_SCALE_W] = 1.0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the dependency table: for every stored entry of the samples of the call, the position of the previous sample of the
+// call with the same feature.  One sort of (feature, position) keys.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_win_rowlen(CsrView X, const int64_t* perm, int64_t begin, int64_t ns, int64_t* len) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > ns) return;
+  if (p == ns) {
+    len[p] = 0;
+    return;
+  }
+  const int64_t i = perm ? perm[begin + p] : begin + p;
+  len[p] = X.indptr[i + 1] - X.indptr[i];
+}
+__global__ void k_win_expand(CsrView X, const int64_t* perm, int64_t begin, int64_t ns, const int64_t* off, ull* keys, uint32_t* vals) {
+  const int64_t p = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
+  if (p >= ns) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = perm ? perm[begin + p] : begin + p;
+  const int64_t q0 = X.indptr[i], m = X.indptr[i + 1] - q0, o = off[p];
+  for (int64_t q = lane; q < m; q += kWave) {
+    keys[o + q] = ((ull)(uint32_t)X.indices[q0 + q] << 32) | (ull)(uint32_t)p;
+    vals[o + q] = (uint32_t)(q0 + q);
+  }
+}
+__global__ void k_win_prev(const ull* keys, const uint32_t* vals, int64_t T, int32_t* prev) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= T) return;
+  const ull kcur = keys[e];
+  int32_t p = -1;
+  if (e > 0) {
+    const ull kp = keys[e - 1];
+    if ((kp >> 32) == (kcur >> 32)) p = (int32_t)(uint32_t)(kp & 0xffffffffull);
+  }
+  prev[vals[e]] = p;
+}
+
+static int build_prev(nfm_ctx* ctx, const CsrView& X, const int64_t* perm_dev, int64_t begin, int64_t ns, SeqWin* sw) {
+  hipStream_t st = ctx->stream;
+  NFM_TRY(sw->prev.ensure(sizeof(int32_t) * (size_t)(X.nnz > 0 ? X.nnz : 1)));
+  DevBuf len, off, k0, k1, v0, v1, tmp;
+  NFM_TRY(len.alloc(sizeof(int64_t) * (ns + 1)));
+  NFM_TRY(off.alloc(sizeof(int64_t) * (ns + 1)));
+  hipLaunchKernelGGL(k_win_rowlen, dim3((unsigned)((ns + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, X, perm_dev, begin, ns, len.as<int64_t>());
+  size_t bytes = 0;
+  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, len.as<int64_t>(), off.as<int64_t>(), (int)(ns + 1), st));
+  NFM_TRY(tmp.alloc(bytes));
+  NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, len.as<int64_t>(), off.as<int64_t>(), (int)(ns + 1), st));
+  int64_t T = 0;
+  NFM_HIP_CHECK(hipMemcpyAsync(&T, off.as<int64_t>() + ns, sizeof(T), hipMemcpyDeviceToHost, st));
+  NFM_HIP_CHECK(hipStreamSynchronize(st));
+  if (T == 0) return NFM_OK;
+  NFM_CHECK(T < ((int64_t)1 << 31), NFM_ERR_UNSUPPORTED, "too many entries for the dependency table");
+  NFM_TRY(k0.alloc(sizeof(ull) * T));
+  NFM_TRY(k1.alloc(sizeof(ull) * T));
+  NFM_TRY(v0.alloc(sizeof(uint32_t) * T));
+  NFM_TRY(v1.alloc(sizeof(uint32_t) * T));
+  const int per = kBlock / kWave;
+  hipLaunchKernelGGL(k_win_expand, dim3((unsigned)((ns + per - 1) / per)), dim3(kBlock), 0, st, X, perm_dev, begin, ns, off.as<int64_t>(),
+                     k0.as<ull>(), v0.as<uint32_t>());
+  int fbits = 1;
+  while (((int64_t)1 << fbits) < X.d + 1 && fbits < 31) ++fbits;
+  hipcub::DoubleBuffer<ull> dk(k0.as<ull>(), k1.as<ull>());
+  hipcub::DoubleBuffer<uint32_t> dv(v0.as<uint32_t>(), v1.as<uint32_t>());
+  bytes = 0;
+  NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dk, dv, (int)T, 0, 32 + fbits, st));
+  NFM_TRY(tmp.alloc(bytes));
+  NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, dk, dv, (int)T, 0, 32 + fbits, st));
+  hipLaunchKernelGGL(k_win_prev, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, dk.Current(), dv.Current(), T, sw->prev.as<int32_t>());
+  NFM_HIP_CHECK(hipGetLastError());
+  NFM_HIP_CHECK(hipStreamSynchronize(st));  // the temporaries go back to the pool
+  return NFM_OK;
+}
+
+bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz, int n_cu) {
+  const char* env = getenv("NFM_SEQ_WIN");  // 0: off, 1 (default): when it pays, 2: whenever possible (read per call: tests switch it)
+  const int mode = env ? atoi(env) : 1;
+  if (mode == 0) return false;
+  if (M.kind != NFM_KIND_FM || M.nb != 1 || M.degree != 2 || M.n_aug != 0) return false;
+  if (M.Kp > kWave || M.Kp < 2) return false;
+  if (kWinHdr + (m_cap + 7) / 8 * 8 > kWave * kWinMaxNL) return false;
+  if (nnz >= ((int64_t)1 << 32) || M.d >= ((int64_t)1 << 31) || ns >= ((int64_t)1 << 31)) return false;
+  if (n_cu < 10) return false;
+  return mode == 2 || ns >= 2048;
+}
+
+template <int OPT>
+static int launch_window_t(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes) {
+  auto kern = k_seq_window<OPT>;
+  NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  TimedLaunch tl(ctx, "sequential");
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.W + 1)), dim3(128), lds_bytes, ctx->stream, a);
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+
+int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const int64_t* perm_dev,
+                             int64_t begin, int64_t end, int64_t it0, int m_cap, double* out2_dev, SeqWin* sw, uint64_t ds_uid,
+                             bool perm_is_callers) {
+  hipStream_t st = ctx->stream;
+  const int64_t ns = end - begin;
+  const bool ada = opt_kind == OPT_ADAGRAD;
+  if (m_cap < 1) m_cap = 1;
+  // worker count: a power of two, one workgroup per CU with one CU left for the conductor
+  int W = 64;
+  if (const char* env = getenv("NFM_SEQ_WIN_W")) W = atoi(env);
+  int lgW = 3;
+  while ((2 << lgW) <= W && lgW < 7) ++lgW;
+  W = 1 << lgW;
+  while (W + 1 > ctx->n_cu && lgW > 3) W = 1 << --lgW;
+  NFM_CHECK(W > kWinDepth && W + 1 <= ctx->n_cu, NFM_ERR_UNSUPPORTED, "the dependency window needs %d resident workgroups", W + 1);
+  int lgKp = 1;
+  while ((1 << lgKp) < M.Kp) ++lgKp;
+  const int FW = kWinHdr + (m_cap + 7) / 8 * 8;
+  // the previous-position table of this order (kept while the same samples are walked in storage order)
+  const bool reuse = sw->valid && !perm_is_callers && !sw->had_perm && sw->ds_uid == ds_uid && sw->begin == begin && sw->end == end && sw->nnz == X.nnz;
+  if (!reuse) {
+    sw->valid = false;
+    TimedLaunch tl(ctx, "seq_window_deps");
+    NFM_TRY(build_prev(ctx, X, perm_dev, begin, ns, sw));
+    sw->valid = true;
+    sw->had_perm = perm_dev != nullptr;
+    sw->ds_uid = ds_uid;
+    sw->begin = begin;
+    sw->end = end;
+    sw->nnz = X.nnz;
+  }
+  const size_t n_fwd = (size_t)W * 2 * FW, n_res = (size_t)W * 2 * 2;
+  NFM_TRY(sw->mail.ensure(sizeof(ull) * (n_fwd + n_res)));
+  NFM_TRY(sw->ctl.ensure(sizeof(unsigned) * (W + 64) + sizeof(double) * 2 * (W + 1) + sizeof(int64_t) * 2));
+  if (!ada) NFM_TRY(sw->scales.ensure(sizeof(double) * 2 * (size_t)ns));
+  WinArgs a{};
+  a.X = X;
+  a.M = M;
+  a.O = O;
+  a.perm = perm_dev;
+  a.begin = begin;
+  a.prev = sw->prev.as<int32_t>();
+  a.scales = ada ? nullptr : sw->scales.as<double>();
+  a.fwd = sw->mail.as<ull>();
+  a.res = a.fwd + n_fwd;
+  a.completed = sw->ctl.as<unsigned>();
+  a.ctrl = a.completed + W;
+  a.partial = reinterpret_cast<double*>(a.completed + W + 64);
+  int64_t* info = reinterpret_cast<int64_t*>(a.partial + 2 * (W + 1));
+  a.W = W;
+  a.lgW = lgW;
+  a.m_cap = m_cap;
+  a.FW = FW;
+  a.lgKp = lgKp;
+  const size_t rows = (size_t)m_cap * M.Kp;
+  size_t lds_worker = sizeof(double) * ((ada ? 4 : 2) * rows + kWave + (ada ? 4 : 2) * (size_t)m_cap) + sizeof(int) * 2 * (size_t)m_cap + sizeof(unsigned) * W;
+  const size_t lds_cond = sizeof(double) * 2 + sizeof(ull) * (size_t)kWinRing * FW;
+  size_t lds_bytes = lds_worker > lds_cond ? lds_worker : lds_cond;
+  NFM_CHECK(lds_bytes <= 160 * 1024, NFM_ERR_UNSUPPORTED, "row too long for the dependency window (%zu bytes of LDS)", lds_bytes);
+  if (lds_bytes < 81 * 1024) lds_bytes = 81 * 1024;  // one workgroup per CU
+  NFM_HIP_CHECK(hipMemsetAsync(out2_dev, 0, sizeof(double) * 2, st));
+  int64_t pos = 0;
+  while (pos < ns) {
+    int64_t last = ns - 1;
+    int64_t host_info[2] = {ns - 1, 0};
+    if (!ada) {
+      hipLaunchKernelGGL(k_win_scales, dim3(1), dim3(kWave), 0, st, M, O, it0 + pos, pos, ns, sw->scales.as<double>(), info);
+      NFM_HIP_CHECK(hipMemcpyAsync(host_info, info, sizeof(host_info), hipMemcpyDeviceToHost, st));
+      NFM_HIP_CHECK(hipStreamSynchronize(st));
+      last = host_info[0];
+    }
+    // mailboxes empty, counters and abort word zero
+    {
+      NFM_HIP_CHECK(hipMemsetAsync(sw->ctl.p, 0, sizeof(unsigned) * (W + 64) + sizeof(double) * 2 * (W + 1), st));
+      const int64_t nm = (int64_t)(n_fwd + n_res);
+      hipLaunchKernelGGL(k_win_fill, dim3((unsigned)((nm + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sw->mail.as<ull>(), nm, kWinSentinel);
+    }
+    a.seg0 = pos;
+    a.n_seg = last - pos + 1;
+    a.it0 = it0 + pos;
+    if (ada) NFM_TRY(launch_window_t<OPT_ADAGRAD>(ctx, a, lds_bytes));
+    else NFM_TRY(launch_window_t<OPT_SGD>(ctx, a, lds_bytes));
+    hipLaunchKernelGGL(k_win_finish, dim3(1), dim3(kWave), 0, st, a.partial, W, out2_dev);
+    if (!ada && host_info[1]) {
+      const int64_t nP = (int64_t)M.nb * M.da * M.Kp;
+      hipLaunchKernelGGL(k_win_rescale, dim3(1024), dim3(kBlock), 0, st, M.P, nP, M.sc + SC_SCALE_P, info, 1);
+      hipLaunchKernelGGL(k_win_rescale, dim3(256), dim3(kBlock), 0, st, M.w, M.d, M.sc + SC_SCALE_W, info, 2);
+      hipLaunchKernelGGL(k_win_rescale_done, dim3(1), dim3(1), 0, st, M.sc, info);
+    }
+    unsigned aborted = 0;
+    NFM_HIP_CHECK(hipMemcpyAsync(&aborted, a.ctrl, sizeof(aborted), hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+    NFM_CHECK(aborted == 0, NFM_ERR_HIP, "the dependency-window kernel gave up waiting (a workgroup was not resident or a hand-off was lost)");
+    pos = last + 1;
+  }
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+
+}  // namespace nfm

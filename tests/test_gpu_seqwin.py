@@ -1,0 +1,222 @@
+"""-m gpu: the dependency-window form of NFM_MODE_SEQUENTIAL (seqwin.hip) -- the reference's one-sample-at-a-time order
+(optimizer/sgd.nim:246-258,294-308, optimizer/adagrad.nim:169-184) spread over the chip.
+
+Two bars: (1) BIT FOR BIT the parameters / linear weights / intercept / AdaGrad state of the one-workgroup kernels
+(NFM_SEQ_WIN=0), which test_gpu_sequential.py holds to the oracle -- on conflict-heavy data (8 features: every sample
+depends on its predecessor), ragged rows, every lanes-per-row value, small and large windows; (2) the oracle's
+reference-faithful fit (O.fm_sgd_fit / O.fm_adagrad_fit) at rtol 1e-8 on the reference's grids and on sparse shapes
+where most samples run concurrently.  Hand-offs are exercised under uneven load by construction: rows of 0 ... 100
+entries make the workers' step times differ by two orders of magnitude."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+import nimfm_amd as nf
+import oracle as O
+from common import assert_close, init_fm, make_fm_dataset, make_perms, random_csr
+from gpu_common import gpu_fm, ragged_csr, to_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+class env:
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def fit(kind, win, W, Xo, y, task, k, P0, w0, b0, epochs, perms=None, it0=1, nCalls=-1, fit_linear=True, fit_intercept=True, **kw):
+    """one fit in sequential mode; win = 0: the one-workgroup kernels, 2: the window kernel with W workers.  nCalls > 0:
+    the reference's per-nCalls callbacks (sgd.nim:303-308): the epoch becomes a series of calls over sub-ranges of the
+    order with a finalize in between"""
+    with env(NFM_SEQ_WIN=win, NFM_SEQ_WIN_W=W):
+        fm = gpu_fm(task, 2, k, "explicit", fit_linear, fit_intercept, P0, w0, b0)
+        mk = nf.newSGD if kind == "sgd" else nf.newAdaGrad
+        opt = mk(maxIter=epochs, verbose=0, tol=0, shuffle=False, mode="sequential", nCalls=nCalls, **kw)
+        opt.it = it0
+        seen = []
+        opt.fit(to_gpu(Xo), y, fm, perms=perms, callback=(lambda o_, m_: seen.append(o_.it)) if nCalls > 0 else None)
+        state = opt.get_state(fm) if kind == "adagrad" else None
+        return fm.P.copy(), fm.w.copy(), fm.intercept, opt.it, list(opt.history), state
+
+
+def same_bits(a, b, what):
+    a, b = np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+    assert a.shape == b.shape, what
+    bad = a.view(np.uint64) != b.view(np.uint64)
+    assert not bad.any(), "%s: %d of %d words differ, max |diff| %.3e" % (what, bad.sum(), bad.size, np.abs(a - b)[bad].max())
+
+
+def check_pair(kind, Xo, y, task, k, W, epochs=2, seed=0, perms=None, oracle_rtol=1e-8, **kw):
+    rng = np.random.default_rng(seed)
+    d = Xo.d
+    P0, w0, b0 = rng.standard_normal((1, k, d)) * 0.1 / np.sqrt(k), rng.standard_normal(d) * 0.01, 0.05
+    ref = fit(kind, 0, W, Xo, y, task, k, P0, w0, b0, epochs, perms, **kw)
+    win = fit(kind, 2, W, Xo, y, task, k, P0, w0, b0, epochs, perms, **kw)
+    same_bits(win[0], ref[0], "P")
+    same_bits(win[1], ref[1], "w")
+    assert win[2] == ref[2] and win[3] == ref[3]
+    if ref[4]:
+        assert_close([h[1] for h in win[4]], [h[1] for h in ref[4]], 1e-12, 1e-15, "loss per epoch")
+        assert_close([h[0] for h in win[4]], [h[0] for h in ref[4]], 1e-11, 1e-14, "viol per epoch")
+    if kind == "adagrad":
+        for g, h, name in zip(win[5], ref[5], ["g_sum.P", "g_norm.P", "g_sum.w", "g_norm.w", "g_sum.b", "g_norm.b"]):
+            same_bits(np.atleast_1d(g), np.atleast_1d(h), name)
+    return win, (P0, w0, b0)
+
+
+@pytest.mark.parametrize("kind,k,W", itertools.product(["sgd", "adagrad"], [1, 3, 4, 8, 16, 30, 64], [8, 64]))
+def test_conflict_heavy_ragged_rows_bitwise(kind, k, W):
+    """8 ... 40 features, rows from empty to longer than a wavefront, unsorted storage order: nearly every sample waits for
+    its predecessors, the waits resolve in every possible order"""
+    d = 8 if k % 2 == 0 else 40
+    Xo = ragged_csr(400, d, seed=k, max_m=d)
+    y = np.random.default_rng(k).standard_normal(Xo.n)
+    check_pair(kind, Xo, y, "regression", k, W, epochs=2, seed=k)
+
+
+@pytest.mark.parametrize("kind,W", itertools.product(["sgd", "adagrad"], [8, 32, 128]))
+def test_long_rows_and_more_features_bitwise(kind, W):
+    Xo = ragged_csr(1500, 300, seed=3, max_m=100)  # rows of up to 100 entries: two 64-lane chunks
+    rng = np.random.default_rng(4)
+    y = np.sign(rng.standard_normal(Xo.n))
+    perms = make_perms(Xo.n, 2)
+    check_pair(kind, Xo, y, "classification", 16, W, epochs=2, perms=perms, loss="logistic")
+
+
+@pytest.mark.parametrize("loss,scheduling", itertools.product(["squared", "squared_hinge", "logistic", "huber"],
+                                                              ["constant", "optimal", "invscaling", "pegasos"]))
+def test_sgd_losses_and_schedules_bitwise_and_oracle(loss, scheduling):
+    n, d, k = 600, 50, 8
+    Xo = random_csr(n, d, 6, seed=11)
+    rng = np.random.default_rng(12)
+    task = "classification" if loss in ("squared_hinge", "logistic") else "regression"
+    y = rng.standard_normal(n)
+    kw = dict(alpha0=0.5, alpha=0.5, beta=0.5) if scheduling == "pegasos" else {}
+    it0 = 20 if scheduling == "pegasos" else 1
+    perms = make_perms(n, 2)
+    win, (P0, w0, b0) = check_pair("sgd", Xo, y, task, k, 16, epochs=2, perms=perms, it0=it0, loss=loss, scheduling=scheduling,
+                                   power=0.75, **kw)
+    yo = np.sign(y) if task == "classification" else y
+    Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, yo, 2, P0, w0, b0, O.sgd_cfg(loss=loss, scheduling=scheduling, power=0.75, **kw), 2,
+                                  0, perms=perms, it=it0)
+    assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
+    assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
+    assert abs(win[2] - bf) < 1e-9
+
+
+@pytest.mark.parametrize("fit_linear,fit_intercept,kind", itertools.product([False, True], [False, True], ["sgd", "adagrad"]))
+def test_reference_grid_flags(fit_linear, fit_intercept, kind):
+    """the reference's degree-2 grid (tests/test_sgd.nim:92-126, test_adagrad.nim:92-126: n = 80, d = 8, k = 4) through the
+    window kernel, against the oracle's fit and the brute-force model at the reference's tolerance"""
+    N, D, K = 80, 8, 4
+    Xo, Xd, y = make_fm_dataset(N, D, 2, K, 42, "explicit", fit_linear, fit_intercept, threshold=0.3)
+    P0, w0, b0, n_aug = init_fm(D, 2, K, "explicit", fit_linear)
+    perms = make_perms(N, 5)
+    win = fit(kind, 2, 8, Xo, y, "regression", K, P0, w0, b0, 5, perms, fit_linear=fit_linear, fit_intercept=fit_intercept)
+    if kind == "sgd":
+        cfg = O.sgd_cfg(fit_linear=fit_linear, fit_intercept=fit_intercept)
+        Pf, wf, bf, it, el, ev, _ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, cfg, 5, n_aug, perms=perms)
+        Ps, ws, bs, _ = O.slow_fm_sgd_fit(Xd, y, 2, P0, w0, b0, cfg, 5, n_aug, perms)
+    else:
+        cfg = O.adagrad_cfg(fit_linear=fit_linear, fit_intercept=fit_intercept)
+        Pf, wf, bf, it, el, ev, _, st = O.fm_adagrad_fit(Xo, y, 2, P0, w0, b0, cfg, 5, n_aug, perms=perms)
+        Ps, ws, bs, _ = O.slow_fm_adagrad_fit(Xd, y, 2, P0, w0, b0, cfg, 5, n_aug, perms)
+    assert win[3] == it
+    assert_close(win[0], Pf, 1e-8, 1e-11, "P")
+    assert_close(win[1], wf, 1e-8, 1e-11, "w")
+    assert abs(win[2] - bf) < 1e-9
+    assert_close([h[1] for h in win[4]], el, 1e-9, 1e-12, "loss")
+    assert_close([h[0] for h in win[4]], ev, 1e-8, 1e-11, "viol")
+    assert_close(win[0], Ps, 1e-6, 1e-9, "P vs slow")
+    assert_close(win[1], ws, 1e-6, 1e-9, "w vs slow")
+    if not fit_linear:
+        assert (win[1] == 0.0).all()
+    if not fit_intercept:
+        assert win[2] == 0.0
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad"])
+def test_bit_exact_against_the_oracle_where_the_arithmetic_is_the_same(kind):
+    """no L2 decay (scale stays 1) and a loss without exp / log: the device's arithmetic is the oracle's, operation for
+    operation -- the window kernel must then equal the reference restatement to the last bit (AdaGrad always does)"""
+    n, d, k = 3000, 2000, 16
+    Xo = random_csr(n, d, 12, seed=21)
+    rng = np.random.default_rng(22)
+    y = rng.standard_normal(n)
+    P0, w0, b0 = rng.standard_normal((1, k, d)) * 0.05, np.zeros(d), 0.0
+    perms = make_perms(n, 2)
+    if kind == "sgd":
+        kw = dict(alpha0=0.0, alpha=0.0, beta=0.0, scheduling="constant", loss="squared")
+        cfg = O.sgd_cfg(**kw)
+        Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, cfg, 2, 0, perms=perms)
+    else:
+        kw = dict(loss="squared")
+        cfg = O.adagrad_cfg(**kw)
+        Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, y, 2, P0, w0, b0, cfg, 2, 0, perms=perms)
+    win = fit(kind, 2, 64, Xo, y, "regression", k, P0, w0, b0, 2, perms, **kw)
+    same_bits(win[0], Pf, "P vs oracle")
+    same_bits(win[1], wf, "w vs oracle")
+    assert win[2] == bf
+
+
+def test_reset_scaling_mid_epoch():
+    """a step size x beta large enough that scaling_P falls below 1e-9 several times inside one epoch (resetScaling,
+    sgd.nim:116-131): the launch is cut there, the dense rescale runs, the next launch continues"""
+    n, d, k = 2500, 400, 8
+    Xo = random_csr(n, d, 8, seed=31)
+    y = np.random.default_rng(32).standard_normal(n)
+    perms = make_perms(n, 2)
+    win, (P0, w0, b0) = check_pair("sgd", Xo, y, "regression", k, 32, epochs=2, perms=perms, eta0=0.05, beta=0.5, alpha=0.3,
+                                   scheduling="constant")
+    Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, O.sgd_cfg(eta0=0.05, beta=0.5, alpha=0.3, scheduling="constant"), 2, 0,
+                                  perms=perms)
+    assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
+    assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad"])
+def test_sparse_shape_most_samples_concurrent(kind):
+    """d = 1e5, 32 entries per row: two samples share a feature with probability 1 % -- the window is full of samples
+    running side by side; fixed order, no permutation (the dependency table is reused by the second epoch)"""
+    n, d, k = 20000, 100000, 16
+    rng = np.random.default_rng(41)
+    idx = np.sort(rng.integers(0, d, size=(n, 32)), axis=1)
+    idx += np.arange(32)  # distinct inside a row
+    idx %= d
+    idx.sort(axis=1)
+    ok = (np.diff(idx, axis=1) > 0).all(axis=1)
+    idx = idx[ok]
+    n = len(idx)
+    Xo = O.Dataset(np.arange(n + 1, dtype=np.int64) * 32, idx.ravel().astype(np.int64), rng.uniform(-1, 1, n * 32), n, d)
+    y = np.sign(rng.standard_normal(n))
+    win, (P0, w0, b0) = check_pair(kind, Xo, y, "classification", k, 64, epochs=2, loss="logistic")
+    if kind == "sgd":
+        Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, O.sgd_cfg(loss="logistic"), 2, 0)
+    else:
+        Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, y, 2, P0, w0, b0, O.adagrad_cfg(loss="logistic"), 2, 0)
+    assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
+    assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
+    assert abs(win[2] - bf) < 1e-9
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad"])
+def test_sub_ranges_of_the_order(kind):
+    """nCalls = 37: every epoch is a series of calls over 37-sample stretches of the permuted order (positions relative to
+    the call's first sample in the dependency table), a finalize + read-back between them"""
+    Xo = ragged_csr(500, 60, seed=5, max_m=30)
+    y = np.random.default_rng(6).standard_normal(Xo.n)
+    perms = make_perms(Xo.n, 2)
+    check_pair(kind, Xo, y, "regression", 8, 8, epochs=2, perms=perms, nCalls=37)
