@@ -50,8 +50,8 @@ typedef unsigned long long ull;
 constexpr ull kWinSentinel = 0x7FF4DEADBEEF0000ull;  // a signalling NaN no arithmetic produces (results are quiet NaNs)
 constexpr ull kWinQuietNaN = 0x7FF8000000000000ull;
 constexpr int kWinRing = 8;    // LDS ring slots between the conductor's fetch and chain wavefronts (power of two)
-constexpr int kWinDepth = 4;   // mailboxes the fetch wavefront has requested ahead (must stay < W, see below)
-constexpr int kWinHdr = 4;     // mailbox header: anova sum, target, eta(alpha0) | eta0 (it-1) alpha0, spare
+constexpr int kWinDepth = 8;   // mailboxes the fetch wavefront has requested ahead (must stay < W, see below)
+constexpr int kWinHdr = 4;     // mailbox tail, after the MC term slots: anova sum, target, eta(alpha0) | eta0 (it-1) alpha0, spare
 constexpr int kWinMaxNL = 5;   // 64-lane loads per mailbox: rows of up to 316 entries
 constexpr long long kWinTimeoutTicks = 400000000ll;  // 4 s of the 100 MHz wall clock without progress: abort
 
@@ -64,13 +64,16 @@ struct WinArgs {
   int64_t seg0, n_seg;    // this launch: positions begin + seg0 ... begin + seg0 + n_seg - 1
   int64_t it0;            // step counter of the launch's first sample
   const int32_t* prev;    // [nnz] position (relative to `begin`) of the previous sample of the call with this feature, -1: none
+  const uint8_t* prevq;   // [nnz] the feature's entry index in that sample's row (rows of up to 64 entries: the forwarding path)
+  const int32_t* next;    // [nnz] position of the next sample of the call with this feature, -1: none
+  ull* fw;                // [W][kFwSlot] forwarding areas: a worker's rows that a near successor waits for
   const double* scales;   // SGD: [ns][2] {scale_P, scale_w} BEFORE each sample of the call
   ull* fwd;               // [W][2][FW] worker -> conductor
   ull* res;               // [W][2][2]  conductor -> worker {dL, yhat}
   unsigned* completed;    // [W] samples of this launch a worker has finished
   unsigned* ctrl;         // [0]: abort
   double* partial;        // [W + 1][2] {loss, viol} per worker, last: the conductor's
-  int W, lgW, m_cap, FW, lgKp;
+  int W, lgW, m_cap, FW, lgKp;  // FW = MC + kWinHdr words per mailbox, MC = m_cap rounded up to the chain's chunk
 };
 
 __device__ __forceinline__ ull ld_u64(const ull* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -107,7 +110,7 @@ struct Spin {
 // worker: one wavefront, lanes (r, s) = (row slot, factor), Kp lanes per row, R = 64 / Kp rows per instruction
 // ------------------------------------------------------------------------------------------------------------------
 template <int OPT>
-__device__ void win_worker(const WinArgs& a, const int slot, double* lds) {
+__device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, double* lds) {
   const CsrView& X = a.X;
   const ModelView& M = a.M;
   const OptView& O = a.O;
@@ -258,19 +261,19 @@ __device__ void win_worker(const WinArgs& a, const int slot, double* lds) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) tot = sb + t < k ? tot + r_[t] : tot;
     }
-    // the mailbox: header, then the terms of the linear part; past the row's end -0.0, which changes no sum
+    // the mailbox: the terms of the linear part (past the row's end -0.0, which changes no sum), then the header
     const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
-    for (int e = lane; e < a.FW; e += kWave) {
-      double val;
-      if (e == 0) val = tot;
-      else if (e == 1) val = y;
-      else if (e == 2) val = h2;
-      else if (e == 3) val = 0.0;
-      else {
-        const int q = e - kWinHdr;
-        val = q < m ? (sw * wl[q]) * vl[q] : -0.0;
+    {
+      const int MC = a.FW - kWinHdr;
+      for (int e = lane; e < a.FW; e += kWave) {
+        double val;
+        if (e < MC) val = e < m ? (sw * wl[e]) * vl[e] : -0.0;
+        else if (e == MC) val = tot;
+        else if (e == MC + 1) val = y;
+        else if (e == MC + 2) val = h2;
+        else val = 0.0;
+        st_u64(mb + e, mail_bits(val));
       }
-      st_u64(mb + e, mail_bits(val));
     }
 
     // ---- D. while the conductor works: the derivative (sgd.nim:176-188) and the step sizes ----
@@ -369,8 +372,8 @@ typedef __attribute__((address_space(3))) unsigned lds_uint;
 __device__ __forceinline__ unsigned ldsv_load(unsigned* p) { return *(volatile lds_uint*)(lds_uint*)p; }
 __device__ __forceinline__ void ldsv_store(unsigned* p, unsigned v) { *(volatile lds_uint*)(lds_uint*)p = v; }
 
-template <int OPT>
-__device__ void win_conductor(const WinArgs& a, double* lds) {
+template <int OPT, int CH>  // CH: terms of the linear part the chain requests from LDS together (MC is a multiple)
+__device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
   const ModelView& M = a.M;
   const OptView& O = a.O;
   constexpr bool ADA = OPT == OPT_ADAGRAD;
@@ -403,6 +406,7 @@ __device__ void win_conductor(const WinArgs& a, double* lds) {
 #pragma unroll
     for (int dd = 0; dd < kWinDepth; ++dd)
       if (dd < n) issue(dd, dd);
+    int64_t consumed_seen = 0;
     for (int64_t ub = 0; ub < n; ub += kWinDepth) {
 #pragma unroll
       for (int dd = 0; dd < kWinDepth; ++dd) {
@@ -420,11 +424,13 @@ __device__ void win_conductor(const WinArgs& a, double* lds) {
           }
           issue(dd, u);
         }
-        Spin sp2;
-        while ((int64_t)ldsv_load(c_consumed) + kWinRing <= u) {
-          if (sp2.wait(a.ctrl)) {
-            ldsv_store(c_abort, 1u);
-            return;
+        if (consumed_seen + kWinRing <= u) {
+          Spin sp2;
+          while ((consumed_seen = (int64_t)ldsv_load(c_consumed)) + kWinRing <= u) {
+            if (sp2.wait(a.ctrl)) {
+              ldsv_store(c_abort, 1u);
+              return;
+            }
           }
         }
         ull* dst = ring + (size_t)(u & (kWinRing - 1)) * FW;
@@ -441,25 +447,53 @@ __device__ void win_conductor(const WinArgs& a, double* lds) {
     return;
   }
   // ---- chain ----
+  // Two samples are held in registers at any time: while the additions of sample u run -- each waits for the one
+  // before it -- the LDS reads of sample u + 1 are already in flight (one wavefront issues in order: the reads have
+  // to be REQUESTED ahead of the chain they would otherwise stall).
   double b = M.sc[SC_INTERCEPT];
   double gsb = 0.0, gnb = 0.0, viol_b = 0.0;
   if (ADA) {
     gsb = O.gsc[0];
     gnb = O.gsc[1];
   }
-  const int MC = FW - kWinHdr;  // a multiple of 8
-  for (int64_t u = 0; u < n; ++u) {
-    {
-      int spins = 0;
-      Spin sp;
-      while ((int64_t)ldsv_load(c_ready) <= u) {
-        if (ldsv_load(c_abort)) return;
-        if ((++spins & 1023) == 0 && sp.wait(a.ctrl)) return;
-      }
+  const int MC = FW - kWinHdr;  // a multiple of CH
+  int64_t ready_seen = 0;
+  constexpr int PF = CH < 32 ? CH : 32;  // terms of the NEXT sample requested ahead (two samples' worth must fit the registers)
+  struct Terms {
+    double2 t[PF / 2];
+    double2 h01;
+    double h2;
+  };
+  auto slot_of = [&](int64_t u) { return reinterpret_cast<const double*>(ring + (size_t)(u & (kWinRing - 1)) * FW); };
+  auto request = [&](int64_t u, Terms& T) {
+    const double* sl = slot_of(u);
+    T.h01 = *reinterpret_cast<const double2*>(sl + MC);
+    T.h2 = sl[MC + 2];
+#pragma unroll
+    for (int t = 0; t < PF / 2; ++t) T.t[t] = *reinterpret_cast<const double2*>(sl + 2 * t);
+  };
+  // false: the launch is being aborted
+  auto wait_ready = [&](int64_t u) {
+    if (ready_seen > u) return true;
+    int spins = 0;
+    Spin sp;
+    while ((ready_seen = (int64_t)ldsv_load(c_ready)) <= u) {
+      if (ldsv_load(c_abort)) return false;
+      if ((++spins & 1023) == 0 && sp.wait(a.ctrl)) return false;
     }
     compiler_fence();
-    const double* sl = reinterpret_cast<const double*>(ring + (size_t)(u & (kWinRing - 1)) * FW);
-    const double tot = sl[0], y = sl[1], h2 = sl[2];
+    return true;
+  };
+  auto try_request = [&](int64_t u, Terms& T) {  // the next sample's terms, if the fetch wavefront has them already
+    if (u >= n) return false;
+    if (ready_seen <= u) ready_seen = (int64_t)ldsv_load(c_ready);
+    if (ready_seen <= u) return false;
+    compiler_fence();
+    request(u, T);
+    return true;
+  };
+  auto step = [&](int64_t u, const Terms& T) {
+    const double tot = T.h01.x, y = T.h01.y, h2 = T.h2;
     const int64_t it = a.it0 + u;
     if (ADA && it != 1 && M.fit_intercept) {  // adagrad.nim:101-106
       const double old = b;
@@ -467,13 +501,36 @@ __device__ void win_conductor(const WinArgs& a, double* lds) {
       b = -O.eta0 * gsb / denom;
       viol_b += fabs(old - b);
     }
+    const double* sl = slot_of(u);
+    double2 t2_[CH > PF ? (CH - PF) / 2 : 1];  // the rest of the first chunk: requested now, used after PF additions
+    if constexpr (CH > PF) {
+#pragma unroll
+      for (int t = 0; t < (CH - PF) / 2; ++t) t2_[t] = *reinterpret_cast<const double2*>(sl + PF + 2 * t);
+    }
     double yh = b;  // predictWithGrad, sgd.nim:193-196: intercept first, then the entries in storage order
-    for (int qb = 0; qb < MC; qb += 8) {
-      double t_[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) t_[t] = sl[kWinHdr + qb + t];
+    for (int t = 0; t < PF / 2; ++t) {
+      yh += T.t[t].x;
+      yh += T.t[t].y;
+    }
+    if constexpr (CH > PF) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) yh += t_[t];
+      for (int t = 0; t < (CH - PF) / 2; ++t) {
+        yh += t2_[t].x;
+        yh += t2_[t].y;
+      }
+    }
+    if (MC > CH) {  // rows longer than one chunk
+      for (int qb = CH; qb < MC; qb += CH) {
+        double2 t_[CH / 2];
+#pragma unroll
+        for (int t = 0; t < CH / 2; ++t) t_[t] = *reinterpret_cast<const double2*>(sl + qb + 2 * t);
+#pragma unroll
+        for (int t = 0; t < CH / 2; ++t) {
+          yh += t_[t].x;
+          yh += t_[t].y;
+        }
+      }
     }
     yh += tot;
     const double dL = dev::loss_grad(O.loss, O.loss_param, y, yh);
@@ -492,6 +549,23 @@ __device__ void win_conductor(const WinArgs& a, double* lds) {
     if (lane < 2) st_u64(rp + lane, mail_bits(lane == 0 ? dL : yh));
     lds_fence();  // the ring slot has been read
     if (lane == 0) ldsv_store(c_consumed, (unsigned)(u + 1));
+  };
+  Terms A, B;
+  bool haveA = false, haveB = false;
+  for (int64_t u = 0; u < n; u += 2) {
+    if (!haveA) {
+      if (!wait_ready(u)) return;
+      request(u, A);
+    }
+    haveB = try_request(u + 1, B);
+    step(u, A);
+    if (u + 1 >= n) break;
+    if (!haveB) {
+      if (!wait_ready(u + 1)) return;
+      request(u + 1, B);
+    }
+    haveA = try_request(u + 2, A);
+    step(u + 1, B);
   }
   if (lane == 0) {
     M.sc[SC_INTERCEPT] = b;
@@ -504,13 +578,417 @@ __device__ void win_conductor(const WinArgs& a, double* lds) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// worker for rows of 64 factors (Kp = 64) and at most 64 entries: lane = factor, lane q also holds entry q of the sample;
+// the sample's 64 stored rows stay in REGISTERS between predictWithGrad and update() (no LDS round trips, no branches
+// that depend on a lane), an entry travels by v_readlane.  SGD gathers its rows BEFORE it has waited for the samples it
+// depends on and reads again only the rows that wait concerned: the gather's latency is off the path of a sample that
+// has to wait.  One divisor -- the new scale -- divides all of a sample's values: a/b is formed as Markstein's twice-
+// corrected a * (1/b), which equals the IEEE quotient (tools/divtest.hip: 2.7e11 pairs, no mismatch; a divisor whose
+// significand is all ones, where the theorem does not hold, takes the division instruction).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double div_by(double a, double b, double y /* = 1 / b */) {
+  const double q0 = a * y;
+  const double e0 = fma(-b, q0, a);
+  const double q1 = fma(e0, y, q0);
+  const double e1 = fma(-b, q1, a);
+  return fma(e1, y, q1);
+}
+
+// A forwarded value: two 8-byte granules {32-bit tag, half of the double}; the tag is the writer's sample index + 1, so
+// a granule needs no reset and no flag -- a reader takes the value when both tags are the sample it waits for.
+__device__ __forceinline__ void fw_store(ull* p, unsigned tag, double v) {
+  st_u64(p, ((ull)tag << 32) | (ull)(unsigned)__double2loint(v));
+  st_u64(p + 1, ((ull)tag << 32) | (ull)(unsigned)__double2hiint(v));
+}
+__device__ __forceinline__ bool fw_load(const ull* p, unsigned tag, double& v) {
+  const ull g0 = ld_u64(p), g1 = ld_u64(p + 1);
+  v = __hiloint2double((int)(unsigned)(g1 & 0xffffffffull), (int)(unsigned)(g0 & 0xffffffffull));
+  return (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
+}
+constexpr int kFwVals = 3;                                             // per row: stored P, (AdaGrad) g_sum, g_norm
+constexpr size_t kFwSlot = (size_t)kFwVals * (kWave * kWave + kWave) * 2;  // granules per worker: rows, then the linear terms
+
 template <int OPT>
+__device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot, double* lds) {
+  const CsrView& X = a.X;
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  constexpr bool ADA = OPT == OPT_ADAGRAD;
+  constexpr int K = 64;
+  const int lane = threadIdx.x;
+  const int k = M.k, W = a.W, lgW = a.lgW, MC = a.FW - kWinHdr;
+  double* Fl = lds;                                    // [64][64] rows that arrived late (forwarded or read again)
+  double* Gl = Fl + K * K;                             // AdaGrad: [64][64] g_sum of the sample's rows
+  double* Nl = Gl + (ADA ? K * K : 0);                 // AdaGrad: [64][64] g_norm
+  double* red = Nl + (ADA ? K * K : 0);                // [64]
+  unsigned* cnt = reinterpret_cast<unsigned*>(red + K);  // [W] completion counters as last seen
+  for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
+  double loss_acc = 0.0, viol_acc = 0.0;
+  double Pr[K];
+  ull* fw_base = a.fw + (size_t)slot * kFwSlot;
+  auto fw_row = [&](ull* base, int v, int q) { return base + ((size_t)(v * K + q) * K + lane) * 2; };
+  auto fw_lin = [&](ull* base, int v, int q) { return base + (size_t)kFwVals * K * K * 2 + (size_t)(v * K + q) * 2; };
+
+  for (int64_t u = slot; u < a.n_seg; u += W) {
+    const int64_t pos = a.seg0 + u, pa = a.begin + pos;
+    const int64_t i = a.perm ? a.perm[pa] : pa;
+    const int64_t q0 = X.indptr[i];
+    const int m = (int)(X.indptr[i + 1] - q0);
+    const double y = dev::target_of(X.y[i], M.task);
+    const int64_t it = a.it0 + u;
+    const double itf = (double)it;
+    const int par = (int)((u >> lgW) & 1);
+    ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
+    ull* rp = a.res + (size_t)(slot * 2 + par) * 2;
+    int jq = 0, pq = -1, pqu = 0, nq = -1;
+    double vq = 0.0;
+    if (lane < m) {
+      jq = X.indices[q0 + lane];
+      vq = X.data[q0 + lane];
+      pq = a.prev[q0 + lane];
+      pqu = a.prevq[q0 + lane];
+      nq = a.next[q0 + lane];
+    }
+    double sP = 1.0, sw = 1.0;
+    if constexpr (!ADA) {
+      sP = a.scales[2 * pos];
+      sw = a.scales[2 * pos + 1];
+    }
+    const double itp = (double)(it - 1);
+    const double tmpP = O.eta0 * itp * O.beta;
+    auto pending = [&]() {
+      const int64_t v = (int64_t)pq - a.seg0;
+      return v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW);
+    };
+    compiler_fence();
+    // entries whose previous sample is not known to be finished: a NEAR one (fewer than W positions back) hands its new
+    // row over directly (it wrote it to its forwarding area first of all); a far one is waited for by its counter
+    const bool pend = pending(), near = pend && (pos - (int64_t)pq) < W;
+    const ull fwdmask = __ballot(near), farmask = __ballot(pend && !near), latemask = fwdmask | farmask;
+    const bool late = (latemask >> lane) & 1ull;
+    // the next sample with one of this sample's features within W positions will ask for that row
+    const ull hotmask = __ballot(nq >= 0 && ((int64_t)nq - pos) < W);
+    // step sizes first: nothing below waits for them
+    const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
+    double eta_w = 0.0, eta_P = 0.0, sPn = 1.0, swn = 1.0;
+    if constexpr (!ADA) {
+      eta_w = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, itf);
+      eta_P = dev::get_eta(O.sched, O.eta0, O.power, O.beta, itf);
+      sPn = sP * (1 - eta_P * O.beta);
+      swn = sw * (1 - eta_w * O.alpha);
+    }
+    const double ry = 1.0 / sPn;
+    const bool odd_divisor = (__double_as_longlong(sPn) & 0xFFFFFFFFFFFFFll) == 0xFFFFFFFFFFFFFll;
+
+    // ---- A. all rows requested right away (the late ones are replaced below) ----
+    double wv = 0.0, gwr = 0.0, nwr = 0.0;
+    // AdaGrad update() of one row from (stored P, g_sum, g_norm): adagrad.nim:87-100
+    auto ada_row = [&](double pold, double g, double n, size_t e, bool ok) {
+      double p = pold;
+      if (it != 1) {
+        p = dev::adagrad_param(g, n, O.eta0, tmpP);
+        viol_acc = ok ? viol_acc + fabs(pold - p) : viol_acc;
+        if (ok) st_f64(M.P + e, p);
+      }
+      return p;
+    };
+    auto ada_lin = [&](double wold, double gw, double nw_) {  // fit_linear.nim:50-57
+      double nv = wold;
+      if (it != 1) {
+        const double denom = itp * O.eta0 * O.alpha;
+        nv = -O.eta0 * gw / (denom + sqrt(nw_));
+        viol_acc += fabs(wold - nv);
+        st_f64(M.w + jq, nv);
+      }
+      return nv;
+    };
+    if constexpr (!ADA) {
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        if (q < m) Pr[q] = ld_f64(M.P + (size_t)readlane_i(jq, q) * K + lane);
+      if (lane < m) wv = ld_f64(M.w + jq);
+    } else {
+#pragma unroll
+      for (int qb = 0; qb < K; qb += 8) {
+        if (qb < m) {
+          double p_[8], g_[8], n_[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const size_t e = (size_t)readlane_i(jq, qb + t < m ? qb + t : qb) * K + lane;
+            p_[t] = ld_f64(M.P + e);
+            g_[t] = ld_f64(O.G + e);
+            n_[t] = ld_f64(O.N + e);
+          }
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const bool ok = qb + t < m && !((latemask >> (qb + t)) & 1ull);  // a late row is done again below
+            Pr[qb + t] = ada_row(p_[t], g_[t], n_[t], (size_t)readlane_i(jq, qb + t < m ? qb + t : qb) * K + lane, ok);
+            Gl[(qb + t) * K + lane] = g_[t];
+            Nl[(qb + t) * K + lane] = n_[t];
+          }
+        }
+      }
+      if (lane < m) {
+        wv = ld_f64(M.w + jq);
+        if (M.fit_linear) {
+          gwr = ld_f64(O.Gw + jq);
+          nwr = ld_f64(O.Nw + jq);
+          if (!late) wv = ada_lin(wv, gwr, nwr);
+        }
+      }
+    }
+    // ---- B. far dependencies: wait for the counters, read those rows again ----
+    if (farmask) {
+      Spin sp;
+      while (true) {
+        for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
+        compiler_fence();
+        if (!__any(pend && !near && pending())) break;
+        if (sp.wait(a.ctrl)) return;
+      }
+      for (ull mk = farmask; mk; mk &= mk - 1) {
+        const int q = __builtin_ctzll(mk);
+        const size_t e = (size_t)readlane_i(jq, q) * K + lane;
+        Fl[q * K + lane] = ld_f64(M.P + e);
+        if constexpr (ADA) {
+          Gl[q * K + lane] = ld_f64(O.G + e);
+          Nl[q * K + lane] = ld_f64(O.N + e);
+        }
+      }
+      if ((farmask >> lane) & 1ull) {
+        wv = ld_f64(M.w + jq);
+        if (ADA && M.fit_linear) {
+          gwr = ld_f64(O.Gw + jq);
+          nwr = ld_f64(O.Nw + jq);
+        }
+      }
+    }
+    // ---- C. near dependencies: the writer's forwarding area, polled until it carries the writer's tag ----
+    if (fwdmask) {
+      for (ull mk = fwdmask; mk; mk &= mk - 1) {
+        const int q = __builtin_ctzll(mk);
+        const int64_t up = (int64_t)readlane_i(pq, q) - a.seg0;
+        const unsigned tag = (unsigned)(up + 1);
+        ull* src = a.fw + (size_t)(up & (W - 1)) * kFwSlot;
+        const int qu = readlane_i(pqu, q);
+        Spin sp;
+        double pv, gv = 0.0, nv = 0.0;
+        while (true) {
+          bool ok = fw_load(fw_row(src, 0, qu), tag, pv);
+          if constexpr (ADA) {
+            ok = fw_load(fw_row(src, 1, qu), tag, gv) && ok;
+            ok = fw_load(fw_row(src, 2, qu), tag, nv) && ok;
+          }
+          if (__all(ok)) break;
+          if (sp.wait(a.ctrl)) return;
+        }
+        Fl[q * K + lane] = pv;
+        if constexpr (ADA) {
+          Gl[q * K + lane] = gv;
+          Nl[q * K + lane] = nv;
+        }
+      }
+      const bool mine = (fwdmask >> lane) & 1ull;
+      const int64_t up = (int64_t)pq - a.seg0;
+      const unsigned tag = (unsigned)(up + 1);
+      ull* src = a.fw + (size_t)(mine ? (up & (W - 1)) : 0) * kFwSlot;
+      Spin sp;
+      while (true) {
+        bool ok = true;
+        if (mine) {
+          ok = fw_load(fw_lin(src, 0, pqu), tag, wv);
+          if (ADA && M.fit_linear) {
+            ok = fw_load(fw_lin(src, 1, pqu), tag, gwr) && ok;
+            ok = fw_load(fw_lin(src, 2, pqu), tag, nwr) && ok;
+          }
+        }
+        if (__all(ok)) break;
+        if (sp.wait(a.ctrl)) return;
+      }
+    }
+    if (latemask) {
+      compiler_fence();
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        if (q < m && ((latemask >> q) & 1ull)) {
+          if constexpr (ADA) Pr[q] = ada_row(Fl[q * K + lane], Gl[q * K + lane], Nl[q * K + lane], (size_t)readlane_i(jq, q) * K + lane, true);
+          else Pr[q] = Fl[q * K + lane];
+        }
+      }
+      if (ADA && M.fit_linear && late) wv = ada_lin(wv, gwr, nwr);
+    }
+    // ---- D. per-factor sums over the entries in storage order, their sum over the factors in ascending order ----
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      if (q < m) {
+        const double t = readlane_d(vq, q) * (sP * Pr[q]);
+        a1 += t;
+        a2 += t * t;
+      }
+    }
+    const double kv = (a1 * a1 - a2) / 2;
+    red[lane] = lane < k ? kv : 0.0;  // (never -0.0: adding the padding changes nothing)
+    compiler_fence();
+    // what the update needs of a row (scale x stored value, the entry's value, its address) is formed again there: kept
+    // alive from here, 64 rows' worth of it would not fit the registers
+#pragma unroll
+    for (int q = 0; q < K; ++q) asm volatile("" : "+v"(Pr[q]));
+    asm volatile("" : "+v"(vq), "+v"(jq));
+    double tot = 0.0;
+#pragma unroll
+    for (int tb = 0; tb < K / 2; tb += 8) {  // 16 values requested together (the rows keep 128 registers)
+      double2 r_[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) r_[t] = *reinterpret_cast<const double2*>(red + 2 * (tb + t));
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        tot += r_[t].x;
+        tot += r_[t].y;
+      }
+    }
+    if (lane < MC) st_u64(mb + lane, mail_bits(lane < m ? (sw * wv) * vq : -0.0));
+    if (lane < kWinHdr) st_u64(mb + MC + lane, mail_bits(lane == 0 ? tot : lane == 1 ? y : lane == 2 ? h2 : 0.0));
+
+    // ---- E. {dL, yhat} from the conductor ----
+    double dL, yh;
+    {
+      Spin sp;
+      ull rv;
+      while (true) {
+        rv = ld_u64(rp + (lane & 1));
+        if (__all(rv != kWinSentinel)) break;
+        if (sp.wait(a.ctrl)) return;
+      }
+      const double rd = __longlong_as_double((long long)rv);
+      dL = readlane_d(rd, 0);
+      yh = readlane_d(rd, 1);
+    }
+
+    // ---- F. update(): sgd.nim:205-243 / updateG(): adagrad.nim:113-134; the rows somebody is about to ask for first ----
+    const unsigned mytag = (unsigned)(u + 1);
+    // (the forwarding area's base is made opaque per sample and per use: left to itself the compiler hoists the 192
+    // row addresses out of the sample loop and spills them)
+    auto row_step = [&](int q, double prq, bool hot) {
+      ull* fw_mine = fw_base;
+      asm volatile("" : "+s"(fw_mine));
+      const size_t e = (size_t)readlane_i(jq, q) * K + lane;
+      const double vs = readlane_d(vq, q);
+      const double p = sP * prq;
+      const double d_ = vs * (a1 - p * vs);
+      if constexpr (ADA) {
+        const double grad = dL * d_;
+        const double gn = Gl[q * K + lane] + grad, nn = Nl[q * K + lane] + grad * grad;
+        if (hot) {
+          fw_store(fw_row(fw_mine, 0, q), mytag, prq);
+          fw_store(fw_row(fw_mine, 1, q), mytag, gn);
+          fw_store(fw_row(fw_mine, 2, q), mytag, nn);
+        }
+        st_f64(O.G + e, gn);
+        st_f64(O.N + e, nn);
+      } else {
+        const double update = eta_P * (dL * d_ + O.beta * p);
+        viol_acc += fabs(update);
+        const double nv = div_by(p - update, sPn, ry);
+        if (hot) fw_store(fw_row(fw_mine, 0, q), mytag, nv);
+        st_f64(M.P + e, nv);
+      }
+    };
+    double w_new = 0.0, gw_new = 0.0, nw_new = 0.0;
+    if (M.fit_linear && lane < m) {
+      if constexpr (ADA) {
+        const double gg = dL * vq;
+        gw_new = gwr + gg;
+        nw_new = nwr + gg * gg;
+        w_new = wv;
+      } else {
+        const double wj = sw * wv;
+        const double update = eta_w * (dL * vq + O.alpha * wj);
+        viol_acc += fabs(update);
+        w_new = (wj - update) / swn;
+      }
+    } else {
+      w_new = wv;
+    }
+    if (!ADA && odd_divisor) {
+      // a divisor with an all-ones significand (one sample in 2^52): the division instruction, rows through LDS
+#pragma unroll
+      for (int q = 0; q < K; ++q) Fl[q * K + lane] = Pr[q];
+      compiler_fence();
+      for (int q = 0; q < m; ++q) {
+        const size_t e = (size_t)readlane_i(jq, q) * K + lane;
+        const double vs = readlane_d(vq, q);
+        const double p = sP * Fl[q * K + lane];
+        const double update = eta_P * (dL * (vs * (a1 - p * vs)) + O.beta * p);
+        viol_acc += fabs(update);
+        const double nv = (p - update) / sPn;
+        if ((hotmask >> q) & 1ull) fw_store(fw_row(fw_base, 0, q), mytag, nv);
+        st_f64(M.P + e, nv);
+      }
+    } else if (hotmask) {
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        if (q < m && ((hotmask >> q) & 1ull)) row_step(q, Pr[q], true);
+    }
+    if (hotmask) {
+      ull* fw_mine = fw_base;
+      asm volatile("" : "+s"(fw_mine));
+      if ((hotmask >> lane) & 1ull) {
+        fw_store(fw_lin(fw_mine, 0, lane), mytag, w_new);
+        if constexpr (ADA) {
+          fw_store(fw_lin(fw_mine, 1, lane), mytag, gw_new);
+          fw_store(fw_lin(fw_mine, 2, lane), mytag, nw_new);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) asm volatile("" : "+v"(Pr[q]));
+    asm volatile("" : "+v"(vq), "+v"(jq));
+    if (ADA || !odd_divisor) {
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        if (q < m && !((hotmask >> q) & 1ull)) row_step(q, Pr[q], false);
+    }
+    if (M.fit_linear && lane < m) {
+      if constexpr (ADA) {
+        st_f64(O.Gw + jq, gw_new);
+        st_f64(O.Nw + jq, nw_new);
+      } else {
+        st_f64(M.w + jq, w_new);
+      }
+    }
+    // both mailboxes back to "empty" for their next use, two samples of this worker from now: these stores have
+    // completed (vmcnt(0) below) before this worker posts its next sample, which the conductor consumes before it can
+    // look at these words again (kWinDepth < W)
+    if (lane < a.FW) st_u64(mb + lane, kWinSentinel);
+    if (lane < a.FW - kWave) st_u64(mb + kWave + lane, kWinSentinel);
+    if (lane < 2) st_u64(rp + lane, kWinSentinel);
+    if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
+    // ---- G. rows written: tell the far waiters ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
+  }
+  viol_acc = dev::wave_sum(viol_acc);
+  if (lane == 0) {
+    a.partial[2 * slot] = loss_acc;
+    a.partial[2 * slot + 1] = viol_acc;
+  }
+}
+
+template <int OPT, int CH, bool K64>
 __global__ __launch_bounds__(128) void k_seq_window(WinArgs a) {
   extern __shared__ double lds[];
   if (blockIdx.x == 0) {
-    win_conductor<OPT>(a, lds);
-  } else {
-    if (threadIdx.x < kWave) win_worker<OPT>(a, (int)blockIdx.x - 1, lds);
+    win_conductor<OPT, CH>(a, lds);
+  } else if (threadIdx.x < kWave) {
+    if constexpr (K64) win_worker_k64<OPT>(a, (int)blockIdx.x - 1, lds);
+    else win_worker<OPT>(a, (int)blockIdx.x - 1, lds);
   }
 }
 
@@ -630,21 +1108,37 @@ __global__ void k_win_expand(CsrView X, const int64_t* perm, int64_t begin, int6
     vals[o + q] = (uint32_t)(q0 + q);
   }
 }
-__global__ void k_win_prev(const ull* keys, const uint32_t* vals, int64_t T, int32_t* prev) {
+__global__ void k_win_prev(CsrView X, const int64_t* perm, int64_t begin, const ull* keys, const uint32_t* vals, int64_t T,
+                           int32_t* prev, uint8_t* prevq, int32_t* next) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= T) return;
   const ull kcur = keys[e];
-  int32_t p = -1;
+  int32_t p = -1, nx = -1;
+  uint8_t pqu = 0;
   if (e > 0) {
     const ull kp = keys[e - 1];
-    if ((kp >> 32) == (kcur >> 32)) p = (int32_t)(uint32_t)(kp & 0xffffffffull);
+    if ((kp >> 32) == (kcur >> 32)) {
+      p = (int32_t)(uint32_t)(kp & 0xffffffffull);
+      const int64_t ip = perm ? perm[begin + p] : begin + p;
+      const int64_t qu = (int64_t)vals[e - 1] - X.indptr[ip];  // the feature's place in the previous sample's row
+      pqu = (uint8_t)(qu < 256 ? qu : 255);
+    }
   }
-  prev[vals[e]] = p;
+  if (e + 1 < T) {
+    const ull kn = keys[e + 1];
+    if ((kn >> 32) == (kcur >> 32)) nx = (int32_t)(uint32_t)(kn & 0xffffffffull);
+  }
+  const uint32_t at = vals[e];
+  prev[at] = p;
+  prevq[at] = pqu;
+  next[at] = nx;
 }
 
 static int build_prev(nfm_ctx* ctx, const CsrView& X, const int64_t* perm_dev, int64_t begin, int64_t ns, SeqWin* sw) {
   hipStream_t st = ctx->stream;
   NFM_TRY(sw->prev.ensure(sizeof(int32_t) * (size_t)(X.nnz > 0 ? X.nnz : 1)));
+  NFM_TRY(sw->next.ensure(sizeof(int32_t) * (size_t)(X.nnz > 0 ? X.nnz : 1)));
+  NFM_TRY(sw->prevq.ensure((size_t)(X.nnz > 0 ? X.nnz : 1)));
   DevBuf len, off, k0, k1, v0, v1, tmp;
   NFM_TRY(len.alloc(sizeof(int64_t) * (ns + 1)));
   NFM_TRY(off.alloc(sizeof(int64_t) * (ns + 1)));
@@ -673,7 +1167,8 @@ static int build_prev(nfm_ctx* ctx, const CsrView& X, const int64_t* perm_dev, i
   NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dk, dv, (int)T, 0, 32 + fbits, st));
   NFM_TRY(tmp.alloc(bytes));
   NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, dk, dv, (int)T, 0, 32 + fbits, st));
-  hipLaunchKernelGGL(k_win_prev, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, dk.Current(), dv.Current(), T, sw->prev.as<int32_t>());
+  hipLaunchKernelGGL(k_win_prev, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, X, perm_dev, begin, dk.Current(), dv.Current(), T,
+                     sw->prev.as<int32_t>(), sw->prevq.as<uint8_t>(), sw->next.as<int32_t>());
   NFM_HIP_CHECK(hipGetLastError());
   NFM_HIP_CHECK(hipStreamSynchronize(st));  // the temporaries go back to the pool
   return NFM_OK;
@@ -685,20 +1180,25 @@ bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz
   if (mode == 0) return false;
   if (M.kind != NFM_KIND_FM || M.nb != 1 || M.degree != 2 || M.n_aug != 0) return false;
   if (M.Kp > kWave || M.Kp < 2) return false;
-  if (kWinHdr + (m_cap + 7) / 8 * 8 > kWave * kWinMaxNL) return false;
+  if (kWinHdr + (m_cap + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
   if (nnz >= ((int64_t)1 << 32) || M.d >= ((int64_t)1 << 31) || ns >= ((int64_t)1 << 31)) return false;
   if (n_cu < 10) return false;
   return mode == 2 || ns >= 2048;
 }
 
-template <int OPT>
+template <int OPT, int CH, bool K64>
 static int launch_window_t(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes) {
-  auto kern = k_seq_window<OPT>;
+  auto kern = k_seq_window<OPT, CH, K64>;
   NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   TimedLaunch tl(ctx, "sequential");
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.W + 1)), dim3(128), lds_bytes, ctx->stream, a);
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
+}
+template <int OPT>
+static int launch_window(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes, int ch, bool k64) {
+  if (k64) return ch == 32 ? launch_window_t<OPT, 32, true>(ctx, a, lds_bytes) : launch_window_t<OPT, 64, true>(ctx, a, lds_bytes);
+  return ch == 32 ? launch_window_t<OPT, 32, false>(ctx, a, lds_bytes) : launch_window_t<OPT, 64, false>(ctx, a, lds_bytes);
 }
 
 int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const int64_t* perm_dev,
@@ -711,14 +1211,16 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   // worker count: a power of two, one workgroup per CU with one CU left for the conductor
   int W = 64;
   if (const char* env = getenv("NFM_SEQ_WIN_W")) W = atoi(env);
-  int lgW = 3;
+  int lgW = 4;
   while ((2 << lgW) <= W && lgW < 7) ++lgW;
   W = 1 << lgW;
-  while (W + 1 > ctx->n_cu && lgW > 3) W = 1 << --lgW;
+  while (W + 1 > ctx->n_cu && lgW > 4) W = 1 << --lgW;
   NFM_CHECK(W > kWinDepth && W + 1 <= ctx->n_cu, NFM_ERR_UNSUPPORTED, "the dependency window needs %d resident workgroups", W + 1);
   int lgKp = 1;
   while ((1 << lgKp) < M.Kp) ++lgKp;
-  const int FW = kWinHdr + (m_cap + 7) / 8 * 8;
+  const int ch = m_cap <= 32 ? 32 : 64;  // the chain's chunk of terms; a mailbox holds MC = a multiple of it
+  const int FW = kWinHdr + (m_cap + ch - 1) / ch * ch;
+  const bool k64 = M.Kp == kWave && m_cap <= kWave;  // the register-resident worker
   // the previous-position table of this order (kept while the same samples are walked in storage order)
   const bool reuse = sw->valid && !perm_is_callers && !sw->had_perm && sw->ds_uid == ds_uid && sw->begin == begin && sw->end == end && sw->nnz == X.nnz;
   if (!reuse) {
@@ -743,6 +1245,10 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   a.perm = perm_dev;
   a.begin = begin;
   a.prev = sw->prev.as<int32_t>();
+  a.prevq = sw->prevq.as<uint8_t>();
+  a.next = sw->next.as<int32_t>();
+  NFM_TRY(sw->fw.ensure(sizeof(ull) * kFwSlot * (size_t)W));
+  a.fw = sw->fw.as<ull>();
   a.scales = ada ? nullptr : sw->scales.as<double>();
   a.fwd = sw->mail.as<ull>();
   a.res = a.fwd + n_fwd;
@@ -757,6 +1263,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   a.lgKp = lgKp;
   const size_t rows = (size_t)m_cap * M.Kp;
   size_t lds_worker = sizeof(double) * ((ada ? 4 : 2) * rows + kWave + (ada ? 4 : 2) * (size_t)m_cap) + sizeof(int) * 2 * (size_t)m_cap + sizeof(unsigned) * W;
+  if (k64) lds_worker = sizeof(double) * ((ada ? 3 : 1) * (size_t)kWave * kWave + kWave) + sizeof(unsigned) * W;
   const size_t lds_cond = sizeof(double) * 2 + sizeof(ull) * (size_t)kWinRing * FW;
   size_t lds_bytes = lds_worker > lds_cond ? lds_worker : lds_cond;
   NFM_CHECK(lds_bytes <= 160 * 1024, NFM_ERR_UNSUPPORTED, "row too long for the dependency window (%zu bytes of LDS)", lds_bytes);
@@ -775,14 +1282,15 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     // mailboxes empty, counters and abort word zero
     {
       NFM_HIP_CHECK(hipMemsetAsync(sw->ctl.p, 0, sizeof(unsigned) * (W + 64) + sizeof(double) * 2 * (W + 1), st));
+      if (k64) NFM_HIP_CHECK(hipMemsetAsync(sw->fw.p, 0, sizeof(ull) * kFwSlot * (size_t)W, st));  // tag 0: nobody's
       const int64_t nm = (int64_t)(n_fwd + n_res);
       hipLaunchKernelGGL(k_win_fill, dim3((unsigned)((nm + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sw->mail.as<ull>(), nm, kWinSentinel);
     }
     a.seg0 = pos;
     a.n_seg = last - pos + 1;
     a.it0 = it0 + pos;
-    if (ada) NFM_TRY(launch_window_t<OPT_ADAGRAD>(ctx, a, lds_bytes));
-    else NFM_TRY(launch_window_t<OPT_SGD>(ctx, a, lds_bytes));
+    if (ada) NFM_TRY(launch_window<OPT_ADAGRAD>(ctx, a, lds_bytes, ch, k64));
+    else NFM_TRY(launch_window<OPT_SGD>(ctx, a, lds_bytes, ch, k64));
     hipLaunchKernelGGL(k_win_finish, dim3(1), dim3(kWave), 0, st, a.partial, W, out2_dev);
     if (!ada && host_info[1]) {
       const int64_t nP = (int64_t)M.nb * M.da * M.Kp;

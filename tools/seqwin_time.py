@@ -10,10 +10,25 @@ Ws = [int(w) for w in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 32, 
 shapes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["cfg2", "headline"]
 dev = torch.device("cuda", 0)
 ctx = nf.Context(0); nf.set_default_context(ctx)
-SH = {"cfg2": (100_000, 32, 16), "headline": (1_000_000, 64, 64)}
+SH = {"cfg2": (100_000, 32, 16), "headline": (1_000_000, 64, 64), "nodep64": (0, 64, 64), "nodep32": (0, 32, 16),
+      "dep1_64": (-1, 64, 64), "dep4_64": (-4, 64, 64), "dep16_64": (-16, 64, 64), "dep1_32": (-1, 32, 16)}
 for name in shapes:
     d, m, k = SH[name]
-    indptr, indices, data = gen_shard(torch, dev, n, d, m, 42)
+    if d < 0:  # sample t shares exactly ONE feature with sample t - delta: time per sample x delta = the turnaround of a dependency
+        delta = -d
+        d = n * m + delta
+        indptr = torch.arange(n + 1, device=dev, dtype=torch.int64) * m
+        idx = torch.arange(n * m, device=dev, dtype=torch.int64).reshape(n, m)
+        idx[delta:, 0] = idx[:-delta, 1]
+        indices = idx.reshape(-1).to(torch.int32)
+        data = torch.rand(n * m, device=dev, dtype=torch.float64) * 2 - 1
+    elif d == 0:  # no two samples share a feature: what the conductor alone sustains
+        d = n * m
+        indptr = torch.arange(n + 1, device=dev, dtype=torch.int64) * m
+        indices = torch.arange(n * m, device=dev, dtype=torch.int32)
+        data = torch.rand(n * m, device=dev, dtype=torch.float64) * 2 - 1
+    else:
+        indptr, indices, data = gen_shard(torch, dev, n, d, m, 42)
     X = nf.CSRDataset.from_device(ctx, n, d, n * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), keep=(indptr, indices, data))
     y = np.sign(np.random.default_rng(0).standard_normal(n))
     for solver in ("sgd", "adagrad"):
