@@ -500,7 +500,8 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     # reference exactly, reported beside the mini-batch rule's ----
     exact = None
     if rank == 0 and world == 1 and not F:
-        ns_ = min(n, 20000)
+        windowed = wl["degree"] == 2 and k <= 64  # seqwin.hip: the order as a dependency window over the chip
+        ns_ = min(n, 2_000_000 if windowed else 20_000)
         Xs = nf.CSRDataset.from_device(ctx, ns_, d, ns_ * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(),
                                        keep=(indptr, indices, data))
         Xs.set_targets(np.ascontiguousarray(y[:ns_]))
@@ -509,15 +510,35 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         mk_ = nf.newSGD if wl["solver"] == "sgd" else nf.newAdaGrad
         opt_s = mk_(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="sequential")
         opt_s._handle(fm_s, ctx, "sequential")
+        ctx.timing_reset()
+        ctx.timing_enable(True)
+        opt_s._epoch(Xs, None, 0, ns_)  # first epoch: builds the dependency table of this order (kept while the order stays)
+        opt_s.it += ns_
+        ctx.synchronize()
+        deps_ms = ctx.timing_get("seq_window_deps")[1]
+        ctx.timing_reset()
+        t_s = time.perf_counter()
         opt_s._epoch(Xs, None, 0, ns_)
         opt_s.it += ns_
         ctx.synchronize()
-        t_s = time.perf_counter()
-        opt_s._epoch(Xs, None, 0, ns_)
-        ctx.synchronize()
         t_s = time.perf_counter() - t_s
-        exact = {"value": round(ns_ / t_s, 1), "unit": "samples/s", "us_per_step": round(t_s / ns_ * 1e6, 2),
-                 "sample": "the first %d samples of the shard, storage order, mode=sequential (csrc/seq.hip)" % ns_}
+        kern_ms = ctx.timing_get("sequential")[1]
+        # the reference's default: a fresh order every epoch (sgd.nim:297) -- permutation from the host, table rebuilt
+        perm_s = np.random.default_rng(5).permutation(ns_).astype(np.int64)
+        t_p = time.perf_counter()
+        opt_s._epoch(Xs, perm_s, 0, ns_)
+        ctx.synchronize()
+        t_p = time.perf_counter() - t_p
+        ctx.timing_enable(False)
+        exact = {"value": round(ns_ / t_s, 1), "unit": "samples/s", "us_per_step": round(t_s / ns_ * 1e6, 3),
+                 "kernel_only": round(ns_ / (kern_ms * 1e-3), 1) if kern_ms > 0 else None,
+                 "value_fresh_order": round(ns_ / t_p, 1),
+                 "dependency_table_ms": round(deps_ms, 2),
+                 "sample": "the first %d samples of the shard, mode=sequential: %s; value = one epoch call (wall clock) over a fixed "
+                           "order whose dependency table exists, value_fresh_order = one epoch call with a new permutation from "
+                           "the host (upload + table build inside)" %
+                           (ns_, "the reference's order as a dependency window over the chip (csrc/seqwin.hip), results bit-equal to "
+                            "the one-workgroup kernel" if windowed else "one workgroup (csrc/seq.hip)")}
         del opt_s, fm_s, Xs
 
     # ---- roofline leg: per-kernel durations from HIP events on the library's stream (one replica, no exchange) ----
@@ -564,6 +585,9 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not F:
         cpu = cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, cheap=not primary)
 
+    if exact is not None and cpu is not None and cpu.get("value"):
+        # both run the reference's sample order and give the same parameters: the like-for-like ratio
+        exact["vs_cpu_port_1_thread"] = round(exact["value"] / cpu["value"], 2)
     return {"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "steps": steps, "warmup": warmup,
             "value_shuffled": round(value_shuffled, 1),
             "value_shuffled_host_perm": round(value_shuffled_host, 1),

@@ -1021,6 +1021,7 @@ __global__ __launch_bounds__(64) void k_win_scales(ModelView M, OptView O, int64
   double sc = lane == 0 ? M.sc[SC_SCALE_P] : M.sc[SC_SCALE_W];  // lane 0 carries scale_P, lane 1 scale_w
   int64_t last = ns - 1;
   int flags = 0;
+  const bool watch = lane == 0 || M.fit_linear;
   for (int64_t base = pos0; base < ns; base += kWave) {
     const int cnt = (int)(ns - base < kWave ? ns - base : kWave);
     const double itf = (double)(it0 + (base - pos0) + lane);
@@ -1029,18 +1030,35 @@ __global__ __launch_bounds__(64) void k_win_scales(ModelView M, OptView O, int64
     f[1][lane] = M.fit_linear ? 1 - dev::get_eta(O.sched, O.eta0, O.power, O.alpha, itf) * O.alpha : 1.0;
     __syncthreads();
     if (lane < 2) {
-      int stop = -1;
-      double c = sc;
-      const bool watch = lane == 0 || M.fit_linear;
-      for (int t = 0; t < cnt; ++t) {
-        o[lane][t] = c;
-        c = c * f[lane][t];
-        if (watch && c < 1e-9) {  // resetScaling after this sample (sgd.nim:116-131)
-          stop = t;
-          break;
-        }
+      // the 64 factors into registers at once, then the chain: one multiplication per sample, nothing else on its path
+      double fr[kWave], orr[kWave];
+#pragma unroll
+      for (int t = 0; t < kWave; t += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(&f[lane][t]);
+        fr[t] = v.x;
+        fr[t + 1] = v.y;
       }
-      sc = c;
+      double c = sc;
+#pragma unroll
+      for (int t = 0; t < kWave; ++t) {
+        orr[t] = c;
+        c = c * fr[t];
+        fr[t] = c;  // the value after sample t
+      }
+      int stop = -1;
+      if (watch) {  // resetScaling after the first sample that leaves the scale below 1e-9 (sgd.nim:116-131)
+#pragma unroll
+        for (int t = kWave - 1; t >= 0; --t)
+          if (t < cnt && fr[t] < 1e-9) stop = t;
+      }
+#pragma unroll
+      for (int t = 0; t < kWave; t += 2) *reinterpret_cast<double2*>(&o[lane][t]) = double2{orr[t], orr[t + 1]};
+      sc = stop >= 0 ? fr[0] : c;  // (overwritten below when a chain stops)
+      if (cnt < kWave && stop < 0) {  // a short last block: the value after its last sample
+#pragma unroll
+        for (int t = 0; t < kWave; ++t)
+          if (t == cnt - 1) sc = fr[t];
+      }
       stp[lane] = stop;
     }
     __syncthreads();
