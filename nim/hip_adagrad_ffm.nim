@@ -13,7 +13,8 @@ proc fit*[L](self: AdaGrad[L], X: HipCSRFieldDataset, y: seq[float64], ffm: Fiel
   hipFitAdaGrad(self, X, y, ffm, push(ffm), ffm.P.shape, nfmModeSequential, 1, callback)
 
 proc fit*[L](self: AdaGrad[L], X: HipCSRFieldDataset, y: seq[float64], ffm: FieldAwareFactorizationMachine,
-             maxThreads: int, callback: (AdaGrad[L], FieldAwareFactorizationMachine)->void = nil) =
+             maxThreads: int, callback: (AdaGrad[L], FieldAwareFactorizationMachine)->void = nil,
+             miniBatchSize: int = defaultBatch(), syncPeriod: int = 0, group: HipGroup = nil) =
+  discard maxThreads  # selects the mini-batch mode; its knobs are the defaulted arguments (hip_sgd.nim)
   ffm.init(X)
-  hipFitAdaGrad(self, X, y, ffm, push(ffm), ffm.P.shape, nfmModeMinibatch,
-                (if maxThreads >= 64: maxThreads else: defaultBatch()), callback)
+  hipFitAdaGrad(self, X, y, ffm, push(ffm), ffm.P.shape, nfmModeMinibatch, miniBatchSize, callback, group, syncPeriod)

@@ -7,7 +7,7 @@
 import nimfm_hip
 
 proc hipFitSGD[L](self: SGD[L], X: HipCSRDataset, y: seq[float64], fm: FactorizationMachine, mode: int32,
-                  batch: int, callback: (SGD[L], FactorizationMachine)->void) =
+                  batch: int, callback: (SGD[L], FactorizationMachine)->void, group: HipGroup = nil, syncPeriod = 0) =
   fm.init(X)                                    # generic over the dataset: factorization_machine.nim:125-139
   var yy = fm.checkTarget(y)                    # fm_base.nim:29-36 (the device applies the same rule by task)
   if yy.len != X.nSamples: raise newException(ValueError, "len(y) != nSamples")
@@ -19,6 +19,7 @@ proc hipFitSGD[L](self: SGD[L], X: HipCSRDataset, y: seq[float64], fm: Factoriza
                       scheduling: ord(self.scheduling).int32, mode: mode, batch: batch.int64)
   var o: NfmOpt
   check nfm_sgd_create(m, addr cfg, addr o)
+  attach(o, group, syncPeriod)
   let fc = HipFitCfg(maxIter: self.maxIter, verbose: self.verbose, nCalls: self.nCalls, tol: self.tol,
                      alpha0: self.alpha0, alpha: self.alpha, beta: self.beta, shuffle: self.shuffle,
                      callbackEveryEpochOnly: true, minibatch: mode == nfmModeMinibatch)
@@ -39,7 +40,11 @@ proc fit*[L](self: SGD[L], X: HipCSRDataset, y: seq[float64], fm: FactorizationM
   hipFitSGD(self, X, y, fm, nfmModeSequential, 1, callback)
 
 proc fit*[L](self: SGD[L], X: HipCSRDataset, y: seq[float64], fm: FactorizationMachine, maxThreads: int,
-             callback: (SGD[L], FactorizationMachine)->void = nil) =
-  ## optimizer/sgd_multi.nim:40-120: the Hogwild overload is served by the deterministic mini-batch mode;
-  ## maxThreads > 1 is read as the mini-batch size when it is >= 64, else the default 8192 is used
-  hipFitSGD(self, X, y, fm, nfmModeMinibatch, (if maxThreads >= 64: maxThreads else: defaultBatch()), callback)
+             callback: (SGD[L], FactorizationMachine)->void = nil, miniBatchSize: int = defaultBatch(),
+             syncPeriod: int = 0, group: HipGroup = nil) =
+  ## optimizer/sgd_multi.nim:40-120: the Hogwild overload is served by the deterministic mini-batch mode.  `maxThreads`
+  ## keeps its place in the signature and only selects this mode: a thread count is not a batch size.  The knobs of the
+  ## mode are explicit and defaulted: `miniBatchSize` (NIMFM_HIP_BATCH, else 8192), and across GPUs -- one process per
+  ## GPU, X being this rank's slice -- `group` with `syncPeriod` mini-batches between exchanges.
+  discard maxThreads
+  hipFitSGD(self, X, y, fm, nfmModeMinibatch, miniBatchSize, callback, group, syncPeriod)

@@ -9,7 +9,8 @@
 import nimfm_hip
 
 proc hipFitSGDFFM[L](self: SGD[L], X: HipCSRFieldDataset, y: seq[float64], ffm: FieldAwareFactorizationMachine,
-                     mode: int32, batch: int, callback: (SGD[L], FieldAwareFactorizationMachine)->void) =
+                     mode: int32, batch: int, callback: (SGD[L], FieldAwareFactorizationMachine)->void,
+                     group: HipGroup = nil, syncPeriod = 0) =
   ffm.init(X)                                   # nimfm_hip.init: field_aware_factorization_machine.nim:79-92
   var yy = ffm.checkTarget(y)
   if yy.len != X.nSamples: raise newException(ValueError, "len(y) != nSamples")
@@ -22,6 +23,7 @@ proc hipFitSGDFFM[L](self: SGD[L], X: HipCSRFieldDataset, y: seq[float64], ffm: 
                       mode: mode, batch: batch.int64)
   var o: NfmOpt
   check nfm_sgd_create(m, addr cfg, addr o)
+  attach(o, group, syncPeriod)
   let fc = HipFitCfg(maxIter: self.maxIter, verbose: self.verbose, nCalls: self.nCalls, tol: self.tol,
                      alpha0: self.alpha0, alpha: self.alpha, beta: self.beta, shuffle: self.shuffle,
                      callbackEveryEpochOnly: true, minibatch: mode == nfmModeMinibatch)
@@ -42,6 +44,8 @@ proc fit*[L](self: SGD[L], X: HipCSRFieldDataset, y: seq[float64], ffm: FieldAwa
   hipFitSGDFFM(self, X, y, ffm, nfmModeSequential, 1, callback)
 
 proc fit*[L](self: SGD[L], X: HipCSRFieldDataset, y: seq[float64], ffm: FieldAwareFactorizationMachine,
-             maxThreads: int, callback: (SGD[L], FieldAwareFactorizationMachine)->void = nil) =
-  ## optimizer/sgd_ffm_multi.nim -> the deterministic mini-batch mode
-  hipFitSGDFFM(self, X, y, ffm, nfmModeMinibatch, (if maxThreads >= 64: maxThreads else: defaultBatch()), callback)
+             maxThreads: int, callback: (SGD[L], FieldAwareFactorizationMachine)->void = nil,
+             miniBatchSize: int = defaultBatch(), syncPeriod: int = 0, group: HipGroup = nil) =
+  ## optimizer/sgd_ffm_multi.nim -> the deterministic mini-batch mode; maxThreads only selects it (hip_sgd.nim)
+  discard maxThreads
+  hipFitSGDFFM(self, X, y, ffm, nfmModeMinibatch, miniBatchSize, callback, group, syncPeriod)

@@ -26,6 +26,7 @@
 ## toolchain there, SURVEY.md section 0).  tests/test_nim_shim.py checks every `proc nfm_*` below against
 ## include/nimfm_hip.h (name, arity, parameter widths, struct layouts).  The executable stand-in with the same
 ## control flow is nimfm_amd/host.py.
+import os, strutils
 import nimfm/[dataset, loss, metrics, utils]
 import nimfm/tensor/[tensor, sparse]
 import nimfm/model/[fm_base, factorization_machine, field_aware_factorization_machine, params]
@@ -385,4 +386,33 @@ proc hipEpochLoop*(o: NfmOpt, m: NfmModel, ds: NfmDataset, nSamples: int, c: Hip
     echo("Objective did not converge. Increase maxIter.")
   pull()                                      # finalize + transpose back, sgd.nim:327-328 / adagrad.nim:202-203
 
-proc defaultBatch*(): int = 8192   ## mini-batch of the maxThreads overloads (BASELINE.json configs[2])
+proc defaultBatch*(): int =
+  ## mini-batch size of the maxThreads overloads when the caller does not pass `miniBatchSize`: the environment's
+  ## NIMFM_HIP_BATCH, else 8192 (BASELINE.json configs[2]).  `maxThreads` itself only SELECTS the mini-batch mode -- its
+  ## value (a thread count in the reference, optimizer/sgd_multi.nim:13-18) says nothing about a batch size.
+  let e = getEnv("NIMFM_HIP_BATCH")
+  if e.len > 0: max(1, parseInt(e)) else: 8192
+
+type HipGroup* = ref object
+  ## one rank's handle of a data-parallel group (nfm_dp_*): one process per GPU, every rank calls `fit` on its own
+  ## contiguous slice of the samples (optimizer/sgd_multi.nim:85-88) and passes its handle as `group`
+  handle*: NfmDp
+
+proc newHipGroup*(ctx: NfmCtx, id: array[128, byte], rank, world: int): HipGroup =
+  ## `id`: made once by rank 0 (hipGroupId) and carried to the other ranks by whatever the host has (a file, MPI ...)
+  new(result)
+  var idv = id
+  check nfm_dp_create(ctx, addr idv[0], rank.int32, world.int32, addr result.handle)
+
+proc hipGroupId*(): array[128, byte] =
+  check nfm_dp_unique_id(addr result[0])
+
+proc close*(g: HipGroup) =
+  if not g.isNil and not g.handle.isNil:
+    discard nfm_dp_destroy(g.handle)
+    g.handle = nil
+
+proc attach*(o: NfmOpt, group: HipGroup, syncPeriod: int) =
+  ## the maxThreads overloads across GPUs: replicas reconciled every `syncPeriod` mini-batches (0: at the end of every
+  ## epoch only) and exactly at the end of every epoch call
+  if not group.isNil: check nfm_opt_set_dp(o, group.handle, syncPeriod.int64, 1)

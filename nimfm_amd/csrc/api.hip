@@ -103,8 +103,9 @@ struct nfm_opt {
   const int64_t* announced = nullptr;
   int64_t announced_begin = 0, announced_end = 0;
   const int64_t* next_plan_perm = nullptr;  // the host array next_plan was built from
-  int64_t next_probe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t next_probe[64] = {0};  // entries of that array at 64 evenly spaced places: it must come back unchanged
   nfm_dp* dp = nullptr;
+  uint64_t dp_uid = 0;  // the group is checked against the live groups before every use (it may have been destroyed)
   int64_t dp_sync_period = 0;
   bool dp_overlap = true;
   int dp_combine = 0;  // NFM_DP_MEAN / NFM_DP_SUM (SGD)
@@ -777,6 +778,10 @@ int32_t nfm_opt_set_it(nfm_opt* o, int64_t it) {
   // newMBPSGD starts at it = 0 and a warm-started fit keeps it (minibatch_psgd.nim:63,153-154)
   NFM_CHECK(it >= (o->kind == OPT_PSGD ? 0 : 1), NFM_ERR_INVALID, "it must be >= 1");
   o->it = it;
+  // a new fit starts here: a plan prepared for "the next epoch" of an earlier fit (announced or device-drawn order) is
+  // not carried into it
+  o->next_plan_ready = false;
+  o->announced = nullptr;
   return NFM_OK;
 }
 int32_t nfm_opt_get_it(nfm_opt* o, int64_t* it) {
@@ -874,6 +879,29 @@ static int ensure_unit_scale(nfm_model* m) {
   return NFM_OK;
 }
 
+// what one nfm_opt_epoch call of an optimizer with a group attached exchanges (dp.h)
+static int dp_epoch_setup(nfm_opt* o, nfm_model* m, const ModelView& M, DpEpoch* out) {
+  NFM_CHECK(o->kind != OPT_PSGD, NFM_ERR_UNSUPPORTED, "MBPSGD has no data-parallel mode");
+  DpEpoch& de = *out;
+  de.dp = o->dp;
+  de.opt_kind = o->kind;
+  de.sync_period = o->dp_sync_period;
+  de.overlap = o->dp_overlap;
+  de.combine_w = (o->kind == OPT_SGD && o->dp_combine == NFM_DP_MEAN) ? 1.0 / (double)o->dp->t->world : 1.0;
+  if (o->kind == OPT_SGD) {
+    de.arena = m->arena.as<double>();
+    de.n = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double)) + SC_COUNT;
+    de.skip_lo = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double)) + SC_SCALE_P;
+    de.skip_hi = de.skip_lo + 2;  // {scale_P, scale_w}
+    de.seg_w = (int64_t)((reinterpret_cast<char*>(M.w) - m->arena.as<char>()) / sizeof(double));
+    de.seg_sc = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double));
+  } else {
+    de.arena = o->state_arena.as<double>();
+    de.n = (int64_t)((o->gsc.as<char>() - o->state_arena.as<char>()) / sizeof(double)) + 2;
+  }
+  return NFM_OK;
+}
+
 int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t begin, int64_t end, double* loss_sum,
                       double* viol_sum) {
   NFM_CHECK(o && ds, NFM_ERR_INVALID, "null argument");
@@ -881,6 +909,8 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
   NFM_TRY(model_of(o, &m));
   nfm_ctx* ctx = m->ctx;
   NFM_CHECK(ds->ctx == ctx, NFM_ERR_INVALID, "optimizer and dataset belong to different contexts");
+  NFM_CHECK(!o->dp || dp_is_live(o->dp, o->dp_uid), NFM_ERR_INVALID,
+            "the optimizer's data-parallel group was destroyed; detach it (nfm_opt_set_dp(o, NULL, 0, 0)) or attach a new one");
   NFM_TRY(check_predict_shapes(m, ds));
   NFM_CHECK(ds->has_y, NFM_ERR_INVALID, "dataset has no targets");
   // MBPSGD consumes a stream of sample indices that may wrap past the end of the data (minibatch_psgd.nim:104-108)
@@ -958,8 +988,8 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         o->next_plan_ready = false;
       } else if (perm && o->next_plan_ready && o->next_plan && o->next_plan_perm == perm && plan_matches(*o->next_plan, first_singleton) &&
                  [&] {  // the array the plan was built from, unchanged as promised (a few probes)
-                   for (int q = 0; q < 8; ++q)
-                     if (perm[begin + (ns - 1) * q / 7] != o->next_probe[q]) return false;
+                   for (int q = 0; q < 64; ++q)
+                     if (perm[begin + (ns - 1) * q / 63] != o->next_probe[q]) return false;
                    return true;
                  }()) {
         std::swap(o->plan, o->next_plan);
@@ -980,23 +1010,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       DpEpoch de;
       if (o->dp) {
         // the ranks of the group run this call together on their own shards (equal step counters at its start)
-        NFM_CHECK(o->kind != OPT_PSGD, NFM_ERR_UNSUPPORTED, "MBPSGD has no data-parallel mode");
-        de.dp = o->dp;
-        de.opt_kind = o->kind;
-        de.sync_period = o->dp_sync_period;
-        de.overlap = o->dp_overlap;
-        de.combine_w = (o->kind == OPT_SGD && o->dp_combine == NFM_DP_MEAN) ? 1.0 / (double)o->dp->t->world : 1.0;
-        if (o->kind == OPT_SGD) {
-          de.arena = m->arena.as<double>();
-          de.n = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double)) + SC_COUNT;
-          de.skip_lo = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double)) + SC_SCALE_P;
-          de.skip_hi = de.skip_lo + 2;  // {scale_P, scale_w}
-          de.seg_w = (int64_t)((reinterpret_cast<char*>(M.w) - m->arena.as<char>()) / sizeof(double));
-          de.seg_sc = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double));
-        } else {
-          de.arena = o->state_arena.as<double>();
-          de.n = (int64_t)((o->gsc.as<char>() - o->state_arena.as<char>()) / sizeof(double)) + 2;
-        }
+        NFM_TRY(dp_epoch_setup(o, m, M, &de));
         // leading mini-batches of the regular length (everything but a shorter tail) look alike on every rank
         const Plan& PL = *o->plan;
         int64_t regular = PL.n_batches;
@@ -1006,6 +1020,16 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         NFM_TRY(dp_epoch_begin(de, regular, PL.n_batches));
         o->W.after_batch = [&de](int64_t b) { return dp_after_batch(de, b); };
       }
+      // the hook refers to this frame: whatever way the call leaves, it is taken off again; a call that fails between
+      // a sync point and its fold-in leaves no exchange marked pending (dp_epoch_begin would refuse every later epoch)
+      struct DpGuard {
+        nfm_opt* o;
+        bool ok = false;
+        ~DpGuard() {
+          o->W.after_batch = nullptr;
+          if (!ok && o->dp) o->dp->pending = false;
+        }
+      } dp_guard{o};
       int rc_epoch;
       // device shuffle: the epoch is only ENQUEUED here; the next epoch's order and plan are then built on a second
       // stream (its host-side waits block on that stream only) while this epoch runs
@@ -1031,7 +1055,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
                                  sort_by_count, o->next_plan.get(), o->plan_stream, nullptr, &ds->csc);
             if (rc_next == NFM_OK) {
               o->next_plan_perm = ann;
-              for (int q = 0; q < 8; ++q) o->next_probe[q] = ann[begin + (ns - 1) * q / 7];
+              for (int q = 0; q < 64; ++q) o->next_probe[q] = ann[begin + (ns - 1) * q / 63];
             }
           } else {
             rc_next = gen_permutation(ctx, o->plan_stream, o->shuffle_seed, o->shuffle_epoch + 1, begin, ns, &o->perm_next);
@@ -1068,6 +1092,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         // samples of all ranks
         o->it += (int64_t)(sums[2] + 0.5) - ns;
       }
+      dp_guard.ok = true;
     }
     o->it += o->kind == OPT_PSGD ? ns / o->batch : ns;
     if (o->kind == OPT_SGD && !o->dp) {  // resetScaling, sgd.nim:116-131
@@ -1076,6 +1101,25 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       NFM_HIP_CHECK(hipStreamSynchronize(st));
       if (sc[SC_SCALE_P] < 1e-9 || (m->cfg.fit_linear && sc[SC_SCALE_W] < 1e-9)) NFM_TRY(launch_rescale(ctx, M));
     }
+  }
+  else if (o->dp) {
+    // An empty shard (dp.shard_bounds hands ranks 0 .. W-2 nothing when there are fewer samples than ranks): this rank
+    // still issues the collectives its peers wait in -- the agreement on the sync points (it offers none, so the group
+    // has none mid-epoch), then the closing exchange with a zero increment -- and leaves with the group's sums and counter.
+    NFM_CHECK(o->mode == NFM_MODE_MINIBATCH, NFM_ERR_UNSUPPORTED, "the data-parallel exchange needs NFM_MODE_MINIBATCH");
+    const ModelView M = m->view();
+    DpEpoch de;
+    NFM_TRY(dp_epoch_setup(o, m, M, &de));
+    NFM_TRY(dp_epoch_begin(de, 0, 0));
+    NFM_TRY(o->dp_sums.ensure(sizeof(double) * 3));
+    double sums[3] = {0.0, 0.0, 0.0};
+    NFM_HIP_CHECK(hipMemcpyAsync(o->dp_sums.p, sums, sizeof(sums), hipMemcpyHostToDevice, st));
+    NFM_TRY(dp_epoch_end(de, o->dp_sums.as<double>()));
+    NFM_HIP_CHECK(hipMemcpyAsync(sums, o->dp_sums.p, sizeof(sums), hipMemcpyDeviceToHost, st));
+    NFM_HIP_CHECK(hipStreamSynchronize(st));
+    out2[0] = sums[0];
+    out2[1] = sums[1];
+    o->it += (int64_t)(sums[2] + 0.5);
   }
   if (loss_sum) *loss_sum = out2[0];
   if (viol_sum) *viol_sum = out2[1];
@@ -1178,7 +1222,9 @@ int32_t nfm_opt_set_dp(nfm_opt* o, nfm_dp* dp, int64_t sync_period, int32_t over
   NFM_CHECK(!dp || dp->ctx == o->ctx, NFM_ERR_INVALID, "optimizer and group belong to different contexts");
   NFM_CHECK(!dp || o->mode == NFM_MODE_MINIBATCH, NFM_ERR_UNSUPPORTED, "the data-parallel exchange needs NFM_MODE_MINIBATCH");
   NFM_CHECK(!dp || o->kind != OPT_PSGD, NFM_ERR_UNSUPPORTED, "MBPSGD has no data-parallel mode");
+  NFM_CHECK(!dp || dp_is_live(dp, dp->uid), NFM_ERR_INVALID, "the group was destroyed");
   o->dp = dp;
+  o->dp_uid = dp ? dp->uid : 0;
   o->dp_sync_period = sync_period;
   o->dp_overlap = overlap != 0;
   return NFM_OK;
@@ -1195,6 +1241,7 @@ int32_t nfm_opt_finalize(nfm_opt* o) {
   NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
   nfm_model* m = nullptr;
   NFM_TRY(model_of(o, &m));
+  o->announced = nullptr;  // the end of a fit (or a callback): an announced order refers to an array of the caller's loop
   NFM_TRY(use_device(m->ctx));
   if (o->kind == OPT_SGD) {
     NFM_TRY(launch_rescale(m->ctx, m->view()));

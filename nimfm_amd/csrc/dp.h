@@ -41,6 +41,8 @@ struct nfm_dp {
   int64_t pending_n = 0;
   // statistics (bench.py): collectives issued and bytes moved per rank
   int64_t n_collectives = 0, bytes = 0;
+  uint64_t uid = 0;                         // process-unique: an optimizer refers to its group by (pointer, uid)
+  ~nfm_dp();                                // releases the stream, the events and the transport (dp.hip)
 };
 
 namespace nfm {
@@ -58,6 +60,9 @@ struct DpEpoch {
   bool overlap = true;
   double combine_w = 1.0;      // SGD: 1 / world (mean of the ranks' increments, the default) or 1 (their sum); AdaGrad: 1
 };
+
+// a group handle that nfm_dp_destroy has not seen yet (an optimizer may outlive the group it was attached to)
+bool dp_is_live(const nfm_dp* dp, uint64_t uid);
 
 // agree on the number of mid-epoch sync points: min over ranks of (full mini-batches / sync_period), strictly before
 // the rank's last batch; AdaGrad: base <- state

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <map>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -355,10 +356,41 @@ int dp_epoch_end(DpEpoch& e, double* sums_dev) {
 
 }  // namespace nfm
 
+namespace nfm {
+// live groups by uid (an optimizer keeps a raw nfm_dp*: it is checked against this table before every use)
+static std::mutex g_dp_mu;
+static std::map<uint64_t, const nfm_dp*> g_dps;
+static uint64_t dp_register(const nfm_dp* dp) {
+  static uint64_t next = 0;
+  std::lock_guard<std::mutex> lk(g_dp_mu);
+  g_dps[++next] = dp;
+  return next;
+}
+bool dp_is_live(const nfm_dp* dp, uint64_t uid) {
+  std::lock_guard<std::mutex> lk(g_dp_mu);
+  auto it = g_dps.find(uid);
+  return it != g_dps.end() && it->second == dp;
+}
+}  // namespace nfm
+nfm_dp::~nfm_dp() {
+  {
+    std::lock_guard<std::mutex> lk(nfm::g_dp_mu);
+    nfm::g_dps.erase(uid);
+  }
+  if (ctx) (void)hipSetDevice(ctx->device);
+  if (comm) {
+    (void)hipStreamSynchronize(comm);
+    (void)hipStreamDestroy(comm);
+  }
+  if (ev_ready) (void)hipEventDestroy(ev_ready);
+  if (ev_done) (void)hipEventDestroy(ev_done);
+  delete t;
+}
 using namespace nfm;
 
 static int dp_common_init(nfm_ctx* ctx, nfm_dp* dp) {
   dp->ctx = ctx;
+  dp->uid = nfm::dp_register(dp);
   NFM_HIP_CHECK(hipSetDevice(ctx->device));
   NFM_HIP_CHECK(hipStreamCreateWithFlags(&dp->comm, hipStreamNonBlocking));
   NFM_HIP_CHECK(hipEventCreateWithFlags(&dp->ev_ready, hipEventDisableTiming));
@@ -442,13 +474,6 @@ int32_t nfm_dp_destroy(nfm_dp* dp) {
   if (!dp) return NFM_OK;
   (void)hipSetDevice(dp->ctx->device);
   (void)hipStreamSynchronize(dp->ctx->stream);
-  if (dp->comm) {
-    (void)hipStreamSynchronize(dp->comm);
-    (void)hipStreamDestroy(dp->comm);
-  }
-  if (dp->ev_ready) (void)hipEventDestroy(dp->ev_ready);
-  if (dp->ev_done) (void)hipEventDestroy(dp->ev_done);
-  delete dp->t;
   delete dp;
   return NFM_OK;
 }

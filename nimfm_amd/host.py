@@ -814,11 +814,30 @@ class _OptimizerBase:
         b = C.c_double(0.0)
         return 0.5 * self.alpha * wsq.value + 0.5 * self.beta * psq.value  # intercept term added by caller
 
-    def fit(self, X, y, fm, maxThreads=None, callback=None, perms=None):
+    def fit(self, X, y, fm, maxThreads=None, callback=None, perms=None, miniBatchSize=None, syncPeriod=None, devices=None):
         """optimizer/sgd.nim:261-328, adagrad.nim:137-203 (and the FFM / *_multi overloads).
-        maxThreads (the reference's Hogwild overload) selects the data-parallel mini-batch mode.
+        maxThreads (the reference's Hogwild overload) only SELECTS the mini-batch mode: a thread count is not a batch
+        size.  The mode's knobs are explicit and defaulted: miniBatchSize (else the optimizer's `batch`, 8192),
+        syncPeriod (mini-batches between exchanges of a data-parallel fit: setDataParallel, or `devices`), and
+        devices = [ids]: ONE process trains over several GPUs (or one GPU listed several times) -- contiguous slices of
+        the samples per device (optimizer/sgd_multi.nim:85-88), one replica + host thread each, reconciled by the library
+        (nfm_dp_create_local).
         perms ([maxIter][n], optional) replaces the internal shuffle with explicit permutations: the
         reference shuffles with Nim's global RNG (sgd.nim:297), which a Nim host passes in here."""
+        if devices is not None and len(devices) > 1:
+            return self._fit_devices(X, y, fm, list(devices), miniBatchSize, syncPeriod or 0, callback)
+        if miniBatchSize is not None:  # for this fit only
+            if int(miniBatchSize) < 1:
+                raise ValueError("miniBatchSize < 1.")
+            keep, self.batch = self.batch, int(miniBatchSize)
+            try:
+                return self.fit(X, y, fm, maxThreads, callback, perms, None, syncPeriod, None)
+            finally:
+                self.batch = keep
+        if syncPeriod is not None and self._dp is not None:
+            self._dp = (self._dp[0], int(syncPeriod)) + tuple(self._dp[2:])
+            if self._h is not None:
+                self._attach_dp()
         if isinstance(X, StreamCSRDataset):
             return self._fit_stream(X, y, fm, maxThreads, callback)
         fm.init(X)
@@ -918,6 +937,66 @@ class _OptimizerBase:
         return self
 
 
+def _fit_devices(self, X, y, fm, devices, miniBatchSize, syncPeriod, callback):
+    """fit(..., devices=[...]): the maxThreads overloads over several GPUs from ONE process.  Rank r gets the contiguous
+    slice dp.shard_bounds(n, r, world) of the samples on devices[r] (the reference's thread partition,
+    optimizer/sgd_multi.nim:85-88), its own replica of `fm` and of this optimizer, and a host thread; the library
+    reconciles the replicas every syncPeriod mini-batches and exactly at the end of every epoch (nfm_dp_create_local).
+    All replicas end bitwise identical; rank 0's comes back in `fm`, its history / step counter in `self`."""
+    import copy
+    import threading
+
+    from . import dp
+
+    fm.init(X)
+    y = _f64(y)
+    n, world = X.nSamples, len(devices)
+    if len(y) != n:
+        raise ValueError("len(y) != nSamples")
+    indptr, indices, data, fields = X.to_host()
+    ctxs = [Context(int(d_)) for d_ in devices]
+    groups = dp.Group.local(ctxs)
+    P0, w0, b0 = np.array(fm.P), np.array(fm.w), float(fm.intercept)
+    models, opts, err = [None] * world, [None] * world, []
+
+    def body(r):
+        try:
+            lo, hi = dp.shard_bounds(n, r, world)
+            a, b = int(indptr[lo]), int(indptr[hi])
+            if fields is not None:
+                Xr = newCSRFieldDataset(data[a:b], indices[a:b], indptr[lo:hi + 1] - a, fields[a:b], hi - lo, X.nFeatures, X.nFields, ctx=ctxs[r])
+            else:
+                Xr = newCSRDataset(data[a:b], indices[a:b], indptr[lo:hi + 1] - a, hi - lo, X.nFeatures, ctx=ctxs[r])
+            fr = copy.copy(fm)
+            fr._h, fr._ctx, fr._dirty = None, None, True  # a replica of its own on this rank's device
+            fr.warmStart = True
+            fr.set_params(P0, w0, b0)
+            orr = copy.copy(self)
+            orr._h, orr._model, orr._mode_built, orr._mh, orr.history = None, None, None, None, []
+            if miniBatchSize is not None:
+                orr.batch = int(miniBatchSize)
+            orr.setDataParallel(groups[r], syncPeriod=syncPeriod)
+            orr.fit(Xr, y[lo:hi], fr, maxThreads=world, callback=None)
+            models[r], opts[r] = fr, orr
+        except BaseException as e:  # noqa: BLE001
+            err.append((r, e))
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for g in groups:
+        g.close()
+    if err:
+        raise err[0][1]
+    fm.set_params(models[0].P, models[0].w, models[0].intercept)
+    self.it, self.history = opts[0].it, list(opts[0].history)
+    if callback is not None:
+        callback(self, fm)
+    return self
+
+
 def _fit_stream(self, X, y, fm, maxThreads=None, callback=None):
     """fit over a dataset that is resident one row block at a time (optimizer/sgd_multi.nim:83-97: `while nRest > 0:
     X.readCache(...)`): blocks in file order, no shuffling (sgd.nim:297 shuffles only a fully cached dataset); the
@@ -977,6 +1056,7 @@ def _fit_stream(self, X, y, fm, maxThreads=None, callback=None):
 
 
 _OptimizerBase._fit_stream = _fit_stream
+_OptimizerBase._fit_devices = _fit_devices
 
 
 class SGD(_OptimizerBase):

@@ -253,25 +253,30 @@ class SGD {
         power(power_), verbose(verbose_), tol(tol_), shuffle(shuffle_), nCalls(nCalls_) {}
   ~SGD() { if (o_) nfm_opt_destroy(o_); }
   // fit, optimizer/sgd.nim:261-328; maxThreads != 0 = the Hogwild overload (sgd_multi.nim:40-42) -> mini-batch mode
+  // maxThreads only SELECTS the mini-batch mode (a thread count is not a batch size); the mode's knobs are explicit:
+  // miniBatchSize (0: this->batch), and across GPUs -- one process per GPU, X this rank's slice -- group + syncPeriod
   void fit(const CSRDataset& X, const std::vector<double>& y, FactorizationMachine& fm, int maxThreads = 0,
-           std::function<void(SGD&, FactorizationMachine&)> callback = nullptr) {
+           std::function<void(SGD&, FactorizationMachine&)> callback = nullptr, int64_t miniBatchSize = 0,
+           int64_t syncPeriod = 0, nfm_dp* group = nullptr) {
     fm.init(X);
     if ((int64_t)y.size() != X.nSamples()) throw std::invalid_argument("len(y) != nSamples");
     check(nfm_dataset_set_targets(X.handle(), y.data()));
     if (!fm.warmStart) it = 1;
     nfm_model* m = fm.push();
-    const int md = maxThreads != 0 ? NFM_MODE_MINIBATCH : mode;
-    if (!o_ || m_ != m || md_ != md) {
+    const int md = (maxThreads != 0 || group) ? NFM_MODE_MINIBATCH : mode;
+    const int64_t bsz = miniBatchSize > 0 ? miniBatchSize : batch;
+    if (!o_ || m_ != m || md_ != md || b_ != bsz) {
       if (o_) nfm_opt_destroy(o_);
-      nfm_sgd_cfg c{eta0, alpha0, alpha, beta, power, loss.param, L::id, (int32_t)scheduling, md, 0, batch};
+      nfm_sgd_cfg c{eta0, alpha0, alpha, beta, power, loss.param, L::id, (int32_t)scheduling, md, 0, bsz};
       check(nfm_sgd_create(m, &c, &o_));
-      m_ = m; md_ = md;
+      m_ = m; md_ = md; b_ = bsz;
     }
+    if (md == NFM_MODE_MINIBATCH) check(nfm_opt_set_dp(o_, group, syncPeriod, 1));
     detail::run_fit<SGD>(*this, o_, X, fm, callback, nCalls <= 0 || md == NFM_MODE_MINIBATCH);
   }
 
  private:
-  nfm_opt* o_ = nullptr; nfm_model* m_ = nullptr; int md_ = -1;
+  nfm_opt* o_ = nullptr; nfm_model* m_ = nullptr; int md_ = -1; int64_t b_ = -1;
 };
 
 template <class L = Squared>
@@ -287,24 +292,27 @@ class AdaGrad {
         verbose(verbose_), tol(tol_), shuffle(shuffle_), nCalls(nCalls_) {}
   ~AdaGrad() { if (o_) nfm_opt_destroy(o_); }
   void fit(const CSRDataset& X, const std::vector<double>& y, FactorizationMachine& fm, int maxThreads = 0,
-           std::function<void(AdaGrad&, FactorizationMachine&)> callback = nullptr) {
+           std::function<void(AdaGrad&, FactorizationMachine&)> callback = nullptr, int64_t miniBatchSize = 0,
+           int64_t syncPeriod = 0, nfm_dp* group = nullptr) {
     fm.init(X);
     if ((int64_t)y.size() != X.nSamples()) throw std::invalid_argument("len(y) != nSamples");
     check(nfm_dataset_set_targets(X.handle(), y.data()));
     if (!fm.warmStart) it = 1;
     nfm_model* m = fm.push();
-    const int md = maxThreads != 0 ? NFM_MODE_MINIBATCH : mode;
-    if (!o_ || m_ != m || md_ != md) {
+    const int md = (maxThreads != 0 || group) ? NFM_MODE_MINIBATCH : mode;
+    const int64_t bsz = miniBatchSize > 0 ? miniBatchSize : batch;
+    if (!o_ || m_ != m || md_ != md || b_ != bsz) {
       if (o_) nfm_opt_destroy(o_);
-      nfm_adagrad_cfg c{eta0, alpha0, alpha, beta, eps, loss.param, L::id, md, 1, 0, batch};
+      nfm_adagrad_cfg c{eta0, alpha0, alpha, beta, eps, loss.param, L::id, md, 1, 0, bsz};
       check(nfm_adagrad_create(m, &c, &o_));
-      m_ = m; md_ = md;
+      m_ = m; md_ = md; b_ = bsz;
     }
+    if (md == NFM_MODE_MINIBATCH) check(nfm_opt_set_dp(o_, group, syncPeriod, 1));
     detail::run_fit<AdaGrad>(*this, o_, X, fm, callback, true);
   }
 
  private:
-  nfm_opt* o_ = nullptr; nfm_model* m_ = nullptr; int md_ = -1;
+  nfm_opt* o_ = nullptr; nfm_model* m_ = nullptr; int md_ = -1; int64_t b_ = -1;
 };
 
 // regularizer/{l1,l21,squaredl12,squaredl21}.nim: the penalties with a matrix proximal operator

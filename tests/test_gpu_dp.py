@@ -270,3 +270,66 @@ def test_data_parallel_training_and_held_out_quality():
     assert sgd_mean <= 1.1 * sgd_quarter
     assert sgd_sum <= 0.7 * sgd_mean and np.isfinite(sgd_sum)
     assert ada_dp <= 1.1 * ada_all
+
+
+@pytest.mark.parametrize("solver", ["sgd", "adagrad"])
+def test_fit_devices_keyword(solver):
+    """fit(X, y, fm, maxThreads, miniBatchSize=..., syncPeriod=..., devices=[0, 0]): the explicit knobs of the maxThreads
+    overloads (the thread count itself selects the mode and nothing else).  One process, two ranks on the one GPU: the
+    result equals the same two ranks driven by hand (a thread, a context, a shard, a replica, a group handle each)."""
+    full = random_csr(N, D, M, seed=33)
+    rng = np.random.default_rng(34)
+    y = rng.standard_normal(N)
+    P0, w0, b0 = rng.standard_normal((1, K, D)) * 0.1, rng.standard_normal(D) * 0.01, 0.1
+    world, S = 2, 2
+    mk = (lambda: nf.newSGD(maxIter=2, eta0=0.05, verbose=0, tol=0, shuffle=False, batch=999)) if solver == "sgd" else \
+         (lambda: nf.newAdaGrad(maxIter=2, verbose=0, tol=0, shuffle=False, batch=999))
+    shards = _shards(full, y, world)
+
+    def make_rank(r, ctx, group):
+        shard, ys = shards[r]
+        X = nf.newCSRDataset(shard.data, shard.indices, shard.indptr, shard.n, shard.d, ctx=ctx)
+        fm = gpu_fm("regression", 2, K, "explicit", True, True, P0, w0, b0)
+        opt = mk()
+        opt.setDataParallel(group, syncPeriod=S)
+        opt.fit(X, ys, fm, maxThreads=4, miniBatchSize=B)
+        return fm.P.copy(), fm.w.copy(), fm.intercept, opt.it, list(opt.history)
+
+    res, _ = _run_ranks(world, make_rank)
+    X = nf.newCSRDataset(full.data, full.indices, full.indptr, full.n, full.d)
+    fm = gpu_fm("regression", 2, K, "explicit", True, True, P0, w0, b0)
+    opt = mk()
+    opt.fit(X, y, fm, maxThreads=4, miniBatchSize=B, syncPeriod=S, devices=[0, 0])
+    assert opt.batch == 999  # the optimizer's own default is untouched; maxThreads = 4 did not become a batch size either
+    assert np.array_equal(fm.P, res[0][0]) and np.array_equal(fm.w, res[0][1]) and fm.intercept == res[0][2]
+    assert opt.it == res[0][3] and opt.history == res[0][4]
+    assert np.array_equal(res[0][0], res[1][0])  # the replicas agree
+
+
+def test_rank_with_an_empty_range_still_joins_the_exchange():
+    """dp.shard_bounds hands ranks 0 .. W-2 nothing when there are fewer samples than ranks; such a rank's
+    nfm_opt_epoch(begin == end) must issue the same collectives as its peers (they would wait for it forever) and leave
+    with the group's sums, step counter and model"""
+    full = random_csr(40, D, M, seed=9)
+    rng = np.random.default_rng(10)
+    y = rng.standard_normal(full.n)
+    P0, w0, b0 = rng.standard_normal((1, K, D)) * 0.1, np.zeros(D), 0.0
+    world = 3
+
+    def make_rank(r, ctx, group):
+        X = nf.newCSRDataset(full.data, full.indices, full.indptr, full.n, full.d, ctx=ctx)
+        X.set_targets(y)
+        fm = gpu_fm("regression", 2, K, "explicit", True, True, P0, w0, b0)
+        opt = nf.newSGD(maxIter=1, eta0=0.05, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=16)
+        opt.setDataParallel(group, syncPeriod=1)
+        opt._handle(fm, ctx, "minibatch")
+        ls, vs = opt._epoch(X, None, 0, full.n if r == world - 1 else 0)  # only the last rank has samples
+        opt._sync_it()
+        opt._finalize_into(fm)
+        return fm.P.copy(), fm.w.copy(), fm.intercept, opt.it, ls, vs
+
+    res, info = _run_ranks(world, make_rank)
+    for r in range(world):
+        assert np.array_equal(res[r][0], res[world - 1][0]) and np.array_equal(res[r][1], res[world - 1][1])
+        assert res[r][3] == 1 + full.n and res[r][4] == res[world - 1][4]
+    assert not np.array_equal(res[0][0], P0)  # and the model did move

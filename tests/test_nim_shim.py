@@ -119,3 +119,14 @@ def test_reference_surface_is_overloaded_under_its_own_names():
     assert "eps: self.eps" in ada and "nfm_opt_set_state" in ada and "nfm_opt_get_state" in ada and "self.g_sum" in ada
     assert "lossParam(self.loss)" in sgd and "loss.dloss(0.0, Inf)" in core
     assert "callback(self, fm)" in sgd and "nCalls" in core
+
+
+def test_max_threads_is_never_read_as_a_batch_size():
+    """the maxThreads overloads take the mini-batch size from an explicit, defaulted `miniBatchSize` (and
+    `syncPeriod`, `group` for the multi-GPU form); the reference's thread count only selects the mode"""
+    for name in ("hip_sgd.nim", "hip_adagrad.nim", "hip_sgd_ffm.nim", "hip_adagrad_ffm.nim"):
+        src = open(os.path.join(NIM, name)).read()
+        assert "maxThreads >=" not in src and "maxThreads else" not in src, name
+        sig = re.search(r"maxThreads: int,\s*callback:[^=]*= nil,\s*miniBatchSize: int = defaultBatch\(\),\s*syncPeriod: int = 0, group: HipGroup = nil\)", src)
+        assert sig, name
+        assert "discard maxThreads" in src, name
