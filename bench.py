@@ -18,6 +18,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), carrying
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -294,26 +295,35 @@ def make_dataset(torch, nf, ctx, dev, wl, n, rank):
     return X, indptr, indices, data
 
 
-def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, cheap=False):
+def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, cheap=False, fields=None):
     """the reference-faithful CPU port (oracle/, test infrastructure used here as the reported baseline) on a bounded
     prefix of the same shard: built -O3 -march=native on this host (oracle/Makefile `timing`), one warm-up epoch, the
     median of the next three; Hogwild (optimizer/sgd_multi.nim semantics) at T = 4 (the reference
     benchmarks' value), this GPU's share of the host's cores, and twice that (the reference's default maxThreads)."""
     import oracle as O
 
-    epochs = 2 if cheap else 4
-    nc = min(n, args.cpu_samples, max(10_000, int((0.6e9 if cheap else 1.6e9) / (n_orders * m * k * epochs))))
+    epochs = 4  # one warm-up epoch, then the median of three
+    F = wl.get("fields", 0)
+    work = (F * m * k) if F else (n_orders * m * k)  # parameter values a sample's step touches
+    nc = min(n, args.cpu_samples, max(5_000, int((0.8e9 if cheap else 1.6e9) / (work * epochs))))
     ip = indptr[: nc + 1].cpu().numpy()
     ix = indices[: nc * m].cpu().numpy().astype(np.int64)
     dv = data[: nc * m].cpu().numpy()
-    Xo = O.Dataset(ip, ix, dv, nc, d)
-    P0 = np.random.default_rng(1).standard_normal((n_orders, k, d)) * 0.01
-    w0 = np.zeros(d)
     sgd = wl["solver"] == "sgd"
     cfg = O.sgd_cfg(loss=wl["loss"]) if sgd else O.adagrad_cfg(loss=wl["loss"])
+    if F:
+        fl = fields[: nc * m].cpu().numpy().astype(np.int64)
+        Xo = O.Dataset(ip, ix, dv, nc, d, fl, F)
+        P0 = np.random.default_rng(1).standard_normal((F, d, k)) * 0.01
+    else:
+        Xo = O.Dataset(ip, ix, dv, nc, d)
+        P0 = np.random.default_rng(1).standard_normal((n_orders, k, d)) * 0.01
+    w0 = np.zeros(d)
 
     def med(threads):
-        if sgd:
+        if F:
+            (O.ffm_sgd_fit if sgd else O.ffm_adagrad_fit)(Xo, y[:nc], P0, w0, 0.0, cfg, epochs)
+        elif sgd:
             O.fm_sgd_fit(Xo, y[:nc], wl["degree"], P0, w0, 0.0, cfg, epochs, hogwild_threads=threads)
         else:
             O.fm_adagrad_fit(Xo, y[:nc], wl["degree"], P0, w0, 0.0, cfg, epochs)
@@ -325,7 +335,7 @@ def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, c
 
     jag = None
     with O.variant("timing"):
-        if sgd and wl["degree"] == 2 and not cheap:  # the reference's own storage: one heap block per parameter row
+        if sgd and wl["degree"] == 2 and not cheap and not F:  # the reference's own storage: one heap block per parameter row
             jag = {"value": round(nc / med_jagged(1), 1), "cores": 1,
                    "hogwild_4_threads": round(nc / med_jagged(min(4, os.cpu_count() or 1)), 1),
                    "note": "the same epoch on jagged storage (seq-of-seq as tensor/tensor.nim:8-17: a malloc'd row with a seq header "
@@ -334,7 +344,7 @@ def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, c
         threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
         th = None
         sweep = []
-        if sgd:
+        if sgd and not F:
             for T_ in sorted({min(4, threads), threads} if cheap else {min(4, threads), threads, 2 * threads}):
                 tt_ = med(T_)
                 sweep.append({"threads": T_, "value": round(nc / tt_, 1)})
@@ -350,7 +360,7 @@ def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, c
             "sample": "the first %d samples of the same shard (same d, nnz/row, k); C restatement of optimizer/%s semantics, "
                       "flat arrays, gcc -O3 -march=native on this host, 1 thread, 1 warm-up epoch then the median of %d; "
                       "epoch loop only (the per-fit layout transposes, sgd.nim:292,328, are outside)"
-                      % (nc, "sgd.nim:261-328" if sgd else "adagrad.nim:137-203", epochs - 1),
+                      % (nc, ("sgd_ffm.nim:49-106" if sgd else "adagrad_ffm.nim:11-66") if F else ("sgd.nim:261-328" if sgd else "adagrad.nim:137-203"), epochs - 1),
             "jagged": jag,
             "hogwild": None if th is None else {"value": round(nc / th, 1), "threads": threads,
                                                 "note": "optimizer/sgd_multi.nim semantics (racy), same port and build",
@@ -434,9 +444,19 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
 
     for _ in range(warmup):
         step()
+    dp_info0 = run_training.group.info() if use_dp else None
     dt, last = timed(steps)
     ms_per_step = dt / steps * 1e3
     value = n * world / (dt / steps)
+    dp_stats = None
+    if use_dp:  # what the exchange moved during the timed steps (nfm_dp_info: this rank's collectives and bytes)
+        i1 = run_training.group.info()
+        dp_stats = {"combine": ("mean" if args.combine == "mean" else "sum") if wl["solver"] == "sgd" else "state-summed",
+                    "sync_period": sync_period, "world": i1["world"],
+                    "collectives_per_step": (i1["collectives"] - dp_info0["collectives"]) / steps,
+                    "bytes_per_step_per_rank": (i1["bytes"] - dp_info0["bytes"]) / steps,
+                    "note": "mid-epoch all-reduces of the whole parameter (SGD) / state (AdaGrad) arena on the group's own stream, "
+                            "delayed by one period, plus the exact closing exchange of every epoch call"}
 
     # ---- the reference's default shuffle = true (optimizer/sgd.nim:297): every epoch gets a FRESH permutation, so the
     # batch plan is rebuilt for every epoch inside the timed region.
@@ -541,6 +561,91 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                             "the one-workgroup kernel" if windowed else "one workgroup (csrc/seq.hip)")}
         del opt_s, fm_s, Xs
 
+    # ---- what the mini-batch rule costs statistically, measured: a coordinate touched c times in a
+    # batch advances once where the reference's order advances c times; c_bar = lambda / (1 - exp(-lambda)),
+    # lambda = batch * nnz_per_row / d is the mean touch count per touched coordinate.  time_to_target: both modes start
+    # from the same parameters with the same step size on the first n_t samples; the sequential (reference-order) run
+    # makes ONE epoch, its loss on n_h held-out samples is the target; the mini-batch rule runs epochs until it is at
+    # or below it. ----
+    lam = batch * m / d
+    c_bar = lam / (1.0 - math.exp(-lam)) if lam > 1e-12 else 1.0
+    t2t = None
+    if rank == 0 and world == 1 and not F and wl["degree"] == 2 and k <= 64 and (primary or name == "cfg2") and n >= 400_000:
+        n_t, n_h = min(1_000_000, n - 200_000), 200_000
+        ip_t = torch.arange(n_t + 1, device=dev, dtype=torch.int64) * m
+        ip_h = torch.arange(n_h + 1, device=dev, dtype=torch.int64) * m
+        Xt = nf.CSRDataset.from_device(ctx, n_t, d, n_t * m, ip_t.data_ptr(), indices.data_ptr(), data.data_ptr(), keep=(ip_t, indices, data))
+        off = n_t * m
+        Xh = nf.CSRDataset.from_device(ctx, n_h, d, n_h * m, ip_h.data_ptr(), indices.data_ptr() + 4 * off, data.data_ptr() + 8 * off,
+                                       keep=(ip_h, indices, data))
+        y_t, y_h = np.ascontiguousarray(y[:n_t]), np.ascontiguousarray(y[n_t:n_t + n_h])
+        Xt.set_targets(y_t)
+
+        def held_out_loss(model):
+            p = model.decisionFunction(Xh)
+            if wl["loss"] == "logistic":
+                z = p * y_h
+                return float(np.mean(np.where(z > 0, np.log1p(np.exp(-np.abs(z))), np.log1p(np.exp(-np.abs(z))) - z)))
+            return float(np.mean(0.5 * (p - y_h) ** 2))
+
+        mk_ = nf.newSGD if wl["solver"] == "sgd" else nf.newAdaGrad
+        f_seq = nf.newFactorizationMachine(task, degree=2, nComponents=k, warmStart=True, randomState=1)
+        f_seq.init(Xt)
+        l_init = held_out_loss(f_seq)
+        o_seq = mk_(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="sequential")
+        o_seq._handle(f_seq, ctx, "sequential")
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        o_seq._epoch(Xt, None, 0, n_t)
+        o_seq.it += n_t
+        ctx.synchronize()
+        t_seq = time.perf_counter() - t0
+        o_seq._finalize_into(f_seq)
+        target = held_out_loss(f_seq)
+        def run_mb(batch_):
+            lam_ = batch_ * m / d
+            cb_ = lam_ / (1.0 - math.exp(-lam_)) if lam_ > 1e-12 else 1.0
+            f_mb = nf.newFactorizationMachine(task, degree=2, nComponents=k, warmStart=True, randomState=1)
+            f_mb.init(Xt)
+            P_i, w_i = np.array(f_mb.P), np.array(f_mb.w)
+            o_mb = mk_(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch", batch=batch_)
+            o_mb._handle(f_mb, ctx, "minibatch")
+            o_mb._epoch(Xt, None, 0, n_t)  # plan + graph built outside the clock, then start again from the same point
+            f_mb.set_params(P_i, w_i, 0.0)
+            f_mb._push(ctx)
+            o_mb.it = 1
+            capi.check(capi.lib().nfm_opt_set_it(o_mb._h, 1))  # (AdaGrad: the state starts over at it == 1)
+            t_mb, e_mb, l_mb, cap = 0.0, 0, l_init, int(4 * cb_ + 8)
+            while e_mb < cap:
+                ctx.synchronize()
+                t0_ = time.perf_counter()
+                o_mb._epoch(Xt, None, 0, n_t)
+                o_mb.it += n_t
+                ctx.synchronize()
+                t_mb += time.perf_counter() - t0_
+                e_mb += 1
+                o_mb._finalize_into(f_mb)
+                f_mb._dirty = False
+                l_mb = held_out_loss(f_mb)
+                if l_mb <= target:
+                    break
+            return {"batch": batch_, "c_bar": round(cb_, 3), "epochs": e_mb, "seconds": round(t_mb, 4), "held_out_loss": round(l_mb, 6),
+                    "reached": bool(l_mb <= target),
+                    "speedup_to_target": round(t_seq / t_mb, 2) if l_mb <= target and t_mb > 0 else None}
+
+        runs = [run_mb(b_) for b_ in sorted({batch, 8192, 2048}, reverse=True)]
+        best = max((r_ for r_ in runs if r_["reached"]), key=lambda r_: r_["speedup_to_target"], default=None)
+        t2t = {"train_samples": n_t, "held_out_samples": n_h, "held_out_loss_at_start": round(l_init, 6),
+               "target": round(target, 6), "target_is": "held-out mean loss after ONE epoch in the reference's order (mode=sequential, "
+                                                        "the window kernel), same start, same step size and schedule",
+               "sequential": {"epochs": 1, "seconds": round(t_seq, 4)},
+               "minibatch": runs,
+               "note": "epochs are capped at 4 c_bar + 8; the step counter advances per SAMPLE in both modes, so under the default "
+                       "`optimal` schedule a run that needs c_bar times the epochs also takes them at smaller step sizes",
+               "speedup_to_target": None if best is None else best["speedup_to_target"],
+               "best_batch": None if best is None else best["batch"]}
+        del o_seq, f_seq, Xt, Xh
+
     # ---- roofline leg: per-kernel durations from HIP events on the library's stream (one replica, no exchange) ----
     roof = None
     if use_dp:
@@ -582,8 +687,9 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                 "launches_per_step": {f: fam[f][0] / reps for f in fam}}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not F:
-        cpu = cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, cheap=not primary)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, cheap=not primary,
+                               fields=X._keep[3] if F else None)
 
     if exact is not None and cpu is not None and cpu.get("value"):
         # both run the reference's sample order and give the same parameters: the like-for-like ratio
@@ -601,12 +707,18 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                                       "per-sample steps, DESIGN.md section 4) -- NOT the reference's sample-by-sample order, "
                                       "which NFM_MODE_SEQUENTIAL reproduces (exact_order: its samples/s on this shape)",
                        "samples_per_gpu": n, "batch": batch,
+                       "c_bar": round(c_bar, 4),
+                       "c_bar_note": "mean touch count per touched coordinate in a mini-batch, lambda / (1 - exp(-lambda)), lambda = "
+                                     "batch * nnz_per_row / d: one epoch of this rule makes about 1 / c_bar of the reference order's "
+                                     "progress at equal step size (DESIGN.md section 4); `effective` = value / c_bar, "
+                                     "`time_to_target` measures it",
                        "parallelism": ("%d ranks, one process per GPU, contiguous sample shards; replicas %s in the library over "
                                        "RCCL every %s on a second stream + exactly at the end of every epoch"
                                        % (world, ("increments %s" % ("averaged" if args.combine == "mean" else "summed")) if wl["solver"] == "sgd" else "state-summed",
                                           ("%d mini-batches" % sync_period) if sync_period else "epoch (no mid-epoch exchange)"))
                        if use_dp else "1 GPU"},
             "last_step": {"mean_loss": last[0] / (n * world), "viol": last[1]}, "predict": pred, "exact_order": exact,
+            "c_bar": round(c_bar, 4), "effective": round(value / c_bar, 1), "time_to_target": t2t, "dp": dp_stats,
             "roofline": roof, "cpu_baseline": cpu}
 
 
@@ -688,13 +800,22 @@ def main():
 
     res = run_training(args, args.workload, torch, nf, dist, rank, world, dev, ctx, primary=True)
     extra = None
-    if args.workload == "headline" and world == 1 and not args.no_extra and not args.n:
+    forced_dp = os.environ.get("NIMFM_BENCH_FORCE_DP") == "1"
+    if args.workload == "headline" and world == 1 and not forced_dp and not args.no_extra and not args.n:
         import gc
 
         gc.collect()
         torch.cuda.empty_cache()
         c2 = run_training(args, "cfg2", torch, nf, dist, rank, world, dev, ctx, primary=False)
         extra = {"cfg2": {"metric": "SGD training samples/sec/epoch", "unit": "samples/s", **c2}}
+    if args.workload == "headline" and (world > 1 or forced_dp) and not args.no_extra:
+        # BASELINE.json configs[2] as written: AdaGrad, mini-batch 8192, data-parallel -- the replicas' state increments summed
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        c3 = run_training(args, "cfg3", torch, nf, dist, rank, world, dev, ctx, primary=False)
+        extra = {"cfg3": {"metric": "AdaGrad training samples/sec/epoch", "unit": "samples/s", **c3}}
     if rank == 0:
         out = {"metric": "SGD training samples/sec/epoch", "value": res["value"], "unit": "samples/s",
                "n_gpus": world, "steps": res["steps"], "warmup": res["warmup"], "ms_per_step": res["ms_per_step"],
@@ -702,6 +823,7 @@ def main():
                "config": res["config"], "value_shuffled": res["value_shuffled"],
                "value_shuffled_host_perm": res["value_shuffled_host_perm"], "shuffled_note": res["shuffled_note"],
                "last_step": res["last_step"], "predict": res["predict"], "exact_order": res["exact_order"],
+               "effective": res["effective"], "time_to_target": res["time_to_target"], "dp": res["dp"],
                "roofline": res["roofline"],
                "cpu_baseline": res["cpu_baseline"], "extra": extra}
         print(json.dumps(out))

@@ -777,6 +777,7 @@ int orc_ffm_sgd_fit(const orc_csr* X, const double* y, int k, double* P, double*
   S.P = P; /* FFM trains in place: P is already [f][j][s] (sgd_ffm.nim:78) */
   int is_converged = 0, epochs = 0;
   for (int epoch = 0; epoch < max_iter; epoch++) {
+    const double t_epoch = orc_now();
     double viol = 0.0, running_loss = 0.0;
     for (int64_t ii = 0; ii < n; ii++) {
       const int64_t i = perms ? perms[(size_t)epoch * n + ii] : ii;
@@ -787,6 +788,7 @@ int orc_ffm_sgd_fit(const orc_csr* X, const double* y, int k, double* P, double*
       viol += sgd_update(&S, r, 0, dA, y[i], y_pred);
       S.it++;
     }
+    if (epoch < ORC_MAX_TIMED_EPOCHS) orc_epoch_seconds[epoch] = orc_now() - t_epoch;
     running_loss /= (double)n;
     if (epoch_loss) epoch_loss[epoch] = running_loss;
     if (epoch_viol) epoch_viol[epoch] = viol;
@@ -818,6 +820,7 @@ int orc_ffm_adagrad_fit(const orc_csr* X, const double* y, int k, double* P, dou
   ada_init(&S);
   int is_converged = 0, epochs = 0;
   for (int epoch = 0; epoch < max_iter; epoch++) {
+    const double t_epoch = orc_now();
     double viol = 0.0, running_loss = 0.0;
     for (int64_t ii = 0; ii < n; ii++) {
       const int64_t i = perms ? perms[(size_t)epoch * n + ii] : ii;
@@ -828,6 +831,7 @@ int orc_ffm_adagrad_fit(const orc_csr* X, const double* y, int k, double* P, dou
       ada_update_g(&S, r, 0, dA, y[i], y_pred);
       S.it++;
     }
+    if (epoch < ORC_MAX_TIMED_EPOCHS) orc_epoch_seconds[epoch] = orc_now() - t_epoch;
     running_loss /= (double)n;
     if (epoch_loss) epoch_loss[epoch] = running_loss;
     if (epoch_viol) epoch_viol[epoch] = viol;
