@@ -344,6 +344,17 @@ int32_t nfm_opt_set_dp(nfm_opt* o, nfm_dp* dp, int64_t sync_period, int32_t over
 enum { NFM_DP_MEAN = 0, NFM_DP_SUM = 1 };
 int32_t nfm_opt_set_dp_combine(nfm_opt* o, int32_t combine);
 
+/* SGD, NFM_MODE_MINIBATCH: how a mini-batch combines the per-sample steps (optimizer/sgd.nim:205-243) of the `c` samples
+ * that touch one coordinate.  The reference's Hogwild threads (optimizer/sgd_multi.nim:83-101, maxThreads of them) each
+ * apply their step at full strength to a shared model that is at most maxThreads steps stale.  Here: up to `cap` of a
+ * batch's steps on a coordinate are SUMMED; a coordinate touched c > cap times receives cap / c of the sum (and cap / c
+ * of the batch's decay exponent).  cap = 1 (the default) is the per-coordinate MEAN: always stable, but one epoch then
+ * makes about 1 / c_bar of the sequential order's progress, c_bar = mean touch count per touched coordinate.  cap =
+ * the reference's thread count gives its staleness; 16 matched one sequential epoch's held-out loss per epoch on the
+ * bench workloads and stayed stable where the plain sum (cap = infinity) diverges on dense coordinates and the
+ * intercept.  Deterministic for every value. */
+int32_t nfm_opt_set_touch_cap(nfm_opt* o, double cap);
+
 /* ---- host-side random numbers (no device work) ----
  * FactorizationMachine.init draws P with randomNormal (model/factorization_machine.nim:125-139,
  * tensor/tensor.nim:561-580: Box-Muller over rand(1.0); z = sqrt(-2 ln(1-x)) cos(2 pi y) and the sine twin go

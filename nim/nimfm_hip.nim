@@ -118,6 +118,7 @@ proc nfm_dp_info*(dp: NfmDp, rank, world: ptr int32, nCollectives, bytes: ptr in
 proc nfm_dp_destroy*(dp: NfmDp): int32
 proc nfm_opt_set_dp*(o: NfmOpt, dp: NfmDp, syncPeriod: int64, overlap: int32): int32
 proc nfm_opt_set_dp_combine*(o: NfmOpt, combine: int32): int32  # 0: mean of the ranks' SGD increments (default), 1: their sum
+proc nfm_opt_set_touch_cap*(o: NfmOpt, cap: float64): int32     # SGD mini-batch rule: steps per coordinate summed before averaging sets in
 {.pop.}
 
 proc check*(rc: int32) =

@@ -718,6 +718,7 @@ int32_t nfm_sgd_create(nfm_model* m, const nfm_sgd_cfg* c, nfm_opt** out) {
   o->ctx = m->ctx; o->m = m; o->m_uid = m->uid; o->kind = OPT_SGD; o->mode = c->mode; o->batch = c->mode == NFM_MODE_MINIBATCH ? c->batch : 1; o->it = 1;
   o->o.eta0 = c->eta0; o->o.alpha0 = c->alpha0; o->o.alpha = c->alpha; o->o.beta = c->beta; o->o.power = c->power;
   o->o.eps = 0.0; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = c->scheduling; o->o.track_viol = 1;
+  o->o.touch_cap = 1.0;
   NFM_TRY(use_device(m->ctx));
   NFM_TRY(o->out2.alloc(sizeof(double) * 2));
   *out = o.release();
@@ -731,6 +732,7 @@ int32_t nfm_adagrad_create(nfm_model* m, const nfm_adagrad_cfg* c, nfm_opt** out
   o->ctx = m->ctx; o->m = m; o->m_uid = m->uid; o->kind = OPT_ADAGRAD; o->mode = c->mode; o->batch = c->mode == NFM_MODE_MINIBATCH ? c->batch : 1; o->it = 1;
   o->o.eta0 = c->eta0; o->o.alpha0 = c->alpha0; o->o.alpha = c->alpha; o->o.beta = c->beta; o->o.power = 1.0;
   o->o.eps = c->eps; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = 0; o->o.track_viol = c->track_viol;
+  o->o.touch_cap = 1.0;
   NFM_TRY(use_device(m->ctx));
   NFM_TRY(o->out2.alloc(sizeof(double) * 2));
   {
@@ -766,6 +768,7 @@ int32_t nfm_mbpsgd_create(nfm_model* m, const nfm_mbpsgd_cfg* c, nfm_opt** out) 
   o->ctx = m->ctx; o->m = m; o->m_uid = m->uid; o->kind = OPT_PSGD; o->mode = NFM_MODE_MINIBATCH; o->batch = c->batch; o->it = 1;
   o->o.eta0 = c->eta0; o->o.alpha0 = c->alpha0; o->o.alpha = c->alpha; o->o.beta = c->beta; o->o.power = c->power;
   o->o.eps = 0.0; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = c->scheduling; o->o.track_viol = 0;
+  o->o.touch_cap = 1.0;
   o->o.gamma = c->gamma; o->o.bsize = (double)c->batch; o->o.reg = c->reg; o->o.reg_transpose = c->reg_transpose ? 1 : 0;
   NFM_TRY(use_device(m->ctx));
   NFM_TRY(o->out2.alloc(sizeof(double) * 2));
@@ -1227,6 +1230,18 @@ int32_t nfm_opt_set_dp(nfm_opt* o, nfm_dp* dp, int64_t sync_period, int32_t over
   o->dp_uid = dp ? dp->uid : 0;
   o->dp_sync_period = sync_period;
   o->dp_overlap = overlap != 0;
+  return NFM_OK;
+}
+
+int32_t nfm_opt_set_touch_cap(nfm_opt* o, double cap) {
+  NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
+  NFM_CHECK(o->kind == OPT_SGD && o->mode == NFM_MODE_MINIBATCH, NFM_ERR_UNSUPPORTED,
+            "the touch cap belongs to SGD in NFM_MODE_MINIBATCH (AdaGrad's state sums every step anyway)");
+  NFM_CHECK(cap >= 1.0 && cap == cap, NFM_ERR_INVALID, "touch cap must be >= 1");
+  if (o->o.touch_cap != cap) {
+    o->o.touch_cap = cap;
+    o->W.drop_graph();  // a captured epoch holds the optimizer's parameters by value
+  }
   return NFM_OK;
 }
 

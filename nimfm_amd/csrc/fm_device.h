@@ -114,6 +114,10 @@ __device__ __forceinline__ double get_eta(int sched, double eta0, double power, 
   }
 }
 
+// SGD mini-batch rule: a coordinate touched c times in a batch receives (sum of the c per-sample steps) / touch_div --
+// the sum itself up to `cap` touches, cap / c of it beyond (cap = 1: the mean)
+__device__ __forceinline__ double touch_div(double c, double cap) { return c > cap ? c / cap : 1.0; }
+
 // model/fm_base.nim:32-34: classification targets are sign(y)
 __device__ __forceinline__ double target_of(double y, int task) {
   if (task == NFM_TASK_CLASSIFICATION) return (double)((y > 0) - (y < 0));

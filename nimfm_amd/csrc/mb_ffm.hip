@@ -537,10 +537,11 @@ __device__ __forceinline__ double ffm_unit(const FColArgs& a, int64_t j, int f, 
     }
     return 0.0;
   }
+  const double cd = dev::touch_div(c, O.touch_cap);  // SGD: divisor of the summed steps (mb_fm_kernels.h)
   if (OPT == OPT_SGD) {
-    viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
-    st.x = st.x * fP - (acc.x / c) / sPn;
-    st.y = st.y * fP - (acc.y / c) / sPn;
+    viol += fabs((acc.x + seta * O.beta * p.x) / cd) + fabs((acc.y + seta * O.beta * p.y) / cd);
+    st.x = st.x * fP - (acc.x / cd) / sPn;
+    st.y = st.y * fP - (acc.y / cd) / sPn;
     ffm_st<4>(M.P + e, st);
   } else {
     g2.x += acc.x; g2.y += acc.y; n2.x += accn.x; n2.y += accn.y;
@@ -551,8 +552,8 @@ __device__ __forceinline__ double ffm_unit(const FColArgs& a, int64_t j, int f, 
     const double wt = M.w[j];
     if (OPT == OPT_SGD) {
       const double wj = sw * wt;
-      viol += fabs((a0 + a1 * O.alpha * wj) / c);
-      M.w[j] = wt * fw - (a0 / c) / swn;
+      viol += fabs((a0 + a1 * O.alpha * wj) / cd);
+      M.w[j] = wt * fw - (a0 / cd) / swn;
     } else {
       const double gw = O.Gw[j], nw = O.Nw[j];
       if (!a.use_stored) {
@@ -572,9 +573,9 @@ __device__ __forceinline__ void ffm_touch_factors(const FColArgs& a, int64_t ci,
   fP = 1.0;
   fw = 1.0;
   if (ci > 1) {
-    const double c = (double)ci;
-    if (ci <= kFtab) { fP = a.Ftab_b[ci - 1]; fw = a.Ftab_b[kFtab + ci - 1]; }
-    else { fP = pow(a.Dtab_b[0], 1.0 / c) / a.Dtab_b[0]; fw = pow(a.Dtab_b[1], 1.0 / c) / a.Dtab_b[1]; }
+    const double c = dev::touch_div((double)ci, a.O.touch_cap);
+    if (ci <= kFtab) { fP = a.Ftab_b[ci - 1]; fw = a.Ftab_b[kFtab + ci - 1]; }  // (the table has the cap in it)
+    else if (c > 1.0) { fP = pow(a.Dtab_b[0], 1.0 / c) / a.Dtab_b[0]; fw = pow(a.Dtab_b[1], 1.0 / c) / a.Dtab_b[1]; }
   }
 }
 
@@ -670,10 +671,7 @@ __global__ __launch_bounds__(kBlock) void k_ffm_col_phase(FColArgs a) {
     if (OPT == OPT_SGD) {
       sP = a.scales_b[0]; sw = a.scales_b[1]; sPn = a.scales_n[0]; swn = a.scales_n[1];
       const int64_t ci = t1 - t0;
-      if (ci > 1) {
-        if (ci <= kFtab) { fP = a.Ftab_b[ci - 1]; fw = a.Ftab_b[kFtab + ci - 1]; }
-        else { fP = pow(a.Dtab_b[0], 1.0 / c) / a.Dtab_b[0]; fw = pow(a.Dtab_b[1], 1.0 / c) / a.Dtab_b[1]; }
-      }
+      ffm_touch_factors(a, ci, fP, fw);
     }
     if (t1 - t0 <= kHeavyTouches)  // heavy features: k_ffm_heavy_partial / k_ffm_heavy_apply
       viol += ffm_unit<L, OPT, 0>(a, j, f, l, t0, t1, c, sP, sPn, sw, swn, fP, fw, itp, nullptr, 0, 0);
@@ -705,9 +703,9 @@ __global__ __launch_bounds__(kBlock) void k_ffm_col_phase(FColArgs a) {
     double v = red[1][0] + red[4][0];
     if (M.fit_intercept) {
       if (OPT == OPT_SGD) {
-        const double b0 = M.sc[SC_INTERCEPT], f0 = a.Dtab_b[3];
-        v += fabs((red[2][0] + red[3][0] * O.alpha0 * b0) / a.len);
-        M.sc[SC_INTERCEPT] = f0 * b0 - red[2][0] / a.len;
+        const double b0 = M.sc[SC_INTERCEPT], f0 = a.Dtab_b[3], lc = dev::touch_div(a.len, O.touch_cap);
+        v += fabs((red[2][0] + red[3][0] * O.alpha0 * b0) / lc);
+        M.sc[SC_INTERCEPT] = f0 * b0 - red[2][0] / lc;
       } else {
         if (!a.use_stored) {
           const double old = M.sc[SC_INTERCEPT];

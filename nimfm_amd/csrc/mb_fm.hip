@@ -65,15 +65,17 @@ __global__ void k_schedule(OptView O, int fit_linear, int fit_intercept, const i
     Dtab[4 * b + 0] = red[0][0];
     Dtab[4 * b + 1] = red[1][0];
     Dtab[4 * b + 2] = red[2][0];
-    const double len = (double)(p1 - p0);  // the intercept is touched by every sample: c = len
-    Dtab[4 * b + 3] = len == 1.0 ? red[2][0] : pow(red[2][0], 1.0 / len);
+    // the intercept is touched by every sample: c = len (as a divisor: len / touch_cap beyond the cap)
+    const double lc = dev::touch_div((double)(p1 - p0), O.touch_cap);
+    Dtab[4 * b + 3] = lc == 1.0 ? red[2][0] : pow(red[2][0], 1.0 / lc);
   }
   // a coordinate touched c times receives D^(1/c) instead of D; relative to the global scale
   // (which advances by D) that is the factor D^(1/c) / D, tabulated for c = 1..kFtab
   if (threadIdx.x < 2 * kFtab) {
     const int which = threadIdx.x / kFtab, c = threadIdx.x % kFtab + 1;
     const double D = red[which][0];
-    Ftab[((size_t)b * 2 + which) * kFtab + (c - 1)] = c == 1 ? 1.0 : pow(D, 1.0 / (double)c) / D;
+    const double cd = dev::touch_div((double)c, O.touch_cap);
+    Ftab[((size_t)b * 2 + which) * kFtab + (c - 1)] = cd == 1.0 ? 1.0 : pow(D, 1.0 / cd) / D;
   }
 }
 

@@ -1218,7 +1218,7 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
     return 0.0;
   }
   if (OPT == OPT_SGD) {
-    const double c = MODE == 0 ? (double)(t1 - t0) : c_total;
+    const double c = dev::touch_div(MODE == 0 ? (double)(t1 - t0) : c_total, O.touch_cap);
     viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
     stored.x = stored.x * fP - (acc.x / c) / sPn;
     stored.y = stored.y * fP - (acc.y / c) / sPn;
@@ -1346,7 +1346,7 @@ __device__ __forceinline__ double col_block_d3(const ColArgs& a, int64_t j, int 
       }
     }
   }
-  const double c = (double)(t1 - t0);
+  const double c = dev::touch_div((double)(t1 - t0), O.touch_cap);
 #pragma unroll
   for (int o = 0; o < 2; ++o) {
     if (OPT == OPT_SGD) {
@@ -1376,9 +1376,10 @@ __device__ __forceinline__ double w_epilogue(const ColArgs& a, int64_t j, int l,
   const double wt = M.w[j];
   if (OPT == OPT_SGD) {
     const double wj = sw * wt;
+    const double cd = dev::touch_div(c, O.touch_cap);
     if (l == 0) {
-      viol += fabs((wacc.a0 + wacc.a1 * O.alpha * wj) / c);
-      M.w[j] = wt * fw - (wacc.a0 / c) / swn;
+      viol += fabs((wacc.a0 + wacc.a1 * O.alpha * wj) / cd);
+      M.w[j] = wt * fw - (wacc.a0 / cd) / swn;
     }
   } else if (OPT == OPT_PSGD) {  // model/params.nim:43-45; swn carries eta_w
     if (l == 0) {
@@ -1405,12 +1406,13 @@ __device__ __forceinline__ void touch_factors(const ColArgs& a, int64_t c, doubl
   fP = 1.0;
   fw = 1.0;
   if (c > 1) {
-    if (c <= kFtab) {
+    if (c <= kFtab) {  // (the table has the touch cap in it: k_schedule)
       fP = a.Ftab_b[c - 1];
       fw = a.Ftab_b[kFtab + c - 1];
     } else {
-      fP = pow(a.Dtab_b[0], 1.0 / (double)c) / a.Dtab_b[0];
-      fw = pow(a.Dtab_b[1], 1.0 / (double)c) / a.Dtab_b[1];
+      const double cd = dev::touch_div((double)c, a.O.touch_cap);
+      fP = cd == 1.0 ? 1.0 : pow(a.Dtab_b[0], 1.0 / cd) / a.Dtab_b[0];
+      fw = cd == 1.0 ? 1.0 : pow(a.Dtab_b[1], 1.0 / cd) / a.Dtab_b[1];
     }
   }
 }
@@ -1567,9 +1569,9 @@ __device__ __forceinline__ void col_closer(const ColArgs& a, double (&red)[5][kB
     double v = red[1][0] + red[4][0];
     if (M.fit_intercept) {
       if (OPT == OPT_SGD) {  // the intercept is touched by every sample of the batch: c = len
-        const double b0 = M.sc[SC_INTERCEPT], f0 = a.Dtab_b[3];
-        v += fabs((red[2][0] + red[3][0] * O.alpha0 * b0) / a.len);
-        M.sc[SC_INTERCEPT] = f0 * b0 - red[2][0] / a.len;
+        const double b0 = M.sc[SC_INTERCEPT], f0 = a.Dtab_b[3], lc = dev::touch_div(a.len, O.touch_cap);
+        v += fabs((red[2][0] + red[3][0] * O.alpha0 * b0) / lc);
+        M.sc[SC_INTERCEPT] = f0 * b0 - red[2][0] / lc;
       } else if (OPT == OPT_PSGD) {
         // model/params.nim:47 gates the intercept's step on grad.fitLinear -- kept as the reference has it
         if (O.gradb != nullptr)
@@ -1863,7 +1865,7 @@ __global__ __launch_bounds__(kBlock, NFM_COL_SPARSE_MINW) void k_col_sparse(ColA
         }
       }
     }
-    const double c = (double)(t1 - t0);
+    const double c = OPT == OPT_SGD ? dev::touch_div((double)(t1 - t0), O.touch_cap) : (double)(t1 - t0);
     if (OPT == OPT_SGD) {
       viol += fabs((acc.x + seta * O.beta * p.x) / c) + fabs((acc.y + seta * O.beta * p.y) / c);
       stored.x = stored.x * s.fP - (acc.x / c) / sPn;

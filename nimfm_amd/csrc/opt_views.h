@@ -10,6 +10,10 @@ enum { OPT_SGD = 0, OPT_ADAGRAD = 1, OPT_PSGD = 2 };
 struct OptView {
   // hyper-parameters (newSGD optimizer/sgd.nim:23-52, newAdaGrad optimizer/adagrad.nim:20-44)
   double eta0, alpha0, alpha, beta, power, eps, loss_param;
+  // SGD mini-batch rule: at most this many of a batch's per-sample steps on one coordinate are SUMMED (the reference's
+  // Hogwild threads apply theirs at full strength too, optimizer/sgd_multi.nim:83-101); a coordinate touched c > cap
+  // times receives cap / c of the sum.  1 (default): the per-coordinate mean
+  double touch_cap;
   int32_t loss, sched, track_viol, pad_;
   // AdaGrad state, device layout: G/N [nb][da][Kp] (padding: G = 0, N = eps), Gw/Nw [d],
   // gsc[0] = g_sum.intercept, gsc[1] = g_norm.intercept

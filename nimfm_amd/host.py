@@ -1062,19 +1062,26 @@ _OptimizerBase._fit_devices = _fit_devices
 class SGD(_OptimizerBase):
     def __init__(self, maxIter=100, eta0=0.01, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squared",
                  scheduling="optimal", power=1.0, verbose=1, tol=1e-3, shuffle=True, nCalls=-1, mode="sequential",
-                 batch=8192, lossParam=1.0, deviceShuffle=False):
+                 batch=8192, lossParam=1.0, deviceShuffle=False, touchCap=1.0):
         super().__init__(maxIter, alpha0, alpha, beta, loss, verbose, tol, shuffle, nCalls, mode, batch, lossParam, deviceShuffle)
         if scheduling not in capi.SCHED:
             raise ValueError("unknown scheduling %r" % (scheduling,))
         self.eta0, self.scheduling, self.power = float(eta0), scheduling, float(power)
+        # mini-batch mode: how many of a batch's per-sample steps on one coordinate are summed before averaging sets in
+        # (nfm_opt_set_touch_cap; 1 = the per-coordinate mean; the reference's Hogwild with T threads ~ T)
+        if not float(touchCap) >= 1.0:
+            raise ValueError("touchCap < 1.")
+        self.touchCap = float(touchCap)
 
     def _create(self, mh, mode):
         cfg = capi.SGDCfg(self.eta0, self.alpha0, self.alpha, self.beta, self.power, self.lossParam,
                           capi.LOSS[self.loss], capi.SCHED[self.scheduling], capi.MODE[mode], 0, self.batch)
         capi.check(capi.lib().nfm_sgd_create(mh, C.byref(cfg), C.byref(self._h)))
+        if mode == "minibatch" and self.touchCap != 1.0:
+            capi.check(capi.lib().nfm_opt_set_touch_cap(self._h, self.touchCap))
 
     def _cfg_key(self):
-        return super()._cfg_key() + (self.eta0, self.scheduling, self.power)
+        return super()._cfg_key() + (self.eta0, self.scheduling, self.power, self.touchCap)
 
     def _per_epoch_callback(self, callback):
         return callback is not None and (self.nCalls <= 0 or self.mode != "sequential")  # sgd.nim:312

@@ -358,8 +358,25 @@ def slow_ffm_adagrad_fit(Xd, field_of, n_fields, y, P, w, intercept, cfg, max_it
 
 
 # ---- this repository's mini-batch rule (see nimfm_mb.c) ----
-def fm_sgd_epoch_mb(X, y, degree, P, w, intercept, cfg, batch, n_aug=0, perm=None, begin=0, end=None, it=1):
+class _touch_cap:
+    """the SGD mini-batch rule's touch cap for the calls inside (oracle/nimfm_mb.c: orc_mb_touch_cap; 1 = the mean)"""
+
+    def __init__(self, cap):
+        self.cap = float(cap)
+
+    def __enter__(self):
+        self.var = C.c_double.in_dll(lib(), "orc_mb_touch_cap")
+        self.old, self.var.value = self.var.value, self.cap
+
+    def __exit__(self, *a):
+        self.var.value = self.old
+
+
+def fm_sgd_epoch_mb(X, y, degree, P, w, intercept, cfg, batch, n_aug=0, perm=None, begin=0, end=None, it=1, touch_cap=1.0):
     """In place on P (model layout) and w; returns (intercept, it, loss_sum, viol_sum)."""
+    if touch_cap != 1.0:
+        with _touch_cap(touch_cap):
+            return fm_sgd_epoch_mb(X, y, degree, P, w, intercept, cfg, batch, n_aug, perm, begin, end, it)
     O, k, da = P.shape
     assert P.dtype == np.float64 and P.flags.c_contiguous and w.flags.c_contiguous
     y = f64(y)
@@ -398,7 +415,10 @@ def fm_adagrad_finalize(degree, P, w, intercept, cfg, it, state, n_aug=0):
     return b.value
 
 
-def ffm_sgd_epoch_mb(X, y, P, w, intercept, cfg, batch, perm=None, begin=0, end=None, it=1):
+def ffm_sgd_epoch_mb(X, y, P, w, intercept, cfg, batch, perm=None, begin=0, end=None, it=1, touch_cap=1.0):
+    if touch_cap != 1.0:
+        with _touch_cap(touch_cap):
+            return ffm_sgd_epoch_mb(X, y, P, w, intercept, cfg, batch, perm, begin, end, it)
     F, d, k = P.shape
     y = f64(y)
     end = X.n if end is None else end

@@ -22,6 +22,10 @@
  */
 #include "nimfm_oracle.c"
 
+/* touch cap of the SGD rule (1: the per-coordinate MEAN of the batch's steps; larger: up to that many of them are
+ * SUMMED, the rest averaged in) -- see sgd_epoch_mb */
+double orc_mb_touch_cap = 1.0;
+
 typedef double (*mb_predict_fn)(const orc_csr* X, int64_t i, int n_blocks, int k, int degree,
                                 int n_aug, const double* Pt, const double* w, double intercept,
                                 double* A, double* dA);
@@ -52,7 +56,11 @@ static double mb_predict_ffm(const orc_csr* X, int64_t i, int n_blocks, int k, i
  * plain mini-batch SGD on the batch mean) coordinates alike.  A plain sum (Hogwild without lost
  * updates) multiplies the step of a coordinate by c_j and diverges on dense ones (intercept).
  * The intercept is a coordinate touched by every sample (c = len).  batch == 1 gives the
- * reference's step exactly. */
+ * reference's step exactly.
+ * Touch cap (orc_mb_touch_cap = C >= 1, nfm_opt_set_touch_cap in the library): c_j above is replaced by
+ * max(1, c_j / C) -- up to C of the batch's steps on a coordinate are SUMMED (what the reference's C Hogwild
+ * threads do to their shared model), beyond that the sum is scaled by C / c_j; the decay exponent follows.
+ * C = 1 is the mean written above. */
 static int sgd_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict, int n_blocks,
                         int k, int degree, int n_aug, double* Pt /*[n_blocks][da][k]*/, double* w,
                         double* intercept, const orc_sgd_cfg* c, const int64_t* perm, int64_t begin,
@@ -108,7 +116,7 @@ static int sgd_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict
       D0 *= (1 - eta0 * c->alpha0);
     }
     for (int64_t j = 0; j < da; j++) {
-      const double cj = cnt[j];
+      const double cj = cnt[j] > orc_mb_touch_cap ? cnt[j] / orc_mb_touch_cap : (cnt[j] > 0 ? 1.0 : 0.0);
       const double fP = cj > 0 ? (cj == 1.0 ? DP : pow(DP, 1.0 / cj)) : DP;
       for (int o = 0; o < n_blocks; o++)
         for (int s = 0; s < k; s++) {
@@ -131,9 +139,10 @@ static int sgd_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict
       }
     }
     if (c->fit_intercept) {
-      const double f0 = len == 1.0 ? D0 : pow(D0, 1.0 / len);
-      viol += fabs((accb + seta0 * c->alpha0 * *intercept) / len);
-      *intercept = f0 * *intercept - accb / len;
+      const double lb = len > orc_mb_touch_cap ? len / orc_mb_touch_cap : 1.0;
+      const double f0 = lb == 1.0 ? D0 : pow(D0, 1.0 / lb);
+      viol += fabs((accb + seta0 * c->alpha0 * *intercept) / lb);
+      *intercept = f0 * *intercept - accb / lb;
     }
     *it += p1 - p0;
   }

@@ -557,3 +557,52 @@ def test_epoch_over_a_sub_range(dense, with_perm):
         assert abs(fm.intercept - b) < 1e-11
         assert_close(fm.w, w, RTOL, ATOL, solver + " w")
         assert_close(fm.P, P, RTOL, ATOL, solver + " P")
+
+
+@pytest.mark.parametrize("cap,model,batch", itertools.product([2.0, 4.0, 16.0], ["fm2", "fm3", "ffm"], [7, 64, 1000]))
+def test_sgd_touch_cap_vs_mb_oracle(cap, model, batch):
+    """nfm_opt_set_touch_cap: up to `cap` of a batch's per-sample steps on one coordinate are summed, beyond that the sum
+    is scaled by cap / c (the reference's Hogwild threads apply their steps at full strength, sgd_multi.nim:83-101;
+    cap = 1, the default of every other test here, is the per-coordinate mean).  Sparse and dense coordinates, the
+    intercept (touched by every sample), features past the 64-entry decay table and the segment path (> 128 touches)."""
+    from common import init_ffm
+    from gpu_common import gpu_ffm
+    rng = np.random.default_rng(int(cap) * 100 + batch)
+    n, d, k = 1200, 90, 8
+    rows, vals, indptr = [], [], [0]
+    for i in range(n):
+        m = int(rng.integers(1, 12))
+        p = np.full(d, 1.0)
+        p[:2] = d  # two features most samples have: far more than 64 / 128 touches per batch of 1000
+        idx = np.sort(rng.choice(d, size=m, replace=False, p=p / p.sum()))
+        rows.append(idx)
+        vals.append(rng.uniform(-1, 1, size=m))
+        indptr.append(indptr[-1] + m)
+    idx, val, indptr = np.concatenate(rows).astype(np.int64), np.concatenate(vals), np.array(indptr)
+    y = rng.standard_normal(n)
+    perms = make_perms(n, 2)
+    cfg = O.sgd_cfg(eta0=0.02, scheduling="invscaling", power=0.5)
+    kw = dict(maxIter=2, eta0=0.02, scheduling="invscaling", power=0.5, verbose=0, tol=0, mode="minibatch", batch=batch, touchCap=cap)
+    if model == "ffm":
+        F = 5
+        field_of = rng.integers(0, F, size=d)
+        Xo = O.Dataset(indptr, idx, val, n, d, field_of[idx], F)
+        P0, w0, b0 = init_ffm(d, F, k, scale=0.05)
+        P, w, b, it = P0.copy(), w0.copy(), 0.1, 1
+        for e in range(2):
+            b, it, _, _ = O.ffm_sgd_epoch_mb(Xo, y, P, w, b, cfg, batch, perm=perms[e], it=it, touch_cap=cap)
+        mdl = gpu_ffm("regression", k, True, True, P0, w0, 0.1)
+    else:
+        degree = 2 if model == "fm2" else 3
+        Xo = O.Dataset(indptr, idx, val, n, d)
+        P0, w0 = rng.standard_normal((degree - 1, k, d)) * 0.05, rng.standard_normal(d) * 0.01
+        P, w, b, it = P0.copy(), w0.copy(), 0.1, 1
+        for e in range(2):
+            b, it, _, _ = O.fm_sgd_epoch_mb(Xo, y, degree, P, w, b, cfg, batch, perm=perms[e], it=it, touch_cap=cap)
+        mdl = gpu_fm("regression", degree, k, "explicit", True, True, P0, w0, 0.1)
+    opt = nf.newSGD(**kw)
+    opt.fit(to_gpu(Xo), y, mdl, perms=perms)
+    assert np.isfinite(P).all()
+    assert opt.it == it and abs(mdl.intercept - b) < 1e-10
+    assert_close(mdl.w, w, RTOL, ATOL, "w")
+    assert_close(mdl.P, P, RTOL, ATOL, "P")
