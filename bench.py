@@ -452,7 +452,9 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     dp_stats = None
     if use_dp:  # what the exchange moved during the timed steps (nfm_dp_info: this rank's collectives and bytes)
         i1 = run_training.group.info()
-        dp_stats = {"combine": ("mean" if args.combine == "mean" else "sum") if wl["solver"] == "sgd" else "state-summed",
+        comb = args.combine if args.combine != "auto" else ("mean" if wl["solver"] == "sgd" else ("sum" if sync_period == 1 else "state_mean"))
+        dp_stats = {"combine": comb if wl["solver"] == "sgd" else {"sum": "state increments summed", "mean": "state increments summed",
+                                                                    "state_mean": "state increments averaged"}[comb],
                     "sync_period": sync_period, "world": i1["world"],
                     "collectives_per_step": (i1["collectives"] - dp_info0["collectives"]) / steps,
                     "bytes_per_step_per_rank": (i1["bytes"] - dp_info0["bytes"]) / steps,
@@ -737,7 +739,8 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                                      "`time_to_target` measures the real thing",
                        "parallelism": ("%d ranks, one process per GPU, contiguous sample shards; replicas %s in the library over "
                                        "RCCL every %s on a second stream + exactly at the end of every epoch"
-                                       % (world, ("increments %s" % ("averaged" if args.combine == "mean" else "summed")) if wl["solver"] == "sgd" else "state-summed",
+                                       % (world, ("increments %s" % ("summed" if args.combine == "sum" else "averaged")) if wl["solver"] == "sgd"
+                                          else ("state increments %s" % ("averaged" if args.combine in ("auto", "state_mean") and sync_period != 1 else "summed")),
                                           ("%d mini-batches" % sync_period) if sync_period else "epoch (no mid-epoch exchange)"))
                        if use_dp else "1 GPU"},
             "last_step": {"mean_loss": last[0] / (n * world), "viol": last[1]}, "predict": pred, "exact_order": exact,
@@ -762,8 +765,9 @@ def main():
     ap.add_argument("--sync-period", type=int, default=-1,
                     help="N > 1: mini-batches between exchanges (0 = only at the end of every epoch; default 128 for epochs "
                          "of >= 512 mini-batches, 64 for >= 256, else 0)")
-    ap.add_argument("--combine", default="mean", choices=["mean", "sum"],
-                    help="N > 1, SGD: how the ranks' increments are combined at an exchange (DESIGN.md section 6)")
+    ap.add_argument("--combine", default="auto", choices=["auto", "mean", "sum", "state_mean"],
+                    help="N > 1: how the ranks' increments are combined at an exchange (DESIGN.md section 6); auto = SGD: the mean, "
+                         "AdaGrad: the state increments averaged (summed when the ranks exchange after every mini-batch)")
     ap.add_argument("--touch-cap", type=float, default=16.0,
                     help="SGD mini-batch rule: steps of a batch on one coordinate that are summed before averaging sets in "
                          "(nfm_opt_set_touch_cap; 1 = the per-coordinate mean, the library's default; 16 matches one "

@@ -341,7 +341,12 @@ int32_t nfm_opt_set_dp(nfm_opt* o, nfm_dp* dp, int64_t sync_period, int32_t over
  * reference's shared one (optimizer/sgd_multi.nim:83-101): the progress of all ranks' steps, at the price of a step size
  * that is effectively multiplied by the number of ranks wherever their features overlap (keep sync_period small).
  * DESIGN.md section 6 has the measurements. */
-enum { NFM_DP_MEAN = 0, NFM_DP_SUM = 1 };
+/* AdaGrad: the state increments are SUMMED by default (with an exchange after every mini-batch that is synchronous
+ * data-parallel AdaGrad -- the state ONE process would hold).  With long periods every rank fits its own shard between
+ * exchanges and the summed state over-shoots by up to the number of ranks (measured: 4 ranks x 16 mini-batches between
+ * exchanges left the held-out RMSE at 2.9 where one rank reaches 1.04, tools/dp_convergence.py); NFM_DP_STATE_MEAN averages
+ * the ranks' state increments instead -- the replicas' mean, as stable as one rank at any period. */
+enum { NFM_DP_MEAN = 0, NFM_DP_SUM = 1, NFM_DP_STATE_MEAN = 2 };
 int32_t nfm_opt_set_dp_combine(nfm_opt* o, int32_t combine);
 
 /* SGD, NFM_MODE_MINIBATCH: how a mini-batch combines the per-sample steps (optimizer/sgd.nim:205-243) of the `c` samples

@@ -890,7 +890,9 @@ static int dp_epoch_setup(nfm_opt* o, nfm_model* m, const ModelView& M, DpEpoch*
   de.opt_kind = o->kind;
   de.sync_period = o->dp_sync_period;
   de.overlap = o->dp_overlap;
-  de.combine_w = (o->kind == OPT_SGD && o->dp_combine == NFM_DP_MEAN) ? 1.0 / (double)o->dp->t->world : 1.0;
+  // SGD: the ranks' increments averaged unless NFM_DP_SUM; AdaGrad: its state increments summed unless NFM_DP_STATE_MEAN
+  const bool averaged = o->kind == OPT_SGD ? o->dp_combine != NFM_DP_SUM : o->dp_combine == NFM_DP_STATE_MEAN;
+  de.combine_w = averaged ? 1.0 / (double)o->dp->t->world : 1.0;
   if (o->kind == OPT_SGD) {
     de.arena = m->arena.as<double>();
     de.n = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double)) + SC_COUNT;
@@ -1247,7 +1249,8 @@ int32_t nfm_opt_set_touch_cap(nfm_opt* o, double cap) {
 
 int32_t nfm_opt_set_dp_combine(nfm_opt* o, int32_t combine) {
   NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
-  NFM_CHECK(combine == NFM_DP_MEAN || combine == NFM_DP_SUM, NFM_ERR_INVALID, "combine must be NFM_DP_MEAN or NFM_DP_SUM");
+  NFM_CHECK(combine == NFM_DP_MEAN || combine == NFM_DP_SUM || combine == NFM_DP_STATE_MEAN, NFM_ERR_INVALID,
+            "combine must be NFM_DP_MEAN, NFM_DP_SUM or NFM_DP_STATE_MEAN");
   o->dp_combine = combine;
   return NFM_OK;
 }

@@ -91,6 +91,8 @@ struct LocalGroup {
   int world = 0, arrived = 0;
   uint64_t generation = 0;
   const double* send[kMaxLocalWorld] = {};
+  int64_t count[kMaxLocalWorld] = {};  // what every rank believes the collective's length and operation to be
+  int opcode[kMaxLocalWorld] = {};
   hipEvent_t ready[kMaxLocalWorld] = {}, done[kMaxLocalWorld] = {};
   int device[kMaxLocalWorld] = {};
   bool broken = false;
@@ -138,7 +140,21 @@ struct LocalTransport : DpTransport {
     LocalGroup& G = *g;
     NFM_HIP_CHECK(hipEventRecord(G.ready[rank], st));
     G.send[rank] = send;
+    G.count[rank] = n;
+    G.opcode[rank] = op;
     NFM_CHECK(G.barrier(), NFM_ERR_HIP, "a rank of the local group did not reach the collective");  // buffers published, "ready" recorded
+    // the ranks must be in the SAME collective: a rank that left its epoch loop early (or entered another call) would
+    // otherwise have its short buffer read at this rank's length
+    for (int q = 0; q < world; ++q)
+      if (G.count[q] != n || G.opcode[q] != op) {
+        {
+          std::lock_guard<std::mutex> lk(G.mu);
+          G.broken = true;
+        }
+        G.cv.notify_all();
+        return set_error(NFM_ERR_INVALID, "local group: rank %d is in a collective of %lld values (op %d), rank %d in one of %lld (op %d): "
+                         "the ranks did not make the same sequence of calls", rank, (long long)n, op, q, (long long)G.count[q], G.opcode[q]);
+      }
     PeerPtrs pp{};
     for (int q = 0; q < world; ++q) {
       pp.p[q] = G.send[q];
@@ -214,9 +230,9 @@ __global__ void k_inc_fold_own(double* __restrict__ x, double* __restrict__ base
   }
 }
 // closing: x = base + R (every rank forms the same sum), base = x
-__global__ void k_inc_close(double* __restrict__ x, double* __restrict__ base, const double* __restrict__ R, int64_t n) {
+__global__ void k_inc_close(double* __restrict__ x, double* __restrict__ base, const double* __restrict__ R, int64_t n, double w) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double g = base[i] + R[i];
+    const double g = base[i] + w * R[i];
     x[i] = g;
     base[i] = g;
   }
@@ -343,7 +359,7 @@ int dp_epoch_end(DpEpoch& e, double* sums_dev) {
     hipLaunchKernelGGL(k_inc_own, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->snap.as<double>(), e.n,
                        (int64_t)0, (int64_t)0);
     NFM_TRY(dp->t->allreduce(dp->snap.as<double>(), dp->recv.as<double>(), e.n, DP_SUM, st));
-    hipLaunchKernelGGL(k_inc_close, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(), e.n);
+    hipLaunchKernelGGL(k_inc_close, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(), e.n, e.combine_w);
   }
   NFM_HIP_CHECK(hipGetLastError());
   dp->n_collectives++;

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include <map>
+#include <thread>
 #include <mutex>
 
 #include "common.h"
@@ -28,14 +29,18 @@ const char* last_error() { return g_err; }
 // ---- device memory: a small caching allocator ----
 // hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises the device; the batch plan of an epoch
 // with a fresh permutation makes ~35 temporary allocations (8 of the 10 ms such an epoch took on cfg2).
-// Released blocks are kept per device and handed out again to requests of similar size.  All work of a
-// context is stream-ordered on one stream, and the API calls that release buffers end with a stream
-// synchronisation, so a recycled block is never still in use.  NFM_POOL=0 disables the cache,
-// NFM_POOL_MAX_GB (default 64) bounds what it keeps.
+// Released blocks are kept per device and handed out again to requests of similar size.  A block may still be in
+// use by kernels ENQUEUED on the releasing thread's stream: handing it to the same host thread again is safe (its
+// work is stream-ordered behind them), handing it to ANOTHER thread -- another context with its own stream: the ranks
+// of a local data-parallel group on one GPU (nfm_dp_create_local) -- is not.  The free lists are therefore kept per
+// (device, host thread); a request that finds nothing in its own list may take a block another thread released only
+// after the whole device has drained (hipDeviceSynchronize: rare -- a rank's first allocations).  Found the hard way:
+// 4 and 8 ranks on one GPU faulted now and then (a rank's plan tables overwritten by a neighbour's fresh buffer).
+// NFM_POOL=0 disables the cache, NFM_POOL_MAX_GB (default 64) bounds what it keeps.
 namespace {
 struct BlockPool {
   std::mutex mu;
-  std::multimap<size_t, void*> free_blocks[16];
+  std::map<std::thread::id, std::multimap<size_t, void*>> free_blocks[16];
   size_t kept = 0;
   bool enabled = !(getenv("NFM_POOL") && atoi(getenv("NFM_POOL")) == 0);
   size_t max_kept = (size_t)(getenv("NFM_POOL_MAX_GB") ? atof(getenv("NFM_POOL_MAX_GB")) : 64.0) << 30;
@@ -48,6 +53,7 @@ size_t round_request(size_t n) {
   if (n <= (1u << 20)) return (n + 255) / 256 * 256;
   return (n + (1u << 20) - 1) >> 20 << 20;  // whole MiB: sizes that differ a little between epochs match
 }
+bool fits(size_t have, size_t want) { return have >= want && have <= want + want / 4 + (1u << 20); }
 }  // namespace
 
 int DevBuf::alloc(size_t nbytes) {
@@ -58,25 +64,56 @@ int DevBuf::alloc(size_t nbytes) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (bp.enabled && dev >= 0 && dev < 16) {
-    std::lock_guard<std::mutex> lk(bp.mu);
-    auto it = bp.free_blocks[dev].lower_bound(want);
-    if (it != bp.free_blocks[dev].end() && it->first <= want + want / 4 + (1u << 20)) {
-      p = it->second;
-      cap = it->first;
-      bytes = nbytes;
-      device = dev;
-      bp.kept -= it->first;
-      bp.free_blocks[dev].erase(it);
-      return NFM_OK;
+    const std::thread::id me = std::this_thread::get_id();
+    bool foreign = false;
+    {
+      std::lock_guard<std::mutex> lk(bp.mu);
+      auto mine = bp.free_blocks[dev].find(me);
+      if (mine != bp.free_blocks[dev].end()) {
+        auto it = mine->second.lower_bound(want);
+        if (it != mine->second.end() && fits(it->first, want)) {
+          p = it->second;
+          cap = it->first;
+          bytes = nbytes;
+          device = dev;
+          bp.kept -= it->first;
+          mine->second.erase(it);
+          return NFM_OK;
+        }
+      }
+      for (auto& kv : bp.free_blocks[dev])
+        if (kv.first != me) {
+          auto it = kv.second.lower_bound(want);
+          if (it != kv.second.end() && fits(it->first, want)) foreign = true;
+        }
+    }
+    if (foreign) {
+      // another thread's block: only once nothing on the device can still be using it
+      (void)hipDeviceSynchronize();
+      std::lock_guard<std::mutex> lk(bp.mu);
+      for (auto& kv : bp.free_blocks[dev]) {
+        if (kv.first == me) continue;
+        auto it = kv.second.lower_bound(want);
+        if (it != kv.second.end() && fits(it->first, want)) {
+          p = it->second;
+          cap = it->first;
+          bytes = nbytes;
+          device = dev;
+          bp.kept -= it->first;
+          kv.second.erase(it);
+          return NFM_OK;
+        }
+      }
     }
   }
   hipError_t e = hipMalloc(&p, want);
   if (e != hipSuccess && bp.enabled) {  // out of memory: give the cached blocks back and retry
     {
       std::lock_guard<std::mutex> lk(bp.mu);
-      for (auto& m : bp.free_blocks) {
-        for (auto& kv : m) (void)hipFree(kv.second);
-        m.clear();
+      for (auto& per_dev : bp.free_blocks) {
+        for (auto& per_thread : per_dev)
+          for (auto& kv : per_thread.second) (void)hipFree(kv.second);
+        per_dev.clear();
       }
       bp.kept = 0;
     }
@@ -99,7 +136,7 @@ void DevBuf::release() {
     if (bp.enabled && device >= 0 && device < 16 && cap > 0) {
       std::lock_guard<std::mutex> lk(bp.mu);
       if (bp.kept + cap <= bp.max_kept) {
-        bp.free_blocks[device].emplace(cap, p);
+        bp.free_blocks[device][std::this_thread::get_id()].emplace(cap, p);
         bp.kept += cap;
         kept = true;
       }

@@ -761,7 +761,7 @@ class _OptimizerBase:
                 self._attach_dp()
         return self._h
 
-    def setDataParallel(self, group, syncPeriod=0, overlap=True, combine="mean"):
+    def setDataParallel(self, group, syncPeriod=0, overlap=True, combine="auto"):
         """The maxThreads overloads across GPUs (optimizer/sgd_multi.nim:40-120 and twins): `group` is this rank's
         dp.Group; X handed to fit is then this rank's contiguous slice of the samples (dp.shard_bounds), every rank
         calls fit together, and the library reconciles the replicas every syncPeriod mini-batches (0: only at the end of
@@ -770,8 +770,13 @@ class _OptimizerBase:
         rank's steps land in the model, as every Hogwild thread's steps do in the reference; acts like a step size times
         the number of ranks where features overlap -- keep syncPeriod small).  The epoch's loss / viol and the step
         counter `it` then cover the samples of ALL ranks."""
-        if combine not in ("mean", "sum"):
-            raise ValueError("combine must be 'mean' or 'sum'")
+        if combine not in ("auto", "mean", "sum", "state_mean"):
+            raise ValueError("combine must be 'auto', 'mean', 'sum' or 'state_mean'")
+        if combine == "auto":
+            # what tools/dp_convergence.py measured (DESIGN.md section 6): SGD -- the mean at any period; AdaGrad -- the summed
+            # state is synchronous data-parallel AdaGrad when the ranks exchange after EVERY mini-batch and over-shoots
+            # with longer periods, where the averaged state stays as stable as one rank
+            combine = "mean" if not isinstance(self, AdaGrad) else ("sum" if int(syncPeriod) == 1 else "state_mean")
         self._dp = None if group is None else (group, int(syncPeriod), bool(overlap), combine)
         if self._h is not None:
             self._attach_dp()
@@ -780,7 +785,7 @@ class _OptimizerBase:
         g = self._dp
         capi.check(capi.lib().nfm_opt_set_dp(self._h, None if g is None else g[0].h, 0 if g is None else g[1],
                                              1 if g is None or g[2] else 0))
-        capi.check(capi.lib().nfm_opt_set_dp_combine(self._h, 1 if g is not None and g[3] == "sum" else 0))
+        capi.check(capi.lib().nfm_opt_set_dp_combine(self._h, 0 if g is None else {"mean": 0, "sum": 1, "state_mean": 2}[g[3]]))
 
     def _sync_it(self):
         """with a group attached the library advances `it` by the samples of all ranks"""

@@ -59,7 +59,7 @@ def rank_sgd(epoch_fn, P, w, b, cfg, n, B, S, it0, overlap, world, combine="mean
     n_sync = int(-(yield ("max", np.array([-float(n_sync_mine(bounds, B, S))])))[0])
     loss = viol = 0.0
     pending = None
-    cw = 1.0 / world if combine == "mean" else 1.0  # the ranks' increments are averaged (default) or added up
+    cw = 1.0 if combine == "sum" else 1.0 / world  # the ranks' increments are averaged (default) or added up
 
     def flat():
         return np.concatenate([P.ravel(), w, [b]])
@@ -131,7 +131,7 @@ def _ada_unflat(st, f):
     st.gsum_b.value, st.gnorm_b.value = f[-2], f[-1]
 
 
-def rank_adagrad(epoch_fn, st, n, B, S, it0, overlap, world):
+def rank_adagrad(epoch_fn, st, n, B, S, it0, overlap, world, w=1.0):
     """epoch_fn(begin, end, it) -> (loss, viol): the oracle's AdaGrad mini-batch epoch over [begin, end), updating st"""
     bounds = batch_bounds(n, B, it0 == 1)
     nb = len(bounds) - 1
@@ -152,8 +152,8 @@ def rank_adagrad(epoch_fn, st, n, B, S, it0, overlap, world):
         if pending is None:
             return
         total, own = pending
-        _ada_unflat(st, _ada_flat(st) + (total - own))
-        base = base + total
+        _ada_unflat(st, _ada_flat(st) + (w * total - own))
+        base = base + w * total
         pending = None
 
     for k in range(1, n_sync + 1):
@@ -168,7 +168,7 @@ def rank_adagrad(epoch_fn, st, n, B, S, it0, overlap, world):
     fold()
     own = _ada_flat(st) - base
     total = yield ("sum", own.copy())
-    _ada_unflat(st, base + total)
+    _ada_unflat(st, base + w * total)
     sums = yield ("sum", np.array([loss, viol, float(n)]))
     return st, sums[0], sums[1], it0 + int(round(sums[2]))
 

@@ -66,6 +66,25 @@ def _run_ranks(world, make_rank):
 @pytest.mark.parametrize("world,S,overlap,combine", [(2, 0, True, "mean"), (2, 2, True, "mean"), (3, 3, True, "mean"), (2, 3, False, "mean"),
                                                        (3, 2, True, "sum")])
 def test_local_group_sgd_and_adagrad_vs_rule(world, S, overlap, combine):
+    _vs_rule(N, D, world, S, overlap, combine)
+
+
+@pytest.mark.parametrize("world,S,combine", [(4, 4, "mean"), (8, 2, "mean"), (8, 0, "mean"), (4, 0, "mean"), (4, 3, "state_mean"),
+                                              (8, 0, "state_mean")])
+def test_local_group_many_ranks_vs_rule(world, S, combine):
+    """4 and 8 ranks (tools/dp_convergence.py runs these group sizes), several mid-epoch exchanges per rank; state_mean:
+    AdaGrad's state increments averaged instead of summed (NFM_DP_STATE_MEAN; for SGD it is the mean)"""
+    _vs_rule(4003, 300, world, S, True, combine)
+
+
+@pytest.mark.parametrize("world,S", [(2, 2), (4, 4), (8, 3)])
+def test_local_group_sparse_regime_vs_rule(world, S):
+    """batch x nnz / d < 1.4: most features of a batch are touched once and are updated by the ROW phase (plan.use_singles),
+    the regime of the headline shape -- the exchange must not care where a row was written"""
+    _vs_rule(4003, 2000, world, S, True, "mean")
+
+
+def _vs_rule(N, D, world, S, overlap, combine):
     full = random_csr(N, D, M, seed=21)
     rng = np.random.default_rng(5)
     y = rng.standard_normal(N)
@@ -102,7 +121,7 @@ def test_local_group_sgd_and_adagrad_vs_rule(world, S, overlap, combine):
                     def ep(lo, hi, it_):
                         hold[0], _, ls, vs = O.fm_adagrad_epoch_mb(shard, ys, 2, P, w, hold[0], cfg, B, st, begin=lo, end=hi, it=it_)
                         return ls, vs
-                    st, ls, vs, it = yield from R.rank_adagrad(ep, st, shard.n, B, S, it, overlap, world)
+                    st, ls, vs, it = yield from R.rank_adagrad(ep, st, shard.n, B, S, it, overlap, world, 1.0 / world if combine == "state_mean" else 1.0)
                     hist.append((vs, ls / N))
                 bb = O.fm_adagrad_finalize(2, P, w, hold[0], cfg, it, st)
                 return P, w, bb, hist, it

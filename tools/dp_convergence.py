@@ -14,34 +14,51 @@ import threading
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 import nimfm_amd as nf  # noqa: E402
-import oracle as O  # noqa: E402
-from common import random_csr  # noqa: E402
 from nimfm_amd import dp  # noqa: E402
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 CAP = float(sys.argv[2]) if len(sys.argv) > 2 else 16.0
 n, nt, d, m, k, B = 160_000, 20_000, 20_000, 16, 8, 512
-full = random_csr(n + nt, d, m, seed=5)
+rng = np.random.default_rng(5)
+idx = np.sort(rng.integers(0, d, size=(n + nt, m)), axis=1)
+for _ in range(50):  # distinct ids inside a row
+    dup = np.zeros_like(idx, dtype=bool)
+    dup[:, 1:] = idx[:, 1:] == idx[:, :-1]
+    if not dup.any():
+        break
+    idx[dup] = rng.integers(0, d, size=int(dup.sum()))
+    idx.sort(axis=1)
+val = rng.uniform(-1.0, 1.0, size=(n + nt, m))
+
+
+class Part:
+    def __init__(self, lo, hi):
+        self.n = hi - lo
+        self.indptr = np.arange(self.n + 1, dtype=np.int64) * m
+        self.indices = np.ascontiguousarray(idx[lo:hi].ravel())
+        self.data = np.ascontiguousarray(val[lo:hi].ravel())
+
+
+Xtr, Xte = Part(0, n), Part(n, n + nt)
 rng = np.random.default_rng(9)
-Pt, wt = rng.standard_normal((1, k, d)) * 0.3, rng.standard_normal(d) * 0.3
-yfull = O.fm_decision_function(full, 2, Pt, wt, 0.1) + 0.1 * rng.standard_normal(n + nt)
-
-
-def sub(lo, hi):
-    a, b = full.indptr[lo], full.indptr[hi]
-    return O.Dataset(full.indptr[lo:hi + 1] - a, full.indices[a:b], full.data[a:b], hi - lo, d)
-
-
-Xtr, Xte, ytr, yte = sub(0, n), sub(n, n + nt), yfull[:n], yfull[n:]
+planted = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True)
+planted.set_params(rng.standard_normal((1, k, d)) * 0.3, rng.standard_normal(d) * 0.3, 0.1)
+Xall_gpu = nf.newCSRDataset(np.concatenate([Xtr.data, Xte.data]), np.concatenate([Xtr.indices, Xte.indices]),
+                            np.arange(n + nt + 1, dtype=np.int64) * m, n + nt, d)
+yfull = planted.decisionFunction(Xall_gpu) + 0.1 * rng.standard_normal(n + nt)
+del planted, Xall_gpu
+ytr, yte = yfull[:n], yfull[n:]
+Xte_gpu = nf.newCSRDataset(Xte.data, Xte.indices, Xte.indptr, nt, d)
 P0, w0 = np.random.default_rng(1).standard_normal((1, k, d)) * 0.01, np.zeros(d)
 
 
 def rmse(P, w, b):
-    return float(np.sqrt(np.mean((O.fm_decision_function(Xte, 2, P, w, b) - yte) ** 2)))
+    fm = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True)
+    fm.set_params(P, w, b)
+    return float(np.sqrt(np.mean((fm.decisionFunction(Xte_gpu) - yte) ** 2)))
 
 
 def make_opt(solver, eta_scale=1.0):
@@ -66,7 +83,7 @@ def ranks(solver, world, S, combine="mean", eta_scale=1.0):
     def body(r):
         try:
             lo, hi = dp.shard_bounds(n, r, world)
-            a, b = Xtr.indptr[lo], Xtr.indptr[hi]
+            a, b = lo * m, hi * m
             X = nf.newCSRDataset(Xtr.data[a:b], Xtr.indices[a:b], Xtr.indptr[lo:hi + 1] - a, hi - lo, d, ctx=ctxs[r])
             fm = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True)
             fm.set_params(P0, w0, 0.0)
@@ -91,18 +108,29 @@ def ranks(solver, world, S, combine="mean", eta_scale=1.0):
 
 
 L0 = rmse(P0, w0, 0.0)
+if len(sys.argv) > 3:  # one row in a process of its own: "solver world S one_rank_value"
+    solver, world, S, one = sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
+    nb = (n // world) // B
+    row = []
+    variants = [("mean", 1.0), ("sum", 1.0)] if solver == "sgd" else [("sum", 1.0), ("state_mean", 1.0)]
+    for combine, es in variants:
+        v = ranks(solver, world, S, combine, es)
+        prog = (L0 - v) / (L0 - one) if np.isfinite(v) else float("nan")
+        row.append("%s %.4f (progress %.2f)" % (combine if solver == "sgd" else ("state-" + combine.replace("state_", "")), v, prog))
+    print("  %d ranks, exchange every %s (%d mini-batches per rank and epoch): %s" % (world, "%d mini-batches" % S if S else "epoch", nb, "; ".join(row)), flush=True)
+    sys.exit(0)
+import subprocess  # noqa: E402
+
 print("planted FM: %d train / %d held-out samples, d=%d, m=%d, k=%d, mini-batch %d, %d epochs, SGD touch cap %g; held-out RMSE at start %.4f"
       % (n, nt, d, m, k, B, E, CAP, L0), flush=True)
 for solver in ("sgd", "adagrad"):
     one = single(solver)
     print("%s: one rank over all samples: %.4f" % (solver, one), flush=True)
     for world in (2, 4, 8):
-        nb = (n // world) // B
         for S in (1, 4, 16, 0):
-            row = []
-            variants = [("mean", 1.0), ("sum", 1.0), ("mean", float(world))] if solver == "sgd" else [("mean", 1.0)]
-            for combine, es in variants:
-                v = ranks(solver, world, S, combine, es)
-                prog = (L0 - v) / (L0 - one) if np.isfinite(v) else float("nan")
-                row.append("%s%s %.4f (progress %.2f)" % (combine if solver == "sgd" else "state-sum", " x%d step" % world if es != 1.0 else "", v, prog))
-            print("  %d ranks, exchange every %s (%d mini-batches per rank and epoch): %s" % (world, "%d mini-batches" % S if S else "epoch", nb, "; ".join(row)), flush=True)
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), str(E), str(CAP), solver, str(world), str(S), repr(one)],
+                                 capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in out.stdout.splitlines() if ln.startswith("  ")]
+            print(lines[-1] if lines else "  %d ranks, S=%d: FAILED rc=%d %s" % (world, S, out.returncode, (out.stderr or "")[-300:]), flush=True)
+            if out.returncode != 0 and "Memory access fault" in (out.stderr or ""):
+                raise SystemExit("GPU fault in %s world=%d S=%d: stopping" % (solver, world, S))
