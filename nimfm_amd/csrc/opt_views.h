@@ -40,7 +40,7 @@ int launch_sequential(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelV
 struct SeqWin {           // kept on the optimizer between calls
   DevBuf prev;            // [nnz] per stored entry: previous position of the call with the same feature
   DevBuf prevq, next;     // [nnz] that feature's entry index in the previous sample's row; next position with the feature
-  DevBuf scales, mail, ctl, fw;
+  DevBuf scales, mail, ctl, fw, trace;
   bool valid = false, had_perm = false;
   uint64_t ds_uid = 0;
   int64_t begin = 0, end = 0, nnz = 0;

@@ -39,7 +39,10 @@
 // (LDS request), W + 1 <= number of CUs: all workgroups are resident, every wait is on a workgroup that is running.
 // Every spin has a wall-clock limit and watches an abort word: a launch always drains.
 #include <hipcub/hipcub.hpp>
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <vector>
 
 #include "fm_device.h"
 #include "opt_views.h"
@@ -66,10 +69,11 @@ struct WinArgs {
   const int32_t* prev;    // [nnz] position (relative to `begin`) of the previous sample of the call with this feature, -1: none
   const uint8_t* prevq;   // [nnz] the feature's entry index in that sample's row (rows of up to 64 entries: the forwarding path)
   const int32_t* next;    // [nnz] position of the next sample of the call with this feature, -1: none
-  ull* fw;                // [W][kFwSlot] forwarding areas: a worker's rows that a near successor waits for
+  ull* fw;                // [W][2][kFwSlot] forwarding areas: the recipes of a worker's rows that a near successor asks for
+  long long* trace;       // debugging (NFM_SEQ_WIN_TRACE=1): [n_seg][8] wall-clock stamps per sample, or null
   const double* scales;   // SGD: [ns][2] {scale_P, scale_w} BEFORE each sample of the call
   ull* fwd;               // [W][2][FW] worker -> conductor
-  ull* res;               // [W][2][2]  conductor -> worker {dL, yhat}
+  ull* res;               // [W][2][4]  conductor -> worker(s): {dL, yhat} as tagged granules
   unsigned* completed;    // [W] samples of this launch a worker has finished
   unsigned* ctrl;         // [0]: abort
   double* partial;        // [W + 1][2] {loss, viol} per worker, last: the conductor's
@@ -80,6 +84,12 @@ __device__ __forceinline__ ull ld_u64(const ull* p) { return __hip_atomic_load(p
 __device__ __forceinline__ void st_u64(ull* p, ull v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a store through an address that was SELECTED between two arrays: the pointer is given its address space explicitly (a
+// select of pointers loses it, and an sc1 store through a flat_ instruction is not the hand-off this kernel relies on)
+typedef __attribute__((address_space(1))) double global_double;
+__device__ __forceinline__ void st_f64_at(unsigned long long addr, double v) {
+  __hip_atomic_store(reinterpret_cast<global_double*>(addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ unsigned ld_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ ull mail_bits(double v) {  // a value as a mailbox word: never the "empty" pattern
@@ -105,6 +115,29 @@ struct Spin {
     return false;
   }
 };
+
+// A forwarded value: two 8-byte granules {32-bit tag, half of the double}; the tag is the writer's sample index + 1, so
+// a granule needs no reset and no flag -- a reader takes the value when both tags are the sample it waits for.
+__device__ __forceinline__ void fw_store(ull* p, unsigned tag, double v) {
+  st_u64(p, ((ull)tag << 32) | (ull)(unsigned)__double2loint(v));
+  st_u64(p + 1, ((ull)tag << 32) | (ull)(unsigned)__double2hiint(v));
+}
+__device__ __forceinline__ bool fw_load(const ull* p, unsigned tag, double& v) {
+  const ull g0 = ld_u64(p), g1 = ld_u64(p + 1);
+  v = __hiloint2double((int)(unsigned)(g1 & 0xffffffffull), (int)(unsigned)(g0 & 0xffffffffull));
+  return (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
+}
+// A worker's forwarding area (one per parity of its sample count): what a successor within W positions needs to form
+// the rows it shares with this sample BY ITSELF as soon as the conductor's dL for this sample lands -- the RECIPE, known
+// at this sample's forward pass, not the result, known only after its update:
+//   [64 lanes]           the per-factor sums a1
+//   [3][64 q][64 lanes]  per hot row: its value as this sample used it; AdaGrad: g_sum and g_norm as loaded
+//   [4][64 q]            per hot entry: linear weight as used, AdaGrad g_sum / g_norm of it, the entry's value
+constexpr int kFwVals = 3;
+constexpr size_t kFwRows = (size_t)kWave * 2;                                    // granules of a1
+constexpr size_t kFwLin = kFwRows + (size_t)kFwVals * kWave * kWave * 2;         // start of the per-entry part
+constexpr size_t kFwSlot = kFwLin + (size_t)4 * kWave * 2;                       // granules per (worker, parity)
+constexpr int kResWords = 4;  // conductor -> worker: {dL, yhat} as tagged granules (several workers may read them)
 
 // ------------------------------------------------------------------------------------------------------------------
 // worker: one wavefront, lanes (r, s) = (row slot, factor), Kp lanes per row, R = 64 / Kp rows per instruction
@@ -145,7 +178,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
     const double itf = (double)it;
     const int par = (int)((u >> lgW) & 1);
     ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
-    ull* rp = a.res + (size_t)(slot * 2 + par) * 2;
+    const ull* rp = a.res + (size_t)(slot * 2 + par) * kResWords;
     for (int q = lane; q < m; q += kWave) {
       jl[q] = X.indices[q0 + q];
       vl[q] = X.data[q0 + q];
@@ -296,17 +329,16 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       swn = sw * (1 - eta_w * O.alpha);
     }
 
-    // ---- E. {dL, yhat} from the conductor ----
+    // ---- E. {dL, yhat} from the conductor (tagged granules) ----
     double dL, yh;
     {
       Spin sp;
-      ull rv;
+      double rd;
       while (true) {
-        rv = ld_u64(rp + (lane & 1));
-        if (__all(rv != kWinSentinel)) break;
+        const bool ok = fw_load(rp + (size_t)(lane & 1) * 2, (unsigned)(u + 1), rd);
+        if (__all(ok)) break;
         if (sp.wait(a.ctrl)) return;
       }
-      const double rd = __longlong_as_double((long long)rv);
       dL = dev::shfl_d(rd, 0);
       yh = dev::shfl_d(rd, 1);
     }
@@ -314,7 +346,6 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
     // completed (vmcnt(0) below) before this worker posts its next sample, which the conductor consumes before it can
     // look at these words again (kWinDepth < W)
     for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);
-    if (lane < 2) st_u64(rp + lane, kWinSentinel);
     if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
 
     // ---- F. update(): sgd.nim:205-243 / updateG(): adagrad.nim:113-134 ----
@@ -441,6 +472,7 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
         }
         lds_fence();  // LDS operations of a wavefront execute in order: data, then the counter
         if (lane == 0) ldsv_store(c_ready, (unsigned)(u + 1));
+        if (a.trace && lane == 0) a.trace[u * 8 + 5] = wall_clock64();  // mailbox fetched
         if (u + kWinDepth < n) issue(dd, u + kWinDepth);
       }
     }
@@ -493,6 +525,7 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
     return true;
   };
   auto step = [&](int64_t u, const Terms& T) {
+    if (a.trace && lane == 0) a.trace[u * 8 + 6] = wall_clock64();  // chain starts
     const double tot = T.h01.x, y = T.h01.y, h2 = T.h2;
     const int64_t it = a.it0 + u;
     if (ADA && it != 1 && M.fit_intercept) {  // adagrad.nim:101-106
@@ -545,10 +578,15 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
       }
     }
     const int slot = (int)(u & (W - 1)), par = (int)((u >> lgW) & 1);
-    ull* rp = a.res + (size_t)(slot * 2 + par) * 2;
-    if (lane < 2) st_u64(rp + lane, mail_bits(lane == 0 ? dL : yh));
+    ull* rp = a.res + (size_t)(slot * 2 + par) * kResWords;
+    if (lane < kResWords) {  // {dL, yhat} as granules tagged with the sample: its worker and near successors read them
+      const double v = lane < 2 ? dL : yh;
+      const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+      st_u64(rp + lane, ((ull)(unsigned)(u + 1) << 32) | (ull)half);
+    }
     lds_fence();  // the ring slot has been read
     if (lane == 0) ldsv_store(c_consumed, (unsigned)(u + 1));
+    if (a.trace && lane == 0) a.trace[u * 8 + 7] = wall_clock64();  // answer posted
   };
   Terms A, B;
   bool haveA = false, haveB = false;
@@ -600,20 +638,6 @@ __device__ __forceinline__ double div_by(double a, double b, double y /* = 1 / b
   return fma(e1, y, q1);
 }
 
-// A forwarded value: two 8-byte granules {32-bit tag, half of the double}; the tag is the writer's sample index + 1, so
-// a granule needs no reset and no flag -- a reader takes the value when both tags are the sample it waits for.
-__device__ __forceinline__ void fw_store(ull* p, unsigned tag, double v) {
-  st_u64(p, ((ull)tag << 32) | (ull)(unsigned)__double2loint(v));
-  st_u64(p + 1, ((ull)tag << 32) | (ull)(unsigned)__double2hiint(v));
-}
-__device__ __forceinline__ bool fw_load(const ull* p, unsigned tag, double& v) {
-  const ull g0 = ld_u64(p), g1 = ld_u64(p + 1);
-  v = __hiloint2double((int)(unsigned)(g1 & 0xffffffffull), (int)(unsigned)(g0 & 0xffffffffull));
-  return (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
-}
-constexpr int kFwVals = 3;                                             // per row: stored P, (AdaGrad) g_sum, g_norm
-constexpr size_t kFwSlot = (size_t)kFwVals * (kWave * kWave + kWave) * 2;  // granules per worker: rows, then the linear terms
-
 template <int OPT>
 __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot, double* lds) {
   const CsrView& X = a.X;
@@ -631,9 +655,10 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
   for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
   double loss_acc = 0.0, viol_acc = 0.0;
   double Pr[K];
-  ull* fw_base = a.fw + (size_t)slot * kFwSlot;
-  auto fw_row = [&](ull* base, int v, int q) { return base + ((size_t)(v * K + q) * K + lane) * 2; };
-  auto fw_lin = [&](ull* base, int v, int q) { return base + (size_t)kFwVals * K * K * 2 + (size_t)(v * K + q) * 2; };
+  auto fw_area = [&](int64_t u_) { return a.fw + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kFwSlot; };
+  auto fw_row = [&](ull* base, int v, int q) { return base + kFwRows + ((size_t)(v * K + q) * K + lane) * 2; };
+  auto fw_lin = [&](ull* base, int v, int q) { return base + kFwLin + (size_t)(v * K + q) * 2; };
+  auto res_of = [&](int64_t u_) { return a.res + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kResWords; };
 
   for (int64_t u = slot; u < a.n_seg; u += W) {
     const int64_t pos = a.seg0 + u, pa = a.begin + pos;
@@ -645,7 +670,6 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     const double itf = (double)it;
     const int par = (int)((u >> lgW) & 1);
     ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
-    ull* rp = a.res + (size_t)(slot * 2 + par) * 2;
     int jq = 0, pq = -1, pqu = 0, nq = -1;
     double vq = 0.0;
     if (lane < m) {
@@ -667,12 +691,13 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       return v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW);
     };
     compiler_fence();
-    // entries whose previous sample is not known to be finished: a NEAR one (fewer than W positions back) hands its new
-    // row over directly (it wrote it to its forwarding area first of all); a far one is waited for by its counter
+    // entries whose previous sample is not known to be finished: a NEAR one (fewer than W positions back) left the recipe
+    // of the shared row in its forwarding area; a far one is waited for by its counter
     const bool pend = pending(), near = pend && (pos - (int64_t)pq) < W;
     const ull fwdmask = __ballot(near), farmask = __ballot(pend && !near), latemask = fwdmask | farmask;
+    if (a.trace && lane == 0) a.trace[u * 8 + 0] = wall_clock64();  // sample taken up
     const bool late = (latemask >> lane) & 1ull;
-    // the next sample with one of this sample's features within W positions will ask for that row
+    // the next sample with one of this sample's features within W positions will ask for that row's recipe
     const ull hotmask = __ballot(nq >= 0 && ((int64_t)nq - pos) < W);
     // step sizes first: nothing below waits for them
     const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
@@ -709,9 +734,11 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       return nv;
     };
     if constexpr (!ADA) {
+      // no branch per row anywhere on the hot path: a row past the sample's end is feature 0's row with value 0 (its terms
+      // are +0.0: they change no sum), its store goes to a scratch row -- per-row uniform branches made the compiler keep 64
+      // predicates as spilled masks and wait for ALL memory at every row
 #pragma unroll
-      for (int q = 0; q < K; ++q)
-        if (q < m) Pr[q] = ld_f64(M.P + (size_t)readlane_i(jq, q) * K + lane);
+      for (int q = 0; q < K; ++q) Pr[q] = ld_f64(M.P + (size_t)readlane_i(jq, q) * K + lane);
       if (lane < m) wv = ld_f64(M.w + jq);
     } else {
 #pragma unroll
@@ -732,6 +759,9 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
             Gl[(qb + t) * K + lane] = g_[t];
             Nl[(qb + t) * K + lane] = n_[t];
           }
+        } else {  // (the sums below run over all 64 slots: x 0 must meet a number)
+#pragma unroll
+          for (int t = 0; t < 8; ++t) Pr[qb + t] = 0.0;
         }
       }
       if (lane < m) {
@@ -769,47 +799,114 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
         }
       }
     }
-    // ---- C. near dependencies: the writer's forwarding area, polled until it carries the writer's tag ----
+    // ---- C. near dependencies: the writer's recipe + the conductor's dL for the writer's sample -> the row as the writer
+    // will (or did) write it, formed here with the writer's own arithmetic ----
     if (fwdmask) {
-      for (ull mk = fwdmask; mk; mk &= mk - 1) {
-        const int q = __builtin_ctzll(mk);
+      // Everything the recipes hold was posted at the writers' forward passes, long ago: it is requested FIRST (the
+      // shared entries' lanes: their entry's part; all lanes: the first shared row's part), the poll for the writers' dL
+      // runs while those loads are in flight, and only then are the recipes' tags looked at.
+      const bool mine = (fwdmask >> lane) & 1ull;
+      const int64_t upl = (int64_t)pq - a.seg0;
+      const unsigned tagl = (unsigned)(upl + 1);
+      ull* srcl = fw_area(mine ? upl : 0);
+      const ull* rsrcl = res_of(mine ? upl : 0);
+      double wu = 0.0, gwu = 0.0, nwu = 0.0, vsl = 0.0, dLl = 0.0;
+      bool okl = true;
+      auto load_lin = [&]() {
+        okl = true;
+        if (mine) {
+          okl = fw_load(fw_lin(srcl, 0, pqu), tagl, wu);
+          if (ADA && M.fit_linear) {
+            okl = fw_load(fw_lin(srcl, 1, pqu), tagl, gwu) && okl;
+            okl = fw_load(fw_lin(srcl, 2, pqu), tagl, nwu) && okl;
+          }
+          okl = fw_load(fw_lin(srcl, 3, pqu), tagl, vsl) && okl;
+        }
+      };
+      const int q_first = __builtin_ctzll(fwdmask);
+      double a1u, pv, gv = 0.0, nv = 0.0;
+      bool okr = true;
+      auto load_row = [&](int q) {
         const int64_t up = (int64_t)readlane_i(pq, q) - a.seg0;
         const unsigned tag = (unsigned)(up + 1);
-        ull* src = a.fw + (size_t)(up & (W - 1)) * kFwSlot;
+        ull* src = fw_area(up);
         const int qu = readlane_i(pqu, q);
+        okr = fw_load(src + (size_t)lane * 2, tag, a1u);
+        okr = fw_load(fw_row(src, 0, qu), tag, pv) && okr;
+        if constexpr (ADA) {
+          okr = fw_load(fw_row(src, 1, qu), tag, gv) && okr;
+          okr = fw_load(fw_row(src, 2, qu), tag, nv) && okr;
+        }
+      };
+      load_lin();
+      load_row(q_first);
+      // the writers' scales and step sizes (functions of their step counters alone) while those loads are in flight
+      double sPul = 1.0, etaPul = 0.0, sPnul = 1.0, swul = 1.0, etawul = 0.0;
+      if constexpr (!ADA) {
+        if (mine) {
+          sPul = a.scales[2 * (a.seg0 + upl)];
+          swul = a.scales[2 * (a.seg0 + upl) + 1];
+          etaPul = dev::get_eta(O.sched, O.eta0, O.power, O.beta, (double)(a.it0 + upl));
+          etawul = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, (double)(a.it0 + upl));
+          sPnul = sPul * (1 - etaPul * O.beta);
+        }
+      }
+      const double rynul = 1.0 / sPnul;
+      {
+        // one loop: the dL of the writers, and -- as long as they do not carry the writers' tags yet (this worker may have
+        // arrived before the writers' forward passes) -- the recipes again, so that they are in hand when dL lands
         Spin sp;
-        double pv, gv = 0.0, nv = 0.0;
         while (true) {
-          bool ok = fw_load(fw_row(src, 0, qu), tag, pv);
-          if constexpr (ADA) {
-            ok = fw_load(fw_row(src, 1, qu), tag, gv) && ok;
-            ok = fw_load(fw_row(src, 2, qu), tag, nv) && ok;
-          }
+          bool ok = true;
+          if (mine) ok = fw_load(rsrcl, tagl, dLl);
+          if (!__all(okl)) load_lin();
+          if (!__all(okr)) load_row(q_first);
           if (__all(ok)) break;
           if (sp.wait(a.ctrl)) return;
         }
-        Fl[q * K + lane] = pv;
-        if constexpr (ADA) {
-          Gl[q * K + lane] = gv;
-          Nl[q * K + lane] = nv;
+      }
+      if (a.trace && lane == 0) a.trace[u * 8 + 0] = wall_clock64();  // (tracing: the writers' dL seen)
+      {
+        Spin sp;
+        while (!__all(okl)) {
+          if (sp.wait(a.ctrl)) return;
+          load_lin();
         }
       }
-      const bool mine = (fwdmask >> lane) & 1ull;
-      const int64_t up = (int64_t)pq - a.seg0;
-      const unsigned tag = (unsigned)(up + 1);
-      ull* src = a.fw + (size_t)(mine ? (up & (W - 1)) : 0) * kFwSlot;
-      Spin sp;
-      while (true) {
-        bool ok = true;
-        if (mine) {
-          ok = fw_load(fw_lin(src, 0, pqu), tag, wv);
-          if (ADA && M.fit_linear) {
-            ok = fw_load(fw_lin(src, 1, pqu), tag, gwr) && ok;
-            ok = fw_load(fw_lin(src, 2, pqu), tag, nwr) && ok;
+      for (ull mk = fwdmask; mk; mk &= mk - 1) {
+        const int q = __builtin_ctzll(mk);
+        const double vsu = readlane_d(vsl, q), dLu = readlane_d(dLl, q);
+        if (q != q_first) load_row(q);
+        Spin sp;
+        while (!__all(okr)) {
+          if (sp.wait(a.ctrl)) return;
+          load_row(q);
+        }
+        if constexpr (ADA) {  // the writer's updateG of this row (adagrad.nim:113-134)
+          const double grad = dLu * (vsu * (a1u - pv * vsu));
+          Fl[q * K + lane] = pv;
+          Gl[q * K + lane] = gv + grad;
+          Nl[q * K + lane] = nv + grad * grad;
+        } else {  // the writer's update() of this row (sgd.nim:217-223), with ITS scale and step size
+          const double sPu = readlane_d(sPul, q), etaPu = readlane_d(etaPul, q), sPnu = readlane_d(sPnul, q);
+          const double p = sPu * pv;
+          const double update = etaPu * (dLu * (vsu * (a1u - p * vsu)) + O.beta * p);
+          const bool oddu = (__double_as_longlong(sPnu) & 0xFFFFFFFFFFFFFll) == 0xFFFFFFFFFFFFFll;
+          Fl[q * K + lane] = oddu ? (p - update) / sPnu : div_by(p - update, sPnu, readlane_d(rynul, q));
+        }
+      }
+      if (mine) {
+        wv = wu;
+        if (M.fit_linear) {
+          if constexpr (ADA) {
+            const double gg = dLl * vsl;
+            gwr = gwu + gg;
+            nwr = nwu + gg * gg;
+          } else {  // fit_linear.nim:41-47 with the writer's scale and step size
+            const double wj = swul * wu;
+            wv = (wj - etawul * (dLl * vsl + O.alpha * wj)) / (swul * (1 - etawul * O.alpha));
           }
         }
-        if (__all(ok)) break;
-        if (sp.wait(a.ctrl)) return;
       }
     }
     if (latemask) {
@@ -823,14 +920,44 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       }
       if (ADA && M.fit_linear && late) wv = ada_lin(wv, gwr, nwr);
     }
+    if (a.trace && lane == 0) a.trace[u * 8 + 1] = wall_clock64();  // dependencies resolved
     // ---- D. per-factor sums over the entries in storage order, their sum over the factors in ascending order ----
     double a1 = 0.0, a2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < K; ++q) {
-      if (q < m) {
-        const double t = readlane_d(vq, q) * (sP * Pr[q]);
-        a1 += t;
-        a2 += t * t;
+    for (int q = 0; q < K; ++q) {  // (entries past the end have value 0: + 0.0)
+      const double t = readlane_d(vq, q) * (sP * Pr[q]);
+      a1 += t;
+      a2 += t * t;
+    }
+    const unsigned mytag = (unsigned)(u + 1);
+    if (hotmask) {  // the recipes of the rows a near successor shares (the base is made opaque per use: left to itself the
+                    // compiler hoists the 192 row addresses out of the sample loop and spills them)
+      // (an opaque OFFSET, not an opaque pointer: the address must stay provably global -- sc1 through flat_ instructions
+      // is not the hand-off this kernel relies on)
+      size_t fwo = ((size_t)(u & (W - 1)) * 2 + (size_t)((u >> lgW) & 1)) * kFwSlot;
+      asm volatile("" : "+s"(fwo));
+      ull* fwm = a.fw + fwo;
+      fw_store(fwm + (size_t)lane * 2, mytag, a1);
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        if (q < m && ((hotmask >> q) & 1ull)) {
+          size_t fqo = ((size_t)(u & (W - 1)) * 2 + (size_t)((u >> lgW) & 1)) * kFwSlot;
+          asm volatile("" : "+s"(fqo));
+          ull* fq_ = a.fw + fqo;
+          fw_store(fw_row(fq_, 0, q), mytag, Pr[q]);
+          if constexpr (ADA) {
+            fw_store(fw_row(fq_, 1, q), mytag, Gl[q * K + lane]);
+            fw_store(fw_row(fq_, 2, q), mytag, Nl[q * K + lane]);
+          }
+        }
+      }
+      if ((hotmask >> lane) & 1ull) {
+        fw_store(fw_lin(fwm, 0, lane), mytag, wv);
+        if constexpr (ADA) {
+          fw_store(fw_lin(fwm, 1, lane), mytag, gwr);
+          fw_store(fw_lin(fwm, 2, lane), mytag, nwr);
+        }
+        fw_store(fw_lin(fwm, 3, lane), mytag, vq);
       }
     }
     const double kv = (a1 * a1 - a2) / 2;
@@ -855,67 +982,25 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     }
     if (lane < MC) st_u64(mb + lane, mail_bits(lane < m ? (sw * wv) * vq : -0.0));
     if (lane < kWinHdr) st_u64(mb + MC + lane, mail_bits(lane == 0 ? tot : lane == 1 ? y : lane == 2 ? h2 : 0.0));
+    if (a.trace && lane == 0) a.trace[u * 8 + 2] = wall_clock64();  // mailbox posted
 
-    // ---- E. {dL, yhat} from the conductor ----
+    // ---- E. {dL, yhat} from the conductor: tagged granules (a near successor reads them too) ----
     double dL, yh;
     {
+      const ull* rp = res_of(u);
       Spin sp;
-      ull rv;
+      double rd;
       while (true) {
-        rv = ld_u64(rp + (lane & 1));
-        if (__all(rv != kWinSentinel)) break;
+        const bool ok = fw_load(rp + (size_t)(lane & 1) * 2, mytag, rd);
+        if (__all(ok)) break;
         if (sp.wait(a.ctrl)) return;
       }
-      const double rd = __longlong_as_double((long long)rv);
       dL = readlane_d(rd, 0);
       yh = readlane_d(rd, 1);
     }
+    if (a.trace && lane == 0) a.trace[u * 8 + 3] = wall_clock64();  // dL received
 
-    // ---- F. update(): sgd.nim:205-243 / updateG(): adagrad.nim:113-134; the rows somebody is about to ask for first ----
-    const unsigned mytag = (unsigned)(u + 1);
-    // (the forwarding area's base is made opaque per sample and per use: left to itself the compiler hoists the 192
-    // row addresses out of the sample loop and spills them)
-    auto row_step = [&](int q, double prq, bool hot) {
-      ull* fw_mine = fw_base;
-      asm volatile("" : "+s"(fw_mine));
-      const size_t e = (size_t)readlane_i(jq, q) * K + lane;
-      const double vs = readlane_d(vq, q);
-      const double p = sP * prq;
-      const double d_ = vs * (a1 - p * vs);
-      if constexpr (ADA) {
-        const double grad = dL * d_;
-        const double gn = Gl[q * K + lane] + grad, nn = Nl[q * K + lane] + grad * grad;
-        if (hot) {
-          fw_store(fw_row(fw_mine, 0, q), mytag, prq);
-          fw_store(fw_row(fw_mine, 1, q), mytag, gn);
-          fw_store(fw_row(fw_mine, 2, q), mytag, nn);
-        }
-        st_f64(O.G + e, gn);
-        st_f64(O.N + e, nn);
-      } else {
-        const double update = eta_P * (dL * d_ + O.beta * p);
-        viol_acc += fabs(update);
-        const double nv = div_by(p - update, sPn, ry);
-        if (hot) fw_store(fw_row(fw_mine, 0, q), mytag, nv);
-        st_f64(M.P + e, nv);
-      }
-    };
-    double w_new = 0.0, gw_new = 0.0, nw_new = 0.0;
-    if (M.fit_linear && lane < m) {
-      if constexpr (ADA) {
-        const double gg = dL * vq;
-        gw_new = gwr + gg;
-        nw_new = nwr + gg * gg;
-        w_new = wv;
-      } else {
-        const double wj = sw * wv;
-        const double update = eta_w * (dL * vq + O.alpha * wj);
-        viol_acc += fabs(update);
-        w_new = (wj - update) / swn;
-      }
-    } else {
-      w_new = wv;
-    }
+    // ---- F. update(): sgd.nim:205-243 / updateG(): adagrad.nim:113-134 ----
     if (!ADA && odd_divisor) {
       // a divisor with an all-ones significand (one sample in 2^52): the division instruction, rows through LDS
 #pragma unroll
@@ -927,52 +1012,50 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
         const double p = sP * Fl[q * K + lane];
         const double update = eta_P * (dL * (vs * (a1 - p * vs)) + O.beta * p);
         viol_acc += fabs(update);
-        const double nv = (p - update) / sPn;
-        if ((hotmask >> q) & 1ull) fw_store(fw_row(fw_base, 0, q), mytag, nv);
-        st_f64(M.P + e, nv);
+        st_f64(M.P + e, (p - update) / sPn);
       }
-    } else if (hotmask) {
+    } else {
+      double* const junk = reinterpret_cast<double*>(a.fw + (size_t)2 * W * kFwSlot) + (size_t)slot * 2 * K + lane;  // scratch rows
 #pragma unroll
-      for (int q = 0; q < K; ++q)
-        if (q < m && ((hotmask >> q) & 1ull)) row_step(q, Pr[q], true);
-    }
-    if (hotmask) {
-      ull* fw_mine = fw_base;
-      asm volatile("" : "+s"(fw_mine));
-      if ((hotmask >> lane) & 1ull) {
-        fw_store(fw_lin(fw_mine, 0, lane), mytag, w_new);
+      for (int q = 0; q < K; ++q) {
+        const bool in = q < m;
+        const size_t e = (size_t)readlane_i(jq, q) * K + lane;
+        const double vs = readlane_d(vq, q);
+        const double p = sP * Pr[q];
+        const double d_ = vs * (a1 - p * vs);
         if constexpr (ADA) {
-          fw_store(fw_lin(fw_mine, 1, lane), mytag, gw_new);
-          fw_store(fw_lin(fw_mine, 2, lane), mytag, nw_new);
+          const double grad = dL * d_;
+          st_f64_at(in ? (ull)(O.G + e) : (ull)junk, Gl[q * K + lane] + grad);
+          st_f64_at(in ? (ull)(O.N + e) : (ull)(junk + K), Nl[q * K + lane] + grad * grad);
+        } else {
+          const double update = eta_P * (dL * d_ + O.beta * p);
+          viol_acc += in ? fabs(update) : 0.0;
+          st_f64_at(in ? (ull)(M.P + e) : (ull)junk, div_by(p - update, sPn, ry));
         }
       }
     }
-#pragma unroll
-    for (int q = 0; q < K; ++q) asm volatile("" : "+v"(Pr[q]));
-    asm volatile("" : "+v"(vq), "+v"(jq));
-    if (ADA || !odd_divisor) {
-#pragma unroll
-      for (int q = 0; q < K; ++q)
-        if (q < m && !((hotmask >> q) & 1ull)) row_step(q, Pr[q], false);
-    }
     if (M.fit_linear && lane < m) {
       if constexpr (ADA) {
-        st_f64(O.Gw + jq, gw_new);
-        st_f64(O.Nw + jq, nw_new);
+        const double gg = dL * vq;
+        st_f64(O.Gw + jq, gwr + gg);
+        st_f64(O.Nw + jq, nwr + gg * gg);
       } else {
-        st_f64(M.w + jq, w_new);
+        const double wj = sw * wv;
+        const double update = eta_w * (dL * vq + O.alpha * wj);
+        viol_acc += fabs(update);
+        st_f64(M.w + jq, (wj - update) / swn);
       }
     }
-    // both mailboxes back to "empty" for their next use, two samples of this worker from now: these stores have
-    // completed (vmcnt(0) below) before this worker posts its next sample, which the conductor consumes before it can
-    // look at these words again (kWinDepth < W)
+    // the mailbox back to "empty" for its next use, two samples of this worker from now: these stores have completed
+    // (vmcnt(0) below) before this worker posts its next sample, which the conductor consumes before it can look at
+    // these words again (kWinDepth < W)
     if (lane < a.FW) st_u64(mb + lane, kWinSentinel);
     if (lane < a.FW - kWave) st_u64(mb + kWave + lane, kWinSentinel);
-    if (lane < 2) st_u64(rp + lane, kWinSentinel);
     if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
     // ---- G. rows written: tell the far waiters ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
+    if (a.trace && lane == 0) a.trace[u * 8 + 4] = wall_clock64();  // rows written
   }
   viol_acc = dev::wave_sum(viol_acc);
   if (lane == 0) {
@@ -1252,7 +1335,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     sw->end = end;
     sw->nnz = X.nnz;
   }
-  const size_t n_fwd = (size_t)W * 2 * FW, n_res = (size_t)W * 2 * 2;
+  const size_t n_fwd = (size_t)W * 2 * FW, n_res = (size_t)W * 2 * kResWords;
   NFM_TRY(sw->mail.ensure(sizeof(ull) * (n_fwd + n_res)));
   NFM_TRY(sw->ctl.ensure(sizeof(unsigned) * (W + 64) + sizeof(double) * 2 * (W + 1) + sizeof(int64_t) * 2));
   if (!ada) NFM_TRY(sw->scales.ensure(sizeof(double) * 2 * (size_t)ns));
@@ -1265,8 +1348,14 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   a.prev = sw->prev.as<int32_t>();
   a.prevq = sw->prevq.as<uint8_t>();
   a.next = sw->next.as<int32_t>();
-  NFM_TRY(sw->fw.ensure(sizeof(ull) * kFwSlot * (size_t)W));
+  NFM_TRY(sw->fw.ensure(sizeof(ull) * (kFwSlot * 2 + 2 * kWave) * (size_t)W));  // + two scratch rows per worker
   a.fw = sw->fw.as<ull>();
+  a.trace = nullptr;
+  if (getenv("NFM_SEQ_WIN_TRACE") && atoi(getenv("NFM_SEQ_WIN_TRACE")) != 0) {  // debugging: stamps of the first launch's samples
+    NFM_TRY(sw->trace.ensure(sizeof(long long) * 8 * (size_t)ns));
+    NFM_HIP_CHECK(hipMemsetAsync(sw->trace.p, 0, sizeof(long long) * 8 * (size_t)ns, st));
+    a.trace = sw->trace.as<long long>();
+  }
   a.scales = ada ? nullptr : sw->scales.as<double>();
   a.fwd = sw->mail.as<ull>();
   a.res = a.fwd + n_fwd;
@@ -1300,9 +1389,10 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     // mailboxes empty, counters and abort word zero
     {
       NFM_HIP_CHECK(hipMemsetAsync(sw->ctl.p, 0, sizeof(unsigned) * (W + 64) + sizeof(double) * 2 * (W + 1), st));
-      if (k64) NFM_HIP_CHECK(hipMemsetAsync(sw->fw.p, 0, sizeof(ull) * kFwSlot * (size_t)W, st));  // tag 0: nobody's
-      const int64_t nm = (int64_t)(n_fwd + n_res);
+      if (k64) NFM_HIP_CHECK(hipMemsetAsync(sw->fw.p, 0, sizeof(ull) * kFwSlot * 2 * (size_t)W, st));  // tag 0: nobody's
+      const int64_t nm = (int64_t)n_fwd;  // the workers' mailboxes "empty"; the conductor's answers carry tags (0: nobody's)
       hipLaunchKernelGGL(k_win_fill, dim3((unsigned)((nm + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sw->mail.as<ull>(), nm, kWinSentinel);
+      NFM_HIP_CHECK(hipMemsetAsync(sw->mail.as<ull>() + n_fwd, 0, sizeof(ull) * n_res, st));
     }
     a.seg0 = pos;
     a.n_seg = last - pos + 1;
@@ -1320,6 +1410,15 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     NFM_HIP_CHECK(hipMemcpyAsync(&aborted, a.ctrl, sizeof(aborted), hipMemcpyDeviceToHost, st));
     NFM_HIP_CHECK(hipStreamSynchronize(st));
     NFM_CHECK(aborted == 0, NFM_ERR_HIP, "the dependency-window kernel gave up waiting (a workgroup was not resident or a hand-off was lost)");
+    if (a.trace) {  // debugging: the stamps go to a file (100 MHz ticks: taken up, deps, posted, dL, written | fetched, chain, answered)
+      std::vector<long long> h((size_t)8 * a.n_seg);
+      NFM_HIP_CHECK(hipMemcpy(h.data(), a.trace, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+      const char* path = getenv("NFM_SEQ_WIN_TRACE_FILE") ? getenv("NFM_SEQ_WIN_TRACE_FILE") : "/tmp/seqwin_trace.bin";
+      if (FILE* f = fopen(path, "wb")) {
+        fwrite(h.data(), sizeof(long long), h.size(), f);
+        fclose(f);
+      }
+    }
     pos = last + 1;
   }
   NFM_HIP_CHECK(hipGetLastError());
