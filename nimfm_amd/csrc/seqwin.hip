@@ -930,6 +930,30 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       a2 += t * t;
     }
     const unsigned mytag = (unsigned)(u + 1);
+    const double kv = (a1 * a1 - a2) / 2;
+    red[lane] = lane < k ? kv : 0.0;  // (never -0.0: adding the padding changes nothing)
+    compiler_fence();
+    // what the update needs of a row (scale x stored value, the entry's value, its address) is formed again there: kept
+    // alive from here, 64 rows' worth of it would not fit the registers
+#pragma unroll
+    for (int q = 0; q < K; ++q) asm volatile("" : "+v"(Pr[q]));
+    asm volatile("" : "+v"(vq), "+v"(jq));
+    double tot = 0.0;
+#pragma unroll
+    for (int tb = 0; tb < K / 2; tb += 8) {  // 16 values requested together (the rows keep 128 registers)
+      double2 r_[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) r_[t] = *reinterpret_cast<const double2*>(red + 2 * (tb + t));
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        tot += r_[t].x;
+        tot += r_[t].y;
+      }
+    }
+    if (lane < MC) st_u64(mb + lane, mail_bits(lane < m ? (sw * wv) * vq : -0.0));
+    if (lane < kWinHdr) st_u64(mb + MC + lane, mail_bits(lane == 0 ? tot : lane == 1 ? y : lane == 2 ? h2 : 0.0));
+    if (a.trace && lane == 0) a.trace[u * 8 + 2] = wall_clock64();  // mailbox posted
+    // (after the mailbox: a successor needs them together with this sample's dL, which the conductor forms from the mailbox)
     if (hotmask) {  // the recipes of the rows a near successor shares (the base is made opaque per use: left to itself the
                     // compiler hoists the 192 row addresses out of the sample loop and spills them)
       // (an opaque OFFSET, not an opaque pointer: the address must stay provably global -- sc1 through flat_ instructions
@@ -960,29 +984,6 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
         fw_store(fw_lin(fwm, 3, lane), mytag, vq);
       }
     }
-    const double kv = (a1 * a1 - a2) / 2;
-    red[lane] = lane < k ? kv : 0.0;  // (never -0.0: adding the padding changes nothing)
-    compiler_fence();
-    // what the update needs of a row (scale x stored value, the entry's value, its address) is formed again there: kept
-    // alive from here, 64 rows' worth of it would not fit the registers
-#pragma unroll
-    for (int q = 0; q < K; ++q) asm volatile("" : "+v"(Pr[q]));
-    asm volatile("" : "+v"(vq), "+v"(jq));
-    double tot = 0.0;
-#pragma unroll
-    for (int tb = 0; tb < K / 2; tb += 8) {  // 16 values requested together (the rows keep 128 registers)
-      double2 r_[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) r_[t] = *reinterpret_cast<const double2*>(red + 2 * (tb + t));
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        tot += r_[t].x;
-        tot += r_[t].y;
-      }
-    }
-    if (lane < MC) st_u64(mb + lane, mail_bits(lane < m ? (sw * wv) * vq : -0.0));
-    if (lane < kWinHdr) st_u64(mb + MC + lane, mail_bits(lane == 0 ? tot : lane == 1 ? y : lane == 2 ? h2 : 0.0));
-    if (a.trace && lane == 0) a.trace[u * 8 + 2] = wall_clock64();  // mailbox posted
 
     // ---- E. {dL, yhat} from the conductor: tagged granules (a near successor reads them too) ----
     double dL, yh;
