@@ -150,8 +150,11 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
   constexpr bool ADA = OPT == OPT_ADAGRAD;
   constexpr int U = 4;  // rows a lane requests together
   const int lane = threadIdx.x;
-  const int Kp = M.Kp, lgK = a.lgKp, k = M.k, mc = a.m_cap;
+  const int Kp = M.Kp, lgK = a.lgKp, k = M.k;
   const int R = kWave >> lgK, r = lane >> lgK, s = lane & (Kp - 1);
+  // rows are handled R * U at a time WITHOUT a branch per row (a row past the sample's end: feature 0's row with value 0,
+  // its stores go to a scratch row): the per-sample arrays are padded to whole groups
+  const int mc = (a.m_cap + R * U - 1) / (R * U) * (R * U);
   const int W = a.W, lgW = a.lgW;
   double* Pl = lds;                                   // [mc][Kp] stored parameter values of the sample's rows
   double* Tl = Pl + (size_t)mc * Kp;                  // [mc][Kp] x_q p_qs, then the derivative
@@ -179,12 +182,14 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
     const int par = (int)((u >> lgW) & 1);
     ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
     const ull* rp = a.res + (size_t)(slot * 2 + par) * kResWords;
-    for (int q = lane; q < m; q += kWave) {
-      jl[q] = X.indices[q0 + q];
-      vl[q] = X.data[q0 + q];
-      pl[q] = a.prev[q0 + q];
+    for (int q = lane; q < mc; q += kWave) {
+      const bool in = q < m;
+      jl[q] = in ? X.indices[q0 + q] : 0;
+      vl[q] = in ? X.data[q0 + q] : 0.0;
+      pl[q] = in ? a.prev[q0 + q] : -1;
     }
     compiler_fence();
+    double* const junk = reinterpret_cast<double*>(a.fw + (size_t)2 * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
 
     // ---- A. every earlier sample of this launch that shares a feature has written its rows ----
     {
@@ -216,10 +221,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       double v_[U], g_[ADA ? U : 1], n_[ADA ? U : 1];
       int j_[U];
 #pragma unroll
-      for (int t = 0; t < U; ++t) {
-        const int q = qb + t * R + r;
-        j_[t] = jl[q < m ? q : 0];
-      }
+      for (int t = 0; t < U; ++t) j_[t] = jl[qb + t * R + r];  // (0 past the end)
 #pragma unroll
       for (int t = 0; t < U; ++t) {
         const size_t e = (size_t)j_[t] * Kp + s;
@@ -232,20 +234,19 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
 #pragma unroll
       for (int t = 0; t < U; ++t) {
         const int q = qb + t * R + r;
-        if (q < m) {
-          double p = v_[t];
-          if constexpr (ADA) {
-            if (it != 1) {
-              p = dev::adagrad_param(g_[t], n_[t], O.eta0, tmpP);
-              viol_acc += fabs(v_[t] - p);
-              st_f64(M.P + (size_t)j_[t] * Kp + s, p);
-            }
-            Gl[(size_t)q * Kp + s] = g_[t];
-            Nl[(size_t)q * Kp + s] = n_[t];
+        const bool in = q < m;
+        double p = v_[t];
+        if constexpr (ADA) {
+          if (it != 1) {
+            p = dev::adagrad_param(g_[t], n_[t], O.eta0, tmpP);
+            viol_acc += in ? fabs(v_[t] - p) : 0.0;
+            st_f64_at(in ? (ull)(M.P + (size_t)j_[t] * Kp + s) : (ull)junk, p);
           }
-          Pl[(size_t)q * Kp + s] = p;
-          Tl[(size_t)q * Kp + s] = vl[q] * (sP * p);
+          Gl[(size_t)q * Kp + s] = g_[t];
+          Nl[(size_t)q * Kp + s] = n_[t];
         }
+        Pl[(size_t)q * Kp + s] = p;
+        Tl[(size_t)q * Kp + s] = vl[q] * (sP * p);
       }
     }
     for (int q = lane; q < m; q += kWave) {
@@ -314,11 +315,9 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
 #pragma unroll
       for (int t = 0; t < U; ++t) {
         const int q = qb + t * R + r;
-        if (q < m) {
-          const double val = vl[q];
-          const double p = sP * Pl[(size_t)q * Kp + s];
-          Tl[(size_t)q * Kp + s] = val * (a1 - p * val);
-        }
+        const double val = vl[q];
+        const double p = sP * Pl[(size_t)q * Kp + s];
+        Tl[(size_t)q * Kp + s] = val * (a1 - p * val);
       }
     }
     double eta_w = 0.0, eta_P = 0.0, sPn = 1.0, swn = 1.0;
@@ -353,19 +352,18 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
 #pragma unroll
       for (int t = 0; t < U; ++t) {
         const int q = qb + t * R + r;
-        if (q < m) {
-          const size_t e = (size_t)jl[q] * Kp + s;
-          const double d_ = Tl[(size_t)q * Kp + s];
-          if constexpr (ADA) {
-            const double grad = dL * d_;
-            st_f64(O.G + e, Gl[(size_t)q * Kp + s] + grad);
-            st_f64(O.N + e, Nl[(size_t)q * Kp + s] + grad * grad);
-          } else {
-            const double p = sP * Pl[(size_t)q * Kp + s];
-            const double update = eta_P * (dL * d_ + O.beta * p);
-            viol_acc += fabs(update);
-            st_f64(M.P + e, (p - update) / sPn);
-          }
+        const bool in = q < m;
+        const size_t e = (size_t)jl[q] * Kp + s;
+        const double d_ = Tl[(size_t)q * Kp + s];
+        if constexpr (ADA) {
+          const double grad = dL * d_;
+          st_f64_at(in ? (ull)(O.G + e) : (ull)junk, Gl[(size_t)q * Kp + s] + grad);
+          st_f64_at(in ? (ull)(O.N + e) : (ull)(junk + kWave), Nl[(size_t)q * Kp + s] + grad * grad);
+        } else {
+          const double p = sP * Pl[(size_t)q * Kp + s];
+          const double update = eta_P * (dL * d_ + O.beta * p);
+          viol_acc += in ? fabs(update) : 0.0;
+          st_f64_at(in ? (ull)(M.P + e) : (ull)junk, (p - update) / sPn);
         }
       }
     }
@@ -1369,8 +1367,10 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   a.m_cap = m_cap;
   a.FW = FW;
   a.lgKp = lgKp;
-  const size_t rows = (size_t)m_cap * M.Kp;
-  size_t lds_worker = sizeof(double) * ((ada ? 4 : 2) * rows + kWave + (ada ? 4 : 2) * (size_t)m_cap) + sizeof(int) * 2 * (size_t)m_cap + sizeof(unsigned) * W;
+  const int grp = (kWave >> lgKp) * 4;  // rows the general worker handles together (R * U): its arrays are padded to whole groups
+  const size_t mcp = (size_t)(m_cap + grp - 1) / grp * grp;
+  const size_t rows = mcp * M.Kp;
+  size_t lds_worker = sizeof(double) * ((ada ? 4 : 2) * rows + kWave + (ada ? 4 : 2) * mcp) + sizeof(int) * 2 * mcp + sizeof(unsigned) * W;
   if (k64) lds_worker = sizeof(double) * ((ada ? 3 : 1) * (size_t)kWave * kWave + kWave) + sizeof(unsigned) * W;
   const size_t lds_cond = sizeof(double) * 2 + sizeof(ull) * (size_t)kWinRing * FW;
   size_t lds_bytes = lds_worker > lds_cond ? lds_worker : lds_cond;
