@@ -53,6 +53,7 @@ struct Plan {
 // first epoch that can use it: column j holds its entries [cptr[j], cptr[j+1]) in sample order.
 struct CscIndex {
   bool built = false, usable = false;
+  bool seg_unfit = false;  // a (batch, feature range) cell of this dataset overflowed once: plans by bucketing are not tried again
   int64_t max_col = 0;
   DevBuf cptr;  // int64[d + 1]
   DevBuf crow;  // int32[nnz] sample

@@ -560,6 +560,257 @@ __global__ __launch_bounds__(kBlock) void k_csc_fill(CsrView X, const int64_t* _
   }
 }
 
+// ---- plans by bucketing: no sort over the epoch's touches ----
+// A fresh order changes which samples share a batch, so the plan of a shuffled epoch is rebuilt from the rows.  The sort
+// path orders all T (batch, feature) keys of the epoch with a device-wide radix sort (headline: 640 M pairs, four passes),
+// although the touches ARRIVE grouped by batch and a feature's touches in a batch are few.  Here:
+//   1. the feature range is cut into `nbk` buckets of 2^fl features; a "cell" is (batch, bucket), a few thousand touches.
+//      k_seg_count: touches per cell (LDS histogram per chunk of samples, one global add per non-empty chunk bin); scan.
+//   2. k_seg_scatter: every touch goes to its cell as ONE 64-bit item (feature's low bits, position in the batch, entry).
+//      The order inside a cell is whatever the atomics gave: it is fixed in step 4 by comparing positions.
+//   3. k_seg_classify: a workgroup per cell, histogram over the 2^fl features in LDS: features touched once get their
+//      flag in sample order (sparse regime), the cell's number of column-phase features and touches is counted; scan.
+//   4. k_seg_fill: the same histogram, then a touch's place = its feature's first slot + the number of touches of the
+//      same feature at smaller positions (a feature has a handful: compared one by one) -- the stable order of the sort.
+// The plan's arrays are bitwise those of the sort path (tests/test_gpu_plan_seg.py).  Falls back to the sort when a cell
+// exceeds kSegCap touches (skewed popularity), when batches are tiny, or with dummy features.   NFM_PLAN_SEG=0: off.
+constexpr int kSegCap = 4096;          // touches per cell a workgroup holds (16 per thread)
+constexpr int kSegMaxBuckets = 4096;   // LDS histogram of the chunk kernels
+constexpr int kSegPosBits = 26, kSegFlShift = 52;
+constexpr uint64_t kSegMask26 = (1ull << 26) - 1;
+
+struct SegGeo {
+  const int64_t* bat_pos;   // device, n_batches + 1 (relative to begin)
+  const int64_t* rowstart;  // first stored entry of the sample at every position
+  const int64_t* toff;      // touch offset of every position (+ 1)
+  int cpb, S, fl, nbk;      // chunks per batch, samples per chunk, features per bucket = 2^fl, buckets
+};
+
+__global__ void k_seg_rows(CsrView X, const int64_t* __restrict__ perm, int64_t begin, int64_t ns, int64_t* __restrict__ rowstart) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ns; r += (int64_t)gridDim.x * blockDim.x)
+    rowstart[r] = X.indptr[perm ? perm[r] : begin + r];
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(kBlock) void k_seg_chunks(CsrView X, SegGeo g, uint32_t* __restrict__ cellcnt,
+                                                       const uint32_t* __restrict__ cellptr, uint64_t* __restrict__ items) {
+  extern __shared__ uint32_t seg_lds[];
+  uint32_t* lh = seg_lds;          // [nbk] touches of this chunk per bucket, then the running rank
+  uint32_t* lb = seg_lds + g.nbk;  // [nbk] (SCATTER) where the chunk's touches of a bucket start
+  const int b = blockIdx.x / g.cpb, c = blockIdx.x - b * g.cpb;
+  const int64_t bp = g.bat_pos[b];
+  const int64_t p0 = bp + (int64_t)c * g.S;
+  int64_t p1 = p0 + g.S;
+  if (p1 > g.bat_pos[b + 1]) p1 = g.bat_pos[b + 1];
+  if (p0 >= p1) return;  // the whole workgroup
+  for (int i = threadIdx.x; i < g.nbk; i += kBlock) lh[i] = 0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  for (int64_t p = p0 + wave; p < p1; p += kWavesPerBlock) {
+    const int64_t q0 = g.rowstart[p];
+    const int m = (int)(g.toff[p + 1] - g.toff[p]);
+    for (int q = lane; q < m; q += kWave) atomicAdd(&lh[(uint32_t)X.indices[q0 + q] >> g.fl], 1u);
+  }
+  __syncthreads();
+  const size_t cell0 = (size_t)b * g.nbk;
+  if (!SCATTER) {
+    for (int i = threadIdx.x; i < g.nbk; i += kBlock)
+      if (lh[i]) atomicAdd(&cellcnt[cell0 + i], lh[i]);
+    return;
+  }
+  for (int i = threadIdx.x; i < g.nbk; i += kBlock) {
+    const uint32_t n = lh[i];
+    if (n) lb[i] = cellptr[cell0 + i] + atomicAdd(&cellcnt[cell0 + i], n);  // cellcnt: zeroed again, the cells' cursors
+    lh[i] = 0;
+  }
+  __syncthreads();
+  const uint32_t lowmask = (1u << g.fl) - 1;
+  for (int64_t p = p0 + wave; p < p1; p += kWavesPerBlock) {
+    const int64_t q0 = g.rowstart[p];
+    const int m = (int)(g.toff[p + 1] - g.toff[p]);
+    const uint64_t hi = (uint64_t)(p - bp) << kSegPosBits;
+    for (int q = lane; q < m; q += kWave) {
+      const uint32_t j = (uint32_t)X.indices[q0 + q];
+      const uint32_t bk = j >> g.fl;
+      const uint32_t slot = lb[bk] + atomicAdd(&lh[bk], 1u);
+      items[slot] = ((uint64_t)(j & lowmask) << kSegFlShift) | hi | (uint64_t)q;
+    }
+  }
+}
+
+__global__ void k_seg_maxcell(int64_t cells, const uint32_t* __restrict__ cellcnt, unsigned int* __restrict__ out) {
+  unsigned int mx = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x)
+    mx = cellcnt[i] > mx ? cellcnt[i] : mx;
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned int o = __shfl_xor(mx, d);
+    mx = o > mx ? o : mx;
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && mx) atomicMax(out, mx);
+}
+
+// exclusive scan of one value per thread over the workgroup (kBlock threads); sh: kWavesPerBlock words of LDS
+__device__ __forceinline__ uint64_t seg_block_scan(uint64_t v, uint64_t* sh, uint64_t* total) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  uint64_t inc = v;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const uint64_t t = (uint64_t)__shfl_up((unsigned long long)inc, d);
+    if (lane >= d) inc += t;
+  }
+  if (lane == kWave - 1) sh[wave] = inc;
+  __syncthreads();
+  uint64_t woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kWavesPerBlock; ++w) {
+    const uint64_t x = sh[w];
+    woff += w < wave ? x : 0;
+    tot += x;
+  }
+  __syncthreads();
+  if (total) *total = tot;
+  return woff + inc - v;
+}
+
+// one workgroup per cell: flags of the single-touch features (thr = 2), the cell's column-phase features and touches
+__global__ __launch_bounds__(kBlock) void k_seg_classify(int nbk, int fl, int thr, const uint32_t* __restrict__ cellptr,
+                                                          const uint64_t* __restrict__ items, const int64_t* __restrict__ bat_pos,
+                                                          const int64_t* __restrict__ toff, uint8_t* __restrict__ single,
+                                                          uint64_t* __restrict__ cellUT) {
+  extern __shared__ uint32_t seg_lds[];
+  __shared__ uint64_t sh[kWavesPerBlock];
+  const int64_t cell = blockIdx.x;
+  const uint32_t i0 = cellptr[cell];
+  const int n = (int)(cellptr[cell + 1] - i0);
+  if (n == 0) {
+    if (threadIdx.x == 0) cellUT[cell] = 0;
+    return;
+  }
+  const int NB = 1 << fl;
+  for (int i = threadIdx.x; i < NB; i += kBlock) seg_lds[i] = 0;
+  __syncthreads();
+  uint64_t it[kSegCap / kBlock];
+#pragma unroll
+  for (int e = 0; e < kSegCap / kBlock; ++e) {
+    const int idx = threadIdx.x + e * kBlock;
+    if (idx < n) {
+      it[e] = items[i0 + idx];
+      atomicAdd(&seg_lds[it[e] >> kSegFlShift], 1u);
+    }
+  }
+  __syncthreads();
+  if (single) {
+    const int64_t bp = bat_pos[cell / nbk];
+#pragma unroll
+    for (int e = 0; e < kSegCap / kBlock; ++e) {
+      const int idx = threadIdx.x + e * kBlock;
+      if (idx < n && seg_lds[it[e] >> kSegFlShift] == 1u)
+        single[toff[bp + (int64_t)((it[e] >> kSegPosBits) & kSegMask26)] + (int64_t)(it[e] & kSegMask26)] = 1;
+    }
+  }
+  uint64_t ut = 0;
+  for (int i = threadIdx.x; i < NB; i += kBlock) {
+    const uint32_t c = seg_lds[i];
+    if (c >= (uint32_t)thr) ut += ((uint64_t)1 << 32) | c;
+  }
+  uint64_t tot;
+  seg_block_scan(ut, sh, &tot);
+  if (threadIdx.x == 0) cellUT[cell] = tot;
+}
+
+struct SegOut {
+  int32_t* tpos;
+  double* tx;
+  int64_t* tq;  // or null
+  int32_t* ucol;
+  int64_t* uptr;
+  int64_t* ubatch;
+};
+
+// one workgroup per cell: every column-phase touch to its place in (feature, position) order
+__global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl, int thr, const uint32_t* __restrict__ cellptr,
+                                                      const uint64_t* __restrict__ items, const int64_t* __restrict__ bat_pos,
+                                                      const int64_t* __restrict__ rowstart, const int64_t* __restrict__ toff,
+                                                      const uint64_t* __restrict__ cellOff, SegOut o) {
+  extern __shared__ uint32_t seg_lds[];
+  __shared__ uint64_t sh[kWavesPerBlock];
+  const int64_t cell = blockIdx.x;
+  const uint32_t i0 = cellptr[cell];
+  const int n = (int)(cellptr[cell + 1] - i0);
+  if (n == 0) return;
+  const int NB = 1 << fl;
+  uint32_t* A = seg_lds;        // [NB] count | first slot among all touches of the cell << 16
+  uint32_t* Bv = seg_lds + NB;  // [NB] first column-phase touch | column-phase feature index << 16
+  uint32_t* ps = seg_lds + 2 * NB;  // [kSegCap] positions, grouped by feature
+  for (int i = threadIdx.x; i < NB; i += kBlock) A[i] = 0;
+  __syncthreads();
+  uint64_t it[kSegCap / kBlock];
+  uint32_t rk[kSegCap / kBlock];
+#pragma unroll
+  for (int e = 0; e < kSegCap / kBlock; ++e) {
+    const int idx = threadIdx.x + e * kBlock;
+    if (idx < n) {
+      it[e] = items[i0 + idx];
+      rk[e] = atomicAdd(&A[it[e] >> kSegFlShift], 1u);
+    }
+  }
+  __syncthreads();
+  {  // bins [t * per, (t + 1) * per) belong to thread t
+    const int per = NB / kBlock;  // fl >= 8
+    uint64_t mine = 0;            // all touches | column-phase touches << 16 | column-phase features << 32
+    for (int i = 0; i < per; ++i) {
+      const uint32_t c = A[threadIdx.x * per + i];
+      mine += (uint64_t)c + (c >= (uint32_t)thr ? ((uint64_t)c << 16) + ((uint64_t)1 << 32) : 0);
+    }
+    uint64_t run = seg_block_scan(mine, sh, nullptr);
+    for (int i = 0; i < per; ++i) {
+      const int bin = threadIdx.x * per + i;
+      const uint32_t c = A[bin];
+      A[bin] = c | ((uint32_t)(run & 0xFFFF) << 16);
+      Bv[bin] = (uint32_t)((run >> 16) & 0xFFFF) | ((uint32_t)((run >> 32) & 0xFFFF) << 16);
+      run += (uint64_t)c + (c >= (uint32_t)thr ? ((uint64_t)c << 16) + ((uint64_t)1 << 32) : 0);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < kSegCap / kBlock; ++e) {
+    const int idx = threadIdx.x + e * kBlock;
+    if (idx < n) ps[(A[it[e] >> kSegFlShift] >> 16) + rk[e]] = (uint32_t)((it[e] >> kSegPosBits) & kSegMask26);
+  }
+  __syncthreads();
+  const int64_t b = cell / nbk;
+  const int64_t bp = bat_pos[b];
+  const uint64_t off = cellOff[cell];
+  const int64_t u0 = (int64_t)(off >> 32), t0 = (int64_t)(off & 0xFFFFFFFFull);
+  const int32_t jbase = (int32_t)((cell - b * nbk) << fl);
+#pragma unroll
+  for (int e = 0; e < kSegCap / kBlock; ++e) {
+    const int idx = threadIdx.x + e * kBlock;
+    if (idx >= n) continue;
+    const uint32_t bin = (uint32_t)(it[e] >> kSegFlShift);
+    const uint32_t a = A[bin];
+    const uint32_t c = a & 0xFFFF;
+    if (c < (uint32_t)thr) continue;
+    const uint32_t pos = (uint32_t)((it[e] >> kSegPosBits) & kSegMask26);
+    const uint32_t sb = a >> 16;
+    int rank = 0;
+    for (uint32_t i = 0; i < c; ++i) rank += ps[sb + i] < pos ? 1 : 0;
+    const uint32_t bv = Bv[bin];
+    const int64_t tb = t0 + (bv & 0xFFFF);
+    const int64_t ts = tb + rank;
+    const int64_t q = (int64_t)(it[e] & kSegMask26);
+    o.tpos[ts] = (int32_t)pos;
+    o.tx[ts] = X.data[rowstart[bp + pos] + q];
+    if (o.tq) o.tq[ts] = toff[bp + pos] + q;
+    if (rank == 0) {
+      const int64_t u = u0 + (bv >> 16);
+      o.ucol[u] = jbase + (int32_t)bin;
+      o.uptr[u] = tb;
+      o.ubatch[u] = b;
+    }
+  }
+}
+
 template <class KeyT>
 static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_aug, const int64_t* perm_host, const int64_t* perm_given_dev,
                         int64_t begin, int64_t end, int64_t batch, bool first_singleton, bool want_tq, bool use_singles,
@@ -707,7 +958,103 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
       NFM_HIP_CHECK(hipStreamSynchronize(st));  // the temporaries of this block go out of scope
     }
   }
-  if (!use_csc) {
+  // Everything else whose cells fit: plans by bucketing (above).
+  bool use_seg = false;
+  {
+    const char* e = getenv("NFM_PLAN_SEG");  // read per build: the tests switch it
+    const bool seg_on = !(e && atoi(e) == 0);
+    const double bt = (double)T / (double)P.n_batches;  // touches per batch
+    if (!use_csc && seg_on && n_aug == 0 && bt >= 8192.0 && P.max_batch < ((int64_t)1 << kSegPosBits) &&
+        X.max_row < (1 << kSegPosBits) && X.d < ((int64_t)1 << 31) && !(csc && csc->seg_unfit)) {
+      static const int fl_env = getenv("NFM_SEG_FL") ? atoi(getenv("NFM_SEG_FL")) : 0;
+      static const int tgt_env = getenv("NFM_SEG_CELL") ? atoi(getenv("NFM_SEG_CELL")) : 0;
+      const double target = tgt_env > 0 ? tgt_env : 2048.0;  // touches per cell aimed at
+      int fl = 8;
+      while (fl < 12 && (double)(((X.d - 1) >> (fl + 1)) + 1) * target >= bt) ++fl;  // the largest bucket count with >= target per cell
+      if (fl_env >= 8 && fl_env <= 12) fl = fl_env;
+      const int64_t nbk = ((X.d - 1) >> fl) + 1;
+      const int64_t cells = P.n_batches * nbk;
+      if (nbk <= kSegMaxBuckets && cells <= ((int64_t)1 << 24) && bt / (double)nbk <= 0.75 * kSegCap) {
+        DevBuf rowstart, cellcnt, cellptr, items, mx, cellUT, cellOff;
+        NFM_TRY(rowstart.alloc(sizeof(int64_t) * ns));
+        NFM_TRY(cellcnt.alloc(sizeof(uint32_t) * (cells + 1)));
+        NFM_TRY(cellptr.alloc(sizeof(uint32_t) * (cells + 1)));
+        NFM_TRY(mx.alloc(sizeof(unsigned int)));
+        NFM_HIP_CHECK(hipMemsetAsync(cellcnt.p, 0, sizeof(uint32_t) * (cells + 1), st));
+        NFM_HIP_CHECK(hipMemsetAsync(mx.p, 0, sizeof(unsigned int), st));
+        hipLaunchKernelGGL(k_seg_rows, dim3(grid1d(ns)), dim3(kBlock), 0, st, X, perm_dev, begin, ns, rowstart.as<int64_t>());
+        SegGeo g;
+        g.bat_pos = P.bat_pos_dev.as<int64_t>();
+        g.rowstart = rowstart.as<int64_t>();
+        g.toff = toff.as<int64_t>();
+        g.S = 128;
+        g.cpb = (int)((P.max_batch + g.S - 1) / g.S);
+        g.fl = fl;
+        g.nbk = (int)nbk;
+        const int64_t chunk_blocks = P.n_batches * g.cpb;
+        NFM_CHECK(chunk_blocks < ((int64_t)1 << 31), NFM_ERR_UNSUPPORTED, "too many sample chunks");
+        hipLaunchKernelGGL((k_seg_chunks<false>), dim3((unsigned)chunk_blocks), dim3(kBlock), sizeof(uint32_t) * 2 * nbk, st, X, g,
+                           cellcnt.as<uint32_t>(), (const uint32_t*)nullptr, (uint64_t*)nullptr);
+        hipLaunchKernelGGL(k_seg_maxcell, dim3(grid1d(cells)), dim3(kBlock), 0, st, cells, cellcnt.as<uint32_t>(), mx.as<unsigned int>());
+        tmp_bytes = 0;
+        NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cellcnt.as<uint32_t>(), cellptr.as<uint32_t>(), (int)(cells + 1), st));
+        NFM_TRY(tmp.alloc(tmp_bytes));
+        NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, cellcnt.as<uint32_t>(), cellptr.as<uint32_t>(), (int)(cells + 1), st));
+        unsigned int h_mx = 0;
+        NFM_HIP_CHECK(hipMemcpyAsync(&h_mx, mx.p, sizeof(h_mx), hipMemcpyDeviceToHost, st));
+        NFM_HIP_CHECK(hipStreamSynchronize(st));
+        if (h_mx > (unsigned)kSegCap) {
+          if (csc) csc->seg_unfit = true;  // a popular feature: this dataset's plans come from the sort
+        } else {
+          use_seg = true;
+          TimedLaunch tl(ctx, "plan_seg");  // (the tests count these to know which path built the plan)
+          const int thr = use_singles ? 2 : 1;
+          NFM_TRY(items.alloc(sizeof(uint64_t) * T));
+          NFM_TRY(cellUT.alloc(sizeof(uint64_t) * (cells + 1)));
+          NFM_TRY(cellOff.alloc(sizeof(uint64_t) * (cells + 1)));
+          NFM_HIP_CHECK(hipMemsetAsync(cellcnt.p, 0, sizeof(uint32_t) * (cells + 1), st));
+          NFM_HIP_CHECK(hipMemsetAsync(cellUT.as<uint64_t>() + cells, 0, sizeof(uint64_t), st));
+          hipLaunchKernelGGL((k_seg_chunks<true>), dim3((unsigned)chunk_blocks), dim3(kBlock), sizeof(uint32_t) * 2 * nbk, st, X, g,
+                             cellcnt.as<uint32_t>(), cellptr.as<uint32_t>(), items.as<uint64_t>());
+          if (use_singles) {
+            NFM_TRY(P.single.alloc(sizeof(uint8_t) * T));
+            NFM_HIP_CHECK(hipMemsetAsync(P.single.p, 0, sizeof(uint8_t) * T, st));
+          }
+          const size_t NB = (size_t)1 << fl;
+          hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)cells), dim3(kBlock), sizeof(uint32_t) * NB, st, (int)nbk, fl, thr,
+                             cellptr.as<uint32_t>(), items.as<uint64_t>(), P.bat_pos_dev.as<int64_t>(), toff.as<int64_t>(),
+                             use_singles ? P.single.as<uint8_t>() : nullptr, cellUT.as<uint64_t>());
+          tmp_bytes = 0;
+          NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cellUT.as<uint64_t>(), cellOff.as<uint64_t>(), (int)(cells + 1), st));
+          NFM_TRY(tmp.alloc(tmp_bytes));
+          NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, cellUT.as<uint64_t>(), cellOff.as<uint64_t>(), (int)(cells + 1), st));
+          uint64_t h_tot = 0;
+          NFM_HIP_CHECK(hipMemcpyAsync(&h_tot, cellOff.as<uint64_t>() + cells, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+          NFM_HIP_CHECK(hipStreamSynchronize(st));
+          U = (int64_t)(h_tot >> 32);
+          TM = (int64_t)(h_tot & 0xFFFFFFFFull);
+          P.U = U;
+          P.TM = TM;
+          NFM_TRY(P.tpos.alloc(sizeof(int32_t) * TM)); NFM_TRY(P.tx.alloc(sizeof(double) * TM));
+          if (want_tq) NFM_TRY(P.tq.alloc(sizeof(int64_t) * TM));
+          NFM_TRY(P.ucol.alloc(sizeof(int32_t) * U));
+          NFM_TRY(P.uptr.alloc(sizeof(int64_t) * (U + 1)));
+          NFM_TRY(ubatch.alloc(sizeof(int64_t) * (U + 1)));
+          SegOut so{P.tpos.as<int32_t>(), P.tx.as<double>(), want_tq ? P.tq.as<int64_t>() : nullptr, P.ucol.as<int32_t>(),
+                    P.uptr.as<int64_t>(), ubatch.as<int64_t>()};
+          if (TM > 0)
+            hipLaunchKernelGGL(k_seg_fill, dim3((unsigned)cells), dim3(kBlock), sizeof(uint32_t) * (2 * NB + kSegCap), st, X, (int)nbk, fl,
+                               thr, cellptr.as<uint32_t>(), items.as<uint64_t>(), P.bat_pos_dev.as<int64_t>(), rowstart.as<int64_t>(),
+                               toff.as<int64_t>(), cellOff.as<uint64_t>(), so);
+          if (U > 0)
+            hipLaunchKernelGGL(k_batch_first, dim3(grid1d(U)), dim3(kBlock), 0, st, U, ubatch.as<int64_t>(), bfu.as<int64_t>());
+          NFM_HIP_CHECK(hipGetLastError());
+          NFM_HIP_CHECK(hipStreamSynchronize(st));  // the temporaries of this block go out of scope
+        }
+      }
+    }
+  }
+  if (!use_csc && !use_seg) {
   // 2. expand to (batch, feature) keys
   DevBuf k0, k1, v0, v1, pay_un;
   NFM_TRY(k0.alloc(sizeof(KeyT) * T)); NFM_TRY(k1.alloc(sizeof(KeyT) * T));
