@@ -968,7 +968,8 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       const double lambda = (double)o->batch * ((double)ds->v.nnz / (double)std::max<int64_t>(ds->v.n, 1)) / (double)m->d;
       bool use_singles = o->kind != OPT_PSGD && m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2 && (o->batch == 1 || lambda <= 1.4);
       if (const char* env = getenv("NFM_SINGLES")) use_singles = use_singles && atoi(env) != 0;  // tuning override
-      const bool sort_by_count = m->Kp * (int)sizeof(double) >= 128;  // rows of at least one 128-byte line (plan.hip)
+      bool sort_by_count = m->Kp * (int)sizeof(double) >= 128;  // rows of at least one 128-byte line (plan.hip)
+      if (const char* env = getenv("NFM_SORT_BY_COUNT")) sort_by_count = atoi(env) != 0;  // tuning override
       const bool dev_shuffle = !perm && o->shuffle_seed >= 0 && o->kind != OPT_PSGD;
       auto plan_matches = [&](const Plan& PL, bool fs) {
         return PL.ds_uid == ds->uid && PL.ds_nnz == ds->v.nnz && PL.begin == begin && PL.end == end && PL.batch == o->batch &&

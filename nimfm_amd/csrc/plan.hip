@@ -144,13 +144,19 @@ __global__ void k_compact(int64_t T, const KeyT* __restrict__ keys, const uint32
   }
 }
 
+// The column phase walks a batch's unique features in the order of DESCENDING touch count (plan.h); counts of kCntMax and
+// more share a class and keep their feature order among themselves.  16 classes: counts differ by a few around their
+// mean (Poisson), and a 4-bit class keeps the (batch, class) key of the sort path at two radix passes.
+constexpr int kCntClassBits = 4, kCntClasses = 1 << kCntClassBits, kCntMax = kCntClasses - 1;
+__host__ __device__ __forceinline__ uint32_t count_class(int64_t c, uint32_t cmax) { return cmax - (c < (int64_t)cmax ? (uint32_t)c : cmax); }
+
 // (batch, descending touch count) keys of the unique features, and the gather into the sorted tables
-__global__ void k_ukeys(int64_t U, const int64_t* __restrict__ ubatch, const int64_t* __restrict__ uptr, int bucket, int cbits,
+__global__ void k_ukeys(int64_t U, const int64_t* __restrict__ ubatch, const int64_t* __restrict__ uptr, int cbits,
                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const uint32_t cmax = (1u << cbits) - 1;  // counts beyond it share a key: they stay in feature order among themselves
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t c = (uptr[u + 1] - uptr[u]) / bucket;
-    keys[u] = ((uint32_t)ubatch[u] << cbits) | (cmax - (c < (int64_t)cmax ? (uint32_t)c : cmax));
+    const int64_t c = uptr[u + 1] - uptr[u];
+    keys[u] = ((uint32_t)ubatch[u] << cbits) | count_class(c, cmax);
     vals[u] = (uint32_t)u;
   }
 }
@@ -672,20 +678,50 @@ __device__ __forceinline__ uint64_t seg_block_scan(uint64_t v, uint64_t* sh, uin
   return woff + inc - v;
 }
 
+// the same for NW words per thread (one pair of barriers for all of them)
+template <int NW>
+__device__ __forceinline__ void seg_block_scan_n(uint64_t (&v)[NW], uint64_t (*sh)[kWavesPerBlock]) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  uint64_t inc[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    inc[w] = v[w];
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const uint64_t t = (uint64_t)__shfl_up((unsigned long long)inc[w], d);
+      if (lane >= d) inc[w] += t;
+    }
+    if (lane == kWave - 1) sh[w][wave] = inc[w];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    uint64_t woff = 0;
+#pragma unroll
+    for (int q = 0; q < kWavesPerBlock; ++q) woff += q < wave ? sh[w][q] : 0;
+    v[w] = woff + inc[w] - v[w];
+  }
+  __syncthreads();
+}
+
 // one workgroup per cell: flags of the single-touch features (thr = 2), the cell's column-phase features and touches
 __global__ __launch_bounds__(kBlock) void k_seg_classify(int nbk, int fl, int thr, const uint32_t* __restrict__ cellptr,
                                                           const uint64_t* __restrict__ items, const int64_t* __restrict__ bat_pos,
                                                           const int64_t* __restrict__ toff, uint8_t* __restrict__ single,
-                                                          uint64_t* __restrict__ cellUT) {
+                                                          uint64_t* __restrict__ cellUT, int by_count, uint16_t* __restrict__ cls,
+                                                          unsigned long long* __restrict__ n_heavy) {
   extern __shared__ uint32_t seg_lds[];
   __shared__ uint64_t sh[kWavesPerBlock];
+  __shared__ uint32_t cl[kCntClasses];  // column-phase features of the cell per touch-count class
   const int64_t cell = blockIdx.x;
   const uint32_t i0 = cellptr[cell];
   const int n = (int)(cellptr[cell + 1] - i0);
   if (n == 0) {
     if (threadIdx.x == 0) cellUT[cell] = 0;
+    if (threadIdx.x < kCntClasses) cls[cell * kCntClasses + threadIdx.x] = 0;
     return;
   }
+  if (threadIdx.x < kCntClasses) cl[threadIdx.x] = 0;
   const int NB = 1 << fl;
   for (int i = threadIdx.x; i < NB; i += kBlock) seg_lds[i] = 0;
   __syncthreads();
@@ -709,13 +745,42 @@ __global__ __launch_bounds__(kBlock) void k_seg_classify(int nbk, int fl, int th
     }
   }
   uint64_t ut = 0;
+  unsigned int heavy = 0;
   for (int i = threadIdx.x; i < NB; i += kBlock) {
     const uint32_t c = seg_lds[i];
-    if (c >= (uint32_t)thr) ut += ((uint64_t)1 << 32) | c;
+    if (c >= (uint32_t)thr) {
+      ut += ((uint64_t)1 << 32) | c;
+      atomicAdd(&cl[by_count ? count_class(c, kCntMax) : 0], 1u);
+      heavy += c > (uint32_t)kHeavyTouches ? 1 : 0;
+    }
   }
   uint64_t tot;
-  seg_block_scan(ut, sh, &tot);
+  seg_block_scan(ut, sh, &tot);  // (its barriers also cover cl)
   if (threadIdx.x == 0) cellUT[cell] = tot;
+  if (threadIdx.x < kCntClasses) cls[cell * kCntClasses + threadIdx.x] = (uint16_t)cl[threadIdx.x];
+  if (heavy) atomicAdd(n_heavy, (unsigned long long)heavy);
+}
+
+// one workgroup per batch: where the features of every (cell, class) start in the batch's list ordered by (class, feature):
+// an exclusive scan over the batch's cells, class after class
+__global__ __launch_bounds__(kBlock) void k_seg_unit_offsets(int nbk, const uint16_t* __restrict__ cls, uint32_t* __restrict__ uoffc) {
+  __shared__ uint64_t sh[kWavesPerBlock];
+  const size_t c0 = (size_t)blockIdx.x * nbk;
+  const int len = kCntClasses * nbk;
+  const int per = (len + kBlock - 1) / kBlock;
+  const int s0 = threadIdx.x * per;
+  uint64_t mine = 0;
+  for (int s = s0; s < s0 + per && s < len; ++s) mine += cls[(c0 + (s % nbk)) * kCntClasses + s / nbk];
+  uint64_t run = seg_block_scan(mine, sh, nullptr);
+  for (int s = s0; s < s0 + per && s < len; ++s) {
+    const size_t at = (c0 + (s % nbk)) * kCntClasses + s / nbk;
+    uoffc[at] = (uint32_t)run;
+    run += cls[at];
+  }
+}
+__global__ void k_seg_batch_uoff(int64_t n_batches, int nbk, const uint64_t* __restrict__ cellOff, int64_t* __restrict__ out) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= n_batches; b += (int64_t)gridDim.x * blockDim.x)
+    out[b] = (int64_t)(cellOff[b * nbk] >> 32);  // (cellOff has cells + 1 entries: the last one is the total)
 }
 
 struct SegOut {
@@ -724,16 +789,21 @@ struct SegOut {
   int64_t* tq;  // or null
   int32_t* ucol;
   int64_t* uptr;
-  int64_t* ubatch;
+  int32_t* ucol_s;  // the same features in the column phase's order (batch, class, feature)
+  int64_t* ubeg_s;
+  int32_t* ucnt_s;
 };
 
 // one workgroup per cell: every column-phase touch to its place in (feature, position) order
 __global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl, int thr, const uint32_t* __restrict__ cellptr,
                                                       const uint64_t* __restrict__ items, const int64_t* __restrict__ bat_pos,
                                                       const int64_t* __restrict__ rowstart, const int64_t* __restrict__ toff,
-                                                      const uint64_t* __restrict__ cellOff, SegOut o) {
+                                                      const uint64_t* __restrict__ cellOff, int by_count,
+                                                      const uint32_t* __restrict__ uoffc, SegOut o) {
   extern __shared__ uint32_t seg_lds[];
   __shared__ uint64_t sh[kWavesPerBlock];
+  __shared__ uint64_t sh4[kCntClasses / 4][kWavesPerBlock];
+  __shared__ uint32_t uo[kCntClasses];
   const int64_t cell = blockIdx.x;
   const uint32_t i0 = cellptr[cell];
   const int n = (int)(cellptr[cell + 1] - i0);
@@ -742,6 +812,8 @@ __global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl,
   uint32_t* A = seg_lds;        // [NB] count | first slot among all touches of the cell << 16
   uint32_t* Bv = seg_lds + NB;  // [NB] first column-phase touch | column-phase feature index << 16
   uint32_t* ps = seg_lds + 2 * NB;  // [kSegCap] positions, grouped by feature
+  uint16_t* Cv = reinterpret_cast<uint16_t*>(seg_lds + 2 * NB + kSegCap);  // [NB] the feature's rank among the cell's features of its class
+  if (threadIdx.x < kCntClasses) uo[threadIdx.x] = uoffc[cell * kCntClasses + threadIdx.x];
   for (int i = threadIdx.x; i < NB; i += kBlock) A[i] = 0;
   __syncthreads();
   uint64_t it[kSegCap / kBlock];
@@ -762,13 +834,36 @@ __global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl,
       const uint32_t c = A[threadIdx.x * per + i];
       mine += (uint64_t)c + (c >= (uint32_t)thr ? ((uint64_t)c << 16) + ((uint64_t)1 << 32) : 0);
     }
+    // ... and, per class, the column-phase features before this thread's bins: 16 counters of 16 bits in four words
+    uint64_t cw[kCntClasses / 4] = {0, 0, 0, 0};
+    for (int i = 0; i < per; ++i) {
+      const uint32_t c = A[threadIdx.x * per + i];
+      if (c >= (uint32_t)thr) {
+        const uint32_t k = by_count ? count_class(c, kCntMax) : 0;
+        const uint64_t inc = (uint64_t)1 << ((k & 3) * 16);
+#pragma unroll
+        for (int w = 0; w < kCntClasses / 4; ++w) cw[w] += (k >> 2) == (uint32_t)w ? inc : 0;
+      }
+    }
     uint64_t run = seg_block_scan(mine, sh, nullptr);
+    seg_block_scan_n(cw, sh4);
     for (int i = 0; i < per; ++i) {
       const int bin = threadIdx.x * per + i;
       const uint32_t c = A[bin];
       A[bin] = c | ((uint32_t)(run & 0xFFFF) << 16);
       Bv[bin] = (uint32_t)((run >> 16) & 0xFFFF) | ((uint32_t)((run >> 32) & 0xFFFF) << 16);
       run += (uint64_t)c + (c >= (uint32_t)thr ? ((uint64_t)c << 16) + ((uint64_t)1 << 32) : 0);
+      if (c >= (uint32_t)thr) {
+        const uint32_t k = by_count ? count_class(c, kCntMax) : 0;
+        const int sft = (int)(k & 3) * 16;
+        uint64_t word = 0;
+#pragma unroll
+        for (int w = 0; w < kCntClasses / 4; ++w) word = (k >> 2) == (uint32_t)w ? cw[w] : word;
+        Cv[bin] = (uint16_t)((word >> sft) & 0xFFFF);
+        const uint64_t inc = (uint64_t)1 << sft;
+#pragma unroll
+        for (int w = 0; w < kCntClasses / 4; ++w) cw[w] += (k >> 2) == (uint32_t)w ? inc : 0;
+      }
     }
   }
   __syncthreads();
@@ -782,6 +877,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl,
   const int64_t bp = bat_pos[b];
   const uint64_t off = cellOff[cell];
   const int64_t u0 = (int64_t)(off >> 32), t0 = (int64_t)(off & 0xFFFFFFFFull);
+  const int64_t ub0 = (int64_t)(cellOff[b * nbk] >> 32);  // the batch's first feature
   const int32_t jbase = (int32_t)((cell - b * nbk) << fl);
 #pragma unroll
   for (int e = 0; e < kSegCap / kBlock; ++e) {
@@ -806,7 +902,10 @@ __global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl,
       const int64_t u = u0 + (bv >> 16);
       o.ucol[u] = jbase + (int32_t)bin;
       o.uptr[u] = tb;
-      o.ubatch[u] = b;
+      const int64_t us = ub0 + uo[by_count ? count_class(c, kCntMax) : 0] + Cv[bin];
+      o.ucol_s[us] = jbase + (int32_t)bin;
+      o.ubeg_s[us] = tb;
+      o.ucnt_s[us] = (int32_t)c;
     }
   }
 }
@@ -960,6 +1059,7 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
   }
   // Everything else whose cells fit: plans by bucketing (above).
   bool use_seg = false;
+  unsigned long long seg_heavy = 0;  // (use_seg) features with more than kHeavyTouches touches
   {
     const char* e = getenv("NFM_PLAN_SEG");  // read per build: the tests switch it
     const bool seg_on = !(e && atoi(e) == 0);
@@ -987,7 +1087,8 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
         g.bat_pos = P.bat_pos_dev.as<int64_t>();
         g.rowstart = rowstart.as<int64_t>();
         g.toff = toff.as<int64_t>();
-        g.S = 128;
+        static const int s_env = getenv("NFM_SEG_S") ? atoi(getenv("NFM_SEG_S")) : 0;
+        g.S = s_env > 0 ? s_env : 128;  // samples per chunk workgroup
         g.cpb = (int)((P.max_batch + g.S - 1) / g.S);
         g.fl = fl;
         g.nbk = (int)nbk;
@@ -1012,6 +1113,12 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
           NFM_TRY(items.alloc(sizeof(uint64_t) * T));
           NFM_TRY(cellUT.alloc(sizeof(uint64_t) * (cells + 1)));
           NFM_TRY(cellOff.alloc(sizeof(uint64_t) * (cells + 1)));
+          DevBuf cls, uoffc, nheavy, buoff;
+          NFM_TRY(cls.alloc(sizeof(uint16_t) * kCntClasses * cells));
+          NFM_TRY(uoffc.alloc(sizeof(uint32_t) * kCntClasses * cells));
+          NFM_TRY(nheavy.alloc(sizeof(unsigned long long)));
+          NFM_TRY(buoff.alloc(sizeof(int64_t) * (P.n_batches + 1)));
+          NFM_HIP_CHECK(hipMemsetAsync(nheavy.p, 0, sizeof(unsigned long long), st));
           NFM_HIP_CHECK(hipMemsetAsync(cellcnt.p, 0, sizeof(uint32_t) * (cells + 1), st));
           NFM_HIP_CHECK(hipMemsetAsync(cellUT.as<uint64_t>() + cells, 0, sizeof(uint64_t), st));
           hipLaunchKernelGGL((k_seg_chunks<true>), dim3((unsigned)chunk_blocks), dim3(kBlock), sizeof(uint32_t) * 2 * nbk, st, X, g,
@@ -1023,13 +1130,20 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
           const size_t NB = (size_t)1 << fl;
           hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)cells), dim3(kBlock), sizeof(uint32_t) * NB, st, (int)nbk, fl, thr,
                              cellptr.as<uint32_t>(), items.as<uint64_t>(), P.bat_pos_dev.as<int64_t>(), toff.as<int64_t>(),
-                             use_singles ? P.single.as<uint8_t>() : nullptr, cellUT.as<uint64_t>());
+                             use_singles ? P.single.as<uint8_t>() : nullptr, cellUT.as<uint64_t>(), sort_by_count ? 1 : 0,
+                             cls.as<uint16_t>(), nheavy.as<unsigned long long>());
+          hipLaunchKernelGGL(k_seg_unit_offsets, dim3((unsigned)P.n_batches), dim3(kBlock), 0, st, (int)nbk, cls.as<uint16_t>(),
+                             uoffc.as<uint32_t>());
           tmp_bytes = 0;
           NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cellUT.as<uint64_t>(), cellOff.as<uint64_t>(), (int)(cells + 1), st));
           NFM_TRY(tmp.alloc(tmp_bytes));
           NFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, cellUT.as<uint64_t>(), cellOff.as<uint64_t>(), (int)(cells + 1), st));
           uint64_t h_tot = 0;
           NFM_HIP_CHECK(hipMemcpyAsync(&h_tot, cellOff.as<uint64_t>() + cells, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+          hipLaunchKernelGGL(k_seg_batch_uoff, dim3(grid1d(P.n_batches + 1)), dim3(kBlock), 0, st, P.n_batches, (int)nbk,
+                             cellOff.as<uint64_t>(), buoff.as<int64_t>());
+          NFM_HIP_CHECK(hipMemcpyAsync(P.bat_uoff.data(), buoff.p, sizeof(int64_t) * (P.n_batches + 1), hipMemcpyDeviceToHost, st));
+          NFM_HIP_CHECK(hipMemcpyAsync(&seg_heavy, nheavy.p, sizeof(seg_heavy), hipMemcpyDeviceToHost, st));
           NFM_HIP_CHECK(hipStreamSynchronize(st));
           U = (int64_t)(h_tot >> 32);
           TM = (int64_t)(h_tot & 0xFFFFFFFFull);
@@ -1039,15 +1153,16 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
           if (want_tq) NFM_TRY(P.tq.alloc(sizeof(int64_t) * TM));
           NFM_TRY(P.ucol.alloc(sizeof(int32_t) * U));
           NFM_TRY(P.uptr.alloc(sizeof(int64_t) * (U + 1)));
-          NFM_TRY(ubatch.alloc(sizeof(int64_t) * (U + 1)));
+          NFM_TRY(P.ucol_s.alloc(sizeof(int32_t) * std::max<int64_t>(U, 1)));
+          NFM_TRY(P.ubeg_s.alloc(sizeof(int64_t) * std::max<int64_t>(U, 1)));
+          NFM_TRY(P.ucnt_s.alloc(sizeof(int32_t) * std::max<int64_t>(U, 1)));
           SegOut so{P.tpos.as<int32_t>(), P.tx.as<double>(), want_tq ? P.tq.as<int64_t>() : nullptr, P.ucol.as<int32_t>(),
-                    P.uptr.as<int64_t>(), ubatch.as<int64_t>()};
+                    P.uptr.as<int64_t>(), P.ucol_s.as<int32_t>(), P.ubeg_s.as<int64_t>(), P.ucnt_s.as<int32_t>()};
           if (TM > 0)
-            hipLaunchKernelGGL(k_seg_fill, dim3((unsigned)cells), dim3(kBlock), sizeof(uint32_t) * (2 * NB + kSegCap), st, X, (int)nbk, fl,
-                               thr, cellptr.as<uint32_t>(), items.as<uint64_t>(), P.bat_pos_dev.as<int64_t>(), rowstart.as<int64_t>(),
-                               toff.as<int64_t>(), cellOff.as<uint64_t>(), so);
-          if (U > 0)
-            hipLaunchKernelGGL(k_batch_first, dim3(grid1d(U)), dim3(kBlock), 0, st, U, ubatch.as<int64_t>(), bfu.as<int64_t>());
+            hipLaunchKernelGGL(k_seg_fill, dim3((unsigned)cells), dim3(kBlock), sizeof(uint32_t) * (2 * NB + kSegCap) + sizeof(uint16_t) * NB,
+                               st, X, (int)nbk, fl, thr, cellptr.as<uint32_t>(), items.as<uint64_t>(), P.bat_pos_dev.as<int64_t>(),
+                               rowstart.as<int64_t>(), toff.as<int64_t>(), cellOff.as<uint64_t>(), sort_by_count ? 1 : 0,
+                               uoffc.as<uint32_t>(), so);
           NFM_HIP_CHECK(hipGetLastError());
           NFM_HIP_CHECK(hipStreamSynchronize(st));  // the temporaries of this block go out of scope
         }
@@ -1118,6 +1233,8 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
   NFM_HIP_CHECK(hipStreamSynchronize(st));  // the sort's temporaries go out of scope with this block
   }
   NFM_HIP_CHECK(hipMemcpyAsync(P.uptr.as<int64_t>() + U, &TM, sizeof(int64_t), hipMemcpyHostToDevice, st));
+  unsigned long long h_heavy = seg_heavy;
+  if (!use_seg) {  // (the bucketing path has written the ordered tables and the batch offsets itself)
   // the per-batch order by descending touch count (the batch ranges [bat_uoff[b], bat_uoff[b+1]) are unchanged)
   NFM_TRY(P.ucol_s.alloc(sizeof(int32_t) * std::max<int64_t>(U, 1)));
   NFM_TRY(P.ubeg_s.alloc(sizeof(int64_t) * std::max<int64_t>(U, 1)));
@@ -1128,10 +1245,9 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
   DevBuf uk0, uk1, uv0, uv1, utmp;  // alive until the synchronisation below
   if (U > 0) {
     NFM_CHECK(P.n_batches < ((int64_t)1 << 31), NFM_ERR_UNSUPPORTED, "too many batches");
-    static const int cnt_bucket = getenv("NFM_CNT_BUCKET") && atoi(getenv("NFM_CNT_BUCKET")) > 0 ? atoi(getenv("NFM_CNT_BUCKET")) : 1;
-    // (batch, descending touch count) in 32 bits, the count clamped to 8 bits (fewer when there are more than 2^24
-    // batches): two or three radix passes instead of the five to six of a 64-bit (batch << 32 | count) key
-    const int cbits = bbits <= 24 ? 8 : 32 - bbits;
+    // (batch, descending touch count) in 32 bits, the count clamped to 4 bits (fewer when there are more than 2^28
+    // batches): two radix passes instead of the five to six of a 64-bit (batch << 32 | count) key
+    const int cbits = bbits <= 32 - kCntClassBits ? kCntClassBits : 32 - bbits;
     const uint32_t* order = nullptr;
     // Parameter rows shorter than a 128-byte line (k <= 8) keep the feature order: neighbours in the list are
     // neighbours in memory and share their lines, which is worth more than balanced wavefronts (cfg5, k = 8:
@@ -1141,7 +1257,7 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
       NFM_TRY(uv0.alloc(sizeof(uint32_t) * U)); NFM_TRY(uv1.alloc(sizeof(uint32_t) * U));
       hipcub::DoubleBuffer<uint32_t> udk(uk0.as<uint32_t>(), uk1.as<uint32_t>());
       hipcub::DoubleBuffer<uint32_t> udv(uv0.as<uint32_t>(), uv1.as<uint32_t>());
-      hipLaunchKernelGGL(k_ukeys, dim3(grid1d(U)), dim3(kBlock), 0, st, U, ubatch.as<int64_t>(), P.uptr.as<int64_t>(), cnt_bucket, cbits,
+      hipLaunchKernelGGL(k_ukeys, dim3(grid1d(U)), dim3(kBlock), 0, st, U, ubatch.as<int64_t>(), P.uptr.as<int64_t>(), cbits,
                          uk0.as<uint32_t>(), uv0.as<uint32_t>());
       size_t ub = 0;
       NFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, ub, udk, udv, (int)U, 0, cbits + bbits, st));
@@ -1154,12 +1270,12 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
                        n_heavy.as<unsigned long long>());
   }
   std::vector<int64_t> first(P.n_batches);
-  unsigned long long h_heavy = 0;
   NFM_HIP_CHECK(hipMemcpyAsync(first.data(), bfu.p, sizeof(int64_t) * P.n_batches, hipMemcpyDeviceToHost, st));
   NFM_HIP_CHECK(hipMemcpyAsync(&h_heavy, n_heavy.p, sizeof(h_heavy), hipMemcpyDeviceToHost, st));
   NFM_HIP_CHECK(hipStreamSynchronize(st));  // also: the sort's temporaries may go
   P.bat_uoff[P.n_batches] = U;
   for (int64_t b = P.n_batches - 1; b >= 0; --b) P.bat_uoff[b] = first[b] != none ? first[b] : P.bat_uoff[b + 1];
+  }
   P.max_unique = 0;
   for (int64_t b = 0; b < P.n_batches; ++b) P.max_unique = std::max(P.max_unique, P.bat_uoff[b + 1] - P.bat_uoff[b]);
   // heavy features: flags -> scans -> compact lists + per-batch offsets
