@@ -590,11 +590,65 @@ struct SegGeo {
   const int64_t* rowstart;  // first stored entry of the sample at every position
   const int64_t* toff;      // touch offset of every position (+ 1)
   int cpb, S, fl, nbk;      // chunks per batch, samples per chunk, features per bucket = 2^fl, buckets
+  int64_t n_batches;
+  int xcd;                  // seg_map
 };
+
+// Workgroups are dealt to the 8 XCDs round-robin by their index.  All workgroups of ONE batch are put on ONE XCD: what they
+// share -- the batch's rows (gathered values), its cells' item regions and its stretch of the single-touch flags, all
+// written a few bytes at a time -- then meets in one L2, which merges the pieces into whole lines before they leave.
+// xcd = 0: the plain order (workgroup = batch * per_batch + part).
+__device__ __forceinline__ bool seg_map(int64_t blk, int per_batch, int64_t n_batches, int xcd, int64_t& b, int& part) {
+  if (!xcd) {
+    b = blk / per_batch;
+    part = (int)(blk - b * per_batch);
+    return true;
+  }
+  const int64_t g = blk / (8 * (int64_t)per_batch), r = blk - g * 8 * per_batch;
+  b = g * 8 + (r & 7);
+  part = (int)(r >> 3);
+  return b < n_batches;
+}
+static inline int64_t seg_grid(int64_t n_batches, int per_batch, int xcd) {
+  return (xcd ? (n_batches + 7) / 8 * 8 : n_batches) * per_batch;
+}
 
 __global__ void k_seg_rows(CsrView X, const int64_t* __restrict__ perm, int64_t begin, int64_t ns, int64_t* __restrict__ rowstart) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < ns; r += (int64_t)gridDim.x * blockDim.x)
     rowstart[r] = X.indptr[perm ? perm[r] : begin + r];
+}
+
+// every wavefront walks its rows four at a time (their first 64 ids requested together: a row at a time the walk was a
+// chain of dependent round trips -- row start, ids, LDS -- per row); f(id, entry, position)
+template <class F>
+__device__ __forceinline__ void seg_walk_rows(const CsrView& X, const SegGeo& g, int64_t p0, int64_t p1, F&& f) {
+  constexpr int U = 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  for (int64_t pb = p0 + (int64_t)wave * kWave; pb < p1; pb += (int64_t)kWavesPerBlock * kWave) {  // 64 rows per wavefront and trip
+    const int64_t pl = pb + lane;
+    const bool have = pl < p1;
+    const int64_t q0_l = have ? g.rowstart[pl] : 0;
+    const int m_l = have ? (int)(g.toff[pl + 1] - g.toff[pl]) : 0;
+    const int rows = (int)(p1 - pb < kWave ? p1 - pb : kWave);
+    for (int r = 0; r < rows; r += U) {
+      int64_t q0[U];
+      int m[U];
+      int32_t j[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int src = r + u < rows ? r + u : r;
+        q0[u] = __shfl((long long)q0_l, src, kWave);
+        m[u] = r + u < rows ? __shfl(m_l, src, kWave) : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) j[u] = lane < m[u] ? X.indices[q0[u] + lane] : 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (lane < m[u]) f((uint32_t)j[u], lane, pb + r + u);
+        for (int q = lane + kWave; q < m[u]; q += kWave) f((uint32_t)X.indices[q0[u] + q], q, pb + r + u);  // rows beyond 64 entries
+      }
+    }
+  }
 }
 
 template <bool SCATTER>
@@ -603,7 +657,9 @@ __global__ __launch_bounds__(kBlock) void k_seg_chunks(CsrView X, SegGeo g, uint
   extern __shared__ uint32_t seg_lds[];
   uint32_t* lh = seg_lds;          // [nbk] touches of this chunk per bucket, then the running rank
   uint32_t* lb = seg_lds + g.nbk;  // [nbk] (SCATTER) where the chunk's touches of a bucket start
-  const int b = blockIdx.x / g.cpb, c = blockIdx.x - b * g.cpb;
+  int64_t b;
+  int c;
+  if (!seg_map(blockIdx.x, g.cpb, g.n_batches, SCATTER ? g.xcd : 0, b, c)) return;
   const int64_t bp = g.bat_pos[b];
   const int64_t p0 = bp + (int64_t)c * g.S;
   int64_t p1 = p0 + g.S;
@@ -611,12 +667,8 @@ __global__ __launch_bounds__(kBlock) void k_seg_chunks(CsrView X, SegGeo g, uint
   if (p0 >= p1) return;  // the whole workgroup
   for (int i = threadIdx.x; i < g.nbk; i += kBlock) lh[i] = 0;
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-  for (int64_t p = p0 + wave; p < p1; p += kWavesPerBlock) {
-    const int64_t q0 = g.rowstart[p];
-    const int m = (int)(g.toff[p + 1] - g.toff[p]);
-    for (int q = lane; q < m; q += kWave) atomicAdd(&lh[(uint32_t)X.indices[q0 + q] >> g.fl], 1u);
-  }
+  const int fl = g.fl;
+  seg_walk_rows(X, g, p0, p1, [&](uint32_t j, int, int64_t) { atomicAdd(&lh[j >> fl], 1u); });
   __syncthreads();
   const size_t cell0 = (size_t)b * g.nbk;
   if (!SCATTER) {
@@ -630,18 +682,12 @@ __global__ __launch_bounds__(kBlock) void k_seg_chunks(CsrView X, SegGeo g, uint
     lh[i] = 0;
   }
   __syncthreads();
-  const uint32_t lowmask = (1u << g.fl) - 1;
-  for (int64_t p = p0 + wave; p < p1; p += kWavesPerBlock) {
-    const int64_t q0 = g.rowstart[p];
-    const int m = (int)(g.toff[p + 1] - g.toff[p]);
-    const uint64_t hi = (uint64_t)(p - bp) << kSegPosBits;
-    for (int q = lane; q < m; q += kWave) {
-      const uint32_t j = (uint32_t)X.indices[q0 + q];
-      const uint32_t bk = j >> g.fl;
-      const uint32_t slot = lb[bk] + atomicAdd(&lh[bk], 1u);
-      items[slot] = ((uint64_t)(j & lowmask) << kSegFlShift) | hi | (uint64_t)q;
-    }
-  }
+  const uint32_t lowmask = (1u << fl) - 1;
+  seg_walk_rows(X, g, p0, p1, [&](uint32_t j, int q, int64_t p) {
+    const uint32_t bk = j >> fl;
+    const uint32_t slot = lb[bk] + atomicAdd(&lh[bk], 1u);
+    items[slot] = ((uint64_t)(j & lowmask) << kSegFlShift) | ((uint64_t)(p - bp) << kSegPosBits) | (uint64_t)q;
+  });
 }
 
 __global__ void k_seg_maxcell(int64_t cells, const uint32_t* __restrict__ cellcnt, unsigned int* __restrict__ out) {
@@ -705,15 +751,19 @@ __device__ __forceinline__ void seg_block_scan_n(uint64_t (&v)[NW], uint64_t (*s
 }
 
 // one workgroup per cell: flags of the single-touch features (thr = 2), the cell's column-phase features and touches
+template <int IPT>  // items per thread: the workgroup holds up to kBlock * IPT touches of its cell
 __global__ __launch_bounds__(kBlock) void k_seg_classify(int nbk, int fl, int thr, const uint32_t* __restrict__ cellptr,
                                                           const uint64_t* __restrict__ items, const int64_t* __restrict__ bat_pos,
                                                           const int64_t* __restrict__ toff, uint8_t* __restrict__ single,
                                                           uint64_t* __restrict__ cellUT, int by_count, uint16_t* __restrict__ cls,
-                                                          unsigned long long* __restrict__ n_heavy) {
+                                                          unsigned long long* __restrict__ n_heavy, int64_t n_batches, int xcd) {
   extern __shared__ uint32_t seg_lds[];
   __shared__ uint64_t sh[kWavesPerBlock];
   __shared__ uint32_t cl[kCntClasses];  // column-phase features of the cell per touch-count class
-  const int64_t cell = blockIdx.x;
+  int64_t b_;
+  int part_;
+  if (!seg_map(blockIdx.x, nbk, n_batches, xcd, b_, part_)) return;
+  const int64_t cell = b_ * nbk + part_;
   const uint32_t i0 = cellptr[cell];
   const int n = (int)(cellptr[cell + 1] - i0);
   if (n == 0) {
@@ -725,9 +775,9 @@ __global__ __launch_bounds__(kBlock) void k_seg_classify(int nbk, int fl, int th
   const int NB = 1 << fl;
   for (int i = threadIdx.x; i < NB; i += kBlock) seg_lds[i] = 0;
   __syncthreads();
-  uint64_t it[kSegCap / kBlock];
+  uint64_t it[IPT];
 #pragma unroll
-  for (int e = 0; e < kSegCap / kBlock; ++e) {
+  for (int e = 0; e < IPT; ++e) {
     const int idx = threadIdx.x + e * kBlock;
     if (idx < n) {
       it[e] = items[i0 + idx];
@@ -738,7 +788,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_classify(int nbk, int fl, int th
   if (single) {
     const int64_t bp = bat_pos[cell / nbk];
 #pragma unroll
-    for (int e = 0; e < kSegCap / kBlock; ++e) {
+    for (int e = 0; e < IPT; ++e) {
       const int idx = threadIdx.x + e * kBlock;
       if (idx < n && seg_lds[it[e] >> kSegFlShift] == 1u)
         single[toff[bp + (int64_t)((it[e] >> kSegPosBits) & kSegMask26)] + (int64_t)(it[e] & kSegMask26)] = 1;
@@ -795,31 +845,35 @@ struct SegOut {
 };
 
 // one workgroup per cell: every column-phase touch to its place in (feature, position) order
+template <int IPT>
 __global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl, int thr, const uint32_t* __restrict__ cellptr,
                                                       const uint64_t* __restrict__ items, const int64_t* __restrict__ bat_pos,
                                                       const int64_t* __restrict__ rowstart, const int64_t* __restrict__ toff,
                                                       const uint64_t* __restrict__ cellOff, int by_count,
-                                                      const uint32_t* __restrict__ uoffc, SegOut o) {
+                                                      const uint32_t* __restrict__ uoffc, SegOut o, int64_t n_batches, int xcd) {
   extern __shared__ uint32_t seg_lds[];
   __shared__ uint64_t sh[kWavesPerBlock];
   __shared__ uint64_t sh4[kCntClasses / 4][kWavesPerBlock];
   __shared__ uint32_t uo[kCntClasses];
-  const int64_t cell = blockIdx.x;
+  int64_t b_;
+  int part_;
+  if (!seg_map(blockIdx.x, nbk, n_batches, xcd, b_, part_)) return;
+  const int64_t cell = b_ * nbk + part_;
   const uint32_t i0 = cellptr[cell];
   const int n = (int)(cellptr[cell + 1] - i0);
   if (n == 0) return;
   const int NB = 1 << fl;
   uint32_t* A = seg_lds;        // [NB] count | first slot among all touches of the cell << 16
   uint32_t* Bv = seg_lds + NB;  // [NB] first column-phase touch | column-phase feature index << 16
-  uint32_t* ps = seg_lds + 2 * NB;  // [kSegCap] positions, grouped by feature
-  uint16_t* Cv = reinterpret_cast<uint16_t*>(seg_lds + 2 * NB + kSegCap);  // [NB] the feature's rank among the cell's features of its class
+  uint32_t* ps = seg_lds + 2 * NB;  // [kBlock * IPT] positions, grouped by feature
+  uint16_t* Cv = reinterpret_cast<uint16_t*>(seg_lds + 2 * NB + kBlock * IPT);  // [NB] the feature's rank among the cell's features of its class
   if (threadIdx.x < kCntClasses) uo[threadIdx.x] = uoffc[cell * kCntClasses + threadIdx.x];
   for (int i = threadIdx.x; i < NB; i += kBlock) A[i] = 0;
   __syncthreads();
-  uint64_t it[kSegCap / kBlock];
-  uint32_t rk[kSegCap / kBlock];
+  uint64_t it[IPT];
+  uint32_t rk[IPT];
 #pragma unroll
-  for (int e = 0; e < kSegCap / kBlock; ++e) {
+  for (int e = 0; e < IPT; ++e) {
     const int idx = threadIdx.x + e * kBlock;
     if (idx < n) {
       it[e] = items[i0 + idx];
@@ -868,7 +922,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl,
   }
   __syncthreads();
 #pragma unroll
-  for (int e = 0; e < kSegCap / kBlock; ++e) {
+  for (int e = 0; e < IPT; ++e) {
     const int idx = threadIdx.x + e * kBlock;
     if (idx < n) ps[(A[it[e] >> kSegFlShift] >> 16) + rk[e]] = (uint32_t)((it[e] >> kSegPosBits) & kSegMask26);
   }
@@ -880,7 +934,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl,
   const int64_t ub0 = (int64_t)(cellOff[b * nbk] >> 32);  // the batch's first feature
   const int32_t jbase = (int32_t)((cell - b * nbk) << fl);
 #pragma unroll
-  for (int e = 0; e < kSegCap / kBlock; ++e) {
+  for (int e = 0; e < IPT; ++e) {
     const int idx = threadIdx.x + e * kBlock;
     if (idx >= n) continue;
     const uint32_t bin = (uint32_t)(it[e] >> kSegFlShift);
@@ -1088,10 +1142,13 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
         g.rowstart = rowstart.as<int64_t>();
         g.toff = toff.as<int64_t>();
         static const int s_env = getenv("NFM_SEG_S") ? atoi(getenv("NFM_SEG_S")) : 0;
-        g.S = s_env > 0 ? s_env : 128;  // samples per chunk workgroup
+        g.S = s_env > 0 ? s_env : 256;  // samples per chunk workgroup: 64 rows per wavefront and trip (seg_walk_rows)
         g.cpb = (int)((P.max_batch + g.S - 1) / g.S);
         g.fl = fl;
         g.nbk = (int)nbk;
+        g.n_batches = P.n_batches;
+        static const int xcd = !(getenv("NFM_SEG_XCD") && atoi(getenv("NFM_SEG_XCD")) == 0) ? 1 : 0;
+        g.xcd = xcd;
         const int64_t chunk_blocks = P.n_batches * g.cpb;
         NFM_CHECK(chunk_blocks < ((int64_t)1 << 31), NFM_ERR_UNSUPPORTED, "too many sample chunks");
         hipLaunchKernelGGL((k_seg_chunks<false>), dim3((unsigned)chunk_blocks), dim3(kBlock), sizeof(uint32_t) * 2 * nbk, st, X, g,
@@ -1121,17 +1178,23 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
           NFM_HIP_CHECK(hipMemsetAsync(nheavy.p, 0, sizeof(unsigned long long), st));
           NFM_HIP_CHECK(hipMemsetAsync(cellcnt.p, 0, sizeof(uint32_t) * (cells + 1), st));
           NFM_HIP_CHECK(hipMemsetAsync(cellUT.as<uint64_t>() + cells, 0, sizeof(uint64_t), st));
-          hipLaunchKernelGGL((k_seg_chunks<true>), dim3((unsigned)chunk_blocks), dim3(kBlock), sizeof(uint32_t) * 2 * nbk, st, X, g,
+          hipLaunchKernelGGL((k_seg_chunks<true>), dim3((unsigned)seg_grid(P.n_batches, g.cpb, xcd)), dim3(kBlock), sizeof(uint32_t) * 2 * nbk, st, X, g,
                              cellcnt.as<uint32_t>(), cellptr.as<uint32_t>(), items.as<uint64_t>());
           if (use_singles) {
             NFM_TRY(P.single.alloc(sizeof(uint8_t) * T));
             NFM_HIP_CHECK(hipMemsetAsync(P.single.p, 0, sizeof(uint8_t) * T, st));
           }
           const size_t NB = (size_t)1 << fl;
-          hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)cells), dim3(kBlock), sizeof(uint32_t) * NB, st, (int)nbk, fl, thr,
-                             cellptr.as<uint32_t>(), items.as<uint64_t>(), P.bat_pos_dev.as<int64_t>(), toff.as<int64_t>(),
-                             use_singles ? P.single.as<uint8_t>() : nullptr, cellUT.as<uint64_t>(), sort_by_count ? 1 : 0,
-                             cls.as<uint16_t>(), nheavy.as<unsigned long long>());
+          auto classify = [&](auto ipt) {
+            constexpr int IPT = decltype(ipt)::value;
+            hipLaunchKernelGGL(k_seg_classify<IPT>, dim3((unsigned)seg_grid(P.n_batches, (int)nbk, xcd)), dim3(kBlock), sizeof(uint32_t) * NB, st, (int)nbk, fl, thr,
+                               cellptr.as<uint32_t>(), items.as<uint64_t>(), P.bat_pos_dev.as<int64_t>(), toff.as<int64_t>(),
+                               use_singles ? P.single.as<uint8_t>() : nullptr, cellUT.as<uint64_t>(), sort_by_count ? 1 : 0,
+                               cls.as<uint16_t>(), nheavy.as<unsigned long long>(), P.n_batches, xcd);
+          };
+          if (h_mx <= 4 * kBlock) classify(std::integral_constant<int, 4>{});
+          else if (h_mx <= 8 * kBlock) classify(std::integral_constant<int, 8>{});
+          else classify(std::integral_constant<int, kSegCap / kBlock>{});
           hipLaunchKernelGGL(k_seg_unit_offsets, dim3((unsigned)P.n_batches), dim3(kBlock), 0, st, (int)nbk, cls.as<uint16_t>(),
                              uoffc.as<uint32_t>());
           tmp_bytes = 0;
@@ -1158,11 +1221,18 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
           NFM_TRY(P.ucnt_s.alloc(sizeof(int32_t) * std::max<int64_t>(U, 1)));
           SegOut so{P.tpos.as<int32_t>(), P.tx.as<double>(), want_tq ? P.tq.as<int64_t>() : nullptr, P.ucol.as<int32_t>(),
                     P.uptr.as<int64_t>(), P.ucol_s.as<int32_t>(), P.ubeg_s.as<int64_t>(), P.ucnt_s.as<int32_t>()};
-          if (TM > 0)
-            hipLaunchKernelGGL(k_seg_fill, dim3((unsigned)cells), dim3(kBlock), sizeof(uint32_t) * (2 * NB + kSegCap) + sizeof(uint16_t) * NB,
-                               st, X, (int)nbk, fl, thr, cellptr.as<uint32_t>(), items.as<uint64_t>(), P.bat_pos_dev.as<int64_t>(),
-                               rowstart.as<int64_t>(), toff.as<int64_t>(), cellOff.as<uint64_t>(), sort_by_count ? 1 : 0,
-                               uoffc.as<uint32_t>(), so);
+          auto fill = [&](auto ipt) {
+            constexpr int IPT = decltype(ipt)::value;
+            hipLaunchKernelGGL(k_seg_fill<IPT>, dim3((unsigned)seg_grid(P.n_batches, (int)nbk, xcd)), dim3(kBlock),
+                               sizeof(uint32_t) * (2 * NB + (size_t)kBlock * IPT) + sizeof(uint16_t) * NB, st, X, (int)nbk, fl, thr,
+                               cellptr.as<uint32_t>(), items.as<uint64_t>(), P.bat_pos_dev.as<int64_t>(), rowstart.as<int64_t>(),
+                               toff.as<int64_t>(), cellOff.as<uint64_t>(), sort_by_count ? 1 : 0, uoffc.as<uint32_t>(), so, P.n_batches, xcd);
+          };
+          if (TM > 0) {
+            if (h_mx <= 4 * kBlock) fill(std::integral_constant<int, 4>{});
+            else if (h_mx <= 8 * kBlock) fill(std::integral_constant<int, 8>{});
+            else fill(std::integral_constant<int, kSegCap / kBlock>{});
+          }
           NFM_HIP_CHECK(hipGetLastError());
           NFM_HIP_CHECK(hipStreamSynchronize(st));  // the temporaries of this block go out of scope
         }
