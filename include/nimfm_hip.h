@@ -143,6 +143,12 @@ typedef struct nfm_stream nfm_stream;
 int32_t nfm_stream_open(nfm_ctx* ctx, const char* x_path, const char* y_path /*or NULL*/, nfm_stream** out);
 int32_t nfm_stream_shape(const nfm_stream* s, int64_t* n_samples, int64_t* n_features, int64_t* nnz, int64_t* n_fields);
 int32_t nfm_stream_load_rows(nfm_stream* s, int64_t row_begin, int64_t row_end, nfm_dataset** out);
+/* Starts loading rows [row_begin, row_end) in the background (a thread and a HIP stream of the stream object's own: file
+ * walk, upload and split run beside the caller's epoch over the current block) and returns at once; the next
+ * nfm_stream_load_rows of exactly that range hands the block over (and reports the load's error, if any), any other range
+ * drops it.  One block ahead at most.  The reference's readCache (tensor/sparse_stream.nim:232-270) reads the next block
+ * only when the epoch loop asks for it (optimizer/sgd_multi.nim:83-97). */
+int32_t nfm_stream_prefetch_rows(nfm_stream* s, int64_t row_begin, int64_t row_end);
 int32_t nfm_stream_close(nfm_stream* s);
 /* convertSVMLightFile (dataset.nim:1017-1097): svmlight text -> STREAMCSR file +
  * raw float64 label file; the text is parsed on the GPU. */

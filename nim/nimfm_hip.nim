@@ -79,6 +79,7 @@ proc nfm_dataset_load_stream*(ctx: NfmCtx, xPath, yPath: cstring, outp: ptr NfmD
 proc nfm_stream_open*(ctx: NfmCtx, xPath, yPath: cstring, outp: ptr NfmStream): int32
 proc nfm_stream_shape*(s: NfmStream, nSamples, nFeatures, nnz, nFields: ptr int64): int32
 proc nfm_stream_load_rows*(s: NfmStream, rowBegin, rowEnd: int64, outp: ptr NfmDataset): int32
+proc nfm_stream_prefetch_rows*(s: NfmStream, rowBegin, rowEnd: int64): int32
 proc nfm_stream_close*(s: NfmStream): int32
 proc nfm_convert_svmlight*(ctx: NfmCtx, fIn, fOutX, fOutY: cstring): int32
 proc nfm_dataset_shape*(ds: NfmDataset, nSamples, nFeatures, nnz, nFields: ptr int64): int32

@@ -41,7 +41,7 @@ SYMBOLS = [
     "nfm_rng_randomize", "nfm_rng_random_normal", "nfm_rng_shuffle",
     "nfm_dp_unique_id", "nfm_dp_create", "nfm_dp_create_local", "nfm_dp_info", "nfm_dp_destroy", "nfm_opt_set_dp", "nfm_opt_set_dp_combine", "nfm_opt_set_touch_cap",
     "nfm_opt_set_shuffle", "nfm_opt_get_perm", "nfm_opt_announce_perm",
-    "nfm_stream_open", "nfm_stream_shape", "nfm_stream_load_rows", "nfm_stream_close",
+    "nfm_stream_open", "nfm_stream_shape", "nfm_stream_load_rows", "nfm_stream_prefetch_rows", "nfm_stream_close",
 ]
 
 
@@ -175,6 +175,7 @@ def lib():
         "nfm_stream_open": [vp, C.c_char_p, C.c_char_p, pp],
         "nfm_stream_shape": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
         "nfm_stream_load_rows": [vp, i64, i64, pp],
+        "nfm_stream_prefetch_rows": [vp, i64, i64],
         "nfm_stream_close": [vp],
     }
     for name, args in sig.items():

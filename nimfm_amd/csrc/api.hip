@@ -6,9 +6,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <memory>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "dp.h"
@@ -411,6 +414,60 @@ int32_t nfm_dataset_load_stream(nfm_ctx* ctx, const char* x_path, const char* y_
 struct nfm_stream {
   nfm_ctx* ctx = nullptr;
   StreamFile f;
+  // One row block loaded ahead (nfm_stream_prefetch_rows) by a thread of the stream object's own -- ONE thread for all
+  // blocks: the device-memory cache hands a thread its own released blocks back without a device-wide wait (util.hip),
+  // so the block-sized staging buffer of the previous load is reused while the caller's epoch is still running -- on a
+  // HIP stream of its own.
+  std::thread worker;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool job = false, busy = false, quit = false;
+  hipStream_t pf_stream = nullptr;
+  bool pf_active = false;
+  int64_t pf_r0 = 0, pf_r1 = 0;
+  int pf_rc = NFM_OK;
+  std::string pf_err;
+  std::unique_ptr<IngestResult> pf_res;
+  void run() {
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+      busy = false;
+      pf_rc = NFM_ERR_HIP;
+      pf_err = "the prefetch thread could not select the context's device";
+      cv.notify_all();
+      return;
+    }
+    std::unique_lock<std::mutex> lk(mu);
+    while (true) {
+      cv.wait(lk, [&] { return job || quit; });
+      if (quit) return;
+      job = false;
+      lk.unlock();
+      const int rc = f.load_rows(ctx, pf_r0, pf_r1, pf_res.get(), pf_stream);
+      std::string err = rc != NFM_OK ? nfm_last_error() : "";  // (the message lives in this thread's slot)
+      lk.lock();
+      pf_rc = rc;
+      pf_err = err;
+      busy = false;
+      cv.notify_all();
+    }
+  }
+  void join() {  // until the block being loaded, if any, is there
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return !busy; });
+  }
+  ~nfm_stream() {
+    join();
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+    }
+    cv.notify_all();
+    if (worker.joinable()) worker.join();
+    pf_res.reset();
+    if (pf_stream) (void)hipStreamDestroy(pf_stream);
+  }
 };
 
 int32_t nfm_stream_open(nfm_ctx* ctx, const char* x_path, const char* y_path, nfm_stream** out) {
@@ -431,15 +488,50 @@ int32_t nfm_stream_shape(const nfm_stream* s, int64_t* n_samples, int64_t* n_fea
   return NFM_OK;
 }
 
+int32_t nfm_stream_prefetch_rows(nfm_stream* s, int64_t row_begin, int64_t row_end) {
+  NFM_CHECK(s, NFM_ERR_INVALID, "null stream");
+  NFM_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= s->f.n, NFM_ERR_INVALID, "rows [%lld,%lld) outside [0,%lld)",
+            (long long)row_begin, (long long)row_end, (long long)s->f.n);
+  NFM_TRY(use_device(s->ctx));
+  s->join();  // at most one block ahead; an unclaimed one is dropped
+  s->pf_res.reset();
+  if (!s->pf_stream) NFM_HIP_CHECK(hipStreamCreateWithFlags(&s->pf_stream, hipStreamNonBlocking));
+  s->pf_active = true;
+  s->pf_r0 = row_begin;
+  s->pf_r1 = row_end;
+  s->pf_rc = NFM_OK;
+  s->pf_err.clear();
+  s->pf_res.reset(new IngestResult());
+  if (!s->worker.joinable()) s->worker = std::thread([s]() { s->run(); });
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    NFM_CHECK(!s->quit, NFM_ERR_HIP, "the prefetch thread could not select device %d", s->ctx->device);
+    s->job = true;
+    s->busy = true;
+  }
+  s->cv.notify_all();
+  return NFM_OK;
+}
+
 int32_t nfm_stream_load_rows(nfm_stream* s, int64_t row_begin, int64_t row_end, nfm_dataset** out) {
   NFM_CHECK(s && out, NFM_ERR_INVALID, "null argument");
   NFM_TRY(use_device(s->ctx));
+  s->join();
+  if (s->pf_active && s->pf_r0 == row_begin && s->pf_r1 == row_end) {  // the block asked for ahead
+    s->pf_active = false;
+    std::unique_ptr<IngestResult> r(std::move(s->pf_res));
+    if (s->pf_rc != NFM_OK) return set_error(s->pf_rc, "%s", s->pf_err.c_str());
+    return dataset_from_ingest(s->ctx, *r, r->n_fields > 0, -1, -1, out);
+  }
+  s->pf_active = false;
+  s->pf_res.reset();
   IngestResult r;
   NFM_TRY(s->f.load_rows(s->ctx, row_begin, row_end, &r));
   return dataset_from_ingest(s->ctx, r, r.n_fields > 0, -1, -1, out);
 }
 
 int32_t nfm_stream_close(nfm_stream* s) {
+  if (s && use_device(s->ctx) != NFM_OK) return NFM_ERR_HIP;
   delete s;
   return NFM_OK;
 }

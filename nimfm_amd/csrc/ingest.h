@@ -34,7 +34,8 @@ struct StreamFile {
   ~StreamFile();
   static int open_file(const char* x_path, const char* y_path, StreamFile* S);
   int offset_of(int64_t r, int64_t* off_out);
-  int load_rows(nfm_ctx* ctx, int64_t r0, int64_t r1, IngestResult* out);  // rows [r0, r1) -> CSR in HBM
+  // rows [r0, r1) -> CSR in HBM; st: the stream the upload and the split run on (default: the context's)
+  int load_rows(nfm_ctx* ctx, int64_t r0, int64_t r1, IngestResult* out, hipStream_t st = nullptr);
 };
 
 // convertSVMLightFile (dataset.nim:1017-1097): text -> STREAMCSR + raw float64 labels

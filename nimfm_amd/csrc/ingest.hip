@@ -793,9 +793,9 @@ int StreamFile::offset_of(int64_t r, int64_t* off_out) {
   return NFM_OK;
 }
 
-int StreamFile::load_rows(nfm_ctx* ctx, int64_t r0, int64_t r1, IngestResult* out) {
+int StreamFile::load_rows(nfm_ctx* ctx, int64_t r0, int64_t r1, IngestResult* out, hipStream_t st_in) {
   NFM_CHECK(r0 >= 0 && r0 <= r1 && r1 <= n, NFM_ERR_INVALID, "rows [%lld,%lld) outside [0,%lld)", (long long)r0, (long long)r1, (long long)n);
-  hipStream_t st = ctx->stream;
+  hipStream_t st = st_in ? st_in : ctx->stream;  // every copy below is ordered on st (a prefetch runs beside the epoch's stream)
   const int64_t nr = r1 - r0;
   int64_t off0 = 0;
   NFM_TRY(offset_of(r0, &off0));
@@ -815,8 +815,7 @@ int StreamFile::load_rows(nfm_ctx* ctx, int64_t r0, int64_t r1, IngestResult* ou
   const int64_t nbytes = pos - off0, nz = acc;
   DevBuf raw, status;
   NFM_TRY(raw.alloc((size_t)nbytes + 64));
-  NFM_HIP_CHECK(hipStreamSynchronize(st));
-  if (nbytes) NFM_HIP_CHECK(hipMemcpy(raw.p, map + off0, (size_t)nbytes, hipMemcpyHostToDevice));
+  if (nbytes) NFM_HIP_CHECK(hipMemcpyAsync(raw.p, map + off0, (size_t)nbytes, hipMemcpyHostToDevice, st));
   NFM_TRY(out->indptr.alloc(sizeof(int64_t) * (nr + 1)));
   NFM_HIP_CHECK(hipMemcpyAsync(out->indptr.p, indptr.data(), sizeof(int64_t) * (nr + 1), hipMemcpyHostToDevice, st));
   NFM_TRY(out->indices.alloc(sizeof(int32_t) * std::max<int64_t>(nz, 1)));
@@ -843,7 +842,10 @@ int StreamFile::load_rows(nfm_ctx* ctx, int64_t r0, int64_t r1, IngestResult* ou
     const bool ok = fseeko(f, (off_t)(8 * r0), SEEK_SET) == 0 && (nr == 0 || fread(yb.data(), 8, (size_t)nr, f) == (size_t)nr);
     fclose(f);
     NFM_CHECK(ok, NFM_ERR_INVALID, "%s holds fewer than %lld labels", y_path.c_str(), (long long)r1);
-    if (nr) NFM_HIP_CHECK(hipMemcpy(out->y.p, yb.data(), (size_t)(8 * nr), hipMemcpyHostToDevice));
+    if (nr) {
+      NFM_HIP_CHECK(hipMemcpyAsync(out->y.p, yb.data(), (size_t)(8 * nr), hipMemcpyHostToDevice, st));
+      NFM_HIP_CHECK(hipStreamSynchronize(st));  // yb goes out of scope
+    }
   } else {
     NFM_HIP_CHECK(hipMemsetAsync(out->y.p, 0, sizeof(double) * std::max<int64_t>(nr, 1), st));
     NFM_HIP_CHECK(hipStreamSynchronize(st));

@@ -646,6 +646,11 @@ class StreamCSRDataset:
     def blocks(self):
         return [(r0, min(self.nSamples, r0 + self.cacheRows)) for r0 in range(0, self.nSamples, self.cacheRows)]
 
+    def prefetch(self, r0, r1):
+        """starts loading rows [r0, r1) beside whatever runs on the context's stream (nfm_stream_prefetch_rows); the next
+        load(r0, r1) hands the block over"""
+        capi.check(capi.lib().nfm_stream_prefetch_rows(self.h, r0, r1))
+
     def load(self, r0, r1):
         """rows [r0, r1) as a resident dataset"""
         h = C.c_void_p()
@@ -664,7 +669,8 @@ class StreamCSRDataset:
 def newStreamCSRDataset(f, fY=None, ctx=None, cacheRows=None):
     """dataset.nim:170-174 newStreamCSRDataset (+ loadStreamLabel, :1007-1014, when fY is given).  cacheRows = None:
     the STREAMCSR / STREAMCSRFIELD file is made resident in HBM as a whole; cacheRows = r: a StreamCSRDataset that
-    keeps at most r rows resident (the reference's cacheSize, in rows).  -> (dataset, y)"""
+    keeps at most r rows resident per block (the reference's cacheSize, in rows; fit loads the next block while the
+    current one trains, so two blocks are resident at a time).  -> (dataset, y)"""
     ctx = ctx or default_context()
     if cacheRows is not None:
         ds = StreamCSRDataset(f, cacheRows, ctx, fY)
@@ -1023,10 +1029,13 @@ def _fit_stream(self, X, y, fm, maxThreads=None, callback=None):
     n = X.nSamples
     isConverged = False
     self.history = []
+    blocks = X.blocks()
     for epoch in range(self.maxIter):
         viol = runningLoss = 0.0
-        for r0, r1 in X.blocks():
+        for bi, (r0, r1) in enumerate(blocks):
             blk = X.load(r0, r1)
+            if len(blocks) > 1 and os.environ.get("NIMFM_STREAM_PREFETCH", "1") != "0":  # the next block (the next epoch's first one after the last) is read, uploaded and split
+                X.prefetch(*blocks[(bi + 1) % len(blocks)])  # while this one trains: two blocks resident at a time
             blk.set_targets(y[r0:r1])
             ls, vs = self._epoch(blk, None, 0, r1 - r0)
             runningLoss += ls

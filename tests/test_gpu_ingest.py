@@ -241,6 +241,34 @@ def test_stream_file_in_row_blocks(tmp_path):
     assert abs(fm.intercept - b) < 1e-11
 
 
+def test_stream_block_loaded_ahead(tmp_path):
+    """nfm_stream_prefetch_rows: the block asked for ahead is the block a plain load returns; asking for another range
+    drops it; an unclaimed one is released with the stream object."""
+    rng = np.random.default_rng(4)
+    n, d = 5000, 300
+    text = random_csr_text(rng, n, d, 0.05, wide=False)
+    xb, yb = ingest.convert_svmlight(text)
+    (tmp_path / "x.bin").write_bytes(xb)
+    (tmp_path / "y.bin").write_bytes(yb)
+    Xs, _ = nf.newStreamCSRDataset(str(tmp_path / "x.bin"), str(tmp_path / "y.bin"), cacheRows=1024)
+    plain = [Xs.load(r0, r1).to_host() for r0, r1 in Xs.blocks()]
+    for bi, (r0, r1) in enumerate(Xs.blocks()):  # each block ahead of its load, the next one requested before this one is used
+        if bi == 0:
+            Xs.prefetch(r0, r1)
+        blk = Xs.load(r0, r1)
+        nxt = Xs.blocks()[(bi + 1) % len(Xs.blocks())]
+        Xs.prefetch(*nxt)
+        got = blk.to_host()
+        for a, b in zip(got[:3], plain[bi][:3]):
+            assert np.array_equal(a, b)
+    other = Xs.load(1024, 2048)  # not the range asked for ahead: loaded in line, the other block dropped
+    assert np.array_equal(other.to_host()[1], plain[1][1])
+    Xs.prefetch(0, 1024)
+    with pytest.raises(ValueError):
+        Xs.prefetch(0, n + 1)
+    del Xs  # an unclaimed block goes with the stream object
+
+
 def test_reference_literal_dataset_through_the_device(tmp_path):
     """The literal 4 x 6 matrix and targets of the reference's dataset suite (tests/test_dataset.nim:124-128, committed as
     tests/golden/ref_dataset_literal.json) pushed through every loader of this path, as its tests do (:130-156):
