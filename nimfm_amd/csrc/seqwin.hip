@@ -167,9 +167,15 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
   double* nwl = gwl + (ADA ? mc : 0);                 // AdaGrad: [mc] g_norm
   int* jl = reinterpret_cast<int*>(nwl + (ADA ? mc : 0));  // [mc] feature ids
   int* pl = jl + mc;                                       // [mc] previous position with the same feature
-  unsigned* cnt = reinterpret_cast<unsigned*>(pl + mc);    // [W] completion counters as last seen
+  int* ll = pl + mc;                                       // [mc] 1: the row comes from its writer's recipe (below), not from memory
+  unsigned* cnt = reinterpret_cast<unsigned*>(ll + mc);    // [W] completion counters as last seen
   for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
   double loss_acc = 0.0, viol_acc = 0.0;
+  auto fw_area = [&](int64_t u_) { return a.fw + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kFwSlot; };
+  // (the forwarding areas are laid out for 64 entries of up to 64 factors: entry q's row at stride Kp)
+  auto fw_row = [&](ull* base, int v, int q) { return base + kFwRows + ((size_t)(v * kWave + q) * Kp + s) * 2; };
+  auto fw_lin = [&](ull* base, int v, int q) { return base + kFwLin + (size_t)(v * kWave + q) * 2; };
+  auto res_of = [&](int64_t u_) { return a.res + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kResWords; };
 
   for (int64_t u = slot; u < a.n_seg; u += W) {
     const int64_t pos = a.seg0 + u, pa = a.begin + pos;
@@ -182,16 +188,32 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
     const int par = (int)((u >> lgW) & 1);
     ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
     const ull* rp = a.res + (size_t)(slot * 2 + par) * kResWords;
+    // the sample's first 64 entries also sit one per lane: they are the ones that can take the forwarding path
+    const bool e_in = lane < m;
+    const int pq = e_in ? a.prev[q0 + lane] : -1;
+    const int pqu = e_in ? (int)a.prevq[q0 + lane] : 0;
+    const int nq = e_in ? a.next[q0 + lane] : -1;
+    bool near;
+    {
+      const int64_t v = (int64_t)pq - a.seg0;
+      const bool pend = v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW);
+      // a NEAR previous sample (fewer than W positions back, the shared feature among ITS first 64 entries) left the recipe
+      // of the shared row in its forwarding area; every other one is waited for by its counter
+      near = pend && (pos - (int64_t)pq) < W && pqu < kWave;
+    }
+    const ull fwdmask = __ballot(near);
+    const ull hotmask = __ballot(nq >= 0 && ((int64_t)nq - pos) < W);  // rows a near successor will ask the recipe of
     for (int q = lane; q < mc; q += kWave) {
       const bool in = q < m;
       jl[q] = in ? X.indices[q0 + q] : 0;
       vl[q] = in ? X.data[q0 + q] : 0.0;
       pl[q] = in ? a.prev[q0 + q] : -1;
+      ll[q] = (q < kWave && near) ? 1 : 0;
     }
     compiler_fence();
     double* const junk = reinterpret_cast<double*>(a.fw + (size_t)2 * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
 
-    // ---- A. every earlier sample of this launch that shares a feature has written its rows ----
+    // ---- A. every earlier sample of this launch that shares a feature has written its rows (far ones only) ----
     {
       Spin sp;
       bool first = true;
@@ -199,7 +221,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
         bool need = false;
         for (int q = lane; q < m; q += kWave) {
           const int64_t v = (int64_t)pl[q] - a.seg0;
-          if (v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW)) need = true;
+          if (v >= 0 && !ll[q] && cnt[v & (W - 1)] <= (unsigned)(v >> lgW)) need = true;
         }
         if (!__any(need)) break;
         if (!first && sp.wait(a.ctrl)) return;
@@ -234,7 +256,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
 #pragma unroll
       for (int t = 0; t < U; ++t) {
         const int q = qb + t * R + r;
-        const bool in = q < m;
+        const bool in = q < m && !ll[q];  // (a forwarded row is done again in C)
         double p = v_[t];
         if constexpr (ADA) {
           if (it != 1) {
@@ -249,6 +271,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
         Tl[(size_t)q * Kp + s] = vl[q] * (sP * p);
       }
     }
+    const double denw = itp * O.eta0 * O.alpha;
     for (int q = lane; q < m; q += kWave) {
       const int j = jl[q];
       double wv = ld_f64(M.w + j);
@@ -257,9 +280,8 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
           const double gw = ld_f64(O.Gw + j), nw_ = ld_f64(O.Nw + j);
           gwl[q] = gw;
           nwl[q] = nw_;
-          if (it != 1) {
-            const double denom = itp * O.eta0 * O.alpha;
-            const double nv = -O.eta0 * gw / (denom + sqrt(nw_));
+          if (it != 1 && !ll[q]) {
+            const double nv = -O.eta0 * gw / (denw + sqrt(nw_));
             viol_acc += fabs(wv - nv);
             st_f64(M.w + j, nv);
             wv = nv;
@@ -269,6 +291,124 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       wl[q] = wv;
     }
     compiler_fence();
+
+    // ---- B2. near dependencies: the writer's recipe + the conductor's dL for the WRITER's sample -> the row as the writer
+    // will (or did) write it, formed here with the writer's own arithmetic (no wait for its update, store and counter) ----
+    if (fwdmask) {
+      const bool mine = (fwdmask >> lane) & 1ull;  // lane = entry
+      const int64_t upl = (int64_t)pq - a.seg0;
+      const unsigned tagl = (unsigned)(upl + 1);
+      ull* srcl = fw_area(mine ? upl : 0);
+      const ull* rsrcl = res_of(mine ? upl : 0);
+      double wu = 0.0, gwu = 0.0, nwu = 0.0, vsl = 0.0, dLl = 0.0;
+      bool okl = true;
+      auto load_lin = [&]() {
+        okl = true;
+        if (mine) {
+          okl = fw_load(fw_lin(srcl, 0, pqu), tagl, wu);
+          if (ADA && M.fit_linear) {
+            okl = fw_load(fw_lin(srcl, 1, pqu), tagl, gwu) && okl;
+            okl = fw_load(fw_lin(srcl, 2, pqu), tagl, nwu) && okl;
+          }
+          okl = fw_load(fw_lin(srcl, 3, pqu), tagl, vsl) && okl;
+        }
+      };
+      load_lin();
+      double sPul = 1.0, etaPul = 0.0, sPnul = 1.0, swul = 1.0, etawul = 0.0;
+      if constexpr (!ADA) {  // the writers' scales and step sizes: functions of their step counters alone
+        if (mine) {
+          sPul = a.scales[2 * (a.seg0 + upl)];
+          swul = a.scales[2 * (a.seg0 + upl) + 1];
+          etaPul = dev::get_eta(O.sched, O.eta0, O.power, O.beta, (double)(a.it0 + upl));
+          etawul = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, (double)(a.it0 + upl));
+          sPnul = sPul * (1 - etaPul * O.beta);
+        }
+      }
+      {
+        Spin sp;
+        while (true) {  // the writers' dL (their recipes were posted before it could exist)
+          bool ok = true;
+          if (mine) ok = fw_load(rsrcl, tagl, dLl);
+          if (!__all(okl)) load_lin();
+          if (__all(ok)) break;
+          if (sp.wait(a.ctrl)) return;
+        }
+      }
+      {
+        Spin sp;
+        while (!__all(okl)) {
+          if (sp.wait(a.ctrl)) return;
+          load_lin();
+        }
+      }
+      for (ull mk = fwdmask; mk; mk &= mk - 1) {
+        const int q = __builtin_ctzll(mk);
+        const int64_t up = (int64_t)__builtin_amdgcn_readlane(pq, q) - a.seg0;
+        const unsigned tag = (unsigned)(up + 1);
+        ull* src = fw_area(up);
+        const int qu = __builtin_amdgcn_readlane(pqu, q);
+        double a1u, pv, gv = 0.0, nv = 0.0;
+        {
+          Spin sp;
+          while (true) {
+            bool ok = fw_load(src + (size_t)s * 2, tag, a1u);
+            ok = fw_load(fw_row(src, 0, qu), tag, pv) && ok;
+            if constexpr (ADA) {
+              ok = fw_load(fw_row(src, 1, qu), tag, gv) && ok;
+              ok = fw_load(fw_row(src, 2, qu), tag, nv) && ok;
+            }
+            if (__all(ok)) break;
+            if (sp.wait(a.ctrl)) return;
+          }
+        }
+        const double vsu = dev::shfl_d(vsl, q), dLu = dev::shfl_d(dLl, q);
+        const size_t e = (size_t)jl[q] * Kp + s;
+        double p;
+        if constexpr (ADA) {  // the writer's updateG of this row (adagrad.nim:113-134), then this sample's update() of it
+          const double grad = dLu * (vsu * (a1u - pv * vsu));
+          const double g = gv + grad, n = nv + grad * grad;
+          p = pv;
+          if (it != 1) {
+            p = dev::adagrad_param(g, n, O.eta0, tmpP);
+            if (r == 0) {
+              viol_acc += fabs(pv - p);
+              st_f64(M.P + e, p);
+            }
+          }
+          Gl[(size_t)q * Kp + s] = g;
+          Nl[(size_t)q * Kp + s] = n;
+        } else {  // the writer's update() of this row (sgd.nim:217-223), with ITS scale and step size
+          const double sPu = dev::shfl_d(sPul, q), etaPu = dev::shfl_d(etaPul, q), sPnu = dev::shfl_d(sPnul, q);
+          const double pw = sPu * pv;
+          const double update = etaPu * (dLu * (vsu * (a1u - pw * vsu)) + O.beta * pw);
+          p = (pw - update) / sPnu;
+        }
+        Pl[(size_t)q * Kp + s] = p;  // (all row slots write the same value)
+        Tl[(size_t)q * Kp + s] = vl[q] * (sP * p);
+      }
+      if (mine) {  // the linear weight of the shared feature, the same way
+        double wv = wu;
+        if (M.fit_linear) {
+          if constexpr (ADA) {
+            const double gg = dLl * vsl;
+            const double gw = gwu + gg, nw_ = nwu + gg * gg;
+            gwl[lane] = gw;
+            nwl[lane] = nw_;
+            if (it != 1) {
+              const double nv = -O.eta0 * gw / (denw + sqrt(nw_));
+              viol_acc += fabs(wv - nv);
+              st_f64(M.w + jl[lane], nv);
+              wv = nv;
+            }
+          } else {  // fit_linear.nim:41-47 with the writer's scale and step size
+            const double wj = swul * wu;
+            wv = (wj - etawul * (dLl * vsl + O.alpha * wj)) / (swul * (1 - etawul * O.alpha));
+          }
+        }
+        wl[lane] = wv;
+      }
+      compiler_fence();
+    }
 
     // ---- C. the per-factor sums over all entries in storage order (sgd.nim:160-170), their sum over the factors in
     // ascending order (:172-173); every row slot runs them, so every lane ends with its factor's sums ----
@@ -307,6 +447,32 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
         else if (e == MC + 2) val = h2;
         else val = 0.0;
         st_u64(mb + e, mail_bits(val));
+      }
+    }
+    // (after the mailbox: a successor needs them together with this sample's dL, which the conductor forms from the mailbox)
+    if (hotmask) {
+      const unsigned mytag = (unsigned)(u + 1);
+      ull* fwm = fw_area(u);
+      if (r == 0) fw_store(fwm + (size_t)s * 2, mytag, a1);
+      for (ull mk = hotmask; mk; mk &= mk - 1) {
+        const int q = __builtin_ctzll(mk);
+        if (r == 0) {
+          fw_store(fw_row(fwm, 0, q), mytag, Pl[(size_t)q * Kp + s]);
+          if constexpr (ADA) {
+            fw_store(fw_row(fwm, 1, q), mytag, Gl[(size_t)q * Kp + s]);
+            fw_store(fw_row(fwm, 2, q), mytag, Nl[(size_t)q * Kp + s]);
+          }
+        }
+      }
+      if ((hotmask >> lane) & 1ull) {
+        fw_store(fw_lin(fwm, 0, lane), mytag, wl[lane]);
+        if constexpr (ADA) {
+          if (M.fit_linear) {
+            fw_store(fw_lin(fwm, 1, lane), mytag, gwl[lane]);
+            fw_store(fw_lin(fwm, 2, lane), mytag, nwl[lane]);
+          }
+        }
+        fw_store(fw_lin(fwm, 3, lane), mytag, vl[lane]);
       }
     }
 
@@ -1370,7 +1536,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   const int grp = (kWave >> lgKp) * 4;  // rows the general worker handles together (R * U): its arrays are padded to whole groups
   const size_t mcp = (size_t)(m_cap + grp - 1) / grp * grp;
   const size_t rows = mcp * M.Kp;
-  size_t lds_worker = sizeof(double) * ((ada ? 4 : 2) * rows + kWave + (ada ? 4 : 2) * mcp) + sizeof(int) * 2 * mcp + sizeof(unsigned) * W;
+  size_t lds_worker = sizeof(double) * ((ada ? 4 : 2) * rows + kWave + (ada ? 4 : 2) * mcp) + sizeof(int) * 3 * mcp + sizeof(unsigned) * W;
   if (k64) lds_worker = sizeof(double) * ((ada ? 3 : 1) * (size_t)kWave * kWave + kWave) + sizeof(unsigned) * W;
   const size_t lds_cond = sizeof(double) * 2 + sizeof(ull) * (size_t)kWinRing * FW;
   size_t lds_bytes = lds_worker > lds_cond ? lds_worker : lds_cond;
@@ -1390,7 +1556,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     // mailboxes empty, counters and abort word zero
     {
       NFM_HIP_CHECK(hipMemsetAsync(sw->ctl.p, 0, sizeof(unsigned) * (W + 64) + sizeof(double) * 2 * (W + 1), st));
-      if (k64) NFM_HIP_CHECK(hipMemsetAsync(sw->fw.p, 0, sizeof(ull) * kFwSlot * 2 * (size_t)W, st));  // tag 0: nobody's
+      NFM_HIP_CHECK(hipMemsetAsync(sw->fw.p, 0, sizeof(ull) * kFwSlot * 2 * (size_t)W, st));  // tag 0: nobody's
       const int64_t nm = (int64_t)n_fwd;  // the workers' mailboxes "empty"; the conductor's answers carry tags (0: nobody's)
       hipLaunchKernelGGL(k_win_fill, dim3((unsigned)((nm + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sw->mail.as<ull>(), nm, kWinSentinel);
       NFM_HIP_CHECK(hipMemsetAsync(sw->mail.as<ull>() + n_fwd, 0, sizeof(ull) * n_res, st));
