@@ -54,7 +54,7 @@ constexpr ull kWinSentinel = 0x7FF4DEADBEEF0000ull;  // a signalling NaN no arit
 constexpr ull kWinQuietNaN = 0x7FF8000000000000ull;
 constexpr int kWinRing = 8;    // LDS ring slots between the conductor's fetch and chain wavefronts (power of two)
 constexpr int kWinDepth = 8;   // mailboxes the fetch wavefront has requested ahead (must stay < W, see below)
-constexpr int kWinHdr = 4;     // mailbox tail, after the MC term slots: anova sum, target, eta(alpha0) | eta0 (it-1) alpha0, spare
+constexpr int kWinHdr = 4;     // mailbox tail, after the MC term slots: anova sum, target, eta(alpha0) | eta0 (it-1) alpha0, number of chain terms
 constexpr int kWinMaxNL = 5;   // 64-lane loads per mailbox: rows of up to 316 entries
 constexpr long long kWinTimeoutTicks = 400000000ll;  // 4 s of the 100 MHz wall clock without progress: abort
 
@@ -445,7 +445,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
         else if (e == MC) val = tot;
         else if (e == MC + 1) val = y;
         else if (e == MC + 2) val = h2;
-        else val = 0.0;
+        else val = (double)m;  // the number of chain terms
         st_u64(mb + e, mail_bits(val));
       }
     }
@@ -527,6 +527,289 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
           st_f64_at(in ? (ull)(O.N + e) : (ull)(junk + kWave), Nl[(size_t)q * Kp + s] + grad * grad);
         } else {
           const double p = sP * Pl[(size_t)q * Kp + s];
+          const double update = eta_P * (dL * d_ + O.beta * p);
+          viol_acc += in ? fabs(update) : 0.0;
+          st_f64_at(in ? (ull)(M.P + e) : (ull)junk, (p - update) / sPn);
+        }
+      }
+    }
+    if (M.fit_linear) {
+      for (int q = lane; q < m; q += kWave) {
+        const int j = jl[q];
+        if constexpr (ADA) {
+          const double gg = dL * vl[q];
+          st_f64(O.Gw + j, gwl[q] + gg);
+          st_f64(O.Nw + j, nwl[q] + gg * gg);
+        } else {
+          const double wj = sw * wl[q];
+          const double update = eta_w * (dL * vl[q] + O.alpha * wj);
+          viol_acc += fabs(update);
+          st_f64(M.w + j, (wj - update) / swn);
+        }
+      }
+    }
+    // ---- G. rows written: tell the waiters ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
+  }
+  viol_acc = dev::wave_sum(viol_acc);
+  if (lane == 0) {
+    a.partial[2 * slot] = loss_acc;
+    a.partial[2 * slot + 1] = viol_acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// worker for field-aware models (optimizer/sgd_ffm.nim:11-30, 33-106; adagrad_ffm.nim:11-66): the reference's step reads
+// and updates ALL nFields rows of every feature of the sample, so a sample's rows are its "slots" c = q * F + f (entry q,
+// field f) -- in the feature-major layout (common.h) the F rows of a feature are one contiguous run, and a slot is
+// handled like a row of the general worker above.  The prediction is the intercept, then the linear terms in storage
+// order, then ONE term per pair (q1, q2) with j_q1 < j_q2 in the order of the reference's double loop: all of them go to
+// the conductor's chain as mailbox terms.  A slot's derivative is collected over its field's entries in the order that
+// loop visits them (three passes, as in seq.hip).  Dependencies by counters only.
+// ------------------------------------------------------------------------------------------------------------------
+template <int OPT>
+__device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot, double* lds) {
+  const CsrView& X = a.X;
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  constexpr bool ADA = OPT == OPT_ADAGRAD;
+  constexpr int U = 4;
+  const int lane = threadIdx.x;
+  const int Kp = M.Kp, lgK = a.lgKp, k = M.k, F = M.nb, mcap = a.m_cap;
+  const int R = kWave >> lgK, r = lane >> lgK, s = lane & (Kp - 1);
+  const int mcs = (mcap * F + R * U - 1) / (R * U) * (R * U);  // slots, padded to whole groups
+  const int W = a.W, lgW = a.lgW;
+  double* Pl = lds;                                   // [mcs][Kp] stored parameter values of the sample's slots
+  double* Tl = Pl + (size_t)mcs * Kp;                 // [mcs][Kp] the slots' derivative
+  double* Gl = Tl + (size_t)mcs * Kp;                 // AdaGrad: g_sum
+  double* Nl = Gl + (ADA ? (size_t)mcs * Kp : 0);     // AdaGrad: g_norm
+  double* vl = Nl + (ADA ? (size_t)mcs * Kp : 0);     // [mcap] values
+  double* wl = vl + mcap;                             // [mcap] stored linear weights (AdaGrad: after update())
+  double* gwl = wl + mcap;                            // AdaGrad: [mcap]
+  double* nwl = gwl + (ADA ? mcap : 0);               // AdaGrad: [mcap]
+  int* jl = reinterpret_cast<int*>(nwl + (ADA ? mcap : 0));  // [mcap] feature ids
+  int* fl = jl + mcap;                                       // [mcap] fields
+  int* pl = fl + mcap;                                       // [mcap] previous position with the same feature
+  int* fcnt = pl + mcap;                                     // [F] entries of the sample per field
+  int* fent = fcnt + F;                                      // [F][mcap] ... which ones, ascending
+  unsigned* cnt = reinterpret_cast<unsigned*>(fent + (size_t)F * mcap);  // [W]
+  for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
+  double loss_acc = 0.0, viol_acc = 0.0;
+  const ull lt_mask = lane == 0 ? 0ull : (~0ull >> (kWave - lane));
+
+  for (int64_t u = slot; u < a.n_seg; u += W) {
+    const int64_t pos = a.seg0 + u, pa = a.begin + pos;
+    const int64_t i = a.perm ? a.perm[pa] : pa;
+    const int64_t q0 = X.indptr[i];
+    const int m = (int)(X.indptr[i + 1] - q0);
+    const int nsl = m * F;
+    const double y = dev::target_of(X.y[i], M.task);
+    const int64_t it = a.it0 + u;
+    const double itf = (double)it;
+    const int par = (int)((u >> lgW) & 1);
+    ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
+    const ull* rp = a.res + (size_t)(slot * 2 + par) * kResWords;
+    for (int q = lane; q < mcap; q += kWave) {
+      const bool in = q < m;
+      jl[q] = in ? X.indices[q0 + q] : 0;
+      fl[q] = in ? X.fields[q0 + q] : 0;
+      vl[q] = in ? X.data[q0 + q] : 0.0;
+      pl[q] = in ? a.prev[q0 + q] : -1;
+    }
+    compiler_fence();
+    double* const junk = reinterpret_cast<double*>(a.fw + (size_t)2 * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
+
+    // ---- A. every earlier sample of this launch that shares a feature has written its rows ----
+    {
+      Spin sp;
+      bool first = true;
+      while (true) {
+        bool need = false;
+        for (int q = lane; q < m; q += kWave) {
+          const int64_t v = (int64_t)pl[q] - a.seg0;
+          if (v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW)) need = true;
+        }
+        if (!__any(need)) break;
+        if (!first && sp.wait(a.ctrl)) return;
+        first = false;
+        for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
+        compiler_fence();
+      }
+    }
+
+    // ---- B. all F rows of every feature -> LDS (AdaGrad: update() first, adagrad.nim:87-110) ----
+    double sP = 1.0, sw = 1.0;
+    if constexpr (!ADA) {
+      sP = a.scales[2 * pos];
+      sw = a.scales[2 * pos + 1];
+    }
+    const double itp = (double)(it - 1);
+    const double tmpP = O.eta0 * itp * O.beta;
+    auto slot_row = [&](int c) {  // where slot c's row starts (a slot past the end: slot 0)
+      const int cc = c < nsl ? c : 0;
+      const int q = cc / F, f = cc - q * F;
+      return M.row(f, jl[q]) * (size_t)Kp + s;
+    };
+    for (int cb = 0; cb < nsl; cb += R * U) {
+      double v_[U], g_[ADA ? U : 1], n_[ADA ? U : 1];
+      size_t e_[U];
+#pragma unroll
+      for (int t = 0; t < U; ++t) e_[t] = slot_row(cb + t * R + r);
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        v_[t] = ld_f64(M.P + e_[t]);
+        if constexpr (ADA) {
+          g_[t] = ld_f64(O.G + e_[t]);
+          n_[t] = ld_f64(O.N + e_[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        const int c = cb + t * R + r;
+        const bool in = c < nsl;
+        double p = v_[t];
+        if constexpr (ADA) {
+          if (it != 1) {
+            p = dev::adagrad_param(g_[t], n_[t], O.eta0, tmpP);
+            viol_acc += in ? fabs(v_[t] - p) : 0.0;
+            st_f64_at(in ? (ull)(M.P + e_[t]) : (ull)junk, p);
+          }
+          Gl[(size_t)c * Kp + s] = g_[t];
+          Nl[(size_t)c * Kp + s] = n_[t];
+        }
+        Pl[(size_t)c * Kp + s] = p;
+      }
+    }
+    const double denw = itp * O.eta0 * O.alpha;
+    for (int q = lane; q < m; q += kWave) {
+      const int j = jl[q];
+      double wv = ld_f64(M.w + j);
+      if constexpr (ADA) {
+        if (M.fit_linear) {
+          const double gw = ld_f64(O.Gw + j), nw_ = ld_f64(O.Nw + j);
+          gwl[q] = gw;
+          nwl[q] = nw_;
+          if (it != 1) {
+            const double nv = -O.eta0 * gw / (denw + sqrt(nw_));
+            viol_acc += fabs(wv - nv);
+            st_f64(M.w + j, nv);
+            wv = nv;
+          }
+        }
+      }
+      wl[q] = wv;
+    }
+    // the sample's entries by field, ascending (sgd_ffm.nim:24-30 walks a field's entries in this order)
+    for (int f = lane; f < F; f += kWave) {
+      int c_ = 0;
+      for (int q = 0; q < m; ++q)
+        if (fl[q] == f) fent[(size_t)f * mcap + c_++] = q;
+      fcnt[f] = c_;
+    }
+    compiler_fence();
+
+    // ---- C. predictWithGrad, sgd_ffm.nim:11-30.  The pairs (q1, q2), j_q1 < j_q2, q1 outer / q2 inner, add
+    //   result += (P[f2][j1] . P[f1][j2]) x1 x2,   dA[f2][q1] += x1 x2 P[f1][j2],   dA[f1][q2] += x1 x2 P[f2][j1]
+    // so slot (q, f) collects, over the entries q' of field f, x_q x_q' P[field(q)][j_q'] in the order q' < q with
+    // j_q' < j_q (visited as (q', q)), then all q' with j_q' > j_q (visited as (q, q')), then q' > q with j_q' < j_q ----
+    for (int cb = 0; cb < nsl; cb += R) {
+      const int c = cb + r;
+      if (c < nsl) {
+        const int q = c / F, f = c - q * F;
+        const int j = jl[q], fq = fl[q], nf = fcnt[f];
+        const double xq = vl[q];
+        const int* ent = fent + (size_t)f * mcap;
+        double acc = 0.0;
+        for (int ph = 0; ph < 3; ++ph)
+          for (int t = 0; t < nf; ++t) {
+            const int q2 = ent[t];
+            const int j2 = jl[q2];
+            const bool take = ph == 0 ? (q2 < q && j2 < j) : ph == 1 ? (j2 > j) : (q2 > q && j2 < j);
+            if (take) {
+              const double v12 = (j2 < j) ? vl[q2] * xq : xq * vl[q2];
+              acc += v12 * (sP * Pl[((size_t)q2 * F + fq) * Kp + s]);
+            }
+          }
+        Tl[(size_t)c * Kp + s] = acc;
+      }
+    }
+    // the pairs' terms: lane = ordered pair (q1, q2); per pair ONE dot product over the factors, ascending s, times x1,
+    // times x2; the valid ones go to the mailbox behind the linear terms in the order the double loop visits them
+    const int MC = a.FW - kWinHdr;
+    int n_pairs = 0;
+    for (int pb = 0; pb < m * m; pb += kWave) {
+      const int p = pb + lane;
+      bool valid = false;
+      double term = 0.0;
+      if (p < m * m) {
+        const int q1 = p / m, q2 = p - q1 * m;
+        if (jl[q1] < jl[q2]) {
+          valid = true;
+          const double* pa_ = Pl + ((size_t)q1 * F + fl[q2]) * Kp;  // P[f2][j1]
+          const double* pb_ = Pl + ((size_t)q2 * F + fl[q1]) * Kp;  // P[f1][j2]
+          double tmp = 0.0;
+          for (int t = 0; t < k; ++t) tmp += (sP * pa_[t]) * (sP * pb_[t]);
+          term = tmp * vl[q1] * vl[q2];
+        }
+      }
+      const ull mask = __ballot(valid);
+      if (valid) st_u64(mb + m + n_pairs + __popcll(mask & lt_mask), mail_bits(term));
+      n_pairs += __popcll(mask);
+    }
+    const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
+    for (int e = lane; e < a.FW; e += kWave) {
+      double val;
+      bool put = true;
+      if (e < m) val = (sw * wl[e]) * vl[e];
+      else if (e < m + n_pairs) put = false;  // a pair's term, stored above
+      else if (e < MC) val = -0.0;            // (changes no sum)
+      else if (e == MC) val = -0.0;           // no separate interaction sum: the pairs are chain terms
+      else if (e == MC + 1) val = y;
+      else if (e == MC + 2) val = h2;
+      else val = (double)(m + n_pairs);  // the number of chain terms
+      if (put) st_u64(mb + e, mail_bits(val));
+    }
+
+    // ---- D. the step sizes while the conductor works ----
+    double eta_w = 0.0, eta_P = 0.0, sPn = 1.0, swn = 1.0;
+    if constexpr (!ADA) {
+      eta_w = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, itf);
+      eta_P = dev::get_eta(O.sched, O.eta0, O.power, O.beta, itf);
+      sPn = sP * (1 - eta_P * O.beta);
+      swn = sw * (1 - eta_w * O.alpha);
+    }
+
+    // ---- E. {dL, yhat} from the conductor (tagged granules) ----
+    double dL, yh;
+    {
+      Spin sp;
+      double rd;
+      while (true) {
+        const bool ok = fw_load(rp + (size_t)(lane & 1) * 2, (unsigned)(u + 1), rd);
+        if (__all(ok)) break;
+        if (sp.wait(a.ctrl)) return;
+      }
+      dL = dev::shfl_d(rd, 0);
+      yh = dev::shfl_d(rd, 1);
+    }
+    for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);  // (as in the general worker)
+    if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
+
+    // ---- F. update() / updateG() over all slots (the shared loops of sgd.nim:205-243, adagrad.nim:113-134) ----
+    for (int cb = 0; cb < nsl; cb += R * U) {
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        const int c = cb + t * R + r;
+        const bool in = c < nsl;
+        const size_t e = slot_row(c);
+        const double d_ = Tl[(size_t)c * Kp + s];
+        if constexpr (ADA) {
+          const double grad = dL * d_;
+          st_f64_at(in ? (ull)(O.G + e) : (ull)junk, Gl[(size_t)c * Kp + s] + grad);
+          st_f64_at(in ? (ull)(O.N + e) : (ull)(junk + kWave), Nl[(size_t)c * Kp + s] + grad * grad);
+        } else {
+          const double p = sP * Pl[(size_t)c * Kp + s];
           const double update = eta_P * (dL * d_ + O.beta * p);
           viol_acc += in ? fabs(update) : 0.0;
           st_f64_at(in ? (ull)(M.P + e) : (ull)junk, (p - update) / sPn);
@@ -657,25 +940,31 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
   constexpr int PF = CH < 32 ? CH : 32;  // terms of the NEXT sample requested ahead (two samples' worth must fit the registers)
   struct Terms {
     double2 t[PF / 2];
-    double2 h01;
-    double h2;
+    double2 h01, h23;  // {the interaction sum, y}, {the intercept's step size, the number of chain terms}
   };
   auto slot_of = [&](int64_t u) { return reinterpret_cast<const double*>(ring + (size_t)(u & (kWinRing - 1)) * FW); };
   auto request = [&](int64_t u, Terms& T) {
     const double* sl = slot_of(u);
     T.h01 = *reinterpret_cast<const double2*>(sl + MC);
-    T.h2 = sl[MC + 2];
+    T.h23 = *reinterpret_cast<const double2*>(sl + MC + 2);
 #pragma unroll
     for (int t = 0; t < PF / 2; ++t) T.t[t] = *reinterpret_cast<const double2*>(sl + 2 * t);
   };
   // false: the launch is being aborted
+  // The chain wavefront issues NO vector-memory load inside its loop: the compiler's wait-count insertion is conservative
+  // at joins -- one load on a slow path (the abort word) made it wait for vmcnt(0) before every sample's additions, i.e.
+  // for the previous sample's answer STORE to be acknowledged (gfx9 counts stores in vmcnt): 1.5 us per sample.  The
+  // abort word is watched by the fetch wavefront, which raises the LDS flag; this wavefront only has its clock.
   auto wait_ready = [&](int64_t u) {
     if (ready_seen > u) return true;
     int spins = 0;
-    Spin sp;
+    const long long t0 = wall_clock64();
     while ((ready_seen = (int64_t)ldsv_load(c_ready)) <= u) {
       if (ldsv_load(c_abort)) return false;
-      if ((++spins & 1023) == 0 && sp.wait(a.ctrl)) return false;
+      if ((++spins & 1023) == 0 && wall_clock64() - t0 > kWinTimeoutTicks) {
+        st_u32(a.ctrl, 1u);
+        return false;
+      }
     }
     compiler_fence();
     return true;
@@ -690,7 +979,8 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
   };
   auto step = [&](int64_t u, const Terms& T) {
     if (a.trace && lane == 0) a.trace[u * 8 + 6] = wall_clock64();  // chain starts
-    const double tot = T.h01.x, y = T.h01.y, h2 = T.h2;
+    const double tot = T.h01.x, y = T.h01.y, h2 = T.h23.x;
+    const int nt = (int)T.h23.y;  // terms beyond it are -0.0 padding: not added (they would change nothing but cost an addition each)
     const int64_t it = a.it0 + u;
     if (ADA && it != 1 && M.fit_intercept) {  // adagrad.nim:101-106
       const double old = b;
@@ -717,13 +1007,13 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
         yh += t2_[t].y;
       }
     }
-    if (MC > CH) {  // rows longer than one chunk
-      for (int qb = CH; qb < MC; qb += CH) {
-        double2 t_[CH / 2];
+    if (MC > CH) {  // rows longer than one chunk: sixteen terms at a time, as far as the sample's terms go
+      for (int qb = CH; qb < nt; qb += 16) {
+        double2 t_[8];
 #pragma unroll
-        for (int t = 0; t < CH / 2; ++t) t_[t] = *reinterpret_cast<const double2*>(sl + qb + 2 * t);
+        for (int t = 0; t < 8; ++t) t_[t] = *reinterpret_cast<const double2*>(sl + qb + 2 * t);
 #pragma unroll
-        for (int t = 0; t < CH / 2; ++t) {
+        for (int t = 0; t < 8; ++t) {
           yh += t_[t].x;
           yh += t_[t].y;
         }
@@ -1115,7 +1405,7 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       }
     }
     if (lane < MC) st_u64(mb + lane, mail_bits(lane < m ? (sw * wv) * vq : -0.0));
-    if (lane < kWinHdr) st_u64(mb + MC + lane, mail_bits(lane == 0 ? tot : lane == 1 ? y : lane == 2 ? h2 : 0.0));
+    if (lane < kWinHdr) st_u64(mb + MC + lane, mail_bits(lane == 0 ? tot : lane == 1 ? y : lane == 2 ? h2 : (double)m));
     if (a.trace && lane == 0) a.trace[u * 8 + 2] = wall_clock64();  // mailbox posted
     // (after the mailbox: a successor needs them together with this sample's dL, which the conductor forms from the mailbox)
     if (hotmask) {  // the recipes of the rows a near successor shares (the base is made opaque per use: left to itself the
@@ -1229,13 +1519,15 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
   }
 }
 
-template <int OPT, int CH, bool K64>
+enum { WK_GENERAL = 0, WK_K64 = 1, WK_FFM = 2 };  // which worker
+template <int OPT, int CH, int WK>
 __global__ __launch_bounds__(128) void k_seq_window(WinArgs a) {
   extern __shared__ double lds[];
   if (blockIdx.x == 0) {
     win_conductor<OPT, CH>(a, lds);
   } else if (threadIdx.x < kWave) {
-    if constexpr (K64) win_worker_k64<OPT>(a, (int)blockIdx.x - 1, lds);
+    if constexpr (WK == WK_K64) win_worker_k64<OPT>(a, (int)blockIdx.x - 1, lds);
+    else if constexpr (WK == WK_FFM) win_worker_ffm<OPT>(a, (int)blockIdx.x - 1, lds);
     else win_worker<OPT>(a, (int)blockIdx.x - 1, lds);
   }
 }
@@ -1440,21 +1732,38 @@ static int build_prev(nfm_ctx* ctx, const CsrView& X, const int64_t* perm_dev, i
   return NFM_OK;
 }
 
+static int win_ffm_terms(int m_cap) { return m_cap + m_cap * (m_cap - 1) / 2; }
+static size_t win_ffm_lds(const ModelView& M, int m_cap, bool ada, int W) {  // the carve-up of win_worker_ffm
+  int lgKp = 1;
+  while ((1 << lgKp) < M.Kp) ++lgKp;
+  const int grp = (kWave >> lgKp) * 4;
+  const size_t mcs = ((size_t)m_cap * M.nb + grp - 1) / grp * grp;
+  return sizeof(double) * ((ada ? 4 : 2) * mcs * M.Kp + (ada ? 4 : 2) * (size_t)m_cap) +
+         sizeof(int) * (3 * (size_t)m_cap + M.nb + (size_t)M.nb * m_cap) + sizeof(unsigned) * W + 64;
+}
+
 bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz, int n_cu) {
   const char* env = getenv("NFM_SEQ_WIN");  // 0: off, 1 (default): when it pays, 2: whenever possible (read per call: tests switch it)
   const int mode = env ? atoi(env) : 1;
   if (mode == 0) return false;
-  if (M.kind != NFM_KIND_FM || M.nb != 1 || M.degree != 2 || M.n_aug != 0) return false;
   if (M.Kp > kWave || M.Kp < 2) return false;
-  if (kWinHdr + (m_cap + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
+  if (M.kind == NFM_KIND_FFM) {
+    // field-aware: one chain term per entry and per pair of entries; all nFields rows of every feature in LDS
+    if (M.n_aug != 0 || M.nb < 1 || m_cap < 1) return false;
+    if (kWinHdr + (win_ffm_terms(m_cap) + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
+    if (win_ffm_lds(M, m_cap, true, 128) > 160 * 1024) return false;
+  } else {
+    if (M.kind != NFM_KIND_FM || M.nb != 1 || M.degree != 2 || M.n_aug != 0) return false;
+    if (kWinHdr + (m_cap + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
+  }
   if (nnz >= ((int64_t)1 << 32) || M.d >= ((int64_t)1 << 31) || ns >= ((int64_t)1 << 31)) return false;
   if (n_cu < 10) return false;
   return mode == 2 || ns >= 2048;
 }
 
-template <int OPT, int CH, bool K64>
+template <int OPT, int CH, int WK>
 static int launch_window_t(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes) {
-  auto kern = k_seq_window<OPT, CH, K64>;
+  auto kern = k_seq_window<OPT, CH, WK>;
   NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   TimedLaunch tl(ctx, "sequential");
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.W + 1)), dim3(128), lds_bytes, ctx->stream, a);
@@ -1462,9 +1771,10 @@ static int launch_window_t(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes) {
   return NFM_OK;
 }
 template <int OPT>
-static int launch_window(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes, int ch, bool k64) {
-  if (k64) return ch == 32 ? launch_window_t<OPT, 32, true>(ctx, a, lds_bytes) : launch_window_t<OPT, 64, true>(ctx, a, lds_bytes);
-  return ch == 32 ? launch_window_t<OPT, 32, false>(ctx, a, lds_bytes) : launch_window_t<OPT, 64, false>(ctx, a, lds_bytes);
+static int launch_window(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes, int ch, int wk) {
+  if (wk == WK_K64) return ch == 32 ? launch_window_t<OPT, 32, WK_K64>(ctx, a, lds_bytes) : launch_window_t<OPT, 64, WK_K64>(ctx, a, lds_bytes);
+  if (wk == WK_FFM) return ch == 32 ? launch_window_t<OPT, 32, WK_FFM>(ctx, a, lds_bytes) : launch_window_t<OPT, 64, WK_FFM>(ctx, a, lds_bytes);
+  return ch == 32 ? launch_window_t<OPT, 32, WK_GENERAL>(ctx, a, lds_bytes) : launch_window_t<OPT, 64, WK_GENERAL>(ctx, a, lds_bytes);
 }
 
 int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O, const int64_t* perm_dev,
@@ -1484,9 +1794,12 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   NFM_CHECK(W > kWinDepth && W + 1 <= ctx->n_cu, NFM_ERR_UNSUPPORTED, "the dependency window needs %d resident workgroups", W + 1);
   int lgKp = 1;
   while ((1 << lgKp) < M.Kp) ++lgKp;
-  const int ch = m_cap <= 32 ? 32 : 64;  // the chain's chunk of terms; a mailbox holds MC = a multiple of it
-  const int FW = kWinHdr + (m_cap + ch - 1) / ch * ch;
-  const bool k64 = M.Kp == kWave && m_cap <= kWave;  // the register-resident worker
+  const bool ffm = M.kind == NFM_KIND_FFM;
+  const int terms = ffm ? win_ffm_terms(m_cap) : m_cap;  // what a sample hands to the conductor's chain
+  const int ch = terms <= 32 ? 32 : 64;  // the chain's chunk of terms; a mailbox holds MC = a multiple of it
+  const int FW = kWinHdr + (terms + ch - 1) / ch * ch;
+  const bool k64 = !ffm && M.Kp == kWave && m_cap <= kWave;  // the register-resident worker
+  const int wk = ffm ? WK_FFM : k64 ? WK_K64 : WK_GENERAL;
   // the previous-position table of this order (kept while the same samples are walked in storage order)
   const bool reuse = sw->valid && !perm_is_callers && !sw->had_perm && sw->ds_uid == ds_uid && sw->begin == begin && sw->end == end && sw->nnz == X.nnz;
   if (!reuse) {
@@ -1538,6 +1851,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   const size_t rows = mcp * M.Kp;
   size_t lds_worker = sizeof(double) * ((ada ? 4 : 2) * rows + kWave + (ada ? 4 : 2) * mcp) + sizeof(int) * 3 * mcp + sizeof(unsigned) * W;
   if (k64) lds_worker = sizeof(double) * ((ada ? 3 : 1) * (size_t)kWave * kWave + kWave) + sizeof(unsigned) * W;
+  if (ffm) lds_worker = win_ffm_lds(M, m_cap, ada, W);
   const size_t lds_cond = sizeof(double) * 2 + sizeof(ull) * (size_t)kWinRing * FW;
   size_t lds_bytes = lds_worker > lds_cond ? lds_worker : lds_cond;
   NFM_CHECK(lds_bytes <= 160 * 1024, NFM_ERR_UNSUPPORTED, "row too long for the dependency window (%zu bytes of LDS)", lds_bytes);
@@ -1564,8 +1878,8 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     a.seg0 = pos;
     a.n_seg = last - pos + 1;
     a.it0 = it0 + pos;
-    if (ada) NFM_TRY(launch_window<OPT_ADAGRAD>(ctx, a, lds_bytes, ch, k64));
-    else NFM_TRY(launch_window<OPT_SGD>(ctx, a, lds_bytes, ch, k64));
+    if (ada) NFM_TRY(launch_window<OPT_ADAGRAD>(ctx, a, lds_bytes, ch, wk));
+    else NFM_TRY(launch_window<OPT_SGD>(ctx, a, lds_bytes, ch, wk));
     hipLaunchKernelGGL(k_win_finish, dim3(1), dim3(kWave), 0, st, a.partial, W, out2_dev);
     if (!ada && host_info[1]) {
       const int64_t nP = (int64_t)M.nb * M.da * M.Kp;

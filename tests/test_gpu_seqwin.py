@@ -220,3 +220,84 @@ def test_sub_ranges_of_the_order(kind):
     y = np.random.default_rng(6).standard_normal(Xo.n)
     perms = make_perms(Xo.n, 2)
     check_pair(kind, Xo, y, "regression", 8, 8, epochs=2, perms=perms, nCalls=37)
+
+
+def _ffm_data(n, d, F, max_m, seed, one_per_field=False):
+    rng = np.random.default_rng(seed)
+    field_of = rng.integers(0, F, size=d) if not one_per_field else np.arange(d) // (d // F)
+    rows, vals, indptr = [], [], [0]
+    for i in range(n):
+        if one_per_field:  # one entry per field (the benchmark shape, cfg4)
+            idx = rng.integers(0, d // F, size=F) + np.arange(F) * (d // F)
+        else:
+            m = 0 if i % 11 == 5 else int(rng.integers(1, max_m + 1))
+            idx = rng.choice(d, size=m, replace=False)
+            if i % 3:
+                idx = np.sort(idx)  # the pair order of sgd_ffm.nim:18-30 depends on the storage order
+        rows.append(idx)
+        vals.append(rng.uniform(-1, 1, size=len(idx)))
+        indptr.append(indptr[-1] + len(idx))
+    idx = np.concatenate(rows).astype(np.int64)
+    return O.Dataset(np.array(indptr), idx, np.concatenate(vals), n, d, field_of[idx], F), rng.standard_normal(n)
+
+
+def _ffm_fit(kind, win, W, Xo, y, k, P0, w0, b0, epochs, perms=None, **kw):
+    from gpu_common import gpu_ffm
+    with env(NFM_SEQ_WIN=win, NFM_SEQ_WIN_W=W):
+        ffm = gpu_ffm("regression", k, True, True, P0, w0, b0)
+        mk = nf.newSGD if kind == "sgd" else nf.newAdaGrad
+        opt = mk(maxIter=epochs, verbose=0, tol=0, shuffle=False, mode="sequential", **kw)
+        ctx = nf.default_context()
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        opt.fit(to_gpu(Xo), y, ffm, perms=perms)
+        windowed = ctx.timing_get("seq_window_deps")[0] > 0
+        ctx.timing_enable(False)
+        assert windowed == (int(win) != 0), "the %s kernel ran" % ("one-workgroup" if int(win) else "window")
+        state = opt.get_state(ffm) if kind == "adagrad" else None
+        return ffm.P.copy(), ffm.w.copy(), ffm.intercept, opt.it, list(opt.history), state
+
+
+@pytest.mark.parametrize("kind,F,k,d,max_m,W", [
+    ("sgd", 3, 2, 12, 6, 8), ("adagrad", 3, 2, 12, 6, 8),          # few features: every sample waits
+    ("sgd", 16, 8, 64, 16, 16), ("adagrad", 16, 8, 64, 16, 64),    # cfg4's fields and factors
+    ("sgd", 7, 20, 30, 7, 8), ("adagrad", 7, 20, 30, 7, 32),       # factors not a power of two
+    ("sgd", 5, 4, 400, 20, 64), ("adagrad", 5, 4, 400, 20, 64),    # 20 entries: 210 chain terms, several entries per field
+])
+def test_field_aware_window_bitwise_and_oracle(kind, F, k, d, max_m, W):
+    """field-aware models in the dependency window (win_worker_ffm): parameters, linear weights, intercept, AdaGrad state
+    bit for bit those of the one-workgroup kernel, and the oracle's fit (O.ffm_*_fit, sgd_ffm.nim / adagrad_ffm.nim)"""
+    from common import init_ffm
+    Xo, y = _ffm_data(300, d, F, max_m, seed=F * 100 + k)
+    P0, w0, b0 = init_ffm(d, F, k)
+    perms = make_perms(Xo.n, 2)
+    kw = dict(eta0=0.05) if kind == "sgd" else {}
+    ref = _ffm_fit(kind, 0, W, Xo, y, k, P0, w0, b0, 2, perms, **kw)
+    win = _ffm_fit(kind, 2, W, Xo, y, k, P0, w0, b0, 2, perms, **kw)
+    same_bits(win[0], ref[0], "P")
+    same_bits(win[1], ref[1], "w")
+    assert win[2] == ref[2] and win[3] == ref[3]
+    assert_close([h[1] for h in win[4]], [h[1] for h in ref[4]], 1e-12, 1e-15, "loss per epoch")
+    assert_close([h[0] for h in win[4]], [h[0] for h in ref[4]], 1e-11, 1e-14, "viol per epoch")
+    if kind == "adagrad":
+        for g, h, name in zip(win[5], ref[5], ["g_sum.P", "g_norm.P", "g_sum.w", "g_norm.w", "g_sum.b", "g_norm.b"]):
+            same_bits(np.atleast_1d(g), np.atleast_1d(h), name)
+        Pf, wf, bf, *_ = O.ffm_adagrad_fit(Xo, y, P0, w0, b0, O.adagrad_cfg(), 2, perms=perms)
+    else:
+        Pf, wf, bf, *_ = O.ffm_sgd_fit(Xo, y, P0, w0, b0, O.sgd_cfg(eta0=0.05), 2, perms=perms)
+    assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
+    assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
+    assert abs(win[2] - bf) < 1e-9
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad"])
+def test_field_aware_window_benchmark_shape(kind):
+    """16 fields x one entry, k = 8 (BASELINE configs[3]'s row shape), 3000 samples over 1600 features, 64 workers"""
+    from common import init_ffm
+    Xo, y = _ffm_data(3000, 1600, 16, 16, seed=9, one_per_field=True)
+    P0, w0, b0 = init_ffm(1600, 16, 8)
+    ref = _ffm_fit(kind, 0, 64, Xo, y, 8, P0, w0, b0, 1)
+    win = _ffm_fit(kind, 2, 64, Xo, y, 8, P0, w0, b0, 1)
+    same_bits(win[0], ref[0], "P")
+    same_bits(win[1], ref[1], "w")
+    assert win[2] == ref[2]
