@@ -872,35 +872,44 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
     // ---- fetch: kWinDepth mailboxes requested ahead; a word still "empty" means the worker has not posted yet ----
     const int NL = (FW + kWave - 1) / kWave;
     ull v[kWinDepth][kWinMaxNL];
+    // Always kWinMaxNL loads per mailbox (a lane past the mailbox's end reads its last word again) and never a load
+    // behind a branch: the loads of kWinDepth mailboxes are in flight, and the wait before a mailbox is looked at must be
+    // for ITS loads only -- the compiler counts the loads issued since, which it can only do when every path issues the
+    // same number (with conditional loads it fell back to vmcnt(0): every sample waited for the mailbox requested last,
+    // a full round trip per sample; the prefetch bought nothing).
     auto issue = [&](int dd, int64_t u) {
-      const int slot = (int)(u & (W - 1)), par = (int)((u >> lgW) & 1);
+      const int64_t uu = u < n ? u : n - 1;  // (past the end: the last mailbox again, never looked at)
+      const int slot = (int)(uu & (W - 1)), par = (int)((uu >> lgW) & 1);
       const ull* mb = a.fwd + (size_t)(slot * 2 + par) * FW;
 #pragma unroll
       for (int l = 0; l < kWinMaxNL; ++l) {
         const int e = lane + kWave * l;
-        v[dd][l] = (l < NL && e < FW) ? ld_u64(mb + e) : 0ull;
+        v[dd][l] = ld_u64(mb + (e < FW ? e : FW - 1));
       }
     };
 #pragma unroll
-    for (int dd = 0; dd < kWinDepth; ++dd)
-      if (dd < n) issue(dd, dd);
+    for (int dd = 0; dd < kWinDepth; ++dd) issue(dd, dd);
     int64_t consumed_seen = 0;
     for (int64_t ub = 0; ub < n; ub += kWinDepth) {
 #pragma unroll
       for (int dd = 0; dd < kWinDepth; ++dd) {
         const int64_t u = ub + dd;
         if (u >= n) break;
-        Spin sp;
-        while (true) {
-          bool bad = false;
+        bool bad = false;
 #pragma unroll
-          for (int l = 0; l < kWinMaxNL; ++l) bad = bad || v[dd][l] == kWinSentinel;
-          if (!__any(bad)) break;
-          if (sp.wait(a.ctrl)) {
-            ldsv_store(c_abort, 1u);
-            return;
-          }
-          issue(dd, u);
+        for (int l = 0; l < kWinMaxNL; ++l) bad = bad || v[dd][l] == kWinSentinel;
+        if (__any(bad)) {  // not posted yet: ask again until it is (this path drains every load before it rejoins)
+          Spin sp;
+          do {
+            if (sp.wait(a.ctrl)) {
+              ldsv_store(c_abort, 1u);
+              return;
+            }
+            issue(dd, u);
+            bad = false;
+#pragma unroll
+            for (int l = 0; l < kWinMaxNL; ++l) bad = bad || v[dd][l] == kWinSentinel;
+          } while (__any(bad));
         }
         if (consumed_seen + kWinRing <= u) {
           Spin sp2;
@@ -920,7 +929,7 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
         lds_fence();  // LDS operations of a wavefront execute in order: data, then the counter
         if (lane == 0) ldsv_store(c_ready, (unsigned)(u + 1));
         if (a.trace && lane == 0) a.trace[u * 8 + 5] = wall_clock64();  // mailbox fetched
-        if (u + kWinDepth < n) issue(dd, u + kWinDepth);
+        issue(dd, u + kWinDepth);
       }
     }
     return;
