@@ -843,6 +843,293 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// worker for FMs of any degree / several orders (fitLower = explicit: order o has degree `degree - o`; kernels of
+// optimizer/sgd.nim:146-188): a sample's rows are its slots c = q * nb + o (entry q, order o), handled like the rows of the
+// general worker.  Per order: the ANOVA recursion over the entries in storage order (every lane runs it for its factor),
+// the derivative of the order's slots, the sum over the factors in ascending order -- ONE chain term per order, behind the
+// linear terms (predictWithGrad adds the orders' kernels to the prediction one after the other, sgd.nim:198-201).
+// Dependencies by counters only.  No dummy features (fitLower = augment: every sample would depend on its predecessor).
+// ------------------------------------------------------------------------------------------------------------------
+template <int OPT>
+__device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot, double* lds) {
+  const CsrView& X = a.X;
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  constexpr bool ADA = OPT == OPT_ADAGRAD;
+  constexpr int U = 4, DG = dev::kMaxDeg;
+  const int lane = threadIdx.x;
+  const int Kp = M.Kp, lgK = a.lgKp, k = M.k, nb = M.nb, mcap = a.m_cap;
+  const int R = kWave >> lgK, r = lane >> lgK, s = lane & (Kp - 1);
+  const int mcs = (mcap * nb + R * U - 1) / (R * U) * (R * U);  // slots, padded to whole groups
+  const int W = a.W, lgW = a.lgW;
+  double* Pl = lds;                                   // [mcs][Kp] stored parameter values of the sample's slots
+  double* Tl = Pl + (size_t)mcs * Kp;                 // [mcs][Kp] the slots' derivative
+  double* Gl = Tl + (size_t)mcs * Kp;                 // AdaGrad: g_sum
+  double* Nl = Gl + (ADA ? (size_t)mcs * Kp : 0);     // AdaGrad: g_norm
+  double* red = Nl + (ADA ? (size_t)mcs * Kp : 0);    // [64]
+  double* vl = red + kWave;                           // [mcap] values
+  double* wl = vl + mcap;                             // [mcap] stored linear weights (AdaGrad: after update())
+  double* gwl = wl + mcap;                            // AdaGrad: [mcap]
+  double* nwl = gwl + (ADA ? mcap : 0);               // AdaGrad: [mcap]
+  int* jl = reinterpret_cast<int*>(nwl + (ADA ? mcap : 0));  // [mcap] feature ids
+  int* pl = jl + mcap;                                       // [mcap] previous position with the same feature
+  unsigned* cnt = reinterpret_cast<unsigned*>(pl + mcap);    // [W]
+  for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
+  double loss_acc = 0.0, viol_acc = 0.0;
+
+  for (int64_t u = slot; u < a.n_seg; u += W) {
+    const int64_t pos = a.seg0 + u, pa = a.begin + pos;
+    const int64_t i = a.perm ? a.perm[pa] : pa;
+    const int64_t q0 = X.indptr[i];
+    const int m = (int)(X.indptr[i + 1] - q0);
+    const int nsl = m * nb;
+    const double y = dev::target_of(X.y[i], M.task);
+    const int64_t it = a.it0 + u;
+    const double itf = (double)it;
+    const int par = (int)((u >> lgW) & 1);
+    ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
+    const ull* rp = a.res + (size_t)(slot * 2 + par) * kResWords;
+    for (int q = lane; q < mcap; q += kWave) {
+      const bool in = q < m;
+      jl[q] = in ? X.indices[q0 + q] : 0;
+      vl[q] = in ? X.data[q0 + q] : 0.0;
+      pl[q] = in ? a.prev[q0 + q] : -1;
+    }
+    compiler_fence();
+    double* const junk = reinterpret_cast<double*>(a.fw + (size_t)2 * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
+
+    // ---- A. every earlier sample of this launch that shares a feature has written its rows ----
+    {
+      Spin sp;
+      bool first = true;
+      while (true) {
+        bool need = false;
+        for (int q = lane; q < m; q += kWave) {
+          const int64_t v = (int64_t)pl[q] - a.seg0;
+          if (v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW)) need = true;
+        }
+        if (!__any(need)) break;
+        if (!first && sp.wait(a.ctrl)) return;
+        first = false;
+        for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
+        compiler_fence();
+      }
+    }
+
+    // ---- B. the rows of every (entry, order) -> LDS (AdaGrad: update() first, adagrad.nim:87-110) ----
+    double sP = 1.0, sw = 1.0;
+    if constexpr (!ADA) {
+      sP = a.scales[2 * pos];
+      sw = a.scales[2 * pos + 1];
+    }
+    const double itp = (double)(it - 1);
+    const double tmpP = O.eta0 * itp * O.beta;
+    auto slot_row = [&](int c) {  // where slot c's row starts (a slot past the end: slot 0)
+      const int cc = c < nsl ? c : 0;
+      const int q = cc / nb, o = cc - q * nb;
+      return M.row(o, jl[q]) * (size_t)Kp + s;
+    };
+    for (int cb = 0; cb < nsl; cb += R * U) {
+      double v_[U], g_[ADA ? U : 1], n_[ADA ? U : 1];
+      size_t e_[U];
+#pragma unroll
+      for (int t = 0; t < U; ++t) e_[t] = slot_row(cb + t * R + r);
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        v_[t] = ld_f64(M.P + e_[t]);
+        if constexpr (ADA) {
+          g_[t] = ld_f64(O.G + e_[t]);
+          n_[t] = ld_f64(O.N + e_[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        const int c = cb + t * R + r;
+        const bool in = c < nsl;
+        double p = v_[t];
+        if constexpr (ADA) {
+          if (it != 1) {
+            p = dev::adagrad_param(g_[t], n_[t], O.eta0, tmpP);
+            viol_acc += in ? fabs(v_[t] - p) : 0.0;
+            st_f64_at(in ? (ull)(M.P + e_[t]) : (ull)junk, p);
+          }
+          Gl[(size_t)c * Kp + s] = g_[t];
+          Nl[(size_t)c * Kp + s] = n_[t];
+        }
+        Pl[(size_t)c * Kp + s] = p;
+      }
+    }
+    const double denw = itp * O.eta0 * O.alpha;
+    for (int q = lane; q < m; q += kWave) {
+      const int j = jl[q];
+      double wv = ld_f64(M.w + j);
+      if constexpr (ADA) {
+        if (M.fit_linear) {
+          const double gw = ld_f64(O.Gw + j), nw_ = ld_f64(O.Nw + j);
+          gwl[q] = gw;
+          nwl[q] = nw_;
+          if (it != 1) {
+            const double nv = -O.eta0 * gw / (denw + sqrt(nw_));
+            viol_acc += fabs(wv - nv);
+            st_f64(M.w + j, nv);
+            wv = nv;
+          }
+        }
+      }
+      wl[q] = wv;
+    }
+    compiler_fence();
+
+    // ---- C. per order: computeAnova (sgd.nim:146-173) and computeAnovaDerivative (:176-188) ----
+    const int MC = a.FW - kWinHdr;
+    for (int o = 0; o < nb; ++o) {
+      const int deg = M.degree - o;
+      double A[DG + 1];
+      double kv;
+      if (deg != 2) {  // sgd.nim:152-159
+        A[0] = 1.0;
+#pragma unroll
+        for (int t = 1; t <= DG; ++t) A[t] = 0.0;
+        for (int q = 0; q < m; ++q) {
+          const double val = vl[q];
+          const double p = sP * Pl[((size_t)q * nb + o) * Kp + s];
+#pragma unroll
+          for (int t = DG; t >= 1; --t)
+            if (t <= deg) A[t] += A[t - 1] * p * val;
+        }
+        kv = 0.0;
+#pragma unroll
+        for (int t = 1; t <= DG; ++t)
+          if (t == deg) kv = A[t];
+      } else {  // sgd.nim:160-170
+        double a1 = 0.0, a2 = 0.0;
+        for (int q = 0; q < m; ++q) {
+          const double vp = vl[q] * (sP * Pl[((size_t)q * nb + o) * Kp + s]);
+          a1 += vp;
+          a2 += vp * vp;
+        }
+        A[0] = 1.0;
+        A[1] = a1;
+#pragma unroll
+        for (int t = 2; t <= DG; ++t) A[t] = 0.0;
+        kv = (a1 * a1 - a2) / 2;
+      }
+      for (int qb = 0; qb < m; qb += R) {  // the order's slots: row slot r takes entries r, r + R, ...
+        const int q = qb + r;
+        if (q < m) {
+          const double val = vl[q];
+          const double p = sP * Pl[((size_t)q * nb + o) * Kp + s];
+          double d_;
+          if (deg != 2) {
+            d_ = val;
+#pragma unroll
+            for (int t = 1; t < DG; ++t)
+              if (t < deg) d_ = val * (A[t] - p * d_);
+          } else {
+            d_ = val * (A[1] - p * val);
+          }
+          Tl[((size_t)q * nb + o) * Kp + s] = d_;
+        }
+      }
+      if (r == 0) red[s] = s < k ? kv : 0.0;
+      compiler_fence();
+      double tot = 0.0;
+      for (int sb = 0; sb < k; sb += 8) {  // sgd.nim:172-173, ascending s
+        double r_[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) r_[t] = red[sb + t < k ? sb + t : sb];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) tot = sb + t < k ? tot + r_[t] : tot;
+      }
+      compiler_fence();  // (red is written again by the next order)
+      if (lane == 0) st_u64(mb + m + o, mail_bits(tot));  // the order's kernel: a chain term behind the linear terms
+    }
+    const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
+    for (int e = lane; e < a.FW; e += kWave) {
+      double val;
+      bool put = true;
+      if (e < m) val = (sw * wl[e]) * vl[e];
+      else if (e < m + nb) put = false;  // an order's kernel, stored above
+      else if (e < MC) val = -0.0;       // (changes no sum)
+      else if (e == MC) val = -0.0;      // no separate interaction sum
+      else if (e == MC + 1) val = y;
+      else if (e == MC + 2) val = h2;
+      else val = (double)(m + nb);       // the number of chain terms
+      if (put) st_u64(mb + e, mail_bits(val));
+    }
+
+    // ---- D. the step sizes while the conductor works ----
+    double eta_w = 0.0, eta_P = 0.0, sPn = 1.0, swn = 1.0;
+    if constexpr (!ADA) {
+      eta_w = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, itf);
+      eta_P = dev::get_eta(O.sched, O.eta0, O.power, O.beta, itf);
+      sPn = sP * (1 - eta_P * O.beta);
+      swn = sw * (1 - eta_w * O.alpha);
+    }
+
+    // ---- E. {dL, yhat} from the conductor (tagged granules) ----
+    double dL, yh;
+    {
+      Spin sp;
+      double rd;
+      while (true) {
+        const bool ok = fw_load(rp + (size_t)(lane & 1) * 2, (unsigned)(u + 1), rd);
+        if (__all(ok)) break;
+        if (sp.wait(a.ctrl)) return;
+      }
+      dL = dev::shfl_d(rd, 0);
+      yh = dev::shfl_d(rd, 1);
+    }
+    for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);  // (as in the general worker)
+    if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
+
+    // ---- F. update() / updateG() over all slots ----
+    for (int cb = 0; cb < nsl; cb += R * U) {
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        const int c = cb + t * R + r;
+        const bool in = c < nsl;
+        const size_t e = slot_row(c);
+        const double d_ = Tl[(size_t)c * Kp + s];
+        if constexpr (ADA) {
+          const double grad = dL * d_;
+          st_f64_at(in ? (ull)(O.G + e) : (ull)junk, Gl[(size_t)c * Kp + s] + grad);
+          st_f64_at(in ? (ull)(O.N + e) : (ull)(junk + kWave), Nl[(size_t)c * Kp + s] + grad * grad);
+        } else {
+          const double p = sP * Pl[(size_t)c * Kp + s];
+          const double update = eta_P * (dL * d_ + O.beta * p);
+          viol_acc += in ? fabs(update) : 0.0;
+          st_f64_at(in ? (ull)(M.P + e) : (ull)junk, (p - update) / sPn);
+        }
+      }
+    }
+    if (M.fit_linear) {
+      for (int q = lane; q < m; q += kWave) {
+        const int j = jl[q];
+        if constexpr (ADA) {
+          const double gg = dL * vl[q];
+          st_f64(O.Gw + j, gwl[q] + gg);
+          st_f64(O.Nw + j, nwl[q] + gg * gg);
+        } else {
+          const double wj = sw * wl[q];
+          const double update = eta_w * (dL * vl[q] + O.alpha * wj);
+          viol_acc += fabs(update);
+          st_f64(M.w + j, (wj - update) / swn);
+        }
+      }
+    }
+    // ---- G. rows written: tell the waiters ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
+  }
+  viol_acc = dev::wave_sum(viol_acc);
+  if (lane == 0) {
+    a.partial[2 * slot] = loss_acc;
+    a.partial[2 * slot + 1] = viol_acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // conductor: wavefront 1 fetches the mailboxes in sample order into an LDS ring, wavefront 0 runs the scalar chain
 // ------------------------------------------------------------------------------------------------------------------
 // the conductor's three LDS words (ready, consumed, abort): volatile accesses in the LDS address space (ds_read / ds_write)
@@ -1528,7 +1815,7 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
   }
 }
 
-enum { WK_GENERAL = 0, WK_K64 = 1, WK_FFM = 2 };  // which worker
+enum { WK_GENERAL = 0, WK_K64 = 1, WK_FFM = 2, WK_FMX = 3 };  // which worker
 template <int OPT, int CH, int WK>
 __global__ __launch_bounds__(128) void k_seq_window(WinArgs a) {
   extern __shared__ double lds[];
@@ -1537,6 +1824,7 @@ __global__ __launch_bounds__(128) void k_seq_window(WinArgs a) {
   } else if (threadIdx.x < kWave) {
     if constexpr (WK == WK_K64) win_worker_k64<OPT>(a, (int)blockIdx.x - 1, lds);
     else if constexpr (WK == WK_FFM) win_worker_ffm<OPT>(a, (int)blockIdx.x - 1, lds);
+    else if constexpr (WK == WK_FMX) win_worker_fmx<OPT>(a, (int)blockIdx.x - 1, lds);
     else win_worker<OPT>(a, (int)blockIdx.x - 1, lds);
   }
 }
@@ -1751,6 +2039,15 @@ static size_t win_ffm_lds(const ModelView& M, int m_cap, bool ada, int W) {  // 
          sizeof(int) * (3 * (size_t)m_cap + M.nb + (size_t)M.nb * m_cap) + sizeof(unsigned) * W + 64;
 }
 
+static size_t win_fmx_lds(const ModelView& M, int m_cap, bool ada, int W) {  // the carve-up of win_worker_fmx
+  int lgKp = 1;
+  while ((1 << lgKp) < M.Kp) ++lgKp;
+  const int grp = (kWave >> lgKp) * 4;
+  const size_t mcs = ((size_t)m_cap * M.nb + grp - 1) / grp * grp;
+  return sizeof(double) * ((ada ? 4 : 2) * mcs * M.Kp + kWave + (ada ? 4 : 2) * (size_t)m_cap) + sizeof(int) * 2 * (size_t)m_cap +
+         sizeof(unsigned) * W + 64;
+}
+
 bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz, int n_cu) {
   const char* env = getenv("NFM_SEQ_WIN");  // 0: off, 1 (default): when it pays, 2: whenever possible (read per call: tests switch it)
   const int mode = env ? atoi(env) : 1;
@@ -1761,6 +2058,11 @@ bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz
     if (M.n_aug != 0 || M.nb < 1 || m_cap < 1) return false;
     if (kWinHdr + (win_ffm_terms(m_cap) + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
     if (win_ffm_lds(M, m_cap, true, 128) > 160 * 1024) return false;
+  } else if (M.kind == NFM_KIND_FM && (M.nb != 1 || M.degree != 2)) {
+    // several orders / degree >= 3: one chain term per entry and per order; the rows of every (entry, order) in LDS
+    if (M.n_aug != 0 || M.nb < 1 || M.degree < 2 || M.degree > dev::kMaxDeg || m_cap < 1) return false;
+    if (kWinHdr + (m_cap + M.nb + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
+    if (win_fmx_lds(M, m_cap, true, 128) > 160 * 1024) return false;
   } else {
     if (M.kind != NFM_KIND_FM || M.nb != 1 || M.degree != 2 || M.n_aug != 0) return false;
     if (kWinHdr + (m_cap + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
@@ -1783,6 +2085,7 @@ template <int OPT>
 static int launch_window(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes, int ch, int wk) {
   if (wk == WK_K64) return ch == 32 ? launch_window_t<OPT, 32, WK_K64>(ctx, a, lds_bytes) : launch_window_t<OPT, 64, WK_K64>(ctx, a, lds_bytes);
   if (wk == WK_FFM) return ch == 32 ? launch_window_t<OPT, 32, WK_FFM>(ctx, a, lds_bytes) : launch_window_t<OPT, 64, WK_FFM>(ctx, a, lds_bytes);
+  if (wk == WK_FMX) return ch == 32 ? launch_window_t<OPT, 32, WK_FMX>(ctx, a, lds_bytes) : launch_window_t<OPT, 64, WK_FMX>(ctx, a, lds_bytes);
   return ch == 32 ? launch_window_t<OPT, 32, WK_GENERAL>(ctx, a, lds_bytes) : launch_window_t<OPT, 64, WK_GENERAL>(ctx, a, lds_bytes);
 }
 
@@ -1804,11 +2107,12 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   int lgKp = 1;
   while ((1 << lgKp) < M.Kp) ++lgKp;
   const bool ffm = M.kind == NFM_KIND_FFM;
-  const int terms = ffm ? win_ffm_terms(m_cap) : m_cap;  // what a sample hands to the conductor's chain
+  const bool fmx = !ffm && (M.nb != 1 || M.degree != 2);  // several orders / degree >= 3
+  const int terms = ffm ? win_ffm_terms(m_cap) : fmx ? m_cap + M.nb : m_cap;  // what a sample hands to the conductor's chain
   const int ch = terms <= 32 ? 32 : 64;  // the chain's chunk of terms; a mailbox holds MC = a multiple of it
   const int FW = kWinHdr + (terms + ch - 1) / ch * ch;
-  const bool k64 = !ffm && M.Kp == kWave && m_cap <= kWave;  // the register-resident worker
-  const int wk = ffm ? WK_FFM : k64 ? WK_K64 : WK_GENERAL;
+  const bool k64 = !ffm && !fmx && M.Kp == kWave && m_cap <= kWave;  // the register-resident worker
+  const int wk = ffm ? WK_FFM : fmx ? WK_FMX : k64 ? WK_K64 : WK_GENERAL;
   // the previous-position table of this order (kept while the same samples are walked in storage order)
   const bool reuse = sw->valid && !perm_is_callers && !sw->had_perm && sw->ds_uid == ds_uid && sw->begin == begin && sw->end == end && sw->nnz == X.nnz;
   if (!reuse) {
@@ -1861,6 +2165,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   size_t lds_worker = sizeof(double) * ((ada ? 4 : 2) * rows + kWave + (ada ? 4 : 2) * mcp) + sizeof(int) * 3 * mcp + sizeof(unsigned) * W;
   if (k64) lds_worker = sizeof(double) * ((ada ? 3 : 1) * (size_t)kWave * kWave + kWave) + sizeof(unsigned) * W;
   if (ffm) lds_worker = win_ffm_lds(M, m_cap, ada, W);
+  if (fmx) lds_worker = win_fmx_lds(M, m_cap, ada, W);
   const size_t lds_cond = sizeof(double) * 2 + sizeof(ull) * (size_t)kWinRing * FW;
   size_t lds_bytes = lds_worker > lds_cond ? lds_worker : lds_cond;
   NFM_CHECK(lds_bytes <= 160 * 1024, NFM_ERR_UNSUPPORTED, "row too long for the dependency window (%zu bytes of LDS)", lds_bytes);

@@ -301,3 +301,53 @@ def test_field_aware_window_benchmark_shape(kind):
     same_bits(win[0], ref[0], "P")
     same_bits(win[1], ref[1], "w")
     assert win[2] == ref[2]
+
+
+def _fmx_fit(kind, win, W, Xo, y, degree, fit_lower, k, P0, w0, b0, epochs, perms=None, **kw):
+    with env(NFM_SEQ_WIN=win, NFM_SEQ_WIN_W=W):
+        fm = gpu_fm("regression", degree, k, fit_lower, True, True, P0, w0, b0)
+        mk = nf.newSGD if kind == "sgd" else nf.newAdaGrad
+        opt = mk(maxIter=epochs, verbose=0, tol=0, shuffle=False, mode="sequential", **kw)
+        ctx = nf.default_context()
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        opt.fit(to_gpu(Xo), y, fm, perms=perms)
+        windowed = ctx.timing_get("seq_window_deps")[0] > 0
+        ctx.timing_enable(False)
+        assert windowed == (int(win) != 0), "the %s kernel ran" % ("one-workgroup" if int(win) else "window")
+        state = opt.get_state(fm) if kind == "adagrad" else None
+        return fm.P.copy(), fm.w.copy(), fm.intercept, opt.it, list(opt.history), state
+
+
+@pytest.mark.parametrize("kind,degree,fit_lower,k,d,W", [
+    ("sgd", 3, "explicit", 8, 10, 8), ("adagrad", 3, "explicit", 8, 10, 16),     # two orders (degrees 3 and 2): cfg5's model
+    ("sgd", 4, "explicit", 4, 40, 64), ("adagrad", 4, "explicit", 4, 40, 64),    # three orders
+    ("sgd", 3, "none", 5, 30, 32), ("adagrad", 5, "none", 3, 30, 8),             # one order of degree >= 3
+    ("sgd", 2, "explicit", 16, 300, 64),                                         # (degree 2: the general worker, for reference)
+])
+def test_higher_degree_window_bitwise_and_oracle(kind, degree, fit_lower, k, d, W):
+    """several orders / degree >= 3 in the dependency window (win_worker_fmx): bit for bit the one-workgroup kernel's
+    parameters and state, and the oracle's fit (computeAnova's recursion, sgd.nim:146-188)"""
+    Xo = ragged_csr(400, d, seed=degree * 10 + k, max_m=min(d, 24))
+    rng = np.random.default_rng(degree)
+    y = rng.standard_normal(Xo.n)
+    P0, w0, b0, n_aug = init_fm(d, degree, k, fit_lower, True, scale=0.1)
+    assert n_aug == 0
+    perms = make_perms(Xo.n, 2)
+    kw = dict(eta0=0.02) if kind == "sgd" else {}
+    ref = _fmx_fit(kind, 0, W, Xo, y, degree, fit_lower, k, P0, w0, b0, 2, perms, **kw)
+    win = _fmx_fit(kind, 2, W, Xo, y, degree, fit_lower, k, P0, w0, b0, 2, perms, **kw)
+    same_bits(win[0], ref[0], "P")
+    same_bits(win[1], ref[1], "w")
+    assert win[2] == ref[2] and win[3] == ref[3]
+    assert_close([h[1] for h in win[4]], [h[1] for h in ref[4]], 1e-12, 1e-15, "loss per epoch")
+    assert_close([h[0] for h in win[4]], [h[0] for h in ref[4]], 1e-11, 1e-14, "viol per epoch")
+    if kind == "adagrad":
+        for g, h, name in zip(win[5], ref[5], ["g_sum.P", "g_norm.P", "g_sum.w", "g_norm.w", "g_sum.b", "g_norm.b"]):
+            same_bits(np.atleast_1d(g), np.atleast_1d(h), name)
+        Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, y, degree, P0, w0, b0, O.adagrad_cfg(), 2, 0, perms=perms)
+    else:
+        Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, degree, P0, w0, b0, O.sgd_cfg(eta0=0.02), 2, 0, perms=perms)
+    assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
+    assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
+    assert abs(win[2] - bf) < 1e-9
