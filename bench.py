@@ -292,7 +292,7 @@ def make_dataset(torch, nf, ctx, dev, wl, n, rank):
     X = nf.CSRDataset.from_device(ctx, n, d, n * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(),
                                   fields_ptr=fields.data_ptr() if F else None, nFields=F,
                                   keep=(indptr, indices, data, fields))
-    return X, indptr, indices, data
+    return X, indptr, indices, data, fields
 
 
 def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, cheap=False, fields=None):
@@ -382,7 +382,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     batch = args.batch if (args.batch and primary) else wl["batch"]
     steps, warmup = (args.steps, args.warmup) if primary else (min(args.steps, 10), min(args.warmup, 3))
     F = wl.get("fields", 0)
-    X, indptr, indices, data = make_dataset(torch, nf, ctx, dev, wl, n, rank)
+    X, indptr, indices, data, _keep_fields = make_dataset(torch, nf, ctx, dev, wl, n, rank)
     # labels from a planted FM (k, scale 0.1), like tests/utils.nim:29-47; classification -> sign
     rng = np.random.default_rng(1234)
     planted = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True)
@@ -522,13 +522,19 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     # reference-faithful CPU restatement) on a bounded prefix of the shard: the speed of the mode that reproduces the
     # reference exactly, reported beside the mini-batch rule's ----
     exact = None
-    if rank == 0 and world == 1 and not F:
-        windowed = wl["degree"] == 2 and k <= 64  # seqwin.hip: the order as a dependency window over the chip
-        ns_ = min(n, 2_000_000 if windowed else 20_000)
+    if rank == 0 and world == 1:
+        # seqwin.hip: the order as a dependency window over the chip (degree-2 FMs, several orders / degree <= 6, field-aware
+        # models whose chain terms -- one per entry and per pair of entries -- fit a mailbox)
+        windowed = k <= 64 and wl["degree"] <= 6 and (not F or m + m * (m - 1) // 2 <= 252)
+        ns_ = min(n, (2_000_000 if not F and wl["degree"] == 2 else 500_000) if windowed else 20_000)
         Xs = nf.CSRDataset.from_device(ctx, ns_, d, ns_ * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(),
-                                       keep=(indptr, indices, data))
+                                       fields_ptr=_keep_fields.data_ptr() if F else None, nFields=F,
+                                       keep=(indptr, indices, data, _keep_fields))
         Xs.set_targets(np.ascontiguousarray(y[:ns_]))
-        fm_s = nf.newFactorizationMachine(task, degree=wl["degree"], nComponents=k, warmStart=True, randomState=1)
+        if F:
+            fm_s = nf.newFieldAwareFactorizationMachine(task, nComponents=k, warmStart=True, randomState=1)
+        else:
+            fm_s = nf.newFactorizationMachine(task, degree=wl["degree"], nComponents=k, warmStart=True, randomState=1)
         fm_s.init(Xs)
         mk_ = nf.newSGD if wl["solver"] == "sgd" else nf.newAdaGrad
         opt_s = mk_(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="sequential")
