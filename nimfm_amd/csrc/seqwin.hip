@@ -591,12 +591,26 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
   int* jl = reinterpret_cast<int*>(nwl + (ADA ? mcap : 0));  // [mcap] feature ids
   int* fl = jl + mcap;                                       // [mcap] fields
   int* pl = fl + mcap;                                       // [mcap] previous position with the same feature
-  int* fcnt = pl + mcap;                                     // [F] entries of the sample per field
+  int* ll = pl + mcap;                                       // [mcap] 1: the entry's rows come from their writer's recipe
+  int* fcnt = ll + mcap;                                     // [F] entries of the sample per field
   int* fent = fcnt + F;                                      // [F][mcap] ... which ones, ascending
   unsigned* cnt = reinterpret_cast<unsigned*>(fent + (size_t)F * mcap);  // [W]
   for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
   double loss_acc = 0.0, viol_acc = 0.0;
   const ull lt_mask = lane == 0 ? 0ull : (~0ull >> (kWave - lane));
+  const int nb = F;  // (a slot is (entry, field): the forwarding below is the higher-degree worker's, field for order)
+  // Recipe forwarding per slot, as in win_worker_fmx below: of a hot entry (its feature is asked for again within W
+  // positions; among the sample's first kFxHot entries -- as many as the area holds) the writer posts, per order, the row as it used it and the row's
+  // DERIVATIVE (known before the conductor answers), AdaGrad's state rows as loaded, and the linear weight; the successor
+  // forms the rows the writer will write from them and the conductor's dL for the writer's sample.
+  const int hot_cap = (int)((size_t)kFwVals * kWave * kWave / ((size_t)nb * 4 * Kp));  // entries whose recipes a forwarding area holds
+  const int kFxHot = hot_cap < kWave ? hot_cap : kWave;
+  const bool fwd_on = kFxHot >= 1;
+  auto fw_area = [&](int64_t u_) { return a.fw + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kFwSlot; };
+  auto fw_slot = [&](ull* base, int q, int o, int v) { return base + kFwRows + ((size_t)((q * nb + o) * 4 + v) * Kp + s) * 2; };
+  auto fw_lin = [&](ull* base, int v, int q) { return base + kFwLin + (size_t)(v * kWave + q) * 2; };
+  auto res_of = [&](int64_t u_) { return a.res + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kResWords; };
+
 
   for (int64_t u = slot; u < a.n_seg; u += W) {
     const int64_t pos = a.seg0 + u, pa = a.begin + pos;
@@ -610,12 +624,25 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
     const int par = (int)((u >> lgW) & 1);
     ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
     const ull* rp = a.res + (size_t)(slot * 2 + par) * kResWords;
+    const bool e_in = lane < m;
+    const int pq = e_in ? a.prev[q0 + lane] : -1;
+    const int pqu = e_in ? (int)a.prevq[q0 + lane] : 0;
+    const int nq = e_in ? a.next[q0 + lane] : -1;
+    bool near;
+    {
+      const int64_t v = (int64_t)pq - a.seg0;
+      const bool pend = v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW);
+      near = fwd_on && pend && (pos - (int64_t)pq) < W && pqu < kFxHot;
+    }
+    const ull fwdmask = __ballot(near);
+    const ull hotmask = __ballot(fwd_on && lane < kFxHot && nq >= 0 && ((int64_t)nq - pos) < W);
     for (int q = lane; q < mcap; q += kWave) {
       const bool in = q < m;
       jl[q] = in ? X.indices[q0 + q] : 0;
       fl[q] = in ? X.fields[q0 + q] : 0;
       vl[q] = in ? X.data[q0 + q] : 0.0;
       pl[q] = in ? a.prev[q0 + q] : -1;
+      ll[q] = (q < kWave && near) ? 1 : 0;
     }
     compiler_fence();
     double* const junk = reinterpret_cast<double*>(a.fw + (size_t)2 * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
@@ -628,7 +655,7 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
         bool need = false;
         for (int q = lane; q < m; q += kWave) {
           const int64_t v = (int64_t)pl[q] - a.seg0;
-          if (v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW)) need = true;
+          if (v >= 0 && !ll[q] && cnt[v & (W - 1)] <= (unsigned)(v >> lgW)) need = true;
         }
         if (!__any(need)) break;
         if (!first && sp.wait(a.ctrl)) return;
@@ -667,7 +694,7 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
 #pragma unroll
       for (int t = 0; t < U; ++t) {
         const int c = cb + t * R + r;
-        const bool in = c < nsl;
+        const bool in = c < nsl && !ll[c / F];  // (a forwarded entry's rows are done again in B2)
         double p = v_[t];
         if constexpr (ADA) {
           if (it != 1) {
@@ -690,7 +717,7 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
           const double gw = ld_f64(O.Gw + j), nw_ = ld_f64(O.Nw + j);
           gwl[q] = gw;
           nwl[q] = nw_;
-          if (it != 1) {
+          if (it != 1 && !ll[q]) {
             const double nv = -O.eta0 * gw / (denw + sqrt(nw_));
             viol_acc += fabs(wv - nv);
             st_f64(M.w + j, nv);
@@ -700,6 +727,127 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
       }
       wl[q] = wv;
     }
+    compiler_fence();
+    // ---- B2. near dependencies: the writer's recipe + the conductor's dL for the WRITER's sample -> the rows as the writer
+    // will (or did) write them ----
+    if (fwdmask) {
+      const bool mine = (fwdmask >> lane) & 1ull;  // lane = entry
+      const int64_t upl = (int64_t)pq - a.seg0;
+      const unsigned tagl = (unsigned)(upl + 1);
+      ull* srcl = fw_area(mine ? upl : 0);
+      const ull* rsrcl = res_of(mine ? upl : 0);
+      double wu = 0.0, gwu = 0.0, nwu = 0.0, vsl = 0.0, dLl = 0.0;
+      bool okl = true;
+      auto load_lin = [&]() {
+        okl = true;
+        if (mine) {
+          okl = fw_load(fw_lin(srcl, 0, pqu), tagl, wu);
+          if (ADA && M.fit_linear) {
+            okl = fw_load(fw_lin(srcl, 1, pqu), tagl, gwu) && okl;
+            okl = fw_load(fw_lin(srcl, 2, pqu), tagl, nwu) && okl;
+          }
+          okl = fw_load(fw_lin(srcl, 3, pqu), tagl, vsl) && okl;
+        }
+      };
+      load_lin();
+      double sPul = 1.0, etaPul = 0.0, sPnul = 1.0, swul = 1.0, etawul = 0.0;
+      if constexpr (!ADA) {  // the writers' scales and step sizes: functions of their step counters alone
+        if (mine) {
+          sPul = a.scales[2 * (a.seg0 + upl)];
+          swul = a.scales[2 * (a.seg0 + upl) + 1];
+          etaPul = dev::get_eta(O.sched, O.eta0, O.power, O.beta, (double)(a.it0 + upl));
+          etawul = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, (double)(a.it0 + upl));
+          sPnul = sPul * (1 - etaPul * O.beta);
+        }
+      }
+      {
+        Spin sp;
+        while (true) {
+          bool ok = true;
+          if (mine) ok = fw_load(rsrcl, tagl, dLl);
+          if (!__all(okl)) load_lin();
+          if (__all(ok)) break;
+          if (sp.wait(a.ctrl)) return;
+        }
+      }
+      {
+        Spin sp;
+        while (!__all(okl)) {
+          if (sp.wait(a.ctrl)) return;
+          load_lin();
+        }
+      }
+      for (ull mk = fwdmask; mk; mk &= mk - 1) {
+        const int q = __builtin_ctzll(mk);
+        const int64_t up = (int64_t)__builtin_amdgcn_readlane(pq, q) - a.seg0;
+        const unsigned tag = (unsigned)(up + 1);
+        ull* src = fw_area(up);
+        const int qu = __builtin_amdgcn_readlane(pqu, q);
+        const double dLu = dev::shfl_d(dLl, q);
+        const double sPu = dev::shfl_d(sPul, q), etaPu = dev::shfl_d(etaPul, q), sPnu = dev::shfl_d(sPnul, q);
+        for (int o = 0; o < nb; ++o) {
+          double pv, dv, gv = 0.0, nv = 0.0;
+          {
+            Spin sp;
+            while (true) {
+              bool ok = fw_load(fw_slot(src, qu, o, 0), tag, pv);
+              ok = fw_load(fw_slot(src, qu, o, 1), tag, dv) && ok;
+              if constexpr (ADA) {
+                ok = fw_load(fw_slot(src, qu, o, 2), tag, gv) && ok;
+                ok = fw_load(fw_slot(src, qu, o, 3), tag, nv) && ok;
+              }
+              if (__all(ok)) break;
+              if (sp.wait(a.ctrl)) return;
+            }
+          }
+          const size_t c = (size_t)q * nb + o;
+          const size_t e = M.row(o, jl[q]) * (size_t)Kp + s;
+          double p;
+          if constexpr (ADA) {  // the writer's updateG of this row, then this sample's update() of it
+            const double grad = dLu * dv;
+            const double g = gv + grad, n = nv + grad * grad;
+            p = pv;
+            if (it != 1) {
+              p = dev::adagrad_param(g, n, O.eta0, tmpP);
+              if (r == 0) {
+                viol_acc += fabs(pv - p);
+                st_f64(M.P + e, p);
+              }
+            }
+            Gl[c * Kp + s] = g;
+            Nl[c * Kp + s] = n;
+          } else {  // the writer's update() of this row with ITS scale and step size
+            const double pw = sPu * pv;
+            const double update = etaPu * (dLu * dv + O.beta * pw);
+            p = (pw - update) / sPnu;
+          }
+          Pl[c * Kp + s] = p;  // (all row slots write the same value)
+        }
+      }
+      if (mine) {  // the linear weight of the shared feature, the same way
+        double wv = wu;
+        if (M.fit_linear) {
+          if constexpr (ADA) {
+            const double gg = dLl * vsl;
+            const double gw = gwu + gg, nw_ = nwu + gg * gg;
+            gwl[lane] = gw;
+            nwl[lane] = nw_;
+            if (it != 1) {
+              const double nv = -O.eta0 * gw / (denw + sqrt(nw_));
+              viol_acc += fabs(wv - nv);
+              st_f64(M.w + jl[lane], nv);
+              wv = nv;
+            }
+          } else {
+            const double wj = swul * wu;
+            wv = (wj - etawul * (dLl * vsl + O.alpha * wj)) / (swul * (1 - etawul * O.alpha));
+          }
+        }
+        wl[lane] = wv;
+      }
+      compiler_fence();
+    }
+
     // the sample's entries by field, ascending (sgd_ffm.nim:24-30 walks a field's entries in this order)
     for (int f = lane; f < F; f += kWave) {
       int c_ = 0;
@@ -769,6 +917,36 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
       else if (e == MC + 2) val = h2;
       else val = (double)(m + n_pairs);  // the number of chain terms
       if (put) st_u64(mb + e, mail_bits(val));
+    }
+
+    // (after the mailbox: a successor needs them together with this sample's dL, which the conductor forms from the mailbox)
+    if (hotmask) {
+      const unsigned mytag = (unsigned)(u + 1);
+      ull* fwm = fw_area(u);
+      for (ull mk = hotmask; mk; mk &= mk - 1) {
+        const int q = __builtin_ctzll(mk);
+        if (r == 0) {
+          for (int o = 0; o < nb; ++o) {
+            const size_t c = (size_t)q * nb + o;
+            fw_store(fw_slot(fwm, q, o, 0), mytag, Pl[c * Kp + s]);
+            fw_store(fw_slot(fwm, q, o, 1), mytag, Tl[c * Kp + s]);
+            if constexpr (ADA) {
+              fw_store(fw_slot(fwm, q, o, 2), mytag, Gl[c * Kp + s]);
+              fw_store(fw_slot(fwm, q, o, 3), mytag, Nl[c * Kp + s]);
+            }
+          }
+        }
+      }
+      if ((hotmask >> lane) & 1ull) {
+        fw_store(fw_lin(fwm, 0, lane), mytag, wl[lane]);
+        if constexpr (ADA) {
+          if (M.fit_linear) {
+            fw_store(fw_lin(fwm, 1, lane), mytag, gwl[lane]);
+            fw_store(fw_lin(fwm, 2, lane), mytag, nwl[lane]);
+          }
+        }
+        fw_store(fw_lin(fwm, 3, lane), mytag, vl[lane]);
+      }
     }
 
     // ---- D. the step sizes while the conductor works ----
@@ -2211,7 +2389,7 @@ static size_t win_ffm_lds(const ModelView& M, int m_cap, bool ada, int W) {  // 
   const int grp = (kWave >> lgKp) * 4;
   const size_t mcs = ((size_t)m_cap * M.nb + grp - 1) / grp * grp;
   return sizeof(double) * ((ada ? 4 : 2) * mcs * M.Kp + (ada ? 4 : 2) * (size_t)m_cap) +
-         sizeof(int) * (3 * (size_t)m_cap + M.nb + (size_t)M.nb * m_cap) + sizeof(unsigned) * W + 64;
+         sizeof(int) * (4 * (size_t)m_cap + M.nb + (size_t)M.nb * m_cap) + sizeof(unsigned) * W + 64;
 }
 
 static size_t win_fmx_lds(const ModelView& M, int m_cap, bool ada, int W) {  // the carve-up of win_worker_fmx
