@@ -1063,96 +1063,108 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
 // ------------------------------------------------------------------------------------------------------------------
 template <int OPT>
 __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot, double* lds) {
+  // Four wavefronts per worker, as in win_worker_ffm: the slots are dealt to the wavefronts, the phases are separated by
+  // workgroup barriers; wavefront 0 alone talks to the counters and writes the mailbox.
   const CsrView& X = a.X;
   const ModelView& M = a.M;
   const OptView& O = a.O;
   constexpr bool ADA = OPT == OPT_ADAGRAD;
-  constexpr int U = 4, DG = dev::kMaxDeg;
-  const int lane = threadIdx.x;
-  const int Kp = M.Kp, lgK = a.lgKp, k = M.k, nb = M.nb, mcap = a.m_cap;
+  constexpr int U = 4, NW = kFfmWaves, DG = dev::kMaxDeg;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
+  const int Kp = M.Kp, lgK = a.lgKp, k = M.k, F = M.nb, mcap = a.m_cap;
   const int R = kWave >> lgK, r = lane >> lgK, s = lane & (Kp - 1);
-  const int mcs = (mcap * nb + R * U - 1) / (R * U) * (R * U);  // slots, padded to whole groups
+  const int mcs = (mcap * F + R * U - 1) / (R * U) * (R * U);  // slots, padded to whole groups
   const int W = a.W, lgW = a.lgW;
   double* Pl = lds;                                   // [mcs][Kp] stored parameter values of the sample's slots
   double* Tl = Pl + (size_t)mcs * Kp;                 // [mcs][Kp] the slots' derivative
   double* Gl = Tl + (size_t)mcs * Kp;                 // AdaGrad: g_sum
   double* Nl = Gl + (ADA ? (size_t)mcs * Kp : 0);     // AdaGrad: g_norm
-  double* red = Nl + (ADA ? (size_t)mcs * Kp : 0);    // [64]
-  double* vl = red + kWave;                           // [mcap] values
+  double* red = Nl + (ADA ? (size_t)mcs * Kp : 0);    // [64] an order's kernel per factor
+  double* bc = red + kWave;              // [4][64] per near entry: the writer's dL, scale, step size, next scale
+  double* vsum = bc + 4 * kWave;                      // [NW] the wavefronts' viol
+  double* vl = vsum + NW;                             // [mcap] values
   double* wl = vl + mcap;                             // [mcap] stored linear weights (AdaGrad: after update())
   double* gwl = wl + mcap;                            // AdaGrad: [mcap]
   double* nwl = gwl + (ADA ? mcap : 0);               // AdaGrad: [mcap]
-  int* jl = reinterpret_cast<int*>(nwl + (ADA ? mcap : 0));  // [mcap] feature ids
+  ull* mk_l = reinterpret_cast<ull*>(nwl + (ADA ? mcap : 0));  // [2] {near entries, hot entries} of the sample
+  int* jl = reinterpret_cast<int*>(mk_l + 2);                  // [mcap] feature ids
   int* pl = jl + mcap;                                       // [mcap] previous position with the same feature
-  int* ll = pl + mcap;                                       // [mcap] 1: the entry's rows come from their writer's recipe
-  unsigned* cnt = reinterpret_cast<unsigned*>(ll + mcap);    // [W]
-  for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
+  int* ql = pl + mcap;                                       // [mcap] the feature's entry index in that sample
+  int* ll = ql + mcap;                                       // [mcap] 1: the entry's rows come from their writer's recipe
+  unsigned* cnt = reinterpret_cast<unsigned*>(ll + mcap);    // [W] (wavefront 0's)
+  if (wv == 0)
+    for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
   double loss_acc = 0.0, viol_acc = 0.0;
+  const int nb = F;
   // Recipe forwarding as in the general worker, per slot: of a hot entry (its feature is asked for again within W
-  // positions; among the sample's first kFxHot entries -- as many as the area holds) the writer posts, per order, the row as it used it and the row's
-  // DERIVATIVE (known before the conductor answers), AdaGrad's state rows as loaded, and the linear weight; the successor
-  // forms the rows the writer will write from them and the conductor's dL for the writer's sample.
-  const int hot_cap = (int)((size_t)kFwVals * kWave * kWave / ((size_t)nb * 4 * Kp));  // entries whose recipes a forwarding area holds
+  // positions; among the sample's first kFxHot entries -- as many as the area holds) the writer posts, per order, the row
+  // as it used it and the row's DERIVATIVE (known before the conductor answers), AdaGrad's state rows as loaded, and the
+  // linear weight; the successor forms the rows the writer will write from them and the conductor's dL for the writer's sample.
+  const int hot_cap = (int)((size_t)kFwVals * kWave * kWave / ((size_t)nb * 4 * Kp));
   const int kFxHot = hot_cap < kWave ? hot_cap : kWave;
   const bool fwd_on = kFxHot >= 1;
   auto fw_area = [&](int64_t u_) { return a.fw + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kFwSlot; };
   auto fw_slot = [&](ull* base, int q, int o, int v) { return base + kFwRows + ((size_t)((q * nb + o) * 4 + v) * Kp + s) * 2; };
   auto fw_lin = [&](ull* base, int v, int q) { return base + kFwLin + (size_t)(v * kWave + q) * 2; };
   auto res_of = [&](int64_t u_) { return a.res + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kResWords; };
+  __syncthreads();
 
   for (int64_t u = slot; u < a.n_seg; u += W) {
     const int64_t pos = a.seg0 + u, pa = a.begin + pos;
     const int64_t i = a.perm ? a.perm[pa] : pa;
     const int64_t q0 = X.indptr[i];
     const int m = (int)(X.indptr[i + 1] - q0);
-    const int nsl = m * nb;
+    const int nsl = m * F;
     const double y = dev::target_of(X.y[i], M.task);
     const int64_t it = a.it0 + u;
     const double itf = (double)it;
     const int par = (int)((u >> lgW) & 1);
     ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
     const ull* rp = a.res + (size_t)(slot * 2 + par) * kResWords;
-    const bool e_in = lane < m;
-    const int pq = e_in ? a.prev[q0 + lane] : -1;
-    const int pqu = e_in ? (int)a.prevq[q0 + lane] : 0;
-    const int nq = e_in ? a.next[q0 + lane] : -1;
-    bool near;
-    {
+    // ---- 0. the entries; which of them take the forwarding path (wavefront 0 decides for all) ----
+    if (wv == 0) {
+      const bool e_in = lane < m;
+      const int pq = e_in ? a.prev[q0 + lane] : -1;
+      const int pqu = e_in ? (int)a.prevq[q0 + lane] : 0;
+      const int nq = e_in ? a.next[q0 + lane] : -1;
       const int64_t v = (int64_t)pq - a.seg0;
       const bool pend = v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW);
-      near = fwd_on && pend && (pos - (int64_t)pq) < W && pqu < kFxHot;
-    }
-    const ull fwdmask = __ballot(near);
-    const ull hotmask = __ballot(fwd_on && lane < kFxHot && nq >= 0 && ((int64_t)nq - pos) < W);
-    for (int q = lane; q < mcap; q += kWave) {
-      const bool in = q < m;
-      jl[q] = in ? X.indices[q0 + q] : 0;
-      vl[q] = in ? X.data[q0 + q] : 0.0;
-      pl[q] = in ? a.prev[q0 + q] : -1;
-      ll[q] = (q < kWave && near) ? 1 : 0;
-    }
-    compiler_fence();
-    double* const junk = reinterpret_cast<double*>(a.fw + (size_t)2 * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
-
-    // ---- A. every earlier sample of this launch that shares a feature has written its rows ----
-    {
+      const bool near = fwd_on && pend && (pos - (int64_t)pq) < W && pqu < kFxHot;
+      const ull fm_ = __ballot(near), hm_ = __ballot(fwd_on && lane < kFxHot && nq >= 0 && ((int64_t)nq - pos) < W);
+      if (lane == 0) {
+        mk_l[0] = fm_;
+        mk_l[1] = hm_;
+      }
+      for (int q = lane; q < mcap; q += kWave) {
+        const bool in = q < m;
+        jl[q] = in ? X.indices[q0 + q] : 0;
+        vl[q] = in ? X.data[q0 + q] : 0.0;
+        pl[q] = in ? a.prev[q0 + q] : -1;
+        ql[q] = in ? (int)a.prevq[q0 + q] : 0;
+        ll[q] = (q < kWave && near) ? 1 : 0;
+      }
+      compiler_fence();
+      // ---- A. every earlier sample of this launch that shares a feature has written its rows (far ones only) ----
       Spin sp;
       bool first = true;
       while (true) {
         bool need = false;
         for (int q = lane; q < m; q += kWave) {
-          const int64_t v = (int64_t)pl[q] - a.seg0;
-          if (v >= 0 && !ll[q] && cnt[v & (W - 1)] <= (unsigned)(v >> lgW)) need = true;
+          const int64_t v2 = (int64_t)pl[q] - a.seg0;
+          if (v2 >= 0 && !ll[q] && cnt[v2 & (W - 1)] <= (unsigned)(v2 >> lgW)) need = true;
         }
         if (!__any(need)) break;
-        if (!first && sp.wait(a.ctrl)) return;
+        if (!first && sp.wait(a.ctrl)) break;  // (aborting: every wait below ends the same way)
         first = false;
         for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
         compiler_fence();
       }
     }
+    __syncthreads();
+    const ull fwdmask = mk_l[0], hotmask = mk_l[1];
+    double* const junk = reinterpret_cast<double*>(a.fw + (size_t)2 * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
 
-    // ---- B. the rows of every (entry, order) -> LDS (AdaGrad: update() first, adagrad.nim:87-110) ----
+    // ---- B. the rows of every (entry, order) -> LDS (AdaGrad: update() first, adagrad.nim:87-110): the slots dealt to the wavefronts ----
     double sP = 1.0, sw = 1.0;
     if constexpr (!ADA) {
       sP = a.scales[2 * pos];
@@ -1160,12 +1172,13 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
     }
     const double itp = (double)(it - 1);
     const double tmpP = O.eta0 * itp * O.beta;
+    const double denw = itp * O.eta0 * O.alpha;
     auto slot_row = [&](int c) {  // where slot c's row starts (a slot past the end: slot 0)
       const int cc = c < nsl ? c : 0;
-      const int q = cc / nb, o = cc - q * nb;
-      return M.row(o, jl[q]) * (size_t)Kp + s;
+      const int q = cc / F, f = cc - q * F;
+      return M.row(f, jl[q]) * (size_t)Kp + s;
     };
-    for (int cb = 0; cb < nsl; cb += R * U) {
+    for (int cb = wv * R * U; cb < nsl; cb += NW * R * U) {
       double v_[U], g_[ADA ? U : 1], n_[ADA ? U : 1];
       size_t e_[U];
 #pragma unroll
@@ -1181,7 +1194,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
 #pragma unroll
       for (int t = 0; t < U; ++t) {
         const int c = cb + t * R + r;
-        const bool in = c < nsl && !ll[c / nb];  // (a forwarded entry's rows are done again in B2)
+        const bool in = c < nsl && !ll[c / F];  // (a forwarded entry's rows are done again in B2)
         double p = v_[t];
         if constexpr (ADA) {
           if (it != 1) {
@@ -1195,85 +1208,110 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
         Pl[(size_t)c * Kp + s] = p;
       }
     }
-    const double denw = itp * O.eta0 * O.alpha;
-    for (int q = lane; q < m; q += kWave) {
-      const int j = jl[q];
-      double wv = ld_f64(M.w + j);
-      if constexpr (ADA) {
-        if (M.fit_linear) {
-          const double gw = ld_f64(O.Gw + j), nw_ = ld_f64(O.Nw + j);
-          gwl[q] = gw;
-          nwl[q] = nw_;
-          if (it != 1 && !ll[q]) {
-            const double nv = -O.eta0 * gw / (denw + sqrt(nw_));
-            viol_acc += fabs(wv - nv);
-            st_f64(M.w + j, nv);
-            wv = nv;
+    if (wv == NW - 1) {  // the linear weights (the last wavefront has the fewest slots)
+      for (int q = lane; q < m; q += kWave) {
+        const int j = jl[q];
+        double wvv = ld_f64(M.w + j);
+        if constexpr (ADA) {
+          if (M.fit_linear) {
+            const double gw = ld_f64(O.Gw + j), nw_ = ld_f64(O.Nw + j);
+            gwl[q] = gw;
+            nwl[q] = nw_;
+            if (it != 1 && !ll[q]) {
+              const double nv = -O.eta0 * gw / (denw + sqrt(nw_));
+              viol_acc += fabs(wvv - nv);
+              st_f64(M.w + j, nv);
+              wvv = nv;
+            }
           }
         }
+        wl[q] = wvv;
       }
-      wl[q] = wv;
     }
-    compiler_fence();
+    __syncthreads();
 
     // ---- B2. near dependencies: the writer's recipe + the conductor's dL for the WRITER's sample -> the rows as the writer
-    // will (or did) write them ----
+    // will (or did) write them.  Wavefront 0 polls what is per entry, all wavefronts form the rows (fields dealt out) ----
     if (fwdmask) {
-      const bool mine = (fwdmask >> lane) & 1ull;  // lane = entry
-      const int64_t upl = (int64_t)pq - a.seg0;
-      const unsigned tagl = (unsigned)(upl + 1);
-      ull* srcl = fw_area(mine ? upl : 0);
-      const ull* rsrcl = res_of(mine ? upl : 0);
-      double wu = 0.0, gwu = 0.0, nwu = 0.0, vsl = 0.0, dLl = 0.0;
-      bool okl = true;
-      auto load_lin = [&]() {
-        okl = true;
-        if (mine) {
-          okl = fw_load(fw_lin(srcl, 0, pqu), tagl, wu);
-          if (ADA && M.fit_linear) {
-            okl = fw_load(fw_lin(srcl, 1, pqu), tagl, gwu) && okl;
-            okl = fw_load(fw_lin(srcl, 2, pqu), tagl, nwu) && okl;
+      if (wv == 0) {
+        const bool mine = (fwdmask >> lane) & 1ull;  // lane = entry
+        const int64_t upl = (int64_t)pl[mine ? lane : 0] - a.seg0;
+        const int pqu = ql[mine ? lane : 0];
+        const unsigned tagl = (unsigned)(upl + 1);
+        ull* srcl = fw_area(mine ? upl : 0);
+        const ull* rsrcl = res_of(mine ? upl : 0);
+        double wu = 0.0, gwu = 0.0, nwu = 0.0, vsl = 0.0, dLl = 0.0;
+        bool okl = true, dead = false;
+        auto load_lin = [&]() {
+          okl = true;
+          if (mine) {
+            okl = fw_load(fw_lin(srcl, 0, pqu), tagl, wu);
+            if (ADA && M.fit_linear) {
+              okl = fw_load(fw_lin(srcl, 1, pqu), tagl, gwu) && okl;
+              okl = fw_load(fw_lin(srcl, 2, pqu), tagl, nwu) && okl;
+            }
+            okl = fw_load(fw_lin(srcl, 3, pqu), tagl, vsl) && okl;
           }
-          okl = fw_load(fw_lin(srcl, 3, pqu), tagl, vsl) && okl;
+        };
+        load_lin();
+        double sPul = 1.0, etaPul = 0.0, sPnul = 1.0, swul = 1.0, etawul = 0.0;
+        if constexpr (!ADA) {
+          if (mine) {
+            sPul = a.scales[2 * (a.seg0 + upl)];
+            swul = a.scales[2 * (a.seg0 + upl) + 1];
+            etaPul = dev::get_eta(O.sched, O.eta0, O.power, O.beta, (double)(a.it0 + upl));
+            etawul = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, (double)(a.it0 + upl));
+            sPnul = sPul * (1 - etaPul * O.beta);
+          }
         }
-      };
-      load_lin();
-      double sPul = 1.0, etaPul = 0.0, sPnul = 1.0, swul = 1.0, etawul = 0.0;
-      if constexpr (!ADA) {  // the writers' scales and step sizes: functions of their step counters alone
-        if (mine) {
-          sPul = a.scales[2 * (a.seg0 + upl)];
-          swul = a.scales[2 * (a.seg0 + upl) + 1];
-          etaPul = dev::get_eta(O.sched, O.eta0, O.power, O.beta, (double)(a.it0 + upl));
-          etawul = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, (double)(a.it0 + upl));
-          sPnul = sPul * (1 - etaPul * O.beta);
+        {
+          Spin sp;
+          while (true) {
+            bool ok = true;
+            if (mine) ok = fw_load(rsrcl, tagl, dLl);
+            if (!__all(okl)) load_lin();
+            if (__all(ok) && __all(okl)) break;
+            if (sp.wait(a.ctrl)) {
+              dead = true;
+              break;
+            }
+          }
+        }
+        if (mine && !dead) {
+          bc[lane] = dLl;
+          bc[kWave + lane] = sPul;
+          bc[2 * kWave + lane] = etaPul;
+          bc[3 * kWave + lane] = sPnul;
+          double wvv = wu;  // the linear weight of the shared feature, the same way
+          if (M.fit_linear) {
+            if constexpr (ADA) {
+              const double gg = dLl * vsl;
+              const double gw = gwu + gg, nw_ = nwu + gg * gg;
+              gwl[lane] = gw;
+              nwl[lane] = nw_;
+              if (it != 1) {
+                const double nv = -O.eta0 * gw / (denw + sqrt(nw_));
+                viol_acc += fabs(wvv - nv);
+                st_f64(M.w + jl[lane], nv);
+                wvv = nv;
+              }
+            } else {
+              const double wj = swul * wu;
+              wvv = (wj - etawul * (dLl * vsl + O.alpha * wj)) / (swul * (1 - etawul * O.alpha));
+            }
+          }
+          wl[lane] = wvv;
         }
       }
-      {
-        Spin sp;
-        while (true) {
-          bool ok = true;
-          if (mine) ok = fw_load(rsrcl, tagl, dLl);
-          if (!__all(okl)) load_lin();
-          if (__all(ok)) break;
-          if (sp.wait(a.ctrl)) return;
-        }
-      }
-      {
-        Spin sp;
-        while (!__all(okl)) {
-          if (sp.wait(a.ctrl)) return;
-          load_lin();
-        }
-      }
+      __syncthreads();
       for (ull mk = fwdmask; mk; mk &= mk - 1) {
         const int q = __builtin_ctzll(mk);
-        const int64_t up = (int64_t)__builtin_amdgcn_readlane(pq, q) - a.seg0;
+        const int64_t up = (int64_t)pl[q] - a.seg0;
         const unsigned tag = (unsigned)(up + 1);
         ull* src = fw_area(up);
-        const int qu = __builtin_amdgcn_readlane(pqu, q);
-        const double dLu = dev::shfl_d(dLl, q);
-        const double sPu = dev::shfl_d(sPul, q), etaPu = dev::shfl_d(etaPul, q), sPnu = dev::shfl_d(sPnul, q);
-        for (int o = 0; o < nb; ++o) {
+        const int qu = ql[q];
+        const double dLu = bc[q], sPu = bc[kWave + q], etaPu = bc[2 * kWave + q], sPnu = bc[3 * kWave + q];
+        for (int o = wv; o < nb; o += NW) {
           double pv, dv, gv = 0.0, nv = 0.0;
           {
             Spin sp;
@@ -1285,13 +1323,13 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
                 ok = fw_load(fw_slot(src, qu, o, 3), tag, nv) && ok;
               }
               if (__all(ok)) break;
-              if (sp.wait(a.ctrl)) return;
+              if (sp.wait(a.ctrl)) break;
             }
           }
           const size_t c = (size_t)q * nb + o;
           const size_t e = M.row(o, jl[q]) * (size_t)Kp + s;
           double p;
-          if constexpr (ADA) {  // the writer's updateG of this row, then this sample's update() of it
+          if constexpr (ADA) {
             const double grad = dLu * dv;
             const double g = gv + grad, n = nv + grad * grad;
             p = pv;
@@ -1304,39 +1342,19 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
             }
             Gl[c * Kp + s] = g;
             Nl[c * Kp + s] = n;
-          } else {  // the writer's update() of this row with ITS scale and step size
+          } else {
             const double pw = sPu * pv;
             const double update = etaPu * (dLu * dv + O.beta * pw);
             p = (pw - update) / sPnu;
           }
-          Pl[c * Kp + s] = p;  // (all row slots write the same value)
+          Pl[c * Kp + s] = p;
         }
       }
-      if (mine) {  // the linear weight of the shared feature, the same way
-        double wv = wu;
-        if (M.fit_linear) {
-          if constexpr (ADA) {
-            const double gg = dLl * vsl;
-            const double gw = gwu + gg, nw_ = nwu + gg * gg;
-            gwl[lane] = gw;
-            nwl[lane] = nw_;
-            if (it != 1) {
-              const double nv = -O.eta0 * gw / (denw + sqrt(nw_));
-              viol_acc += fabs(wv - nv);
-              st_f64(M.w + jl[lane], nv);
-              wv = nv;
-            }
-          } else {
-            const double wj = swul * wu;
-            wv = (wj - etawul * (dLl * vsl + O.alpha * wj)) / (swul * (1 - etawul * O.alpha));
-          }
-        }
-        wl[lane] = wv;
-      }
-      compiler_fence();
+      __syncthreads();
     }
 
-    // ---- C. per order: computeAnova (sgd.nim:146-173) and computeAnovaDerivative (:176-188) ----
+    // ---- C. per order: computeAnova (sgd.nim:146-173) in every wavefront, computeAnovaDerivative (:176-188) of the
+    // order's slots dealt to the wavefronts; one chain term per order behind the linear terms ----
     const int MC = a.FW - kWinHdr;
     for (int o = 0; o < nb; ++o) {
       const int deg = M.degree - o;
@@ -1370,7 +1388,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
         for (int t = 2; t <= DG; ++t) A[t] = 0.0;
         kv = (a1 * a1 - a2) / 2;
       }
-      for (int qb = 0; qb < m; qb += R) {  // the order's slots: row slot r takes entries r, r + R, ...
+      for (int qb = wv * R; qb < m; qb += NW * R) {  // the order's slots: row slot r of wavefront wv takes entries wv R + r, ...
         const int q = qb + r;
         if (q < m) {
           const double val = vl[q];
@@ -1387,33 +1405,37 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
           Tl[((size_t)q * nb + o) * Kp + s] = d_;
         }
       }
-      if (r == 0) red[s] = s < k ? kv : 0.0;
-      compiler_fence();
-      double tot = 0.0;
-      for (int sb = 0; sb < k; sb += 8) {  // sgd.nim:172-173, ascending s
-        double r_[8];
+      if (wv == 0) {
+        if (r == 0) red[s] = s < k ? kv : 0.0;
+        compiler_fence();
+        double tot = 0.0;
+        for (int sb = 0; sb < k; sb += 8) {  // sgd.nim:172-173, ascending s
+          double r_[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) r_[t] = red[sb + t < k ? sb + t : sb];
+          for (int t = 0; t < 8; ++t) r_[t] = red[sb + t < k ? sb + t : sb];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) tot = sb + t < k ? tot + r_[t] : tot;
+          for (int t = 0; t < 8; ++t) tot = sb + t < k ? tot + r_[t] : tot;
+        }
+        compiler_fence();  // (red is written again by the next order)
+        if (lane == 0) st_u64(mb + m + o, mail_bits(tot));  // the order's kernel: a chain term behind the linear terms
       }
-      compiler_fence();  // (red is written again by the next order)
-      if (lane == 0) st_u64(mb + m + o, mail_bits(tot));  // the order's kernel: a chain term behind the linear terms
     }
-    const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
-    for (int e = lane; e < a.FW; e += kWave) {
-      double val;
-      bool put = true;
-      if (e < m) val = (sw * wl[e]) * vl[e];
-      else if (e < m + nb) put = false;  // an order's kernel, stored above
-      else if (e < MC) val = -0.0;       // (changes no sum)
-      else if (e == MC) val = -0.0;      // no separate interaction sum
-      else if (e == MC + 1) val = y;
-      else if (e == MC + 2) val = h2;
-      else val = (double)(m + nb);       // the number of chain terms
-      if (put) st_u64(mb + e, mail_bits(val));
+    if (wv == 0) {
+      const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
+      for (int e = lane; e < a.FW; e += kWave) {
+        double val;
+        bool put = true;
+        if (e < m) val = (sw * wl[e]) * vl[e];
+        else if (e < m + nb) put = false;  // an order's kernel, stored above
+        else if (e < MC) val = -0.0;       // (changes no sum)
+        else if (e == MC) val = -0.0;      // no separate interaction sum
+        else if (e == MC + 1) val = y;
+        else if (e == MC + 2) val = h2;
+        else val = (double)(m + nb);       // the number of chain terms
+        if (put) st_u64(mb + e, mail_bits(val));
+      }
     }
-
+    __syncthreads();  // (the derivatives of all slots, for the recipes and the update)
     // (after the mailbox: a successor needs them together with this sample's dL, which the conductor forms from the mailbox)
     if (hotmask) {
       const unsigned mytag = (unsigned)(u + 1);
@@ -1421,7 +1443,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
       for (ull mk = hotmask; mk; mk &= mk - 1) {
         const int q = __builtin_ctzll(mk);
         if (r == 0) {
-          for (int o = 0; o < nb; ++o) {
+          for (int o = wv; o < nb; o += NW) {
             const size_t c = (size_t)q * nb + o;
             fw_store(fw_slot(fwm, q, o, 0), mytag, Pl[c * Kp + s]);
             fw_store(fw_slot(fwm, q, o, 1), mytag, Tl[c * Kp + s]);
@@ -1432,7 +1454,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
           }
         }
       }
-      if ((hotmask >> lane) & 1ull) {
+      if (wv == NW - 1 && ((hotmask >> lane) & 1ull)) {
         fw_store(fw_lin(fwm, 0, lane), mytag, wl[lane]);
         if constexpr (ADA) {
           if (M.fit_linear) {
@@ -1453,24 +1475,31 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
       swn = sw * (1 - eta_w * O.alpha);
     }
 
-    // ---- E. {dL, yhat} from the conductor (tagged granules) ----
+    // ---- E. {dL, yhat} from the conductor (tagged granules): every wavefront takes them itself ----
     double dL, yh;
+    bool dead = false;
     {
       Spin sp;
       double rd;
       while (true) {
         const bool ok = fw_load(rp + (size_t)(lane & 1) * 2, (unsigned)(u + 1), rd);
         if (__all(ok)) break;
-        if (sp.wait(a.ctrl)) return;
+        if (sp.wait(a.ctrl)) {
+          dead = true;
+          break;
+        }
       }
       dL = dev::shfl_d(rd, 0);
       yh = dev::shfl_d(rd, 1);
     }
-    for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);  // (as in the general worker)
-    if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
+    if (dead) break;  // (the launch is being aborted: every wavefront finds the abort word set)
+    if (wv == 0) {
+      for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);  // (as in the general worker)
+      if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
+    }
 
-    // ---- F. update() / updateG() over all slots ----
-    for (int cb = 0; cb < nsl; cb += R * U) {
+    // ---- F. update() / updateG() over all slots (the shared loops of sgd.nim:205-243, adagrad.nim:113-134) ----
+    for (int cb = wv * R * U; cb < nsl; cb += NW * R * U) {
 #pragma unroll
       for (int t = 0; t < U; ++t) {
         const int c = cb + t * R + r;
@@ -1489,7 +1518,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
         }
       }
     }
-    if (M.fit_linear) {
+    if (M.fit_linear && wv == NW - 1) {
       for (int q = lane; q < m; q += kWave) {
         const int j = jl[q];
         if constexpr (ADA) {
@@ -1504,14 +1533,19 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
         }
       }
     }
-    // ---- G. rows written: tell the waiters ----
+    // ---- G. rows written (every wavefront's stores): tell the waiters ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
+    __syncthreads();
+    if (tid == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
   }
   viol_acc = dev::wave_sum(viol_acc);
-  if (lane == 0) {
+  if (lane == 0) vsum[wv] = viol_acc;
+  __syncthreads();
+  if (tid == 0) {
+    double v = 0.0;
+    for (int w_ = 0; w_ < NW; ++w_) v += vsum[w_];
     a.partial[2 * slot] = loss_acc;
-    a.partial[2 * slot + 1] = viol_acc;
+    a.partial[2 * slot + 1] = v;
   }
 }
 
@@ -2203,7 +2237,7 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
 
 enum { WK_GENERAL = 0, WK_K64 = 1, WK_FFM = 2, WK_FMX = 3 };  // which worker
 template <int OPT, int CH, int WK>
-__global__ __launch_bounds__(WK == WK_FFM ? kFfmWaves * kWave : 128) void k_seq_window(WinArgs a) {
+__global__ __launch_bounds__(WK >= WK_FFM ? kFfmWaves * kWave : 128) void k_seq_window(WinArgs a) {
   extern __shared__ double lds[];
   if (blockIdx.x == 0) {
     if (threadIdx.x < 2 * kWave) {
@@ -2213,9 +2247,10 @@ __global__ __launch_bounds__(WK == WK_FFM ? kFfmWaves * kWave : 128) void k_seq_
     }
   } else if constexpr (WK == WK_FFM) {
     win_worker_ffm<OPT>(a, (int)blockIdx.x - 1, lds);  // all wavefronts of the workgroup
+  } else if constexpr (WK == WK_FMX) {
+    win_worker_fmx<OPT>(a, (int)blockIdx.x - 1, lds);
   } else if (threadIdx.x < kWave) {
     if constexpr (WK == WK_K64) win_worker_k64<OPT>(a, (int)blockIdx.x - 1, lds);
-    else if constexpr (WK == WK_FMX) win_worker_fmx<OPT>(a, (int)blockIdx.x - 1, lds);
     else win_worker<OPT>(a, (int)blockIdx.x - 1, lds);
   }
 }
@@ -2435,8 +2470,8 @@ static size_t win_fmx_lds(const ModelView& M, int m_cap, bool ada, int W) {  // 
   while ((1 << lgKp) < M.Kp) ++lgKp;
   const int grp = (kWave >> lgKp) * 4;
   const size_t mcs = ((size_t)m_cap * M.nb + grp - 1) / grp * grp;
-  return sizeof(double) * ((ada ? 4 : 2) * mcs * M.Kp + kWave + (ada ? 4 : 2) * (size_t)m_cap) + sizeof(int) * 3 * (size_t)m_cap +
-         sizeof(unsigned) * W + 64;
+  return sizeof(double) * ((ada ? 4 : 2) * mcs * M.Kp + kWave + 4 * kWave + kFfmWaves + (ada ? 4 : 2) * (size_t)m_cap) + sizeof(ull) * 2 +
+         sizeof(int) * 4 * (size_t)m_cap + sizeof(unsigned) * W + 64;
 }
 
 bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz, int n_cu) {
@@ -2468,7 +2503,7 @@ static int launch_window_t(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes) {
   auto kern = k_seq_window<OPT, CH, WK>;
   NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   TimedLaunch tl(ctx, "sequential");
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.W + 1)), dim3(WK == WK_FFM ? kFfmWaves * kWave : 128), lds_bytes, ctx->stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.W + 1)), dim3(WK >= WK_FFM ? kFfmWaves * kWave : 128), lds_bytes, ctx->stream, a);
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }
