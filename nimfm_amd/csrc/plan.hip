@@ -1128,7 +1128,7 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
       if (fl_env >= 8 && fl_env <= 12) fl = fl_env;
       const int64_t nbk = ((X.d - 1) >> fl) + 1;
       const int64_t cells = P.n_batches * nbk;
-      if (nbk <= kSegMaxBuckets && cells <= ((int64_t)1 << 24) && bt / (double)nbk <= 0.75 * kSegCap) {
+      if (nbk <= kSegMaxBuckets && cells <= ((int64_t)1 << 23) && bt / (double)nbk <= 0.75 * kSegCap) {
         DevBuf rowstart, cellcnt, cellptr, items, mx, cellUT, cellOff;
         NFM_TRY(rowstart.alloc(sizeof(int64_t) * ns));
         NFM_TRY(cellcnt.alloc(sizeof(uint32_t) * (cells + 1)));
