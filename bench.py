@@ -592,14 +592,22 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     cap_eff = cap if wl["solver"] == "sgd" else float("inf")  # AdaGrad's state sums every step
     c_bar = c_bar_of(lam, cap_eff)
     t2t = None
-    if rank == 0 and world == 1 and not F and wl["degree"] == 2 and k <= 64 and (primary or name == "cfg2") and n >= 400_000:
-        n_t, n_h = min(1_000_000, n - 200_000), 200_000
+    t2t_window = k <= 64 and wl["degree"] <= 6 and (not F or m + m * (m - 1) // 2 <= 252)  # the exact order at speed (seqwin.hip)
+    if rank == 0 and world == 1 and t2t_window and (primary or name == "cfg2") and n >= 400_000:
+        n_t, n_h = min(1_000_000 if not F and wl["degree"] == 2 else 400_000, n - 200_000), 200_000
         ip_t = torch.arange(n_t + 1, device=dev, dtype=torch.int64) * m
         ip_h = torch.arange(n_h + 1, device=dev, dtype=torch.int64) * m
-        Xt = nf.CSRDataset.from_device(ctx, n_t, d, n_t * m, ip_t.data_ptr(), indices.data_ptr(), data.data_ptr(), keep=(ip_t, indices, data))
         off = n_t * m
+        Xt = nf.CSRDataset.from_device(ctx, n_t, d, n_t * m, ip_t.data_ptr(), indices.data_ptr(), data.data_ptr(),
+                                       fields_ptr=_keep_fields.data_ptr() if F else None, nFields=F, keep=(ip_t, indices, data, _keep_fields))
         Xh = nf.CSRDataset.from_device(ctx, n_h, d, n_h * m, ip_h.data_ptr(), indices.data_ptr() + 4 * off, data.data_ptr() + 8 * off,
-                                       keep=(ip_h, indices, data))
+                                       fields_ptr=_keep_fields.data_ptr() + 4 * off if F else None, nFields=F,
+                                       keep=(ip_h, indices, data, _keep_fields))
+
+        def new_model():
+            if F:
+                return nf.newFieldAwareFactorizationMachine(task, nComponents=k, warmStart=True, randomState=1)
+            return nf.newFactorizationMachine(task, degree=wl["degree"], nComponents=k, warmStart=True, randomState=1)
         y_t, y_h = np.ascontiguousarray(y[:n_t]), np.ascontiguousarray(y[n_t:n_t + n_h])
         Xt.set_targets(y_t)
 
@@ -611,7 +619,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
             return float(np.mean(0.5 * (p - y_h) ** 2))
 
         mk_ = nf.newSGD if wl["solver"] == "sgd" else nf.newAdaGrad
-        f_seq = nf.newFactorizationMachine(task, degree=2, nComponents=k, warmStart=True, randomState=1)
+        f_seq = new_model()
         f_seq.init(Xt)
         l_init = held_out_loss(f_seq)
         o_seq = mk_(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="sequential")
@@ -627,7 +635,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         def run_mb(batch_, cap_):
             lam_ = batch_ * m / d
             cb_ = c_bar_of(lam_, cap_ if wl["solver"] == "sgd" else float("inf"))
-            f_mb = nf.newFactorizationMachine(task, degree=2, nComponents=k, warmStart=True, randomState=1)
+            f_mb = new_model()
             f_mb.init(Xt)
             P_i, w_i = np.array(f_mb.P), np.array(f_mb.w)
             o_mb = mk_(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch", batch=batch_,
