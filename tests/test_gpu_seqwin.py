@@ -263,6 +263,7 @@ def _ffm_fit(kind, win, W, Xo, y, k, P0, w0, b0, epochs, perms=None, **kw):
     ("sgd", 16, 8, 64, 16, 16), ("adagrad", 16, 8, 64, 16, 64),    # cfg4's fields and factors
     ("sgd", 7, 20, 30, 7, 8), ("adagrad", 7, 20, 30, 7, 32),       # factors not a power of two
     ("sgd", 5, 4, 400, 20, 64), ("adagrad", 5, 4, 400, 20, 64),    # 20 entries: 210 chain terms, several entries per field
+    ("sgd", 4, 64, 40, 8, 16), ("adagrad", 2, 33, 25, 10, 8),      # 64 factors per row (one row per instruction)
 ])
 def test_field_aware_window_bitwise_and_oracle(kind, F, k, d, max_m, W):
     """field-aware models in the dependency window (win_worker_ffm): parameters, linear weights, intercept, AdaGrad state
@@ -324,6 +325,8 @@ def _fmx_fit(kind, win, W, Xo, y, degree, fit_lower, k, P0, w0, b0, epochs, perm
     ("sgd", 4, "explicit", 4, 40, 64), ("adagrad", 4, "explicit", 4, 40, 64),    # three orders
     ("sgd", 3, "none", 5, 30, 32), ("adagrad", 5, "none", 3, 30, 8),             # one order of degree >= 3
     ("sgd", 2, "explicit", 16, 300, 64),                                         # (degree 2: the general worker, for reference)
+    ("sgd", 3, "explicit", 64, 30, 16), ("adagrad", 3, "none", 40, 30, 8),       # 64 factors per row
+    ("sgd", 6, "explicit", 2, 60, 32),                                           # the highest degree: five orders
 ])
 def test_higher_degree_window_bitwise_and_oracle(kind, degree, fit_lower, k, d, W):
     """several orders / degree >= 3 in the dependency window (win_worker_fmx): bit for bit the one-workgroup kernel's
@@ -351,3 +354,18 @@ def test_higher_degree_window_bitwise_and_oracle(kind, degree, fit_lower, k, d, 
     assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
     assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
     assert abs(win[2] - bf) < 1e-9
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad"])
+def test_higher_degree_window_long_rows(kind):
+    """rows of up to 150 entries (the entries beyond the first 64 take the counter path, the forwarding area holds fewer
+    hot entries than a row has), 20 features only: every sample waits"""
+    Xo = ragged_csr(300, 150, seed=8, max_m=150)
+    y = np.random.default_rng(8).standard_normal(Xo.n)
+    P0, w0, b0, _ = init_fm(150, 3, 8, "explicit", True, scale=0.05)
+    kw = dict(eta0=0.005) if kind == "sgd" else {}
+    ref = _fmx_fit(kind, 0, 16, Xo, y, 3, "explicit", 8, P0, w0, b0, 2, None, **kw)
+    win = _fmx_fit(kind, 2, 16, Xo, y, 3, "explicit", 8, P0, w0, b0, 2, None, **kw)
+    same_bits(win[0], ref[0], "P")
+    same_bits(win[1], ref[1], "w")
+    assert win[2] == ref[2]
