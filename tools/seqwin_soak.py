@@ -1,0 +1,45 @@
+"""Soak: the window kernel against the one-workgroup kernel, bit for bit, on the benchmark row shapes at a size where every
+hand-off path is taken thousands of times (near and far dependencies, forwarding, four-wavefront workers).
+usage: python tools/seqwin_soak.py [n] [cfg2,cfg4,cfg5,headline]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+import nimfm_amd as nf
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60_000
+names = sys.argv[2].split(",") if len(sys.argv) > 2 else ["cfg2", "cfg4", "cfg5"]
+dev = torch.device("cuda", 0)
+ctx = nf.default_context()
+bad = 0
+for name in names:
+    wl = dict(bench.WORKLOADS[name])
+    wl["d"] = max(2000, wl["d"] // 20)  # twenty times the benchmark's conflict rate
+    X, *_keep = bench.make_dataset(torch, nf, ctx, dev, wl, n, 0)
+    y = np.random.default_rng(0).standard_normal(n)
+    X.set_targets(y)
+    for solver in ("sgd", "adagrad"):
+        out = {}
+        for win in ("0", "2"):
+            os.environ["NFM_SEQ_WIN"] = win
+            if wl.get("fields"):
+                fm = nf.newFieldAwareFactorizationMachine("regression", nComponents=wl["k"], randomState=1, warmStart=True)
+            else:
+                fm = nf.newFactorizationMachine("regression", degree=wl["degree"], nComponents=wl["k"], randomState=1, warmStart=True)
+            fm.init(X)
+            mk = nf.newSGD if solver == "sgd" else nf.newAdaGrad
+            opt = mk(maxIter=1, verbose=0, tol=0, shuffle=False, mode="sequential", **({"eta0": 0.002} if solver == "sgd" else {}))
+            opt._handle(fm, ctx, "sequential")
+            t0 = time.perf_counter()
+            for _ in range(2):
+                opt._epoch(X, None, 0, n)
+                opt.it += n
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            opt._finalize_into(fm)
+            out[win] = (np.array(fm.P).copy(), np.array(fm.w).copy(), fm.intercept, dt)
+        a, b = out["0"], out["2"]
+        same = np.array_equal(a[0].view(np.uint64), b[0].view(np.uint64)) and np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64)) and a[2] == b[2]
+        finite = np.isfinite(b[0]).all()
+        bad += 0 if (same and finite) else 1
+        print("%-8s %-8s d=%d: %s (finite %s); one workgroup %.2f s, window %.2f s" % (name, solver, wl["d"], "bit-equal" if same else "DIFFERENT", finite, a[3], b[3]), flush=True)
+sys.exit(1 if bad else 0)
