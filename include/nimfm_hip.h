@@ -54,7 +54,11 @@ enum { NFM_LOSS_SQUARED = 0, NFM_LOSS_SQUARED_HINGE = 1, NFM_LOSS_LOGISTIC = 2, 
 enum { NFM_SCHED_CONSTANT = 0, NFM_SCHED_OPTIMAL = 1, NFM_SCHED_INVSCALING = 2, NFM_SCHED_PEGASOS = 3 }; /* optimizer/sgd.nim:7-11 */
 /* NFM_MODE_SEQUENTIAL: one sample at a time in the given order -- the
  *   reference's single-thread semantics (optimizer/sgd.nim:294-308,
- *   optimizer/adagrad.nim:164-184), the parity vehicle.
+ *   optimizer/adagrad.nim:164-184): results equal to the CPU path's.  Run as
+ *   a dependency window over the chip (0.8-1.3e6 samples/s; degree-2 FMs,
+ *   several orders / degree <= 6, field-aware models of up to 22 entries per
+ *   row; n_components <= 64; calls of >= 2048 samples), else one sample in
+ *   flight (fitLower = augment, longer field-aware rows, more factors).
  * NFM_MODE_MINIBATCH: this library's deterministic data-parallel rule
  *   (DESIGN.md section 4); replaces the reference's racy Hogwild drivers
  *   (optimizer/sgd_multi.nim:40-120, adagrad_multi.nim:39-115); equals the

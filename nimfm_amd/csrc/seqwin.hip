@@ -8,7 +8,7 @@
 // the rounding.  (a) ties t only to the EARLIER samples that share a feature with it -- at d = 1e6, 64 entries per row,
 // two samples do with probability 0.4 %.  So:
 //
-//   * W worker wavefronts (one workgroup = one wavefront = one CU each) take the samples round-robin: worker s owns
+//   * W workers (one workgroup = one CU each; one wavefront, four for field-aware models and degrees >= 3) take the samples round-robin: worker s owns
 //     positions s, s + W, s + 2W ...  A worker waits until every earlier sample that shares a feature with its sample has
 //     written its rows (a per-entry "previous position with this feature" table, built once per order by one sort, and a
 //     completion counter per worker), gathers the rows, forms everything of predictWithGrad (sgd.nim:191-202) that does
@@ -26,7 +26,13 @@
 //     sample after which a scale drops below 1e-9 (resetScaling, sgd.nim:116-131): the launch ends there, the dense
 //     rescale runs, the next launch continues.
 //
-// Same arithmetic, same order of every sum as k_sequential_pipe (seq.hip): parameters, linear weights, intercept and
+// Four workers: win_worker_k64 (degree 2, rows of 64 factors, up to 64 entries: the rows stay in registers), win_worker
+// (degree 2, any row shape: rows in LDS), win_worker_fmx (several orders / degree <= 6), win_worker_ffm (field-aware: one
+// chain term per pair of entries).  A dependency on a sample fewer than W positions back does not wait for that sample's
+// update: the writer posts a RECIPE (row as used + per-factor sums or derivative) before the conductor answers, the
+// successor forms the new row itself from it and the conductor's dL for the writer's sample.
+//
+// Same arithmetic, same order of every sum as the one-workgroup kernels (seq.hip): parameters, linear weights, intercept and
 // AdaGrad state come out BIT FOR BIT equal to the one-workgroup kernels (tests/test_gpu_seqwin.py); only the epoch's
 // loss / viol totals are associated differently (per worker, then in worker order).
 //
