@@ -6,6 +6,7 @@
 // preprocessing (one stable radix sort of (batch, feature) keys per plan, rocPRIM via hipCUB);
 // with shuffle off the plan is reused by every epoch.
 #include <hipcub/hipcub.hpp>
+#include <type_traits>
 
 #include <stdlib.h>
 
@@ -583,7 +584,12 @@ __global__ __launch_bounds__(kBlock) void k_csc_fill(CsrView X, const int64_t* _
 constexpr int kSegCap = 4096;          // touches per cell a workgroup holds (16 per thread)
 constexpr int kSegMaxBuckets = 4096;   // LDS histogram of the chunk kernels
 constexpr int kSegPosBits = 26, kSegFlShift = 52;
-constexpr uint64_t kSegMask26 = (1ull << 26) - 1;
+// an item = feature's low bits << sh_fl | position in the batch << sh_pos | entry of the row; 32 bits when the three fit
+// (headline: 11 + 13 + 6), else 64 (26 bits each for position and entry)
+struct SegFmt {
+  int sh_pos, sh_fl;
+  uint64_t qmask, pmask;
+};
 
 struct SegGeo {
   const int64_t* bat_pos;   // device, n_batches + 1 (relative to begin)
@@ -592,6 +598,7 @@ struct SegGeo {
   int cpb, S, fl, nbk;      // chunks per batch, samples per chunk, features per bucket = 2^fl, buckets
   int64_t n_batches;
   int xcd;                  // seg_map
+  SegFmt fmt;
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin by their index.  All workgroups of ONE batch are put on ONE XCD: what they
@@ -651,9 +658,9 @@ __device__ __forceinline__ void seg_walk_rows(const CsrView& X, const SegGeo& g,
   }
 }
 
-template <bool SCATTER>
+template <bool SCATTER, class IT>
 __global__ __launch_bounds__(kBlock) void k_seg_chunks(CsrView X, SegGeo g, uint32_t* __restrict__ cellcnt,
-                                                       const uint32_t* __restrict__ cellptr, uint64_t* __restrict__ items) {
+                                                       const uint32_t* __restrict__ cellptr, IT* __restrict__ items) {
   extern __shared__ uint32_t seg_lds[];
   uint32_t* lh = seg_lds;          // [nbk] touches of this chunk per bucket, then the running rank
   uint32_t* lb = seg_lds + g.nbk;  // [nbk] (SCATTER) where the chunk's touches of a bucket start
@@ -686,7 +693,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_chunks(CsrView X, SegGeo g, uint
   seg_walk_rows(X, g, p0, p1, [&](uint32_t j, int q, int64_t p) {
     const uint32_t bk = j >> fl;
     const uint32_t slot = lb[bk] + atomicAdd(&lh[bk], 1u);
-    items[slot] = ((uint64_t)(j & lowmask) << kSegFlShift) | ((uint64_t)(p - bp) << kSegPosBits) | (uint64_t)q;
+    items[slot] = (IT)(((uint64_t)(j & lowmask) << g.fmt.sh_fl) | ((uint64_t)(p - bp) << g.fmt.sh_pos) | (uint64_t)q);
   });
 }
 
@@ -751,9 +758,9 @@ __device__ __forceinline__ void seg_block_scan_n(uint64_t (&v)[NW], uint64_t (*s
 }
 
 // one workgroup per cell: flags of the single-touch features (thr = 2), the cell's column-phase features and touches
-template <int IPT>  // items per thread: the workgroup holds up to kBlock * IPT touches of its cell
-__global__ __launch_bounds__(kBlock) void k_seg_classify(int nbk, int fl, int thr, const uint32_t* __restrict__ cellptr,
-                                                          const uint64_t* __restrict__ items, const int64_t* __restrict__ bat_pos,
+template <int IPT, class IT>  // items per thread: the workgroup holds up to kBlock * IPT touches of its cell
+__global__ __launch_bounds__(kBlock) void k_seg_classify(SegFmt fmt, int nbk, int fl, int thr, const uint32_t* __restrict__ cellptr,
+                                                          const IT* __restrict__ items, const int64_t* __restrict__ bat_pos,
                                                           const int64_t* __restrict__ toff, uint8_t* __restrict__ single,
                                                           uint64_t* __restrict__ cellUT, int by_count, uint16_t* __restrict__ cls,
                                                           unsigned long long* __restrict__ n_heavy, int64_t n_batches, int xcd) {
@@ -781,7 +788,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_classify(int nbk, int fl, int th
     const int idx = threadIdx.x + e * kBlock;
     if (idx < n) {
       it[e] = items[i0 + idx];
-      atomicAdd(&seg_lds[it[e] >> kSegFlShift], 1u);
+      atomicAdd(&seg_lds[it[e] >> fmt.sh_fl], 1u);
     }
   }
   __syncthreads();
@@ -790,8 +797,8 @@ __global__ __launch_bounds__(kBlock) void k_seg_classify(int nbk, int fl, int th
 #pragma unroll
     for (int e = 0; e < IPT; ++e) {
       const int idx = threadIdx.x + e * kBlock;
-      if (idx < n && seg_lds[it[e] >> kSegFlShift] == 1u)
-        single[toff[bp + (int64_t)((it[e] >> kSegPosBits) & kSegMask26)] + (int64_t)(it[e] & kSegMask26)] = 1;
+      if (idx < n && seg_lds[it[e] >> fmt.sh_fl] == 1u)
+        single[toff[bp + (int64_t)((it[e] >> fmt.sh_pos) & fmt.pmask)] + (int64_t)(it[e] & fmt.qmask)] = 1;
     }
   }
   uint64_t ut = 0;
@@ -845,9 +852,9 @@ struct SegOut {
 };
 
 // one workgroup per cell: every column-phase touch to its place in (feature, position) order
-template <int IPT>
-__global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl, int thr, const uint32_t* __restrict__ cellptr,
-                                                      const uint64_t* __restrict__ items, const int64_t* __restrict__ bat_pos,
+template <int IPT, class IT>
+__global__ __launch_bounds__(kBlock) void k_seg_fill(SegFmt fmt, CsrView X, int nbk, int fl, int thr, const uint32_t* __restrict__ cellptr,
+                                                      const IT* __restrict__ items, const int64_t* __restrict__ bat_pos,
                                                       const int64_t* __restrict__ rowstart, const int64_t* __restrict__ toff,
                                                       const uint64_t* __restrict__ cellOff, int by_count,
                                                       const uint32_t* __restrict__ uoffc, SegOut o, int64_t n_batches, int xcd) {
@@ -877,7 +884,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl,
     const int idx = threadIdx.x + e * kBlock;
     if (idx < n) {
       it[e] = items[i0 + idx];
-      rk[e] = atomicAdd(&A[it[e] >> kSegFlShift], 1u);
+      rk[e] = atomicAdd(&A[it[e] >> fmt.sh_fl], 1u);
     }
   }
   __syncthreads();
@@ -924,7 +931,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl,
 #pragma unroll
   for (int e = 0; e < IPT; ++e) {
     const int idx = threadIdx.x + e * kBlock;
-    if (idx < n) ps[(A[it[e] >> kSegFlShift] >> 16) + rk[e]] = (uint32_t)((it[e] >> kSegPosBits) & kSegMask26);
+    if (idx < n) ps[(A[it[e] >> fmt.sh_fl] >> 16) + rk[e]] = (uint32_t)((it[e] >> fmt.sh_pos) & fmt.pmask);
   }
   __syncthreads();
   const int64_t b = cell / nbk;
@@ -937,18 +944,18 @@ __global__ __launch_bounds__(kBlock) void k_seg_fill(CsrView X, int nbk, int fl,
   for (int e = 0; e < IPT; ++e) {
     const int idx = threadIdx.x + e * kBlock;
     if (idx >= n) continue;
-    const uint32_t bin = (uint32_t)(it[e] >> kSegFlShift);
+    const uint32_t bin = (uint32_t)(it[e] >> fmt.sh_fl);
     const uint32_t a = A[bin];
     const uint32_t c = a & 0xFFFF;
     if (c < (uint32_t)thr) continue;
-    const uint32_t pos = (uint32_t)((it[e] >> kSegPosBits) & kSegMask26);
+    const uint32_t pos = (uint32_t)((it[e] >> fmt.sh_pos) & fmt.pmask);
     const uint32_t sb = a >> 16;
     int rank = 0;
     for (uint32_t i = 0; i < c; ++i) rank += ps[sb + i] < pos ? 1 : 0;
     const uint32_t bv = Bv[bin];
     const int64_t tb = t0 + (bv & 0xFFFF);
     const int64_t ts = tb + rank;
-    const int64_t q = (int64_t)(it[e] & kSegMask26);
+    const int64_t q = (int64_t)(it[e] & fmt.qmask);
     o.tpos[ts] = (int32_t)pos;
     o.tx[ts] = X.data[rowstart[bp + pos] + q];
     if (o.tq) o.tq[ts] = toff[bp + pos] + q;
@@ -1147,11 +1154,17 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
         g.fl = fl;
         g.nbk = (int)nbk;
         g.n_batches = P.n_batches;
+        int pbits = 1, qbits = 1;
+        while (((int64_t)1 << pbits) < P.max_batch) ++pbits;
+        while ((1 << qbits) < X.max_row) ++qbits;
+        const bool narrow = fl + pbits + qbits <= 32;
+        g.fmt = narrow ? SegFmt{qbits, qbits + pbits, ((uint64_t)1 << qbits) - 1, ((uint64_t)1 << pbits) - 1}
+                       : SegFmt{kSegPosBits, kSegFlShift, ((uint64_t)1 << kSegPosBits) - 1, ((uint64_t)1 << kSegPosBits) - 1};
         static const int xcd = !(getenv("NFM_SEG_XCD") && atoi(getenv("NFM_SEG_XCD")) == 0) ? 1 : 0;
         g.xcd = xcd;
         const int64_t chunk_blocks = P.n_batches * g.cpb;
         NFM_CHECK(chunk_blocks < ((int64_t)1 << 31), NFM_ERR_UNSUPPORTED, "too many sample chunks");
-        hipLaunchKernelGGL((k_seg_chunks<false>), dim3((unsigned)chunk_blocks), dim3(kBlock), sizeof(uint32_t) * 2 * nbk, st, X, g,
+        hipLaunchKernelGGL((k_seg_chunks<false, uint64_t>), dim3((unsigned)chunk_blocks), dim3(kBlock), sizeof(uint32_t) * 2 * nbk, st, X, g,
                            cellcnt.as<uint32_t>(), (const uint32_t*)nullptr, (uint64_t*)nullptr);
         hipLaunchKernelGGL(k_seg_maxcell, dim3(grid1d(cells)), dim3(kBlock), 0, st, cells, cellcnt.as<uint32_t>(), mx.as<unsigned int>());
         tmp_bytes = 0;
@@ -1167,7 +1180,7 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
           use_seg = true;
           TimedLaunch tl(ctx, "plan_seg");  // (the tests count these to know which path built the plan)
           const int thr = use_singles ? 2 : 1;
-          NFM_TRY(items.alloc(sizeof(uint64_t) * T));
+          NFM_TRY(items.alloc((narrow ? sizeof(uint32_t) : sizeof(uint64_t)) * T));
           NFM_TRY(cellUT.alloc(sizeof(uint64_t) * (cells + 1)));
           NFM_TRY(cellOff.alloc(sizeof(uint64_t) * (cells + 1)));
           DevBuf cls, uoffc, nheavy, buoff;
@@ -1178,8 +1191,12 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
           NFM_HIP_CHECK(hipMemsetAsync(nheavy.p, 0, sizeof(unsigned long long), st));
           NFM_HIP_CHECK(hipMemsetAsync(cellcnt.p, 0, sizeof(uint32_t) * (cells + 1), st));
           NFM_HIP_CHECK(hipMemsetAsync(cellUT.as<uint64_t>() + cells, 0, sizeof(uint64_t), st));
-          hipLaunchKernelGGL((k_seg_chunks<true>), dim3((unsigned)seg_grid(P.n_batches, g.cpb, xcd)), dim3(kBlock), sizeof(uint32_t) * 2 * nbk, st, X, g,
-                             cellcnt.as<uint32_t>(), cellptr.as<uint32_t>(), items.as<uint64_t>());
+          if (narrow)
+            hipLaunchKernelGGL((k_seg_chunks<true, uint32_t>), dim3((unsigned)seg_grid(P.n_batches, g.cpb, xcd)), dim3(kBlock), sizeof(uint32_t) * 2 * nbk, st,
+                               X, g, cellcnt.as<uint32_t>(), cellptr.as<uint32_t>(), items.as<uint32_t>());
+          else
+            hipLaunchKernelGGL((k_seg_chunks<true, uint64_t>), dim3((unsigned)seg_grid(P.n_batches, g.cpb, xcd)), dim3(kBlock), sizeof(uint32_t) * 2 * nbk, st,
+                               X, g, cellcnt.as<uint32_t>(), cellptr.as<uint32_t>(), items.as<uint64_t>());
           if (use_singles) {
             NFM_TRY(P.single.alloc(sizeof(uint8_t) * T));
             NFM_HIP_CHECK(hipMemsetAsync(P.single.p, 0, sizeof(uint8_t) * T, st));
@@ -1187,10 +1204,15 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
           const size_t NB = (size_t)1 << fl;
           auto classify = [&](auto ipt) {
             constexpr int IPT = decltype(ipt)::value;
-            hipLaunchKernelGGL(k_seg_classify<IPT>, dim3((unsigned)seg_grid(P.n_batches, (int)nbk, xcd)), dim3(kBlock), sizeof(uint32_t) * NB, st, (int)nbk, fl, thr,
-                               cellptr.as<uint32_t>(), items.as<uint64_t>(), P.bat_pos_dev.as<int64_t>(), toff.as<int64_t>(),
-                               use_singles ? P.single.as<uint8_t>() : nullptr, cellUT.as<uint64_t>(), sort_by_count ? 1 : 0,
-                               cls.as<uint16_t>(), nheavy.as<unsigned long long>(), P.n_batches, xcd);
+            auto go = [&](auto* it_ptr) {
+              using IT = std::remove_pointer_t<decltype(it_ptr)>;
+              hipLaunchKernelGGL((k_seg_classify<IPT, IT>), dim3((unsigned)seg_grid(P.n_batches, (int)nbk, xcd)), dim3(kBlock), sizeof(uint32_t) * NB, st,
+                                 g.fmt, (int)nbk, fl, thr, cellptr.as<uint32_t>(), (const IT*)it_ptr, P.bat_pos_dev.as<int64_t>(), toff.as<int64_t>(),
+                                 use_singles ? P.single.as<uint8_t>() : nullptr, cellUT.as<uint64_t>(), sort_by_count ? 1 : 0,
+                                 cls.as<uint16_t>(), nheavy.as<unsigned long long>(), P.n_batches, xcd);
+            };
+            if (narrow) go(items.as<uint32_t>());
+            else go(items.as<uint64_t>());
           };
           if (h_mx <= 4 * kBlock) classify(std::integral_constant<int, 4>{});
           else if (h_mx <= 8 * kBlock) classify(std::integral_constant<int, 8>{});
@@ -1223,10 +1245,15 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
                     P.uptr.as<int64_t>(), P.ucol_s.as<int32_t>(), P.ubeg_s.as<int64_t>(), P.ucnt_s.as<int32_t>()};
           auto fill = [&](auto ipt) {
             constexpr int IPT = decltype(ipt)::value;
-            hipLaunchKernelGGL(k_seg_fill<IPT>, dim3((unsigned)seg_grid(P.n_batches, (int)nbk, xcd)), dim3(kBlock),
-                               sizeof(uint32_t) * (2 * NB + (size_t)kBlock * IPT) + sizeof(uint16_t) * NB, st, X, (int)nbk, fl, thr,
-                               cellptr.as<uint32_t>(), items.as<uint64_t>(), P.bat_pos_dev.as<int64_t>(), rowstart.as<int64_t>(),
-                               toff.as<int64_t>(), cellOff.as<uint64_t>(), sort_by_count ? 1 : 0, uoffc.as<uint32_t>(), so, P.n_batches, xcd);
+            auto go = [&](auto* it_ptr) {
+              using IT = std::remove_pointer_t<decltype(it_ptr)>;
+              hipLaunchKernelGGL((k_seg_fill<IPT, IT>), dim3((unsigned)seg_grid(P.n_batches, (int)nbk, xcd)), dim3(kBlock),
+                                 sizeof(uint32_t) * (2 * NB + (size_t)kBlock * IPT) + sizeof(uint16_t) * NB, st, g.fmt, X, (int)nbk, fl, thr,
+                                 cellptr.as<uint32_t>(), (const IT*)it_ptr, P.bat_pos_dev.as<int64_t>(), rowstart.as<int64_t>(),
+                                 toff.as<int64_t>(), cellOff.as<uint64_t>(), sort_by_count ? 1 : 0, uoffc.as<uint32_t>(), so, P.n_batches, xcd);
+            };
+            if (narrow) go(items.as<uint32_t>());
+            else go(items.as<uint64_t>());
           };
           if (TM > 0) {
             if (h_mx <= 4 * kBlock) fill(std::integral_constant<int, 4>{});
