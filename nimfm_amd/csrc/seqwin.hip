@@ -912,7 +912,17 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
         const double* pa_ = Pl + ((size_t)q1 * F + fl[q2]) * Kp;  // P[f2][j1]
         const double* pb_ = Pl + ((size_t)q2 * F + fl[q1]) * Kp;  // P[f1][j2]
         double tmp = 0.0;
-        for (int t = 0; t < k; ++t) tmp += (sP * pa_[t]) * (sP * pb_[t]);
+        for (int tb = 0; tb < k; tb += 8) {
+          double a_[8], b_[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int tt = tb + e < k ? tb + e : tb;
+            a_[e] = pa_[tt];
+            b_[e] = pb_[tt];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) tmp = tb + e < k ? tmp + (sP * a_[e]) * (sP * b_[e]) : tmp;
+        }
         term = tmp * vl[q1] * vl[q2];
       }
       pc[p] = term;
@@ -1370,12 +1380,26 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
         A[0] = 1.0;
 #pragma unroll
         for (int t = 1; t <= DG; ++t) A[t] = 0.0;
-        for (int q = 0; q < m; ++q) {
-          const double val = vl[q];
-          const double p = sP * Pl[((size_t)q * nb + o) * Kp + s];
+        for (int qb = 0; qb < m; qb += 8) {  // eight entries' values requested together (a dependent LDS read per entry otherwise)
+          double v_[8], p_[8];
 #pragma unroll
-          for (int t = DG; t >= 1; --t)
-            if (t <= deg) A[t] += A[t - 1] * p * val;
+          for (int e = 0; e < 8; ++e) {
+            const int qq = qb + e < m ? qb + e : qb;
+            v_[e] = vl[qq];
+            p_[e] = Pl[((size_t)qq * nb + o) * Kp + s];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const bool ok = qb + e < m;
+            const double val = v_[e];
+            const double p = sP * p_[e];
+#pragma unroll
+            for (int t = DG; t >= 1; --t)
+              if (t <= deg) {
+                const double nx = A[t] + A[t - 1] * p * val;
+                A[t] = ok ? nx : A[t];
+              }
+          }
         }
         kv = 0.0;
 #pragma unroll
@@ -1383,10 +1407,21 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
           if (t == deg) kv = A[t];
       } else {  // sgd.nim:160-170
         double a1 = 0.0, a2 = 0.0;
-        for (int q = 0; q < m; ++q) {
-          const double vp = vl[q] * (sP * Pl[((size_t)q * nb + o) * Kp + s]);
-          a1 += vp;
-          a2 += vp * vp;
+        for (int qb = 0; qb < m; qb += 8) {
+          double v_[8], p_[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int qq = qb + e < m ? qb + e : qb;
+            v_[e] = vl[qq];
+            p_[e] = Pl[((size_t)qq * nb + o) * Kp + s];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const bool ok = qb + e < m;
+            const double vp = v_[e] * (sP * p_[e]);
+            a1 = ok ? a1 + vp : a1;
+            a2 = ok ? a2 + vp * vp : a2;
+          }
         }
         A[0] = 1.0;
         A[1] = a1;
@@ -1730,6 +1765,8 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
       }
     }
     if (MC > CH) {  // rows longer than one chunk: sixteen terms at a time, as far as the sample's terms go
+                    // (requesting the next sixteen before the current ones are added measured SLOWER: 1.16 -> 1.40 us on
+                    // cfg4's rows -- the copies between the two sets cost more than the overlap gains)
       for (int qb = CH; qb < nt; qb += 16) {
         double2 t_[8];
 #pragma unroll
