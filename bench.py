@@ -4,10 +4,14 @@
 One "step" = one pass of the hot path (nfm_opt_epoch, mini-batch mode) over the rank's whole
 synthetic shard, inputs already resident in HBM.  N = 1 runs the north-star headline workload of
 BASELINE.json (synthetic CSR 1e7 x 1e6, 64 nnz/row, k = 64, SGD, Logistic loss, mini-batch 8192, 1 MI355X)
-and, as `extra.cfg2`, BASELINE.json configs[1] (1e6 x 1e5, 32 nnz/row, k = 16).
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank trains on its own
-shard of the same size (weak scaling) and the replicas are averaged with one all-reduce of P / w /
-intercept per step; there is no collective inside the epoch.  `--gpus N` without
+and, as `extra.cfg2` ... `extra.cfg5`, the other BASELINE.json configs on one GPU: configs[1] (1e6 x 1e5, 32 nnz/row,
+k = 16), [2] (the headline's data with AdaGrad, a 4e6-sample shard), [3] (field-aware, 16 fields, k = 8), [4] (degree 3,
+k = 8) -- each with its own roofline, shuffled rate, exact-order rate (NFM_MODE_SEQUENTIAL), time_to_target and a bounded
+cpu_baseline; about two minutes in all.
+N > 1: one process per GPU (torch.distributed for the bootstrap and the clock; the exchange is the library's own RCCL
+communicator), every rank trains on its own shard of the same size (weak scaling), the replicas are reconciled every
+sync_period mini-batches on a second stream and exactly at the end of every epoch; the line then
+carries `extra.cfg3` (configs[2] as written: AdaGrad, data-parallel).  `--gpus N` without
 torchrun's environment starts the N ranks itself (a torch.distributed.run child; this parent process
 never touches a GPU).
 
@@ -53,6 +57,9 @@ WORKLOADS = {
     "cfg2z": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768, zipf=1.1),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+EXTRA_N = {"cfg3": 4_000_000}  # samples of the extra.cfg3 leg of the default run (the workload line says so)
 
 
 def algorithmic_bytes_per_sample(solver, m, k, n_orders=1, fields=0):
@@ -375,12 +382,14 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     from nimfm_amd import _capi as capi
 
     wl = dict(WORKLOADS[name])
+    if not primary and name in EXTRA_N:  # an extra leg of the default run: a bounded shard
+        wl["n"] = EXTRA_N[name]
     if args.n and primary:
         wl["n"] = args.n
     n, d, m, k = wl["n"], wl["d"], wl["m"], wl["k"]
     n_orders = wl["degree"] - 1  # fitLower=explicit (model/factorization_machine.nim:81-97)
     batch = args.batch if (args.batch and primary) else wl["batch"]
-    steps, warmup = (args.steps, args.warmup) if primary else (min(args.steps, 10), min(args.warmup, 3))
+    steps, warmup = (args.steps, args.warmup) if primary else (min(args.steps, 5 if name != "cfg2" else 10), min(args.warmup, 2))
     F = wl.get("fields", 0)
     X, indptr, indices, data, _keep_fields = make_dataset(torch, nf, ctx, dev, wl, n, rank)
     # labels from a planted FM (k, scale 0.1), like tests/utils.nim:29-47; classification -> sign
@@ -593,7 +602,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     c_bar = c_bar_of(lam, cap_eff)
     t2t = None
     t2t_window = k <= 64 and wl["degree"] <= 6 and (not F or m + m * (m - 1) // 2 <= 252)  # the exact order at speed (seqwin.hip)
-    if rank == 0 and world == 1 and t2t_window and (primary or name == "cfg2") and n >= 400_000:
+    if rank == 0 and world == 1 and t2t_window and n >= 400_000:
         n_t, n_h = min(1_000_000 if not F and wl["degree"] == 2 else 400_000, n - 200_000), 200_000
         ip_t = torch.arange(n_t + 1, device=dev, dtype=torch.int64) * m
         ip_h = torch.arange(n_h + 1, device=dev, dtype=torch.int64) * m
@@ -771,7 +780,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="mini-batch size (default: per workload)")
     ap.add_argument("--n", "--samples", dest="n", type=int, default=0, help="override samples per GPU (--samples under torchrun, whose parser claims --n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra.cfg2 leg of the default (headline) run")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra.cfg2 ... extra.cfg5 legs of the default (headline) run")
     ap.add_argument("--no-viol", action="store_true",
                     help="AdaGrad without the reference's viol = sum|P_old - P_new| (no stored copy of P is read or "
                          "written; the stopping criterion is then unavailable) -- an information run, not the metric")
@@ -847,12 +856,18 @@ def main():
     extra = None
     forced_dp = os.environ.get("NIMFM_BENCH_FORCE_DP") == "1"
     if args.workload == "headline" and world == 1 and not forced_dp and not args.no_extra and not args.n:
+        # the other BASELINE.json configs on the same line: configs[1] (cfg2), [2] on one GPU (cfg3, a 4e6-sample shard),
+        # [3] (cfg4, field-aware) and [4] (cfg5, degree 3) -- each with its own roofline, shuffled rate, exact-order rate,
+        # time_to_target and a bounded cpu_baseline
         import gc
 
-        gc.collect()
-        torch.cuda.empty_cache()
-        c2 = run_training(args, "cfg2", torch, nf, dist, rank, world, dev, ctx, primary=False)
-        extra = {"cfg2": {"metric": "SGD training samples/sec/epoch", "unit": "samples/s", **c2}}
+        extra = {}
+        for ename in ("cfg2", "cfg3", "cfg4", "cfg5"):
+            gc.collect()
+            torch.cuda.empty_cache()
+            ce = run_training(args, ename, torch, nf, dist, rank, world, dev, ctx, primary=False)
+            extra[ename] = {"metric": "%s training samples/sec/epoch" % ("SGD" if WORKLOADS[ename]["solver"] == "sgd" else "AdaGrad"),
+                            "unit": "samples/s", **ce}
     if args.workload == "headline" and (world > 1 or forced_dp) and not args.no_extra:
         # BASELINE.json configs[2] as written: AdaGrad, mini-batch 8192, data-parallel -- the replicas' state increments summed
         import gc
