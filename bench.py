@@ -602,7 +602,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     c_bar = c_bar_of(lam, cap_eff)
     t2t = None
     t2t_window = k <= 64 and wl["degree"] <= 6 and (not F or m + m * (m - 1) // 2 <= 252)  # the exact order at speed (seqwin.hip)
-    if rank == 0 and world == 1 and t2t_window and n >= 400_000:
+    if rank == 0 and world == 1 and t2t_window and n >= 400_000 and not args.no_t2t:
         n_t, n_h = min(1_000_000 if not F and wl["degree"] == 2 else 400_000, n - 200_000), 200_000
         ip_t = torch.arange(n_t + 1, device=dev, dtype=torch.int64) * m
         ip_h = torch.arange(n_h + 1, device=dev, dtype=torch.int64) * m
@@ -781,6 +781,7 @@ def main():
     ap.add_argument("--n", "--samples", dest="n", type=int, default=0, help="override samples per GPU (--samples under torchrun, whose parser claims --n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra.cfg2 ... extra.cfg5 legs of the default (headline) run")
+    ap.add_argument("--no-t2t", action="store_true", help="skip the time_to_target leg (profiling runs: its other batch sizes would mix into the per-kernel averages)")
     ap.add_argument("--no-viol", action="store_true",
                     help="AdaGrad without the reference's viol = sum|P_old - P_new| (no stored copy of P is read or "
                          "written; the stopping criterion is then unavailable) -- an information run, not the metric")
