@@ -355,8 +355,10 @@ int32_t nfm_opt_set_dp(nfm_opt* o, nfm_dp* dp, int64_t sync_period, int32_t over
  * data-parallel AdaGrad -- the state ONE process would hold).  With long periods every rank fits its own shard between
  * exchanges and the summed state over-shoots by up to the number of ranks (measured: 4 ranks x 16 mini-batches between
  * exchanges left the held-out RMSE at 2.9 where one rank reaches 1.04, tools/dp_convergence.py); NFM_DP_STATE_MEAN averages
- * the ranks' state increments instead -- the replicas' mean, as stable as one rank at any period. */
-enum { NFM_DP_MEAN = 0, NFM_DP_SUM = 1, NFM_DP_STATE_MEAN = 2 };
+ * the ranks' state increments instead -- the replicas' mean, as stable as one rank at any period.
+ * NFM_DP_AUTO (the default of every optimizer, so a host that only calls nfm_opt_set_dp gets it): SGD -- the mean;
+ * AdaGrad -- the sum when sync_period == 1, the averaged state increments otherwise (sync_period 0 included). */
+enum { NFM_DP_AUTO = -1, NFM_DP_MEAN = 0, NFM_DP_SUM = 1, NFM_DP_STATE_MEAN = 2 };
 int32_t nfm_opt_set_dp_combine(nfm_opt* o, int32_t combine);
 
 /* SGD, NFM_MODE_MINIBATCH: how a mini-batch combines the per-sample steps (optimizer/sgd.nim:205-243) of the `c` samples

@@ -111,7 +111,7 @@ struct nfm_opt {
   uint64_t dp_uid = 0;  // the group is checked against the live groups before every use (it may have been destroyed)
   int64_t dp_sync_period = 0;
   bool dp_overlap = true;
-  int dp_combine = 0;  // NFM_DP_MEAN / NFM_DP_SUM (SGD)
+  int dp_combine = NFM_DP_AUTO;  // NFM_DP_AUTO: SGD the mean; AdaGrad summed at sync_period 1, its state increments averaged otherwise
   DevBuf dp_sums;
 };
 
@@ -983,7 +983,10 @@ static int dp_epoch_setup(nfm_opt* o, nfm_model* m, const ModelView& M, DpEpoch*
   de.sync_period = o->dp_sync_period;
   de.overlap = o->dp_overlap;
   // SGD: the ranks' increments averaged unless NFM_DP_SUM; AdaGrad: its state increments summed unless NFM_DP_STATE_MEAN
-  const bool averaged = o->kind == OPT_SGD ? o->dp_combine != NFM_DP_SUM : o->dp_combine == NFM_DP_STATE_MEAN;
+  // (NFM_DP_AUTO, the default no host has to know about: what DESIGN.md section 6 measured as stable at every period --
+  // AdaGrad's SUMMED state over-shoots as soon as the ranks run more than one mini-batch between exchanges)
+  const bool averaged = o->kind == OPT_SGD ? o->dp_combine != NFM_DP_SUM
+                                           : (o->dp_combine == NFM_DP_STATE_MEAN || (o->dp_combine == NFM_DP_AUTO && o->dp_sync_period != 1));
   de.combine_w = averaged ? 1.0 / (double)o->dp->t->world : 1.0;
   if (o->kind == OPT_SGD) {
     de.arena = m->arena.as<double>();
@@ -1039,13 +1042,35 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         NFM_HIP_CHECK(hipMemcpyAsync(o->perm_dev.p, perm + begin, sizeof(int64_t) * ns, hipMemcpyHostToDevice, st));
         perm_dev = o->perm_dev.as<int64_t>() - begin;  // indexed by absolute position
       }
-      if (seq_window_supported(M, ds->max_row + m->n_aug, ns, ds->v.nnz, ctx->n_cu)) {
+      // The window kernel's workgroups wait for each other; should one of those waits time out (CUs held by another tenant)
+      // the call's samples are partly applied.  So the call starts from a snapshot of everything it may write -- the model's
+      // arena, AdaGrad's state arena: one device-to-device copy, 0.2 ms for the headline's 520 MB -- and an aborted call is
+      // put back and run by the one-workgroup kernel.  The window is used when the snapshot costs less than a quarter of it.
+      const size_t snap_bytes = m->arena.bytes + (o->kind == OPT_ADAGRAD ? o->state_arena.bytes : 0);
+      const char* win_env = getenv("NFM_SEQ_WIN");
+      const bool snap_pays = (win_env && atoi(win_env) == 2) || (double)ns * 0.8e-6 * 0.25 >= (double)snap_bytes / 2.0e12;
+      bool windowed = false;
+      if (snap_pays && seq_window_supported(M, ds->max_row + m->n_aug, ns, ds->v.nnz, ctx->n_cu)) {
         if (!o->seqwin) o->seqwin.reset(new SeqWin());
-        NFM_TRY(launch_sequential_window(ctx, o->kind, ds->v, M, o->o, perm_dev, begin, end, o->it, ds->max_row + m->n_aug,
-                                         o->out2.as<double>(), o->seqwin.get(), (ds->uid << 20) ^ ds->serial, perm != nullptr));
-      } else {
-        NFM_TRY(launch_sequential(ctx, o->kind, ds->v, M, o->o, perm_dev, begin, end, o->it, ds->max_row + m->n_aug, o->out2.as<double>()));
+        SeqWin* sw = o->seqwin.get();
+        NFM_TRY(sw->snap.ensure(snap_bytes));
+        NFM_HIP_CHECK(hipMemcpyAsync(sw->snap.p, m->arena.p, m->arena.bytes, hipMemcpyDeviceToDevice, st));
+        if (o->kind == OPT_ADAGRAD)
+          NFM_HIP_CHECK(hipMemcpyAsync(sw->snap.as<char>() + m->arena.bytes, o->state_arena.p, o->state_arena.bytes, hipMemcpyDeviceToDevice, st));
+        const int rc = launch_sequential_window(ctx, o->kind, ds->v, M, o->o, perm_dev, begin, end, o->it, ds->max_row + m->n_aug,
+                                                o->out2.as<double>(), sw, (ds->uid << 20) ^ ds->serial, perm != nullptr);
+        if (rc == NFM_WIN_FALLBACK) {
+          NFM_HIP_CHECK(hipMemcpyAsync(m->arena.p, sw->snap.p, m->arena.bytes, hipMemcpyDeviceToDevice, st));
+          if (o->kind == OPT_ADAGRAD)
+            NFM_HIP_CHECK(hipMemcpyAsync(o->state_arena.p, sw->snap.as<char>() + m->arena.bytes, o->state_arena.bytes, hipMemcpyDeviceToDevice, st));
+          ++sw->fallbacks;
+        } else {
+          NFM_TRY(rc);
+          windowed = true;
+        }
       }
+      if (!windowed)
+        NFM_TRY(launch_sequential(ctx, o->kind, ds->v, M, o->o, perm_dev, begin, end, o->it, ds->max_row + m->n_aug, o->out2.as<double>()));
       NFM_HIP_CHECK(hipMemcpyAsync(out2, o->out2.p, sizeof(out2), hipMemcpyDeviceToHost, st));
       NFM_HIP_CHECK(hipStreamSynchronize(st));
     } else {
@@ -1342,8 +1367,8 @@ int32_t nfm_opt_set_touch_cap(nfm_opt* o, double cap) {
 
 int32_t nfm_opt_set_dp_combine(nfm_opt* o, int32_t combine) {
   NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
-  NFM_CHECK(combine == NFM_DP_MEAN || combine == NFM_DP_SUM || combine == NFM_DP_STATE_MEAN, NFM_ERR_INVALID,
-            "combine must be NFM_DP_MEAN, NFM_DP_SUM or NFM_DP_STATE_MEAN");
+  NFM_CHECK(combine == NFM_DP_AUTO || combine == NFM_DP_MEAN || combine == NFM_DP_SUM || combine == NFM_DP_STATE_MEAN, NFM_ERR_INVALID,
+            "combine must be NFM_DP_AUTO, NFM_DP_MEAN, NFM_DP_SUM or NFM_DP_STATE_MEAN");
   o->dp_combine = combine;
   return NFM_OK;
 }

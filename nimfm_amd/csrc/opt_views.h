@@ -41,11 +41,17 @@ struct SeqWin {           // kept on the optimizer between calls
   DevBuf prev;            // [nnz] per stored entry: previous position of the call with the same feature
   DevBuf prevq, next;     // [nnz] that feature's entry index in the previous sample's row; next position with the feature
   DevBuf scales, mail, ctl, fw, trace;
+  DevBuf snap;            // the model's arena (+ AdaGrad: the state arena) as it was when the call began (abort: put back)
+  int64_t fallbacks = 0;  // calls that ended in the one-workgroup kernel after an abort
   bool valid = false, had_perm = false;
   uint64_t ds_uid = 0;
   int64_t begin = 0, end = 0, nnz = 0;
 };
 bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz, int n_cu);
+// launch_sequential_window's third outcome besides NFM_OK and an error: the window could not run to its end (the kernel does
+// not fit a CU, or a wait inside it timed out and the launch aborted).  Parameters and state of the call may be partly
+// updated: the caller puts its snapshot back and runs launch_sequential over the same range.
+constexpr int NFM_WIN_FALLBACK = 1;
 int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M, const OptView& O,
                              const int64_t* perm_dev, int64_t begin, int64_t end, int64_t it0, int m_cap,
                              double* out2_dev /*{loss_sum, viol_sum}*/, SeqWin* sw, uint64_t ds_uid, bool perm_is_callers);

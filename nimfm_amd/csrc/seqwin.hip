@@ -84,6 +84,8 @@ struct WinArgs {
   unsigned* ctrl;         // [0]: abort
   double* partial;        // [W + 1][2] {loss, viol} per worker, last: the conductor's
   int W, lgW, m_cap, FW, lgKp;  // FW = MC + kWinHdr words per mailbox, MC = m_cap rounded up to the chain's chunk
+  int dead_slot;          // test hook (NFM_SEQ_WIN_TEST_DEAD_SLOT): this worker leaves at once, as a workgroup that never became
+                          // resident would; -1 otherwise.  The others time out, the launch aborts, the host restores + falls back
 };
 
 __device__ __forceinline__ ull ld_u64(const ull* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -2282,6 +2284,7 @@ enum { WK_GENERAL = 0, WK_K64 = 1, WK_FFM = 2, WK_FMX = 3 };  // which worker
 template <int OPT, int CH, int WK>
 __global__ __launch_bounds__(WK >= WK_FFM ? kFfmWaves * kWave : 128) void k_seq_window(WinArgs a) {
   extern __shared__ double lds[];
+  if ((int)blockIdx.x - 1 == a.dead_slot) return;
   if (blockIdx.x == 0) {
     if (threadIdx.x < 2 * kWave) {
       win_conductor<OPT, CH>(a, lds);
@@ -2537,7 +2540,7 @@ bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz
     if (kWinHdr + (m_cap + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
   }
   if (nnz >= ((int64_t)1 << 32) || M.d >= ((int64_t)1 << 31) || ns >= ((int64_t)1 << 31)) return false;
-  if (n_cu < 10) return false;
+  if (n_cu < 17) return false;  // the smallest window: 16 workers + the conductor, one CU each (launch_sequential_window)
   return mode == 2 || ns >= 2048;
 }
 
@@ -2545,8 +2548,14 @@ template <int OPT, int CH, int WK>
 static int launch_window_t(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes) {
   auto kern = k_seq_window<OPT, CH, WK>;
   NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  // the W + 1 workgroups wait for each other: every one of them must be resident.  One workgroup per CU (the LDS request
+  // sees to that) and W + 1 <= CUs is the launcher's rule; here the kernel itself is asked whether a CU can hold it at all
+  constexpr int threads = WK >= WK_FFM ? kFfmWaves * kWave : 128;
+  int per_cu = 0;
+  NFM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds_bytes));
+  if (per_cu < 1) return NFM_WIN_FALLBACK;
   TimedLaunch tl(ctx, "sequential");
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.W + 1)), dim3(WK >= WK_FFM ? kFfmWaves * kWave : 128), lds_bytes, ctx->stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.W + 1)), dim3(threads), lds_bytes, ctx->stream, a);
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }
@@ -2572,7 +2581,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   while ((2 << lgW) <= W && lgW < 7) ++lgW;
   W = 1 << lgW;
   while (W + 1 > ctx->n_cu && lgW > 4) W = 1 << --lgW;
-  NFM_CHECK(W > kWinDepth && W + 1 <= ctx->n_cu, NFM_ERR_UNSUPPORTED, "the dependency window needs %d resident workgroups", W + 1);
+  if (!(W > kWinDepth && W + 1 <= ctx->n_cu)) return NFM_WIN_FALLBACK;  // (seq_window_supported keeps such devices out)
   int lgKp = 1;
   while ((1 << lgKp) < M.Kp) ++lgKp;
   const bool ffm = M.kind == NFM_KIND_FFM;
@@ -2625,6 +2634,8 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   int64_t* info = reinterpret_cast<int64_t*>(a.partial + 2 * (W + 1));
   a.W = W;
   a.lgW = lgW;
+  a.dead_slot = -1;
+  if (const char* env = getenv("NFM_SEQ_WIN_TEST_DEAD_SLOT")) a.dead_slot = atoi(env);  // test hook, see WinArgs
   a.m_cap = m_cap;
   a.FW = FW;
   a.lgKp = lgKp;
@@ -2673,7 +2684,13 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     unsigned aborted = 0;
     NFM_HIP_CHECK(hipMemcpyAsync(&aborted, a.ctrl, sizeof(aborted), hipMemcpyDeviceToHost, st));
     NFM_HIP_CHECK(hipStreamSynchronize(st));
-    NFM_CHECK(aborted == 0, NFM_ERR_HIP, "the dependency-window kernel gave up waiting (a workgroup was not resident or a hand-off was lost)");
+    if (aborted != 0) {
+      // a wait ran into its wall-clock limit (a workgroup was not resident -- other tenants on the CUs -- or a hand-off was
+      // lost): the samples of this call are partly applied.  The caller restores its snapshot and runs the one-workgroup kernel
+      fprintf(stderr, "[nimfm_hip] the dependency-window kernel gave up waiting at positions [%lld, %lld]; falling back to the one-workgroup kernel\n",
+              (long long)(begin + pos), (long long)(begin + last));
+      return NFM_WIN_FALLBACK;
+    }
     if (a.trace) {  // debugging: the stamps go to a file (100 MHz ticks: taken up, deps, posted, dL, written | fetched, chain, answered)
       std::vector<long long> h((size_t)8 * a.n_seg);
       NFM_HIP_CHECK(hipMemcpy(h.data(), a.trace, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));

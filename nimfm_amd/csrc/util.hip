@@ -65,7 +65,8 @@ int DevBuf::alloc(size_t nbytes) {
   (void)hipGetDevice(&dev);
   if (bp.enabled && dev >= 0 && dev < 16) {
     const std::thread::id me = std::this_thread::get_id();
-    bool foreign = false;
+    void* taken = nullptr;  // a block ANOTHER thread released: removed from its list under the lock, used after a device sync
+    size_t taken_cap = 0;
     {
       std::lock_guard<std::mutex> lk(bp.mu);
       auto mine = bp.free_blocks[dev].find(me);
@@ -81,29 +82,28 @@ int DevBuf::alloc(size_t nbytes) {
           return NFM_OK;
         }
       }
-      for (auto& kv : bp.free_blocks[dev])
-        if (kv.first != me) {
-          auto it = kv.second.lower_bound(want);
-          if (it != kv.second.end() && fits(it->first, want)) foreign = true;
-        }
-    }
-    if (foreign) {
-      // another thread's block: only once nothing on the device can still be using it
-      (void)hipDeviceSynchronize();
-      std::lock_guard<std::mutex> lk(bp.mu);
       for (auto& kv : bp.free_blocks[dev]) {
         if (kv.first == me) continue;
         auto it = kv.second.lower_bound(want);
         if (it != kv.second.end() && fits(it->first, want)) {
-          p = it->second;
-          cap = it->first;
-          bytes = nbytes;
-          device = dev;
+          taken = it->second;
+          taken_cap = it->first;
           bp.kept -= it->first;
           kv.second.erase(it);
-          return NFM_OK;
+          break;
         }
       }
+    }
+    if (taken) {
+      // The block left its owner's list while the lock was held, so whatever the owner had enqueued on it was enqueued
+      // BEFORE this point: the device-wide drain below covers it.  (Looking the lists over again AFTER the drain -- the
+      // earlier version -- could pick a block released in between, its kernels still in flight.)
+      (void)hipDeviceSynchronize();
+      p = taken;
+      cap = taken_cap;
+      bytes = nbytes;
+      device = dev;
+      return NFM_OK;
     }
   }
   hipError_t e = hipMalloc(&p, want);

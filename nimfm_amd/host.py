@@ -778,11 +778,10 @@ class _OptimizerBase:
         counter `it` then cover the samples of ALL ranks."""
         if combine not in ("auto", "mean", "sum", "state_mean"):
             raise ValueError("combine must be 'auto', 'mean', 'sum' or 'state_mean'")
-        if combine == "auto":
-            # what tools/dp_convergence.py measured (DESIGN.md section 6): SGD -- the mean at any period; AdaGrad -- the summed
-            # state is synchronous data-parallel AdaGrad when the ranks exchange after EVERY mini-batch and over-shoots
-            # with longer periods, where the averaged state stays as stable as one rank
-            combine = "mean" if not isinstance(self, AdaGrad) else ("sum" if int(syncPeriod) == 1 else "state_mean")
+        # "auto" is resolved IN THE LIBRARY (NFM_DP_AUTO, the default of every optimizer -- the Nim and C++ hosts only call
+        # nfm_opt_set_dp): what tools/dp_convergence.py measured (DESIGN.md section 6): SGD -- the mean at any period; AdaGrad
+        # -- the summed state is synchronous data-parallel AdaGrad when the ranks exchange after EVERY mini-batch and
+        # over-shoots with longer periods, where the averaged state stays as stable as one rank
         self._dp = None if group is None else (group, int(syncPeriod), bool(overlap), combine)
         if self._h is not None:
             self._attach_dp()
@@ -791,7 +790,7 @@ class _OptimizerBase:
         g = self._dp
         capi.check(capi.lib().nfm_opt_set_dp(self._h, None if g is None else g[0].h, 0 if g is None else g[1],
                                              1 if g is None or g[2] else 0))
-        capi.check(capi.lib().nfm_opt_set_dp_combine(self._h, 0 if g is None else {"mean": 0, "sum": 1, "state_mean": 2}[g[3]]))
+        capi.check(capi.lib().nfm_opt_set_dp_combine(self._h, -1 if g is None else {"auto": -1, "mean": 0, "sum": 1, "state_mean": 2}[g[3]]))
 
     def _sync_it(self):
         """with a group attached the library advances `it` by the samples of all ranks"""

@@ -1,0 +1,80 @@
+"""The ONE JSON line of bench.py's contract stays under 6 KB and is the LAST stdout line.  (Round 3's line had grown to
+24 KB; the driver keeps about 8 KB of stdout, so its record of that round started in the middle of `extra.cfg4` and
+could not be parsed.)  Canned input: the full result of a default run (profiles/r03z_default_bench.json, every prose
+field included) with the time_to_target / exact_order legs in their current shape."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def canned():
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03z_default_bench.json")))
+    t2t = {"train_samples": 1000000, "held_out_samples": 200000, "problem": "labels from a planted degree-2 FM " + "x" * 200,
+           "held_out_loss_at_start": 0.693169, "planted_model_held_out_loss": 0.403512, "targets_are": "y" * 300,
+           "sequential": [{"epochs": e, "seconds": 0.7747 * e, "held_out_loss": 0.69 - 0.01 * e, "gap_closed": 0.1234 * i}
+                          for i, e in enumerate((1, 3, 10), 1)],
+           "minibatch": [{"batch": b, "touch_cap": 16.0, "epochs_run": 40, "held_out_loss": 0.612345, "seconds_per_epoch": 0.01789,
+                          "targets": [{"seq_epochs": e, "target": 0.69 - 0.01 * e, "reached": b != 32768 or e < 10, "epochs": 3 * e,
+                                       "seconds": 0.0531 * e, "speedup": 43.64 if (b != 32768 or e < 10) else None} for e in (1, 3, 10)]}
+                         for b in (32768, 8192, 2048)],
+           "best_batch": 2048, "note": "z" * 200}
+    for leg in [full] + list(full["extra"].values()):
+        leg["time_to_target"] = t2t
+        leg["exact_order"]["bit_equal"] = True
+        leg["exact_order"]["bit_equal_sample"] = "w" * 120
+    return full
+
+
+def test_contract_line_is_short_and_complete():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    full = canned()
+    assert len(json.dumps(full)) > 20000  # the detail is as verbose as round 3's line was
+    line = bench.contract_line(full)
+    assert "\n" not in line and len(line) < 6000, len(line)
+    out = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["value"] == full["value"] and out["ms_per_step"] == full["ms_per_step"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(out["roofline"])
+    assert out["roofline"]["frac"] == full["roofline"]["frac"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(out["cpu_baseline"])
+    assert "workload" in out["config"] and "model" not in out["config"] and len(out["config"]["update_rule"]) <= 120
+    assert out["exact_order"]["bit_equal"] is True
+    assert [h["seq_epochs"] for h in out["time_to_target"]["targets"]] == [1, 3, 10]
+    assert out["time_to_target"]["batch"] == 2048
+    assert sorted(out["extra"]) == ["cfg2", "cfg3", "cfg4", "cfg5"]
+    for e in out["extra"].values():
+        assert e["frac"] is not None and e["value"] > 0 and e["reached"] is True and len(e["t2t_speedup"]) == 3
+
+
+def test_contract_line_sheds_optional_parts_rather_than_overflow():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    full = canned()
+    full["extra"] = {("cfg%d" % i): v for i in range(40) for v in [full["extra"]["cfg2"]]}  # an absurd number of legs
+    line = bench.contract_line(full)
+    assert len(line) < 6000
+    out = json.loads(line)
+    assert out["roofline"]["frac"] == full["roofline"]["frac"] and out["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+
+
+def test_last_8000_bytes_of_stdout_parse(tmp_path):
+    """what the driver does: keep the tail of stdout, parse its last line"""
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r); import bench, test_bench_line as t; "
+            "print('RCCL version : banner on stdout'); bench.ROOT = %r; bench.emit(t.canned())" % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    tail = r.stdout[-8000:].decode()
+    last = tail.strip().splitlines()[-1]
+    out = json.loads(last)
+    assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
+    detail = json.load(open(os.path.join(str(tmp_path), "gpurun_out", "bench_detail.json")))
+    assert detail["extra"]["cfg4"]["time_to_target"]["best_batch"] == 2048  # nothing is lost: the detail keeps everything
+    assert len(r.stderr) > 20000

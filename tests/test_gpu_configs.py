@@ -22,7 +22,9 @@ from test_gpu_fullsize import big_csr
 pytestmark = pytest.mark.gpu
 
 
-def test_cfg5_shape_degree3_sgd_vs_mb_oracle():
+@pytest.mark.parametrize("cap", [1.0, 16.0])
+def test_cfg5_shape_degree3_sgd_vs_mb_oracle(cap):
+    """(cap = 16: the touch cap bench.py trains this config with, nfm_opt_set_touch_cap)"""
     n, d, m, k, B = 131_072 + 500, 100_000, 32, 8, 32768  # four full batches and a ragged tail
     Xo = big_csr(n, d, m, 45)
     rng = np.random.default_rng(6)
@@ -32,11 +34,11 @@ def test_cfg5_shape_degree3_sgd_vs_mb_oracle():
     P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
     hist = []
     for _ in range(2):
-        b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 3, P, w, b, cfg, B, it=it)
+        b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 3, P, w, b, cfg, B, it=it, touch_cap=cap)
         hist.append((vs, ls / n))
     X = to_gpu(Xo)
     fm = gpu_fm("regression", 3, k, "explicit", True, True, P0, w0, 0.0)
-    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False, loss="squared", mode="minibatch", batch=B)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False, loss="squared", mode="minibatch", batch=B, touchCap=cap)
     sgd.fit(X, y, fm)
     assert sgd.it == it == 2 * n + 1
     assert abs(fm.intercept - b) < 1e-11
@@ -48,9 +50,9 @@ def test_cfg5_shape_degree3_sgd_vs_mb_oracle():
     # a fresh permutation (the reference's default shuffle = true): the plan is rebuilt for it
     perm = np.random.default_rng(3).permutation(n).astype(np.int64)
     P, w = P0.copy(), w0.copy()
-    b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 3, P, w, 0.0, cfg, B, perm=perm, it=1)
+    b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 3, P, w, 0.0, cfg, B, perm=perm, it=1, touch_cap=cap)
     fm = gpu_fm("regression", 3, k, "explicit", True, True, P0, w0, 0.0)
-    sgd = nf.newSGD(maxIter=1, verbose=0, tol=0, loss="squared", mode="minibatch", batch=B)
+    sgd = nf.newSGD(maxIter=1, verbose=0, tol=0, loss="squared", mode="minibatch", batch=B, touchCap=cap)
     sgd.fit(X, y, fm, perms=perm[None, :])
     assert_close(fm.P, P, 1e-9, 1e-13, "P, permuted")
     assert_close(sgd.history[0][0], vs, 1e-9, 0, "viol, permuted")

@@ -70,10 +70,12 @@ def test_local_group_sgd_and_adagrad_vs_rule(world, S, overlap, combine):
 
 
 @pytest.mark.parametrize("world,S,combine", [(4, 4, "mean"), (8, 2, "mean"), (8, 0, "mean"), (4, 0, "mean"), (4, 3, "state_mean"),
-                                              (8, 0, "state_mean")])
+                                              (8, 0, "state_mean"), (4, 3, "auto"), (4, 0, "auto"), (2, 1, "auto")])
 def test_local_group_many_ranks_vs_rule(world, S, combine):
     """4 and 8 ranks (tools/dp_convergence.py runs these group sizes), several mid-epoch exchanges per rank; state_mean:
-    AdaGrad's state increments averaged instead of summed (NFM_DP_STATE_MEAN; for SGD it is the mean)"""
+    AdaGrad's state increments averaged instead of summed (NFM_DP_STATE_MEAN; for SGD it is the mean); auto: NFM_DP_AUTO,
+    resolved inside the library -- what an optimizer does when its host only ever calls nfm_opt_set_dp (the Nim shim's
+    attach(), nimfm.hpp): SGD the mean, AdaGrad summed at sync_period 1 and averaged otherwise"""
     _vs_rule(4003, 300, world, S, True, combine)
 
 
@@ -85,6 +87,9 @@ def test_local_group_sparse_regime_vs_rule(world, S):
 
 
 def _vs_rule(N, D, world, S, overlap, combine):
+    lib_combine = combine
+    if combine == "auto":  # the rule the library is expected to pick by itself
+        combine = "state_mean" if S != 1 else "sum"
     full = random_csr(N, D, M, seed=21)
     rng = np.random.default_rng(5)
     y = rng.standard_normal(N)
@@ -104,7 +109,7 @@ def _vs_rule(N, D, world, S, overlap, combine):
                     def ep(P_, w_, b_, lo, hi, it_):
                         b2, _, ls, vs = O.fm_sgd_epoch_mb(shard, ys, 2, P_, w_, b_, cfg, B, begin=lo, end=hi, it=it_)
                         return b2, ls, vs
-                    P, w, b, ls, vs, it = yield from R.rank_sgd(ep, P, w, b, cfg, shard.n, B, S, it, overlap, world, combine)
+                    P, w, b, ls, vs, it = yield from R.rank_sgd(ep, P, w, b, cfg, shard.n, B, S, it, overlap, world, "mean" if lib_combine == "auto" else combine)
                     hist.append((vs, ls / N))
                 return P, w, b, hist, it
 
@@ -143,8 +148,21 @@ def _vs_rule(N, D, world, S, overlap, combine):
                 opt = nf.newSGD(maxIter=epochs, eta0=0.05, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B)
             else:
                 opt = nf.newAdaGrad(maxIter=epochs, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B)
-            opt.setDataParallel(group, S, overlap, combine)
-            opt.fit(X, ys, fm)
+            if lib_combine == "auto":  # only nfm_opt_set_dp, as the Nim / C++ hosts do: the library's default must be the rule
+                opt.batch = B
+                X.set_targets(ys)
+                opt._handle(fm, ctx, "minibatch")
+                from nimfm_amd import _capi as capi
+                capi.check(capi.lib().nfm_opt_set_dp(opt._h, group.h, S, 1 if overlap else 0))
+                for _ in range(epochs):
+                    ls, vs = opt._epoch(X, None, 0, shard.n)
+                    opt._sync_it()
+                    opt.history.append((vs, ls / N))
+                opt._finalize_into(fm)
+                capi.check(capi.lib().nfm_opt_set_dp(opt._h, None, 0, 0))
+            else:
+                opt.setDataParallel(group, S, overlap, combine)
+                opt.fit(X, ys, fm)
             return fm.P.copy(), fm.w.copy(), fm.intercept, list(opt.history), opt.it
 
         got, info = _run_ranks(world, make_rank)

@@ -39,15 +39,19 @@ def problem():
     return Xo, to_gpu(Xo), y, P0, w0
 
 
-def test_cfg2_fullsize_vs_mb_oracle(problem):
+@pytest.mark.parametrize("cap", [1.0, 16.0])
+def test_cfg2_fullsize_vs_mb_oracle(problem, cap):
+    """cap = 16 is the rule bench.py trains cfg2 / the headline / cfg5 with (nfm_opt_set_touch_cap: up to 16 of a batch's
+    steps on a coordinate summed, as that many Hogwild threads of optimizer/sgd_multi.nim:83-101 would; every feature is
+    touched ~10 times per batch here); cap = 1 the library's default (the per-coordinate mean)"""
     Xo, X, y, P0, w0 = problem
     P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
     hist = []
     for _ in range(2):
-        b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, b, O.sgd_cfg(loss="logistic"), B, it=it)
+        b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, b, O.sgd_cfg(loss="logistic"), B, it=it, touch_cap=cap)
         hist.append((vs, ls / N))
     fm = gpu_fm("classification", 2, K, "explicit", True, True, P0, w0, 0.0)
-    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False, loss="logistic", mode="minibatch", batch=B)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False, loss="logistic", mode="minibatch", batch=B, touchCap=cap)
     sgd.fit(X, y, fm)
     assert sgd.it == it == 2 * N + 1
     assert abs(fm.intercept - b) < 1e-11
@@ -152,14 +156,16 @@ def headline_problem():
     return Xo, to_gpu(Xo), y, P0, w0
 
 
-def test_headline_shape_sgd_vs_mb_oracle(headline_problem):
+@pytest.mark.parametrize("cap", [1.0, 16.0])
+def test_headline_shape_sgd_vs_mb_oracle(headline_problem, cap):
+    """(cap = 16: bench.py's rule for this shape; about 40 % of a batch's touches share their feature with another)"""
     Xo, X, y, P0, w0 = headline_problem
     P, w = P0.copy(), w0.copy()
-    b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, 0.0, O.sgd_cfg(loss="logistic"), HB, it=1)
+    b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, 0.0, O.sgd_cfg(loss="logistic"), HB, it=1, touch_cap=cap)
     runs = []
     for _ in range(2):
         fm = gpu_fm("classification", 2, HK, "explicit", True, True, P0, w0, 0.0)
-        sgd = nf.newSGD(maxIter=1, verbose=0, tol=0, shuffle=False, loss="logistic", mode="minibatch", batch=HB)
+        sgd = nf.newSGD(maxIter=1, verbose=0, tol=0, shuffle=False, loss="logistic", mode="minibatch", batch=HB, touchCap=cap)
         sgd.fit(X, y, fm)
         runs.append((fm.P.copy(), fm.w.copy(), fm.intercept, sgd.history[0]))
     Pg, wg, bg, h = runs[0]

@@ -369,3 +369,116 @@ def test_higher_degree_window_long_rows(kind):
     same_bits(win[0], ref[0], "P")
     same_bits(win[1], ref[1], "w")
     assert win[2] == ref[2]
+
+
+def _distinct_rows(n, d, m, seed):
+    """n rows of exactly m distinct sorted features, uniform over d (rows with a repeat are re-drawn)"""
+    rng = np.random.default_rng(seed)
+    idx = np.sort(rng.integers(0, d, size=(n, m)), axis=1)
+    while True:
+        bad = np.nonzero((idx[:, 1:] == idx[:, :-1]).any(axis=1))[0]
+        if len(bad) == 0:
+            break
+        idx[bad] = np.sort(rng.integers(0, d, size=(len(bad), m)), axis=1)
+    return O.Dataset(np.arange(n + 1, dtype=np.int64) * m, idx.ravel().astype(np.int64), rng.uniform(-1, 1, n * m), n, d)
+
+
+def _fit_checked(kind, win, Xo, y, task, k, P0, w0, b0, epochs, perms, **kw):
+    """like fit(), and asserts WHICH kernel ran (the window builds a dependency table, the one-workgroup kernel does not)"""
+    ctx = nf.default_context()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    try:
+        out = fit(kind, win, 64, Xo, y, task, k, P0, w0, b0, epochs, perms, **kw)
+        windowed = ctx.timing_get("seq_window_deps")[0] > 0
+    finally:
+        ctx.timing_enable(False)
+    assert windowed == (int(win) != 0), "the %s kernel ran" % ("one-workgroup" if int(win) else "window")
+    return out
+
+
+@pytest.mark.parametrize("kind,d", itertools.product(["sgd", "adagrad"], [2_000, 200_000]))
+def test_k64_worker_at_the_headline_row_shape(kind, d):
+    """win_worker_k64 (selected for 64 factors and rows of up to 64 entries: the register-resident worker behind bench.py's
+    headline `exact_order`) at ITS shape: 64 entries per row, k = 64, 20 000 samples, two permuted epochs.  d = 2 000: a sample
+    shares a feature with one of its 63 predecessors almost surely (speculative gather re-read, hot-row and recipe
+    forwarding on every sample); d = 200 000: 2 % per pair -- most samples run side by side, the dependent ones are near
+    successors.  Bit for bit the one-workgroup kernel, and the oracle's fit (optimizer/sgd.nim:246-258,294-308,
+    adagrad.nim:169-184) at rtol 1e-8."""
+    n, m, k = 20_000, 64, 64
+    Xo = _distinct_rows(n, d, m, seed=d + 1)
+    rng = np.random.default_rng(d)
+    y = np.sign(rng.standard_normal(n))
+    P0, w0, b0 = rng.standard_normal((1, k, d)) * 0.01, rng.standard_normal(d) * 0.01, 0.02
+    perms = make_perms(n, 2)
+    ref = _fit_checked(kind, 0, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic")
+    win = _fit_checked(kind, 2, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic")
+    same_bits(win[0], ref[0], "P")
+    same_bits(win[1], ref[1], "w")
+    assert win[2] == ref[2] and win[3] == ref[3] == 2 * n + 1
+    assert np.isfinite(win[0]).all() and not np.array_equal(win[0], P0)
+    if kind == "adagrad":
+        for g, h, name in zip(win[5], ref[5], ["g_sum.P", "g_norm.P", "g_sum.w", "g_norm.w", "g_sum.b", "g_norm.b"]):
+            same_bits(np.atleast_1d(g), np.atleast_1d(h), name)
+        Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, y, 2, P0, w0, b0, O.adagrad_cfg(loss="logistic"), 2, 0, perms=perms)
+    else:
+        Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, O.sgd_cfg(loss="logistic"), 2, 0, perms=perms)
+    assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
+    assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
+    assert abs(win[2] - bf) < 1e-9
+
+
+@pytest.mark.parametrize("kind,d", itertools.product(["sgd", "adagrad"], [2_000, 100_000]))
+def test_general_worker_at_cfg2_row_shape(kind, d):
+    """the LDS-resident worker at BASELINE configs[1]'s row shape (32 entries, k = 16), conflict-heavy and sparse, two
+    permuted epochs: bit for bit the one-workgroup kernel, rtol 1e-8 the oracle"""
+    n, m, k = 20_000, 32, 16
+    Xo = _distinct_rows(n, d, m, seed=d + 2)
+    rng = np.random.default_rng(d + 3)
+    y = np.sign(rng.standard_normal(n))
+    P0, w0, b0 = rng.standard_normal((1, k, d)) * 0.01, rng.standard_normal(d) * 0.01, -0.01
+    perms = make_perms(n, 2)
+    ref = _fit_checked(kind, 0, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic")
+    win = _fit_checked(kind, 2, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic")
+    same_bits(win[0], ref[0], "P")
+    same_bits(win[1], ref[1], "w")
+    assert win[2] == ref[2] and win[3] == ref[3]
+    if kind == "adagrad":
+        for g, h, name in zip(win[5], ref[5], ["g_sum.P", "g_norm.P", "g_sum.w", "g_norm.w", "g_sum.b", "g_norm.b"]):
+            same_bits(np.atleast_1d(g), np.atleast_1d(h), name)
+        Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, y, 2, P0, w0, b0, O.adagrad_cfg(loss="logistic"), 2, 0, perms=perms)
+    else:
+        Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, O.sgd_cfg(loss="logistic"), 2, 0, perms=perms)
+    assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
+    assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
+    assert abs(win[2] - bf) < 1e-9
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad"])
+def test_aborted_window_is_put_back_and_rerun_by_the_one_workgroup_kernel(kind, capfd):
+    """The window's workgroups wait for each other.  NFM_SEQ_WIN_TEST_DEAD_SLOT makes worker 3 leave at once, as a workgroup
+    that never became resident would (CUs held by another tenant): the conductor's wait for that worker's mailbox runs
+    into its 4 s wall-clock limit, the launch aborts with samples 0 ... 2 applied and others half-way.  nfm_opt_epoch
+    must put the parameters (and AdaGrad's state) back to what they were when the call began and run the call through
+    the one-workgroup kernel: the fit equals the NFM_SEQ_WIN=0 fit bit for bit, nothing is reported as an error."""
+    n, d, k = 3000, 500, 16
+    Xo = random_csr(n, d, 8, seed=71)
+    y = np.random.default_rng(72).standard_normal(n)
+    rng = np.random.default_rng(73)
+    P0, w0, b0 = rng.standard_normal((1, k, d)) * 0.05, rng.standard_normal(d) * 0.01, 0.1
+    ref = fit(kind, 0, 16, Xo, y, "regression", k, P0, w0, b0, 1)
+    capfd.readouterr()
+    with env(NFM_SEQ_WIN_TEST_DEAD_SLOT=3):
+        got = fit(kind, 2, 16, Xo, y, "regression", k, P0, w0, b0, 1)
+    err = capfd.readouterr().err
+    assert "falling back to the one-workgroup kernel" in err, err[-500:]
+    same_bits(got[0], ref[0], "P")
+    same_bits(got[1], ref[1], "w")
+    assert got[2] == ref[2] and got[3] == ref[3]
+    assert_close([h[1] for h in got[4]], [h[1] for h in ref[4]], 0, 0, "loss per epoch (the fallback's own sums)")
+    if kind == "adagrad":
+        for g, h, name in zip(got[5], ref[5], ["g_sum.P", "g_norm.P", "g_sum.w", "g_norm.w", "g_sum.b", "g_norm.b"]):
+            same_bits(np.atleast_1d(g), np.atleast_1d(h), name)
+    # and the optimizer keeps working: the next fit of the same shape goes through the window again
+    win = fit(kind, 2, 16, Xo, y, "regression", k, P0, w0, b0, 1)
+    same_bits(win[0], ref[0], "P after the hook is gone")
