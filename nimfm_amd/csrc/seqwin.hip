@@ -2284,7 +2284,7 @@ enum { WK_GENERAL = 0, WK_K64 = 1, WK_FFM = 2, WK_FMX = 3 };  // which worker
 template <int OPT, int CH, int WK>
 __global__ __launch_bounds__(WK >= WK_FFM ? kFfmWaves * kWave : 128) void k_seq_window(WinArgs a) {
   extern __shared__ double lds[];
-  if ((int)blockIdx.x - 1 == a.dead_slot) return;
+  if (a.dead_slot >= 0 && (int)blockIdx.x == a.dead_slot + 1) return;  // (test hook; workgroup 0 is the conductor)
   if (blockIdx.x == 0) {
     if (threadIdx.x < 2 * kWave) {
       win_conductor<OPT, CH>(a, lds);

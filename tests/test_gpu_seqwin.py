@@ -37,7 +37,13 @@ class env:
                 os.environ[k] = v
 
 
-def fit(kind, win, W, Xo, y, task, k, P0, w0, b0, epochs, perms=None, it0=1, nCalls=-1, fit_linear=True, fit_intercept=True, **kw):
+def _fallbacks():
+    """calls of this context that began in the window kernel and ended in the one-workgroup kernel (an aborted launch)"""
+    return nf.default_context().timing_get("seq_window_fallback")[0]
+
+
+def fit(kind, win, W, Xo, y, task, k, P0, w0, b0, epochs, perms=None, it0=1, nCalls=-1, fit_linear=True, fit_intercept=True,
+        expect_fallbacks=0, **kw):
     """one fit in sequential mode; win = 0: the one-workgroup kernels, 2: the window kernel with W workers.  nCalls > 0:
     the reference's per-nCalls callbacks (sgd.nim:303-308): the epoch becomes a series of calls over sub-ranges of the
     order with a finalize in between"""
@@ -47,7 +53,9 @@ def fit(kind, win, W, Xo, y, task, k, P0, w0, b0, epochs, perms=None, it0=1, nCa
         opt = mk(maxIter=epochs, verbose=0, tol=0, shuffle=False, mode="sequential", nCalls=nCalls, **kw)
         opt.it = it0
         seen = []
+        fb0 = _fallbacks()
         opt.fit(to_gpu(Xo), y, fm, perms=perms, callback=(lambda o_, m_: seen.append(o_.it)) if nCalls > 0 else None)
+        assert _fallbacks() - fb0 == expect_fallbacks, "window launches that aborted and were re-run by the one-workgroup kernel"
         state = opt.get_state(fm) if kind == "adagrad" else None
         return fm.P.copy(), fm.w.copy(), fm.intercept, opt.it, list(opt.history), state
 
@@ -252,6 +260,7 @@ def _ffm_fit(kind, win, W, Xo, y, k, P0, w0, b0, epochs, perms=None, **kw):
         ctx.timing_reset()
         opt.fit(to_gpu(Xo), y, ffm, perms=perms)
         windowed = ctx.timing_get("seq_window_deps")[0] > 0
+        assert _fallbacks() == 0, "a window launch aborted"
         ctx.timing_enable(False)
         assert windowed == (int(win) != 0), "the %s kernel ran" % ("one-workgroup" if int(win) else "window")
         state = opt.get_state(ffm) if kind == "adagrad" else None
@@ -314,6 +323,7 @@ def _fmx_fit(kind, win, W, Xo, y, degree, fit_lower, k, P0, w0, b0, epochs, perm
         ctx.timing_reset()
         opt.fit(to_gpu(Xo), y, fm, perms=perms)
         windowed = ctx.timing_get("seq_window_deps")[0] > 0
+        assert _fallbacks() == 0, "a window launch aborted"
         ctx.timing_enable(False)
         assert windowed == (int(win) != 0), "the %s kernel ran" % ("one-workgroup" if int(win) else "window")
         state = opt.get_state(fm) if kind == "adagrad" else None
@@ -469,7 +479,7 @@ def test_aborted_window_is_put_back_and_rerun_by_the_one_workgroup_kernel(kind, 
     ref = fit(kind, 0, 16, Xo, y, "regression", k, P0, w0, b0, 1)
     capfd.readouterr()
     with env(NFM_SEQ_WIN_TEST_DEAD_SLOT=3):
-        got = fit(kind, 2, 16, Xo, y, "regression", k, P0, w0, b0, 1)
+        got = fit(kind, 2, 16, Xo, y, "regression", k, P0, w0, b0, 1, expect_fallbacks=1)
     err = capfd.readouterr().err
     assert "falling back to the one-workgroup kernel" in err, err[-500:]
     same_bits(got[0], ref[0], "P")
