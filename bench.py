@@ -846,7 +846,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                                       "samples/s on this shape; time_to_target: what the rule costs statistically against it)"
                                       % (("summed up to touch cap %g, scaled by cap / c beyond it" % cap) if wl["solver"] == "sgd"
                                          else "summed into AdaGrad's additive state"),
-                       "update_rule_short": ("mini-batch rule of this library (DESIGN.md 4): %s; NOT the reference's order (that is exact_order)"
+                       "update_rule_short": ("library's mini-batch rule (DESIGN.md 4): %s; not the reference's order (see exact_order)"
                                              % (("steps summed up to touch cap %g" % cap) if wl["solver"] == "sgd" else "AdaGrad state summed per batch")),
                        "touch_cap": cap if wl["solver"] == "sgd" else None,
                        "samples_per_gpu": n, "batch": batch,
