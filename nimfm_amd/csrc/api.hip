@@ -1151,7 +1151,12 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         bool ok = false;
         ~DpGuard() {
           o->W.after_batch = nullptr;
-          if (!ok && o->dp) o->dp->pending = false;
+          if (!ok && o->dp) {
+            // the all-reduce of the last sync point may still be running on the group's stream (it reads dp->snap and
+            // writes dp->recv): the next epoch must not overwrite them under it
+            if (o->dp->pending && o->dp->comm) (void)hipStreamSynchronize(o->dp->comm);
+            o->dp->pending = false;
+          }
         }
       } dp_guard{o};
       int rc_epoch;

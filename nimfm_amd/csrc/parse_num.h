@@ -114,12 +114,20 @@ NFM_HD int parse_int(const char* s, int64_t n, int64_t* out) {
     ++i;
   }
   if (i >= n || !is_digit(s[i])) return 0;
-  int64_t v = 0;
+  // (Nim raises ValueError "Parsed integer outside of valid range" past int64; here the value saturates -- every caller
+  // range-checks it against nFeatures / nFields afterwards -- instead of overflowing a signed integer: undefined behaviour,
+  // found by the UBSan build of tests/test_sanitizers.py)
+  const uint64_t lim = 0x7FFFFFFFFFFFFFFFull;
+  uint64_t v = 0;
+  bool sat = false;
   while (i < n && is_digit(s[i])) {
-    v = v * 10 + (s[i] - '0');
+    const uint64_t dgt = (uint64_t)(s[i] - '0');
+    if (v > (lim - dgt) / 10) sat = true;
+    else v = v * 10 + dgt;
     ++i;
   }
-  *out = neg ? -v : v;
+  if (sat) v = lim;
+  *out = neg ? -(int64_t)v : (int64_t)v;
   return (int)i;
 }
 

@@ -835,6 +835,12 @@ class _OptimizerBase:
         perms ([maxIter][n], optional) replaces the internal shuffle with explicit permutations: the
         reference shuffles with Nim's global RNG (sgd.nim:297), which a Nim host passes in here."""
         if devices is not None and len(devices) > 1:
+            if perms is not None:
+                raise ValueError("fit(devices=[...]) draws every rank's order itself (the device shuffle of its shard): perms is not supported")
+            if isinstance(X, StreamCSRDataset):
+                raise ValueError("fit(devices=[...]) needs a resident dataset (its rows are split over the devices), not a StreamCSRDataset")
+            if callback is not None and self.nCalls > 0:
+                raise ValueError("fit(devices=[...]) calls back once, after the fit: nCalls is not supported")
             return self._fit_devices(X, y, fm, list(devices), miniBatchSize, syncPeriod or 0, callback)
         if miniBatchSize is not None:  # for this fit only
             if int(miniBatchSize) < 1:
@@ -844,10 +850,16 @@ class _OptimizerBase:
                 return self.fit(X, y, fm, maxThreads, callback, perms, None, syncPeriod, None)
             finally:
                 self.batch = keep
-        if syncPeriod is not None and self._dp is not None:
-            self._dp = (self._dp[0], int(syncPeriod)) + tuple(self._dp[2:])
+        if syncPeriod is not None and self._dp is not None:  # for this fit only, like miniBatchSize
+            keep_dp, self._dp = self._dp, (self._dp[0], int(syncPeriod)) + tuple(self._dp[2:])
             if self._h is not None:
                 self._attach_dp()
+            try:
+                return self.fit(X, y, fm, maxThreads, callback, perms, None, None, None)
+            finally:
+                self._dp = keep_dp
+                if self._h is not None:
+                    self._attach_dp()
         if isinstance(X, StreamCSRDataset):
             return self._fit_stream(X, y, fm, maxThreads, callback)
         fm.init(X)
@@ -1002,7 +1014,7 @@ def _fit_devices(self, X, y, fm, devices, miniBatchSize, syncPeriod, callback):
         raise err[0][1]
     fm.set_params(models[0].P, models[0].w, models[0].intercept)
     self.it, self.history = opts[0].it, list(opts[0].history)
-    if callback is not None:
+    if callback is not None:  # ONCE, with the finished model (the ranks train without a host in their epoch loops)
         callback(self, fm)
     return self
 

@@ -103,6 +103,13 @@ def epoch_seconds(n):
 def lib():
     global _lib
     if _lib is None:
+        if os.environ.get("NIMFM_ORACLE_VARIANT") == "asan":
+            # the same sources under AddressSanitizer + UndefinedBehaviorSanitizer (oracle/Makefile target `asan`); the process
+            # must have been started with LD_PRELOAD=libasan.so (tests/test_sanitizers.py does that for the oracle tests)
+            so = os.path.join(_HERE, "_build", "libnimfm_oracle_asan.so")
+            subprocess.check_call(["make", "-C", _HERE, "-s", "asan"])
+            _lib = _load(so)
+            return _lib
         build()
         _lib = C.CDLL(_SO)
         for name in ("orc_loss", "orc_dloss", "orc_get_eta", "orc_expit", "orc_rmse", "orc_accuracy_sign",
