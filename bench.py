@@ -741,6 +741,24 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                            "the host (upload + table build inside)" %
                            (ns_, "the reference's order as a dependency window over the chip (csrc/seqwin.hip), results bit-equal to "
                             "the one-workgroup kernel" if windowed else "one workgroup (csrc/seq.hip)")}
+        if windowed and not F and wl["degree"] == 2:
+            # fitIntercept = false: no scalar chain ties the samples (the intercept is what serialises the reference's order),
+            # the window runs without its conductor on twice the workers -- the same order, bit-equal results
+            fm_n = nf.newFactorizationMachine(task, degree=2, nComponents=k, fitIntercept=False, warmStart=True, randomState=1)
+            fm_n.init(Xs)
+            opt_n = mk_(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="sequential")
+            opt_n._handle(fm_n, ctx, "sequential")
+            opt_n._epoch(Xs, None, 0, ns_)
+            opt_n.it += ns_
+            ctx.synchronize()
+            t_n = time.perf_counter()
+            opt_n._epoch(Xs, None, 0, ns_)
+            opt_n.it += ns_
+            ctx.synchronize()
+            t_n = time.perf_counter() - t_n
+            exact["no_intercept"] = {"value": round(ns_ / t_n, 1), "unit": "samples/s",
+                                     "note": "the same order with fitIntercept=false: the window without a conductor (csrc/seqwin.hip)"}
+            del opt_n, fm_n
         # the same order through the one-workgroup kernel (NFM_SEQ_WIN=0, csrc/seq.hip, which the parity tests hold to the
         # oracle) on the first 4096 samples: parameters, linear weights and intercept must agree BIT FOR BIT
         nb_ = min(ns_, 4096)
@@ -916,6 +934,7 @@ def _extra_compact(e):
             "value_shuffled": e.get("value_shuffled"),
             "predict": (e.get("predict") or {}).get("value"), "predict_frac": (e.get("predict") or {}).get("roofline_frac"),
             "exact_order": (e.get("exact_order") or {}).get("value"), "exact_bit_equal": (e.get("exact_order") or {}).get("bit_equal"),
+            "exact_no_intercept": ((e.get("exact_order") or {}).get("no_intercept") or {}).get("value"),
             "t2t_batch": t["batch"] if t else None, "t2t_speedup": [h["speedup"] for h in t["targets"]] if t else None,
             "reached": all(h["speedup"] is not None for h in t["targets"]) if t else None,
             "cpu_baseline": (e.get("cpu_baseline") or {}).get("value")}
@@ -935,7 +954,7 @@ def contract_line(full):
     out["predict"] = {"value": p_["value"], "unit": p_["unit"], "roofline_frac": p_["roofline_frac"]} if p_ else None
     x_ = full.get("exact_order")
     out["exact_order"] = {"value": x_["value"], "unit": x_["unit"], "vs_cpu_port_1_thread": x_.get("vs_cpu_port_1_thread"),
-                          "bit_equal": x_.get("bit_equal")} if x_ else None
+                          "bit_equal": x_.get("bit_equal"), "no_intercept": (x_.get("no_intercept") or {}).get("value")} if x_ else None
     out["time_to_target"] = _t2t_compact(full.get("time_to_target"))
     d_ = full.get("dp")
     out["dp"] = {k_: d_[k_] for k_ in ("combine", "sync_period", "world", "collectives_per_step", "bytes_per_step_per_rank",

@@ -163,7 +163,10 @@ static int launch_fm_predict_orders(nfm_ctx* ctx, const CsrView& X, const ModelV
 template <int LT>
 static int launch_fm_predict_orders_LT(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const double* Pf, int lgL, double* out) {
   constexpr int R = kWave / LT;
-  const int split = choose_split(LT, X.n, X.n > 0 ? (double)X.nnz / (double)X.n + M.n_aug : 0.0, ctx->n_cu);
+  int split = choose_split(LT, X.n, X.n > 0 ? (double)X.nnz / (double)X.n + M.n_aug : 0.0, ctx->n_cu);
+  // two row slots per sample even when the chip is full: the degree >= 3 recursion is a dependent chain per entry, and
+  // halving it measured 0.696 -> 0.718 of the roofline on cfg5 (four slots: 0.634)
+  if (R >= 2 && split < 2 && !getenv("NFM_SPLIT")) split = 2;
   if constexpr (R >= 8) if (split >= 8) return launch_fm_predict_orders<LT, 8>(ctx, X, M, Pf, lgL, out);
   if constexpr (R >= 4) if (split >= 4) return launch_fm_predict_orders<LT, 4>(ctx, X, M, Pf, lgL, out);
   if constexpr (R >= 2) if (split >= 2) return launch_fm_predict_orders<LT, 2>(ctx, X, M, Pf, lgL, out);

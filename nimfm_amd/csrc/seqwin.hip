@@ -84,6 +84,11 @@ struct WinArgs {
   unsigned* ctrl;         // [0]: abort
   double* partial;        // [W + 1][2] {loss, viol} per worker, last: the conductor's
   int W, lgW, m_cap, FW, lgKp;  // FW = MC + kWinHdr words per mailbox, MC = m_cap rounded up to the chain's chunk
+  int np;                 // mailboxes / answer words / forwarding areas per worker (a power of two): sample u of a worker uses
+                          // number (u / W) mod np, i.e. they are reused np samples of that worker later
+  int no_cond;            // 1: fitIntercept = false -- no scalar chain ties the samples, there is NO conductor: a worker adds up its
+                          // sample's prediction itself (intercept constant, the entries' terms in storage order, the interaction
+                          // sum: predictWithGrad, sgd.nim:193-201), takes dloss and posts {dL, yhat} for its near successors
   int dead_slot;          // test hook (NFM_SEQ_WIN_TEST_DEAD_SLOT): this worker leaves at once, as a workgroup that never became
                           // resident would; -1 otherwise.  The others time out, the launch aborts, the host restores + falls back
 };
@@ -179,11 +184,12 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
   unsigned* cnt = reinterpret_cast<unsigned*>(ll + mc);    // [W] completion counters as last seen
   for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
   double loss_acc = 0.0, viol_acc = 0.0;
-  auto fw_area = [&](int64_t u_) { return a.fw + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kFwSlot; };
+  const double b_const = M.sc[SC_INTERCEPT];  // (no_cond: the intercept is not fitted and stays what it is)
+  auto fw_area = [&](int64_t u_) { return a.fw + ((size_t)(u_ & (W - 1)) * a.np + (size_t)((u_ >> lgW) & (a.np - 1))) * kFwSlot; };
   // (the forwarding areas are laid out for 64 entries of up to 64 factors: entry q's row at stride Kp)
   auto fw_row = [&](ull* base, int v, int q) { return base + kFwRows + ((size_t)(v * kWave + q) * Kp + s) * 2; };
   auto fw_lin = [&](ull* base, int v, int q) { return base + kFwLin + (size_t)(v * kWave + q) * 2; };
-  auto res_of = [&](int64_t u_) { return a.res + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kResWords; };
+  auto res_of = [&](int64_t u_) { return a.res + ((size_t)(u_ & (W - 1)) * a.np + (size_t)((u_ >> lgW) & (a.np - 1))) * kResWords; };
 
   for (int64_t u = slot; u < a.n_seg; u += W) {
     const int64_t pos = a.seg0 + u, pa = a.begin + pos;
@@ -193,9 +199,28 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
     const double y = dev::target_of(X.y[i], M.task);
     const int64_t it = a.it0 + u;
     const double itf = (double)it;
-    const int par = (int)((u >> lgW) & 1);
-    ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
-    const ull* rp = a.res + (size_t)(slot * 2 + par) * kResWords;
+    const int par = (int)((u >> lgW) & (a.np - 1));
+    ull* mb = a.fwd + (size_t)(slot * a.np + par) * a.FW;
+    const ull* rp = a.res + (size_t)(slot * a.np + par) * kResWords;
+    if (a.no_cond && u >= (int64_t)a.np * W) {
+      // No conductor walks the samples in order, so nothing else keeps a fast worker from running ahead: its forwarding
+      // area and answer words of sample u - np W are about to be reused, and a near successor of that sample (a position
+      // below u - (np - 1) W) may not have read them yet.  Every sample below that must be complete: the workers before
+      // this one have finished c - (np - 2) samples, the others one fewer (c = this worker's count) -- the window spans
+      // at most np W positions.
+      const unsigned c_ = (unsigned)(u >> lgW) - (unsigned)(a.np - 2);
+      Spin sp;
+      bool first = true;
+      while (true) {
+        bool ok = true;
+        for (int l = lane; l < W; l += kWave) ok = ok && cnt[l] >= (l < slot ? c_ : c_ - 1u);
+        if (__all(ok)) break;
+        if (!first && sp.wait(a.ctrl)) return;
+        first = false;
+        for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
+        compiler_fence();
+      }
+    }
     // the sample's first 64 entries also sit one per lane: they are the ones that can take the forwarding path
     const bool e_in = lane < m;
     const int pq = e_in ? a.prev[q0 + lane] : -1;
@@ -219,7 +244,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       ll[q] = (q < kWave && near) ? 1 : 0;
     }
     compiler_fence();
-    double* const junk = reinterpret_cast<double*>(a.fw + (size_t)2 * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
+    double* const junk = reinterpret_cast<double*>(a.fw + (size_t)a.np * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
 
     // ---- A. every earlier sample of this launch that shares a feature has written its rows (far ones only) ----
     {
@@ -445,7 +470,31 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
     }
     // the mailbox: the terms of the linear part (past the row's end -0.0, which changes no sum), then the header
     const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
-    {
+    double dL_own = 0.0, yh_own = 0.0;
+    if (a.no_cond) {
+      // no conductor: the chain of predictWithGrad (sgd.nim:193-201) right here, in every lane -- the constant intercept,
+      // then the linear terms in storage order, then the interaction sum -- and {dL, yhat} posted as the conductor would
+      double yh_ = b_const;
+      for (int eb = 0; eb < m; eb += 8) {
+        double w_[8], v_[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int e = eb + t < m ? eb + t : eb;
+          w_[t] = wl[e];
+          v_[t] = vl[e];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) yh_ = eb + t < m ? yh_ + (sw * w_[t]) * v_[t] : yh_;
+      }
+      yh_ += tot;
+      yh_own = yh_;
+      dL_own = dev::loss_grad(O.loss, O.loss_param, y, yh_);
+      if (lane < kResWords) {
+        const double v = lane < 2 ? dL_own : yh_own;
+        const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+        st_u64(a.res + (size_t)(slot * a.np + par) * kResWords + lane, ((ull)(unsigned)(u + 1) << 32) | (ull)half);
+      }
+    } else {
       const int MC = a.FW - kWinHdr;
       for (int e = lane; e < a.FW; e += kWave) {
         double val;
@@ -504,7 +553,10 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
 
     // ---- E. {dL, yhat} from the conductor (tagged granules) ----
     double dL, yh;
-    {
+    if (a.no_cond) {
+      dL = dL_own;
+      yh = yh_own;
+    } else {
       Spin sp;
       double rd;
       while (true) {
@@ -514,11 +566,11 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       }
       dL = dev::shfl_d(rd, 0);
       yh = dev::shfl_d(rd, 1);
+      // both mailboxes back to "empty" for their next use, two samples of this worker from now: these stores have
+      // completed (vmcnt(0) below) before this worker posts its next sample, which the conductor consumes before it can
+      // look at these words again (kWinDepth < W)
+      for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);
     }
-    // both mailboxes back to "empty" for their next use, two samples of this worker from now: these stores have
-    // completed (vmcnt(0) below) before this worker posts its next sample, which the conductor consumes before it can
-    // look at these words again (kWinDepth < W)
-    for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);
     if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
 
     // ---- F. update(): sgd.nim:205-243 / updateG(): adagrad.nim:113-134 ----
@@ -557,7 +609,18 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       }
     }
     // ---- G. rows written: tell the waiters ----
+    // (no conductor: the other workers' completion counters requested here ride along with this wait -- the run-ahead
+    // check of the next sample then finds them in LDS instead of paying a round trip of its own)
+    unsigned cr0_ = 0u, cr1_ = 0u;
+    if (a.no_cond) {
+      if (lane < W) cr0_ = ld_u32(a.completed + lane);
+      if (kWave + lane < W) cr1_ = ld_u32(a.completed + kWave + lane);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.no_cond) {
+      if (lane < W) cnt[lane] = cr0_;
+      if (kWave + lane < W) cnt[kWave + lane] = cr1_;
+    }
     if (lane == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
   }
   viol_acc = dev::wave_sum(viol_acc);
@@ -623,10 +686,10 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
   const int hot_cap = (int)((size_t)kFwVals * kWave * kWave / ((size_t)nb * 4 * Kp));
   const int kFxHot = hot_cap < kWave ? hot_cap : kWave;
   const bool fwd_on = kFxHot >= 1;
-  auto fw_area = [&](int64_t u_) { return a.fw + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kFwSlot; };
+  auto fw_area = [&](int64_t u_) { return a.fw + ((size_t)(u_ & (W - 1)) * a.np + (size_t)((u_ >> lgW) & (a.np - 1))) * kFwSlot; };
   auto fw_slot = [&](ull* base, int q, int o, int v) { return base + kFwRows + ((size_t)((q * nb + o) * 4 + v) * Kp + s) * 2; };
   auto fw_lin = [&](ull* base, int v, int q) { return base + kFwLin + (size_t)(v * kWave + q) * 2; };
-  auto res_of = [&](int64_t u_) { return a.res + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kResWords; };
+  auto res_of = [&](int64_t u_) { return a.res + ((size_t)(u_ & (W - 1)) * a.np + (size_t)((u_ >> lgW) & (a.np - 1))) * kResWords; };
   __syncthreads();
 
   for (int64_t u = slot; u < a.n_seg; u += W) {
@@ -638,9 +701,9 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
     const double y = dev::target_of(X.y[i], M.task);
     const int64_t it = a.it0 + u;
     const double itf = (double)it;
-    const int par = (int)((u >> lgW) & 1);
-    ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
-    const ull* rp = a.res + (size_t)(slot * 2 + par) * kResWords;
+    const int par = (int)((u >> lgW) & (a.np - 1));
+    ull* mb = a.fwd + (size_t)(slot * a.np + par) * a.FW;
+    const ull* rp = a.res + (size_t)(slot * a.np + par) * kResWords;
     // ---- 0. the entries; which of them take the forwarding path (wavefront 0 decides for all) ----
     if (wv == 0) {
       const bool e_in = lane < m;
@@ -683,7 +746,7 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
     }
     __syncthreads();
     const ull fwdmask = mk_l[0], hotmask = mk_l[1];
-    double* const junk = reinterpret_cast<double*>(a.fw + (size_t)2 * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
+    double* const junk = reinterpret_cast<double*>(a.fw + (size_t)a.np * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
 
     // ---- B. all F rows of every feature -> LDS (AdaGrad: update() first, adagrad.nim:87-110): the slots dealt to the wavefronts ----
     double sP = 1.0, sw = 1.0;
@@ -1121,10 +1184,10 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
   const int hot_cap = (int)((size_t)kFwVals * kWave * kWave / ((size_t)nb * 4 * Kp));
   const int kFxHot = hot_cap < kWave ? hot_cap : kWave;
   const bool fwd_on = kFxHot >= 1;
-  auto fw_area = [&](int64_t u_) { return a.fw + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kFwSlot; };
+  auto fw_area = [&](int64_t u_) { return a.fw + ((size_t)(u_ & (W - 1)) * a.np + (size_t)((u_ >> lgW) & (a.np - 1))) * kFwSlot; };
   auto fw_slot = [&](ull* base, int q, int o, int v) { return base + kFwRows + ((size_t)((q * nb + o) * 4 + v) * Kp + s) * 2; };
   auto fw_lin = [&](ull* base, int v, int q) { return base + kFwLin + (size_t)(v * kWave + q) * 2; };
-  auto res_of = [&](int64_t u_) { return a.res + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kResWords; };
+  auto res_of = [&](int64_t u_) { return a.res + ((size_t)(u_ & (W - 1)) * a.np + (size_t)((u_ >> lgW) & (a.np - 1))) * kResWords; };
   __syncthreads();
 
   for (int64_t u = slot; u < a.n_seg; u += W) {
@@ -1136,9 +1199,9 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
     const double y = dev::target_of(X.y[i], M.task);
     const int64_t it = a.it0 + u;
     const double itf = (double)it;
-    const int par = (int)((u >> lgW) & 1);
-    ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
-    const ull* rp = a.res + (size_t)(slot * 2 + par) * kResWords;
+    const int par = (int)((u >> lgW) & (a.np - 1));
+    ull* mb = a.fwd + (size_t)(slot * a.np + par) * a.FW;
+    const ull* rp = a.res + (size_t)(slot * a.np + par) * kResWords;
     // ---- 0. the entries; which of them take the forwarding path (wavefront 0 decides for all) ----
     if (wv == 0) {
       const bool e_in = lane < m;
@@ -1180,7 +1243,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
     }
     __syncthreads();
     const ull fwdmask = mk_l[0], hotmask = mk_l[1];
-    double* const junk = reinterpret_cast<double*>(a.fw + (size_t)2 * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
+    double* const junk = reinterpret_cast<double*>(a.fw + (size_t)a.np * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
 
     // ---- B. the rows of every (entry, order) -> LDS (AdaGrad: update() first, adagrad.nim:87-110): the slots dealt to the wavefronts ----
     double sP = 1.0, sw = 1.0;
@@ -1629,8 +1692,8 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
     // a full round trip per sample; the prefetch bought nothing).
     auto issue = [&](int dd, int64_t u) {
       const int64_t uu = u < n ? u : n - 1;  // (past the end: the last mailbox again, never looked at)
-      const int slot = (int)(uu & (W - 1)), par = (int)((uu >> lgW) & 1);
-      const ull* mb = a.fwd + (size_t)(slot * 2 + par) * FW;
+      const int slot = (int)(uu & (W - 1)), par = (int)((uu >> lgW) & (a.np - 1));
+      const ull* mb = a.fwd + (size_t)(slot * a.np + par) * FW;
 #pragma unroll
       for (int l = 0; l < kWinMaxNL; ++l) {
         const int e = lane + kWave * l;
@@ -1792,8 +1855,8 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
         b -= update;
       }
     }
-    const int slot = (int)(u & (W - 1)), par = (int)((u >> lgW) & 1);
-    ull* rp = a.res + (size_t)(slot * 2 + par) * kResWords;
+    const int slot = (int)(u & (W - 1)), par = (int)((u >> lgW) & (a.np - 1));
+    ull* rp = a.res + (size_t)(slot * a.np + par) * kResWords;
     if (lane < kResWords) {  // {dL, yhat} as granules tagged with the sample: its worker and near successors read them
       const double v = lane < 2 ? dL : yh;
       const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
@@ -1869,11 +1932,12 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
   unsigned* cnt = reinterpret_cast<unsigned*>(red + K);  // [W] completion counters as last seen
   for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
   double loss_acc = 0.0, viol_acc = 0.0;
+  const double b_const = M.sc[SC_INTERCEPT];  // (no_cond: the intercept is not fitted and stays what it is)
   double Pr[K];
-  auto fw_area = [&](int64_t u_) { return a.fw + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kFwSlot; };
+  auto fw_area = [&](int64_t u_) { return a.fw + ((size_t)(u_ & (W - 1)) * a.np + (size_t)((u_ >> lgW) & (a.np - 1))) * kFwSlot; };
   auto fw_row = [&](ull* base, int v, int q) { return base + kFwRows + ((size_t)(v * K + q) * K + lane) * 2; };
   auto fw_lin = [&](ull* base, int v, int q) { return base + kFwLin + (size_t)(v * K + q) * 2; };
-  auto res_of = [&](int64_t u_) { return a.res + ((size_t)(u_ & (W - 1)) * 2 + (size_t)((u_ >> lgW) & 1)) * kResWords; };
+  auto res_of = [&](int64_t u_) { return a.res + ((size_t)(u_ & (W - 1)) * a.np + (size_t)((u_ >> lgW) & (a.np - 1))) * kResWords; };
 
   for (int64_t u = slot; u < a.n_seg; u += W) {
     const int64_t pos = a.seg0 + u, pa = a.begin + pos;
@@ -1883,8 +1947,27 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     const double y = dev::target_of(X.y[i], M.task);
     const int64_t it = a.it0 + u;
     const double itf = (double)it;
-    const int par = (int)((u >> lgW) & 1);
-    ull* mb = a.fwd + (size_t)(slot * 2 + par) * a.FW;
+    const int par = (int)((u >> lgW) & (a.np - 1));
+    ull* mb = a.fwd + (size_t)(slot * a.np + par) * a.FW;
+    if (a.no_cond && u >= (int64_t)a.np * W) {
+      // No conductor walks the samples in order, so nothing else keeps a fast worker from running ahead: its forwarding
+      // area and answer words of sample u - np W are about to be reused, and a near successor of that sample (a position
+      // below u - (np - 1) W) may not have read them yet.  Every sample below that must be complete: the workers before
+      // this one have finished c - (np - 2) samples, the others one fewer (c = this worker's count) -- the window spans
+      // at most np W positions.
+      const unsigned c_ = (unsigned)(u >> lgW) - (unsigned)(a.np - 2);
+      Spin sp;
+      bool first = true;
+      while (true) {
+        bool ok = true;
+        for (int l = lane; l < W; l += kWave) ok = ok && cnt[l] >= (l < slot ? c_ : c_ - 1u);
+        if (__all(ok)) break;
+        if (!first && sp.wait(a.ctrl)) return;
+        first = false;
+        for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
+        compiler_fence();
+      }
+    }
     int jq = 0, pq = -1, pqu = 0, nq = -1;
     double vq = 0.0;
     if (lane < m) {
@@ -2165,22 +2248,41 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
         tot += r_[t].y;
       }
     }
-    if (lane < MC) st_u64(mb + lane, mail_bits(lane < m ? (sw * wv) * vq : -0.0));
-    if (lane < kWinHdr) st_u64(mb + MC + lane, mail_bits(lane == 0 ? tot : lane == 1 ? y : lane == 2 ? h2 : (double)m));
+    double dL_own = 0.0, yh_own = 0.0;
+    if (a.no_cond) {
+      // no conductor (fitIntercept = false): predictWithGrad's chain (sgd.nim:193-201) in this wavefront -- the constant
+      // intercept, the entries' terms w_j x_j in storage order (lane q holds entry q's), the interaction sum -- then dloss,
+      // and {dL, yhat} posted as tagged granules exactly as the conductor would (near successors read them)
+      const double term = lane < m ? (sw * wv) * vq : -0.0;
+      double yh_ = b_const;
+#pragma unroll
+      for (int q = 0; q < K; ++q) yh_ += readlane_d(term, q);  // (past the row's end: -0.0, which changes no sum)
+      yh_ += tot;
+      yh_own = yh_;
+      dL_own = dev::loss_grad(O.loss, O.loss_param, y, yh_);
+      if (lane < kResWords) {
+        const double v = lane < 2 ? dL_own : yh_own;
+        const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+        st_u64(a.res + ((size_t)(u & (W - 1)) * a.np + (size_t)((u >> lgW) & (a.np - 1))) * kResWords + lane, ((ull)mytag << 32) | (ull)half);
+      }
+    } else {
+      if (lane < MC) st_u64(mb + lane, mail_bits(lane < m ? (sw * wv) * vq : -0.0));
+      if (lane < kWinHdr) st_u64(mb + MC + lane, mail_bits(lane == 0 ? tot : lane == 1 ? y : lane == 2 ? h2 : (double)m));
+    }
     if (a.trace && lane == 0) a.trace[u * 8 + 2] = wall_clock64();  // mailbox posted
     // (after the mailbox: a successor needs them together with this sample's dL, which the conductor forms from the mailbox)
     if (hotmask) {  // the recipes of the rows a near successor shares (the base is made opaque per use: left to itself the
                     // compiler hoists the 192 row addresses out of the sample loop and spills them)
       // (an opaque OFFSET, not an opaque pointer: the address must stay provably global -- sc1 through flat_ instructions
       // is not the hand-off this kernel relies on)
-      size_t fwo = ((size_t)(u & (W - 1)) * 2 + (size_t)((u >> lgW) & 1)) * kFwSlot;
+      size_t fwo = ((size_t)(u & (W - 1)) * a.np + (size_t)((u >> lgW) & (a.np - 1))) * kFwSlot;
       asm volatile("" : "+s"(fwo));
       ull* fwm = a.fw + fwo;
       fw_store(fwm + (size_t)lane * 2, mytag, a1);
 #pragma unroll
       for (int q = 0; q < K; ++q) {
         if (q < m && ((hotmask >> q) & 1ull)) {
-          size_t fqo = ((size_t)(u & (W - 1)) * 2 + (size_t)((u >> lgW) & 1)) * kFwSlot;
+          size_t fqo = ((size_t)(u & (W - 1)) * a.np + (size_t)((u >> lgW) & (a.np - 1))) * kFwSlot;
           asm volatile("" : "+s"(fqo));
           ull* fq_ = a.fw + fqo;
           fw_store(fw_row(fq_, 0, q), mytag, Pr[q]);
@@ -2202,7 +2304,10 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
 
     // ---- E. {dL, yhat} from the conductor: tagged granules (a near successor reads them too) ----
     double dL, yh;
-    {
+    if (a.no_cond) {
+      dL = dL_own;
+      yh = yh_own;
+    } else {
       const ull* rp = res_of(u);
       Spin sp;
       double rd;
@@ -2231,7 +2336,7 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
         st_f64(M.P + e, (p - update) / sPn);
       }
     } else {
-      double* const junk = reinterpret_cast<double*>(a.fw + (size_t)2 * W * kFwSlot) + (size_t)slot * 2 * K + lane;  // scratch rows
+      double* const junk = reinterpret_cast<double*>(a.fw + (size_t)a.np * W * kFwSlot) + (size_t)slot * 2 * K + lane;  // scratch rows
 #pragma unroll
       for (int q = 0; q < K; ++q) {
         const bool in = q < m;
@@ -2265,11 +2370,24 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     // the mailbox back to "empty" for its next use, two samples of this worker from now: these stores have completed
     // (vmcnt(0) below) before this worker posts its next sample, which the conductor consumes before it can look at
     // these words again (kWinDepth < W)
-    if (lane < a.FW) st_u64(mb + lane, kWinSentinel);
-    if (lane < a.FW - kWave) st_u64(mb + kWave + lane, kWinSentinel);
+    if (!a.no_cond) {
+      if (lane < a.FW) st_u64(mb + lane, kWinSentinel);
+      if (lane < a.FW - kWave) st_u64(mb + kWave + lane, kWinSentinel);
+    }
     if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
     // ---- G. rows written: tell the far waiters ----
+    // (no conductor: the other workers' completion counters requested here ride along with this wait -- the run-ahead
+    // check of the next sample then finds them in LDS instead of paying a round trip of its own)
+    unsigned cr0_ = 0u, cr1_ = 0u;
+    if (a.no_cond) {
+      if (lane < W) cr0_ = ld_u32(a.completed + lane);
+      if (kWave + lane < W) cr1_ = ld_u32(a.completed + kWave + lane);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.no_cond) {
+      if (lane < W) cnt[lane] = cr0_;
+      if (kWave + lane < W) cnt[kWave + lane] = cr1_;
+    }
     if (lane == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
     if (a.trace && lane == 0) a.trace[u * 8 + 4] = wall_clock64();  // rows written
   }
@@ -2286,6 +2404,7 @@ __global__ __launch_bounds__(WK >= WK_FFM ? kFfmWaves * kWave : 128) void k_seq_
   extern __shared__ double lds[];
   if (a.dead_slot >= 0 && (int)blockIdx.x == a.dead_slot + 1) return;  // (test hook; workgroup 0 is the conductor)
   if (blockIdx.x == 0) {
+    if (a.no_cond) return;  // nothing to conduct: the workers form their samples' predictions themselves
     if (threadIdx.x < 2 * kWave) {
       win_conductor<OPT, CH>(a, lds);
     } else {
@@ -2575,7 +2694,11 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   const bool ada = opt_kind == OPT_ADAGRAD;
   if (m_cap < 1) m_cap = 1;
   // worker count: a power of two, one workgroup per CU with one CU left for the conductor
-  int W = 64;
+  const bool ffm_ = M.kind == NFM_KIND_FFM, fmx_ = !ffm_ && (M.nb != 1 || M.degree != 2);
+  // fitIntercept = false (degree-2 FMs): no conductor, and nothing but the features ties the samples -- twice the workers
+  static const bool nc_on = !(getenv("NFM_SEQ_WIN_NOCOND") && atoi(getenv("NFM_SEQ_WIN_NOCOND")) == 0);
+  const bool no_cond = nc_on && !M.fit_intercept && !ffm_ && !fmx_;
+  int W = no_cond ? 128 : 64;
   if (const char* env = getenv("NFM_SEQ_WIN_W")) W = atoi(env);
   int lgW = 4;
   while ((2 << lgW) <= W && lgW < 7) ++lgW;
@@ -2604,7 +2727,8 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     sw->end = end;
     sw->nnz = X.nnz;
   }
-  const size_t n_fwd = (size_t)W * 2 * FW, n_res = (size_t)W * 2 * kResWords;
+  const int np = no_cond ? 4 : 2;  // without a conductor the workers may run further apart (see the workers' run-ahead check)
+  const size_t n_fwd = (size_t)W * np * FW, n_res = (size_t)W * np * kResWords;
   NFM_TRY(sw->mail.ensure(sizeof(ull) * (n_fwd + n_res)));
   NFM_TRY(sw->ctl.ensure(sizeof(unsigned) * (W + 64) + sizeof(double) * 2 * (W + 1) + sizeof(int64_t) * 2));
   if (!ada) NFM_TRY(sw->scales.ensure(sizeof(double) * 2 * (size_t)ns));
@@ -2617,7 +2741,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   a.prev = sw->prev.as<int32_t>();
   a.prevq = sw->prevq.as<uint8_t>();
   a.next = sw->next.as<int32_t>();
-  NFM_TRY(sw->fw.ensure(sizeof(ull) * (kFwSlot * 2 + 2 * kWave) * (size_t)W));  // + two scratch rows per worker
+  NFM_TRY(sw->fw.ensure(sizeof(ull) * (kFwSlot * np + 2 * kWave) * (size_t)W));  // + two scratch rows per worker
   a.fw = sw->fw.as<ull>();
   a.trace = nullptr;
   if (getenv("NFM_SEQ_WIN_TRACE") && atoi(getenv("NFM_SEQ_WIN_TRACE")) != 0) {  // debugging: stamps of the first launch's samples
@@ -2634,6 +2758,8 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   int64_t* info = reinterpret_cast<int64_t*>(a.partial + 2 * (W + 1));
   a.W = W;
   a.lgW = lgW;
+  a.no_cond = no_cond ? 1 : 0;
+  a.np = np;
   a.dead_slot = -1;
   if (const char* env = getenv("NFM_SEQ_WIN_TEST_DEAD_SLOT")) a.dead_slot = atoi(env);  // test hook, see WinArgs
   a.m_cap = m_cap;
@@ -2664,7 +2790,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     // mailboxes empty, counters and abort word zero
     {
       NFM_HIP_CHECK(hipMemsetAsync(sw->ctl.p, 0, sizeof(unsigned) * (W + 64) + sizeof(double) * 2 * (W + 1), st));
-      NFM_HIP_CHECK(hipMemsetAsync(sw->fw.p, 0, sizeof(ull) * kFwSlot * 2 * (size_t)W, st));  // tag 0: nobody's
+      NFM_HIP_CHECK(hipMemsetAsync(sw->fw.p, 0, sizeof(ull) * kFwSlot * np * (size_t)W, st));  // tag 0: nobody's
       const int64_t nm = (int64_t)n_fwd;  // the workers' mailboxes "empty"; the conductor's answers carry tags (0: nobody's)
       hipLaunchKernelGGL(k_win_fill, dim3((unsigned)((nm + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sw->mail.as<ull>(), nm, kWinSentinel);
       NFM_HIP_CHECK(hipMemsetAsync(sw->mail.as<ull>() + n_fwd, 0, sizeof(ull) * n_res, st));

@@ -393,13 +393,13 @@ def _distinct_rows(n, d, m, seed):
     return O.Dataset(np.arange(n + 1, dtype=np.int64) * m, idx.ravel().astype(np.int64), rng.uniform(-1, 1, n * m), n, d)
 
 
-def _fit_checked(kind, win, Xo, y, task, k, P0, w0, b0, epochs, perms, **kw):
+def _fit_checked(kind, win, Xo, y, task, k, P0, w0, b0, epochs, perms, W=64, **kw):
     """like fit(), and asserts WHICH kernel ran (the window builds a dependency table, the one-workgroup kernel does not)"""
     ctx = nf.default_context()
     ctx.timing_enable(True)
     ctx.timing_reset()
     try:
-        out = fit(kind, win, 64, Xo, y, task, k, P0, w0, b0, epochs, perms, **kw)
+        out = fit(kind, win, W, Xo, y, task, k, P0, w0, b0, epochs, perms, **kw)
         windowed = ctx.timing_get("seq_window_deps")[0] > 0
     finally:
         ctx.timing_enable(False)
@@ -407,58 +407,64 @@ def _fit_checked(kind, win, Xo, y, task, k, P0, w0, b0, epochs, perms, **kw):
     return out
 
 
-@pytest.mark.parametrize("kind,d", itertools.product(["sgd", "adagrad"], [2_000, 200_000]))
-def test_k64_worker_at_the_headline_row_shape(kind, d):
+@pytest.mark.parametrize("kind,d,fit_intercept", itertools.product(["sgd", "adagrad"], [2_000, 200_000], [True, False]))
+def test_k64_worker_at_the_headline_row_shape(kind, d, fit_intercept):
     """win_worker_k64 (selected for 64 factors and rows of up to 64 entries: the register-resident worker behind bench.py's
     headline `exact_order`) at ITS shape: 64 entries per row, k = 64, 20 000 samples, two permuted epochs.  d = 2 000: a sample
     shares a feature with one of its 63 predecessors almost surely (speculative gather re-read, hot-row and recipe
     forwarding on every sample); d = 200 000: 2 % per pair -- most samples run side by side, the dependent ones are near
     successors.  Bit for bit the one-workgroup kernel, and the oracle's fit (optimizer/sgd.nim:246-258,294-308,
-    adagrad.nim:169-184) at rtol 1e-8."""
+    adagrad.nim:169-184) at rtol 1e-8.  fit_intercept = False: the window without a conductor (128 workers, each adds up
+    its own sample's prediction: no scalar chain ties the samples, only their features do)."""
     n, m, k = 20_000, 64, 64
+    fl = dict(fit_intercept=fit_intercept, W=64 if fit_intercept else 128)
     Xo = _distinct_rows(n, d, m, seed=d + 1)
     rng = np.random.default_rng(d)
     y = np.sign(rng.standard_normal(n))
     P0, w0, b0 = rng.standard_normal((1, k, d)) * 0.01, rng.standard_normal(d) * 0.01, 0.02
     perms = make_perms(n, 2)
-    ref = _fit_checked(kind, 0, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic")
-    win = _fit_checked(kind, 2, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic")
+    ref = _fit_checked(kind, 0, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic", **fl)
+    win = _fit_checked(kind, 2, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic", **fl)
     same_bits(win[0], ref[0], "P")
     same_bits(win[1], ref[1], "w")
     assert win[2] == ref[2] and win[3] == ref[3] == 2 * n + 1
+    assert fit_intercept or win[2] == b0
     assert np.isfinite(win[0]).all() and not np.array_equal(win[0], P0)
+    assert_close([h[1] for h in win[4]], [h[1] for h in ref[4]], 1e-12, 1e-15, "loss per epoch")
     if kind == "adagrad":
         for g, h, name in zip(win[5], ref[5], ["g_sum.P", "g_norm.P", "g_sum.w", "g_norm.w", "g_sum.b", "g_norm.b"]):
             same_bits(np.atleast_1d(g), np.atleast_1d(h), name)
-        Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, y, 2, P0, w0, b0, O.adagrad_cfg(loss="logistic"), 2, 0, perms=perms)
+        Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, y, 2, P0, w0, b0, O.adagrad_cfg(loss="logistic", fit_intercept=fit_intercept), 2, 0, perms=perms)
     else:
-        Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, O.sgd_cfg(loss="logistic"), 2, 0, perms=perms)
+        Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, O.sgd_cfg(loss="logistic", fit_intercept=fit_intercept), 2, 0, perms=perms)
     assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
     assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
     assert abs(win[2] - bf) < 1e-9
 
 
-@pytest.mark.parametrize("kind,d", itertools.product(["sgd", "adagrad"], [2_000, 100_000]))
-def test_general_worker_at_cfg2_row_shape(kind, d):
+@pytest.mark.parametrize("kind,d,fit_intercept", itertools.product(["sgd", "adagrad"], [2_000, 100_000], [True, False]))
+def test_general_worker_at_cfg2_row_shape(kind, d, fit_intercept):
     """the LDS-resident worker at BASELINE configs[1]'s row shape (32 entries, k = 16), conflict-heavy and sparse, two
-    permuted epochs: bit for bit the one-workgroup kernel, rtol 1e-8 the oracle"""
+    permuted epochs: bit for bit the one-workgroup kernel, rtol 1e-8 the oracle (fit_intercept = False: without a conductor)"""
     n, m, k = 20_000, 32, 16
+    fl = dict(fit_intercept=fit_intercept, W=64 if fit_intercept else 128)
     Xo = _distinct_rows(n, d, m, seed=d + 2)
     rng = np.random.default_rng(d + 3)
     y = np.sign(rng.standard_normal(n))
     P0, w0, b0 = rng.standard_normal((1, k, d)) * 0.01, rng.standard_normal(d) * 0.01, -0.01
     perms = make_perms(n, 2)
-    ref = _fit_checked(kind, 0, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic")
-    win = _fit_checked(kind, 2, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic")
+    ref = _fit_checked(kind, 0, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic", **fl)
+    win = _fit_checked(kind, 2, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic", **fl)
     same_bits(win[0], ref[0], "P")
     same_bits(win[1], ref[1], "w")
     assert win[2] == ref[2] and win[3] == ref[3]
+    assert_close([h[1] for h in win[4]], [h[1] for h in ref[4]], 1e-12, 1e-15, "loss per epoch")
     if kind == "adagrad":
         for g, h, name in zip(win[5], ref[5], ["g_sum.P", "g_norm.P", "g_sum.w", "g_norm.w", "g_sum.b", "g_norm.b"]):
             same_bits(np.atleast_1d(g), np.atleast_1d(h), name)
-        Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, y, 2, P0, w0, b0, O.adagrad_cfg(loss="logistic"), 2, 0, perms=perms)
+        Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, y, 2, P0, w0, b0, O.adagrad_cfg(loss="logistic", fit_intercept=fit_intercept), 2, 0, perms=perms)
     else:
-        Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, O.sgd_cfg(loss="logistic"), 2, 0, perms=perms)
+        Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, O.sgd_cfg(loss="logistic", fit_intercept=fit_intercept), 2, 0, perms=perms)
     assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
     assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
     assert abs(win[2] - bf) < 1e-9
