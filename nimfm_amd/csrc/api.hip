@@ -1143,6 +1143,10 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
           regular = PL.n_batches - 1;
         NFM_TRY(dp_epoch_begin(de, regular, PL.n_batches));
         o->W.after_batch = [&de](int64_t b) { return dp_after_batch(de, b); };
+        o->W.is_sync = nullptr;  // (no graphs for the threads of a local group: dp.h)
+        if (!o->dp->t->in_process)
+          o->W.is_sync = [&de](int64_t b) { return de.sync_period > 0 && (b + 1) % de.sync_period == 0 && (b + 1) / de.sync_period <= de.n_sync; };
+        o->W.seg_key_now = (de.sync_period << 32) + de.n_sync;
       }
       // the hook refers to this frame: whatever way the call leaves, it is taken off again; a call that fails between
       // a sync point and its fold-in leaves no exchange marked pending (dp_epoch_begin would refuse every later epoch)
@@ -1151,6 +1155,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
         bool ok = false;
         ~DpGuard() {
           o->W.after_batch = nullptr;
+          o->W.is_sync = nullptr;
           if (!ok && o->dp) {
             // the all-reduce of the last sync point may still be running on the group's stream (it reads dp->snap and
             // writes dp->recv): the next epoch must not overwrite them under it
@@ -1175,6 +1180,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       else
         rc_epoch = mb_ffm_epoch(ctx, o->kind, ds->v, M, o->o, *o->plan, o->W, o->it, out2_dst, prefetch);
       o->W.after_batch = nullptr;
+      o->W.is_sync = nullptr;
       if (prefetch) {
         int rc_next = NFM_OK;
         if (rc_epoch == NFM_OK) {

@@ -24,6 +24,9 @@ enum { DP_SUM = 0, DP_MAX = 1 };
 // rank's device; every rank receives the same bits.
 struct DpTransport {
   int rank = 0, world = 1;
+  // the ranks are host threads of ONE process (nfm_dp_create_local).  Stream capture is not used then: another rank's
+  // thread may synchronise the device (the block cache's cross-thread reuse) while this one captures, which voids the capture
+  bool in_process = false;
   virtual ~DpTransport() {}
   virtual int allreduce(const double* send, double* recv, int64_t n, int op, hipStream_t st) = 0;
 };

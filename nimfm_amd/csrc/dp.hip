@@ -135,6 +135,7 @@ __global__ void k_sum_peers(PeerPtrs src, int world, double* __restrict__ dst, i
   }
 }
 struct LocalTransport : DpTransport {
+  LocalTransport() { in_process = true; }
   std::shared_ptr<LocalGroup> g;
   int allreduce(const double* send, double* recv, int64_t n, int op, hipStream_t st) override {
     LocalGroup& G = *g;

@@ -1,6 +1,7 @@
 // nimfm_amd/csrc/mb.h -- mini-batch mode: work buffers and entry points.
 #pragma once
 #include <functional>
+#include <vector>
 
 #include "opt_views.h"
 #include "plan.h"
@@ -30,6 +31,20 @@ struct MbWork {
   // data-parallel hook (dp.h): called after every mini-batch has been enqueued; set only for the duration of one
   // nfm_opt_epoch call of an optimizer with a group attached (such an epoch is never replayed as a graph)
   std::function<int(int64_t)> after_batch;
+  // Data-parallel epochs as hipGraphs (FM): the mini-batches BETWEEN two exchange points are captured as one graph each;
+  // the exchange itself (increment passes, the collective on the group's stream, events) stays outside.  is_sync(b): the
+  // hook has work after mini-batch b.  seg_execs[s] covers the launches up to and including mini-batch seg_cut[s] (the last
+  // one: to the end of the call); replayed while the key (plan, data, optimizer, period, exchange points) stays the same.
+  std::function<bool(int64_t)> is_sync;
+  std::vector<void*> seg_execs;
+  std::vector<int64_t> seg_cut;
+  uint64_t seg_plan_serial = 0, seg_data_serial = 0;
+  int seg_opt = -1;
+  int64_t seg_key = -1;  // sync_period * 2^32 + exchange points of the call
+  int64_t seg_key_now = -1;
+  bool seg_recording = false;
+  int seg_cut_here(nfm_ctx* ctx, int64_t b);  // ends the capture of the current segment, instantiates and launches it
+  int seg_resume(nfm_ctx* ctx);               // begins the capture of the next one
   void drop_graph();
   ~MbWork();
 };

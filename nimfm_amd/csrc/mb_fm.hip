@@ -146,6 +146,27 @@ __global__ void k_set_double(double* p, double v) { *p = v; }
 void MbWork::drop_graph() {
   if (graph_exec) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec));
   graph_exec = nullptr;
+  for (void* e : seg_execs)
+    if (e) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(e));
+  seg_execs.clear();
+  seg_cut.clear();
+  seg_key = -1;
+}
+int MbWork::seg_cut_here(nfm_ctx* ctx, int64_t b) {
+  hipGraph_t graph = nullptr;
+  NFM_HIP_CHECK(hipStreamEndCapture(ctx->stream, &graph));
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  NFM_HIP_CHECK(e2);
+  seg_execs.push_back(exec);
+  seg_cut.push_back(b);
+  NFM_HIP_CHECK(hipGraphLaunch(exec, ctx->stream));
+  return NFM_OK;
+}
+int MbWork::seg_resume(nfm_ctx* ctx) {
+  NFM_HIP_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  return NFM_OK;
 }
 MbWork::~MbWork() { drop_graph(); }
 
@@ -203,6 +224,37 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
       W.graph_opt = opt_kind;
     }
     NFM_HIP_CHECK(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(W.graph_exec), st));
+  } else if (W.use_graph && W.after_batch && W.is_sync && !ctx->timing.enabled && !P.has_perm && P.n_batches >= 8) {
+    // a data-parallel epoch over a reusable plan: one graph per stretch of mini-batches between exchange points
+    static const bool seg_on = !(getenv("NFM_DP_GRAPH") && atoi(getenv("NFM_DP_GRAPH")) == 0);
+    if (!seg_on) {
+      NFM_TRY(enqueue_epoch(ctx, opt_kind, X, M, O, P, W, TA));
+    } else if (!W.seg_execs.empty() && W.seg_plan_serial == P.serial && W.seg_data_serial == data_serial && W.seg_opt == opt_kind &&
+               W.seg_key == W.seg_key_now) {
+      for (size_t sgi = 0; sgi < W.seg_execs.size(); ++sgi) {
+        NFM_HIP_CHECK(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(W.seg_execs[sgi]), st));
+        if (sgi + 1 < W.seg_execs.size()) NFM_TRY(W.after_batch(W.seg_cut[sgi]));
+      }
+    } else {
+      W.drop_graph();
+      W.seg_recording = true;
+      int rc = W.seg_resume(ctx);
+      if (rc == NFM_OK) rc = enqueue_epoch(ctx, opt_kind, X, M, O, P, W, TA);  // run_batches cuts at the exchange points
+      W.seg_recording = false;
+      if (rc != NFM_OK) {
+        hipGraph_t junk = nullptr;
+        (void)hipStreamEndCapture(st, &junk);  // (whatever state the capture is in)
+        if (junk) (void)hipGraphDestroy(junk);
+        (void)hipGetLastError();
+        W.drop_graph();
+        return rc;
+      }
+      NFM_TRY(W.seg_cut_here(ctx, P.n_batches - 1));
+      W.seg_plan_serial = P.serial;
+      W.seg_data_serial = data_serial;
+      W.seg_opt = opt_kind;
+      W.seg_key = W.seg_key_now;
+    }
   } else {
     NFM_TRY(enqueue_epoch(ctx, opt_kind, X, M, O, P, W, TA));
   }

@@ -2136,7 +2136,13 @@ static int run_batches(nfm_ctx* ctx, const CsrView& X, const ModelView& M, const
     }
     n_prev = nB + nS + nH;
     if (OPT == OPT_PSGD && O.gradP == nullptr) launch_psgd_step(ctx, M, O, W, it0p, it_b);
-    if (W.after_batch) NFM_TRY(W.after_batch(b));
+    if (W.after_batch) {
+      // (recording a data-parallel epoch as graphs: the stretch up to here ends, the exchange runs outside the capture)
+      const bool cut = W.seg_recording && W.is_sync && W.is_sync(b);  // (also after the last mini-batch: the hook must never be captured)
+      if (cut) NFM_TRY(W.seg_cut_here(ctx, b));
+      NFM_TRY(W.after_batch(b));
+      if (cut) NFM_TRY(W.seg_resume(ctx));
+    }
   }
   if (P.n_batches > 0) {
     const double* parts_last = W.partsB.as<double>() + ((P.n_batches - 1) & 1) * partsB_half;
