@@ -633,6 +633,12 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                     "bytes_per_step_per_rank": (i1["bytes"] - dp_info0["bytes"]) / steps,
                     "note": "mid-epoch all-reduces of the whole parameter (SGD) / state (AdaGrad) arena on the group's own stream, "
                             "delayed by one period, plus the exact closing exchange of every epoch call"}
+        # what N ranks' epoch is worth against ONE rank's epoch over all samples (1.0: throughput IS speed-up), measured with
+        # local groups on one GPU on a planted FM (tools/dp_convergence.py); quoted, not measured in this run
+        prog = {"mean": {2: 1.15, 4: 1.20, 8: 1.12}, "state_mean": {2: 1.03, 4: 0.93, 8: 0.75}, "sum": {2: 0.96, 4: 0.98, 8: 1.01}}
+        if i1["world"] in (2, 4, 8) and comb in prog and (wl["solver"] == "adagrad" or comb == "mean"):
+            dp_stats["progress_per_epoch"] = prog[comb][i1["world"]]
+            dp_stats["progress_source"] = "profiles/r03_dp_convergence.txt (planted FM, local groups of this size on one GPU; not this run)"
 
     # ---- the reference's default shuffle = true (optimizer/sgd.nim:297): every epoch gets a FRESH permutation, so the
     # batch plan is rebuilt for every epoch inside the timed region.

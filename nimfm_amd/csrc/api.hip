@@ -988,6 +988,7 @@ static int dp_epoch_setup(nfm_opt* o, nfm_model* m, const ModelView& M, DpEpoch*
   const bool averaged = o->kind == OPT_SGD ? o->dp_combine != NFM_DP_SUM
                                            : (o->dp_combine == NFM_DP_STATE_MEAN || (o->dp_combine == NFM_DP_AUTO && o->dp_sync_period != 1));
   de.combine_w = averaged ? 1.0 / (double)o->dp->t->world : 1.0;
+  if (o->dp_combine == NFM_DP_STATE_RSQRT) de.combine_w = 1.0 / sqrt((double)o->dp->t->world);
   if (o->kind == OPT_SGD) {
     de.arena = m->arena.as<double>();
     de.n = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double)) + SC_COUNT;
@@ -1379,8 +1380,8 @@ int32_t nfm_opt_set_touch_cap(nfm_opt* o, double cap) {
 
 int32_t nfm_opt_set_dp_combine(nfm_opt* o, int32_t combine) {
   NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
-  NFM_CHECK(combine == NFM_DP_AUTO || combine == NFM_DP_MEAN || combine == NFM_DP_SUM || combine == NFM_DP_STATE_MEAN, NFM_ERR_INVALID,
-            "combine must be NFM_DP_AUTO, NFM_DP_MEAN, NFM_DP_SUM or NFM_DP_STATE_MEAN");
+  NFM_CHECK(combine == NFM_DP_AUTO || combine == NFM_DP_MEAN || combine == NFM_DP_SUM || combine == NFM_DP_STATE_MEAN || combine == NFM_DP_STATE_RSQRT,
+            NFM_ERR_INVALID, "combine must be NFM_DP_AUTO, NFM_DP_MEAN, NFM_DP_SUM, NFM_DP_STATE_MEAN or NFM_DP_STATE_RSQRT");
   o->dp_combine = combine;
   return NFM_OK;
 }

@@ -112,7 +112,7 @@ if len(sys.argv) > 3:  # one row in a process of its own: "solver world S one_ra
     solver, world, S, one = sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
     nb = (n // world) // B
     row = []
-    variants = [("mean", 1.0), ("sum", 1.0)] if solver == "sgd" else [("sum", 1.0), ("state_mean", 1.0)]
+    variants = [("mean", 1.0), ("sum", 1.0)] if solver == "sgd" else [("sum", 1.0), ("state_mean", 1.0), ("state_rsqrt", 1.0)]
     for combine, es in variants:
         v = ranks(solver, world, S, combine, es)
         prog = (L0 - v) / (L0 - one) if np.isfinite(v) else float("nan")
