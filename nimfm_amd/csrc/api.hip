@@ -988,7 +988,7 @@ static int dp_epoch_setup(nfm_opt* o, nfm_model* m, const ModelView& M, DpEpoch*
   const bool averaged = o->kind == OPT_SGD ? o->dp_combine != NFM_DP_SUM
                                            : (o->dp_combine == NFM_DP_STATE_MEAN || (o->dp_combine == NFM_DP_AUTO && o->dp_sync_period != 1));
   de.combine_w = averaged ? 1.0 / (double)o->dp->t->world : 1.0;
-  if (o->dp_combine == NFM_DP_STATE_RSQRT) de.combine_w = 1.0 / sqrt((double)o->dp->t->world);
+  if (o->kind == OPT_ADAGRAD && o->dp_combine == NFM_DP_STATE_RSQRT) de.combine_w = 1.0 / sqrt((double)o->dp->t->world);  // (SGD: the mean)
   if (o->kind == OPT_SGD) {
     de.arena = m->arena.as<double>();
     de.n = (int64_t)((m->sc.as<char>() - m->arena.as<char>()) / sizeof(double)) + SC_COUNT;

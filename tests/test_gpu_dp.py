@@ -70,7 +70,7 @@ def test_local_group_sgd_and_adagrad_vs_rule(world, S, overlap, combine):
 
 
 @pytest.mark.parametrize("world,S,combine", [(4, 4, "mean"), (8, 2, "mean"), (8, 0, "mean"), (4, 0, "mean"), (4, 3, "state_mean"),
-                                              (8, 0, "state_mean"), (4, 3, "auto"), (4, 0, "auto"), (2, 1, "auto")])
+                                              (8, 0, "state_mean"), (4, 3, "auto"), (4, 0, "auto"), (2, 1, "auto"), (4, 3, "state_rsqrt")])
 def test_local_group_many_ranks_vs_rule(world, S, combine):
     """4 and 8 ranks (tools/dp_convergence.py runs these group sizes), several mid-epoch exchanges per rank; state_mean:
     AdaGrad's state increments averaged instead of summed (NFM_DP_STATE_MEAN; for SGD it is the mean); auto: NFM_DP_AUTO,
@@ -109,7 +109,7 @@ def _vs_rule(N, D, world, S, overlap, combine):
                     def ep(P_, w_, b_, lo, hi, it_):
                         b2, _, ls, vs = O.fm_sgd_epoch_mb(shard, ys, 2, P_, w_, b_, cfg, B, begin=lo, end=hi, it=it_)
                         return b2, ls, vs
-                    P, w, b, ls, vs, it = yield from R.rank_sgd(ep, P, w, b, cfg, shard.n, B, S, it, overlap, world, "mean" if lib_combine == "auto" else combine)
+                    P, w, b, ls, vs, it = yield from R.rank_sgd(ep, P, w, b, cfg, shard.n, B, S, it, overlap, world, "mean" if lib_combine in ("auto", "state_rsqrt") else combine)
                     hist.append((vs, ls / N))
                 return P, w, b, hist, it
 
@@ -126,7 +126,7 @@ def _vs_rule(N, D, world, S, overlap, combine):
                     def ep(lo, hi, it_):
                         hold[0], _, ls, vs = O.fm_adagrad_epoch_mb(shard, ys, 2, P, w, hold[0], cfg, B, st, begin=lo, end=hi, it=it_)
                         return ls, vs
-                    st, ls, vs, it = yield from R.rank_adagrad(ep, st, shard.n, B, S, it, overlap, world, 1.0 / world if combine == "state_mean" else 1.0)
+                    st, ls, vs, it = yield from R.rank_adagrad(ep, st, shard.n, B, S, it, overlap, world, 1.0 / world if combine == "state_mean" else (1.0 / np.sqrt(world) if combine == "state_rsqrt" else 1.0))
                     hist.append((vs, ls / N))
                 bb = O.fm_adagrad_finalize(2, P, w, hold[0], cfg, it, st)
                 return P, w, bb, hist, it

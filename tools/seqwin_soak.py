@@ -1,6 +1,7 @@
 """Soak: the window kernel against the one-workgroup kernel, bit for bit, on the benchmark row shapes at a size where every
 hand-off path is taken thousands of times (near and far dependencies, forwarding, four-wavefront workers).
-usage: python tools/seqwin_soak.py [n] [cfg2,cfg4,cfg5,headline]"""
+usage: python tools/seqwin_soak.py [n] [cfg2,cfg4,cfg5,headline]   (SOAK_NO_INTERCEPT=1: fitIntercept = false -- the window without
+a conductor for the degree-2 FMs)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,6 +12,7 @@ names = sys.argv[2].split(",") if len(sys.argv) > 2 else ["cfg2", "cfg4", "cfg5"
 dev = torch.device("cuda", 0)
 ctx = nf.default_context()
 bad = 0
+FI = os.environ.get("SOAK_NO_INTERCEPT") != "1"
 for name in names:
     wl = dict(bench.WORKLOADS[name])
     wl["d"] = max(2000, wl["d"] // 20)  # twenty times the benchmark's conflict rate
@@ -22,9 +24,9 @@ for name in names:
         for win in ("0", "2"):
             os.environ["NFM_SEQ_WIN"] = win
             if wl.get("fields"):
-                fm = nf.newFieldAwareFactorizationMachine("regression", nComponents=wl["k"], randomState=1, warmStart=True)
+                fm = nf.newFieldAwareFactorizationMachine("regression", nComponents=wl["k"], fitIntercept=FI, randomState=1, warmStart=True)
             else:
-                fm = nf.newFactorizationMachine("regression", degree=wl["degree"], nComponents=wl["k"], randomState=1, warmStart=True)
+                fm = nf.newFactorizationMachine("regression", degree=wl["degree"], nComponents=wl["k"], fitIntercept=FI, randomState=1, warmStart=True)
             fm.init(X)
             mk = nf.newSGD if solver == "sgd" else nf.newAdaGrad
             opt = mk(maxIter=1, verbose=0, tol=0, shuffle=False, mode="sequential", **({"eta0": 0.002} if solver == "sgd" else {}))
