@@ -606,3 +606,83 @@ def test_sgd_touch_cap_vs_mb_oracle(cap, model, batch):
     assert opt.it == it and abs(mdl.intercept - b) < 1e-10
     assert_close(mdl.w, w, RTOL, ATOL, "w")
     assert_close(mdl.P, P, RTOL, ATOL, "P")
+
+
+@pytest.mark.parametrize("batch,cap", [(64, 1.0), (300, 16.0), (2048, 1.0)])
+def test_ffm_sparse_regime_small_batches(batch, cap):
+    """Field-aware models in the sparse regime (batch x entries / d << 1: the small batches bench.py runs BASELINE configs[3]
+    at): most features of a batch are touched by ONE sample, a few popular ones by many; empty rows, several entries per
+    field, unsorted storage order; SGD (touch cap 1 / 16) and AdaGrad, two permuted epochs, against the CPU restatement of
+    the rule (optimizer/sgd_ffm.nim:43, adagrad_ffm.nim:11-66: all nFields rows of every touched feature) at rtol 1e-9.
+    (A variant of the row phase that updated the single-touch features itself was built in round 4, passed this test bit
+    for bit against the two-phase path, measured +-0 and was not kept: DESIGN.md section 11.)"""
+    import os
+    from common import init_ffm
+    from gpu_common import gpu_ffm
+    rng = np.random.default_rng(batch)
+    n, d, F, k = 2500, 24_000, 8, 8
+    field_of = rng.integers(0, F, size=d)
+    rows, vals, indptr = [], [], [0]
+    for i in range(n):
+        m = 0 if i % 13 == 5 else int(rng.integers(1, 9))
+        p = np.full(d, 1.0)
+        p[:40] = 60.0  # a few popular features: shared by several samples of most batches (the column phase's share)
+        idx = rng.choice(d, size=m, replace=False, p=p / p.sum())
+        if i % 3:
+            idx = np.sort(idx)
+        rows.append(idx)
+        vals.append(rng.uniform(-1, 1, size=m))
+        indptr.append(indptr[-1] + m)
+    idx = np.concatenate(rows).astype(np.int64)
+    Xo = O.Dataset(np.array(indptr), idx, np.concatenate(vals), n, d, field_of[idx], F)
+    y = rng.standard_normal(n)
+    P0, w0, b0 = init_ffm(d, F, k, scale=0.05)
+    w0 = rng.standard_normal(d) * 0.01
+    perms = make_perms(n, 2)
+    X = to_gpu(Xo)
+
+    def gpu(kind, singles):
+        old = os.environ.get("NFM_SINGLES")
+        os.environ["NFM_SINGLES"] = "1" if singles else "0"
+        try:
+            ffm = gpu_ffm("regression", k, True, True, P0, w0, b0)
+            if kind == "sgd":
+                opt = nf.newSGD(maxIter=2, verbose=0, tol=0, eta0=0.01, mode="minibatch", batch=batch, touchCap=cap)
+            else:
+                opt = nf.newAdaGrad(maxIter=2, verbose=0, tol=0, mode="minibatch", batch=batch)
+            ctx = nf.default_context()
+            ctx.timing_enable(True)
+            ctx.timing_reset()
+            opt.fit(X, y, ffm, perms=perms)
+            n_col = ctx.timing_get("col_phase")[0]
+            ctx.timing_enable(False)
+            st = opt.get_state(ffm) if kind == "adagrad" else None
+            return ffm.P.copy(), ffm.w.copy(), ffm.intercept, list(opt.history), st, n_col
+        finally:
+            if old is None:
+                os.environ.pop("NFM_SINGLES", None)
+            else:
+                os.environ["NFM_SINGLES"] = old
+
+    for kind in ("sgd", "adagrad"):
+        a = gpu(kind, True)
+        P, w, b, it = P0.copy(), w0.copy(), b0, 1
+        hist = []
+        if kind == "sgd":
+            for e in range(2):
+                b, it, ls, vs = O.ffm_sgd_epoch_mb(Xo, y, P, w, b, O.sgd_cfg(eta0=0.01), batch, perm=perms[e], it=it, touch_cap=cap)
+                hist.append((vs, ls / n))
+        else:
+            cfg = O.adagrad_cfg()
+            st = O.AdaState(F, d, k, d)
+            for e in range(2):
+                b, it, ls, vs = O.ffm_adagrad_epoch_mb(Xo, y, P, w, b, cfg, batch, st, perm=perms[e], it=it)
+                hist.append((vs, ls / n))
+            b = O.ffm_adagrad_finalize(P, w, b, cfg, it, st)
+            assert_close(a[4][0], st.gsum_P, 1e-9, 1e-13, "g_sum")
+            assert_close(a[4][1], st.gnorm_P, 1e-9, 1e-16, "g_norm")
+        assert abs(a[2] - b) < 1e-11
+        assert_close(a[1], w, RTOL, ATOL, kind + " w")
+        assert_close(a[0], P, RTOL, ATOL, kind + " P")
+        assert_close([h[1] for h in a[3]], [h[1] for h in hist], 1e-10, 1e-13, kind + " loss")
+        assert_close([h[0] for h in a[3]], [h[0] for h in hist], 1e-9, 1e-12, kind + " viol")
