@@ -25,7 +25,8 @@ def means(path, counter):
             for pat, k_ in (("k_row_phase", "row_phase"), ("k_ffm_row_phase", "row_phase"), ("k_col_phase", "col_phase"), ("k_col_sparse", "col_phase"),
                             ("k_ffm_col_phase", "col_phase"), ("k_ffm_refresh", "refresh"), ("k_heavy_partial", "heavy_partial"), ("k_heavy_apply", "heavy_apply"),
                             ("k_ffm_heavy_partial", "heavy_partial"), ("k_ffm_heavy_apply", "heavy_apply"),
-                            ("k_singles", "singles"), ("k_psgd_", "psgd_step"), ("k_prox_", "psgd_step")):
+                            ("k_singles", "singles"), ("k_psgd_", "psgd_step"), ("k_prox_", "psgd_step"),
+                            ("k_fm_predict", "predict"), ("k_ffm_predict", "predict"), ("k_interleave_orders", "predict_interleave")):
                 if pat in name:
                     key = k_
                     break
@@ -43,7 +44,8 @@ def main():
     # one mini-batch = one launch of the row and of the column phase; the heavy kernels run once per batch that has
     # heavy features -- weight every family by its launches relative to the row phase
     base = max(nf.get("row_phase", 1), 1)
-    total = sum((v["FETCH_bytes_corrected"] + v["WRITE_bytes"]) * nf[k] / base for k, v in per_kernel.items())
+    # (decisionFunction's kernels are reported per launch = per pass over the shard; they are not part of a mini-batch)
+    total = sum((v["FETCH_bytes_corrected"] + v["WRITE_bytes"]) * nf[k] / base for k, v in per_kernel.items() if not k.startswith("predict"))
     out = {"workload": workload, "batch": int(batch), "per_kernel": per_kernel, "hbm_bytes_per_minibatch": total,
            "note": "FETCH_SIZE doubled (gfx950, 16 B/lane reads), WRITE_SIZE exact; separate --pmc passes"}
     path = "profiles/%s_pmc_traffic.json" % tag
