@@ -856,6 +856,8 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     if exact is not None and cpu is not None and cpu.get("value"):
         # both run the reference's sample order and give the same parameters: the like-for-like ratio
         exact["vs_cpu_port_1_thread"] = round(exact["value"] / cpu["value"], 2)
+        if exact.get("no_intercept"):  # (the CPU port's step costs the same with or without the intercept's three flops)
+            exact["no_intercept"]["vs_cpu_port_1_thread"] = round(exact["no_intercept"]["value"] / cpu["value"], 2)
     return {"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "steps": steps, "warmup": warmup,
             "value_shuffled": round(value_shuffled, 1),
             "value_shuffled_host_perm": round(value_shuffled_host, 1),
@@ -960,7 +962,8 @@ def contract_line(full):
     out["predict"] = {"value": p_["value"], "unit": p_["unit"], "roofline_frac": p_["roofline_frac"]} if p_ else None
     x_ = full.get("exact_order")
     out["exact_order"] = {"value": x_["value"], "unit": x_["unit"], "vs_cpu_port_1_thread": x_.get("vs_cpu_port_1_thread"),
-                          "bit_equal": x_.get("bit_equal"), "no_intercept": (x_.get("no_intercept") or {}).get("value")} if x_ else None
+                          "bit_equal": x_.get("bit_equal"), "no_intercept": (x_.get("no_intercept") or {}).get("value"),
+                          "no_intercept_vs_cpu_port_1_thread": (x_.get("no_intercept") or {}).get("vs_cpu_port_1_thread")} if x_ else None
     out["time_to_target"] = _t2t_compact(full.get("time_to_target"))
     d_ = full.get("dp")
     out["dp"] = {k_: d_[k_] for k_ in ("combine", "sync_period", "world", "collectives_per_step", "bytes_per_step_per_rank",
