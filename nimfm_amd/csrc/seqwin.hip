@@ -611,15 +611,19 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
     // ---- G. rows written: tell the waiters ----
     // (no conductor: the other workers' completion counters requested here ride along with this wait -- the run-ahead
     // check of the next sample then finds them in LDS instead of paying a round trip of its own)
-    unsigned cr0_ = 0u, cr1_ = 0u;
+    unsigned cr0_ = 0u, cr1_ = 0u, cr2_ = 0u, cr3_ = 0u;
     if (a.no_cond) {
       if (lane < W) cr0_ = ld_u32(a.completed + lane);
       if (kWave + lane < W) cr1_ = ld_u32(a.completed + kWave + lane);
+      if (2 * kWave + lane < W) cr2_ = ld_u32(a.completed + 2 * kWave + lane);
+      if (3 * kWave + lane < W) cr3_ = ld_u32(a.completed + 3 * kWave + lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.no_cond) {
       if (lane < W) cnt[lane] = cr0_;
       if (kWave + lane < W) cnt[kWave + lane] = cr1_;
+      if (2 * kWave + lane < W) cnt[2 * kWave + lane] = cr2_;
+      if (3 * kWave + lane < W) cnt[3 * kWave + lane] = cr3_;
     }
     if (lane == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
   }
@@ -2378,15 +2382,19 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     // ---- G. rows written: tell the far waiters ----
     // (no conductor: the other workers' completion counters requested here ride along with this wait -- the run-ahead
     // check of the next sample then finds them in LDS instead of paying a round trip of its own)
-    unsigned cr0_ = 0u, cr1_ = 0u;
+    unsigned cr0_ = 0u, cr1_ = 0u, cr2_ = 0u, cr3_ = 0u;
     if (a.no_cond) {
       if (lane < W) cr0_ = ld_u32(a.completed + lane);
       if (kWave + lane < W) cr1_ = ld_u32(a.completed + kWave + lane);
+      if (2 * kWave + lane < W) cr2_ = ld_u32(a.completed + 2 * kWave + lane);
+      if (3 * kWave + lane < W) cr3_ = ld_u32(a.completed + 3 * kWave + lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.no_cond) {
       if (lane < W) cnt[lane] = cr0_;
       if (kWave + lane < W) cnt[kWave + lane] = cr1_;
+      if (2 * kWave + lane < W) cnt[2 * kWave + lane] = cr2_;
+      if (3 * kWave + lane < W) cnt[3 * kWave + lane] = cr3_;
     }
     if (lane == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
     if (a.trace && lane == 0) a.trace[u * 8 + 4] = wall_clock64();  // rows written
@@ -2701,10 +2709,11 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   int W = no_cond ? 128 : 64;
   if (const char* env = getenv("NFM_SEQ_WIN_W")) W = atoi(env);
   int lgW = 4;
-  while ((2 << lgW) <= W && lgW < 7) ++lgW;
+  while ((2 << lgW) <= W && lgW < (no_cond ? 8 : 7)) ++lgW;
   W = 1 << lgW;
-  while (W + 1 > ctx->n_cu && lgW > 4) W = 1 << --lgW;
-  if (!(W > kWinDepth && W + 1 <= ctx->n_cu)) return NFM_WIN_FALLBACK;  // (seq_window_supported keeps such devices out)
+  const int extra = no_cond ? 0 : 1;  // the conductor's CU (without a conductor workgroup 0 leaves at once)
+  while (W + extra > ctx->n_cu && lgW > 4) W = 1 << --lgW;
+  if (!(W > kWinDepth && W + extra <= ctx->n_cu)) return NFM_WIN_FALLBACK;  // (seq_window_supported keeps such devices out)
   int lgKp = 1;
   while ((1 << lgKp) < M.Kp) ++lgKp;
   const bool ffm = M.kind == NFM_KIND_FFM;
