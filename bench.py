@@ -747,10 +747,13 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                            "the host (upload + table build inside)" %
                            (ns_, "the reference's order as a dependency window over the chip (csrc/seqwin.hip), results bit-equal to "
                             "the one-workgroup kernel" if windowed else "one workgroup (csrc/seq.hip)")}
-        if windowed and not F and wl["degree"] == 2:
+        if windowed:
             # fitIntercept = false: no scalar chain ties the samples (the intercept is what serialises the reference's order),
             # the window runs without its conductor on twice the workers -- the same order, bit-equal results
-            fm_n = nf.newFactorizationMachine(task, degree=2, nComponents=k, fitIntercept=False, warmStart=True, randomState=1)
+            if F:
+                fm_n = nf.newFieldAwareFactorizationMachine(task, nComponents=k, fitIntercept=False, warmStart=True, randomState=1)
+            else:
+                fm_n = nf.newFactorizationMachine(task, degree=wl["degree"], nComponents=k, fitIntercept=False, warmStart=True, randomState=1)
             fm_n.init(Xs)
             opt_n = mk_(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="sequential")
             opt_n._handle(fm_n, ctx, "sequential")

@@ -573,6 +573,26 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
     }
     if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
 
+    // ---- E2. a row formed from its writer's recipe must not be STORED before the writer's own store of it has landed (two
+    // stores to one address from two CUs are not ordered by anything else: with a conductor the writer's store is several
+    // microseconds ahead by construction, without one the two updates run nearly side by side -- found by the field-aware
+    // no-conductor test: one stale row in a thousand samples).  The writer bumps its counter after its stores have drained. ----
+    if (fwdmask) {
+      Spin sp;
+      bool first = true;
+      while (true) {
+        bool need = false;
+        for (int q = lane; q < m; q += kWave) {
+          const int64_t v2 = (int64_t)pl[q] - a.seg0;
+          if (v2 >= 0 && ll[q] && cnt[v2 & (W - 1)] <= (unsigned)(v2 >> lgW)) need = true;
+        }
+        if (!__any(need)) break;
+        if (!first && sp.wait(a.ctrl)) return;
+        first = false;
+        for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
+        compiler_fence();
+      }
+    }
     // ---- F. update(): sgd.nim:205-243 / updateG(): adagrad.nim:113-134 ----
     for (int qb = 0; qb < m; qb += R * U) {
 #pragma unroll
@@ -682,6 +702,7 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
   unsigned* cnt = reinterpret_cast<unsigned*>(fent + (size_t)F * mcap);  // [W] (wavefront 0's)
   if (wv == 0)
     for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
+  const double b_const = M.sc[SC_INTERCEPT];  // (no_cond: the intercept is not fitted and stays what it is)
   double loss_acc = 0.0, viol_acc = 0.0;
   const ull lt_mask = lane == 0 ? 0ull : (~0ull >> (kWave - lane));
   const int nb = F;
@@ -710,6 +731,20 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
     const ull* rp = a.res + (size_t)(slot * a.np + par) * kResWords;
     // ---- 0. the entries; which of them take the forwarding path (wavefront 0 decides for all) ----
     if (wv == 0) {
+      if (a.no_cond && u >= (int64_t)a.np * W) {  // the run-ahead bound of a window without a conductor (see win_worker)
+        const unsigned c_ = (unsigned)(u >> lgW) - (unsigned)(a.np - 2);
+        Spin sp;
+        bool first = true;
+        while (true) {
+          bool ok = true;
+          for (int l = lane; l < W; l += kWave) ok = ok && cnt[l] >= (l < slot ? c_ : c_ - 1u);
+          if (__all(ok)) break;
+          if (!first && sp.wait(a.ctrl)) break;  // (aborting: every wait below ends the same way)
+          first = false;
+          for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
+          compiler_fence();
+        }
+      }
       const bool e_in = lane < m;
       const int pq = e_in ? a.prev[q0 + lane] : -1;
       const int pqu = e_in ? (int)a.prevq[q0 + lane] : 0;
@@ -998,7 +1033,44 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
     }
     __syncthreads();
     const int MC = a.FW - kWinHdr;
-    if (wv == 0) {  // the mailbox: linear terms, then the valid pairs' terms in the order the double loop visits them
+    if (wv == 0 && a.no_cond) {
+      // no conductor: predictWithGrad's chain (sgd_ffm.nim:13-27) in this wavefront -- the constant intercept, the linear terms
+      // in storage order, then ONE term per pair j_q1 < j_q2 in the order of the reference's double loop (q1 outer, q2 inner) --
+      // dloss, and {dL, yhat} posted as the conductor would
+      double yh_ = b_const;
+      for (int eb = 0; eb < m; eb += 8) {
+        double w_[8], v_[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int e = eb + t < m ? eb + t : eb;
+          w_[t] = wl[e];
+          v_[t] = vl[e];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) yh_ = eb + t < m ? yh_ + (sw * w_[t]) * v_[t] : yh_;
+      }
+      for (int q1 = 0; q1 < m; ++q1) {
+        const int j1 = jl[q1];
+        for (int qb = 0; qb < m; qb += 8) {
+          double t_[8];
+          int j_[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const int q2 = qb + t < m ? qb + t : qb;
+            t_[t] = pc[q1 * m + q2];
+            j_[t] = jl[q2];
+          }
+#pragma unroll
+          for (int t = 0; t < 8; ++t) yh_ = (qb + t < m && j1 < j_[t]) ? yh_ + t_[t] : yh_;
+        }
+      }
+      const double dL_ = dev::loss_grad(O.loss, O.loss_param, y, yh_);
+      if (lane < kResWords) {
+        const double v = lane < 2 ? dL_ : yh_;
+        const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+        st_u64(a.res + (size_t)(slot * a.np + par) * kResWords + lane, ((ull)(unsigned)(u + 1) << 32) | (ull)half);
+      }
+    } else if (wv == 0) {  // the mailbox: linear terms, then the valid pairs' terms in the order the double loop visits them
       int n_pairs = 0;
       for (int pb = 0; pb < m * m; pb += kWave) {
         const int p = pb + lane;
@@ -1083,10 +1155,31 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
     }
     if (dead) break;  // (the launch is being aborted: every wavefront finds the abort word set)
     if (wv == 0) {
-      for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);  // (as in the general worker)
+      if (!a.no_cond)
+        for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);  // (as in the general worker)
       if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
     }
 
+    // ---- E2. rows formed from a near writer's recipe are stored only after that writer's own stores have landed (see win_worker) ----
+    if (fwdmask) {
+      if (wv == 0) {
+        Spin sp;
+        bool first = true;
+        while (true) {
+          bool need = false;
+          for (int q = lane; q < m; q += kWave) {
+            const int64_t v2 = (int64_t)pl[q] - a.seg0;
+            if (v2 >= 0 && ll[q] && cnt[v2 & (W - 1)] <= (unsigned)(v2 >> lgW)) need = true;
+          }
+          if (!__any(need)) break;
+          if (!first && sp.wait(a.ctrl)) break;  // (aborting)
+          first = false;
+          for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
+          compiler_fence();
+        }
+      }
+      __syncthreads();
+    }
     // ---- F. update() / updateG() over all slots (the shared loops of sgd.nim:205-243, adagrad.nim:113-134) ----
     for (int cb = wv * R * U; cb < nsl; cb += NW * R * U) {
 #pragma unroll
@@ -1123,7 +1216,18 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
       }
     }
     // ---- G. rows written (every wavefront's stores): tell the waiters ----
+    unsigned cr_[4] = {0u, 0u, 0u, 0u};
+    if (a.no_cond && wv == 0) {  // (the other workers' counters for the next sample's run-ahead check ride along with the drain)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t * kWave + lane < W) cr_[t] = ld_u32(a.completed + t * kWave + lane);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.no_cond && wv == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t * kWave + lane < W) cnt[t * kWave + lane] = cr_[t];
+    }
     __syncthreads();
     if (tid == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
   }
@@ -1180,6 +1284,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
   if (wv == 0)
     for (int l = lane; l < W; l += kWave) cnt[l] = 0u;
   double loss_acc = 0.0, viol_acc = 0.0;
+  const double b_const = M.sc[SC_INTERCEPT];  // (no_cond: the intercept is not fitted and stays what it is)
   const int nb = F;
   // Recipe forwarding as in the general worker, per slot: of a hot entry (its feature is asked for again within W
   // positions; among the sample's first kFxHot entries -- as many as the area holds) the writer posts, per order, the row
@@ -1208,6 +1313,20 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
     const ull* rp = a.res + (size_t)(slot * a.np + par) * kResWords;
     // ---- 0. the entries; which of them take the forwarding path (wavefront 0 decides for all) ----
     if (wv == 0) {
+      if (a.no_cond && u >= (int64_t)a.np * W) {  // the run-ahead bound of a window without a conductor (see win_worker)
+        const unsigned c_ = (unsigned)(u >> lgW) - (unsigned)(a.np - 2);
+        Spin sp;
+        bool first = true;
+        while (true) {
+          bool ok = true;
+          for (int l = lane; l < W; l += kWave) ok = ok && cnt[l] >= (l < slot ? c_ : c_ - 1u);
+          if (__all(ok)) break;
+          if (!first && sp.wait(a.ctrl)) break;  // (aborting: every wait below ends the same way)
+          first = false;
+          for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
+          compiler_fence();
+        }
+      }
       const bool e_in = lane < m;
       const int pq = e_in ? a.prev[q0 + lane] : -1;
       const int pqu = e_in ? (int)a.prevq[q0 + lane] : 0;
@@ -1441,6 +1560,9 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
     // ---- C. per order: computeAnova (sgd.nim:146-173) in every wavefront, computeAnovaDerivative (:176-188) of the
     // order's slots dealt to the wavefronts; one chain term per order behind the linear terms ----
     const int MC = a.FW - kWinHdr;
+    double ktot[DG];  // (no conductor: the orders' kernels, chain terms behind the linear ones -- wavefront 0's)
+#pragma unroll
+    for (int t = 0; t < DG; ++t) ktot[t] = 0.0;
     for (int o = 0; o < nb; ++o) {
       const int deg = M.degree - o;
       double A[DG + 1];
@@ -1527,10 +1649,39 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
           for (int t = 0; t < 8; ++t) tot = sb + t < k ? tot + r_[t] : tot;
         }
         compiler_fence();  // (red is written again by the next order)
-        if (lane == 0) st_u64(mb + m + o, mail_bits(tot));  // the order's kernel: a chain term behind the linear terms
+        if (a.no_cond) {
+#pragma unroll
+          for (int t = 0; t < DG; ++t) ktot[t] = t == o ? tot : ktot[t];
+        } else if (lane == 0) {
+          st_u64(mb + m + o, mail_bits(tot));  // the order's kernel: a chain term behind the linear terms
+        }
       }
     }
-    if (wv == 0) {
+    if (wv == 0 && a.no_cond) {
+      // predictWithGrad's chain (sgd.nim:193-201) in this wavefront: the constant intercept, the linear terms in storage order,
+      // the orders' kernels one after the other; dloss; {dL, yhat} posted as the conductor would (all wavefronts and the near
+      // successors read them from there)
+      double yh_ = b_const;
+      for (int eb = 0; eb < m; eb += 8) {
+        double w_[8], v_[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int e = eb + t < m ? eb + t : eb;
+          w_[t] = wl[e];
+          v_[t] = vl[e];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) yh_ = eb + t < m ? yh_ + (sw * w_[t]) * v_[t] : yh_;
+      }
+#pragma unroll
+      for (int t = 0; t < DG; ++t) yh_ = t < nb ? yh_ + ktot[t] : yh_;
+      const double dL_ = dev::loss_grad(O.loss, O.loss_param, y, yh_);
+      if (lane < kResWords) {
+        const double v = lane < 2 ? dL_ : yh_;
+        const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+        st_u64(a.res + (size_t)(slot * a.np + par) * kResWords + lane, ((ull)(unsigned)(u + 1) << 32) | (ull)half);
+      }
+    } else if (wv == 0) {
       const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
       for (int e = lane; e < a.FW; e += kWave) {
         double val;
@@ -1604,10 +1755,31 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
     }
     if (dead) break;  // (the launch is being aborted: every wavefront finds the abort word set)
     if (wv == 0) {
-      for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);  // (as in the general worker)
+      if (!a.no_cond)
+        for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);  // (as in the general worker)
       if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
     }
 
+    // ---- E2. rows formed from a near writer's recipe are stored only after that writer's own stores have landed (see win_worker) ----
+    if (fwdmask) {
+      if (wv == 0) {
+        Spin sp;
+        bool first = true;
+        while (true) {
+          bool need = false;
+          for (int q = lane; q < m; q += kWave) {
+            const int64_t v2 = (int64_t)pl[q] - a.seg0;
+            if (v2 >= 0 && ll[q] && cnt[v2 & (W - 1)] <= (unsigned)(v2 >> lgW)) need = true;
+          }
+          if (!__any(need)) break;
+          if (!first && sp.wait(a.ctrl)) break;  // (aborting)
+          first = false;
+          for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
+          compiler_fence();
+        }
+      }
+      __syncthreads();
+    }
     // ---- F. update() / updateG() over all slots (the shared loops of sgd.nim:205-243, adagrad.nim:113-134) ----
     for (int cb = wv * R * U; cb < nsl; cb += NW * R * U) {
 #pragma unroll
@@ -1644,7 +1816,18 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
       }
     }
     // ---- G. rows written (every wavefront's stores): tell the waiters ----
+    unsigned cr_[4] = {0u, 0u, 0u, 0u};
+    if (a.no_cond && wv == 0) {  // (the other workers' counters for the next sample's run-ahead check ride along with the drain)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t * kWave + lane < W) cr_[t] = ld_u32(a.completed + t * kWave + lane);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.no_cond && wv == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t * kWave + lane < W) cnt[t * kWave + lane] = cr_[t];
+    }
     __syncthreads();
     if (tid == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
   }
@@ -2329,6 +2512,17 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     }
     if (a.trace && lane == 0) a.trace[u * 8 + 3] = wall_clock64();  // dL received
 
+    // ---- E2. rows formed from a near writer's recipe are stored only after that writer's own stores have landed (see win_worker) ----
+    if (fwdmask) {
+      Spin sp;
+      bool first = true;
+      while (__any(near && pending())) {
+        if (!first && sp.wait(a.ctrl)) return;
+        first = false;
+        for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
+        compiler_fence();
+      }
+    }
     // ---- F. update(): sgd.nim:205-243 / updateG(): adagrad.nim:113-134 ----
     if (!ADA && odd_divisor) {
       // a divisor with an all-ones significand (one sample in 2^52): the division instruction, rows through LDS
@@ -2706,10 +2900,9 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   const bool ada = opt_kind == OPT_ADAGRAD;
   if (m_cap < 1) m_cap = 1;
   // worker count: a power of two, one workgroup per CU with one CU left for the conductor
-  const bool ffm_ = M.kind == NFM_KIND_FFM, fmx_ = !ffm_ && (M.nb != 1 || M.degree != 2);
   // fitIntercept = false (degree-2 FMs): no conductor, and nothing but the features ties the samples -- twice the workers
-  static const bool nc_on = !(getenv("NFM_SEQ_WIN_NOCOND") && atoi(getenv("NFM_SEQ_WIN_NOCOND")) == 0);
-  const bool no_cond = nc_on && !M.fit_intercept && !ffm_ && !fmx_;
+  const bool nc_on = !(getenv("NFM_SEQ_WIN_NOCOND") && atoi(getenv("NFM_SEQ_WIN_NOCOND")) == 0);  // (read per call: tests switch it)
+  const bool no_cond = nc_on && !M.fit_intercept;  // (every worker: degree-2 FMs, several orders / degree >= 3, field-aware models)
   int W = no_cond ? 128 : 64;
   if (const char* env = getenv("NFM_SEQ_WIN_W")) W = atoi(env);
   int lgW = 4;

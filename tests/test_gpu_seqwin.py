@@ -498,3 +498,98 @@ def test_aborted_window_is_put_back_and_rerun_by_the_one_workgroup_kernel(kind, 
     # and the optimizer keeps working: the next fit of the same shape goes through the window again
     win = fit(kind, 2, 16, Xo, y, "regression", k, P0, w0, b0, 1)
     same_bits(win[0], ref[0], "P after the hook is gone")
+
+
+@pytest.mark.parametrize("kind,degree,fit_lower,k,d,W", [
+    ("sgd", 3, "explicit", 8, 12, 16), ("adagrad", 3, "explicit", 8, 12, 128),   # cfg5's model, every sample waits
+    ("sgd", 4, "explicit", 4, 2000, 128), ("adagrad", 3, "none", 16, 3000, 128),  # mostly concurrent samples
+    ("sgd", 6, "explicit", 2, 60, 32),
+])
+def test_higher_degree_window_without_a_conductor(kind, degree, fit_lower, k, d, W):
+    """fitIntercept = false with several orders / degree >= 3 (win_worker_fmx): no conductor -- wavefront 0 of a worker adds up
+    the prediction (the linear terms in storage order, then the orders' kernels: predictWithGrad, sgd.nim:193-201) and posts
+    {dL, yhat} for the other wavefronts and the near successors.  Bit for bit the one-workgroup kernel, rtol 1e-8 the oracle."""
+    n = 3000 if d >= 2000 else 400
+    Xo = ragged_csr(n, d, seed=degree * 7 + k, max_m=min(d, 24))
+    rng = np.random.default_rng(degree + 11)
+    y = rng.standard_normal(Xo.n)
+    P0, w0, _, n_aug = init_fm(d, degree, k, fit_lower, True, scale=0.1)
+    b0 = 0.3  # (stays where it is)
+    perms = make_perms(Xo.n, 2)
+    kw = dict(eta0=0.02) if kind == "sgd" else {}
+
+    def run(win):
+        with env(NFM_SEQ_WIN=win, NFM_SEQ_WIN_W=W):
+            fm = nf.newFactorizationMachine("regression", degree=degree, nComponents=k, fitLower=fit_lower, fitLinear=True,
+                                            fitIntercept=False, warmStart=True)
+            fm.set_params(P0, w0, b0)
+            mk = nf.newSGD if kind == "sgd" else nf.newAdaGrad
+            opt = mk(maxIter=2, verbose=0, tol=0, shuffle=False, mode="sequential", **kw)
+            ctx = nf.default_context()
+            ctx.timing_enable(True)
+            ctx.timing_reset()
+            opt.fit(to_gpu(Xo), y, fm, perms=perms)
+            windowed = ctx.timing_get("seq_window_deps")[0] > 0
+            assert _fallbacks() == 0, "a window launch aborted"
+            ctx.timing_enable(False)
+            assert windowed == (int(win) != 0)
+            return fm.P.copy(), fm.w.copy(), fm.intercept, list(opt.history)
+
+    ref, win = run(0), run(2)
+    same_bits(win[0], ref[0], "P")
+    same_bits(win[1], ref[1], "w")
+    assert win[2] == ref[2] == b0
+    assert_close([h[1] for h in win[3]], [h[1] for h in ref[3]], 1e-12, 1e-15, "loss per epoch")
+    if kind == "adagrad":
+        Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, y, degree, P0, w0, b0, O.adagrad_cfg(fit_intercept=False), 2, 0, perms=perms)
+    else:
+        Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, degree, P0, w0, b0, O.sgd_cfg(eta0=0.02, fit_intercept=False), 2, 0, perms=perms)
+    assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
+    assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
+    assert bf == b0
+
+
+@pytest.mark.parametrize("kind,F,k,d,max_m,W", [
+    ("sgd", 3, 2, 12, 6, 16), ("adagrad", 3, 2, 12, 6, 128),          # few features: every sample waits
+    ("sgd", 16, 8, 1600, 16, 128), ("adagrad", 16, 8, 1600, 16, 128),  # cfg4's fields and factors, mostly concurrent samples
+    ("sgd", 5, 4, 400, 20, 64),                                       # 20 entries: 210 pair terms, several entries per field
+])
+def test_field_aware_window_without_a_conductor(kind, F, k, d, max_m, W):
+    """fitIntercept = false, field-aware (win_worker_ffm): wavefront 0 of a worker adds up the prediction itself -- the linear
+    terms, then one term per pair in the order of the reference's double loop (sgd_ffm.nim:13-27).  Bit for bit the
+    one-workgroup kernel, rtol 1e-8 the oracle."""
+    from common import init_ffm
+    n = 2500 if d >= 1000 else 300
+    Xo, y = _ffm_data(n, d, F, max_m, seed=F * 31 + k)
+    P0, w0, _ = init_ffm(d, F, k)
+    b0 = -0.2
+    perms = make_perms(Xo.n, 2)
+    kw = dict(eta0=0.05) if kind == "sgd" else {}
+
+    def run(win):
+        with env(NFM_SEQ_WIN=win, NFM_SEQ_WIN_W=W):
+            ffm = nf.newFieldAwareFactorizationMachine("regression", nComponents=k, fitLinear=True, fitIntercept=False, warmStart=True)
+            ffm.set_params(P0, w0, b0)
+            mk = nf.newSGD if kind == "sgd" else nf.newAdaGrad
+            opt = mk(maxIter=2, verbose=0, tol=0, shuffle=False, mode="sequential", **kw)
+            ctx = nf.default_context()
+            ctx.timing_enable(True)
+            ctx.timing_reset()
+            opt.fit(to_gpu(Xo), y, ffm, perms=perms)
+            windowed = ctx.timing_get("seq_window_deps")[0] > 0
+            assert _fallbacks() == 0, "a window launch aborted"
+            ctx.timing_enable(False)
+            assert windowed == (int(win) != 0)
+            return ffm.P.copy(), ffm.w.copy(), ffm.intercept, list(opt.history)
+
+    ref, win = run(0), run(2)
+    same_bits(win[0], ref[0], "P")
+    same_bits(win[1], ref[1], "w")
+    assert win[2] == ref[2] == b0
+    assert_close([h[1] for h in win[3]], [h[1] for h in ref[3]], 1e-12, 1e-15, "loss per epoch")
+    if kind == "adagrad":
+        Pf, wf, bf, *_ = O.ffm_adagrad_fit(Xo, y, P0, w0, b0, O.adagrad_cfg(fit_intercept=False), 2, perms=perms)
+    else:
+        Pf, wf, bf, *_ = O.ffm_sgd_fit(Xo, y, P0, w0, b0, O.sgd_cfg(eta0=0.05, fit_intercept=False), 2, perms=perms)
+    assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
+    assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
