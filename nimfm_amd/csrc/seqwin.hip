@@ -2494,6 +2494,14 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     }
 
     // ---- E. {dL, yhat} from the conductor: tagged granules (a near successor reads them too) ----
+    // E2 rides along: rows formed from a near writer's recipe are stored only after that writer's own stores have landed (see
+    // win_worker) -- the lanes with such an entry ask for their writer's completion counter in the same rounds that poll for
+    // this sample's dL, so the answer is normally there when dL is (a separate poll cost the headline shape 13 %)
+    const int64_t vnear = (int64_t)pq - a.seg0;
+    bool wdone = !near;
+    auto ask_writer = [&]() {
+      if (!wdone) wdone = ld_u32(a.completed + (vnear & (W - 1))) > (unsigned)(vnear >> lgW);
+    };
     double dL, yh;
     if (a.no_cond) {
       dL = dL_own;
@@ -2504,6 +2512,7 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       double rd;
       while (true) {
         const bool ok = fw_load(rp + (size_t)(lane & 1) * 2, mytag, rd);
+        ask_writer();
         if (__all(ok)) break;
         if (sp.wait(a.ctrl)) return;
       }
@@ -2511,16 +2520,12 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       yh = readlane_d(rd, 1);
     }
     if (a.trace && lane == 0) a.trace[u * 8 + 3] = wall_clock64();  // dL received
-
-    // ---- E2. rows formed from a near writer's recipe are stored only after that writer's own stores have landed (see win_worker) ----
     if (fwdmask) {
       Spin sp;
-      bool first = true;
-      while (__any(near && pending())) {
-        if (!first && sp.wait(a.ctrl)) return;
-        first = false;
-        for (int l = lane; l < W; l += kWave) cnt[l] = ld_u32(a.completed + l);
-        compiler_fence();
+      while (true) {
+        ask_writer();
+        if (__all(wdone)) break;
+        if (sp.wait(a.ctrl)) return;
       }
     }
     // ---- F. update(): sgd.nim:205-243 / updateG(): adagrad.nim:113-134 ----
