@@ -78,3 +78,24 @@ def test_last_8000_bytes_of_stdout_parse(tmp_path):
     detail = json.load(open(os.path.join(str(tmp_path), "gpurun_out", "bench_detail.json")))
     assert detail["extra"]["cfg4"]["time_to_target"]["best_batch"] == 2048  # nothing is lost: the detail keeps everything
     assert len(r.stderr) > 20000
+
+
+def test_contract_line_of_a_multi_gpu_run():
+    """N > 1: the line carries the exchange's statistics (and the quoted progress per epoch), extra holds configs[2] only"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    full = canned()
+    full["n_gpus"] = 8
+    full["cpu_baseline"] = None
+    full["exact_order"] = None
+    full["time_to_target"] = None
+    full["dp"] = {"combine": "mean", "sync_period": 128, "world": 8, "collectives_per_step": 10.0, "bytes_per_step_per_rank": 5200000640.0,
+                  "note": "n" * 300, "progress_per_epoch": 1.12, "progress_source": "profiles/r03_dp_convergence.txt"}
+    full["extra"] = {"cfg3": full["extra"]["cfg3"]}
+    line = bench.contract_line(full)
+    assert len(line) < 6000
+    out = json.loads(line)
+    assert out["n_gpus"] == 8 and out["dp"]["world"] == 8 and out["dp"]["progress_per_epoch"] == 1.12 and "note" not in out["dp"]
+    assert out["cpu_baseline"] is None and out["exact_order"] is None and list(out["extra"]) == ["cfg3"]
+    assert out["roofline"]["frac"] == full["roofline"]["frac"]
