@@ -646,27 +646,32 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     # stream beside the current epoch.  value_shuffled_host_perm: the host hands over a permutation per epoch, as the
     # Nim host does after its own shuffle (upload + validation + plan build + un-graphed launches all counted; drawing
     # the permutation is the host's job and is not). ----
-    ks = max(2, min(5, steps))
-    capi.check(capi.lib().nfm_opt_set_shuffle(opt._h, 12345 + rank))
-    step()  # warm-up: the first plan is built in line, the second one already beside this epoch
-    dts, _ = timed(ks)
-    value_shuffled = n * world / (dts / ks)
-    capi.check(capi.lib().nfm_opt_set_shuffle(opt._h, -1))
-    kh = max(1, min(3, steps))
-    perms = [np.random.default_rng(7 + rank * 131 + e).permutation(n).astype(np.int64) for e in range(kh + 1)]
-    step(perms[kh])  # warm-up of the un-cached path (allocator pools sized)
-    _step_plain = step
+    value_shuffled = value_shuffled_host = float("nan")
+    ks = kh = 0
+    if args.no_shuffled:  # profiling runs: the shuffled epochs build plans beside the epoch and would mix into the per-kernel averages
+        pass
+    else:
+        ks = max(2, min(5, steps))
+        capi.check(capi.lib().nfm_opt_set_shuffle(opt._h, 12345 + rank))
+        step()  # warm-up: the first plan is built in line, the second one already beside this epoch
+        dts, _ = timed(ks)
+        value_shuffled = n * world / (dts / ks)
+        capi.check(capi.lib().nfm_opt_set_shuffle(opt._h, -1))
+        kh = max(1, min(3, steps))
+        perms = [np.random.default_rng(7 + rank * 131 + e).permutation(n).astype(np.int64) for e in range(kh + 1)]
+        step(perms[kh])  # warm-up of the un-cached path (allocator pools sized)
+        _step_plain = step
 
-    def step(perm=None, _seq=perms):  # noqa: F811 -- announces the next epoch's permutation, as the host loops do
-        k_ = next(i for i, p_ in enumerate(_seq) if p_ is perm)
-        if k_ + 1 < kh:
-            capi.check(capi.lib().nfm_opt_announce_perm(opt._h, _seq[k_ + 1].ctypes.data, 0, n))
-        return _step_plain(perm)
+        def step(perm=None, _seq=perms):  # noqa: F811 -- announces the next epoch's permutation, as the host loops do
+            k_ = next(i for i, p_ in enumerate(_seq) if p_ is perm)
+            if k_ + 1 < kh:
+                capi.check(capi.lib().nfm_opt_announce_perm(opt._h, _seq[k_ + 1].ctypes.data, 0, n))
+            return _step_plain(perm)
 
-    dth, _ = timed(kh, perms)
-    step = _step_plain
-    value_shuffled_host = n * world / (dth / kh)
-    del perms
+        dth, _ = timed(kh, perms)
+        step = _step_plain
+        value_shuffled_host = n * world / (dth / kh)
+        del perms
 
     # ---- predict samples/s (the metric's second half): decisionFunction over the shard, output on device ----
     pred = None
@@ -862,8 +867,8 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         if exact.get("no_intercept"):  # (the CPU port's step costs the same with or without the intercept's three flops)
             exact["no_intercept"]["vs_cpu_port_1_thread"] = round(exact["no_intercept"]["value"] / cpu["value"], 2)
     return {"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "steps": steps, "warmup": warmup,
-            "value_shuffled": round(value_shuffled, 1),
-            "value_shuffled_host_perm": round(value_shuffled_host, 1),
+            "value_shuffled": None if math.isnan(value_shuffled) else round(value_shuffled, 1),
+            "value_shuffled_host_perm": None if math.isnan(value_shuffled_host) else round(value_shuffled_host, 1),
             "shuffled_note": "%d epochs, each over a fresh random order drawn on the device, the next epoch's batch plan built on "
                              "a second stream beside the current epoch; host_perm: %d epochs, each with a permutation handed "
                              "over by the host (upload, validation, plan build, un-graphed launches all in the timed region)"
@@ -1009,6 +1014,7 @@ def main():
     ap.add_argument("--n", "--samples", dest="n", type=int, default=0, help="override samples per GPU (--samples under torchrun, whose parser claims --n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra.cfg2 ... extra.cfg5 legs of the default (headline) run")
+    ap.add_argument("--no-shuffled", action="store_true", help="skip the shuffled-epoch legs (profiling runs: their plan builds beside the epochs would mix into the per-kernel averages)")
     ap.add_argument("--no-t2t", action="store_true", help="skip the time_to_target leg (profiling runs: its other batch sizes would mix into the per-kernel averages)")
     ap.add_argument("--no-viol", action="store_true",
                     help="AdaGrad without the reference's viol = sum|P_old - P_new| (no stored copy of P is read or "

@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o ${TAG} -- python3 $ROOT/bench.py --workload $WL --batch $B --no-cpu-baseline --no-extra --no-t2t "$@" > $OUT/${TAG}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o ${TAG} -- python3 $ROOT/bench.py --workload $WL --batch $B --no-cpu-baseline --no-extra --no-t2t --no-shuffled "$@" > $OUT/${TAG}_prof.log 2>&1
 cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o f -- python3 $ROOT/bench.py --workload $WL --batch $B --no-cpu-baseline --no-extra --no-t2t --steps 2 --warmup 1 "$@" > $OUT/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o w -- python3 $ROOT/bench.py --workload $WL --batch $B --no-cpu-baseline --no-extra --no-t2t --steps 2 --warmup 1 "$@" > $OUT/${TAG}_pmc_write.log 2>&1
