@@ -1051,7 +1051,8 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       const char* win_env = getenv("NFM_SEQ_WIN");
       const bool snap_pays = (win_env && atoi(win_env) == 2) || (double)ns * 0.8e-6 * 0.25 >= (double)snap_bytes / 2.0e12;
       bool windowed = false;
-      if (snap_pays && seq_window_supported(M, ds->max_row + m->n_aug, ns, ds->v.nnz, ctx->n_cu)) {
+      const bool win_trusted = !o->seqwin || o->seqwin->fallbacks < 2;  // two aborted launches: CUs are being held -- no more 4 s waits
+      if (snap_pays && win_trusted && seq_window_supported(M, ds->max_row + m->n_aug, ns, ds->v.nnz, ctx->n_cu)) {
         if (!o->seqwin) o->seqwin.reset(new SeqWin());
         SeqWin* sw = o->seqwin.get();
         NFM_TRY(sw->snap.ensure(snap_bytes));

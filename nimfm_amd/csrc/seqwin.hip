@@ -2909,6 +2909,11 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   const bool nc_on = !(getenv("NFM_SEQ_WIN_NOCOND") && atoi(getenv("NFM_SEQ_WIN_NOCOND")) == 0);  // (read per call: tests switch it)
   const bool no_cond = nc_on && !M.fit_intercept;  // (every worker: degree-2 FMs, several orders / degree >= 3, field-aware models)
   int W = no_cond ? 128 : 64;
+  // rows of 64 factors without a conductor: a worker on EVERY CU (headline shape 5.8e6 -> 7.1e6 samples/s, AdaGrad 3.8e6 -> 5.9e6;
+  // shorter rows conflict too often to gain) -- until a launch of this optimizer has aborted once: such a launch needs the
+  // whole chip resident, and a tenant that holds a single CU would cost every call its 4 s limit.  (After a second abort
+  // nfm_opt_epoch stops offering the window to this optimizer at all.)
+  if (no_cond && M.kind == NFM_KIND_FM && M.nb == 1 && M.degree == 2 && M.Kp == kWave && m_cap <= kWave && sw->fallbacks == 0) W = 256;
   if (const char* env = getenv("NFM_SEQ_WIN_W")) W = atoi(env);
   int lgW = 4;
   while ((2 << lgW) <= W && lgW < (no_cond ? 8 : 7)) ++lgW;

@@ -417,7 +417,7 @@ def test_k64_worker_at_the_headline_row_shape(kind, d, fit_intercept):
     adagrad.nim:169-184) at rtol 1e-8.  fit_intercept = False: the window without a conductor (128 workers, each adds up
     its own sample's prediction: no scalar chain ties the samples, only their features do)."""
     n, m, k = 20_000, 64, 64
-    fl = dict(fit_intercept=fit_intercept, W=64 if fit_intercept else 128)
+    fl = dict(fit_intercept=fit_intercept, W=64 if fit_intercept else (256 if d > 2_000 else 128))  # (256: a worker on every CU)
     Xo = _distinct_rows(n, d, m, seed=d + 1)
     rng = np.random.default_rng(d)
     y = np.sign(rng.standard_normal(n))
