@@ -2884,6 +2884,7 @@ static int launch_window_t(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes) {
   int per_cu = 0;
   NFM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds_bytes));
   if (per_cu < 1) return NFM_WIN_FALLBACK;
+  ctx->timing.acc["seq_window_launch"].launches += 1;  // (counted with timing on or off: the tests ask which kernel ran)
   TimedLaunch tl(ctx, "sequential");
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.W + 1)), dim3(threads), lds_bytes, ctx->stream, a);
   NFM_HIP_CHECK(hipGetLastError());

@@ -593,3 +593,42 @@ def test_field_aware_window_without_a_conductor(kind, F, k, d, max_m, W):
         Pf, wf, bf, *_ = O.ffm_sgd_fit(Xo, y, P0, w0, b0, O.sgd_cfg(eta0=0.05, fit_intercept=False), 2, perms=perms)
     assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
     assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
+
+
+def test_an_optimizer_stops_asking_for_the_window_after_two_aborted_launches():
+    """A launch that cannot finish costs its 4 s limit.  One abort: the next launch of that optimizer uses 128 workers instead
+    of a worker on every CU; two: the optimizer is no longer offered the window (nfm_opt_epoch, SeqWin::fallbacks) -- a tenant
+    holding CUs must not cost every call 4 s.  Results stay those of the one-workgroup kernel throughout."""
+    n, d, k = 600, 300, 64
+    Xo = random_csr(n, d, 8, seed=91)
+    y = np.random.default_rng(92).standard_normal(n)
+    rng = np.random.default_rng(93)
+    P0, w0, b0 = rng.standard_normal((1, k, d)) * 0.05, rng.standard_normal(d) * 0.01, 0.1
+    X = to_gpu(Xo)
+    ctx = nf.default_context()
+
+    def three_fits(win, dead):
+        with env(NFM_SEQ_WIN=win):
+            os.environ.pop("NFM_SEQ_WIN_W", None)
+            fm = nf.newFactorizationMachine("regression", nComponents=k, fitIntercept=False, warmStart=True)
+            fm.set_params(P0, w0, b0)
+            opt = nf.newSGD(maxIter=1, verbose=0, tol=0, shuffle=False, mode="sequential")
+            seen = []
+            for r in range(3):
+                ctx.timing_enable(True)
+                ctx.timing_reset()
+                if dead and r < 2:
+                    with env(NFM_SEQ_WIN_TEST_DEAD_SLOT=5):
+                        opt.fit(X, y, fm)
+                else:
+                    opt.fit(X, y, fm)
+                seen.append((ctx.timing_get("seq_window_launch")[0], _fallbacks()))
+                ctx.timing_enable(False)
+            return fm.P.copy(), fm.w.copy(), seen
+
+    ref = three_fits(0, False)
+    got = three_fits(2, True)
+    same_bits(got[0], ref[0], "P")
+    same_bits(got[1], ref[1], "w")
+    assert [s_[1] for s_ in got[2]] == [1, 1, 0], got[2]  # (the counter is reset per fit here: one fallback each in fits 1 and 2)
+    assert got[2][0][0] > 0 and got[2][1][0] > 0 and got[2][2][0] == 0, "the third fit must not have tried the window"
