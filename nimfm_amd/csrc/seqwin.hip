@@ -2944,7 +2944,11 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     sw->end = end;
     sw->nnz = X.nnz;
   }
-  const int np = no_cond ? 4 : 2;  // without a conductor the workers may run further apart (see the workers' run-ahead check)
+  int np = no_cond ? 4 : 2;  // without a conductor the workers may run further apart (see the workers' run-ahead check)
+  if (const char* env = getenv("NFM_SEQ_WIN_NP")) {  // tuning: 2, 4 or 8 buffer sets per worker
+    const int v = atoi(env);
+    if (no_cond && (v == 2 || v == 4 || v == 8)) np = v;
+  }
   const size_t n_fwd = (size_t)W * np * FW, n_res = (size_t)W * np * kResWords;
   NFM_TRY(sw->mail.ensure(sizeof(ull) * (n_fwd + n_res)));
   NFM_TRY(sw->ctl.ensure(sizeof(unsigned) * (W + 64) + sizeof(double) * 2 * (W + 1) + sizeof(int64_t) * 2));
