@@ -84,6 +84,9 @@ struct WinArgs {
   unsigned* ctrl;         // [0]: abort
   double* partial;        // [W + 1][2] {loss, viol} per worker, last: the conductor's
   int W, lgW, m_cap, FW, lgKp;  // FW = MC + kWinHdr words per mailbox, MC = m_cap rounded up to the chain's chunk
+  int near_r;             // a dependency on a sample fewer than near_r positions back takes the recipe path (W with a conductor)
+  int thr;                // without a conductor: before sample u every sample below u - thr W is complete (thr W + near_r <= np W:
+                          // a worker's buffer set is reused np W positions later, and only readers within near_r look at it)
   int np;                 // mailboxes / answer words / forwarding areas per worker (a power of two): sample u of a worker uses
                           // number (u / W) mod np, i.e. they are reused np samples of that worker later
   int no_cond;            // 1: fitIntercept = false -- no scalar chain ties the samples, there is NO conductor: a worker adds up its
@@ -202,13 +205,13 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
     const int par = (int)((u >> lgW) & (a.np - 1));
     ull* mb = a.fwd + (size_t)(slot * a.np + par) * a.FW;
     const ull* rp = a.res + (size_t)(slot * a.np + par) * kResWords;
-    if (a.no_cond && u >= (int64_t)a.np * W) {
+    if (a.no_cond && u >= (int64_t)a.thr * W) {
       // No conductor walks the samples in order, so nothing else keeps a fast worker from running ahead: its forwarding
       // area and answer words of sample u - np W are about to be reused, and a near successor of that sample (a position
       // below u - (np - 1) W) may not have read them yet.  Every sample below that must be complete: the workers before
       // this one have finished c - (np - 2) samples, the others one fewer (c = this worker's count) -- the window spans
       // at most np W positions.
-      const unsigned c_ = (unsigned)(u >> lgW) - (unsigned)(a.np - 2);
+      const unsigned c_ = (unsigned)(u >> lgW) - (unsigned)(a.thr - 1);
       Spin sp;
       bool first = true;
       while (true) {
@@ -232,10 +235,10 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       const bool pend = v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW);
       // a NEAR previous sample (fewer than W positions back, the shared feature among ITS first 64 entries) left the recipe
       // of the shared row in its forwarding area; every other one is waited for by its counter
-      near = pend && (pos - (int64_t)pq) < W && pqu < kWave;
+      near = pend && (pos - (int64_t)pq) < a.near_r && pqu < kWave;
     }
     const ull fwdmask = __ballot(near);
-    const ull hotmask = __ballot(nq >= 0 && ((int64_t)nq - pos) < W);  // rows a near successor will ask the recipe of
+    const ull hotmask = __ballot(nq >= 0 && ((int64_t)nq - pos) < a.near_r);  // rows a near successor will ask the recipe of
     for (int q = lane; q < mc; q += kWave) {
       const bool in = q < m;
       jl[q] = in ? X.indices[q0 + q] : 0;
@@ -731,8 +734,8 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
     const ull* rp = a.res + (size_t)(slot * a.np + par) * kResWords;
     // ---- 0. the entries; which of them take the forwarding path (wavefront 0 decides for all) ----
     if (wv == 0) {
-      if (a.no_cond && u >= (int64_t)a.np * W) {  // the run-ahead bound of a window without a conductor (see win_worker)
-        const unsigned c_ = (unsigned)(u >> lgW) - (unsigned)(a.np - 2);
+      if (a.no_cond && u >= (int64_t)a.thr * W) {  // the run-ahead bound of a window without a conductor (see win_worker)
+        const unsigned c_ = (unsigned)(u >> lgW) - (unsigned)(a.thr - 1);
         Spin sp;
         bool first = true;
         while (true) {
@@ -751,8 +754,8 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
       const int nq = e_in ? a.next[q0 + lane] : -1;
       const int64_t v = (int64_t)pq - a.seg0;
       const bool pend = v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW);
-      const bool near = fwd_on && pend && (pos - (int64_t)pq) < W && pqu < kFxHot;
-      const ull fm_ = __ballot(near), hm_ = __ballot(fwd_on && lane < kFxHot && nq >= 0 && ((int64_t)nq - pos) < W);
+      const bool near = fwd_on && pend && (pos - (int64_t)pq) < a.near_r && pqu < kFxHot;
+      const ull fm_ = __ballot(near), hm_ = __ballot(fwd_on && lane < kFxHot && nq >= 0 && ((int64_t)nq - pos) < a.near_r);
       if (lane == 0) {
         mk_l[0] = fm_;
         mk_l[1] = hm_;
@@ -1313,8 +1316,8 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
     const ull* rp = a.res + (size_t)(slot * a.np + par) * kResWords;
     // ---- 0. the entries; which of them take the forwarding path (wavefront 0 decides for all) ----
     if (wv == 0) {
-      if (a.no_cond && u >= (int64_t)a.np * W) {  // the run-ahead bound of a window without a conductor (see win_worker)
-        const unsigned c_ = (unsigned)(u >> lgW) - (unsigned)(a.np - 2);
+      if (a.no_cond && u >= (int64_t)a.thr * W) {  // the run-ahead bound of a window without a conductor (see win_worker)
+        const unsigned c_ = (unsigned)(u >> lgW) - (unsigned)(a.thr - 1);
         Spin sp;
         bool first = true;
         while (true) {
@@ -1333,8 +1336,8 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
       const int nq = e_in ? a.next[q0 + lane] : -1;
       const int64_t v = (int64_t)pq - a.seg0;
       const bool pend = v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW);
-      const bool near = fwd_on && pend && (pos - (int64_t)pq) < W && pqu < kFxHot;
-      const ull fm_ = __ballot(near), hm_ = __ballot(fwd_on && lane < kFxHot && nq >= 0 && ((int64_t)nq - pos) < W);
+      const bool near = fwd_on && pend && (pos - (int64_t)pq) < a.near_r && pqu < kFxHot;
+      const ull fm_ = __ballot(near), hm_ = __ballot(fwd_on && lane < kFxHot && nq >= 0 && ((int64_t)nq - pos) < a.near_r);
       if (lane == 0) {
         mk_l[0] = fm_;
         mk_l[1] = hm_;
@@ -2136,13 +2139,13 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     const double itf = (double)it;
     const int par = (int)((u >> lgW) & (a.np - 1));
     ull* mb = a.fwd + (size_t)(slot * a.np + par) * a.FW;
-    if (a.no_cond && u >= (int64_t)a.np * W) {
+    if (a.no_cond && u >= (int64_t)a.thr * W) {
       // No conductor walks the samples in order, so nothing else keeps a fast worker from running ahead: its forwarding
       // area and answer words of sample u - np W are about to be reused, and a near successor of that sample (a position
       // below u - (np - 1) W) may not have read them yet.  Every sample below that must be complete: the workers before
       // this one have finished c - (np - 2) samples, the others one fewer (c = this worker's count) -- the window spans
       // at most np W positions.
-      const unsigned c_ = (unsigned)(u >> lgW) - (unsigned)(a.np - 2);
+      const unsigned c_ = (unsigned)(u >> lgW) - (unsigned)(a.thr - 1);
       Spin sp;
       bool first = true;
       while (true) {
@@ -2178,12 +2181,12 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     compiler_fence();
     // entries whose previous sample is not known to be finished: a NEAR one (fewer than W positions back) left the recipe
     // of the shared row in its forwarding area; a far one is waited for by its counter
-    const bool pend = pending(), near = pend && (pos - (int64_t)pq) < W;
+    const bool pend = pending(), near = pend && (pos - (int64_t)pq) < a.near_r;
     const ull fwdmask = __ballot(near), farmask = __ballot(pend && !near), latemask = fwdmask | farmask;
     if (a.trace && lane == 0) a.trace[u * 8 + 0] = wall_clock64();  // sample taken up
     const bool late = (latemask >> lane) & 1ull;
     // the next sample with one of this sample's features within W positions will ask for that row's recipe
-    const ull hotmask = __ballot(nq >= 0 && ((int64_t)nq - pos) < W);
+    const ull hotmask = __ballot(nq >= 0 && ((int64_t)nq - pos) < a.near_r);
     // step sizes first: nothing below waits for them
     const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
     double eta_w = 0.0, eta_P = 0.0, sPn = 1.0, swn = 1.0;
@@ -2981,6 +2984,19 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   a.lgW = lgW;
   a.no_cond = no_cond ? 1 : 0;
   a.np = np;
+  // without a conductor: how far back a dependency may lie and still take the recipe path, and how far apart the workers may run
+  int thr = np - 1, near_r = W;
+  if (no_cond) {
+    // (measured, headline shape at 256 workers / cfg2's at 128: np 4, thr 3 -- recipes for dependencies up to W back -- 7.3e6 /
+    // 5.5e6 samples/s; recipes up to 2W or 4W back (np 4 thr 2, np 8 thr 4) 7.1e6 / 5.2e6: the longer reach only adds recipe stores)
+    if (const char* env = getenv("NFM_SEQ_WIN_THR")) {
+      const int v = atoi(env);
+      if (v >= 1 && v < np) thr = v;
+    }
+    near_r = (np - thr) * W;
+  }
+  a.thr = thr;
+  a.near_r = near_r;
   a.dead_slot = -1;
   if (const char* env = getenv("NFM_SEQ_WIN_TEST_DEAD_SLOT")) a.dead_slot = atoi(env);  // test hook, see WinArgs
   a.m_cap = m_cap;
