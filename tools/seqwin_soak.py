@@ -32,8 +32,9 @@ for name in names:
             opt = mk(maxIter=1, verbose=0, tol=0, shuffle=False, mode="sequential", **({"eta0": 0.002} if solver == "sgd" else {}))
             opt._handle(fm, ctx, "sequential")
             t0 = time.perf_counter()
-            for _ in range(2):
-                opt._epoch(X, None, 0, n)
+            for ep_ in range(2):
+                perm_ = np.random.default_rng(100 + ep_).permutation(n).astype(np.int64) if os.environ.get("SOAK_PERM") == "1" else None
+                opt._epoch(X, perm_, 0, n)  # (SOAK_PERM=1: a fresh order per epoch, as the reference's shuffle = true)
                 opt.it += n
             ctx.synchronize()
             dt = time.perf_counter() - t0
