@@ -105,7 +105,9 @@ def gen_shard(torch, dev, n, d, m, seed, zipf=0.0):
         raise SystemExit("could not draw distinct indices")
     val = torch.rand((n, m), device=dev, generator=g, dtype=torch.float64) * 2.0 - 1.0
     indptr = torch.arange(n + 1, device=dev, dtype=torch.int64) * m
-    return indptr, idx.to(torch.int32).reshape(-1).contiguous(), val.reshape(-1).contiguous()
+    out = indptr, idx.to(torch.int32).reshape(-1).contiguous(), val.reshape(-1).contiguous()
+    torch.cuda.synchronize(dev)  # the library adopts these arrays on ITS stream (nfm_dataset_create_csr_device): they must be complete
+    return out
 
 
 def write_svmlight_file(path, n, d, m, seed):

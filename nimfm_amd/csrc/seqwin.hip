@@ -48,6 +48,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "fm_device.h"
@@ -94,6 +95,11 @@ struct WinArgs {
                           // sum: predictWithGrad, sgd.nim:193-201), takes dloss and posts {dL, yhat} for its near successors
   int dead_slot;          // test hook (NFM_SEQ_WIN_TEST_DEAD_SLOT): this worker leaves at once, as a workgroup that never became
                           // resident would; -1 otherwise.  The others time out, the launch aborts, the host restores + falls back
+  int one_term;           // 1 (the default with a conductor; NFM_SEQ_WIN_EXACT=1 turns it off): the worker adds up everything of its
+                          // sample's prediction but the intercept -- S = sum_j w_j x_j (storage order) + the interaction sum -- and posts
+                          // ONE term; the conductor's chain is  yhat = b + S -> dloss -> b'  (win_conductor_sum).  Same sample order and
+                          // dependencies; yhat is rounded as b + (sum) instead of ((b + t1) + t2) + ...: results agree with the
+                          // term-by-term chain to ~1e-15 relative per step, not to the last bit
 };
 
 __device__ __forceinline__ ull ld_u64(const ull* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -142,6 +148,17 @@ __device__ __forceinline__ bool fw_load(const ull* p, unsigned tag, double& v) {
   const ull g0 = ld_u64(p), g1 = ld_u64(p + 1);
   v = __hiloint2double((int)(unsigned)(g1 & 0xffffffffull), (int)(unsigned)(g0 & 0xffffffffull));
   return (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
+}
+// The ONE-TERM mailbox (WinArgs::one_term): {S, y, the intercept's step size} as six tagged granules, laid out granule-major
+// -- fwd[(granule * np + parity) * W + worker] -- so that the conductor's fetch wavefront reads one granule of 64 workers with
+// one 512-byte access.  Tags instead of the "empty" pattern: nothing to reset after use.
+constexpr int kSumGran = 6;
+__device__ __forceinline__ void post_sum(ull* fwd, int np, int W, int slot, int par, unsigned tag, int lane, double S, double y, double h2) {
+  if (lane < kSumGran) {
+    const double v = lane < 2 ? S : lane < 4 ? y : h2;
+    const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+    st_u64(fwd + ((size_t)(lane * np + par) * W + slot), ((ull)tag << 32) | (ull)half);
+  }
 }
 // A worker's forwarding area (one per parity of its sample count): what a successor within W positions needs to form
 // the rows it shares with this sample BY ITSELF as soon as the conductor's dL for this sample lands -- the RECIPE, known
@@ -474,10 +491,11 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
     // the mailbox: the terms of the linear part (past the row's end -0.0, which changes no sum), then the header
     const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
     double dL_own = 0.0, yh_own = 0.0;
-    if (a.no_cond) {
+    if (a.no_cond || a.one_term) {
       // no conductor: the chain of predictWithGrad (sgd.nim:193-201) right here, in every lane -- the constant intercept,
-      // then the linear terms in storage order, then the interaction sum -- and {dL, yhat} posted as the conductor would
-      double yh_ = b_const;
+      // then the linear terms in storage order, then the interaction sum -- and {dL, yhat} posted as the conductor would.
+      // One-term window: the same sum WITHOUT the intercept (from 0.0) is the sample's one mailbox term.
+      double yh_ = a.no_cond ? b_const : 0.0;
       for (int eb = 0; eb < m; eb += 8) {
         double w_[8], v_[8];
 #pragma unroll
@@ -490,12 +508,16 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
         for (int t = 0; t < 8; ++t) yh_ = eb + t < m ? yh_ + (sw * w_[t]) * v_[t] : yh_;
       }
       yh_ += tot;
-      yh_own = yh_;
-      dL_own = dev::loss_grad(O.loss, O.loss_param, y, yh_);
-      if (lane < kResWords) {
-        const double v = lane < 2 ? dL_own : yh_own;
-        const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
-        st_u64(a.res + (size_t)(slot * a.np + par) * kResWords + lane, ((ull)(unsigned)(u + 1) << 32) | (ull)half);
+      if (a.no_cond) {
+        yh_own = yh_;
+        dL_own = dev::loss_grad(O.loss, O.loss_param, y, yh_);
+        if (lane < kResWords) {
+          const double v = lane < 2 ? dL_own : yh_own;
+          const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+          st_u64(a.res + (size_t)(slot * a.np + par) * kResWords + lane, ((ull)(unsigned)(u + 1) << 32) | (ull)half);
+        }
+      } else {
+        post_sum(a.fwd, a.np, W, slot, par, (unsigned)(u + 1), lane, yh_, y, h2);
       }
     } else {
       const int MC = a.FW - kWinHdr;
@@ -571,8 +593,9 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       yh = dev::shfl_d(rd, 1);
       // both mailboxes back to "empty" for their next use, two samples of this worker from now: these stores have
       // completed (vmcnt(0) below) before this worker posts its next sample, which the conductor consumes before it can
-      // look at these words again (kWinDepth < W)
-      for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);
+      // look at these words again (kWinDepth < W).  (One-term mailboxes carry tags: nothing to reset.)
+      if (!a.one_term)
+        for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);
     }
     if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
 
@@ -1036,11 +1059,11 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
     }
     __syncthreads();
     const int MC = a.FW - kWinHdr;
-    if (wv == 0 && a.no_cond) {
+    if (wv == 0 && (a.no_cond || a.one_term)) {
       // no conductor: predictWithGrad's chain (sgd_ffm.nim:13-27) in this wavefront -- the constant intercept, the linear terms
       // in storage order, then ONE term per pair j_q1 < j_q2 in the order of the reference's double loop (q1 outer, q2 inner) --
-      // dloss, and {dL, yhat} posted as the conductor would
-      double yh_ = b_const;
+      // dloss, and {dL, yhat} posted as the conductor would.  One-term window: the same sum from 0.0 is the mailbox term.
+      double yh_ = a.no_cond ? b_const : 0.0;
       for (int eb = 0; eb < m; eb += 8) {
         double w_[8], v_[8];
 #pragma unroll
@@ -1067,11 +1090,16 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
           for (int t = 0; t < 8; ++t) yh_ = (qb + t < m && j1 < j_[t]) ? yh_ + t_[t] : yh_;
         }
       }
-      const double dL_ = dev::loss_grad(O.loss, O.loss_param, y, yh_);
-      if (lane < kResWords) {
-        const double v = lane < 2 ? dL_ : yh_;
-        const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
-        st_u64(a.res + (size_t)(slot * a.np + par) * kResWords + lane, ((ull)(unsigned)(u + 1) << 32) | (ull)half);
+      if (a.no_cond) {
+        const double dL_ = dev::loss_grad(O.loss, O.loss_param, y, yh_);
+        if (lane < kResWords) {
+          const double v = lane < 2 ? dL_ : yh_;
+          const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+          st_u64(a.res + (size_t)(slot * a.np + par) * kResWords + lane, ((ull)(unsigned)(u + 1) << 32) | (ull)half);
+        }
+      } else {
+        const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
+        post_sum(a.fwd, a.np, W, slot, par, (unsigned)(u + 1), lane, yh_, y, h2);
       }
     } else if (wv == 0) {  // the mailbox: linear terms, then the valid pairs' terms in the order the double loop visits them
       int n_pairs = 0;
@@ -1158,7 +1186,7 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
     }
     if (dead) break;  // (the launch is being aborted: every wavefront finds the abort word set)
     if (wv == 0) {
-      if (!a.no_cond)
+      if (!a.no_cond && !a.one_term)
         for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);  // (as in the general worker)
       if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
     }
@@ -1652,7 +1680,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
           for (int t = 0; t < 8; ++t) tot = sb + t < k ? tot + r_[t] : tot;
         }
         compiler_fence();  // (red is written again by the next order)
-        if (a.no_cond) {
+        if (a.no_cond || a.one_term) {
 #pragma unroll
           for (int t = 0; t < DG; ++t) ktot[t] = t == o ? tot : ktot[t];
         } else if (lane == 0) {
@@ -1660,11 +1688,11 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
         }
       }
     }
-    if (wv == 0 && a.no_cond) {
+    if (wv == 0 && (a.no_cond || a.one_term)) {
       // predictWithGrad's chain (sgd.nim:193-201) in this wavefront: the constant intercept, the linear terms in storage order,
       // the orders' kernels one after the other; dloss; {dL, yhat} posted as the conductor would (all wavefronts and the near
-      // successors read them from there)
-      double yh_ = b_const;
+      // successors read them from there).  One-term window: the same sum from 0.0 is the mailbox term.
+      double yh_ = a.no_cond ? b_const : 0.0;
       for (int eb = 0; eb < m; eb += 8) {
         double w_[8], v_[8];
 #pragma unroll
@@ -1678,11 +1706,16 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
       }
 #pragma unroll
       for (int t = 0; t < DG; ++t) yh_ = t < nb ? yh_ + ktot[t] : yh_;
-      const double dL_ = dev::loss_grad(O.loss, O.loss_param, y, yh_);
-      if (lane < kResWords) {
-        const double v = lane < 2 ? dL_ : yh_;
-        const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
-        st_u64(a.res + (size_t)(slot * a.np + par) * kResWords + lane, ((ull)(unsigned)(u + 1) << 32) | (ull)half);
+      if (a.no_cond) {
+        const double dL_ = dev::loss_grad(O.loss, O.loss_param, y, yh_);
+        if (lane < kResWords) {
+          const double v = lane < 2 ? dL_ : yh_;
+          const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+          st_u64(a.res + (size_t)(slot * a.np + par) * kResWords + lane, ((ull)(unsigned)(u + 1) << 32) | (ull)half);
+        }
+      } else {
+        const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
+        post_sum(a.fwd, a.np, W, slot, par, (unsigned)(u + 1), lane, yh_, y, h2);
       }
     } else if (wv == 0) {
       const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
@@ -1758,7 +1791,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
     }
     if (dead) break;  // (the launch is being aborted: every wavefront finds the abort word set)
     if (wv == 0) {
-      if (!a.no_cond)
+      if (!a.no_cond && !a.one_term)
         for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);  // (as in the general worker)
       if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
     }
@@ -2084,6 +2117,230 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
   }
 }
 
+__device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+// ------------------------------------------------------------------------------------------------------------------
+// conductor of the ONE-TERM window (WinArgs::one_term; the default when the intercept is fitted).  What the reference's order
+// really chains through the intercept is  yhat_t = b_t + S_t -> dL_t = dloss(y_t, yhat_t) -> b_{t+1}  (sgd.nim:193-201,224-229;
+// adagrad.nim:101-110,121-123): S_t -- the linear terms and the interaction sum -- does not depend on b.  The term-by-term
+// conductor above adds S_t's m terms onto b one by one (the reference's rounding, 0.17 us of dependent additions + 0.2 us of
+// LDS hand-off per sample); here the WORKER adds them up (same storage order, starting from 0.0) and the chain is one addition,
+// dloss and the intercept's step.  north_star asks for 1e-6 relative on predictions; this variant agrees with the term-by-term
+// chain to ~1e-15 relative per step (tests: rtol 1e-8 against the oracle).
+//   * fetch wavefront: lane = worker (W / 64 workers per lane).  Every poll round loads the six tagged granules of each
+//     worker's CURRENT mailbox (kSumDepth rounds in flight: a fresh snapshot of all W mailboxes every few hundred ns), moves
+//     the ones that arrived into an LDS ring indexed by sample, and publishes the length of the in-order prefix.
+//   * chain wavefront: takes up to 64 consecutive samples out of the ring with ONE LDS access (lane = sample) and walks them
+//     with v_readlane: the LDS hand-off is paid per chunk, not per sample.  It issues no vector-memory load (see above).
+// A worker posts sample u + W only after it has seen the answer for u, so at most W samples are outstanding: the ring
+// (kSumRing >= 2 W slots) needs no "consumed" counter, and a mailbox can be reused two samples of its worker later.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kSumRing = 256;  // LDS ring, in samples (a power of two >= 2 W)
+constexpr int kSumDepth = 4;   // poll rounds in flight
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __forceinline__ double ldsv_load_d(const double* p) { return *(volatile lds_double*)(lds_double*)p; }
+
+template <int OPT, int NLW>  // NLW = W / 64 workers per lane of the fetch wavefront
+__device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds) {
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  constexpr bool ADA = OPT == OPT_ADAGRAD;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int W = a.W, lgW = a.lgW, np = a.np;
+  unsigned* c_ready = reinterpret_cast<unsigned*>(lds);  // samples [0, c_ready) are in the ring
+  unsigned* c_abort = c_ready + 1;
+  double* rS = lds + 2;            // [kSumRing] the samples' sums
+  double* rY = rS + kSumRing;      // [kSumRing] targets
+  double* rH = rY + kSumRing;      // [kSumRing] the intercept's step size (AdaGrad: eta0 (it-1) alpha0)
+  if (threadIdx.x == 0) {
+    ldsv_store(c_ready, 0u);
+    ldsv_store(c_abort, 0u);
+  }
+  __syncthreads();
+  const int64_t n = a.n_seg;
+  if (wave == 1) {
+    // ---- fetch ----
+    int64_t uw[NLW];  // the next sample of worker lane + 64 w that is not in the ring yet
+#pragma unroll
+    for (int w = 0; w < NLW; ++w) uw[w] = lane + kWave * w < W ? lane + kWave * w : n;  // (fewer than 64 workers: idle lanes)
+    ull g[kSumDepth][NLW][kSumGran];
+    // a fixed number of loads per round, none behind a branch (the wait before a round is looked at is then for ITS loads only)
+    auto issue = [&](int dd) {
+#pragma unroll
+      for (int w = 0; w < NLW; ++w) {
+        const int slot = (lane + kWave * w) & (W - 1);
+        const int64_t u = uw[w] < n ? uw[w] : slot;  // (a worker that is done: any of its mailboxes, never taken)
+        const int par = (int)((u >> lgW) & (np - 1));
+#pragma unroll
+        for (int gi = 0; gi < kSumGran; ++gi) g[dd][w][gi] = ld_u64(a.fwd + ((size_t)(gi * np + par) * W + slot));
+      }
+    };
+#pragma unroll
+    for (int dd = 0; dd < kSumDepth; ++dd) issue(dd);
+    int64_t cf = 0;  // samples [0, cf) are in the ring
+    long long t_last = wall_clock64();
+    int rounds = 0;
+    while (cf < n) {
+#pragma unroll
+      for (int dd = 0; dd < kSumDepth; ++dd) {
+        ull done_m[NLW];
+#pragma unroll
+        for (int w = 0; w < NLW; ++w) {
+          const unsigned tag = (unsigned)(uw[w] + 1);
+          bool ok = uw[w] < n;
+#pragma unroll
+          for (int gi = 0; gi < kSumGran; ++gi) ok = ok && (unsigned)(g[dd][w][gi] >> 32) == tag;
+          if (ok) {
+            const int idx = (int)(uw[w] & (kSumRing - 1));
+            rS[idx] = __hiloint2double((int)(unsigned)g[dd][w][1], (int)(unsigned)g[dd][w][0]);
+            rY[idx] = __hiloint2double((int)(unsigned)g[dd][w][3], (int)(unsigned)g[dd][w][2]);
+            rH[idx] = __hiloint2double((int)(unsigned)g[dd][w][5], (int)(unsigned)g[dd][w][4]);
+            if (a.trace) a.trace[uw[w] * 8 + 5] = wall_clock64();  // mailbox fetched
+            uw[w] += W;
+          }
+          // the worker's sample inside [cf, cf + W) is in the ring (its next one lies beyond), or the worker has none left
+          done_m[w] = __ballot(uw[w] >= cf + W || uw[w] >= n);
+        }
+        // the in-order prefix: the workers' bits as a ring of W, read from worker cf mod W on
+        int adv;
+        if constexpr (NLW == 1) {  // W <= 64: lanes past W have no worker
+          const ull full = W >= kWave ? ~0ull : (1ull << W) - 1ull;
+          const ull m0 = done_m[0] & full;
+          const int r = (int)(cf & (W - 1));
+          const ull rot = r ? ((m0 >> r) | (m0 << (W - r))) & full : m0;
+          adv = rot == full ? W : __builtin_ctzll(~rot);
+        } else {
+          int r = (int)(cf & 127);
+          ull m0 = done_m[0], m1 = done_m[NLW - 1];
+          if (r >= 64) {
+            const ull t_ = m0;
+            m0 = m1;
+            m1 = t_;
+            r -= 64;
+          }
+          const ull lo = r ? (m0 >> r) | (m1 << (64 - r)) : m0;
+          const ull hi = r ? (m1 >> r) | (m0 << (64 - r)) : m1;
+          adv = lo != ~0ull ? __builtin_ctzll(~lo) : hi != ~0ull ? 64 + __builtin_ctzll(~hi) : 128;
+        }
+        if (adv > 0) {
+          cf = cf + adv < n ? cf + adv : n;
+          lds_fence();  // LDS operations of a wavefront execute in order: data, then the counter
+          if (lane == 0) ldsv_store(c_ready, (unsigned)cf);
+          t_last = wall_clock64();
+        }
+        issue(dd);
+      }
+      if ((++rounds & 15) == 0) {  // the launch's abort word and the wall-clock limit (no progress for 4 s)
+        if (ld_u32(a.ctrl) != 0u || wall_clock64() - t_last > kWinTimeoutTicks) {
+          st_u32(a.ctrl, 1u);
+          ldsv_store(c_abort, 1u);
+          return;
+        }
+      }
+    }
+    return;
+  }
+  // ---- chain ----
+  double b = M.sc[SC_INTERCEPT];
+  double gsb = 0.0, gnb = 0.0, viol_b = 0.0;
+  if (ADA) {
+    gsb = O.gsc[0];
+    gnb = O.gsc[1];
+  }
+  const bool fit_b = M.fit_intercept != 0;
+  // The loop is compiled once per loss (and with / without the debugging stamps): with the loss a run-time switch every
+  // sample paid a dozen scalar branches that wait on vector compares -- as much as the arithmetic itself.
+  auto run = [&](auto loss_c, auto trace_c) -> bool {
+    constexpr int LOSS = decltype(loss_c)::value;
+    constexpr bool TRACE = decltype(trace_c)::value;
+    int64_t u = 0;
+    int64_t ready = 0;
+    while (u < n) {
+      if (ready <= u) {
+        int spins = 0;
+        const long long t0 = wall_clock64();
+        while ((ready = (int64_t)__builtin_amdgcn_readfirstlane((int)ldsv_load(c_ready))) <= u) {
+          if (ldsv_load(c_abort)) return false;
+          if ((++spins & 1023) == 0 && wall_clock64() - t0 > kWinTimeoutTicks) {
+            st_u32(a.ctrl, 1u);
+            return false;
+          }
+        }
+      }
+      compiler_fence();
+      // up to 64 consecutive samples, lane = sample (lanes past `ready` read slots that are not theirs yet: never used)
+      const int idx = (int)((u + lane) & (kSumRing - 1));
+      const double Sv = ldsv_load_d(rS + idx), yv = ldsv_load_d(rY + idx), hv = ldsv_load_d(rH + idx);
+      const int cnt = (int)(ready - u < kWave ? ready - u : kWave);
+      for (int t = 0; t < cnt; ++t) {
+        const double S = readlane_d(Sv, t), y = readlane_d(yv, t), h2 = readlane_d(hv, t);
+        const int64_t uu = u + t;
+        if (ADA && fit_b && a.it0 + uu != 1) {  // adagrad.nim:101-106
+          const double old = b;
+          b = -O.eta0 * gsb / (sqrt(gnb) + h2);
+          viol_b += fabs(old - b);
+        }
+        const double yh = b + S;  // predictWithGrad, sgd.nim:193-201, with everything but the intercept added up by the worker
+        double dL;
+        if constexpr (LOSS == NFM_LOSS_LOGISTIC) {
+          // loss.nim:66-71 without its branch: z > 0: -y e^{-z} / (1 + e^{-z}), else -y / (e^{z} + 1) -- one exponential of
+          // -|z| serves both (the same operations on the same values: the same bits)
+          const double z = yh * y;
+          const double e = exp(-fabs(z));
+          const double num = z > 0 ? -y * e : -y;
+          dL = num / (1 + e);
+        } else {
+          dL = dev::loss_grad(LOSS, O.loss_param, y, yh);
+        }
+        if (fit_b) {
+          if (ADA) {  // adagrad.nim:121-123
+            gsb += dL;
+            gnb += dL * dL;
+          } else {  // sgd.nim:224-229
+            const double update = h2 * (dL + O.alpha0 * b);
+            viol_b += fabs(update);
+            b -= update;
+          }
+        }
+        ull* rp = a.res + ((size_t)(uu & (W - 1)) * np + (size_t)((uu >> lgW) & (np - 1))) * kResWords;
+        if (lane < kResWords) {  // {dL, yhat} as granules tagged with the sample: its worker and near successors read them
+          const double v = lane < 2 ? dL : yh;
+          const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+          st_u64(rp + lane, ((ull)(unsigned)(uu + 1) << 32) | (ull)half);
+        }
+        if constexpr (TRACE) {
+          if (lane == 0) a.trace[uu * 8 + 7] = wall_clock64();  // answer posted
+        }
+      }
+      u += cnt;
+    }
+    return true;
+  };
+  auto run_l = [&](auto loss_c) {
+    return a.trace ? run(loss_c, std::integral_constant<bool, true>()) : run(loss_c, std::integral_constant<bool, false>());
+  };
+  bool done;
+  switch (O.loss) {
+    case NFM_LOSS_SQUARED: done = run_l(std::integral_constant<int, NFM_LOSS_SQUARED>()); break;
+    case NFM_LOSS_SQUARED_HINGE: done = run_l(std::integral_constant<int, NFM_LOSS_SQUARED_HINGE>()); break;
+    case NFM_LOSS_LOGISTIC: done = run_l(std::integral_constant<int, NFM_LOSS_LOGISTIC>()); break;
+    default: done = run_l(std::integral_constant<int, NFM_LOSS_HUBER>()); break;
+  }
+  if (!done) return;
+  if (lane == 0) {
+    M.sc[SC_INTERCEPT] = b;
+    if (ADA) {
+      O.gsc[0] = gsb;
+      O.gsc[1] = gnb;
+    }
+    a.partial[2 * W] = 0.0;
+    a.partial[2 * W + 1] = viol_b;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // worker for rows of 64 factors (Kp = 64) and at most 64 entries: lane = factor, lane q also holds entry q of the sample;
 // the sample's 64 stored rows stay in REGISTERS between predictWithGrad and update() (no LDS round trips, no branches
@@ -2093,11 +2350,6 @@ __device__ __forceinline__ void win_conductor(const WinArgs& a, double* lds) {
 // corrected a * (1/b), which equals the IEEE quotient (tools/divtest.hip: 2.7e11 pairs, no mismatch; a divisor whose
 // significand is all ones, where the theorem does not hold, takes the division instruction).
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ double readlane_d(double v, int l) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double div_by(double a, double b, double y /* = 1 / b */) {
   const double q0 = a * y;
   const double e0 = fma(-b, q0, a);
@@ -2443,21 +2695,26 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       }
     }
     double dL_own = 0.0, yh_own = 0.0;
-    if (a.no_cond) {
+    if (a.no_cond || a.one_term) {
       // no conductor (fitIntercept = false): predictWithGrad's chain (sgd.nim:193-201) in this wavefront -- the constant
       // intercept, the entries' terms w_j x_j in storage order (lane q holds entry q's), the interaction sum -- then dloss,
-      // and {dL, yhat} posted as tagged granules exactly as the conductor would (near successors read them)
+      // and {dL, yhat} posted as tagged granules exactly as the conductor would (near successors read them).
+      // One-term window: the same sum WITHOUT the intercept (from 0.0) is the sample's one mailbox term.
       const double term = lane < m ? (sw * wv) * vq : -0.0;
-      double yh_ = b_const;
+      double yh_ = a.no_cond ? b_const : 0.0;
 #pragma unroll
       for (int q = 0; q < K; ++q) yh_ += readlane_d(term, q);  // (past the row's end: -0.0, which changes no sum)
       yh_ += tot;
-      yh_own = yh_;
-      dL_own = dev::loss_grad(O.loss, O.loss_param, y, yh_);
-      if (lane < kResWords) {
-        const double v = lane < 2 ? dL_own : yh_own;
-        const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
-        st_u64(a.res + ((size_t)(u & (W - 1)) * a.np + (size_t)((u >> lgW) & (a.np - 1))) * kResWords + lane, ((ull)mytag << 32) | (ull)half);
+      if (a.no_cond) {
+        yh_own = yh_;
+        dL_own = dev::loss_grad(O.loss, O.loss_param, y, yh_);
+        if (lane < kResWords) {
+          const double v = lane < 2 ? dL_own : yh_own;
+          const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+          st_u64(a.res + ((size_t)(u & (W - 1)) * a.np + (size_t)((u >> lgW) & (a.np - 1))) * kResWords + lane, ((ull)mytag << 32) | (ull)half);
+        }
+      } else {
+        post_sum(a.fwd, a.np, W, slot, par, mytag, lane, yh_, y, h2);
       }
     } else {
       if (lane < MC) st_u64(mb + lane, mail_bits(lane < m ? (sw * wv) * vq : -0.0));
@@ -2580,7 +2837,7 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     // the mailbox back to "empty" for its next use, two samples of this worker from now: these stores have completed
     // (vmcnt(0) below) before this worker posts its next sample, which the conductor consumes before it can look at
     // these words again (kWinDepth < W)
-    if (!a.no_cond) {
+    if (!a.no_cond && !a.one_term) {
       if (lane < a.FW) st_u64(mb + lane, kWinSentinel);
       if (lane < a.FW - kWave) st_u64(mb + kWave + lane, kWinSentinel);
     }
@@ -2620,7 +2877,12 @@ __global__ __launch_bounds__(WK >= WK_FFM ? kFfmWaves * kWave : 128) void k_seq_
   if (blockIdx.x == 0) {
     if (a.no_cond) return;  // nothing to conduct: the workers form their samples' predictions themselves
     if (threadIdx.x < 2 * kWave) {
-      win_conductor<OPT, CH>(a, lds);
+      if (a.one_term) {
+        if (a.W == 2 * kWave) win_conductor_sum<OPT, 2>(a, lds);
+        else win_conductor_sum<OPT, 1>(a, lds);
+      } else {
+        win_conductor<OPT, CH>(a, lds);
+      }
     } else {
       __syncthreads();  // (the conductor's one barrier: the workgroup's idle wavefronts pass it and leave)
     }
@@ -2853,24 +3115,45 @@ static size_t win_fmx_lds(const ModelView& M, int m_cap, bool ada, int W) {  // 
          sizeof(int) * 4 * (size_t)m_cap + sizeof(unsigned) * W + 64;
 }
 
+// which flavour of the window a model gets (read per call: tests switch the environment)
+static bool win_no_cond(const ModelView& M) {  // fitIntercept = false: no scalar chain, no conductor
+  const char* env = getenv("NFM_SEQ_WIN_NOCOND");
+  return !(env && atoi(env) == 0) && !M.fit_intercept;
+}
+static bool win_one_term(const ModelView& M) {  // the intercept is fitted: the one-term chain unless NFM_SEQ_WIN_EXACT=1
+  const char* env = getenv("NFM_SEQ_WIN_EXACT");
+  return !win_no_cond(M) && !(env && atoi(env) != 0);
+}
+
 bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz, int n_cu) {
   const char* env = getenv("NFM_SEQ_WIN");  // 0: off, 1 (default): when it pays, 2: whenever possible (read per call: tests switch it)
   const int mode = env ? atoi(env) : 1;
   if (mode == 0) return false;
   if (M.Kp > kWave || M.Kp < 2) return false;
+  // a mailbox of one word per chain term bounds the row length only where the term-by-term conductor runs: not without a
+  // conductor (fitIntercept = false) and not in the one-term window (the default; launch_sequential_window)
+  const bool term_mail = !(win_no_cond(M) || win_one_term(M));
   if (M.kind == NFM_KIND_FFM) {
     // field-aware: one chain term per entry and per pair of entries; all nFields rows of every feature in LDS
     if (M.n_aug != 0 || M.nb < 1 || m_cap < 1) return false;
-    if (kWinHdr + (win_ffm_terms(m_cap) + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
+    if (term_mail && kWinHdr + (win_ffm_terms(m_cap) + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
     if (win_ffm_lds(M, m_cap, true, 128) > 160 * 1024) return false;
   } else if (M.kind == NFM_KIND_FM && (M.nb != 1 || M.degree != 2)) {
     // several orders / degree >= 3: one chain term per entry and per order; the rows of every (entry, order) in LDS
     if (M.n_aug != 0 || M.nb < 1 || M.degree < 2 || M.degree > dev::kMaxDeg || m_cap < 1) return false;
-    if (kWinHdr + (m_cap + M.nb + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
+    if (term_mail && kWinHdr + (m_cap + M.nb + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
     if (win_fmx_lds(M, m_cap, true, 128) > 160 * 1024) return false;
   } else {
     if (M.kind != NFM_KIND_FM || M.nb != 1 || M.degree != 2 || M.n_aug != 0) return false;
-    if (kWinHdr + (m_cap + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
+    if (term_mail && kWinHdr + (m_cap + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
+    // (the general worker keeps the sample's rows in LDS)
+    if (!(M.Kp == kWave && m_cap <= kWave)) {
+      int lgKp_ = 1;
+      while ((1 << lgKp_) < M.Kp) ++lgKp_;
+      const int grp_ = (kWave >> lgKp_) * 4;
+      const size_t mcp_ = (size_t)(m_cap + grp_ - 1) / grp_ * grp_;
+      if (sizeof(double) * (4 * mcp_ * M.Kp + kWave + 4 * mcp_) + sizeof(int) * 3 * mcp_ + sizeof(unsigned) * 256 > 160 * 1024) return false;
+    }
   }
   if (nnz >= ((int64_t)1 << 32) || M.d >= ((int64_t)1 << 31) || ns >= ((int64_t)1 << 31)) return false;
   if (n_cu < 17) return false;  // the smallest window: 16 workers + the conductor, one CU each (launch_sequential_window)
@@ -2910,9 +3193,11 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   if (m_cap < 1) m_cap = 1;
   // worker count: a power of two, one workgroup per CU with one CU left for the conductor
   // fitIntercept = false (degree-2 FMs): no conductor, and nothing but the features ties the samples -- twice the workers
-  const bool nc_on = !(getenv("NFM_SEQ_WIN_NOCOND") && atoi(getenv("NFM_SEQ_WIN_NOCOND")) == 0);  // (read per call: tests switch it)
-  const bool no_cond = nc_on && !M.fit_intercept;  // (every worker: degree-2 FMs, several orders / degree >= 3, field-aware models)
-  int W = no_cond ? 128 : 64;
+  const bool no_cond = win_no_cond(M);  // (every worker: degree-2 FMs, several orders / degree >= 3, field-aware models)
+  // the intercept is fitted: the ONE-TERM chain (the worker adds up its sample's prediction but the intercept; 128 workers:
+  // the conductor is no longer the bound) unless NFM_SEQ_WIN_EXACT=1 asks for the reference's term-by-term rounding
+  bool one_term = win_one_term(M);
+  int W = no_cond || one_term ? 128 : 64;
   // rows of 64 factors without a conductor: a worker on EVERY CU (headline shape 5.8e6 -> 7.1e6 samples/s, AdaGrad 3.8e6 -> 5.9e6;
   // shorter rows conflict too often to gain) -- until a launch of this optimizer has aborted once: such a launch needs the
   // whole chip resident, and a tenant that holds a single CU would cost every call its 4 s limit.  (After a second abort
@@ -2930,8 +3215,8 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   const bool ffm = M.kind == NFM_KIND_FFM;
   const bool fmx = !ffm && (M.nb != 1 || M.degree != 2);  // several orders / degree >= 3
   const int terms = ffm ? win_ffm_terms(m_cap) : fmx ? m_cap + M.nb : m_cap;  // what a sample hands to the conductor's chain
-  const int ch = terms <= 32 ? 32 : 64;  // the chain's chunk of terms; a mailbox holds MC = a multiple of it
-  const int FW = kWinHdr + (terms + ch - 1) / ch * ch;
+  const int ch = one_term || terms <= 32 ? 32 : 64;  // the chain's chunk of terms; a mailbox holds MC = a multiple of it
+  const int FW = one_term ? kWinHdr + 32 : kWinHdr + (terms + ch - 1) / ch * ch;  // (one-term mailboxes: kSumGran granules, see post_sum)
   const bool k64 = !ffm && !fmx && M.Kp == kWave && m_cap <= kWave;  // the register-resident worker
   const int wk = ffm ? WK_FFM : fmx ? WK_FMX : k64 ? WK_K64 : WK_GENERAL;
   // the previous-position table of this order (kept while the same samples are walked in storage order)
@@ -2952,7 +3237,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     const int v = atoi(env);
     if (no_cond && (v == 2 || v == 4 || v == 8)) np = v;
   }
-  const size_t n_fwd = (size_t)W * np * FW, n_res = (size_t)W * np * kResWords;
+  const size_t n_fwd = one_term ? (size_t)kSumGran * np * W : (size_t)W * np * FW, n_res = (size_t)W * np * kResWords;
   NFM_TRY(sw->mail.ensure(sizeof(ull) * (n_fwd + n_res)));
   NFM_TRY(sw->ctl.ensure(sizeof(unsigned) * (W + 64) + sizeof(double) * 2 * (W + 1) + sizeof(int64_t) * 2));
   if (!ada) NFM_TRY(sw->scales.ensure(sizeof(double) * 2 * (size_t)ns));
@@ -2983,6 +3268,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   a.W = W;
   a.lgW = lgW;
   a.no_cond = no_cond ? 1 : 0;
+  a.one_term = one_term ? 1 : 0;
   a.np = np;
   // without a conductor: how far back a dependency may lie and still take the recipe path, and how far apart the workers may run
   int thr = np - 1, near_r = W;
@@ -3009,9 +3295,9 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   if (k64) lds_worker = sizeof(double) * ((ada ? 3 : 1) * (size_t)kWave * kWave + kWave) + sizeof(unsigned) * W;
   if (ffm) lds_worker = win_ffm_lds(M, m_cap, ada, W);
   if (fmx) lds_worker = win_fmx_lds(M, m_cap, ada, W);
-  const size_t lds_cond = sizeof(double) * 2 + sizeof(ull) * (size_t)kWinRing * FW;
+  const size_t lds_cond = one_term ? sizeof(double) * (2 + 3 * (size_t)kSumRing) : sizeof(double) * 2 + sizeof(ull) * (size_t)kWinRing * FW;
   size_t lds_bytes = lds_worker > lds_cond ? lds_worker : lds_cond;
-  NFM_CHECK(lds_bytes <= 160 * 1024, NFM_ERR_UNSUPPORTED, "row too long for the dependency window (%zu bytes of LDS)", lds_bytes);
+  if (lds_bytes > 160 * 1024) return NFM_WIN_FALLBACK;  // (NFM_SEQ_WIN_W beyond what seq_window_supported assumed: the one-workgroup kernel)
   if (lds_bytes < 81 * 1024) lds_bytes = 81 * 1024;  // one workgroup per CU
   NFM_HIP_CHECK(hipMemsetAsync(out2_dev, 0, sizeof(double) * 2, st));
   int64_t pos = 0;
@@ -3029,7 +3315,8 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
       NFM_HIP_CHECK(hipMemsetAsync(sw->ctl.p, 0, sizeof(unsigned) * (W + 64) + sizeof(double) * 2 * (W + 1), st));
       NFM_HIP_CHECK(hipMemsetAsync(sw->fw.p, 0, sizeof(ull) * kFwSlot * np * (size_t)W, st));  // tag 0: nobody's
       const int64_t nm = (int64_t)n_fwd;  // the workers' mailboxes "empty"; the conductor's answers carry tags (0: nobody's)
-      hipLaunchKernelGGL(k_win_fill, dim3((unsigned)((nm + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sw->mail.as<ull>(), nm, kWinSentinel);
+      if (one_term) NFM_HIP_CHECK(hipMemsetAsync(sw->mail.p, 0, sizeof(ull) * n_fwd, st));  // (one-term mailboxes are tagged as well)
+      else hipLaunchKernelGGL(k_win_fill, dim3((unsigned)((nm + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sw->mail.as<ull>(), nm, kWinSentinel);
       NFM_HIP_CHECK(hipMemsetAsync(sw->mail.as<ull>() + n_fwd, 0, sizeof(ull) * n_res, st));
     }
     a.seg0 = pos;

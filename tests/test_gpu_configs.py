@@ -89,6 +89,73 @@ def test_cfg4_shape_ffm_adagrad_vs_mb_oracle():
     assert_close(ffm.decisionFunction(X), O.ffm_decision_function(Xo, P, w, b), 1e-10, 1e-13, "decision")
 
 
+def _cfg4_data(n, d, F, seed):
+    rng = np.random.default_rng(seed)
+    per = d // F
+    idx = rng.integers(0, per, size=(n, F)) + np.arange(F) * per  # field f owns [f d/F, (f+1) d/F) (tests/utils.nim:66-68)
+    val = rng.uniform(-1, 1, size=(n, F))
+    Xo = O.Dataset(np.arange(n + 1, dtype=np.int64) * F, idx.ravel(), val.ravel(), n, d, fields=np.tile(np.arange(F), n),
+                   n_fields=F)
+    return Xo, rng
+
+
+@pytest.mark.parametrize("kind", ["adagrad", "sgd_cap16"])
+def test_cfg4_shape_at_the_bench_batch_2048(kind):
+    """BASELINE configs[3] at the batch bench.py QUOTES it at (2048: the sparse regime -- 1.17 touches per unique feature,
+    k_ffm_row_phase_lds + k_ffm_col_phase WITHOUT the per-batch refresh pass; the B = 32768 test above runs the dense regime
+    with the refresh): F = 16, one entry per field, d = 1e5, k = 8, 19 full batches + the it == 1 singleton + a ragged tail,
+    two epochs -- the second over a fresh permutation -- against the CPU statement of the mini-batch rule
+    (optimizer/adagrad_ffm.nim:11-66, sgd_ffm.nim:43 through oracle/nimfm_mb.c) at rtol 1e-9, decisionFunction at 1e-10."""
+    n, d, F, k, B = 1 + 19 * 2048 + 777, 100_000, 16, 8, 2048
+    Xo, rng = _cfg4_data(n, d, F, 18)
+    y = rng.standard_normal(n)
+    P0, w0 = rng.standard_normal((F, d, k)) * 0.05, rng.standard_normal(d) * 0.01
+    perm = np.random.default_rng(5).permutation(n).astype(np.int64)
+    perms = np.stack([np.arange(n, dtype=np.int64), perm])
+    P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
+    hist = []
+    if kind == "adagrad":
+        cfg = O.adagrad_cfg(loss="squared")
+        st = O.AdaState(F, d, k, d)
+        for e in range(2):
+            b, it, ls, vs = O.ffm_adagrad_epoch_mb(Xo, y, P, w, b, cfg, B, st, perm=perms[e], it=it)
+            hist.append((vs, ls / n))
+        b = O.ffm_adagrad_finalize(P, w, b, cfg, it, st)
+        opt = nf.newAdaGrad(maxIter=2, verbose=0, tol=0, loss="squared", mode="minibatch", batch=B)
+    else:
+        cfg = O.sgd_cfg(loss="squared", eta0=0.02)
+        for e in range(2):
+            b, it, ls, vs = O.ffm_sgd_epoch_mb(Xo, y, P, w, b, cfg, B, perm=perms[e], it=it, touch_cap=16.0)
+            hist.append((vs, ls / n))
+        opt = nf.newSGD(maxIter=2, verbose=0, tol=0, loss="squared", eta0=0.02, mode="minibatch", batch=B, touchCap=16.0)
+    X = to_gpu(Xo)
+    ffm = gpu_ffm("regression", k, True, True, P0, w0, 0.0)
+    ctx = nf.default_context()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    try:
+        opt.fit(X, y, ffm, perms=perms)
+        refresh, rows, cols = (ctx.timing_get(name)[0] for name in ("refresh", "row_phase", "col_phase"))
+    finally:
+        ctx.timing_enable(False)
+    # which path ran: the sparse regime's (no refresh pass), one row + one column launch per mini-batch and epoch
+    n_batches = 1 + 19 + 1 if kind == "adagrad" else 19 + 1  # (AdaGrad: the very first sample is a batch of its own, adagrad.nim:171)
+    assert refresh == 0, "the per-batch refresh pass ran: this is not the path bench.py quotes cfg4 on"
+    assert rows >= 2 * n_batches - 1 and cols >= 2 * n_batches - 1, (rows, cols)
+    assert opt.it == it == 2 * n + 1
+    assert abs(ffm.intercept - b) < 1e-11
+    assert_close(ffm.w, w, 1e-9, 1e-13, "w")
+    assert_close(ffm.P, P, 1e-9, 1e-13, "P")
+    assert_close([h[0] for h in opt.history], [h[0] for h in hist], 1e-9, 0, "viol")
+    assert_close([h[1] for h in opt.history], [h[1] for h in hist], 1e-11, 0, "mean loss")
+    if kind == "adagrad":
+        gs, gn, gsw, gnw, gsb, gnb = opt.get_state(ffm)
+        assert_close(gs, st.gsum_P, 1e-9, 1e-13, "g_sum")
+        assert_close(gn, st.gnorm_P, 1e-9, 1e-16, "g_norm")
+        assert_close(gsw, st.gsum_w, 1e-9, 1e-13, "g_sum.w")
+    assert_close(ffm.decisionFunction(X), O.ffm_decision_function(Xo, P, w, b), 1e-10, 1e-13, "decision")
+
+
 @pytest.mark.parametrize("loss", ["squared", "logistic"])
 def test_cfg3_shape_adagrad_20_batches(loss):
     n, d, m, k, B = 20 * 8192 + 1, 1_000_000, 64, 64, 8192  # the it == 1 singleton + twenty full batches
