@@ -95,6 +95,7 @@ struct WinArgs {
                           // sum: predictWithGrad, sgd.nim:193-201), takes dloss and posts {dL, yhat} for its near successors
   int dead_slot;          // test hook (NFM_SEQ_WIN_TEST_DEAD_SLOT): this worker leaves at once, as a workgroup that never became
                           // resident would; -1 otherwise.  The others time out, the launch aborts, the host restores + falls back
+  int fast_exp;           // one-term conductor, logistic loss: the chunk-parallel exponential (NFM_SEQ_WIN_FASTEXP=0 turns it off)
   int one_term;           // 1 (the default with a conductor; NFM_SEQ_WIN_EXACT=1 turns it off): the worker adds up everything of its
                           // sample's prediction but the intercept -- S = sum_j w_j x_j (storage order) + the interaction sum -- and posts
                           // ONE term; the conductor's chain is  yhat = b + S -> dloss -> b'  (win_conductor_sum).  Same sample order and
@@ -119,6 +120,7 @@ __device__ __forceinline__ ull mail_bits(double v) {  // a value as a mailbox wo
 }
 __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_fence_order() { asm volatile("" ::: "memory"); }  // LDS operations of one wavefront execute in order
 
 // A spin that always ends: the abort word of the launch and a wall-clock limit, looked at every 64 rounds.
 struct Spin {
@@ -149,14 +151,21 @@ __device__ __forceinline__ bool fw_load(const ull* p, unsigned tag, double& v) {
   v = __hiloint2double((int)(unsigned)(g1 & 0xffffffffull), (int)(unsigned)(g0 & 0xffffffffull));
   return (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
 }
-// The ONE-TERM mailbox (WinArgs::one_term): {S, y, the intercept's step size} as six tagged granules, laid out granule-major
-// -- fwd[(granule * np + parity) * W + worker] -- so that the conductor's fetch wavefront reads one granule of 64 workers with
-// one 512-byte access.  Tags instead of the "empty" pattern: nothing to reset after use.
-constexpr int kSumGran = 6;
-__device__ __forceinline__ void post_sum(ull* fwd, int np, int W, int slot, int par, unsigned tag, int lane, double S, double y, double h2) {
+// The ONE-TERM mailbox (WinArgs::one_term): {S, y, the intercept's step size, C, the tag of a writer's sample} as nine tagged
+// granules, laid out granule-major -- fwd[(granule * np + parity) * W + worker] -- so that the conductor's fetch wavefront
+// reads one granule of 64 workers with one 512-byte access.  Tags instead of the "empty" pattern: nothing to reset after use.
+// C / writer (SGD): the sample shares ONE feature with a sample `writer` whose dL the conductor has not produced yet.  The
+// writer's step of the shared row is AFFINE in its dL (sgd.nim:217-223: p' = A + dL B, A and B known at the writer's forward
+// pass) and the prediction is multilinear in the rows of different features, so S = S(A) + dL_writer * C exactly: the worker
+// posts S(A) and C without waiting for dL_writer, the conductor -- which made that dL -- finishes the sum (win_conductor_sum).
+// writer = 0: no such dependency, C is ignored.
+constexpr int kSumGran = 9;
+__device__ __forceinline__ void post_sum(ull* fwd, int np, int W, int slot, int par, unsigned tag, int lane, double S, double y, double h2,
+                                         double C = 0.0, unsigned writer_tag = 0u) {
   if (lane < kSumGran) {
-    const double v = lane < 2 ? S : lane < 4 ? y : h2;
-    const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+    const double v = lane < 2 ? S : lane < 4 ? y : lane < 6 ? h2 : C;
+    unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+    if (lane == 8) half = writer_tag;
     st_u64(fwd + ((size_t)(lane * np + par) * W + slot), ((ull)tag << 32) | (ull)half);
   }
 }
@@ -347,72 +356,53 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
 
     // ---- B2. near dependencies: the writer's recipe + the conductor's dL for the WRITER's sample -> the row as the writer
     // will (or did) write it, formed here with the writer's own arithmetic (no wait for its update, store and counter) ----
-    if (fwdmask) {
-      const bool mine = (fwdmask >> lane) & 1ull;  // lane = entry
-      const int64_t upl = (int64_t)pq - a.seg0;
-      const unsigned tagl = (unsigned)(upl + 1);
-      ull* srcl = fw_area(mine ? upl : 0);
-      const ull* rsrcl = res_of(mine ? upl : 0);
-      double wu = 0.0, gwu = 0.0, nwu = 0.0, vsl = 0.0, dLl = 0.0;
-      bool okl = true;
-      auto load_lin = [&]() {
-        okl = true;
-        if (mine) {
-          okl = fw_load(fw_lin(srcl, 0, pqu), tagl, wu);
-          if (ADA && M.fit_linear) {
-            okl = fw_load(fw_lin(srcl, 1, pqu), tagl, gwu) && okl;
-            okl = fw_load(fw_lin(srcl, 2, pqu), tagl, nwu) && okl;
-          }
-          okl = fw_load(fw_lin(srcl, 3, pqu), tagl, vsl) && okl;
+    // One-term window, SGD, ONE such row whose writer's dL is not there yet: the row is affine in that dL (A + dL B) and the
+    // sample's sum S with it (post_sum): S(A) and the slope are posted at once, the exact row is formed when dL arrives
+    bool affine = false;  // (uniform)
+    double aff_A = 0.0, aff_B = 0.0, aff_Bw = 0.0;
+    const int q_first = fwdmask ? __builtin_ctzll(fwdmask) : 0;
+    const bool mine = (fwdmask >> lane) & 1ull;  // lane = entry
+    const int64_t upl = (int64_t)pq - a.seg0;
+    const unsigned tagl = (unsigned)(upl + 1);
+    ull* srcl = fw_area(mine ? upl : 0);
+    const ull* rsrcl = res_of(mine ? upl : 0);
+    double wu = 0.0, gwu = 0.0, nwu = 0.0, vsl = 0.0, dLl = 0.0;
+    double sPul = 1.0, etaPul = 0.0, sPnul = 1.0, swul = 1.0, etawul = 0.0;
+    bool okl = true;
+    auto load_lin = [&]() {
+      okl = true;
+      if (mine) {
+        okl = fw_load(fw_lin(srcl, 0, pqu), tagl, wu);
+        if (ADA && M.fit_linear) {
+          okl = fw_load(fw_lin(srcl, 1, pqu), tagl, gwu) && okl;
+          okl = fw_load(fw_lin(srcl, 2, pqu), tagl, nwu) && okl;
         }
-      };
-      load_lin();
-      double sPul = 1.0, etaPul = 0.0, sPnul = 1.0, swul = 1.0, etawul = 0.0;
-      if constexpr (!ADA) {  // the writers' scales and step sizes: functions of their step counters alone
-        if (mine) {
-          sPul = a.scales[2 * (a.seg0 + upl)];
-          swul = a.scales[2 * (a.seg0 + upl) + 1];
-          etaPul = dev::get_eta(O.sched, O.eta0, O.power, O.beta, (double)(a.it0 + upl));
-          etawul = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, (double)(a.it0 + upl));
-          sPnul = sPul * (1 - etaPul * O.beta);
-        }
+        okl = fw_load(fw_lin(srcl, 3, pqu), tagl, vsl) && okl;
       }
-      {
-        Spin sp;
-        while (true) {  // the writers' dL (their recipes were posted before it could exist)
-          bool ok = true;
-          if (mine) ok = fw_load(rsrcl, tagl, dLl);
-          if (!__all(okl)) load_lin();
-          if (__all(ok)) break;
-          if (sp.wait(a.ctrl)) return;
-        }
+    };
+    // the recipe of shared row q (all row slots load it): the writer's per-factor sums, the row as it used it (+ AdaGrad's state)
+    auto load_recipe = [&](int q, double& a1u, double& pv, double& gv, double& nv) -> bool {
+      const int64_t up = (int64_t)__builtin_amdgcn_readlane(pq, q) - a.seg0;
+      const unsigned tag = (unsigned)(up + 1);
+      ull* src = fw_area(up);
+      const int qu = __builtin_amdgcn_readlane(pqu, q);
+      bool ok = fw_load(src + (size_t)s * 2, tag, a1u);
+      ok = fw_load(fw_row(src, 0, qu), tag, pv) && ok;
+      if constexpr (ADA) {
+        ok = fw_load(fw_row(src, 1, qu), tag, gv) && ok;
+        ok = fw_load(fw_row(src, 2, qu), tag, nv) && ok;
       }
-      {
-        Spin sp;
-        while (!__all(okl)) {
-          if (sp.wait(a.ctrl)) return;
-          load_lin();
-        }
-      }
-      for (ull mk = fwdmask; mk; mk &= mk - 1) {
+      return ok;
+    };
+    // the exact rows of the near dependencies in `which` (and the shared features' linear weights) once the writers' dL are in hand
+    auto form_near_rows = [&](ull which) -> bool {
+      for (ull mk = which; mk; mk &= mk - 1) {
         const int q = __builtin_ctzll(mk);
-        const int64_t up = (int64_t)__builtin_amdgcn_readlane(pq, q) - a.seg0;
-        const unsigned tag = (unsigned)(up + 1);
-        ull* src = fw_area(up);
-        const int qu = __builtin_amdgcn_readlane(pqu, q);
         double a1u, pv, gv = 0.0, nv = 0.0;
         {
           Spin sp;
-          while (true) {
-            bool ok = fw_load(src + (size_t)s * 2, tag, a1u);
-            ok = fw_load(fw_row(src, 0, qu), tag, pv) && ok;
-            if constexpr (ADA) {
-              ok = fw_load(fw_row(src, 1, qu), tag, gv) && ok;
-              ok = fw_load(fw_row(src, 2, qu), tag, nv) && ok;
-            }
-            if (__all(ok)) break;
-            if (sp.wait(a.ctrl)) return;
-          }
+          while (!__all(load_recipe(q, a1u, pv, gv, nv)))
+            if (sp.wait(a.ctrl)) return false;
         }
         const double vsu = dev::shfl_d(vsl, q), dLu = dev::shfl_d(dLl, q);
         const size_t e = (size_t)jl[q] * Kp + s;
@@ -439,7 +429,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
         Pl[(size_t)q * Kp + s] = p;  // (all row slots write the same value)
         Tl[(size_t)q * Kp + s] = vl[q] * (sP * p);
       }
-      if (mine) {  // the linear weight of the shared feature, the same way
+      if (mine && ((which >> lane) & 1ull)) {  // the linear weight of the shared feature, the same way
         double wv = wu;
         if (M.fit_linear) {
           if constexpr (ADA) {
@@ -461,6 +451,88 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
         wl[lane] = wv;
       }
       compiler_fence();
+      return true;
+    };
+    // The affine candidate: the shared row of the MOST RECENT writer -- the conductor makes the dL in order, so the others'
+    // arrive first and are waited for as before -- provided that writer shares exactly one feature with this sample (two rows
+    // moving with the same dL would make S quadratic in it).
+    int aff_q = -1;
+    ull aff_bit = 0ull;
+    if (fwdmask) {
+      if constexpr (!ADA) {
+        if (a.one_term) {
+          int latest = mine ? (int)upl : -1;
+#pragma unroll
+          for (int sh = 1; sh < kWave; sh <<= 1) {
+            const int o_ = __shfl_xor(latest, sh, kWave);
+            latest = o_ > latest ? o_ : latest;
+          }
+          const ull who = __ballot(mine && (int)upl == latest);
+          if ((who & (who - 1)) == 0ull) {
+            aff_q = __builtin_ctzll(who);
+            aff_bit = who;
+          }
+        }
+      }
+      load_lin();
+      if constexpr (!ADA) {  // the writers' scales and step sizes: functions of their step counters alone
+        if (mine) {
+          sPul = a.scales[2 * (a.seg0 + upl)];
+          swul = a.scales[2 * (a.seg0 + upl) + 1];
+          etaPul = dev::get_eta(O.sched, O.eta0, O.power, O.beta, (double)(a.it0 + upl));
+          etawul = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, (double)(a.it0 + upl));
+          sPnul = sPul * (1 - etaPul * O.beta);
+        }
+      }
+      double a1f = 0.0, pvf = 0.0, gvf = 0.0, nvf = 0.0;
+      {
+        Spin sp;
+        while (true) {  // the writers' dL (their recipes were posted before it could exist)
+          bool ok = true;
+          if (mine) ok = fw_load(rsrcl, tagl, dLl);
+          if (!__all(okl)) load_lin();
+          if (__all(ok)) break;
+          // every dL but the most recent writer's is here, and so is that writer's recipe: S as a function of its dL
+          if (aff_q >= 0 && __all(ok || lane == aff_q) && __all(okl) && __all(load_recipe(aff_q, a1f, pvf, gvf, nvf))) {
+            affine = true;
+            break;
+          }
+          if (sp.wait(a.ctrl)) return;
+        }
+      }
+      if (!affine) {
+        {
+          Spin sp;
+          while (!__all(okl)) {
+            if (sp.wait(a.ctrl)) return;
+            load_lin();
+          }
+        }
+        if (!form_near_rows(fwdmask)) return;
+      } else {
+        if constexpr (!ADA) {
+          if (!form_near_rows(fwdmask & ~aff_bit)) return;  // (the earlier writers' rows: exact)
+          // row'(dL) = (p - eta (dL g + beta p)) / s' = A + dL B  with the writer's scale, step size and per-factor sums
+          const int q = aff_q;
+          const double vsu = dev::shfl_d(vsl, q);
+          const double sPu = dev::shfl_d(sPul, q), etaPu = dev::shfl_d(etaPul, q), sPnu = dev::shfl_d(sPnul, q);
+          const double pw = sPu * pvf;
+          aff_A = (pw - etaPu * (O.beta * pw)) / sPnu;
+          aff_B = -(etaPu * (vsu * (a1f - pw * vsu))) / sPnu;
+          Pl[(size_t)q * Kp + s] = aff_A;
+          Tl[(size_t)q * Kp + s] = vl[q] * (sP * aff_A);
+          if (lane == q) {  // the shared feature's linear weight the same way (fit_linear.nim:41-47): Aw + dL Bw
+            double wv = wu;
+            if (M.fit_linear) {
+              const double wj = swul * wu, den = swul * (1 - etawul * O.alpha);
+              wv = (wj - etawul * (O.alpha * wj)) / den;
+              aff_Bw = -(etawul * vsl) / den;
+            }
+            wl[lane] = wv;
+          }
+          compiler_fence();
+        }
+      }
     }
 
     // ---- C. the per-factor sums over all entries in storage order (sgd.nim:160-170), their sum over the factors in
@@ -516,8 +588,40 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
           const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
           st_u64(a.res + (size_t)(slot * a.np + par) * kResWords + lane, ((ull)(unsigned)(u + 1) << 32) | (ull)half);
         }
-      } else {
+      } else if (!affine) {
         post_sum(a.fwd, a.np, W, slot, par, (unsigned)(u + 1), lane, yh_, y, h2);
+      } else {
+        // dS / d dL_writer: the kernel is multilinear in the rows, so the slope is  sum_s x sP B_s (a1_s - x sP A_s)  -- the
+        // per-factor sums WITHOUT the shared row's own term -- plus the linear term's  sw Bw x
+        const double xs = vl[aff_q];
+        const double rest = a1 - xs * (sP * aff_A);
+        double c1 = dev::wave_sum(r == 0 && s < k ? (xs * (sP * aff_B)) * rest : 0.0);
+        c1 += dev::shfl_d((sw * aff_Bw) * xs, aff_q);
+        post_sum(a.fwd, a.np, W, slot, par, (unsigned)(u + 1), lane, yh_, y, h2, c1, (unsigned)__builtin_amdgcn_readlane((int)tagl, aff_q));
+        // ... and now the exact row: the writer's dL, its update of the shared row, this sample's sums again with it
+        {
+          Spin sp;
+          while (true) {
+            bool ok = true;
+            if (lane == aff_q) ok = fw_load(rsrcl, tagl, dLl);
+            if (__all(ok)) break;
+            if (sp.wait(a.ctrl)) return;
+          }
+        }
+        if (!form_near_rows(aff_bit)) return;
+        a1 = 0.0;
+        a2 = 0.0;
+        for (int qb = 0; qb < m; qb += 8) {
+          double t_[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) t_[t] = Tl[(size_t)(qb + t < m ? qb + t : qb) * Kp + s];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const bool ok = qb + t < m;
+            a1 = ok ? a1 + t_[t] : a1;
+            a2 = ok ? a2 + t_[t] * t_[t] : a2;
+          }
+        }
       }
     } else {
       const int MC = a.FW - kWinHdr;
@@ -2139,7 +2243,7 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 // (kSumRing >= 2 W slots) needs no "consumed" counter, and a mailbox can be reused two samples of its worker later.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kSumRing = 256;  // LDS ring, in samples (a power of two >= 2 W)
-constexpr int kSumDepth = 4;   // poll rounds in flight
+constexpr int kSumDepth = 2;   // poll rounds in flight
 typedef __attribute__((address_space(3))) double lds_double;
 __device__ __forceinline__ double ldsv_load_d(const double* p) { return *(volatile lds_double*)(lds_double*)p; }
 
@@ -2152,12 +2256,18 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
   const int W = a.W, lgW = a.lgW, np = a.np;
   unsigned* c_ready = reinterpret_cast<unsigned*>(lds);  // samples [0, c_ready) are in the ring
   unsigned* c_abort = c_ready + 1;
+  unsigned* c_done = c_ready + 2;                          // samples [0, c_done) have their {dL, yhat} in rD / rP
   double* rS = lds + 2;            // [kSumRing] the samples' sums
   double* rY = rS + kSumRing;      // [kSumRing] targets
   double* rH = rY + kSumRing;      // [kSumRing] the intercept's step size (AdaGrad: eta0 (it-1) alpha0)
+  double* rC = rH + kSumRing;      // [kSumRing] the slope of S in a writer's dL (post_sum)
+  double* rD = rC + kSumRing;      // [kSumRing] the chain's dL per sample: what the post wavefront sends out, and the history a
+  double* rP = rD + kSumRing;      // [kSumRing]   dependent sample's slope is multiplied by; the predictions yhat
+  unsigned* rW = reinterpret_cast<unsigned*>(rP + kSumRing);  // [kSumRing] that writer's tag (its sample + 1), 0: none
   if (threadIdx.x == 0) {
     ldsv_store(c_ready, 0u);
     ldsv_store(c_abort, 0u);
+    ldsv_store(c_done, 0u);
   }
   __syncthreads();
   const int64_t n = a.n_seg;
@@ -2198,6 +2308,8 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
             rS[idx] = __hiloint2double((int)(unsigned)g[dd][w][1], (int)(unsigned)g[dd][w][0]);
             rY[idx] = __hiloint2double((int)(unsigned)g[dd][w][3], (int)(unsigned)g[dd][w][2]);
             rH[idx] = __hiloint2double((int)(unsigned)g[dd][w][5], (int)(unsigned)g[dd][w][4]);
+            rC[idx] = __hiloint2double((int)(unsigned)g[dd][w][7], (int)(unsigned)g[dd][w][6]);
+            rW[idx] = (unsigned)g[dd][w][8];
             if (a.trace) a.trace[uw[w] * 8 + 5] = wall_clock64();  // mailbox fetched
             uw[w] += W;
           }
@@ -2243,6 +2355,43 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
     }
     return;
   }
+  if (wave == 2) {
+    // ---- post: {dL, yhat} of the samples the chain has finished go out as tagged granules (their workers and near successors
+    // poll them), lane = sample.  A wavefront issues one instruction every few cycles whatever it is: the address arithmetic,
+    // the tagging and the store were a quarter of the chain's instructions per sample -- here they cost the chain two LDS writes.
+    int64_t pdone = 0;
+    long long t_last = wall_clock64();
+    int spins = 0;
+    while (pdone < n) {
+      const int64_t done = (int64_t)__builtin_amdgcn_readfirstlane((int)ldsv_load(c_done));
+      if (done <= pdone) {
+        if (ldsv_load(c_abort)) return;
+        if ((++spins & 1023) == 0 && wall_clock64() - t_last > kWinTimeoutTicks) {
+          st_u32(a.ctrl, 1u);
+          ldsv_store(c_abort, 1u);
+          return;
+        }
+        continue;
+      }
+      compiler_fence();
+      const int cntb = (int)(done - pdone < kWave ? done - pdone : kWave);
+      if (lane < cntb) {
+        const int64_t uu = pdone + lane;
+        const int idx = (int)(uu & (kSumRing - 1));
+        const double dL = ldsv_load_d(rD + idx), yh = ldsv_load_d(rP + idx);
+        ull* rp = a.res + ((size_t)(uu & (W - 1)) * np + (size_t)((uu >> lgW) & (np - 1))) * kResWords;
+        const ull tg = (ull)(unsigned)(uu + 1) << 32;
+        st_u64(rp + 0, tg | (ull)(unsigned)__double2loint(dL));
+        st_u64(rp + 1, tg | (ull)(unsigned)__double2hiint(dL));
+        st_u64(rp + 2, tg | (ull)(unsigned)__double2loint(yh));
+        st_u64(rp + 3, tg | (ull)(unsigned)__double2hiint(yh));
+        if (a.trace) a.trace[uu * 8 + 7] = wall_clock64();  // answer posted
+      }
+      pdone += cntb;
+      t_last = wall_clock64();
+    }
+    return;
+  }
   // ---- chain ----
   double b = M.sc[SC_INTERCEPT];
   double gsb = 0.0, gnb = 0.0, viol_b = 0.0;
@@ -2250,14 +2399,16 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
     gsb = O.gsc[0];
     gnb = O.gsc[1];
   }
-  const bool fit_b = M.fit_intercept != 0;
+  const bool fit_b_rt = M.fit_intercept != 0;
   // The loop is compiled once per loss (and with / without the debugging stamps): with the loss a run-time switch every
   // sample paid a dozen scalar branches that wait on vector compares -- as much as the arithmetic itself.
-  auto run = [&](auto loss_c, auto trace_c) -> bool {
+  auto run = [&](auto loss_c, auto trace_c, auto fitb_c) -> bool {
     constexpr int LOSS = decltype(loss_c)::value;
     constexpr bool TRACE = decltype(trace_c)::value;
+    constexpr bool fit_b = decltype(fitb_c)::value;  // (fitIntercept: a select per intercept word and sample otherwise)
     int64_t u = 0;
     int64_t ready = 0;
+    [[maybe_unused]] const long long cyc0 = clock64(), rt0 = wall_clock64();
     while (u < n) {
       if (ready <= u) {
         int spins = 0;
@@ -2273,11 +2424,38 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
       compiler_fence();
       // up to 64 consecutive samples, lane = sample (lanes past `ready` read slots that are not theirs yet: never used)
       const int idx = (int)((u + lane) & (kSumRing - 1));
-      const double Sv = ldsv_load_d(rS + idx), yv = ldsv_load_d(rY + idx), hv = ldsv_load_d(rH + idx);
+      const double Sv = ldsv_load_d(rS + idx), yv = ldsv_load_d(rY + idx), hv = ldsv_load_d(rH + idx), Cv = ldsv_load_d(rC + idx);
+      const int Wv = (int)ldsv_load(rW + idx);
       const int cnt = (int)(ready - u < kWave ? ready - u : kWave);
+      // Logistic loss: the exponential is two thirds of the chain's dependent operations.  Lane-parallel, once per chunk:
+      // E_t = exp(-|z0_t|) with z0_t = y_t (b0 + S_t), b0 = the intercept at the chunk's start.  In the chain the true
+      // z_t = y_t (b_t + S_t) is formed as before and  exp(-|z_t|) = E_t exp(|z0_t| - |z_t|): the intercept moves by a few
+      // step sizes inside a chunk, so the second factor is a degree-11 polynomial of an argument below 2^-3 (four dependent
+      // operations in Estrin's form instead of the twenty of a full exponential; truncation below 3e-20).  A sample whose S
+      // waits for a writer's dL or a short chunk: the full exponential; an intercept that has moved further: E_t again.
+      [[maybe_unused]] double b0 = b, A0v = 0.0, Ev = 0.0;
+      // (targets of a classification task are -1, 0, +1: |z0 - z| <= |b - b0|; anything else takes the full exponential)
+      [[maybe_unused]] const bool fastc = LOSS == NFM_LOSS_LOGISTIC && a.fast_exp && cnt >= a.fast_exp &&
+                                          __ballot(lane < cnt && !(fabs(yv) <= 1.0)) == 0ull;
+      const ull affmask = __ballot(lane < cnt && Wv != 0);  // samples whose S waits for a writer's dL
+      [[maybe_unused]] auto rebase = [&]() {
+        b0 = b;
+        A0v = fabs((b0 + Sv) * yv);
+        Ev = exp(-A0v);
+      };
+      if constexpr (LOSS == NFM_LOSS_LOGISTIC) {
+        if (fastc) rebase();
+      }
       for (int t = 0; t < cnt; ++t) {
-        const double S = readlane_d(Sv, t), y = readlane_d(yv, t), h2 = readlane_d(hv, t);
+        double S = readlane_d(Sv, t);
+        const double y = readlane_d(yv, t), h2 = readlane_d(hv, t);
         const int64_t uu = u + t;
+        const bool aff_t = (affmask >> t) & 1ull;
+        if (aff_t) {  // S is affine in the dL of an earlier sample still inside the window (post_sum): that dL was made here
+          const int wtag = readlane_i(Wv, t);
+          const double dLw = ldsv_load_d(rD + ((wtag - 1) & (kSumRing - 1)));  // (fewer than W <= 128 positions back: still in the ring)
+          S += dLw * readlane_d(Cv, t);
+        }
         if (ADA && fit_b && a.it0 + uu != 1) {  // adagrad.nim:101-106
           const double old = b;
           b = -O.eta0 * gsb / (sqrt(gnb) + h2);
@@ -2289,7 +2467,19 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
           // loss.nim:66-71 without its branch: z > 0: -y e^{-z} / (1 + e^{-z}), else -y / (e^{z} + 1) -- one exponential of
           // -|z| serves both (the same operations on the same values: the same bits)
           const double z = yh * y;
-          const double e = exp(-fabs(z));
+          double e;
+          if (fastc && !aff_t) {
+            if (fabs(b - b0) > 0x1p-3) rebase();  // (rare: all lanes again from the current intercept)
+            const double x = readlane_d(A0v, t) - fabs(z);
+            const double x2 = x * x;
+            const double p01 = 1.0 + x, p23 = fma(x, 1.0 / 6, 0.5), p45 = fma(x, 1.0 / 120, 1.0 / 24), p67 = fma(x, 1.0 / 5040, 1.0 / 720),
+                         p89 = fma(x, 1.0 / 362880, 1.0 / 40320), pab = fma(x, 1.0 / 39916800, 1.0 / 3628800);
+            const double x4 = x2 * x2, q0 = fma(x2, p23, p01), q1 = fma(x2, p67, p45), q2 = fma(x2, pab, p89);
+            const double x8 = x4 * x4, r0 = fma(x4, q1, q0);
+            e = readlane_d(Ev, t) * fma(x8, q2, r0);
+          } else {
+            e = exp(-fabs(z));
+          }
           const double num = z > 0 ? -y * e : -y;
           dL = num / (1 + e);
         } else {
@@ -2305,22 +2495,31 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
             b -= update;
           }
         }
-        ull* rp = a.res + ((size_t)(uu & (W - 1)) * np + (size_t)((uu >> lgW) & (np - 1))) * kResWords;
-        if (lane < kResWords) {  // {dL, yhat} as granules tagged with the sample: its worker and near successors read them
-          const double v = lane < 2 ? dL : yh;
-          const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
-          st_u64(rp + lane, ((ull)(unsigned)(uu + 1) << 32) | (ull)half);
+        // {dL, yhat} to the post wavefront (LDS operations of a wavefront execute in order: data, then the counter)
+        if (lane == 0) {
+          const int di = (int)(uu & (kSumRing - 1));
+          rD[di] = dL;
+          rP[di] = yh;
+          lds_fence_order();
+          ldsv_store(c_done, (unsigned)(uu + 1));
         }
         if constexpr (TRACE) {
-          if (lane == 0) a.trace[uu * 8 + 7] = wall_clock64();  // answer posted
+          if (lane == 0) a.trace[uu * 8 + 6] = wall_clock64();  // chain done with the sample
         }
       }
       u += cnt;
     }
+    if constexpr (TRACE) {  // (debugging: the shader clock against the 100 MHz wall clock over the launch, in the last sample's row)
+      if (lane == 0 && n >= 1) {
+        a.trace[(n - 1) * 8 + 0] = clock64() - cyc0;
+        a.trace[(n - 1) * 8 + 1] = wall_clock64() - rt0;
+      }
+    }
     return true;
   };
   auto run_l = [&](auto loss_c) {
-    return a.trace ? run(loss_c, std::integral_constant<bool, true>()) : run(loss_c, std::integral_constant<bool, false>());
+    if (a.trace) return fit_b_rt ? run(loss_c, std::true_type(), std::true_type()) : run(loss_c, std::true_type(), std::false_type());
+    return fit_b_rt ? run(loss_c, std::false_type(), std::true_type()) : run(loss_c, std::false_type(), std::false_type());
   };
   bool done;
   switch (O.loss) {
@@ -2545,85 +2744,56 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     }
     // ---- C. near dependencies: the writer's recipe + the conductor's dL for the writer's sample -> the row as the writer
     // will (or did) write it, formed here with the writer's own arithmetic ----
-    if (fwdmask) {
-      // Everything the recipes hold was posted at the writers' forward passes, long ago: it is requested FIRST (the
-      // shared entries' lanes: their entry's part; all lanes: the first shared row's part), the poll for the writers' dL
-      // runs while those loads are in flight, and only then are the recipes' tags looked at.
-      const bool mine = (fwdmask >> lane) & 1ull;
-      const int64_t upl = (int64_t)pq - a.seg0;
-      const unsigned tagl = (unsigned)(upl + 1);
-      ull* srcl = fw_area(mine ? upl : 0);
-      const ull* rsrcl = res_of(mine ? upl : 0);
-      double wu = 0.0, gwu = 0.0, nwu = 0.0, vsl = 0.0, dLl = 0.0;
-      bool okl = true;
-      auto load_lin = [&]() {
-        okl = true;
-        if (mine) {
-          okl = fw_load(fw_lin(srcl, 0, pqu), tagl, wu);
-          if (ADA && M.fit_linear) {
-            okl = fw_load(fw_lin(srcl, 1, pqu), tagl, gwu) && okl;
-            okl = fw_load(fw_lin(srcl, 2, pqu), tagl, nwu) && okl;
-          }
-          okl = fw_load(fw_lin(srcl, 3, pqu), tagl, vsl) && okl;
+    // One-term window, SGD, ONE such row whose writer's dL is not there yet: the row is affine in that dL (A + dL B), the
+    // sample's sum S with it (post_sum): S(A) and the slope are posted at once, the exact row is formed when dL arrives
+    bool affine = false;  // (uniform)
+    double aff_A = 0.0, aff_B = 0.0, aff_Bw = 0.0;
+    const unsigned mytag = (unsigned)(u + 1);
+    const int q_first = fwdmask ? __builtin_ctzll(fwdmask) : 0;
+    // the writers' side of the recipes (kept for the affine path's second half)
+    const bool mine = (fwdmask >> lane) & 1ull;
+    const int64_t upl = (int64_t)pq - a.seg0;
+    const unsigned tagl = (unsigned)(upl + 1);
+    double wu = 0.0, gwu = 0.0, nwu = 0.0, vsl = 0.0, dLl = 0.0;
+    double a1u = 0.0, pv = 0.0, gv = 0.0, nv = 0.0;
+    double sPul = 1.0, etaPul = 0.0, sPnul = 1.0, swul = 1.0, etawul = 0.0, rynul = 1.0;
+    ull* srcl = fw_area(mine ? upl : 0);
+    const ull* rsrcl = res_of(mine ? upl : 0);
+    bool okl = true, okr = true;
+    int q_loaded = -1;  // the shared row whose recipe sits in (a1u, pv, gv, nv)
+    auto load_lin = [&]() {
+      okl = true;
+      if (mine) {
+        okl = fw_load(fw_lin(srcl, 0, pqu), tagl, wu);
+        if (ADA && M.fit_linear) {
+          okl = fw_load(fw_lin(srcl, 1, pqu), tagl, gwu) && okl;
+          okl = fw_load(fw_lin(srcl, 2, pqu), tagl, nwu) && okl;
         }
-      };
-      const int q_first = __builtin_ctzll(fwdmask);
-      double a1u, pv, gv = 0.0, nv = 0.0;
-      bool okr = true;
-      auto load_row = [&](int q) {
-        const int64_t up = (int64_t)readlane_i(pq, q) - a.seg0;
-        const unsigned tag = (unsigned)(up + 1);
-        ull* src = fw_area(up);
-        const int qu = readlane_i(pqu, q);
-        okr = fw_load(src + (size_t)lane * 2, tag, a1u);
-        okr = fw_load(fw_row(src, 0, qu), tag, pv) && okr;
-        if constexpr (ADA) {
-          okr = fw_load(fw_row(src, 1, qu), tag, gv) && okr;
-          okr = fw_load(fw_row(src, 2, qu), tag, nv) && okr;
-        }
-      };
-      load_lin();
-      load_row(q_first);
-      // the writers' scales and step sizes (functions of their step counters alone) while those loads are in flight
-      double sPul = 1.0, etaPul = 0.0, sPnul = 1.0, swul = 1.0, etawul = 0.0;
-      if constexpr (!ADA) {
-        if (mine) {
-          sPul = a.scales[2 * (a.seg0 + upl)];
-          swul = a.scales[2 * (a.seg0 + upl) + 1];
-          etaPul = dev::get_eta(O.sched, O.eta0, O.power, O.beta, (double)(a.it0 + upl));
-          etawul = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, (double)(a.it0 + upl));
-          sPnul = sPul * (1 - etaPul * O.beta);
-        }
+        okl = fw_load(fw_lin(srcl, 3, pqu), tagl, vsl) && okl;
       }
-      const double rynul = 1.0 / sPnul;
-      {
-        // one loop: the dL of the writers, and -- as long as they do not carry the writers' tags yet (this worker may have
-        // arrived before the writers' forward passes) -- the recipes again, so that they are in hand when dL lands
-        Spin sp;
-        while (true) {
-          bool ok = true;
-          if (mine) ok = fw_load(rsrcl, tagl, dLl);
-          if (!__all(okl)) load_lin();
-          if (!__all(okr)) load_row(q_first);
-          if (__all(ok)) break;
-          if (sp.wait(a.ctrl)) return;
-        }
+    };
+    auto load_row = [&](int q) {
+      const int64_t up = (int64_t)readlane_i(pq, q) - a.seg0;
+      const unsigned tag = (unsigned)(up + 1);
+      ull* src = fw_area(up);
+      const int qu = readlane_i(pqu, q);
+      okr = fw_load(src + (size_t)lane * 2, tag, a1u);
+      okr = fw_load(fw_row(src, 0, qu), tag, pv) && okr;
+      if constexpr (ADA) {
+        okr = fw_load(fw_row(src, 1, qu), tag, gv) && okr;
+        okr = fw_load(fw_row(src, 2, qu), tag, nv) && okr;
       }
-      if (a.trace && lane == 0) a.trace[u * 8 + 0] = wall_clock64();  // (tracing: the writers' dL seen)
-      {
-        Spin sp;
-        while (!__all(okl)) {
-          if (sp.wait(a.ctrl)) return;
-          load_lin();
-        }
-      }
-      for (ull mk = fwdmask; mk; mk &= mk - 1) {
+      q_loaded = q;
+    };
+    // the exact rows of the near dependencies in `which`, once their writers' dL are in hand (lane `mine`: dLl)
+    auto form_near_rows = [&](ull which) -> bool {
+      for (ull mk = which; mk; mk &= mk - 1) {
         const int q = __builtin_ctzll(mk);
         const double vsu = readlane_d(vsl, q), dLu = readlane_d(dLl, q);
-        if (q != q_first) load_row(q);
+        if (q != q_loaded) load_row(q);
         Spin sp;
         while (!__all(okr)) {
-          if (sp.wait(a.ctrl)) return;
+          if (sp.wait(a.ctrl)) return false;
           load_row(q);
         }
         if constexpr (ADA) {  // the writer's updateG of this row (adagrad.nim:113-134)
@@ -2639,7 +2809,7 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
           Fl[q * K + lane] = oddu ? (p - update) / sPnu : div_by(p - update, sPnu, readlane_d(rynul, q));
         }
       }
-      if (mine) {
+      if (mine && ((which >> lane) & 1ull)) {
         wv = wu;
         if (M.fit_linear) {
           if constexpr (ADA) {
@@ -2652,19 +2822,114 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
           }
         }
       }
+      return true;
+    };
+    // The affine candidate: the shared row of the MOST RECENT writer -- the conductor makes the dL in order, so the others'
+    // arrive first and are waited for as before -- provided that writer shares exactly one feature with this sample (two rows
+    // moving with the same dL would make S quadratic in it).
+    int aff_q = -1;
+    ull aff_bit = 0ull;
+    if (fwdmask) {
+      if constexpr (!ADA) {
+        if (a.one_term) {
+          int latest = mine ? (int)upl : -1;
+#pragma unroll
+          for (int sh = 1; sh < kWave; sh <<= 1) {
+            const int o_ = __shfl_xor(latest, sh, kWave);
+            latest = o_ > latest ? o_ : latest;
+          }
+          const ull who = __ballot(mine && (int)upl == latest);
+          if ((who & (who - 1)) == 0ull) {
+            aff_q = __builtin_ctzll(who);
+            aff_bit = who;
+          }
+        }
+      }
+      // Everything the recipes hold was posted at the writers' forward passes, long ago: it is requested FIRST (the
+      // shared entries' lanes: their entry's part; all lanes: one shared row's part), the poll for the writers' dL
+      // runs while those loads are in flight, and only then are the recipes' tags looked at.
+      const int q_pre = aff_q >= 0 ? aff_q : q_first;
+      load_lin();
+      load_row(q_pre);
+      // the writers' scales and step sizes (functions of their step counters alone) while those loads are in flight
+      if constexpr (!ADA) {
+        if (mine) {
+          sPul = a.scales[2 * (a.seg0 + upl)];
+          swul = a.scales[2 * (a.seg0 + upl) + 1];
+          etaPul = dev::get_eta(O.sched, O.eta0, O.power, O.beta, (double)(a.it0 + upl));
+          etawul = dev::get_eta(O.sched, O.eta0, O.power, O.alpha, (double)(a.it0 + upl));
+          sPnul = sPul * (1 - etaPul * O.beta);
+        }
+      }
+      rynul = 1.0 / sPnul;
+      {
+        // one loop: the dL of the writers, and -- as long as they do not carry the writers' tags yet (this worker may have
+        // arrived before the writers' forward passes) -- the recipes again, so that they are in hand when dL lands
+        Spin sp;
+        while (true) {
+          bool ok = true;
+          if (mine) ok = fw_load(rsrcl, tagl, dLl);
+          if (!__all(okl)) load_lin();
+          if (!__all(okr)) load_row(q_pre);
+          if (__all(ok)) break;
+          // every dL but the most recent writer's is here, and so is that writer's recipe: S as a function of its dL
+          if (aff_q >= 0 && __all(ok || lane == aff_q) && __all(okl) && __all(okr)) {
+            affine = true;
+            break;
+          }
+          if (sp.wait(a.ctrl)) return;
+        }
+      }
+      if (a.trace && lane == 0) a.trace[u * 8 + 0] = wall_clock64();  // (tracing: the writers' dL seen)
+      if (!affine) {
+        {
+          Spin sp;
+          while (!__all(okl)) {
+            if (sp.wait(a.ctrl)) return;
+            load_lin();
+          }
+        }
+        if (!form_near_rows(fwdmask)) return;
+      } else {
+        if constexpr (!ADA) {
+          // row'(dL) = (p - eta (dL g + beta p)) / s' = A + dL B  with the writer's scale, step size and per-factor sums
+          const int q = aff_q;
+          const double vsu = readlane_d(vsl, q);
+          const double sPu = readlane_d(sPul, q), etaPu = readlane_d(etaPul, q), sPnu = readlane_d(sPnul, q);
+          const double p = sPu * pv;
+          aff_A = (p - etaPu * (O.beta * p)) / sPnu;
+          aff_B = -(etaPu * (vsu * (a1u - p * vsu))) / sPnu;
+          if (!form_near_rows(fwdmask & ~aff_bit)) return;  // (the earlier writers' rows: exact)
+          Fl[q * K + lane] = aff_A;
+          if (lane == q) {  // the shared feature's linear weight the same way (fit_linear.nim:41-47): Aw + dL Bw
+            wv = wu;
+            if (M.fit_linear) {
+              const double wj = swul * wu, den = swul * (1 - etawul * O.alpha);
+              wv = (wj - etawul * (O.alpha * wj)) / den;
+              aff_Bw = -(etawul * vsl) / den;
+            }
+          }
+        }
+      }
     }
-    if (latemask) {
+    auto apply_late = [&](ull which) {
       compiler_fence();
 #pragma unroll
       for (int q = 0; q < K; ++q) {
-        if (q < m && ((latemask >> q) & 1ull)) {
+        if (q < m && ((which >> q) & 1ull)) {
           if constexpr (ADA) Pr[q] = ada_row(Fl[q * K + lane], Gl[q * K + lane], Nl[q * K + lane], (size_t)readlane_i(jq, q) * K + lane, true);
           else Pr[q] = Fl[q * K + lane];
         }
       }
+    };
+    if (latemask) {
+      apply_late(latemask);
       if (ADA && M.fit_linear && late) wv = ada_lin(wv, gwr, nwr);
     }
-    if (a.trace && lane == 0) a.trace[u * 8 + 1] = wall_clock64();  // dependencies resolved
+    if (a.trace && lane == 0) {
+      a.trace[u * 8 + 1] = wall_clock64();  // dependencies resolved
+      a.trace[u * 8 + 6] = (affine ? 8 : 0) + (fwdmask ? (fwdmask & (fwdmask - 1) ? 4 : 2) : 0) + (farmask ? 1 : 0);  // which way
+    }
     // ---- D. per-factor sums over the entries in storage order, their sum over the factors in ascending order ----
     double a1 = 0.0, a2 = 0.0;
 #pragma unroll
@@ -2673,7 +2938,6 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       a1 += t;
       a2 += t * t;
     }
-    const unsigned mytag = (unsigned)(u + 1);
     const double kv = (a1 * a1 - a2) / 2;
     red[lane] = lane < k ? kv : 0.0;  // (never -0.0: adding the padding changes nothing)
     compiler_fence();
@@ -2713,8 +2977,39 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
           const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
           st_u64(a.res + ((size_t)(u & (W - 1)) * a.np + (size_t)((u >> lgW) & (a.np - 1))) * kResWords + lane, ((ull)mytag << 32) | (ull)half);
         }
-      } else {
+      } else if (!affine) {
         post_sum(a.fwd, a.np, W, slot, par, mytag, lane, yh_, y, h2);
+      } else {
+        // dS / d dL_writer: the kernel is multilinear in the rows, so the slope is  sum_s x sP B_s (a1_s - x sP A_s)  -- the
+        // per-factor sums WITHOUT the shared row's own term -- plus the linear term's  sw Bw x
+        const double xs = readlane_d(vq, aff_q);
+        const double rest = a1 - xs * (sP * aff_A);
+        double c1 = dev::wave_sum(lane < k ? (xs * (sP * aff_B)) * rest : 0.0);
+        c1 += readlane_d((sw * aff_Bw) * vq, aff_q);
+        post_sum(a.fwd, a.np, W, slot, par, mytag, lane, yh_, y, h2, c1, (unsigned)readlane_i((int)tagl, aff_q));
+        // ... and now the exact row: the writer's dL, its update of the shared row, this sample's sums again with it
+        {
+          Spin sp;
+          while (true) {
+            bool ok = true;
+            if (lane == aff_q) ok = fw_load(rsrcl, tagl, dLl);
+            if (__all(ok)) break;
+            if (sp.wait(a.ctrl)) return;
+          }
+        }
+        if (!form_near_rows(aff_bit)) return;
+        apply_late(aff_bit);
+        a1 = 0.0;
+        a2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          const double t = readlane_d(vq, q) * (sP * Pr[q]);
+          a1 += t;
+          a2 += t * t;
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) asm volatile("" : "+v"(Pr[q]));
+        asm volatile("" : "+v"(vq), "+v"(jq));
       }
     } else {
       if (lane < MC) st_u64(mb + lane, mail_bits(lane < m ? (sw * wv) * vq : -0.0));
@@ -2871,12 +3166,12 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
 
 enum { WK_GENERAL = 0, WK_K64 = 1, WK_FFM = 2, WK_FMX = 3 };  // which worker
 template <int OPT, int CH, int WK>
-__global__ __launch_bounds__(WK >= WK_FFM ? kFfmWaves * kWave : 128) void k_seq_window(WinArgs a) {
+__global__ __launch_bounds__(kFfmWaves * kWave) void k_seq_window(WinArgs a) {
   extern __shared__ double lds[];
   if (a.dead_slot >= 0 && (int)blockIdx.x == a.dead_slot + 1) return;  // (test hook; workgroup 0 is the conductor)
   if (blockIdx.x == 0) {
     if (a.no_cond) return;  // nothing to conduct: the workers form their samples' predictions themselves
-    if (threadIdx.x < 2 * kWave) {
+    if (threadIdx.x < (a.one_term ? 3 : 2) * kWave) {  // (one-term: fetch, chain and post wavefronts)
       if (a.one_term) {
         if (a.W == 2 * kWave) win_conductor_sum<OPT, 2>(a, lds);
         else win_conductor_sum<OPT, 1>(a, lds);
@@ -3166,7 +3461,7 @@ static int launch_window_t(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes) {
   NFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   // the W + 1 workgroups wait for each other: every one of them must be resident.  One workgroup per CU (the LDS request
   // sees to that) and W + 1 <= CUs is the launcher's rule; here the kernel itself is asked whether a CU can hold it at all
-  constexpr int threads = WK >= WK_FFM ? kFfmWaves * kWave : 128;
+  constexpr int threads = kFfmWaves * kWave;  // (the workers of degree-2 FMs use the first wavefront; the conductor needs three)
   int per_cu = 0;
   NFM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds_bytes));
   if (per_cu < 1) return NFM_WIN_FALLBACK;
@@ -3194,10 +3489,10 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   // worker count: a power of two, one workgroup per CU with one CU left for the conductor
   // fitIntercept = false (degree-2 FMs): no conductor, and nothing but the features ties the samples -- twice the workers
   const bool no_cond = win_no_cond(M);  // (every worker: degree-2 FMs, several orders / degree >= 3, field-aware models)
-  // the intercept is fitted: the ONE-TERM chain (the worker adds up its sample's prediction but the intercept; 128 workers:
-  // the conductor is no longer the bound) unless NFM_SEQ_WIN_EXACT=1 asks for the reference's term-by-term rounding
+  // the intercept is fitted: the ONE-TERM chain (the worker adds up its sample's prediction but the intercept) unless
+  // NFM_SEQ_WIN_EXACT=1 asks for the reference's term-by-term rounding
   bool one_term = win_one_term(M);
-  int W = no_cond || one_term ? 128 : 64;
+  int W = no_cond ? 128 : 64;  // (with a conductor the chain is the bound at 64 workers already: measured, 128 gain nothing)
   // rows of 64 factors without a conductor: a worker on EVERY CU (headline shape 5.8e6 -> 7.1e6 samples/s, AdaGrad 3.8e6 -> 5.9e6;
   // shorter rows conflict too often to gain) -- until a launch of this optimizer has aborted once: such a launch needs the
   // whole chip resident, and a tenant that holds a single CU would cost every call its 4 s limit.  (After a second abort
@@ -3269,6 +3564,8 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   a.lgW = lgW;
   a.no_cond = no_cond ? 1 : 0;
   a.one_term = one_term ? 1 : 0;
+  a.fast_exp = 4;  // (the shortest chunk that takes the chunk-parallel exponential)
+  if (const char* env = getenv("NFM_SEQ_WIN_FASTEXP")) a.fast_exp = atoi(env);
   a.np = np;
   // without a conductor: how far back a dependency may lie and still take the recipe path, and how far apart the workers may run
   int thr = np - 1, near_r = W;
@@ -3295,7 +3592,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   if (k64) lds_worker = sizeof(double) * ((ada ? 3 : 1) * (size_t)kWave * kWave + kWave) + sizeof(unsigned) * W;
   if (ffm) lds_worker = win_ffm_lds(M, m_cap, ada, W);
   if (fmx) lds_worker = win_fmx_lds(M, m_cap, ada, W);
-  const size_t lds_cond = one_term ? sizeof(double) * (2 + 3 * (size_t)kSumRing) : sizeof(double) * 2 + sizeof(ull) * (size_t)kWinRing * FW;
+  const size_t lds_cond = one_term ? sizeof(double) * (2 + 7 * (size_t)kSumRing) + sizeof(unsigned) * kSumRing : sizeof(double) * 2 + sizeof(ull) * (size_t)kWinRing * FW;
   size_t lds_bytes = lds_worker > lds_cond ? lds_worker : lds_cond;
   if (lds_bytes > 160 * 1024) return NFM_WIN_FALLBACK;  // (NFM_SEQ_WIN_W beyond what seq_window_supported assumed: the one-workgroup kernel)
   if (lds_bytes < 81 * 1024) lds_bytes = 81 * 1024;  // one workgroup per CU
