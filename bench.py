@@ -35,9 +35,13 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: n, d, m, k, degree, solver, loss   (SURVEY.md 8d / BASELINE.md)
     # cfg2 names no batch size; 32768 keeps the two dependent launches per batch off the critical path
-    # (DESIGN.md section 7).  cfg3 / headline use the 8192 that BASELINE.json states.
+    # (DESIGN.md section 7).  cfg3 uses the 8192 that BASELINE.json states.  The north-star headline (SGD, one GPU) names no batch:
+    # 65536 since round 5 -- the batch with the best seconds-to-target of the sweep 8192 ... 65536 (tools/r5_batch_sweep.sh,
+    # profiles/r05a_*: the same targets in the same number of epochs, 15 % fewer seconds per epoch; at touch rate
+    # lambda = B m / d = 4.2 the column phase writes a row once per 4 touches); `value_batch_8192` on the line is the
+    # figure of rounds 1-4.
     "cfg2": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768),
-    "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="logistic", batch=8192),
+    "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="logistic", batch=65536),
     "cfg3": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="squared", batch=8192),
     "cfg3l": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="logistic", batch=8192),
     # cfg5: higher-order FM, degree 3 with fitLower=explicit -> two parameter blocks (ANOVA degree 3 and 2)
@@ -354,15 +358,41 @@ def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, c
                    "note": "the same epoch on jagged storage (seq-of-seq as tensor/tensor.nim:8-17: a malloc'd row with a seq header "
                            "per feature behind a pointer table), oracle/nimfm_jagged.c, bit-identical results"}
         t1 = med(0)
-        threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
-        th = None
+        # Hogwild (optimizer/sgd_multi.nim: contiguous slices, shared unsynchronised state) at T = 1, 4 (the reference
+        # benchmarks' value), this process's usable CPUs, all physical cores, and the reference's default
+        # min(2 x countProcessors(), MaxThreadPoolSize = 256) (sgd_multi.nim:13-18) -- SURVEY 8(d); the line carries the BEST
+        logical = os.cpu_count() or 1
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            usable = logical
+        physical = logical
+        try:
+            cores_ = set()
+            phys_, core_ = None, None
+            with open("/proc/cpuinfo") as f:
+                for ln in f:
+                    if ln.startswith("physical id"):
+                        phys_ = ln.split(":", 1)[1].strip()
+                    elif ln.startswith("core id"):
+                        core_ = ln.split(":", 1)[1].strip()
+                    elif not ln.strip() and phys_ is not None and core_ is not None:
+                        cores_.add((phys_, core_))
+                        phys_, core_ = None, None
+            if cores_:
+                physical = len(cores_)
+        except OSError:
+            pass
+        ref_default = min(2 * logical, 256)
+        threads = min(16, usable)  # the GPU box's CPU share for one GPU
         sweep = []
         if sgd and not F:
-            for T_ in sorted({min(4, threads), threads} if cheap else {min(4, threads), threads, 2 * threads}):
+            cand = {1, min(4, usable), threads} if cheap else {1, min(4, usable), threads, min(usable, physical), physical, ref_default}
+            for T_ in sorted(cand):
+                if nc // T_ < 8:  # (a slice per thread: nothing to time below a few samples each)
+                    continue
                 tt_ = med(T_)
                 sweep.append({"threads": T_, "value": round(nc / tt_, 1)})
-                if T_ == threads:
-                    th = tt_
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -375,10 +405,11 @@ def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, c
                       "epoch loop only (the per-fit layout transposes, sgd.nim:292,328, are outside)"
                       % (nc, ("sgd_ffm.nim:49-106" if sgd else "adagrad_ffm.nim:11-66") if F else ("sgd.nim:261-328" if sgd else "adagrad.nim:137-203"), epochs - 1),
             "jagged": jag,
-            "hogwild": None if th is None else {"value": round(nc / th, 1), "threads": threads,
-                                                "note": "optimizer/sgd_multi.nim semantics (racy), same port and build",
-                                                "sweep": sweep},
-            "host": {"cpu": cpu_model, "logical_cpus": os.cpu_count()}}
+            "hogwild": None if not sweep else dict(max(sweep, key=lambda e_: e_["value"]),
+                                                   note="optimizer/sgd_multi.nim semantics (racy), same port and build; the BEST of the "
+                                                        "sweep over T (1, 4, usable CPUs, physical cores, the reference's default "
+                                                        "min(2 x logical, 256))", sweep=sweep),
+            "host": {"cpu": cpu_model, "logical_cpus": os.cpu_count(), "usable_cpus": usable, "physical_cores": physical}}
 
 
 def c_bar_of(lam_, cap_):
@@ -525,11 +556,14 @@ def time_to_target_leg(torch, nf, ctx, dev, wl, name, n, batch, cap, indices, da
         return (len(got), got[-1]["speedup"] if got else 0.0)
 
     runs = [run_mb(batch)]
-    for b_ in (batches if batches is not None else (8192, 2048)):
-        if score(runs[0])[0] == len(seq):
-            break  # the bench batch reaches every target: nothing to look for
-        if b_ < batch:
-            runs.append(run_mb(b_))
+    if batches:  # an explicit sweep (--t2t-batches): every batch asked for, smaller or LARGER than the bench batch
+        runs += [run_mb(b_) for b_ in batches if b_ != batch]
+    else:
+        for b_ in (8192, 2048):
+            if score(runs[0])[0] == len(seq):
+                break  # the bench batch reaches every target: nothing to look for
+            if b_ < batch:
+                runs.append(run_mb(b_))
     best = max(runs, key=score)
     return {"train_samples": n_t, "held_out_samples": n_h,
             "problem": "labels from a planted degree-2 FM (w ~ N(0, %g^2), P ~ N(0, %g^2), k = %d)%s; %s %s; start P ~ N(0, 0.01^2), w = 0"
@@ -675,6 +709,22 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         value_shuffled_host = n * world / (dth / kh)
         del perms
 
+    # ---- the headline at the batch of rounds 1-4 (8192), for continuity: a second optimizer on the same model, 3 epochs ----
+    value_b8192 = None
+    if primary and name == "headline" and batch != 8192 and world == 1 and not args.batch and not args.no_shuffled:
+        opt8 = nf.newSGD(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch", batch=8192, touchCap=cap)
+        opt8._handle(fm, ctx, "minibatch")
+        opt8.it = opt.it
+        for e8 in range(4):
+            if e8 == 1:
+                fence()
+                t8 = time.perf_counter()
+            opt8._epoch(X, None, 0, n)
+            opt8.it += n
+        fence()
+        value_b8192 = round(n * 3 / (time.perf_counter() - t8), 1)
+        del opt8
+
     # ---- predict samples/s (the metric's second half): decisionFunction over the shard, output on device ----
     pred = None
     if rank == 0:
@@ -708,7 +758,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     # reference-faithful CPU restatement) on a bounded prefix of the shard: the speed of the mode that reproduces the
     # reference exactly, reported beside the mini-batch rule's ----
     exact = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_exact:
         # seqwin.hip: the order as a dependency window over the chip (degree-2 FMs, several orders / degree <= 6, field-aware
         # models whose chain terms -- one per entry and per pair of entries -- fit a mailbox)
         windowed = k <= 64 and wl["degree"] <= 6 and (not F or m + m * (m - 1) // 2 <= 252)
@@ -749,11 +799,32 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                  "kernel_only": round(ns_ / (kern_ms * 1e-3), 1) if kern_ms > 0 else None,
                  "value_fresh_order": round(ns_ / t_p, 1),
                  "dependency_table_ms": round(deps_ms, 2),
+                 "flavour": "one-term chain (the worker sums its sample's prediction but the intercept, the conductor's chain is "
+                            "b + S -> dloss -> b'; NFM_SEQ_WIN_EXACT=1 is the term-by-term chain, bit-equal to the one-workgroup kernel)"
+                            if windowed else None,
                  "sample": "the first %d samples of the shard, mode=sequential: %s; value = one epoch call (wall clock) over a fixed "
                            "order whose dependency table exists, value_fresh_order = one epoch call with a new permutation from "
                            "the host (upload + table build inside)" %
-                           (ns_, "the reference's order as a dependency window over the chip (csrc/seqwin.hip), results bit-equal to "
-                            "the one-workgroup kernel" if windowed else "one workgroup (csrc/seq.hip)")}
+                           (ns_, "the reference's order as a dependency window over the chip (csrc/seqwin.hip), same sample order and "
+                            "dependencies as the one-workgroup kernel; yhat rounded as b + (sum) (max_rel_diff: what that changes)"
+                            if windowed else "one workgroup (csrc/seq.hip)")}
+        if windowed:  # the bit-exact flavour of the window (the reference's term-by-term rounding of the prediction), for comparison
+            old_ex = os.environ.get("NFM_SEQ_WIN_EXACT")
+            os.environ["NFM_SEQ_WIN_EXACT"] = "1"
+            try:
+                opt_s._epoch(Xs, None, 0, ns_)  # (its mailboxes are sized on the first call)
+                opt_s.it += ns_
+                ctx.synchronize()
+                t_e = time.perf_counter()
+                opt_s._epoch(Xs, None, 0, ns_)
+                opt_s.it += ns_
+                ctx.synchronize()
+                exact["value_term_by_term"] = round(ns_ / (time.perf_counter() - t_e), 1)
+            finally:
+                if old_ex is None:
+                    os.environ.pop("NFM_SEQ_WIN_EXACT", None)
+                else:
+                    os.environ["NFM_SEQ_WIN_EXACT"] = old_ex
         if windowed:
             # fitIntercept = false: no scalar chain ties the samples (the intercept is what serialises the reference's order),
             # the window runs without its conductor on twice the workers -- the same order, bit-equal results
@@ -783,9 +854,10 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                                        keep=(indptr, indices, data, _keep_fields))
         Xb.set_targets(np.ascontiguousarray(y[:nb_]))
         got_ = {}
-        old_env = os.environ.get("NFM_SEQ_WIN")
-        for win_ in ("0", "2"):
-            os.environ["NFM_SEQ_WIN"] = win_
+        old_env, old_ex = os.environ.get("NFM_SEQ_WIN"), os.environ.get("NFM_SEQ_WIN_EXACT")
+        for win_ in ("0", "2", "2x"):  # the one-workgroup kernel, the window (one-term chain), the window's term-by-term flavour
+            os.environ["NFM_SEQ_WIN"] = win_[0]
+            os.environ["NFM_SEQ_WIN_EXACT"] = "1" if win_ == "2x" else "0"
             if F:
                 fb_ = nf.newFieldAwareFactorizationMachine(task, nComponents=k, warmStart=True, randomState=1)
             else:
@@ -798,15 +870,25 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
             ob_._finalize_into(fb_)
             got_[win_] = (np.array(fb_.P).copy(), np.array(fb_.w).copy(), float(fb_.intercept))
             del ob_, fb_
-        if old_env is None:
-            os.environ.pop("NFM_SEQ_WIN", None)
-        else:
-            os.environ["NFM_SEQ_WIN"] = old_env
+        for key_, old_ in (("NFM_SEQ_WIN", old_env), ("NFM_SEQ_WIN_EXACT", old_ex)):
+            if old_ is None:
+                os.environ.pop(key_, None)
+            else:
+                os.environ[key_] = old_
         exact["window_fallbacks"] = ctx.timing_get("seq_window_fallback")[0]  # window launches that aborted (must be 0)
-        exact["bit_equal"] = bool(windowed and exact["window_fallbacks"] == 0 and np.array_equal(got_["0"][0].view(np.uint64), got_["2"][0].view(np.uint64))
-                                  and np.array_equal(got_["0"][1].view(np.uint64), got_["2"][1].view(np.uint64))
-                                  and got_["0"][2] == got_["2"][2] and np.isfinite(got_["2"][0]).all())
-        exact["bit_equal_sample"] = "window kernel vs one-workgroup kernel, first %d samples of the shard, P / w / intercept compared as bits" % nb_
+        exact["bit_equal"] = bool(windowed and exact["window_fallbacks"] == 0 and np.array_equal(got_["0"][0].view(np.uint64), got_["2x"][0].view(np.uint64))
+                                  and np.array_equal(got_["0"][1].view(np.uint64), got_["2x"][1].view(np.uint64))
+                                  and got_["0"][2] == got_["2x"][2] and np.isfinite(got_["2x"][0]).all())
+
+        def rel_(a_, b_):  # max |a - b| / (|b| + 1e-12 max|b|) over the tensor
+            b_ = np.asarray(b_, dtype=np.float64)
+            return float(np.max(np.abs(np.asarray(a_) - b_) / (np.abs(b_) + 1e-12 * max(float(np.max(np.abs(b_))), 1e-300)))) if b_.size else 0.0
+
+        exact["max_rel_diff"] = max(rel_(got_["2"][0], got_["0"][0]), rel_(got_["2"][1], got_["0"][1]),
+                                    abs(got_["2"][2] - got_["0"][2]) / max(abs(got_["0"][2]), 1e-300)) if np.isfinite(got_["2"][0]).all() else None
+        exact["bit_equal_sample"] = ("first %d samples of the shard, P / w / intercept after one epoch: bit_equal = the window's term-by-term "
+                                     "flavour (NFM_SEQ_WIN_EXACT=1) against the one-workgroup kernel, as bits; max_rel_diff = the one-term "
+                                     "flavour (the one `value` is measured with) against the one-workgroup kernel (north_star: 1e-6)" % nb_)
         del opt_s, fm_s, Xs, Xb, got_
 
     # ---- what the mini-batch rule costs statistically: c_bar (a formula) and time_to_target (the measurement) ----
@@ -816,7 +898,8 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     t2t = None
     t2t_window = k <= 64 and wl["degree"] <= 6 and (not F or m + m * (m - 1) // 2 <= 252)  # the exact order at speed (seqwin.hip)
     if rank == 0 and world == 1 and t2t_window and n >= 400_000 and not args.no_t2t:
-        t2t = time_to_target_leg(torch, nf, ctx, dev, wl, name, n, batch, cap, indices, data, _keep_fields, task)
+        t2t = time_to_target_leg(torch, nf, ctx, dev, wl, name, n, batch, cap, indices, data, _keep_fields, task,
+                                 batches=[int(v_) for v_ in args.t2t_batches.split(",")] if args.t2t_batches else None)
 
     # ---- roofline leg: per-kernel durations from HIP events on the library's stream (one replica, no exchange) ----
     roof = None
@@ -869,6 +952,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         if exact.get("no_intercept"):  # (the CPU port's step costs the same with or without the intercept's three flops)
             exact["no_intercept"]["vs_cpu_port_1_thread"] = round(exact["no_intercept"]["value"] / cpu["value"], 2)
     return {"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "steps": steps, "warmup": warmup,
+            "value_batch_8192": value_b8192,
             "value_shuffled": None if math.isnan(value_shuffled) else round(value_shuffled, 1),
             "value_shuffled_host_perm": None if math.isnan(value_shuffled_host) else round(value_shuffled_host, 1),
             "shuffled_note": "%d epochs, each over a fresh random order drawn on the device, the next epoch's batch plan built on "
@@ -952,6 +1036,8 @@ def _extra_compact(e):
             "value_shuffled": e.get("value_shuffled"),
             "predict": (e.get("predict") or {}).get("value"), "predict_frac": (e.get("predict") or {}).get("roofline_frac"),
             "exact_order": (e.get("exact_order") or {}).get("value"), "exact_bit_equal": (e.get("exact_order") or {}).get("bit_equal"),
+            "exact_max_rel_diff": (e.get("exact_order") or {}).get("max_rel_diff"),
+            "exact_vs_cpu_1_thread": (e.get("exact_order") or {}).get("vs_cpu_port_1_thread"),
             "exact_no_intercept": ((e.get("exact_order") or {}).get("no_intercept") or {}).get("value"),
             "t2t_batch": t["batch"] if t else None, "t2t_speedup": [h["speedup"] for h in t["targets"]] if t else None,
             "reached": all(h["speedup"] is not None for h in t["targets"]) if t else None,
@@ -968,10 +1054,12 @@ def contract_line(full):
     out["config"] = {"workload": _short(cfg["workload"], 160), "batch": cfg.get("batch"), "touch_cap": cfg.get("touch_cap"),
                      "update_rule": _short(cfg.get("update_rule_short") or cfg.get("update_rule"), 120), "parallelism": _short(cfg.get("parallelism"), 120)}
     out["value_shuffled"] = full.get("value_shuffled")
+    out["value_batch_8192"] = full.get("value_batch_8192")
     p_ = full.get("predict")
     out["predict"] = {"value": p_["value"], "unit": p_["unit"], "roofline_frac": p_["roofline_frac"]} if p_ else None
     x_ = full.get("exact_order")
     out["exact_order"] = {"value": x_["value"], "unit": x_["unit"], "vs_cpu_port_1_thread": x_.get("vs_cpu_port_1_thread"),
+                          "max_rel_diff": x_.get("max_rel_diff"), "term_by_term": x_.get("value_term_by_term"),
                           "bit_equal": x_.get("bit_equal"), "no_intercept": (x_.get("no_intercept") or {}).get("value"),
                           "no_intercept_vs_cpu_port_1_thread": (x_.get("no_intercept") or {}).get("vs_cpu_port_1_thread")} if x_ else None
     out["time_to_target"] = _t2t_compact(full.get("time_to_target"))
@@ -980,6 +1068,9 @@ def contract_line(full):
                                          "progress_per_epoch") if k_ in d_} if d_ else None
     out["roofline"] = _roof_compact(full.get("roofline"))
     out["cpu_baseline"] = _cpu_compact(full.get("cpu_baseline"))
+    c_ = full.get("cpu_baseline") or {}
+    best_cpu = max([v_ for v_ in (c_.get("value"), (c_.get("hogwild") or {}).get("value")) if v_] or [0])
+    out["vs_best_cpu"] = round(full["value"] / best_cpu, 1) if best_cpu else None  # (the faster of 1 thread and the best Hogwild setting)
     ex = full.get("extra")
     out["extra"] = {k_: _extra_compact(v_) for k_, v_ in ex.items()} if ex else None
     out["detail"] = "gpurun_out/bench_detail.json"
@@ -1013,10 +1104,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS) + ["ingest", "psgd"])
     ap.add_argument("--batch", type=int, default=0, help="mini-batch size (default: per workload)")
+    ap.add_argument("--t2t-batches", default="", help="time_to_target: also run these mini-batch sizes (comma separated), smaller or larger")
     ap.add_argument("--n", "--samples", dest="n", type=int, default=0, help="override samples per GPU (--samples under torchrun, whose parser claims --n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra.cfg2 ... extra.cfg5 legs of the default (headline) run")
     ap.add_argument("--no-shuffled", action="store_true", help="skip the shuffled-epoch legs (profiling runs: their plan builds beside the epochs would mix into the per-kernel averages)")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-order (mode=sequential) leg (batch sweeps)")
     ap.add_argument("--no-t2t", action="store_true", help="skip the time_to_target leg (profiling runs: its other batch sizes would mix into the per-kernel averages)")
     ap.add_argument("--no-viol", action="store_true",
                     help="AdaGrad without the reference's viol = sum|P_old - P_new| (no stored copy of P is read or "

@@ -103,12 +103,19 @@ struct Timing {
 
 }  // namespace nfm
 
+namespace nfm {
+struct DevBuf;
+}
 struct nfm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   nfm::Timing timing;
   int n_cu = 256;
+  // decisionFunction of a model with several orders: the table with the orders interleaved per feature (predict.hip).  It
+  // belongs to the context, not to the call: the kernels that read it are still queued on `stream` when the call returns, and
+  // a block handed back to the device-memory cache may go to another stream (nfm_decision_function_device never synchronizes)
+  nfm::DevBuf* predict_pf = nullptr;
 };
 
 namespace nfm {

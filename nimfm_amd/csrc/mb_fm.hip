@@ -226,7 +226,7 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
     NFM_HIP_CHECK(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(W.graph_exec), st));
   } else if (W.use_graph && W.after_batch && W.is_sync && !ctx->timing.enabled && !P.has_perm && P.n_batches >= 8) {
     // a data-parallel epoch over a reusable plan: one graph per stretch of mini-batches between exchange points
-    static const bool seg_on = !(getenv("NFM_DP_GRAPH") && atoi(getenv("NFM_DP_GRAPH")) == 0);
+    const bool seg_on = !(getenv("NFM_DP_GRAPH") && atoi(getenv("NFM_DP_GRAPH")) == 0);  // (read per call: tests compare both ways)
     if (!seg_on) {
       NFM_TRY(enqueue_epoch(ctx, opt_kind, X, M, O, P, W, TA));
     } else if (!W.seg_execs.empty() && W.seg_plan_serial == P.serial && W.seg_data_serial == data_serial && W.seg_opt == opt_kind &&

@@ -42,7 +42,8 @@ struct SeqWin {           // kept on the optimizer between calls
   DevBuf prevq, next;     // [nnz] that feature's entry index in the previous sample's row; next position with the feature
   DevBuf scales, mail, ctl, fw, trace;
   DevBuf snap;            // the model's arena (+ AdaGrad: the state arena) as it was when the call began (abort: put back)
-  int64_t fallbacks = 0;  // calls that ended in the one-workgroup kernel after an abort
+  int64_t fallbacks = 0;  // calls that ended in the one-workgroup kernel after an abort (forgotten one at a time: 16 clean calls each)
+  int64_t clean_calls = 0;
   bool valid = false, had_perm = false;
   uint64_t ds_uid = 0;
   int64_t begin = 0, end = 0, nnz = 0;

@@ -184,8 +184,14 @@ static int predict_orders(nfm_ctx* ctx, const CsrView& X, const ModelView& M, do
   if (LT > kWave || X.nnz + (int64_t)M.n_aug * X.n < 2 * M.da) return NFM_OK;
   int lgL = 0;
   while ((1 << lgL) < M.L) ++lgL;
-  DevBuf Pf;
-  NFM_TRY(Pf.alloc(sizeof(double) * (size_t)M.da * NBP * M.Kp));
+  // the interleaved table lives on the context: this call's kernels are still queued when it returns (see nfm_ctx::predict_pf)
+  if (!ctx->predict_pf) ctx->predict_pf = new DevBuf();
+  DevBuf& Pf = *ctx->predict_pf;
+  const size_t pf_bytes = sizeof(double) * (size_t)M.da * NBP * M.Kp;
+  if (!(Pf.p && pf_bytes <= Pf.bytes)) {
+    NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (growing: an earlier call's kernels may still read the old block)
+    NFM_TRY(Pf.alloc(pf_bytes));
+  }
   TimedLaunch tl(ctx, "predict");
   {
     const int64_t total = M.da * NBP * (M.Kp / 2);
@@ -204,7 +210,7 @@ static int predict_orders(nfm_ctx* ctx, const CsrView& X, const ModelView& M, do
   }
   NFM_TRY(rc);
   *handled = true;
-  return NFM_OK;  // (Pf goes back to this thread's block cache: stream-ordered behind the kernel that reads it)
+  return NFM_OK;
 }
 
 // FFM: yhat = b + sum w x + sum_{j1<j2} x1 x2 <P[f2][j1], P[f1][j2]>

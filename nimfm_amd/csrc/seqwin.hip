@@ -63,7 +63,7 @@ constexpr int kWinRing = 8;    // LDS ring slots between the conductor's fetch a
 constexpr int kWinDepth = 8;   // mailboxes the fetch wavefront has requested ahead (must stay < W, see below)
 constexpr int kWinHdr = 4;     // mailbox tail, after the MC term slots: anova sum, target, eta(alpha0) | eta0 (it-1) alpha0, number of chain terms
 constexpr int kWinMaxNL = 5;   // 64-lane loads per mailbox: rows of up to 316 entries
-constexpr long long kWinTimeoutTicks = 400000000ll;  // 4 s of the 100 MHz wall clock without progress: abort
+constexpr long long kWinTimeoutTicks = 100000000ll;  // 1 s of the 100 MHz wall clock without progress: abort (every legitimate wait is microseconds)
 
 struct WinArgs {
   CsrView X;
@@ -93,9 +93,9 @@ struct WinArgs {
   int no_cond;            // 1: fitIntercept = false -- no scalar chain ties the samples, there is NO conductor: a worker adds up its
                           // sample's prediction itself (intercept constant, the entries' terms in storage order, the interaction
                           // sum: predictWithGrad, sgd.nim:193-201), takes dloss and posts {dL, yhat} for its near successors
-  int dead_slot;          // test hook (NFM_SEQ_WIN_TEST_DEAD_SLOT): this worker leaves at once, as a workgroup that never became
-                          // resident would; -1 otherwise.  The others time out, the launch aborts, the host restores + falls back
-  int fast_exp;           // one-term conductor, logistic loss: the chunk-parallel exponential (NFM_SEQ_WIN_FASTEXP=0 turns it off)
+  int dead_slot;          // -DNFM_TEST_HOOKS builds only (NFM_SEQ_WIN_TEST_DEAD_SLOT): this worker leaves at once, as a workgroup that
+                          // never became resident would; -1 otherwise.  The others time out, the launch aborts, the host restores + falls back
+  int first_worker;       // workgroups ahead of the workers: 1 (workgroup 0 is the conductor) or 0 (no conductor: none is launched)
   int one_term;           // 1 (the default with a conductor; NFM_SEQ_WIN_EXACT=1 turns it off): the worker adds up everything of its
                           // sample's prediction but the intercept -- S = sum_j w_j x_j (storage order) + the interaction sum -- and posts
                           // ONE term; the conductor's chain is  yhat = b + S -> dloss -> b'  (win_conductor_sum).  Same sample order and
@@ -360,7 +360,6 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
     // sample's sum S with it (post_sum): S(A) and the slope are posted at once, the exact row is formed when dL arrives
     bool affine = false;  // (uniform)
     double aff_A = 0.0, aff_B = 0.0, aff_Bw = 0.0;
-    const int q_first = fwdmask ? __builtin_ctzll(fwdmask) : 0;
     const bool mine = (fwdmask >> lane) & 1ull;  // lane = entry
     const int64_t upl = (int64_t)pq - a.seg0;
     const unsigned tagl = (unsigned)(upl + 1);
@@ -2345,7 +2344,7 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
         }
         issue(dd);
       }
-      if ((++rounds & 15) == 0) {  // the launch's abort word and the wall-clock limit (no progress for 4 s)
+      if ((++rounds & 15) == 0) {  // the launch's abort word and the wall-clock limit (no progress for 1 s)
         if (ld_u32(a.ctrl) != 0u || wall_clock64() - t_last > kWinTimeoutTicks) {
           st_u32(a.ctrl, 1u);
           ldsv_store(c_abort, 1u);
@@ -2427,25 +2426,7 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
       const double Sv = ldsv_load_d(rS + idx), yv = ldsv_load_d(rY + idx), hv = ldsv_load_d(rH + idx), Cv = ldsv_load_d(rC + idx);
       const int Wv = (int)ldsv_load(rW + idx);
       const int cnt = (int)(ready - u < kWave ? ready - u : kWave);
-      // Logistic loss: the exponential is two thirds of the chain's dependent operations.  Lane-parallel, once per chunk:
-      // E_t = exp(-|z0_t|) with z0_t = y_t (b0 + S_t), b0 = the intercept at the chunk's start.  In the chain the true
-      // z_t = y_t (b_t + S_t) is formed as before and  exp(-|z_t|) = E_t exp(|z0_t| - |z_t|): the intercept moves by a few
-      // step sizes inside a chunk, so the second factor is a degree-11 polynomial of an argument below 2^-3 (four dependent
-      // operations in Estrin's form instead of the twenty of a full exponential; truncation below 3e-20).  A sample whose S
-      // waits for a writer's dL or a short chunk: the full exponential; an intercept that has moved further: E_t again.
-      [[maybe_unused]] double b0 = b, A0v = 0.0, Ev = 0.0;
-      // (targets of a classification task are -1, 0, +1: |z0 - z| <= |b - b0|; anything else takes the full exponential)
-      [[maybe_unused]] const bool fastc = LOSS == NFM_LOSS_LOGISTIC && a.fast_exp && cnt >= a.fast_exp &&
-                                          __ballot(lane < cnt && !(fabs(yv) <= 1.0)) == 0ull;
       const ull affmask = __ballot(lane < cnt && Wv != 0);  // samples whose S waits for a writer's dL
-      [[maybe_unused]] auto rebase = [&]() {
-        b0 = b;
-        A0v = fabs((b0 + Sv) * yv);
-        Ev = exp(-A0v);
-      };
-      if constexpr (LOSS == NFM_LOSS_LOGISTIC) {
-        if (fastc) rebase();
-      }
       for (int t = 0; t < cnt; ++t) {
         double S = readlane_d(Sv, t);
         const double y = readlane_d(yv, t), h2 = readlane_d(hv, t);
@@ -2465,21 +2446,11 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
         double dL;
         if constexpr (LOSS == NFM_LOSS_LOGISTIC) {
           // loss.nim:66-71 without its branch: z > 0: -y e^{-z} / (1 + e^{-z}), else -y / (e^{z} + 1) -- one exponential of
-          // -|z| serves both (the same operations on the same values: the same bits)
+          // -|z| serves both (the same operations on the same values: the same bits).  (Tried: exp(-|z|) from a per-chunk
+          // lane-parallel exp(-|z0|) times a degree-11 polynomial of |z0| - |z| -- 20 dependent operations fewer per sample,
+          // measured +-0: a wavefront issues an instruction every ~8 cycles whatever it is, and the sample costs ~90 of them.)
           const double z = yh * y;
-          double e;
-          if (fastc && !aff_t) {
-            if (fabs(b - b0) > 0x1p-3) rebase();  // (rare: all lanes again from the current intercept)
-            const double x = readlane_d(A0v, t) - fabs(z);
-            const double x2 = x * x;
-            const double p01 = 1.0 + x, p23 = fma(x, 1.0 / 6, 0.5), p45 = fma(x, 1.0 / 120, 1.0 / 24), p67 = fma(x, 1.0 / 5040, 1.0 / 720),
-                         p89 = fma(x, 1.0 / 362880, 1.0 / 40320), pab = fma(x, 1.0 / 39916800, 1.0 / 3628800);
-            const double x4 = x2 * x2, q0 = fma(x2, p23, p01), q1 = fma(x2, p67, p45), q2 = fma(x2, pab, p89);
-            const double x8 = x4 * x4, r0 = fma(x4, q1, q0);
-            e = readlane_d(Ev, t) * fma(x8, q2, r0);
-          } else {
-            e = exp(-fabs(z));
-          }
+          const double e = exp(-fabs(z));
           const double num = z > 0 ? -y * e : -y;
           dL = num / (1 + e);
         } else {
@@ -3168,9 +3139,11 @@ enum { WK_GENERAL = 0, WK_K64 = 1, WK_FFM = 2, WK_FMX = 3 };  // which worker
 template <int OPT, int CH, int WK>
 __global__ __launch_bounds__(kFfmWaves * kWave) void k_seq_window(WinArgs a) {
   extern __shared__ double lds[];
-  if (a.dead_slot >= 0 && (int)blockIdx.x == a.dead_slot + 1) return;  // (test hook; workgroup 0 is the conductor)
-  if (blockIdx.x == 0) {
-    if (a.no_cond) return;  // nothing to conduct: the workers form their samples' predictions themselves
+  const int nb0 = a.first_worker;
+#ifdef NFM_TEST_HOOKS
+  if (a.dead_slot >= 0 && (int)blockIdx.x == a.dead_slot + nb0) return;
+#endif
+  if ((int)blockIdx.x < nb0) {
     if (threadIdx.x < (a.one_term ? 3 : 2) * kWave) {  // (one-term: fetch, chain and post wavefronts)
       if (a.one_term) {
         if (a.W == 2 * kWave) win_conductor_sum<OPT, 2>(a, lds);
@@ -3182,12 +3155,12 @@ __global__ __launch_bounds__(kFfmWaves * kWave) void k_seq_window(WinArgs a) {
       __syncthreads();  // (the conductor's one barrier: the workgroup's idle wavefronts pass it and leave)
     }
   } else if constexpr (WK == WK_FFM) {
-    win_worker_ffm<OPT>(a, (int)blockIdx.x - 1, lds);  // all wavefronts of the workgroup
+    win_worker_ffm<OPT>(a, (int)blockIdx.x - nb0, lds);  // all wavefronts of the workgroup
   } else if constexpr (WK == WK_FMX) {
-    win_worker_fmx<OPT>(a, (int)blockIdx.x - 1, lds);
+    win_worker_fmx<OPT>(a, (int)blockIdx.x - nb0, lds);
   } else if (threadIdx.x < kWave) {
-    if constexpr (WK == WK_K64) win_worker_k64<OPT>(a, (int)blockIdx.x - 1, lds);
-    else win_worker<OPT>(a, (int)blockIdx.x - 1, lds);
+    if constexpr (WK == WK_K64) win_worker_k64<OPT>(a, (int)blockIdx.x - nb0, lds);
+    else win_worker<OPT>(a, (int)blockIdx.x - nb0, lds);
   }
 }
 
@@ -3467,7 +3440,20 @@ static int launch_window_t(nfm_ctx* ctx, const WinArgs& a, size_t lds_bytes) {
   if (per_cu < 1) return NFM_WIN_FALLBACK;
   ctx->timing.acc["seq_window_launch"].launches += 1;  // (counted with timing on or off: the tests ask which kernel ran)
   TimedLaunch tl(ctx, "sequential");
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.W + 1)), dim3(threads), lds_bytes, ctx->stream, a);
+  const unsigned grid = (unsigned)(a.W + a.first_worker);
+  if ((int)grid >= ctx->n_cu) {
+    // a workgroup on EVERY CU, all waiting for each other: a cooperative launch, which the runtime starts only when the
+    // whole grid can be resident at once (the occupancy query above says one workgroup fits a CU; it cannot say the CUs are free)
+    WinArgs a_ = a;
+    void* params[] = {&a_};
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3(grid), dim3(threads), params, (unsigned)lds_bytes, ctx->stream);
+    if (e == hipSuccess) {
+      ctx->timing.acc["seq_window_cooperative"].launches += 1;
+      return NFM_OK;
+    }
+    (void)hipGetLastError();  // (not supported / too large for this device: the plain launch, guarded by its time limits)
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_bytes, ctx->stream, a);
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }
@@ -3495,7 +3481,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   int W = no_cond ? 128 : 64;  // (with a conductor the chain is the bound at 64 workers already: measured, 128 gain nothing)
   // rows of 64 factors without a conductor: a worker on EVERY CU (headline shape 5.8e6 -> 7.1e6 samples/s, AdaGrad 3.8e6 -> 5.9e6;
   // shorter rows conflict too often to gain) -- until a launch of this optimizer has aborted once: such a launch needs the
-  // whole chip resident, and a tenant that holds a single CU would cost every call its 4 s limit.  (After a second abort
+  // whole chip resident, and a tenant that holds a single CU would cost every call its 1 s limit.  (After a second abort
   // nfm_opt_epoch stops offering the window to this optimizer at all.)
   if (no_cond && M.kind == NFM_KIND_FM && M.nb == 1 && M.degree == 2 && M.Kp == kWave && m_cap <= kWave && sw->fallbacks == 0) W = 256;
   if (const char* env = getenv("NFM_SEQ_WIN_W")) W = atoi(env);
@@ -3527,11 +3513,9 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     sw->end = end;
     sw->nnz = X.nnz;
   }
-  int np = no_cond ? 4 : 2;  // without a conductor the workers may run further apart (see the workers' run-ahead check)
-  if (const char* env = getenv("NFM_SEQ_WIN_NP")) {  // tuning: 2, 4 or 8 buffer sets per worker
-    const int v = atoi(env);
-    if (no_cond && (v == 2 || v == 4 || v == 8)) np = v;
-  }
+  // without a conductor the workers may run further apart (see the workers' run-ahead check): four buffer sets per worker
+  // (measured: 2 / 4 / 8 sets 6.5e6 / 7.6e6 / 7.6e6 samples/s on the headline shape)
+  const int np = no_cond ? 4 : 2;
   const size_t n_fwd = one_term ? (size_t)kSumGran * np * W : (size_t)W * np * FW, n_res = (size_t)W * np * kResWords;
   NFM_TRY(sw->mail.ensure(sizeof(ull) * (n_fwd + n_res)));
   NFM_TRY(sw->ctl.ensure(sizeof(unsigned) * (W + 64) + sizeof(double) * 2 * (W + 1) + sizeof(int64_t) * 2));
@@ -3563,25 +3547,20 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   a.W = W;
   a.lgW = lgW;
   a.no_cond = no_cond ? 1 : 0;
+  a.first_worker = no_cond ? 0 : 1;
   a.one_term = one_term ? 1 : 0;
-  a.fast_exp = 4;  // (the shortest chunk that takes the chunk-parallel exponential)
-  if (const char* env = getenv("NFM_SEQ_WIN_FASTEXP")) a.fast_exp = atoi(env);
   a.np = np;
   // without a conductor: how far back a dependency may lie and still take the recipe path, and how far apart the workers may run
-  int thr = np - 1, near_r = W;
-  if (no_cond) {
-    // (measured, headline shape at 256 workers / cfg2's at 128: np 4, thr 3 -- recipes for dependencies up to W back -- 7.3e6 /
-    // 5.5e6 samples/s; recipes up to 2W or 4W back (np 4 thr 2, np 8 thr 4) 7.1e6 / 5.2e6: the longer reach only adds recipe stores)
-    if (const char* env = getenv("NFM_SEQ_WIN_THR")) {
-      const int v = atoi(env);
-      if (v >= 1 && v < np) thr = v;
-    }
-    near_r = (np - thr) * W;
-  }
+  // without a conductor: how far back a dependency may lie and still take the recipe path (W), and how far apart the workers
+  // may run (measured, headline shape at 256 workers / cfg2's at 128: recipes for dependencies up to W back 7.3e6 / 5.5e6
+  // samples/s; up to 2W or 4W back 7.1e6 / 5.2e6: the longer reach only adds recipe stores)
+  const int thr = np - 1, near_r = W;
   a.thr = thr;
   a.near_r = near_r;
   a.dead_slot = -1;
-  if (const char* env = getenv("NFM_SEQ_WIN_TEST_DEAD_SLOT")) a.dead_slot = atoi(env);  // test hook, see WinArgs
+#ifdef NFM_TEST_HOOKS  // (libnimfm_hip_testhooks.so only: the product library has no test hooks)
+  if (const char* env = getenv("NFM_SEQ_WIN_TEST_DEAD_SLOT")) a.dead_slot = atoi(env);  // see WinArgs
+#endif
   a.m_cap = m_cap;
   a.FW = FW;
   a.lgKp = lgKp;

@@ -255,6 +255,50 @@ def test_rccl_group_world1():
         grp.close()
 
 
+@pytest.mark.parametrize("solver,overlap", [("sgd", True), ("sgd", False), ("adagrad", True), ("adagrad", False)])
+def test_segment_graphs_between_exchange_points_equal_direct_launches(solver, overlap):
+    """With a multi-process (RCCL) group attached, the mini-batches BETWEEN two exchange points are captured as one hipGraph each
+    on the first epoch over a plan and replayed afterwards (mb_fm.hip: MbWork::seg_execs); the exchange stays outside the
+    capture.  World size 1 through RCCL takes exactly that path on one GPU.  Four epochs, the exchange period changed after
+    the second (the graphs must be dropped and cut again), against the same fit with NFM_DP_GRAPH=0 (every launch direct):
+    bit for bit, history included."""
+    n, b = 64 * 40 + 17, 64  # 40 full mini-batches and a tail: >= 8, the path's own threshold
+    full = random_csr(n, D, M, seed=14)
+    rng = np.random.default_rng(12)
+    y = rng.standard_normal(n)
+    P0, w0 = rng.standard_normal((1, K, D)) * 0.05, np.zeros(D)
+    ctx = nf.default_context()
+    grp = dp.Group.rccl(ctx, dp.Group.unique_id(), 0, 1)
+    try:
+        X = nf.CSRDataset(full.data, full.indices, full.indptr, n, D, ctx=ctx)
+        res = []
+        for graph in ("0", "1"):
+            old = os.environ.get("NFM_DP_GRAPH")
+            os.environ["NFM_DP_GRAPH"] = graph
+            try:
+                fm = gpu_fm("regression", 2, K, "explicit", True, True, P0, w0, 0.0)
+                opt = (nf.newSGD if solver == "sgd" else nf.newAdaGrad)(maxIter=2, verbose=0, tol=0, shuffle=False, mode="minibatch",
+                                                                         batch=b)
+                opt.setDataParallel(grp, 4, overlap)
+                opt.fit(X, y, fm)
+                hist = list(opt.history)
+                opt.setDataParallel(grp, 7, overlap)  # another period: other cut points
+                opt.fit(X, y, fm)
+                hist += list(opt.history)
+                res.append((fm.P.copy(), fm.w.copy(), fm.intercept, hist, opt.it))
+            finally:
+                if old is None:
+                    os.environ.pop("NFM_DP_GRAPH", None)
+                else:
+                    os.environ["NFM_DP_GRAPH"] = old
+        assert res[0][4] == res[1][4] == 1 + 4 * n
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+        assert res[0][3] == res[1][3], "loss / viol per epoch"
+        assert np.isfinite(res[1][0]).all() and not np.array_equal(res[1][0], P0)
+    finally:
+        grp.close()
+
+
 def test_data_parallel_training_and_held_out_quality():
     """Convergence evidence for the exchange: a planted degree-2 FM, 4 ranks (a quarter of the samples
     each, replicas reconciled every 8 mini-batches and at the end of every epoch) against ONE rank, the same number of
