@@ -1210,7 +1210,7 @@ def main():
         out = {"metric": "SGD training samples/sec/epoch", "value": res["value"], "unit": "samples/s",
                "n_gpus": world, "steps": res["steps"], "warmup": res["warmup"], "ms_per_step": res["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": res["config"], "value_shuffled": res["value_shuffled"],
+               "config": res["config"], "value_batch_8192": res.get("value_batch_8192"), "value_shuffled": res["value_shuffled"],
                "value_shuffled_host_perm": res["value_shuffled_host_perm"], "shuffled_note": res["shuffled_note"],
                "last_step": res["last_step"], "predict": res["predict"], "exact_order": res["exact_order"],
                "effective": res["effective"], "time_to_target": res["time_to_target"], "dp": res["dp"],

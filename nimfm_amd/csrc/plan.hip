@@ -1128,8 +1128,7 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
     if (!use_csc && seg_on && n_aug == 0 && bt >= 8192.0 && P.max_batch < ((int64_t)1 << kSegPosBits) &&
         X.max_row < (1 << kSegPosBits) && X.d < ((int64_t)1 << 31) && !(csc && csc->seg_unfit)) {
       static const int fl_env = getenv("NFM_SEG_FL") ? atoi(getenv("NFM_SEG_FL")) : 0;
-      static const int tgt_env = getenv("NFM_SEG_CELL") ? atoi(getenv("NFM_SEG_CELL")) : 0;
-      const double target = tgt_env > 0 ? tgt_env : 2048.0;  // touches per cell aimed at
+      const double target = 2048.0;  // touches per cell aimed at (measured +-0 from 500 to 2000: no knob)
       int fl = 8;
       while (fl < 12 && (double)(((X.d - 1) >> (fl + 1)) + 1) * target >= bt) ++fl;  // the largest bucket count with >= target per cell
       if (fl_env >= 8 && fl_env <= 12) fl = fl_env;

@@ -95,6 +95,7 @@ struct WinArgs {
                           // sum: predictWithGrad, sgd.nim:193-201), takes dloss and posts {dL, yhat} for its near successors
   int dead_slot;          // -DNFM_TEST_HOOKS builds only (NFM_SEQ_WIN_TEST_DEAD_SLOT): this worker leaves at once, as a workgroup that
                           // never became resident would; -1 otherwise.  The others time out, the launch aborts, the host restores + falls back
+  int par_min;            // one-term conductor: the shortest chunk of ready samples whose chain is solved in parallel (0: never)
   int first_worker;       // workgroups ahead of the workers: 1 (workgroup 0 is the conductor) or 0 (no conductor: none is launched)
   int one_term;           // 1 (the default with a conductor; NFM_SEQ_WIN_EXACT=1 turns it off): the worker adds up everything of its
                           // sample's prediction but the intercept -- S = sum_j w_j x_j (storage order) + the interaction sum -- and posts
@@ -263,6 +264,31 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       // of the shared row in its forwarding area; every other one is waited for by its counter
       near = pend && (pos - (int64_t)pq) < a.near_r && pqu < kWave;
     }
+    // One-term window, SGD: the shared row of the MOST RECENT earlier sample inside the window is treated as AFFINE in that
+    // sample's dL (post_sum) -- chosen by POSITIONS alone (never by what happens to be finished when this worker looks), so that
+    // the arithmetic, and with it every bit of the result, is the same from run to run; provided that writer shares exactly
+    // one feature with this sample (two rows moving with the same dL would make S quadratic in it).  The earlier writers' dL
+    // come first (the conductor makes them in order) and are waited for.
+    int aff_q = -1;
+    ull aff_bit = 0ull;
+    if constexpr (!ADA) {
+      if (a.one_term) {
+        const int64_t vq_ = (int64_t)pq - a.seg0;
+        const bool cand = vq_ >= 0 && (pos - (int64_t)pq) < a.near_r && pqu < kWave;
+        int latest = cand ? (int)vq_ : -1;
+#pragma unroll
+        for (int sh = 1; sh < kWave; sh <<= 1) {
+          const int o_ = __shfl_xor(latest, sh, kWave);
+          latest = o_ > latest ? o_ : latest;
+        }
+        const ull who = __ballot(cand && (int)vq_ == latest);
+        if (who != 0ull && (who & (who - 1)) == 0ull) {
+          aff_q = __builtin_ctzll(who);
+          aff_bit = who;
+        }
+      }
+    }
+    near = near || lane == aff_q;
     const ull fwdmask = __ballot(near);
     const ull hotmask = __ballot(nq >= 0 && ((int64_t)nq - pos) < a.near_r);  // rows a near successor will ask the recipe of
     for (int q = lane; q < mc; q += kWave) {
@@ -394,11 +420,13 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       return ok;
     };
     // the exact rows of the near dependencies in `which` (and the shared features' linear weights) once the writers' dL are in hand
+    int have_q = -1;  // the shared row whose recipe is kept in (have_a1, have_pv): read before the mailbox was posted
+    double have_a1 = 0.0, have_pv = 0.0;
     auto form_near_rows = [&](ull which) -> bool {
       for (ull mk = which; mk; mk &= mk - 1) {
         const int q = __builtin_ctzll(mk);
-        double a1u, pv, gv = 0.0, nv = 0.0;
-        {
+        double a1u = have_a1, pv = have_pv, gv = 0.0, nv = 0.0;
+        if (q != have_q) {
           Spin sp;
           while (!__all(load_recipe(q, a1u, pv, gv, nv)))
             if (sp.wait(a.ctrl)) return false;
@@ -452,27 +480,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       compiler_fence();
       return true;
     };
-    // The affine candidate: the shared row of the MOST RECENT writer -- the conductor makes the dL in order, so the others'
-    // arrive first and are waited for as before -- provided that writer shares exactly one feature with this sample (two rows
-    // moving with the same dL would make S quadratic in it).
-    int aff_q = -1;
-    ull aff_bit = 0ull;
     if (fwdmask) {
-      if constexpr (!ADA) {
-        if (a.one_term) {
-          int latest = mine ? (int)upl : -1;
-#pragma unroll
-          for (int sh = 1; sh < kWave; sh <<= 1) {
-            const int o_ = __shfl_xor(latest, sh, kWave);
-            latest = o_ > latest ? o_ : latest;
-          }
-          const ull who = __ballot(mine && (int)upl == latest);
-          if ((who & (who - 1)) == 0ull) {
-            aff_q = __builtin_ctzll(who);
-            aff_bit = who;
-          }
-        }
-      }
       load_lin();
       if constexpr (!ADA) {  // the writers' scales and step sizes: functions of their step counters alone
         if (mine) {
@@ -490,10 +498,14 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
           bool ok = true;
           if (mine) ok = fw_load(rsrcl, tagl, dLl);
           if (!__all(okl)) load_lin();
-          if (__all(ok)) break;
-          // every dL but the most recent writer's is here, and so is that writer's recipe: S as a function of its dL
-          if (aff_q >= 0 && __all(ok || lane == aff_q) && __all(okl) && __all(load_recipe(aff_q, a1f, pvf, gvf, nvf))) {
-            affine = true;
+          // every dL but the affine writer's is here, and so is that writer's recipe: S as a function of its dL -- whether or
+          // not that dL exists already (the same arithmetic every run)
+          if (aff_q >= 0) {
+            if (__all(ok || lane == aff_q) && __all(okl) && __all(load_recipe(aff_q, a1f, pvf, gvf, nvf))) {
+              affine = true;
+              break;
+            }
+          } else if (__all(ok)) {
             break;
           }
           if (sp.wait(a.ctrl)) return;
@@ -518,6 +530,9 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
           const double pw = sPu * pvf;
           aff_A = (pw - etaPu * (O.beta * pw)) / sPnu;
           aff_B = -(etaPu * (vsu * (a1f - pw * vsu))) / sPnu;
+          have_q = q;  // (kept: the writer's forwarding area may be reused by the time this sample's second half runs)
+          have_a1 = a1f;
+          have_pv = pvf;
           Pl[(size_t)q * Kp + s] = aff_A;
           Tl[(size_t)q * Kp + s] = vl[q] * (sP * aff_A);
           if (lane == q) {  // the shared feature's linear weight the same way (fit_linear.nim:41-47): Aw + dL Bw
@@ -2241,6 +2256,30 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 // A worker posts sample u + W only after it has seen the answer for u, so at most W samples are outstanding: the ring
 // (kSumRing >= 2 W slots) needs no "consumed" counter, and a mailbox can be reused two samples of its worker later.
 // ------------------------------------------------------------------------------------------------------------------
+// dloss(y, p) and its derivative in p (loss.nim:15-102, the Huber quirk kept): what the chunk-parallel chain linearises
+template <int LOSS>
+__device__ __forceinline__ double loss_grad_slope(double param, double y, double p, double& slope) {
+  if constexpr (LOSS == NFM_LOSS_SQUARED) {
+    slope = 1.0;
+    return p - y;
+  } else if constexpr (LOSS == NFM_LOSS_SQUARED_HINGE) {
+    const double z = 1 - p * y;
+    slope = z > 0 ? 2 * y * y : 0.0;
+    return z > 0 ? -2 * y * z : 0.0;
+  } else if constexpr (LOSS == NFM_LOSS_LOGISTIC) {
+    const double z = p * y;
+    const double e = exp(-fabs(z));
+    const double r = 1.0 / (1 + e);
+    slope = (y * y) * (e * r) * r;  // y^2 sigma (1 - sigma)
+    const double num = z > 0 ? -y * e : -y;
+    return num / (1 + e);
+  } else {
+    const double z = fabs(y - p);
+    slope = z < param ? -1.0 : 0.0;
+    return z < param ? y - p : param;
+  }
+}
+
 constexpr int kSumRing = 256;  // LDS ring, in samples (a power of two >= 2 W)
 constexpr int kSumDepth = 2;   // poll rounds in flight
 typedef __attribute__((address_space(3))) double lds_double;
@@ -2427,7 +2466,91 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
       const int Wv = (int)ldsv_load(rW + idx);
       const int cnt = (int)(ready - u < kWave ? ready - u : kWave);
       const ull affmask = __ballot(lane < cnt && Wv != 0);  // samples whose S waits for a writer's dL
-      for (int t = 0; t < cnt; ++t) {
+      // ---- the chunk in parallel (SGD).  A wavefront issues an instruction every ~8 cycles, and the sample-by-sample loop
+      // below costs ~90 of them per sample: with a backlog it IS the window's bound.  But the chain is a recurrence in ONE
+      // number:  b' = b - h (dloss(y, b + S) + alpha0 b).  Linearised around estimates bt_t of the intercept before each sample,
+      // dloss = d_t + g_t (b - bt_t), it is an affine map b' = A_t b + B_t per sample, and affine maps compose associatively:
+      // a prefix scan over the lanes (lane = sample) gives every b_t at once; new estimates, again -- Newton's method on the whole
+      // chunk, quadratic: from bt_t = b_0 the estimates are exact to rounding after three or four passes (squared loss: the
+      // recurrence IS affine, one pass).  A pass costs ~100 instructions for 64 samples.  The result satisfies the reference's
+      // recurrence to ~1e-16 relative (the scan associates the products differently): the one-term flavour's tolerance, not bits.
+      // A sample whose S waits for the dL of a writer inside the same chunk takes that dL from the previous pass.  No
+      // convergence in eight passes (or a NaN): the sample-by-sample loop.
+      bool chunk_done = false;
+      if constexpr (!ADA) {
+        if (a.par_min > 0 && cnt >= a.par_min) {
+          const bool in = lane < cnt;
+          const int widx = Wv != 0 ? Wv - 1 : 0;                 // the writer's sample (affine lanes)
+          const bool w_here = Wv != 0 && (int64_t)widx >= u;        // ... inside this chunk: its dL is being found, too
+          const double dLw_old = (in && Wv != 0 && !w_here) ? ldsv_load_d(rD + (widx & (kSumRing - 1))) : 0.0;
+          const double S0 = (in && Wv != 0 && !w_here) ? Sv + dLw_old * Cv : Sv;
+          double bt = b, St = S0, dLt = 0.0, yht = 0.0, updt = 0.0, bnext = b;
+          bool conv = false;
+          const bool coupled = __any(in && w_here);
+          // Newton converges quadratically: estimates that moved by less than 1e-9 of their scale are exact to rounding after
+          // this pass.  The coupling through a writer inside the chunk converges linearly (its dL enters one pass late): 1e-13.
+          const double tol_rel = coupled ? 1e-13 : 1e-9;
+          for (int pass = 0; pass < 8 && !conv; ++pass) {
+            const double dLprev = dLt;
+            if (pass > 0 && coupled) {  // S of the samples that wait for a dL of this chunk
+              const double dLw = __shfl(dLt, (int)((int64_t)widx - u) & (kWave - 1), kWave);
+              St = (in && w_here) ? S0 + dLw * Cv : S0;
+            }
+            double g;
+            yht = bt + St;
+            dLt = loss_grad_slope<LOSS>(O.loss_param, yv, yht, g);
+            // b' = b - h (d + g (b - bt) + alpha0 b) = A b + B
+            double A = 1.0, B = 0.0;
+            if (fit_b && in) {
+              A = 1.0 - hv * (g + O.alpha0);
+              B = -hv * (dLt - g * bt);
+            }
+            double PA = A, PB = B;
+#pragma unroll
+            for (int dd = 1; dd < kWave; dd <<= 1) {
+              const double Ap = __shfl_up(PA, dd, kWave), Bp = __shfl_up(PB, dd, kWave);
+              if (lane >= dd) {
+                PB = PA * Bp + PB;
+                PA = PA * Ap;
+              }
+            }
+            const double after = PA * b + PB;                       // the intercept after this lane's sample
+            const double before = __shfl_up(after, 1, kWave);
+            const double bt_new = lane == 0 ? b : before;
+            // converged: no estimate moved (scale: the intercept and a chunk's worth of its steps), nor a writer's dL
+            const double scale = fabs(bt_new) + 64.0 * fabs(hv * dLt) + 1e-300;
+            bool moved = in && !(fabs(bt_new - bt) <= tol_rel * scale);
+            if (coupled) moved = moved || pass == 0 || (in && !(fabs(dLt - dLprev) <= tol_rel * (fabs(dLt) + 1e-300)));
+            conv = !__any(moved);
+            bt = bt_new;
+            bnext = after;
+            updt = in && fit_b ? hv * (dLt + O.alpha0 * bt) : 0.0;
+            if (conv && pass == 0) {  // (the estimates did not move: dLt, yht are already those of bt)
+            } else if (conv) {
+              double g2;
+              yht = bt + St;
+              dLt = loss_grad_slope<LOSS>(O.loss_param, yv, yht, g2);
+              updt = in && fit_b ? hv * (dLt + O.alpha0 * bt) : 0.0;
+            }
+          }
+          if (conv) {
+            const int di = (int)((u + lane) & (kSumRing - 1));
+            if (in) {
+              rD[di] = dLt;
+              rP[di] = yht;
+            }
+            viol_b += dev::wave_sum(fabs(updt));
+            b = readlane_d(bnext, cnt - 1);
+            lds_fence_order();
+            if (lane == 0) ldsv_store(c_done, (unsigned)(u + cnt));
+            if constexpr (TRACE) {
+              if (in) a.trace[(u + lane) * 8 + 6] = wall_clock64();
+            }
+            chunk_done = true;
+          }
+        }
+      }
+      for (int t = 0; t < cnt && !chunk_done; ++t) {
         double S = readlane_d(Sv, t);
         const double y = readlane_d(yv, t), h2 = readlane_d(hv, t);
         const int64_t uu = u + t;
@@ -2603,7 +2726,32 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     compiler_fence();
     // entries whose previous sample is not known to be finished: a NEAR one (fewer than W positions back) left the recipe
     // of the shared row in its forwarding area; a far one is waited for by its counter
-    const bool pend = pending(), near = pend && (pos - (int64_t)pq) < a.near_r;
+    const bool pend = pending();
+    // One-term window, SGD: the shared row of the MOST RECENT earlier sample inside the window is treated as AFFINE in that
+    // sample's dL (post_sum) -- chosen by POSITIONS alone (never by what happens to be finished when this worker looks), so that
+    // the arithmetic, and with it every bit of the result, is the same from run to run; provided that writer shares exactly
+    // one feature with this sample (two rows moving with the same dL would make S quadratic in it).  The earlier writers' dL
+    // come first (the conductor makes them in order) and are waited for.
+    int aff_q = -1;
+    ull aff_bit = 0ull;
+    if constexpr (!ADA) {
+      if (a.one_term) {
+        const int64_t vq_ = (int64_t)pq - a.seg0;
+        const bool cand = vq_ >= 0 && (pos - (int64_t)pq) < a.near_r;
+        int latest = cand ? (int)vq_ : -1;
+#pragma unroll
+        for (int sh = 1; sh < kWave; sh <<= 1) {
+          const int o_ = __shfl_xor(latest, sh, kWave);
+          latest = o_ > latest ? o_ : latest;
+        }
+        const ull who = __ballot(cand && (int)vq_ == latest);
+        if (who != 0ull && (who & (who - 1)) == 0ull) {
+          aff_q = __builtin_ctzll(who);
+          aff_bit = who;
+        }
+      }
+    }
+    const bool near = (pend && (pos - (int64_t)pq) < a.near_r) || lane == aff_q;
     const ull fwdmask = __ballot(near), farmask = __ballot(pend && !near), latemask = fwdmask | farmask;
     if (a.trace && lane == 0) a.trace[u * 8 + 0] = wall_clock64();  // sample taken up
     const bool late = (latemask >> lane) & 1ull;
@@ -2718,7 +2866,7 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     // One-term window, SGD, ONE such row whose writer's dL is not there yet: the row is affine in that dL (A + dL B), the
     // sample's sum S with it (post_sum): S(A) and the slope are posted at once, the exact row is formed when dL arrives
     bool affine = false;  // (uniform)
-    double aff_A = 0.0, aff_B = 0.0, aff_Bw = 0.0;
+    double aff_A = 0.0, aff_B = 0.0, aff_Bw = 0.0, aff_a1u = 0.0, aff_pv = 0.0;
     const unsigned mytag = (unsigned)(u + 1);
     const int q_first = fwdmask ? __builtin_ctzll(fwdmask) : 0;
     // the writers' side of the recipes (kept for the affine path's second half)
@@ -2795,27 +2943,7 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       }
       return true;
     };
-    // The affine candidate: the shared row of the MOST RECENT writer -- the conductor makes the dL in order, so the others'
-    // arrive first and are waited for as before -- provided that writer shares exactly one feature with this sample (two rows
-    // moving with the same dL would make S quadratic in it).
-    int aff_q = -1;
-    ull aff_bit = 0ull;
     if (fwdmask) {
-      if constexpr (!ADA) {
-        if (a.one_term) {
-          int latest = mine ? (int)upl : -1;
-#pragma unroll
-          for (int sh = 1; sh < kWave; sh <<= 1) {
-            const int o_ = __shfl_xor(latest, sh, kWave);
-            latest = o_ > latest ? o_ : latest;
-          }
-          const ull who = __ballot(mine && (int)upl == latest);
-          if ((who & (who - 1)) == 0ull) {
-            aff_q = __builtin_ctzll(who);
-            aff_bit = who;
-          }
-        }
-      }
       // Everything the recipes hold was posted at the writers' forward passes, long ago: it is requested FIRST (the
       // shared entries' lanes: their entry's part; all lanes: one shared row's part), the poll for the writers' dL
       // runs while those loads are in flight, and only then are the recipes' tags looked at.
@@ -2842,10 +2970,14 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
           if (mine) ok = fw_load(rsrcl, tagl, dLl);
           if (!__all(okl)) load_lin();
           if (!__all(okr)) load_row(q_pre);
-          if (__all(ok)) break;
-          // every dL but the most recent writer's is here, and so is that writer's recipe: S as a function of its dL
-          if (aff_q >= 0 && __all(ok || lane == aff_q) && __all(okl) && __all(okr)) {
-            affine = true;
+          // every dL but the affine writer's is here, and so is that writer's recipe: S as a function of its dL -- whether or
+          // not that dL exists already (the same arithmetic every run)
+          if (aff_q >= 0) {
+            if (__all(ok || lane == aff_q) && __all(okl) && __all(okr)) {
+              affine = true;
+              break;
+            }
+          } else if (__all(ok)) {
             break;
           }
           if (sp.wait(a.ctrl)) return;
@@ -2870,6 +3002,8 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
           const double p = sPu * pv;
           aff_A = (p - etaPu * (O.beta * p)) / sPnu;
           aff_B = -(etaPu * (vsu * (a1u - p * vsu))) / sPnu;
+          aff_a1u = a1u;  // (kept: the writer's forwarding area may be reused by the time this sample's second half runs)
+          aff_pv = pv;
           if (!form_near_rows(fwdmask & ~aff_bit)) return;  // (the earlier writers' rows: exact)
           Fl[q * K + lane] = aff_A;
           if (lane == q) {  // the shared feature's linear weight the same way (fit_linear.nim:41-47): Aw + dL Bw
@@ -2968,6 +3102,10 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
             if (sp.wait(a.ctrl)) return;
           }
         }
+        a1u = aff_a1u;  // (the recipe as read before the mailbox was posted)
+        pv = aff_pv;
+        q_loaded = aff_q;
+        okr = true;
         if (!form_near_rows(aff_bit)) return;
         apply_late(aff_bit);
         a1 = 0.0;
@@ -3478,7 +3616,11 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   // the intercept is fitted: the ONE-TERM chain (the worker adds up its sample's prediction but the intercept) unless
   // NFM_SEQ_WIN_EXACT=1 asks for the reference's term-by-term rounding
   bool one_term = win_one_term(M);
-  int W = no_cond ? 128 : 64;  // (with a conductor the chain is the bound at 64 workers already: measured, 128 gain nothing)
+  // with a conductor: 128 workers for the register-resident worker (64-factor rows: headline shape 2.36e6 -> 2.58e6 samples/s,
+  // 2.8e6 with the chunk-parallel chain), 64 for the others (cfg2's shape: 2.36e6 against 2.2e6 at 128 -- its samples conflict
+  // ten times as often, and every sample in flight is one more writer to wait for)
+  const bool k64_shape = M.kind == NFM_KIND_FM && M.nb == 1 && M.degree == 2 && M.Kp == kWave && m_cap <= kWave;
+  int W = no_cond || k64_shape ? 128 : 64;
   // rows of 64 factors without a conductor: a worker on EVERY CU (headline shape 5.8e6 -> 7.1e6 samples/s, AdaGrad 3.8e6 -> 5.9e6;
   // shorter rows conflict too often to gain) -- until a launch of this optimizer has aborted once: such a launch needs the
   // whole chip resident, and a tenant that holds a single CU would cost every call its 1 s limit.  (After a second abort
@@ -3549,6 +3691,8 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   a.no_cond = no_cond ? 1 : 0;
   a.first_worker = no_cond ? 0 : 1;
   a.one_term = one_term ? 1 : 0;
+  a.par_min = 6;  // (a parallel solve costs about as much as five or six samples of the serial loop)
+  if (const char* env = getenv("NFM_SEQ_WIN_PAR")) a.par_min = atoi(env);  // 0: the sample-by-sample chain only
   a.np = np;
   // without a conductor: how far back a dependency may lie and still take the recipe path, and how far apart the workers may run
   // without a conductor: how far back a dependency may lie and still take the recipe path (W), and how far apart the workers
@@ -3581,6 +3725,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     int64_t last = ns - 1;
     int64_t host_info[2] = {ns - 1, 0};
     if (!ada) {
+      TimedLaunch tls(ctx, "seq_window_scales");
       hipLaunchKernelGGL(k_win_scales, dim3(1), dim3(kWave), 0, st, M, O, it0 + pos, pos, ns, sw->scales.as<double>(), info);
       NFM_HIP_CHECK(hipMemcpyAsync(host_info, info, sizeof(host_info), hipMemcpyDeviceToHost, st));
       NFM_HIP_CHECK(hipStreamSynchronize(st));

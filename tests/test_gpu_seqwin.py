@@ -602,6 +602,32 @@ def test_field_aware_window_without_a_conductor(kind, F, k, d, max_m, W):
     assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
 
 
+@pytest.mark.parametrize("kind,shape", [("sgd", "k64"), ("sgd", "general"), ("adagrad", "k64")])
+def test_one_term_window_is_bitwise_reproducible_with_the_sample_by_sample_chain(kind, shape):
+    """The one-term flavour's arithmetic is fixed by POSITIONS (which row is treated as affine in its writer's dL never
+    depends on what happens to be finished when a worker looks), so with the conductor's sample-by-sample chain
+    (NFM_SEQ_WIN_PAR=0) two runs give the same bits whatever the timing.  The chunk-parallel chain (the default for SGD) solves
+    the chunk of samples that happen to be ready: its results agree with these to rounding (rtol 1e-8 here), run to run as well."""
+    if not _ONE_TERM["variant"]:
+        pytest.skip("the term-by-term flavour is bit-equal to the one-workgroup kernel (every other test of this file)")
+    n, d, m, k = (6000, 3000, 64, 64) if shape == "k64" else (6000, 1500, 20, 16)
+    Xo = _distinct_rows(n, d, m, seed=77)
+    rng = np.random.default_rng(78)
+    y = np.sign(rng.standard_normal(n))
+    P0, w0, b0 = rng.standard_normal((1, k, d)) * 0.01, rng.standard_normal(d) * 0.01, 0.02
+    perms = make_perms(n, 2)
+    runs = []
+    for par in ("0", "0", "6", "6"):
+        with env(NFM_SEQ_WIN_PAR=par):
+            runs.append(fit(kind, 2, 128 if shape == "k64" else 64, Xo, y, "classification", k, P0, w0, b0, 2, perms, loss="logistic"))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2], \
+        "two runs with the sample-by-sample chain differ"
+    for r_ in runs[2:]:
+        assert_close(r_[0], runs[0][0], 1e-8, 1e-11, "P, chunk-parallel chain")
+        assert_close(r_[1], runs[0][1], 1e-8, 1e-11, "w, chunk-parallel chain")
+        assert abs(r_[2] - runs[0][2]) <= 1e-11 + 1e-8 * abs(runs[0][2])
+
+
 def test_abort_paths_in_the_test_hooks_build():
     """The launch-abort paths (a worker that never shows up: snapshot put back, the one-workgroup kernel re-runs the call; two
     aborts: the optimizer stops asking; no memory for the snapshot: the one-workgroup kernel) need hooks inside the library.

@@ -53,9 +53,10 @@ for name in shapes:
             dt = time.perf_counter() - t0
             kt = ctx.timing_get("sequential")
             kd = ctx.timing_get("seq_window_deps")
+            ks = ctx.timing_get("seq_window_scales")
             ctx.timing_enable(False)
             if W == 0 and n > 20_000:
                 print("%-9s %-8s one-workgroup kernel: skipped at n=%d (run with n <= 20000)" % (name, solver, n), flush=True)
                 continue
-            print("%-9s %-8s W=%-3d n=%d: kernel %.3f us per sample = %.3g samples/s; wall %.3g samples/s; deps table %.1f ms" %
-                  (name, solver, W, n, kt[1] / n * 1e3, n / (kt[1] * 1e-3), n / dt, kd[1]), flush=True)
+            print("%-9s %-8s W=%-3d n=%d: kernel %.3f us per sample = %.3g samples/s; wall %.3g samples/s (%.1f ms); deps table %.1f ms; scale chain %.1f ms" %
+                  (name, solver, W, n, kt[1] / n * 1e3, n / (kt[1] * 1e-3), n / dt, dt * 1e3, kd[1], ks[1]), flush=True)
