@@ -1055,7 +1055,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       const bool win_trusted = !o->seqwin || o->seqwin->fallbacks < 2;  // two aborted launches: CUs are being held -- no more 1 s waits
       if (!win_trusted && o->seqwin) o->seqwin->snap.release();  // (no more window launches from this optimizer: its snapshot goes back)
       bool have_snap = false;
-      if (snap_pays && win_trusted && seq_window_supported(M, ds->max_row + m->n_aug, ns, ds->v.nnz, ctx->n_cu)) {
+      if (snap_pays && win_trusted && seq_window_supported(M, ds->max_row + m->n_aug, ns, ds->v.nnz, ctx->n_cu, o->kind == OPT_ADAGRAD)) {
         if (!o->seqwin) o->seqwin.reset(new SeqWin());
         // A model (+ AdaGrad state) beyond half of the free memory has no room for its snapshot: that fit runs in the
         // one-workgroup kernel, which needs none -- it must not fail for want of a safety copy.

@@ -1419,13 +1419,16 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
   double* Nl = Gl + (ADA ? (size_t)mcs * Kp : 0);     // AdaGrad: g_norm
   double* red = Nl + (ADA ? (size_t)mcs * Kp : 0);    // [64] an order's kernel per factor
   double* bc = red + kWave;              // [4][64] per near entry: the writer's dL, scale, step size, next scale
-  double* vsum = bc + 4 * kWave;                      // [NW] the wavefronts' viol
+  double* affB = bc + 4 * kWave;                      // [DG][64] the affine entry's rows: slope in its writer's dL, per order
+  double* affP = affB + DG * kWave;                   // [DG][64] ... the rows as the writer used them, and
+  double* affD = affP + DG * kWave;                   // [DG][64] ... their derivatives (the recipe, kept for the exact rows)
+  double* vsum = affD + DG * kWave;                   // [NW] the wavefronts' viol
   double* vl = vsum + NW;                             // [mcap] values
   double* wl = vl + mcap;                             // [mcap] stored linear weights (AdaGrad: after update())
   double* gwl = wl + mcap;                            // AdaGrad: [mcap]
   double* nwl = gwl + (ADA ? mcap : 0);               // AdaGrad: [mcap]
-  ull* mk_l = reinterpret_cast<ull*>(nwl + (ADA ? mcap : 0));  // [2] {near entries, hot entries} of the sample
-  int* jl = reinterpret_cast<int*>(mk_l + 2);                  // [mcap] feature ids
+  ull* mk_l = reinterpret_cast<ull*>(nwl + (ADA ? mcap : 0));  // [3] {near entries, hot entries, affine entry + 1} of the sample
+  int* jl = reinterpret_cast<int*>(mk_l + 3);                  // [mcap] feature ids
   int* pl = jl + mcap;                                       // [mcap] previous position with the same feature
   int* ql = pl + mcap;                                       // [mcap] the feature's entry index in that sample
   int* ll = ql + mcap;                                       // [mcap] 1: the entry's rows come from their writer's recipe
@@ -1482,11 +1485,29 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
       const int nq = e_in ? a.next[q0 + lane] : -1;
       const int64_t v = (int64_t)pq - a.seg0;
       const bool pend = v >= 0 && cnt[v & (W - 1)] <= (unsigned)(v >> lgW);
-      const bool near = fwd_on && pend && (pos - (int64_t)pq) < a.near_r && pqu < kFxHot;
+      // One-term window, SGD: the rows of the entry shared with the MOST RECENT earlier sample inside the window are treated as
+      // AFFINE in that sample's dL (post_sum; see win_worker) -- chosen by positions alone, so that the arithmetic is the same
+      // from run to run; that writer must share exactly one feature with this sample
+      int aff_q = -1;
+      if constexpr (!ADA) {
+        if (a.one_term && fwd_on) {
+          const bool cand = v >= 0 && (pos - (int64_t)pq) < a.near_r && pqu < kFxHot;
+          int latest = cand ? (int)v : -1;
+#pragma unroll
+          for (int sh = 1; sh < kWave; sh <<= 1) {
+            const int o_ = __shfl_xor(latest, sh, kWave);
+            latest = o_ > latest ? o_ : latest;
+          }
+          const ull who = __ballot(cand && (int)v == latest);
+          if (who != 0ull && (who & (who - 1)) == 0ull) aff_q = __builtin_ctzll(who);
+        }
+      }
+      const bool near = (fwd_on && pend && (pos - (int64_t)pq) < a.near_r && pqu < kFxHot) || lane == aff_q;
       const ull fm_ = __ballot(near), hm_ = __ballot(fwd_on && lane < kFxHot && nq >= 0 && ((int64_t)nq - pos) < a.near_r);
       if (lane == 0) {
         mk_l[0] = fm_;
         mk_l[1] = hm_;
+        mk_l[2] = (ull)(aff_q + 1);
       }
       for (int q = lane; q < mcap; q += kWave) {
         const bool in = q < m;
@@ -1515,6 +1536,8 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
     }
     __syncthreads();
     const ull fwdmask = mk_l[0], hotmask = mk_l[1];
+    const int aff_q = (int)mk_l[2] - 1;  // (uniform over the workgroup) the entry whose rows are posted as affine in its writer's dL
+    const bool affine = aff_q >= 0;
     double* const junk = reinterpret_cast<double*>(a.fw + (size_t)a.np * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
 
     // ---- B. the rows of every (entry, order) -> LDS (AdaGrad: update() first, adagrad.nim:87-110): the slots dealt to the wavefronts ----
@@ -1585,6 +1608,9 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
 
     // ---- B2. near dependencies: the writer's recipe + the conductor's dL for the WRITER's sample -> the rows as the writer
     // will (or did) write them.  Wavefront 0 polls what is per entry, all wavefronts form the rows (fields dealt out) ----
+    // (wavefront 0, lane = entry: the shared feature's linear weight as its writer used it, the entry's value there, the writer's
+    // scale and step size -- kept for the affine entry's second half)
+    double wu = 0.0, gwu = 0.0, nwu = 0.0, vsl = 0.0, swul = 1.0, etawul = 0.0, aff_Bw = 0.0;
     if (fwdmask) {
       if (wv == 0) {
         const bool mine = (fwdmask >> lane) & 1ull;  // lane = entry
@@ -1593,7 +1619,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
         const unsigned tagl = (unsigned)(upl + 1);
         ull* srcl = fw_area(mine ? upl : 0);
         const ull* rsrcl = res_of(mine ? upl : 0);
-        double wu = 0.0, gwu = 0.0, nwu = 0.0, vsl = 0.0, dLl = 0.0;
+        double dLl = 0.0;
         bool okl = true, dead = false;
         auto load_lin = [&]() {
           okl = true;
@@ -1607,7 +1633,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
           }
         };
         load_lin();
-        double sPul = 1.0, etaPul = 0.0, sPnul = 1.0, swul = 1.0, etawul = 0.0;
+        double sPul = 1.0, etaPul = 0.0, sPnul = 1.0;
         if constexpr (!ADA) {
           if (mine) {
             sPul = a.scales[2 * (a.seg0 + upl)];
@@ -1621,7 +1647,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
           Spin sp;
           while (true) {
             bool ok = true;
-            if (mine) ok = fw_load(rsrcl, tagl, dLl);
+            if (mine && lane != aff_q) ok = fw_load(rsrcl, tagl, dLl);  // (the affine writer's dL is not waited for here)
             if (!__all(okl)) load_lin();
             if (__all(ok) && __all(okl)) break;
             if (sp.wait(a.ctrl)) {
@@ -1648,9 +1674,13 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
                 st_f64(M.w + jl[lane], nv);
                 wvv = nv;
               }
-            } else {
+            } else if (lane != aff_q) {
               const double wj = swul * wu;
               wvv = (wj - etawul * (dLl * vsl + O.alpha * wj)) / (swul * (1 - etawul * O.alpha));
+            } else {  // the affine entry's linear weight (fit_linear.nim:41-47): Aw + dL Bw
+              const double wj = swul * wu, den = swul * (1 - etawul * O.alpha);
+              wvv = (wj - etawul * (O.alpha * wj)) / den;
+              aff_Bw = -(etawul * vsl) / den;
             }
           }
           wl[lane] = wvv;
@@ -1695,10 +1725,20 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
             }
             Gl[c * Kp + s] = g;
             Nl[c * Kp + s] = n;
-          } else {
+          } else if (q != aff_q) {
             const double pw = sPu * pv;
             const double update = etaPu * (dLu * dv + O.beta * pw);
             p = (pw - update) / sPnu;
+          } else {
+            // row'(dL) = (pw - eta (dL dv + beta pw)) / s' = A + dL B: A goes into the forward pass, B into the slope, the recipe
+            // is kept (the writer's forwarding area may be reused by the time the exact row is formed)
+            const double pw = sPu * pv;
+            p = (pw - etaPu * (O.beta * pw)) / sPnu;
+            if (r == 0) {
+              affB[o * kWave + s] = -(etaPu * dv) / sPnu;
+              affP[o * kWave + s] = pv;
+              affD[o * kWave + s] = dv;
+            }
           }
           Pl[c * Kp + s] = p;
         }
@@ -1710,6 +1750,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
     // order's slots dealt to the wavefronts; one chain term per order behind the linear terms ----
     const int MC = a.FW - kWinHdr;
     double ktot[DG];  // (no conductor: the orders' kernels, chain terms behind the linear ones -- wavefront 0's)
+    auto forward_orders = [&]() {
 #pragma unroll
     for (int t = 0; t < DG; ++t) ktot[t] = 0.0;
     for (int o = 0; o < nb; ++o) {
@@ -1806,6 +1847,9 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
         }
       }
     }
+    };
+    forward_orders();
+    if (affine) __syncthreads();  // (the slope needs the derivatives of the affine entry's slots: all wavefronts')
     if (wv == 0 && (a.no_cond || a.one_term)) {
       // predictWithGrad's chain (sgd.nim:193-201) in this wavefront: the constant intercept, the linear terms in storage order,
       // the orders' kernels one after the other; dloss; {dL, yhat} posted as the conductor would (all wavefronts and the near
@@ -1831,9 +1875,20 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
           const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
           st_u64(a.res + (size_t)(slot * a.np + par) * kResWords + lane, ((ull)(unsigned)(u + 1) << 32) | (ull)half);
         }
-      } else {
+      } else if (!affine) {
         const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
         post_sum(a.fwd, a.np, W, slot, par, (unsigned)(u + 1), lane, yh_, y, h2);
+      } else {
+        // dS / d dL_writer: the orders' kernels are multilinear in the rows, so the slope is  sum_o sum_s B_os dA_os  -- the
+        // derivative of the affine entry's slots (it does not depend on their own rows) -- plus the linear term's  sw Bw x
+        const double h2 = dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
+        double part = 0.0;
+        if (r == 0 && s < k)
+          for (int o = 0; o < nb; ++o) part += (sP * affB[o * kWave + s]) * Tl[((size_t)aff_q * nb + o) * Kp + s];  // (d true value = sP d stored)
+        double c1 = dev::wave_sum(part);
+        c1 += dev::shfl_d((sw * aff_Bw) * vl[aff_q < m ? aff_q : 0], aff_q);
+        const unsigned wtag = (unsigned)((int64_t)pl[aff_q] - a.seg0 + 1);
+        post_sum(a.fwd, a.np, W, slot, par, (unsigned)(u + 1), lane, yh_, y, h2, c1, wtag);
       }
     } else if (wv == 0) {
       const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
@@ -1851,6 +1906,42 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
       }
     }
     __syncthreads();  // (the derivatives of all slots, for the recipes and the update)
+    if (affine) {
+      // ... and now the exact rows of the affine entry: the writer's dL, its update of the entry's rows, this sample's kernels
+      // and derivatives again with them (they enter the update and this sample's own recipes)
+      if constexpr (!ADA) {
+        const int64_t upa = (int64_t)pl[aff_q] - a.seg0;
+        if (wv == 0) {
+          const ull* rsa = res_of(upa);
+          double dLa = 0.0;
+          Spin sp;
+          while (true) {
+            const bool ok = fw_load(rsa, (unsigned)(upa + 1), dLa);
+            if (__all(ok)) break;
+            if (sp.wait(a.ctrl)) break;  // (aborting: every wait below ends the same way)
+          }
+          if (lane == aff_q) {
+            bc[lane] = dLa;
+            double wvv = wu;
+            if (M.fit_linear) {
+              const double wj = swul * wu;
+              wvv = (wj - etawul * (dLa * vsl + O.alpha * wj)) / (swul * (1 - etawul * O.alpha));
+            }
+            wl[lane] = wvv;
+          }
+        }
+        __syncthreads();
+        const double dLu = bc[aff_q], sPu = bc[kWave + aff_q], etaPu = bc[2 * kWave + aff_q], sPnu = bc[3 * kWave + aff_q];
+        for (int o = wv; o < nb; o += NW) {
+          const double pw = sPu * affP[o * kWave + s];
+          const double update = etaPu * (dLu * affD[o * kWave + s] + O.beta * pw);
+          Pl[((size_t)aff_q * nb + o) * Kp + s] = (pw - update) / sPnu;
+        }
+        __syncthreads();
+        forward_orders();
+        __syncthreads();
+      }
+    }
     // (after the mailbox: a successor needs them together with this sample's dL, which the conductor forms from the mailbox)
     if (hotmask) {
       const unsigned mytag = (unsigned)(u + 1);
@@ -2550,6 +2641,10 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
           }
         }
       }
+      // (AdaGrad: the same Newton iteration on the PAIR (g_sum, g_norm) of the intercept's state -- 2 x 2 affine maps composed by
+      // the scan -- was built and measured: rows that share nothing 0.34 -> 0.24 us per sample at 128 workers, the headline /
+      // cfg2 / cfg4 shapes +-0: with AdaGrad a dependent sample waits for its writer's dL whatever the chain costs (the
+      // writer's step is not affine in dL), and those turnarounds are the bound.  Not kept.)
       for (int t = 0; t < cnt && !chunk_done; ++t) {
         double S = readlane_d(Sv, t);
         const double y = readlane_d(yv, t), h2 = readlane_d(hv, t);
@@ -3316,83 +3411,105 @@ __global__ void k_win_finish(const double* partial, int W, double* out) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// SGD: the lazy-scaling chain (sgd.nim:233-234, 116-131) ahead of the launch.  One wavefront: the step sizes of 64
-// samples in parallel, the two products one sample after the other (lane 0: scale_P, lane 1: scale_w).
+// SGD: the lazy-scaling chain (sgd.nim:233-234, 116-131) ahead of the launch: scale *= 1 - eta(it) reg, one sample after the
+// other (lane 0 of the chain wavefront: scale_P, lane 1: scale_w) -- 2e6 dependent multiplications per 2e6-sample call.  Three
+// wavefronts in a pipeline over blocks of 64 samples (round 5; one wavefront did everything at 32 ns per sample, 8 % of an
+// exact-order epoch): wavefront 1 forms the factors of block i + 1 (64 step sizes in parallel), wavefront 0 multiplies block i
+// through -- nothing else on its path --, wavefront 2 writes block i - 1 out.  The products are formed in the same order as
+// before: the same bits.
 //   scales[pos] = {scale_P, scale_w} before the sample at `pos`;  info[0] = last position of the stretch (the sample after
 //   which a scale falls below 1e-9, or the call's last), info[1] = 1: rescale P, 2: rescale w.  The model's two scale words
 //   get the values after that sample.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_win_scales(ModelView M, OptView O, int64_t it0, int64_t pos0, int64_t ns, double* scales,
-                                                   int64_t* info) {
-  __shared__ double f[2][kWave];
-  __shared__ double o[2][kWave];
-  __shared__ int stp[2];
-  const int lane = threadIdx.x;
-  double sc = lane == 0 ? M.sc[SC_SCALE_P] : M.sc[SC_SCALE_W];  // lane 0 carries scale_P, lane 1 scale_w
+__global__ __launch_bounds__(3 * 64) void k_win_scales(ModelView M, OptView O, int64_t it0, int64_t pos0, int64_t ns, double* scales,
+                                                       int64_t* info) {
+  __shared__ double f[2][2][kWave];  // [buffer][chain][t] the factors 1 - eta reg of a block
+  __shared__ double o[2][2][kWave];  // [buffer][chain][t] the scale AFTER sample t of a block (before sample t: the one after t - 1)
+  __shared__ double cin[2][2];       // [buffer][chain] the scale before the block's first sample
+  __shared__ int stp[2][2];          // [buffer][chain]: the first sample of the block after which the chain's scale is below 1e-9, or -1
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  const int64_t nblk = (ns - pos0 + kWave - 1) / kWave;
+  const bool fit_linear = M.fit_linear != 0;
+  auto factors = [&](int64_t blk) {  // (wavefront 1)
+    const double itf = (double)(it0 + blk * kWave + lane);
+    f[blk & 1][0][lane] = 1 - dev::get_eta(O.sched, O.eta0, O.power, O.beta, itf) * O.beta;
+    // the linear scale moves only when the linear term is fitted (sgd.nim:229-234 as kept by k_sequential_pipe)
+    f[blk & 1][1][lane] = fit_linear ? 1 - dev::get_eta(O.sched, O.eta0, O.power, O.alpha, itf) * O.alpha : 1.0;
+  };
+  auto write_out = [&](int64_t blk, int upto) {  // (wavefront 2)
+    if (lane < upto) {
+      const int64_t pos = pos0 + blk * kWave + lane;
+      scales[2 * pos] = lane == 0 ? cin[blk & 1][0] : o[blk & 1][0][lane - 1];
+      scales[2 * pos + 1] = lane == 0 ? cin[blk & 1][1] : o[blk & 1][1][lane - 1];
+    }
+  };
+  double sc = lane == 0 ? M.sc[SC_SCALE_P] : M.sc[SC_SCALE_W];  // (chain wavefront: lane 0 carries scale_P, lane 1 scale_w)
+  if (wave == 1 && nblk > 0) factors(0);
+  __syncthreads();
   int64_t last = ns - 1;
   int flags = 0;
-  const bool watch = lane == 0 || M.fit_linear;
-  for (int64_t base = pos0; base < ns; base += kWave) {
-    const int cnt = (int)(ns - base < kWave ? ns - base : kWave);
-    const double itf = (double)(it0 + (base - pos0) + lane);
-    f[0][lane] = 1 - dev::get_eta(O.sched, O.eta0, O.power, O.beta, itf) * O.beta;
-    // the linear scale moves only when the linear term is fitted (sgd.nim:229-234 as kept by k_sequential_pipe)
-    f[1][lane] = M.fit_linear ? 1 - dev::get_eta(O.sched, O.eta0, O.power, O.alpha, itf) * O.alpha : 1.0;
-    __syncthreads();
-    if (lane < 2) {
-      // the 64 factors into registers at once, then the chain: one multiplication per sample, nothing else on its path
-      double fr[kWave], orr[kWave];
+  for (int64_t blk = 0; blk < nblk; ++blk) {
+    const int cnt = (int)(ns - (pos0 + blk * kWave) < kWave ? ns - (pos0 + blk * kWave) : kWave);
+    if (wave == 0) {
+      if (lane < 2) {
+        // the 64 factors into registers at once, then the chain IN PLACE: one multiplication per sample and nothing else on
+        // its path (a lone wavefront issues an instruction every ~8 cycles: every copy beside the product costs as much as it)
+        double fr[kWave];
 #pragma unroll
-      for (int t = 0; t < kWave; t += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(&f[lane][t]);
-        fr[t] = v.x;
-        fr[t + 1] = v.y;
+        for (int t = 0; t < kWave; t += 2) {
+          const double2 v = *reinterpret_cast<const double2*>(&f[blk & 1][lane][t]);
+          fr[t] = v.x;
+          fr[t + 1] = v.y;
+        }
+        cin[blk & 1][lane] = sc;
+        fr[0] = sc * fr[0];
+#pragma unroll
+        for (int t = 1; t < kWave; ++t) fr[t] = fr[t - 1] * fr[t];  // the value after sample t
+#pragma unroll
+        for (int t = 0; t < kWave; t += 2) *reinterpret_cast<double2*>(&o[blk & 1][lane][t]) = double2{fr[t], fr[t + 1]};
+        const double c = fr[kWave - 1];
+        double c_end = c;
+        if (cnt < kWave) {  // a short last block: the value after its last sample
+#pragma unroll
+          for (int t = 0; t < kWave; ++t)
+            if (t == cnt - 1) c_end = fr[t];
+        }
+        // resetScaling after the first sample that leaves the scale below 1e-9 (sgd.nim:116-131).  The factors are <= 1, so
+        // the scale never grows: only a block that ENDS below the limit has to be searched.
+        int stop = -1;
+        if ((lane == 0 || fit_linear) && c_end < 1e-9) {
+#pragma unroll
+          for (int t = kWave - 1; t >= 0; --t)
+            if (t < cnt && fr[t] < 1e-9) stop = t;
+        }
+        stp[blk & 1][lane] = stop;
+        sc = c_end;
       }
-      double c = sc;
-#pragma unroll
-      for (int t = 0; t < kWave; ++t) {
-        orr[t] = c;
-        c = c * fr[t];
-        fr[t] = c;  // the value after sample t
-      }
-      int stop = -1;
-      if (watch) {  // resetScaling after the first sample that leaves the scale below 1e-9 (sgd.nim:116-131)
-#pragma unroll
-        for (int t = kWave - 1; t >= 0; --t)
-          if (t < cnt && fr[t] < 1e-9) stop = t;
-      }
-#pragma unroll
-      for (int t = 0; t < kWave; t += 2) *reinterpret_cast<double2*>(&o[lane][t]) = double2{orr[t], orr[t + 1]};
-      sc = stop >= 0 ? fr[0] : c;  // (overwritten below when a chain stops)
-      if (cnt < kWave && stop < 0) {  // a short last block: the value after its last sample
-#pragma unroll
-        for (int t = 0; t < kWave; ++t)
-          if (t == cnt - 1) sc = fr[t];
-      }
-      stp[lane] = stop;
+    } else if (wave == 1) {
+      if (blk + 1 < nblk) factors(blk + 1);
+    } else if (blk > 0) {
+      write_out(blk - 1, kWave);
     }
     __syncthreads();
-    const int s0 = stp[0], s1 = stp[1];
-    const int stop = s0 >= 0 && (s1 < 0 || s0 <= s1) ? s0 : s1;
-    const int upto = stop >= 0 ? stop + 1 : cnt;
-    if (lane < upto) {
-      scales[2 * (base + lane)] = o[0][lane];
-      scales[2 * (base + lane) + 1] = o[1][lane];
-    }
-    if (stop >= 0) {
-      last = base + stop;
+    const int s0 = stp[blk & 1][0], s1 = stp[blk & 1][1];
+    if (s0 >= 0 || s1 >= 0) {  // (uniform: every wavefront reads the same two words after the barrier)
+      const int stop = s0 >= 0 && (s1 < 0 || s0 <= s1) ? s0 : s1;
+      last = pos0 + blk * kWave + stop;
       flags = (s0 == stop ? 1 : 0) | (s1 == stop ? 2 : 0);
-      if (lane < 2) sc = o[lane][stop] * f[lane][stop];  // both chains: the value after sample `stop`
+      if (wave == 2) write_out(blk, stop + 1);
+      if (wave == 0 && lane < 2) sc = o[blk & 1][lane][stop];  // both chains: the value after sample `stop`
       break;
     }
-    __syncthreads();
+    if (blk + 1 == nblk && wave == 2) write_out(blk, cnt);
   }
-  if (lane == 0) {
-    M.sc[SC_SCALE_P] = sc;
-    info[0] = last;
-    info[1] = flags;
+  if (wave == 0) {
+    if (lane == 0) {
+      M.sc[SC_SCALE_P] = sc;
+      info[0] = last;
+      info[1] = flags;
+    }
+    if (lane == 1) M.sc[SC_SCALE_W] = sc;
   }
-  if (lane == 1) M.sc[SC_SCALE_W] = sc;
 }
 
 __global__ void k_win_fill(ull* p, int64_t n, ull v) {
@@ -3517,8 +3634,8 @@ static size_t win_fmx_lds(const ModelView& M, int m_cap, bool ada, int W) {  // 
   while ((1 << lgKp) < M.Kp) ++lgKp;
   const int grp = (kWave >> lgKp) * 4;
   const size_t mcs = ((size_t)m_cap * M.nb + grp - 1) / grp * grp;
-  return sizeof(double) * ((ada ? 4 : 2) * mcs * M.Kp + kWave + 4 * kWave + kFfmWaves + (ada ? 4 : 2) * (size_t)m_cap) + sizeof(ull) * 2 +
-         sizeof(int) * 4 * (size_t)m_cap + sizeof(unsigned) * W + 64;
+  return sizeof(double) * ((ada ? 4 : 2) * mcs * M.Kp + kWave + 4 * kWave + 3 * dev::kMaxDeg * kWave + kFfmWaves + (ada ? 4 : 2) * (size_t)m_cap) +
+         sizeof(ull) * 3 + sizeof(int) * 4 * (size_t)m_cap + sizeof(unsigned) * W + 64;
 }
 
 // which flavour of the window a model gets (read per call: tests switch the environment)
@@ -3531,7 +3648,7 @@ static bool win_one_term(const ModelView& M) {  // the intercept is fitted: the 
   return !win_no_cond(M) && !(env && atoi(env) != 0);
 }
 
-bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz, int n_cu) {
+bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz, int n_cu, bool ada) {
   const char* env = getenv("NFM_SEQ_WIN");  // 0: off, 1 (default): when it pays, 2: whenever possible (read per call: tests switch it)
   const int mode = env ? atoi(env) : 1;
   if (mode == 0) return false;
@@ -3543,12 +3660,12 @@ bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz
     // field-aware: one chain term per entry and per pair of entries; all nFields rows of every feature in LDS
     if (M.n_aug != 0 || M.nb < 1 || m_cap < 1) return false;
     if (term_mail && kWinHdr + (win_ffm_terms(m_cap) + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
-    if (win_ffm_lds(M, m_cap, true, 128) > 160 * 1024) return false;
+    if (win_ffm_lds(M, m_cap, ada, 128) > 160 * 1024) return false;  // (AdaGrad keeps g_sum / g_norm of every slot beside the rows)
   } else if (M.kind == NFM_KIND_FM && (M.nb != 1 || M.degree != 2)) {
     // several orders / degree >= 3: one chain term per entry and per order; the rows of every (entry, order) in LDS
     if (M.n_aug != 0 || M.nb < 1 || M.degree < 2 || M.degree > dev::kMaxDeg || m_cap < 1) return false;
     if (term_mail && kWinHdr + (m_cap + M.nb + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
-    if (win_fmx_lds(M, m_cap, true, 128) > 160 * 1024) return false;
+    if (win_fmx_lds(M, m_cap, ada, 128) > 160 * 1024) return false;
   } else {
     if (M.kind != NFM_KIND_FM || M.nb != 1 || M.degree != 2 || M.n_aug != 0) return false;
     if (term_mail && kWinHdr + (m_cap + 63) / 64 * 64 > kWave * kWinMaxNL) return false;
@@ -3558,7 +3675,7 @@ bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz
       while ((1 << lgKp_) < M.Kp) ++lgKp_;
       const int grp_ = (kWave >> lgKp_) * 4;
       const size_t mcp_ = (size_t)(m_cap + grp_ - 1) / grp_ * grp_;
-      if (sizeof(double) * (4 * mcp_ * M.Kp + kWave + 4 * mcp_) + sizeof(int) * 3 * mcp_ + sizeof(unsigned) * 256 > 160 * 1024) return false;
+      if (sizeof(double) * ((ada ? 4 : 2) * mcp_ * M.Kp + kWave + (ada ? 4 : 2) * mcp_) + sizeof(int) * 3 * mcp_ + sizeof(unsigned) * 256 > 160 * 1024) return false;
     }
   }
   if (nnz >= ((int64_t)1 << 32) || M.d >= ((int64_t)1 << 31) || ns >= ((int64_t)1 << 31)) return false;
@@ -3726,7 +3843,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
     int64_t host_info[2] = {ns - 1, 0};
     if (!ada) {
       TimedLaunch tls(ctx, "seq_window_scales");
-      hipLaunchKernelGGL(k_win_scales, dim3(1), dim3(kWave), 0, st, M, O, it0 + pos, pos, ns, sw->scales.as<double>(), info);
+      hipLaunchKernelGGL(k_win_scales, dim3(1), dim3(3 * kWave), 0, st, M, O, it0 + pos, pos, ns, sw->scales.as<double>(), info);
       NFM_HIP_CHECK(hipMemcpyAsync(host_info, info, sizeof(host_info), hipMemcpyDeviceToHost, st));
       NFM_HIP_CHECK(hipStreamSynchronize(st));
       last = host_info[0];

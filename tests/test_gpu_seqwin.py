@@ -336,6 +336,30 @@ def test_field_aware_window_bitwise_and_oracle(kind, F, k, d, max_m, W):
     assert abs(win[2] - bf) < 1e-9
 
 
+@pytest.mark.parametrize("F,k,n_feat", [(39, 4, 39 * 40), (30, 8, 30 * 25)])
+def test_field_aware_rows_longer_than_a_mailbox_in_the_one_term_window(F, k, n_feat):
+    """Rows of more than 22 entries -- 39 fields x one entry is the shape of click-through data -- are 780 chain terms: no
+    mailbox of the term-by-term conductor holds them (that flavour sends them to the one-workgroup kernel).  The one-term window
+    posts ONE term whatever the row length: SGD fits (its slots' rows + derivatives: 98 KB of LDS at F = 39, k = 4; AdaGrad's
+    state rows beside them do not).  Same results as the one-workgroup kernel at the one-term tolerance, and the oracle's
+    (sgd_ffm.nim:11-106)."""
+    if not _ONE_TERM["variant"]:
+        pytest.skip("the term-by-term flavour has no mailbox for rows this long")
+    from common import init_ffm
+    Xo, y = _ffm_data(2500, n_feat, F, F, seed=F, one_per_field=True)
+    P0, w0, b0 = init_ffm(n_feat, F, k)
+    perms = make_perms(Xo.n, 2)
+    ref = _ffm_fit("sgd", 0, 64, Xo, y, k, P0, w0, b0, 2, perms, eta0=0.02)
+    win = _ffm_fit("sgd", 2, 64, Xo, y, k, P0, w0, b0, 2, perms, eta0=0.02)
+    same_bits(win[0], ref[0], "P")
+    same_bits(win[1], ref[1], "w")
+    assert same_b(win[2], ref[2]) and win[3] == ref[3]
+    Pf, wf, bf, *_ = O.ffm_sgd_fit(Xo, y, P0, w0, b0, O.sgd_cfg(eta0=0.02), 2, perms=perms)
+    assert_close(win[0], Pf, 1e-8, 1e-11, "P vs oracle")
+    assert_close(win[1], wf, 1e-8, 1e-11, "w vs oracle")
+    assert abs(win[2] - bf) < 1e-9
+
+
 @pytest.mark.parametrize("kind", ["sgd", "adagrad"])
 def test_field_aware_window_benchmark_shape(kind):
     """16 fields x one entry, k = 8 (BASELINE configs[3]'s row shape), 3000 samples over 1600 features, 64 workers"""
