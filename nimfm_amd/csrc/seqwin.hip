@@ -152,34 +152,38 @@ __device__ __forceinline__ bool fw_load(const ull* p, unsigned tag, double& v) {
   v = __hiloint2double((int)(unsigned)(g1 & 0xffffffffull), (int)(unsigned)(g0 & 0xffffffffull));
   return (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
 }
-// The ONE-TERM mailbox (WinArgs::one_term): {S, y, the intercept's step size, C, the tag of a writer's sample} as nine tagged
+// The ONE-TERM mailbox (WinArgs::one_term): {S, y, the intercept's step size, C1, C2, C12, two writers} as thirteen tagged
 // granules, laid out granule-major -- fwd[(granule * np + parity) * W + worker] -- so that the conductor's fetch wavefront
 // reads one granule of 64 workers with one 512-byte access.  Tags instead of the "empty" pattern: nothing to reset after use.
-// C / writer (SGD): the sample shares ONE feature with a sample `writer` whose dL the conductor has not produced yet.  The
-// writer's step of the shared row is AFFINE in its dL (sgd.nim:217-223: p' = A + dL B, A and B known at the writer's forward
-// pass) and the prediction is multilinear in the rows of different features, so S = S(A) + dL_writer * C exactly: the worker
-// posts S(A) and C without waiting for dL_writer, the conductor -- which made that dL -- finishes the sum (win_conductor_sum).
-// writer = 0: no such dependency, C is ignored.
-constexpr int kSumGran = 9;
+// C1 / C2 / C12 / writers (SGD): the sample shares a feature with each of (up to) two samples w1 > w2 inside the window whose dL
+// need not exist yet.  A writer's step of the shared row is AFFINE in its dL (sgd.nim:217-223: p' = A + dL B, A and B known at the
+// writer's forward pass) and the prediction is multilinear in the rows of different features, so
+//   S = S(A1, A2) + dL_w1 C1 + dL_w2 C2 + dL_w1 dL_w2 C12
+// exactly: the worker posts the four numbers without waiting for either dL, the conductor -- which made them -- finishes the
+// sum (win_conductor_sum).  The writers travel as distances (sample - writer, 1 ... 127; 0: none) in one granule.
+constexpr int kSumGran = 13;
 __device__ __forceinline__ void post_sum(ull* fwd, int np, int W, int slot, int par, unsigned tag, int lane, double S, double y, double h2,
-                                         double C = 0.0, unsigned writer_tag = 0u) {
+                                         double C1 = 0.0, double C2 = 0.0, double C12 = 0.0, unsigned dists = 0u) {
   if (lane < kSumGran) {
-    const double v = lane < 2 ? S : lane < 4 ? y : lane < 6 ? h2 : C;
+    const double v = lane < 2 ? S : lane < 4 ? y : lane < 6 ? h2 : lane < 8 ? C1 : lane < 10 ? C2 : C12;
     unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
-    if (lane == 8) half = writer_tag;
+    if (lane == 12) half = dists;
     st_u64(fwd + ((size_t)(lane * np + par) * W + slot), ((ull)tag << 32) | (ull)half);
   }
 }
 // A worker's forwarding area (one per parity of its sample count): what a successor within W positions needs to form
 // the rows it shares with this sample BY ITSELF as soon as the conductor's dL for this sample lands -- the RECIPE, known
 // at this sample's forward pass, not the result, known only after its update:
-//   [64 lanes]           the per-factor sums a1
+//   [2][64 lanes]        the per-factor sums a1, and their slope T in the dL of THIS sample's own affine writer (register-
+//                        resident worker, SGD: a sample whose shared row is still affine in an earlier sample's dL posts its
+//                        recipe at once, with a1 = a1(A) + dL_w T, instead of holding it back until that dL exists)
 //   [3][64 q][64 lanes]  per hot row: its value as this sample used it; AdaGrad: g_sum and g_norm as loaded
-//   [4][64 q]            per hot entry: linear weight as used, AdaGrad g_sum / g_norm of it, the entry's value
+//   [5][64 q]            per hot entry: linear weight as used, AdaGrad g_sum / g_norm of it, the entry's value; [4][0]: the
+//                        distance to that affine writer (0: the recipe is exact, T is unused)
 constexpr int kFwVals = 3;
-constexpr size_t kFwRows = (size_t)kWave * 2;                                    // granules of a1
+constexpr size_t kFwRows = (size_t)kWave * 4;                                    // granules of a1 and T
 constexpr size_t kFwLin = kFwRows + (size_t)kFwVals * kWave * kWave * 2;         // start of the per-entry part
-constexpr size_t kFwSlot = kFwLin + (size_t)4 * kWave * 2;                       // granules per (worker, parity)
+constexpr size_t kFwSlot = kFwLin + (size_t)5 * kWave * 2;                       // granules per (worker, parity)
 constexpr int kResWords = 4;  // conductor -> worker: {dL, yhat} as tagged granules (several workers may read them)
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -611,7 +615,8 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
         const double rest = a1 - xs * (sP * aff_A);
         double c1 = dev::wave_sum(r == 0 && s < k ? (xs * (sP * aff_B)) * rest : 0.0);
         c1 += dev::shfl_d((sw * aff_Bw) * xs, aff_q);
-        post_sum(a.fwd, a.np, W, slot, par, (unsigned)(u + 1), lane, yh_, y, h2, c1, (unsigned)__builtin_amdgcn_readlane((int)tagl, aff_q));
+        post_sum(a.fwd, a.np, W, slot, par, (unsigned)(u + 1), lane, yh_, y, h2, c1, 0.0, 0.0,
+                 (unsigned)(u - ((int64_t)__builtin_amdgcn_readlane(pq, aff_q) - a.seg0)));  // (the writer's distance: 1 ... near_r - 1 <= 127)
         // ... and now the exact row: the writer's dL, its update of the shared row, this sample's sums again with it
         {
           Spin sp;
@@ -1887,8 +1892,8 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
           for (int o = 0; o < nb; ++o) part += (sP * affB[o * kWave + s]) * Tl[((size_t)aff_q * nb + o) * Kp + s];  // (d true value = sP d stored)
         double c1 = dev::wave_sum(part);
         c1 += dev::shfl_d((sw * aff_Bw) * vl[aff_q < m ? aff_q : 0], aff_q);
-        const unsigned wtag = (unsigned)((int64_t)pl[aff_q] - a.seg0 + 1);
-        post_sum(a.fwd, a.np, W, slot, par, (unsigned)(u + 1), lane, yh_, y, h2, c1, wtag);
+        const unsigned dist = (unsigned)(u - ((int64_t)pl[aff_q] - a.seg0));  // (1 ... near_r - 1 <= 127)
+        post_sum(a.fwd, a.np, W, slot, par, (unsigned)(u + 1), lane, yh_, y, h2, c1, 0.0, 0.0, dist);
       }
     } else if (wv == 0) {
       const double h2 = ADA ? O.eta0 * itp * O.alpha0 : dev::get_eta(O.sched, O.eta0, O.power, O.alpha0, itf);
@@ -2389,10 +2394,12 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
   double* rS = lds + 2;            // [kSumRing] the samples' sums
   double* rY = rS + kSumRing;      // [kSumRing] targets
   double* rH = rY + kSumRing;      // [kSumRing] the intercept's step size (AdaGrad: eta0 (it-1) alpha0)
-  double* rC = rH + kSumRing;      // [kSumRing] the slope of S in a writer's dL (post_sum)
-  double* rD = rC + kSumRing;      // [kSumRing] the chain's dL per sample: what the post wavefront sends out, and the history a
+  double* rC = rH + kSumRing;      // [kSumRing] the slope of S in the first writer's dL (post_sum)
+  double* rC2 = rC + kSumRing;     // [kSumRing] ... in the second writer's
+  double* rC12 = rC2 + kSumRing;   // [kSumRing] ... in their product
+  double* rD = rC12 + kSumRing;    // [kSumRing] the chain's dL per sample: what the post wavefront sends out, and the history a
   double* rP = rD + kSumRing;      // [kSumRing]   dependent sample's slope is multiplied by; the predictions yhat
-  unsigned* rW = reinterpret_cast<unsigned*>(rP + kSumRing);  // [kSumRing] that writer's tag (its sample + 1), 0: none
+  unsigned* rW = reinterpret_cast<unsigned*>(rP + kSumRing);  // [kSumRing] the writers' distances (first | second << 8), 0: none
   if (threadIdx.x == 0) {
     ldsv_store(c_ready, 0u);
     ldsv_store(c_abort, 0u);
@@ -2438,7 +2445,9 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
             rY[idx] = __hiloint2double((int)(unsigned)g[dd][w][3], (int)(unsigned)g[dd][w][2]);
             rH[idx] = __hiloint2double((int)(unsigned)g[dd][w][5], (int)(unsigned)g[dd][w][4]);
             rC[idx] = __hiloint2double((int)(unsigned)g[dd][w][7], (int)(unsigned)g[dd][w][6]);
-            rW[idx] = (unsigned)g[dd][w][8];
+            rC2[idx] = __hiloint2double((int)(unsigned)g[dd][w][9], (int)(unsigned)g[dd][w][8]);
+            rC12[idx] = __hiloint2double((int)(unsigned)g[dd][w][11], (int)(unsigned)g[dd][w][10]);
+            rW[idx] = (unsigned)g[dd][w][12];
             if (a.trace) a.trace[uw[w] * 8 + 5] = wall_clock64();  // mailbox fetched
             uw[w] += W;
           }
@@ -2554,6 +2563,7 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
       // up to 64 consecutive samples, lane = sample (lanes past `ready` read slots that are not theirs yet: never used)
       const int idx = (int)((u + lane) & (kSumRing - 1));
       const double Sv = ldsv_load_d(rS + idx), yv = ldsv_load_d(rY + idx), hv = ldsv_load_d(rH + idx), Cv = ldsv_load_d(rC + idx);
+      const double C2v = ldsv_load_d(rC2 + idx), C12v = ldsv_load_d(rC12 + idx);
       const int Wv = (int)ldsv_load(rW + idx);
       const int cnt = (int)(ready - u < kWave ? ready - u : kWave);
       const ull affmask = __ballot(lane < cnt && Wv != 0);  // samples whose S waits for a writer's dL
@@ -2571,10 +2581,15 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
       if constexpr (!ADA) {
         if (a.par_min > 0 && cnt >= a.par_min) {
           const bool in = lane < cnt;
-          const int widx = Wv != 0 ? Wv - 1 : 0;                 // the writer's sample (affine lanes)
-          const bool w_here = Wv != 0 && (int64_t)widx >= u;        // ... inside this chunk: its dL is being found, too
-          const double dLw_old = (in && Wv != 0 && !w_here) ? ldsv_load_d(rD + (widx & (kSumRing - 1))) : 0.0;
-          const double S0 = (in && Wv != 0 && !w_here) ? Sv + dLw_old * Cv : Sv;
+          const int64_t me = u + lane;
+          const int d1 = Wv & 255, d2 = (Wv >> 8) & 255;             // the writers' distances (0: none)
+          const bool w1_here = d1 != 0 && me - d1 >= u, w2_here = d2 != 0 && me - d2 >= u;  // ... inside this chunk: their dL are being found, too
+          const bool w_here = w1_here || w2_here;
+          // the dL of writers of EARLIER chunks: final, in the ring
+          const double dL1_old = (in && d1 != 0 && !w1_here) ? ldsv_load_d(rD + ((me - d1) & (kSumRing - 1))) : 0.0;
+          const double dL2_old = (in && d2 != 0 && !w2_here) ? ldsv_load_d(rD + ((me - d2) & (kSumRing - 1))) : 0.0;
+          auto S_of = [&](double dl1, double dl2) { return Sv + dl1 * Cv + dl2 * (C2v + dl1 * C12v); };  // (no writer: dl = 0, C = 0)
+          const double S0 = S_of(dL1_old, dL2_old);
           double bt = b, St = S0, dLt = 0.0, yht = 0.0, updt = 0.0, bnext = b;
           bool conv = false;
           const bool coupled = __any(in && w_here);
@@ -2584,8 +2599,8 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
           for (int pass = 0; pass < 8 && !conv; ++pass) {
             const double dLprev = dLt;
             if (pass > 0 && coupled) {  // S of the samples that wait for a dL of this chunk
-              const double dLw = __shfl(dLt, (int)((int64_t)widx - u) & (kWave - 1), kWave);
-              St = (in && w_here) ? S0 + dLw * Cv : S0;
+              const double dLa = __shfl(dLt, (lane - d1) & (kWave - 1), kWave), dLb = __shfl(dLt, (lane - d2) & (kWave - 1), kWave);
+              St = (in && w_here) ? S_of(w1_here ? dLa : dL1_old, w2_here ? dLb : dL2_old) : S0;
             }
             double g;
             yht = bt + St;
@@ -2650,10 +2665,15 @@ __device__ __forceinline__ void win_conductor_sum(const WinArgs& a, double* lds)
         const double y = readlane_d(yv, t), h2 = readlane_d(hv, t);
         const int64_t uu = u + t;
         const bool aff_t = (affmask >> t) & 1ull;
-        if (aff_t) {  // S is affine in the dL of an earlier sample still inside the window (post_sum): that dL was made here
-          const int wtag = readlane_i(Wv, t);
-          const double dLw = ldsv_load_d(rD + ((wtag - 1) & (kSumRing - 1)));  // (fewer than W <= 128 positions back: still in the ring)
-          S += dLw * readlane_d(Cv, t);
+        if (aff_t) {  // S waits for the dL of one or two earlier samples still inside the window (post_sum): made here
+          const int wp = readlane_i(Wv, t);
+          const int d1 = wp & 255, d2 = (wp >> 8) & 255;  // (fewer than W <= 128 positions back: still in the ring)
+          const double dL1 = ldsv_load_d(rD + ((uu - d1) & (kSumRing - 1)));
+          S += dL1 * readlane_d(Cv, t);
+          if (d2 != 0) {
+            const double dL2 = ldsv_load_d(rD + ((uu - d2) & (kSumRing - 1)));
+            S += dL2 * (readlane_d(C2v, t) + dL1 * readlane_d(C12v, t));
+          }
         }
         if (ADA && fit_b && a.it0 + uu != 1) {  // adagrad.nim:101-106
           const double old = b;
@@ -2846,7 +2866,11 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
         }
       }
     }
-    const bool near = (pend && (pos - (int64_t)pq) < a.near_r) || lane == aff_q;
+    // (one-term SGD: EVERY earlier sample inside the window takes the recipe path, finished or not -- a recipe may carry its
+    // per-factor sums as a function of an earlier dL, and the row formed from it then differs in the last bit from the one in
+    // memory: which of the two is used must not depend on timing)
+    const bool near_pos = (int64_t)pq - a.seg0 >= 0 && (pos - (int64_t)pq) < a.near_r;
+    const bool near = (!ADA && a.one_term) ? near_pos : (pend && near_pos);
     const ull fwdmask = __ballot(near), farmask = __ballot(pend && !near), latemask = fwdmask | farmask;
     if (a.trace && lane == 0) a.trace[u * 8 + 0] = wall_clock64();  // sample taken up
     const bool late = (latemask >> lane) & 1ull;
@@ -2961,7 +2985,9 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     // One-term window, SGD, ONE such row whose writer's dL is not there yet: the row is affine in that dL (A + dL B), the
     // sample's sum S with it (post_sum): S(A) and the slope are posted at once, the exact row is formed when dL arrives
     bool affine = false;  // (uniform)
-    double aff_A = 0.0, aff_B = 0.0, aff_Bw = 0.0, aff_a1u = 0.0, aff_pv = 0.0;
+    double aff_A = 0.0, aff_B = 0.0, aff_B1 = 0.0, aff_Bw = 0.0, aff_a1u = 0.0, aff_pv = 0.0, aff_tu = 0.0;
+    int aff_dw = 0;          // the affine writer's OWN affine writer, as a distance from it (its recipe: a1 = a1u + dL_w' tu); 0: none
+    bool posted_early = false;  // this sample's recipes went out before its second half (a1 as a function of its writer's dL)
     const unsigned mytag = (unsigned)(u + 1);
     const int q_first = fwdmask ? __builtin_ctzll(fwdmask) : 0;
     // the writers' side of the recipes (kept for the affine path's second half)
@@ -2969,7 +2995,7 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     const int64_t upl = (int64_t)pq - a.seg0;
     const unsigned tagl = (unsigned)(upl + 1);
     double wu = 0.0, gwu = 0.0, nwu = 0.0, vsl = 0.0, dLl = 0.0;
-    double a1u = 0.0, pv = 0.0, gv = 0.0, nv = 0.0;
+    double a1u = 0.0, pv = 0.0, gv = 0.0, nv = 0.0, tu = 0.0, dwu = 0.0;
     double sPul = 1.0, etaPul = 0.0, sPnul = 1.0, swul = 1.0, etawul = 0.0, rynul = 1.0;
     ull* srcl = fw_area(mine ? upl : 0);
     const ull* rsrcl = res_of(mine ? upl : 0);
@@ -2993,6 +3019,10 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       const int qu = readlane_i(pqu, q);
       okr = fw_load(src + (size_t)lane * 2, tag, a1u);
       okr = fw_load(fw_row(src, 0, qu), tag, pv) && okr;
+      if constexpr (!ADA) {  // (the recipe's affine part: slope of a1 in its writer's own affine writer's dL, that writer's distance)
+        okr = fw_load(src + (size_t)(K + lane) * 2, tag, tu) && okr;
+        okr = fw_load(fw_lin(src, 4, 0), tag, dwu) && okr;
+      }
       if constexpr (ADA) {
         okr = fw_load(fw_row(src, 1, qu), tag, gv) && okr;
         okr = fw_load(fw_row(src, 2, qu), tag, nv) && okr;
@@ -3010,6 +3040,18 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
           if (sp.wait(a.ctrl)) return false;
           load_row(q);
         }
+        double a1x = a1u;
+        if constexpr (!ADA) {
+          if (dwu != 0.0) {  // an affine recipe: the writer's per-factor sums with ITS writer's dL (which exists: it is earlier)
+            const int64_t uw = (int64_t)readlane_i(pq, q) - a.seg0 - (int64_t)dwu;
+            const ull* rw = res_of(uw);
+            double dLw;
+            Spin spw;
+            while (!__all(fw_load(rw, (unsigned)(uw + 1), dLw)))
+              if (spw.wait(a.ctrl)) return false;
+            a1x = a1u + dLw * tu;
+          }
+        }
         if constexpr (ADA) {  // the writer's updateG of this row (adagrad.nim:113-134)
           const double grad = dLu * (vsu * (a1u - pv * vsu));
           Fl[q * K + lane] = pv;
@@ -3018,7 +3060,7 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
         } else {  // the writer's update() of this row (sgd.nim:217-223), with ITS scale and step size
           const double sPu = readlane_d(sPul, q), etaPu = readlane_d(etaPul, q), sPnu = readlane_d(sPnul, q);
           const double p = sPu * pv;
-          const double update = etaPu * (dLu * (vsu * (a1u - p * vsu)) + O.beta * p);
+          const double update = etaPu * (dLu * (vsu * (a1x - p * vsu)) + O.beta * p);
           const bool oddu = (__double_as_longlong(sPnu) & 0xFFFFFFFFFFFFFll) == 0xFFFFFFFFFFFFFll;
           Fl[q * K + lane] = oddu ? (p - update) / sPnu : div_by(p - update, sPnu, readlane_d(rynul, q));
         }
@@ -3099,6 +3141,10 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
           aff_B = -(etaPu * (vsu * (a1u - p * vsu))) / sPnu;
           aff_a1u = a1u;  // (kept: the writer's forwarding area may be reused by the time this sample's second half runs)
           aff_pv = pv;
+          aff_tu = tu;
+          aff_dw = (int)dwu;
+          // the writer's recipe is itself affine in ITS writer's dL (a1 = a1u + dL_w' tu): B = B0 + dL_w' B1
+          aff_B1 = aff_dw != 0 ? -(etaPu * (vsu * tu)) / sPnu : 0.0;
           if (!form_near_rows(fwdmask & ~aff_bit)) return;  // (the earlier writers' rows: exact)
           Fl[q * K + lane] = aff_A;
           if (lane == q) {  // the shared feature's linear weight the same way (fit_linear.nim:41-47): Aw + dL Bw
@@ -3126,10 +3172,8 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       apply_late(latemask);
       if (ADA && M.fit_linear && late) wv = ada_lin(wv, gwr, nwr);
     }
-    if (a.trace && lane == 0) {
-      a.trace[u * 8 + 1] = wall_clock64();  // dependencies resolved
-      a.trace[u * 8 + 6] = (affine ? 8 : 0) + (fwdmask ? (fwdmask & (fwdmask - 1) ? 4 : 2) : 0) + (farmask ? 1 : 0);  // which way
-    }
+    if (a.trace && lane == 0)  // dependencies resolved (x 16) + which way: 1 far wait, 2 near rows, 4 waited for a writer's dL, 8 affine
+      a.trace[u * 8 + 1] = wall_clock64() * 16 + ((affine ? 8 : 0) + ((fwdmask & ~aff_bit) ? 4 : 0) + (fwdmask ? 2 : 0) + (farmask ? 1 : 0));
     // ---- D. per-factor sums over the entries in storage order, their sum over the factors in ascending order ----
     double a1 = 0.0, a2 = 0.0;
 #pragma unroll
@@ -3186,7 +3230,39 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
         const double rest = a1 - xs * (sP * aff_A);
         double c1 = dev::wave_sum(lane < k ? (xs * (sP * aff_B)) * rest : 0.0);
         c1 += readlane_d((sw * aff_Bw) * vq, aff_q);
-        post_sum(a.fwd, a.np, W, slot, par, mytag, lane, yh_, y, h2, c1, (unsigned)readlane_i((int)tagl, aff_q));
+        const unsigned d1 = (unsigned)(u - ((int64_t)readlane_i(pq, aff_q) - a.seg0));  // (the writer's distance: 1 ... near_r - 1 <= 127)
+        double c12 = 0.0;
+        unsigned dists = d1;
+        if (aff_dw != 0) {  // S = S(A) + dL_u (C1 + dL_w' C12): the writer's writer, d1 + its distance back (<= 254: still in the conductor's ring)
+          c12 = dev::wave_sum(lane < k ? (xs * (sP * aff_B1)) * rest : 0.0);
+          dists |= (d1 + (unsigned)aff_dw) << 8;
+        }
+        post_sum(a.fwd, a.np, W, slot, par, mytag, lane, yh_, y, h2, c1, 0.0, c12, dists);
+        // This sample's own recipes NOW, with a1 as a function of the writer's dL -- a1 = a1(A) + dL_u T, T_s = x sP B_s -- so that
+        // its successors need not wait for that dL either (tools/seqwin_profile.py: what the conductor idled for were samples
+        // waiting for nothing but such a recipe).  Only when S is affine in ONE dL (a recipe that is bilinear already has no
+        // place in this format) and the affine row is not itself one a successor asks for.
+        if (aff_dw == 0 && hotmask && (hotmask & aff_bit) == 0ull) {
+          posted_early = true;
+          size_t fwo = ((size_t)(u & (W - 1)) * a.np + (size_t)((u >> lgW) & (a.np - 1))) * kFwSlot;
+          asm volatile("" : "+s"(fwo));
+          ull* fwm = a.fw + fwo;
+          fw_store(fwm + (size_t)lane * 2, mytag, a1);
+          fw_store(fwm + (size_t)(K + lane) * 2, mytag, lane < k ? xs * (sP * aff_B) : 0.0);
+          if (lane == 0) fw_store(fw_lin(fwm, 4, 0), mytag, (double)d1);
+#pragma unroll
+          for (int q = 0; q < K; ++q) {
+            if (q < m && ((hotmask >> q) & 1ull)) {
+              size_t fqo = ((size_t)(u & (W - 1)) * a.np + (size_t)((u >> lgW) & (a.np - 1))) * kFwSlot;
+              asm volatile("" : "+s"(fqo));
+              fw_store(fw_row(a.fw + fqo, 0, q), mytag, Pr[q]);
+            }
+          }
+          if ((hotmask >> lane) & 1ull) {
+            fw_store(fw_lin(fwm, 0, lane), mytag, wv);
+            fw_store(fw_lin(fwm, 3, lane), mytag, vq);
+          }
+        }
         // ... and now the exact row: the writer's dL, its update of the shared row, this sample's sums again with it
         {
           Spin sp;
@@ -3199,6 +3275,8 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
         }
         a1u = aff_a1u;  // (the recipe as read before the mailbox was posted)
         pv = aff_pv;
+        tu = aff_tu;
+        dwu = (double)aff_dw;
         q_loaded = aff_q;
         okr = true;
         if (!form_near_rows(aff_bit)) return;
@@ -3221,7 +3299,7 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
     }
     if (a.trace && lane == 0) a.trace[u * 8 + 2] = wall_clock64();  // mailbox posted
     // (after the mailbox: a successor needs them together with this sample's dL, which the conductor forms from the mailbox)
-    if (hotmask) {  // the recipes of the rows a near successor shares (the base is made opaque per use: left to itself the
+    if (hotmask && !posted_early) {  // the recipes of the rows a near successor shares (the base is made opaque per use: left to itself the
                     // compiler hoists the 192 row addresses out of the sample loop and spills them)
       // (an opaque OFFSET, not an opaque pointer: the address must stay provably global -- sc1 through flat_ instructions
       // is not the hand-off this kernel relies on)
@@ -3229,6 +3307,10 @@ __device__ __forceinline__ void win_worker_k64(const WinArgs& a, const int slot,
       asm volatile("" : "+s"(fwo));
       ull* fwm = a.fw + fwo;
       fw_store(fwm + (size_t)lane * 2, mytag, a1);
+      if constexpr (!ADA) {  // (an exact recipe: no slope, no writer)
+        fw_store(fwm + (size_t)(K + lane) * 2, mytag, 0.0);
+        if (lane == 0) fw_store(fw_lin(fwm, 4, 0), mytag, 0.0);
+      }
 #pragma unroll
       for (int q = 0; q < K; ++q) {
         if (q < m && ((hotmask >> q) & 1ull)) {
@@ -3832,7 +3914,7 @@ int launch_sequential_window(nfm_ctx* ctx, int opt_kind, const CsrView& X, const
   if (k64) lds_worker = sizeof(double) * ((ada ? 3 : 1) * (size_t)kWave * kWave + kWave) + sizeof(unsigned) * W;
   if (ffm) lds_worker = win_ffm_lds(M, m_cap, ada, W);
   if (fmx) lds_worker = win_fmx_lds(M, m_cap, ada, W);
-  const size_t lds_cond = one_term ? sizeof(double) * (2 + 7 * (size_t)kSumRing) + sizeof(unsigned) * kSumRing : sizeof(double) * 2 + sizeof(ull) * (size_t)kWinRing * FW;
+  const size_t lds_cond = one_term ? sizeof(double) * (2 + 9 * (size_t)kSumRing) + sizeof(unsigned) * kSumRing : sizeof(double) * 2 + sizeof(ull) * (size_t)kWinRing * FW;
   size_t lds_bytes = lds_worker > lds_cond ? lds_worker : lds_cond;
   if (lds_bytes > 160 * 1024) return NFM_WIN_FALLBACK;  // (NFM_SEQ_WIN_W beyond what seq_window_supported assumed: the one-workgroup kernel)
   if (lds_bytes < 81 * 1024) lds_bytes = 81 * 1024;  // one workgroup per CU

@@ -37,7 +37,8 @@ for solver in solvers:
         os.environ.pop("NFM_SEQ_WIN_TRACE", None)
         raw = np.fromfile(path, dtype=np.int64).reshape(-1, 8)
         print("  shader clock over the launch: %.0f MHz" % (100.0 * raw[-1, 0] / max(raw[-1, 1], 1)))
-        kind = raw[:, 6].copy()
+        kind = (raw[:, 1] & 15).copy()
+        raw[:, 1] >>= 4
         t = raw.astype(np.float64) / 100.0  # us
         lo, hi = 4 * W, len(t) - 4 * W
         T, K = t[lo:hi], kind[lo:hi]
@@ -46,8 +47,25 @@ for solver in solvers:
         print("%s W=%d: %.3f us per sample (answer to answer) = %.3g samples/s" % (solver, W, gap.mean(), 1e6 / gap.mean()))
         print("  conductor: gaps > 1 us: %.2f %% of samples, %.1f %% of the time; median gap %.3f us" %
               (100 * (gap > 1).mean(), 100 * gap[gap > 1].sum() / gap.sum(), np.median(gap)))
-        for name, sel in (("plain", K == 0), ("far wait only", K == 1), ("near, one writer, dL there", K & 14 == 2),
-                          ("near, several writers", (K & 4) != 0), ("near, affine", (K & 8) != 0)):
+        big = gap > 1.0
+        print("  of the samples the conductor waited > 1 us for: %s" % ", ".join("%s %.0f %%" % (nm, 100 * (sel_[big]).mean()) for nm, sel_ in
+              (("plain", K == 0), ("far only", K == 1), ("waited for a dL", (K & 4) != 0), ("affine only", (K & 12) == 8), ("near, exact", (K & 14) == 2))))
+        late = T[big]
+        print("    their worker: taken up -> resolved %.2f, resolved -> posted %.2f, posted -> fetched %.2f, fetched -> answered %.2f; taken up %.2f us before the answer"
+              % ((late[:, 1] - late[:, 0]).mean(), (late[:, 2] - late[:, 1]).mean(), (late[:, 5] - late[:, 2]).mean(), (late[:, 7] - late[:, 5]).mean(), (late[:, 7] - late[:, 0]).mean()))
+        # what made their workers late: the same worker's PREVIOUS sample (v - W)
+        idx_late = np.nonzero(big)[0] + lo
+        prev = t[idx_late - W]
+        kprev = kind[idx_late - W]
+        cur = t[idx_late]
+        print("    the same worker's previous sample: answered %.2f us before this answer; answered -> dL seen %.2f, dL seen -> written %.2f, "
+              "written -> this one taken up %.2f; kinds: plain %.0f %%, far %.0f %%, waited for a dL %.0f %%, affine only %.0f %%" %
+              ((cur[:, 7] - prev[:, 7]).mean(), (prev[:, 3] - prev[:, 7]).mean(), (prev[:, 4] - prev[:, 3]).mean(), (cur[:, 0] - prev[:, 4]).mean(),
+               100 * (kprev == 0).mean(), 100 * (kprev == 1).mean(), 100 * ((kprev & 4) != 0).mean(), 100 * ((kprev & 12) == 8).mean()))
+        print("    this sample: taken up -> resolved %.2f (median %.2f), resolved -> posted %.2f (median %.2f)" %
+              ((cur[:, 1] - cur[:, 0]).mean(), np.median(cur[:, 1] - cur[:, 0]), (cur[:, 2] - cur[:, 1]).mean(), np.median(cur[:, 2] - cur[:, 1])))
+        for name, sel in (("plain", K == 0), ("far wait only", K == 1), ("near, exact rows only", (K & 14) == 2),
+                          ("waited for a writer's dL", (K & 4) != 0), ("affine only", (K & 12) == 8)):
             if sel.sum() == 0:
                 continue
             S = T[sel]
