@@ -155,12 +155,14 @@ __device__ __forceinline__ bool fw_load(const ull* p, unsigned tag, double& v) {
 // The ONE-TERM mailbox (WinArgs::one_term): {S, y, the intercept's step size, C1, C2, C12, two writers} as thirteen tagged
 // granules, laid out granule-major -- fwd[(granule * np + parity) * W + worker] -- so that the conductor's fetch wavefront
 // reads one granule of 64 workers with one 512-byte access.  Tags instead of the "empty" pattern: nothing to reset after use.
-// C1 / C2 / C12 / writers (SGD): the sample shares a feature with each of (up to) two samples w1 > w2 inside the window whose dL
-// need not exist yet.  A writer's step of the shared row is AFFINE in its dL (sgd.nim:217-223: p' = A + dL B, A and B known at the
-// writer's forward pass) and the prediction is multilinear in the rows of different features, so
-//   S = S(A1, A2) + dL_w1 C1 + dL_w2 C2 + dL_w1 dL_w2 C12
-// exactly: the worker posts the four numbers without waiting for either dL, the conductor -- which made them -- finishes the
-// sum (win_conductor_sum).  The writers travel as distances (sample - writer, 1 ... 127; 0: none) in one granule.
+// C1 / C12 / writers (SGD): the sample shares ONE feature with a sample u inside the window whose dL need not exist yet.
+// The writer's step of the shared row is AFFINE in its dL (sgd.nim:217-223: p' = A + dL B, A and B known at the writer's forward
+// pass) and the prediction is multilinear in the rows of different features, so S = S(A) + dL_u C1 exactly: the worker posts
+// S(A) and C1 without waiting for dL_u, the conductor -- which made that dL -- finishes the sum (win_conductor_sum).  When u's
+// own recipe is affine in the dL of ITS writer w (see the forwarding area below), S = S(A) + dL_u (C1 + dL_w C12).  The format
+// carries S = S0 + dL_1 C1 + dL_2 (C2 + dL_1 C12) with two writers as distances (sample - writer; 0: none; the second one may
+// lie up to 254 positions back).  (Tried with the C2 slot: TWO writers' rows affine at once, S bilinear in their dL -- measured
+// +-0 on the headline and cfg2 shapes, twice: what the conductor waits for are chains of recipes, not second writers.  Not kept.)
 constexpr int kSumGran = 13;
 __device__ __forceinline__ void post_sum(ull* fwd, int np, int W, int slot, int par, unsigned tag, int lane, double S, double y, double h2,
                                          double C1 = 0.0, double C2 = 0.0, double C12 = 0.0, unsigned dists = 0u) {
@@ -295,6 +297,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
     near = near || lane == aff_q;
     const ull fwdmask = __ballot(near);
     const ull hotmask = __ballot(nq >= 0 && ((int64_t)nq - pos) < a.near_r);  // rows a near successor will ask the recipe of
+    if (a.trace && lane == 0) a.trace[u * 8 + 0] = wall_clock64();  // sample taken up
     for (int q = lane; q < mc; q += kWave) {
       const bool in = q < m;
       jl[q] = in ? X.indices[q0 + q] : 0;
@@ -553,6 +556,8 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       }
     }
 
+    if (a.trace && lane == 0)  // dependencies resolved (x 16) + which way: 2 near rows, 4 waited for a writer's dL, 8 affine
+      a.trace[u * 8 + 1] = wall_clock64() * 16 + ((affine ? 8 : 0) + ((fwdmask & ~aff_bit) ? 4 : 0) + (fwdmask ? 2 : 0));
     // ---- C. the per-factor sums over all entries in storage order (sgd.nim:160-170), their sum over the factors in
     // ascending order (:172-173); every row slot runs them, so every lane ends with its factor's sums ----
     double a1 = 0.0, a2 = 0.0;
@@ -681,6 +686,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       }
     }
 
+    if (a.trace && lane == 0) a.trace[u * 8 + 2] = wall_clock64();  // mailbox (and recipes) posted
     // ---- D. while the conductor works: the derivative (sgd.nim:176-188) and the step sizes ----
     for (int qb = 0; qb < m; qb += R * U) {
 #pragma unroll
@@ -721,6 +727,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
         for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);
     }
     if (lane == 0) loss_acc += dev::loss_value(O.loss, O.loss_param, y, yh);
+    if (a.trace && lane == 0) a.trace[u * 8 + 3] = wall_clock64();  // dL received
 
     // ---- E2. a row formed from its writer's recipe must not be STORED before the writer's own store of it has landed (two
     // stores to one address from two CUs are not ordered by anything else: with a conductor the writer's store is several
@@ -795,6 +802,7 @@ __device__ __forceinline__ void win_worker(const WinArgs& a, const int slot, dou
       if (3 * kWave + lane < W) cnt[3 * kWave + lane] = cr3_;
     }
     if (lane == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
+    if (a.trace && lane == 0) a.trace[u * 8 + 4] = wall_clock64();  // rows written
   }
   viol_acc = dev::wave_sum(viol_acc);
   if (lane == 0) {

@@ -9,7 +9,7 @@ from bench import gen_shard
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150_000
 Ws = [int(w) for w in sys.argv[2].split(",")] if len(sys.argv) > 2 else [64, 128]
 solvers = sys.argv[3].split(",") if len(sys.argv) > 3 else ["sgd", "adagrad"]
-d, m, k = 1_000_000, 64, 64
+d, m, k = (100_000, 32, 16) if os.environ.get("PROFILE_CFG2") else (1_000_000, 64, 64)  # cfg2's row shape: the LDS-resident worker
 dev = torch.device("cuda", 0)
 ctx = nf.Context(0); nf.set_default_context(ctx)
 if os.environ.get("PROFILE_NODEP"):  # no two samples share a feature: the conductor + hand-offs alone

@@ -43,6 +43,14 @@ for name in names:
         a, b = out["0"], out["2"]
         same = np.array_equal(a[0].view(np.uint64), b[0].view(np.uint64)) and np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64)) and a[2] == b[2]
         finite = np.isfinite(b[0]).all()
-        bad += 0 if (same and finite) else 1
-        print("%-8s %-8s d=%d: %s (finite %s); one workgroup %.2f s, window %.2f s" % (name, solver, wl["d"], "bit-equal" if same else "DIFFERENT", finite, a[3], b[3]), flush=True)
+        # the one-term flavour (the default with a fitted intercept) rounds the prediction differently: held to rtol 1e-8 / atol 1e-11
+        # (the tolerance of the oracle comparisons); the term-by-term flavour (NFM_SEQ_WIN_EXACT=1) and fits without an intercept: bits
+        one_term = FI and os.environ.get("NFM_SEQ_WIN_EXACT") != "1"
+        def close(x, y_):
+            return bool(np.all(np.abs(np.asarray(x) - np.asarray(y_)) <= 1e-11 + 1e-8 * np.abs(np.asarray(y_))))
+        ok = (close(b[0], a[0]) and close(b[1], a[1]) and close(b[2], a[2])) if one_term else same
+        rel = float(np.max(np.abs(b[0] - a[0]) / (np.abs(a[0]) + 1e-12 * np.max(np.abs(a[0]))))) if finite else float("nan")
+        bad += 0 if (ok and finite) else 1
+        print("%-8s %-8s d=%d: %s (finite %s, max rel diff %.2e); one workgroup %.2f s, window %.2f s" %
+              (name, solver, wl["d"], ("bit-equal" if same else "equal to 1e-8" if ok else "DIFFERENT"), finite, rel, a[3], b[3]), flush=True)
 sys.exit(1 if bad else 0)
