@@ -620,7 +620,10 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         # the exchange lives in the library (csrc/dp.hip): one RCCL communicator per rank, the replicas reconciled every
         # sync_period mini-batches on a second stream beside the next period's mini-batches, exactly at the end of the
         # epoch; torch.distributed only carried the group id (dp.Group.from_torch, in main)
-        sync_period = args.sync_period if args.sync_period >= 0 else (128 if n // batch >= 512 else (64 if n // batch >= 256 else 0))
+        # an exchange about every 1e6 samples per rank (128 mini-batches of 8192, 16 of 65536) when the epoch has at least four
+        # such stretches (half that for two); shorter epochs: the closing exchange only
+        sp_ = max(1, 1_048_576 // batch)
+        sync_period = args.sync_period if args.sync_period >= 0 else (sp_ if n // batch >= 4 * sp_ else (max(1, sp_ // 2) if n // batch >= 2 * sp_ else 0))
         opt.setDataParallel(run_training.group, sync_period, True, args.combine)
 
     def step(perm=None):
@@ -1116,8 +1119,8 @@ def main():
                          "written; the stopping criterion is then unavailable) -- an information run, not the metric")
     ap.add_argument("--cpu-samples", type=int, default=1_000_000)
     ap.add_argument("--sync-period", type=int, default=-1,
-                    help="N > 1: mini-batches between exchanges (0 = only at the end of every epoch; default 128 for epochs "
-                         "of >= 512 mini-batches, 64 for >= 256, else 0)")
+                    help="N > 1: mini-batches between exchanges (0 = only at the end of every epoch; default: about every 1e6 samples "
+                         "per rank -- 128 mini-batches of 8192, 16 of 65536 -- for epochs of at least four such stretches, else 0)")
     ap.add_argument("--combine", default="auto", choices=["auto", "mean", "sum", "state_mean"],
                     help="N > 1: how the ranks' increments are combined at an exchange (DESIGN.md section 6); auto = SGD: the mean, "
                          "AdaGrad: the state increments averaged (summed when the ranks exchange after every mini-batch)")
