@@ -55,10 +55,16 @@ enum { NFM_SCHED_CONSTANT = 0, NFM_SCHED_OPTIMAL = 1, NFM_SCHED_INVSCALING = 2, 
 /* NFM_MODE_SEQUENTIAL: one sample at a time in the given order -- the
  *   reference's single-thread semantics (optimizer/sgd.nim:294-308,
  *   optimizer/adagrad.nim:164-184): results equal to the CPU path's.  Run as
- *   a dependency window over the chip (0.8-1.3e6 samples/s; degree-2 FMs,
- *   several orders / degree <= 6, field-aware models of up to 22 entries per
- *   row; n_components <= 64; calls of >= 2048 samples), else one sample in
- *   flight (fitLower = augment, longer field-aware rows, more factors).
+ *   a dependency window over the chip (0.9-3.0e6 samples/s; degree-2 FMs,
+ *   several orders / degree <= 6, field-aware models; n_components <= 64;
+ *   calls of >= 2048 samples), else one sample in flight (fitLower = augment,
+ *   more factors, rows too long for the window's LDS).  With a fitted
+ *   intercept the window forms each prediction as intercept + (sum of the
+ *   sample's other terms) -- same order, same dependencies, parameters
+ *   within ~1e-11 relative of the one-sample-in-flight kernel; the environment
+ *   variable NFM_SEQ_WIN_EXACT=1 selects the term-by-term window, BIT-equal to
+ *   it (1.2e6 samples/s), NFM_SEQ_WIN_PAR=0 the bitwise-reproducible chain,
+ *   NFM_SEQ_WIN=0 the one-sample-in-flight kernel itself.
  * NFM_MODE_MINIBATCH: this library's deterministic data-parallel rule
  *   (DESIGN.md section 4); replaces the reference's racy Hogwild drivers
  *   (optimizer/sgd_multi.nim:40-120, adagrad_multi.nim:39-115); equals the
