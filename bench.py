@@ -337,13 +337,17 @@ def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, c
         P0 = np.random.default_rng(1).standard_normal((n_orders, k, d)) * 0.01
     w0 = np.zeros(d)
 
+    check = {}  # the one-thread run's parameters: what the GPU's exact order is compared with (run_training)
+
     def med(threads):
         if F:
-            (O.ffm_sgd_fit if sgd else O.ffm_adagrad_fit)(Xo, y[:nc], P0, w0, 0.0, cfg, epochs)
+            res_ = (O.ffm_sgd_fit if sgd else O.ffm_adagrad_fit)(Xo, y[:nc], P0, w0, 0.0, cfg, epochs)
         elif sgd:
-            O.fm_sgd_fit(Xo, y[:nc], wl["degree"], P0, w0, 0.0, cfg, epochs, hogwild_threads=threads)
+            res_ = O.fm_sgd_fit(Xo, y[:nc], wl["degree"], P0, w0, 0.0, cfg, epochs, hogwild_threads=threads)
         else:
-            O.fm_adagrad_fit(Xo, y[:nc], wl["degree"], P0, w0, 0.0, cfg, epochs)
+            res_ = O.fm_adagrad_fit(Xo, y[:nc], wl["degree"], P0, w0, 0.0, cfg, epochs)
+        if not threads:
+            check.update(P=res_[0], w=res_[1], b=res_[2], P0=P0, nc=nc, epochs=epochs)
         return float(np.median(O.epoch_seconds(epochs)[1:]))  # epoch 0 is the warm-up
 
     def med_jagged(threads_):
@@ -399,7 +403,7 @@ def cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, c
             cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
     except OSError:
         pass
-    return {"value": round(nc / t1, 1), "unit": "samples/s", "cores": 1, "kind": "port",
+    return {"_check": check, "value": round(nc / t1, 1), "unit": "samples/s", "cores": 1, "kind": "port",
             "sample": "the first %d samples of the same shard (same d, nnz/row, k); C restatement of optimizer/%s semantics, "
                       "flat arrays, gcc -O3 -march=native on this host, 1 thread, 1 warm-up epoch then the median of %d; "
                       "epoch loop only (the per-fit layout transposes, sgd.nim:292,328, are outside)"
@@ -761,6 +765,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     # reference-faithful CPU restatement) on a bounded prefix of the shard: the speed of the mode that reproduces the
     # reference exactly, reported beside the mini-batch rule's ----
     exact = None
+    windowed_any = k <= 64 and wl["degree"] <= 6  # (the shapes whose exact order runs at speed: seqwin.hip)
     if rank == 0 and world == 1 and not args.no_exact:
         # seqwin.hip: the order as a dependency window over the chip (degree-2 FMs, several orders / degree <= 6, field-aware
         # models whose chain terms -- one per entry and per pair of entries -- fit a mailbox)
@@ -949,6 +954,37 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         cpu = cpu_baseline_leg(args, wl, n, d, m, k, n_orders, indptr, indices, data, y, cheap=not primary,
                                fields=X._keep[3] if F else None)
 
+    chk = cpu.pop("_check", None) if cpu is not None else None
+    if exact is not None and chk and windowed_any:
+        # PARITY inside the bench: the same prefix, start and hyper-parameters through the GPU's exact order (mode=sequential,
+        # the default window flavour) and through the one-thread CPU port (the oracle's restatement of optimizer/sgd.nim:261-328 /
+        # adagrad.nim:137-203 -- run above as the reported baseline, here only its result is read): parameters after the same epochs
+        nc_, ep_ = chk["nc"], chk["epochs"]
+        Xc = nf.CSRDataset.from_device(ctx, nc_, d, nc_ * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(),
+                                       fields_ptr=_keep_fields.data_ptr() if F else None, nFields=F,
+                                       keep=(indptr, indices, data, _keep_fields))
+        Xc.set_targets(np.ascontiguousarray(y[:nc_]))
+        if F:
+            fc_ = nf.newFieldAwareFactorizationMachine(task, nComponents=k, warmStart=True, randomState=1)
+        else:
+            fc_ = nf.newFactorizationMachine(task, degree=wl["degree"], nComponents=k, warmStart=True, randomState=1)
+        fc_.set_params(chk["P0"], np.zeros(d), 0.0)
+        oc_ = (nf.newSGD if wl["solver"] == "sgd" else nf.newAdaGrad)(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="sequential")
+        oc_._handle(fc_, ctx, "sequential")
+        for _ in range(ep_):
+            oc_._epoch(Xc, None, 0, nc_)
+            oc_.it += nc_
+        oc_._finalize_into(fc_)
+
+        def rel2_(a_, b_):
+            b_ = np.asarray(b_, dtype=np.float64)
+            return float(np.max(np.abs(np.asarray(a_) - b_) / (np.abs(b_) + 1e-12 * max(float(np.max(np.abs(b_))), 1e-300))))
+
+        exact["vs_cpu_port_max_rel_diff"] = max(rel2_(np.array(fc_.P), chk["P"]), rel2_(np.array(fc_.w), chk["w"]),
+                                                abs(float(fc_.intercept) - chk["b"]) / max(abs(chk["b"]), 1e-300))
+        exact["vs_cpu_port_sample"] = ("parameters after %d epochs over the first %d samples: GPU exact order (default window flavour) against "
+                                       "the one-thread CPU port (built -O3 -march=native), same start and hyper-parameters" % (ep_, nc_))
+        del oc_, fc_, Xc
     if exact is not None and cpu is not None and cpu.get("value"):
         # both run the reference's sample order and give the same parameters: the like-for-like ratio
         exact["vs_cpu_port_1_thread"] = round(exact["value"] / cpu["value"], 2)
@@ -1040,6 +1076,7 @@ def _extra_compact(e):
             "predict": (e.get("predict") or {}).get("value"), "predict_frac": (e.get("predict") or {}).get("roofline_frac"),
             "exact_order": (e.get("exact_order") or {}).get("value"), "exact_bit_equal": (e.get("exact_order") or {}).get("bit_equal"),
             "exact_max_rel_diff": (e.get("exact_order") or {}).get("max_rel_diff"),
+            "exact_vs_cpu_port_max_rel_diff": (e.get("exact_order") or {}).get("vs_cpu_port_max_rel_diff"),
             "exact_vs_cpu_1_thread": (e.get("exact_order") or {}).get("vs_cpu_port_1_thread"),
             "exact_no_intercept": ((e.get("exact_order") or {}).get("no_intercept") or {}).get("value"),
             "t2t_batch": t["batch"] if t else None, "t2t_speedup": [h["speedup"] for h in t["targets"]] if t else None,
@@ -1062,7 +1099,8 @@ def contract_line(full):
     out["predict"] = {"value": p_["value"], "unit": p_["unit"], "roofline_frac": p_["roofline_frac"]} if p_ else None
     x_ = full.get("exact_order")
     out["exact_order"] = {"value": x_["value"], "unit": x_["unit"], "vs_cpu_port_1_thread": x_.get("vs_cpu_port_1_thread"),
-                          "max_rel_diff": x_.get("max_rel_diff"), "term_by_term": x_.get("value_term_by_term"),
+                          "max_rel_diff": x_.get("max_rel_diff"), "vs_cpu_port_max_rel_diff": x_.get("vs_cpu_port_max_rel_diff"),
+                          "term_by_term": x_.get("value_term_by_term"),
                           "bit_equal": x_.get("bit_equal"), "no_intercept": (x_.get("no_intercept") or {}).get("value"),
                           "no_intercept_vs_cpu_port_1_thread": (x_.get("no_intercept") or {}).get("vs_cpu_port_1_thread")} if x_ else None
     out["time_to_target"] = _t2t_compact(full.get("time_to_target"))

@@ -1048,7 +1048,7 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
   // without repeats: the plan comes from the column-major copy of the data (above).  NFM_PLAN_CSC=0 switches it off.
   static const bool csc_on = !(getenv("NFM_PLAN_CSC") && atoi(getenv("NFM_PLAN_CSC")) == 0);
   bool use_csc = csc_on && csc && !use_singles && n_aug == 0 && end <= X.n && P.n_batches <= kCscMaxBatches &&
-                 (double)P.n_batches * (double)X.d <= 134217728.0 && (double)T >= 0.5 * (double)P.n_batches * (double)X.d;
+                 (double)P.n_batches * (double)X.d <= 268435456.0 && (double)T >= 0.5 * (double)P.n_batches * (double)X.d;
   if (use_csc && !csc->built) NFM_TRY(csc_build(ctx, st, X, csc));
   use_csc = use_csc && csc->usable;
   if (use_csc) {
