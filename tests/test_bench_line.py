@@ -99,3 +99,26 @@ def test_contract_line_of_a_multi_gpu_run():
     assert out["n_gpus"] == 8 and out["dp"]["world"] == 8 and out["dp"]["progress_per_epoch"] == 1.12 and "note" not in out["dp"]
     assert out["cpu_baseline"] is None and out["exact_order"] is None and list(out["extra"]) == ["cfg3"]
     assert out["roofline"]["frac"] == full["roofline"]["frac"]
+
+
+def test_round5_detail_record_gives_a_complete_line():
+    """this round's own detail record (profiles/r05d_default_bench_detail.json) through contract_line: under 6 KB, and the
+    fields round 5 added are there -- the headline's value at the old batch, the best Hogwild setting and the ratio against
+    it, the exact order's flavours and how far the one-term window is from the one-workgroup kernel"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05d_default_bench_detail.json")))
+    line = bench.contract_line(full)
+    assert "\n" not in line and len(line) < 6000, len(line)
+    out = json.loads(line)
+    assert out["config"]["batch"] == 65536 and out["value_batch_8192"] and out["value_batch_8192"] < out["value"]
+    assert out["roofline"]["frac"] > 0.5
+    hog = out["cpu_baseline"]["hogwild"]
+    sweep = full["cpu_baseline"]["hogwild"]["sweep"]
+    assert hog["value"] == max(e["value"] for e in sweep) and len(sweep) >= 4  # the BEST of the sweep is what the line carries
+    assert abs(out["vs_best_cpu"] - out["value"] / max(hog["value"], out["cpu_baseline"]["value"])) < 0.1
+    x = out["exact_order"]
+    assert x["bit_equal"] is True and 0 < x["max_rel_diff"] < 1e-6 and x["term_by_term"] < x["value"]
+    for e in out["extra"].values():
+        assert e["exact_bit_equal"] is True and e["exact_max_rel_diff"] < 1e-6
