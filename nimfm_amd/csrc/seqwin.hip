@@ -940,6 +940,7 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
         compiler_fence();
       }
     }
+    if (a.trace && tid == 0) a.trace[u * 8 + 0] = wall_clock64();  // sample taken up, far dependencies waited for
     __syncthreads();
     const ull fwdmask = mk_l[0], hotmask = mk_l[1];
     double* const junk = reinterpret_cast<double*>(a.fw + (size_t)a.np * W * kFwSlot) + (size_t)slot * 2 * kWave + (lane & (kWave - 1));
@@ -1289,6 +1290,8 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
       }
     }
 
+    if (a.trace && tid == 0)  // mailbox (and recipes) posted; [1]: the same stamp x 16 + which way (2 near rows, 8 affine)
+      a.trace[u * 8 + 2] = wall_clock64(), a.trace[u * 8 + 1] = wall_clock64() * 16 + (fwdmask ? 2 : 0);
     // ---- D. the step sizes while the conductor works ----
     double eta_w = 0.0, eta_P = 0.0, sPn = 1.0, swn = 1.0;
     if constexpr (!ADA) {
@@ -1316,6 +1319,7 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
       yh = dev::shfl_d(rd, 1);
     }
     if (dead) break;  // (the launch is being aborted: every wavefront finds the abort word set)
+    if (a.trace && tid == 0) a.trace[u * 8 + 3] = wall_clock64();  // dL received
     if (wv == 0) {
       if (!a.no_cond && !a.one_term)
         for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);  // (as in the general worker)
@@ -1392,6 +1396,7 @@ __device__ __forceinline__ void win_worker_ffm(const WinArgs& a, const int slot,
     }
     __syncthreads();
     if (tid == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
+    if (a.trace && tid == 0) a.trace[u * 8 + 4] = wall_clock64();  // rows written
   }
   viol_acc = dev::wave_sum(viol_acc);
   if (lane == 0) vsum[wv] = viol_acc;
@@ -1547,6 +1552,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
         compiler_fence();
       }
     }
+    if (a.trace && tid == 0) a.trace[u * 8 + 0] = wall_clock64();  // sample taken up, far dependencies waited for
     __syncthreads();
     const ull fwdmask = mk_l[0], hotmask = mk_l[1];
     const int aff_q = (int)mk_l[2] - 1;  // (uniform over the workgroup) the entry whose rows are posted as affine in its writer's dL
@@ -1985,6 +1991,8 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
       }
     }
 
+    if (a.trace && tid == 0)  // mailbox (and recipes) posted; [1]: the same stamp x 16 + which way (2 near rows, 8 affine)
+      a.trace[u * 8 + 2] = wall_clock64(), a.trace[u * 8 + 1] = wall_clock64() * 16 + (fwdmask ? 2 : 0) + (affine ? 8 : 0);
     // ---- D. the step sizes while the conductor works ----
     double eta_w = 0.0, eta_P = 0.0, sPn = 1.0, swn = 1.0;
     if constexpr (!ADA) {
@@ -2012,6 +2020,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
       yh = dev::shfl_d(rd, 1);
     }
     if (dead) break;  // (the launch is being aborted: every wavefront finds the abort word set)
+    if (a.trace && tid == 0) a.trace[u * 8 + 3] = wall_clock64();  // dL received
     if (wv == 0) {
       if (!a.no_cond && !a.one_term)
         for (int e = lane; e < a.FW; e += kWave) st_u64(mb + e, kWinSentinel);  // (as in the general worker)
@@ -2088,6 +2097,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
     }
     __syncthreads();
     if (tid == 0) st_u32(a.completed + slot, (unsigned)(u >> lgW) + 1u);
+    if (a.trace && tid == 0) a.trace[u * 8 + 4] = wall_clock64();  // rows written
   }
   viol_acc = dev::wave_sum(viol_acc);
   if (lane == 0) vsum[wv] = viol_acc;

@@ -12,7 +12,13 @@ solvers = sys.argv[3].split(",") if len(sys.argv) > 3 else ["sgd", "adagrad"]
 d, m, k = (100_000, 32, 16) if os.environ.get("PROFILE_CFG2") else (1_000_000, 64, 64)  # cfg2's row shape: the LDS-resident worker
 dev = torch.device("cuda", 0)
 ctx = nf.Context(0); nf.set_default_context(ctx)
-if os.environ.get("PROFILE_NODEP"):  # no two samples share a feature: the conductor + hand-offs alone
+WL = os.environ.get("PROFILE_WL")  # cfg4 / cfg5: bench.py's field-aware / degree-3 workloads (the four-wavefront workers)
+if WL:
+    import bench
+    wl_ = bench.WORKLOADS[WL]
+    d, m, k = wl_["d"], wl_["m"], wl_["k"]
+    X, indptr, indices, data, _kf = bench.make_dataset(torch, nf, ctx, dev, wl_, n, 0)
+elif os.environ.get("PROFILE_NODEP"):  # no two samples share a feature: the conductor + hand-offs alone
     d = n * m
     indptr = torch.arange(n + 1, device=dev, dtype=torch.int64) * m
     indices = torch.arange(n * m, device=dev, dtype=torch.int32)
@@ -20,14 +26,18 @@ if os.environ.get("PROFILE_NODEP"):  # no two samples share a feature: the condu
     torch.cuda.synchronize()
 else:
     indptr, indices, data = gen_shard(torch, dev, n, d, m, 42)
-X = nf.CSRDataset.from_device(ctx, n, d, n * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), keep=(indptr, indices, data))
+if not WL:
+    X = nf.CSRDataset.from_device(ctx, n, d, n * m, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), keep=(indptr, indices, data))
 y = np.sign(np.random.default_rng(0).standard_normal(n))
 path = "/tmp/seqwin_trace.bin"
 for solver in solvers:
     for W in Ws:
         os.environ["NFM_SEQ_WIN"] = "2"; os.environ["NFM_SEQ_WIN_W"] = str(W)
         os.environ.pop("NFM_SEQ_WIN_TRACE", None)
-        fm = nf.newFactorizationMachine("classification", nComponents=k, randomState=1, warmStart=True)
+        if WL and wl_.get("fields"):
+            fm = nf.newFieldAwareFactorizationMachine("classification", nComponents=k, randomState=1, warmStart=True)
+        else:
+            fm = nf.newFactorizationMachine("classification", degree=wl_["degree"] if WL else 2, nComponents=k, randomState=1, warmStart=True)
         fm.init(X)
         mk = nf.newSGD if solver == "sgd" else nf.newAdaGrad
         opt = mk(maxIter=1, loss="logistic", verbose=0, tol=0, shuffle=False, mode="sequential")
