@@ -36,12 +36,13 @@ WORKLOADS = {
     # name: n, d, m, k, degree, solver, loss   (SURVEY.md 8d / BASELINE.md)
     # cfg2 names no batch size; 32768 keeps the two dependent launches per batch off the critical path
     # (DESIGN.md section 7).  cfg3 uses the 8192 that BASELINE.json states.  The north-star headline (SGD, one GPU) names no batch:
-    # 65536 since round 5 -- the batch with the best seconds-to-target of the sweep 8192 ... 65536 (tools/r5_batch_sweep.sh,
-    # profiles/r05a_*: the same targets in the same number of epochs, 15 % fewer seconds per epoch; at touch rate
-    # lambda = B m / d = 4.2 the column phase writes a row once per 4 touches); `value_batch_8192` on the line is the
-    # figure of rounds 1-4.
+    # 131072 since round 5 -- the batch with the best seconds-to-target of the sweep 8192 ... 262144 (tools/r5_batch_sweep.sh,
+    # profiles/r05a_headline_batch_sweep.txt, r05f_headline_batch_sweep_big.txt: the same targets in the same number of epochs
+    # as at 8192 / 65536, 26 % / 14 % fewer seconds per epoch; at touch rate lambda = B m / d = 8.4 the column phase writes a row
+    # once per 8 touches; 262144 moves 7 % more samples per second but needs 2 / 4 / 17 epochs instead of 1 / 3 / 8);
+    # `value_batch_8192` on the line is the figure of rounds 1-4.
     "cfg2": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768),
-    "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="logistic", batch=65536),
+    "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="logistic", batch=131072),
     "cfg3": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="squared", batch=8192),
     "cfg3l": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="logistic", batch=8192),
     # cfg5: higher-order FM, degree 3 with fitLower=explicit -> two parameter blocks (ANOVA degree 3 and 2)
@@ -624,7 +625,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         # the exchange lives in the library (csrc/dp.hip): one RCCL communicator per rank, the replicas reconciled every
         # sync_period mini-batches on a second stream beside the next period's mini-batches, exactly at the end of the
         # epoch; torch.distributed only carried the group id (dp.Group.from_torch, in main)
-        # an exchange about every 1e6 samples per rank (128 mini-batches of 8192, 16 of 65536) when the epoch has at least four
+        # an exchange about every 1e6 samples per rank (128 mini-batches of 8192, 8 of 131072) when the epoch has at least four
         # such stretches (half that for two); shorter epochs: the closing exchange only
         sp_ = max(1, 1_048_576 // batch)
         sync_period = args.sync_period if args.sync_period >= 0 else (sp_ if n // batch >= 4 * sp_ else (max(1, sp_ // 2) if n // batch >= 2 * sp_ else 0))
@@ -1158,7 +1159,7 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=1_000_000)
     ap.add_argument("--sync-period", type=int, default=-1,
                     help="N > 1: mini-batches between exchanges (0 = only at the end of every epoch; default: about every 1e6 samples "
-                         "per rank -- 128 mini-batches of 8192, 16 of 65536 -- for epochs of at least four such stretches, else 0)")
+                         "per rank -- 128 mini-batches of 8192, 8 of 131072 -- for epochs of at least four such stretches, else 0)")
     ap.add_argument("--combine", default="auto", choices=["auto", "mean", "sum", "state_mean"],
                     help="N > 1: how the ranks' increments are combined at an exchange (DESIGN.md section 6); auto = SGD: the mean, "
                          "AdaGrad: the state increments averaged (summed when the ranks exchange after every mini-batch)")

@@ -194,3 +194,39 @@ def test_headline_shape_adagrad_vs_mb_oracle(headline_problem):
     assert_close(fm.w, w, 1e-9, 1e-13, "w")
     assert_close(fm.P, P, 1e-9, 1e-13, "P")
     assert_close(ada.history[0][0], vs, 1e-9, 0, "viol")
+
+
+# ---- the headline at the batch bench.py quotes since round 5: 131072 (touch rate lambda = B m / d = 8.4: every feature of
+# the model is touched in every batch, a row is written once per ~8 touches, the touch cap of 16 bites on the tail of the
+# Poisson(8.4) touch counts).  Two full batches + a ragged one; cap 16 as in the bench.
+HB2 = 131072
+
+
+def test_headline_shape_at_the_bench_batch_131072():
+    n = 2 * HB2 + 4001
+    Xo = big_csr(n, HD, HM, 47)
+    rng = np.random.default_rng(5)
+    y = np.sign(rng.standard_normal(n))
+    P0, w0 = (rng.standard_normal((1, HK, HD)) * 0.01), np.zeros(HD)
+    cfg = O.sgd_cfg(loss="logistic")
+    P, w = P0.copy(), w0.copy()
+    b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, 0.0, cfg, HB2, it=1, touch_cap=16.0)
+    # a second epoch over a permuted order (the plan of a shuffled epoch: the bucketing path)
+    perm = np.random.default_rng(6).permutation(n).astype(np.int64)
+    b, it, ls2, vs2 = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, b, cfg, HB2, it=it, touch_cap=16.0, perm=perm)
+    X = to_gpu(Xo)
+    fm = gpu_fm("classification", 2, HK, "explicit", True, True, P0, w0, 0.0)
+    sgd = nf.newSGD(maxIter=1, verbose=0, tol=0, shuffle=False, loss="logistic", mode="minibatch", batch=HB2, touchCap=16.0)
+    sgd._handle(fm, X.ctx, "minibatch")
+    X.set_targets(y)
+    l1, v1 = sgd._epoch(X, None, 0, n)
+    sgd.it += n
+    l2, v2 = sgd._epoch(X, perm, 0, n)
+    sgd.it += n
+    sgd._finalize_into(fm)
+    assert sgd.it == it
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, 1e-9, 1e-13, "w")
+    assert_close(fm.P, P, 1e-9, 1e-13, "P")
+    assert_close([l1, l2], [ls, ls2], 1e-11, 0, "loss sums")
+    assert_close([v1, v2], [vs, vs2], 1e-9, 0, "viol")

@@ -1,11 +1,12 @@
 #!/bin/bash
 # round 5: the mini-batch rule at LARGER batches -- throughput + roofline per batch, then time_to_target
-# over the same batches (one run: the sequential targets are computed once).  usage: r5_batch_sweep.sh headline|cfg3 [samples]
+# over the same batches (one run: the sequential targets are computed once).  usage: [BATCHES="..." T2T=a,b] r5_batch_sweep.sh headline|cfg3 [samples]
 set -o pipefail
 W=${1:-headline}; NS=${2:-0}
 mkdir -p gpurun_out
 EXTRA=""; [ "$NS" != "0" ] && EXTRA="--samples $NS"
-for B in 8192 16384 32768 65536; do
+BATCHES=${BATCHES:-"8192 16384 32768 65536"}; T2T=${T2T:-16384,32768,65536}
+for B in $BATCHES; do
   timeout -k 10 420 python bench.py --workload $W --batch $B $EXTRA --no-extra --no-t2t --no-exact --no-cpu-baseline --steps 10 --warmup 3 \
     > gpurun_out/r5_sweep_${W}_B${B}.json 2> gpurun_out/r5_sweep_${W}_B${B}.err || { tail -5 gpurun_out/r5_sweep_${W}_B${B}.err; exit 1; }
   python - <<PY
@@ -14,7 +15,7 @@ r = json.loads(open("gpurun_out/r5_sweep_${W}_B${B}.json").read().strip().splitl
 print("$W B=$B: %.4g samples/s, frac %.3f, shuffled %s, avg_ms %s" % (r["value"], r["roofline"]["frac"], r.get("value_shuffled"), r["roofline"]["avg_ms"]), flush=True)
 PY
 done
-timeout -k 10 900 python bench.py --workload $W $EXTRA --no-extra --no-exact --no-cpu-baseline --steps 3 --warmup 1 --t2t-batches 16384,32768,65536 \
+timeout -k 10 900 python bench.py --workload $W $EXTRA --no-extra --no-exact --no-cpu-baseline --steps 3 --warmup 1 --t2t-batches $T2T \
   > gpurun_out/r5_sweep_${W}_t2t.json 2> gpurun_out/r5_sweep_${W}_t2t.err || { tail -5 gpurun_out/r5_sweep_${W}_t2t.err; exit 1; }
 cp gpurun_out/bench_detail.json gpurun_out/r5_sweep_${W}_t2t_detail.json
 python - <<PY
