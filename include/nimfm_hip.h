@@ -185,7 +185,12 @@ typedef struct nfm_model_cfg {
   int32_t kind;          /* NFM_KIND_* */
   int32_t task;          /* NFM_TASK_* */
   int32_t degree;        /* FM only; FFM is degree 2 */
-  int32_t n_components;  /* k */
+  int32_t n_components;  /* k -- no cap for FactorizationMachines: above 128 the factors of an order
+                          * are kept as blocks of at most 128 on the device (an ANOVA kernel is a sum over
+                          * the factors, kernels.nim:46-64), the layouts at this boundary stay the
+                          * reference's; decisionFunction, SGD and AdaGrad in both modes take such models
+                          * (MBPSGD does not: its matrix prox needs a feature's factors in one row).
+                          * Field-aware models: k <= 128 outside NFM_MODE_SEQUENTIAL. */
   int32_t fit_lower;     /* NFM_LOWER_* (FM only) */
   int32_t fit_intercept;
   int32_t fit_linear;

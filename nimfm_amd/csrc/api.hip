@@ -51,7 +51,9 @@ struct nfm_model {
   uint64_t uid = 0;  // process-unique; optimizers refer to their model by it (an address can be handed out again)
   nfm_ctx* ctx = nullptr;
   nfm_model_cfg cfg{};
-  int nb = 0, n_aug = 0, k = 0, Kp = 0, L = 0;
+  // k: n_components; FMs with k > 128: the factors of an order are cut into kc device blocks of kb <= 128 factors
+  // (ModelView::kc) -- nb counts DEVICE blocks (orders x kc; fields for field-aware models), no the reference's orders
+  int nb = 0, no = 0, kc = 1, kb = 0, n_aug = 0, k = 0, Kp = 0, L = 0;
   int64_t d = 0, da = 0;
   // P, w and the scalars live back to back in ONE allocation ([P | w | scalars], each padded to 256 B,
   // padding zero) so the data-parallel exchange is a single collective over the arena
@@ -61,7 +63,7 @@ struct nfm_model {
   ModelView view() const {
     ModelView m{};
     m.P = P.as<double>(); m.w = w.as<double>(); m.sc = sc.as<double>(); m.lams = lams.as<double>();
-    m.d = d; m.da = da; m.nb = nb; m.k = k; m.Kp = Kp; m.L = L;
+    m.d = d; m.da = da; m.nb = nb; m.k = kb; m.Kp = Kp; m.L = L; m.kc = kc;
     if (cfg.kind == NFM_KIND_FFM) { m.bs = 1; m.rs = nb; } else { m.bs = da; m.rs = 1; }
     m.degree = cfg.kind == NFM_KIND_FFM ? 2 : cfg.degree;
     m.n_aug = n_aug; m.kind = cfg.kind; m.fit_linear = cfg.fit_linear; m.fit_intercept = cfg.fit_intercept;
@@ -69,7 +71,42 @@ struct nfm_model {
     return m;
   }
   int64_t nP() const { return (int64_t)nb * da * Kp; }
+  int64_t n_ref() const { return (int64_t)no * k * da; }  // elements of the reference's P (and of each AdaGrad state tensor)
 };
+
+// ---- reference layouts <-> device blocks (util.hip does one block range at a time) ----
+// FM parameters: reference [no][k][da] <-> device [no * kc][da][Kp]; block o * kc + c holds the factors c * kb ... of order o
+static int fm_params_to_device(nfm_model* m, const double* src_ref, double* dst_dev) {
+  if (m->kc == 1) return launch_fm_to_device(m->ctx, src_ref, dst_dev, m->nb, m->k, m->Kp, m->da);
+  for (int o = 0; o < m->no; ++o)
+    for (int c = 0; c < m->kc; ++c) {
+      const int kk = std::min(m->kb, m->k - c * m->kb);
+      NFM_TRY(launch_fm_to_device(m->ctx, src_ref + ((size_t)o * m->k + (size_t)c * m->kb) * m->da,
+                                  dst_dev + (size_t)(o * m->kc + c) * m->da * m->Kp, 1, kk, m->Kp, m->da));
+    }
+  return NFM_OK;
+}
+static int fm_params_from_device(nfm_model* m, const double* src_dev, double* dst_ref, const double* scale_dev) {
+  if (m->kc == 1) return launch_fm_from_device(m->ctx, src_dev, dst_ref, m->nb, m->k, m->Kp, m->da, scale_dev);
+  for (int o = 0; o < m->no; ++o)
+    for (int c = 0; c < m->kc; ++c) {
+      const int kk = std::min(m->kb, m->k - c * m->kb);
+      NFM_TRY(launch_fm_from_device(m->ctx, src_dev + (size_t)(o * m->kc + c) * m->da * m->Kp,
+                                    dst_ref + ((size_t)o * m->k + (size_t)c * m->kb) * m->da, 1, kk, m->Kp, m->da, scale_dev));
+    }
+  return NFM_OK;
+}
+// row tensors in the training layout (AdaGrad state, gradients): reference [no * da][k] <-> device [nb * da][Kp]
+static int rows_to_device(nfm_model* m, const double* src_ref, double* dst_dev, double pad) {
+  const int major = m->cfg.kind == NFM_KIND_FFM ? m->nb : 0;  // (feature-major field rows, ModelView::row)
+  if (m->kc == 1) return launch_rows_to_device(m->ctx, src_ref, dst_dev, (int64_t)m->nb * m->da, m->k, m->Kp, pad, major);
+  return launch_rows_split_to_device(m->ctx, src_ref, dst_dev, m->no, m->da, m->k, m->kc, m->kb, m->Kp, pad);
+}
+static int rows_from_device(nfm_model* m, const double* src_dev, double* dst_ref, const double* scale_dev) {
+  const int major = m->cfg.kind == NFM_KIND_FFM ? m->nb : 0;
+  if (m->kc == 1) return launch_rows_from_device(m->ctx, src_dev, dst_ref, (int64_t)m->nb * m->da, m->k, m->Kp, scale_dev, major);
+  return launch_rows_split_from_device(m->ctx, src_dev, dst_ref, m->no, m->da, m->k, m->kc, m->kb, m->Kp, scale_dev);
+}
 
 struct nfm_opt {
   nfm_ctx* ctx = nullptr;  // kept separately: the optimizer may outlive its model handle
@@ -626,9 +663,16 @@ int32_t nfm_model_create(nfm_ctx* ctx, const nfm_model_cfg* cfg, nfm_model** out
     m->nb = (int)cfg->n_fields;
   }
   m->da = m->d + m->n_aug;
-  m->L = lanes_for_k(m->k);
-  m->Kp = m->k <= 128 ? 2 * m->L : ((m->k + 63) / 64) * 64;
-  if (m->k > 128) m->L = 64;
+  m->no = m->nb;
+  m->kb = m->k;
+  if (cfg->kind == NFM_KIND_FM && m->k > 128) {  // wide FM: kc blocks of kb <= 128 factors per order (ModelView::kc)
+    m->kc = (m->k + 127) / 128;
+    m->kb = (m->k + m->kc - 1) / m->kc;
+    m->nb = m->no * m->kc;
+  }
+  m->L = lanes_for_k(m->kb);
+  m->Kp = m->kb <= 128 ? 2 * m->L : ((m->kb + 63) / 64) * 64;  // (field-aware models keep wide rows: the one-sample-in-flight kernel takes them)
+  if (m->kb > 128) m->L = 64;
   {
     const size_t bP = pad256(sizeof(double) * std::max<int64_t>(m->nP(), 2)), bw = pad256(sizeof(double) * m->d);
     NFM_TRY(m->arena.alloc(bP + bw + sizeof(double) * SC_COUNT));
@@ -638,7 +682,7 @@ int32_t nfm_model_create(nfm_ctx* ctx, const nfm_model_cfg* cfg, nfm_model** out
     m->w = {base + bP, bw};
     m->sc = {base + bP + bw, sizeof(double) * SC_COUNT};
   }
-  NFM_TRY(m->lams.alloc(sizeof(double) * m->Kp));
+  NFM_TRY(m->lams.alloc(sizeof(double) * m->kc * m->Kp));
   double sc[SC_COUNT] = {1.0, 1.0, 0.0, 0, 0, 0, 0, 0};
   NFM_HIP_CHECK(hipMemcpyAsync(m->sc.p, sc, sizeof(sc), hipMemcpyHostToDevice, ctx->stream));
   NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -649,7 +693,7 @@ int32_t nfm_model_create(nfm_ctx* ctx, const nfm_model_cfg* cfg, nfm_model** out
 
 int32_t nfm_model_shape(const nfm_model* m, int32_t* n_blocks, int32_t* n_aug) {
   NFM_CHECK(m, NFM_ERR_INVALID, "null model");
-  if (n_blocks) *n_blocks = m->nb;
+  if (n_blocks) *n_blocks = m->no;  // the reference's orders (fields): the first extent of its P
   if (n_aug) *n_aug = m->n_aug;
   return NFM_OK;
 }
@@ -660,23 +704,23 @@ int32_t nfm_model_set_params(nfm_model* m, const double* P, const double* w, dou
   nfm_ctx* ctx = m->ctx;
   NFM_TRY(use_device(ctx));
   hipStream_t st = ctx->stream;
-  const int64_t n_ref = (int64_t)m->nb * m->k * m->da;
+  const int64_t n_ref = m->n_ref();
   if (n_ref > 0) {
     DevBuf tmp;
     NFM_TRY(tmp.alloc(sizeof(double) * n_ref));
     NFM_HIP_CHECK(hipMemcpyAsync(tmp.p, P, sizeof(double) * n_ref, hipMemcpyHostToDevice, st));
     if (m->cfg.kind == NFM_KIND_FM)
-      NFM_TRY(launch_fm_to_device(ctx, tmp.as<double>(), m->P.as<double>(), m->nb, m->k, m->Kp, m->da));
+      NFM_TRY(fm_params_to_device(m, tmp.as<double>(), m->P.as<double>()));
     else
-      NFM_TRY(launch_rows_to_device(ctx, tmp.as<double>(), m->P.as<double>(), (int64_t)m->nb * m->da, m->k, m->Kp, 0.0, m->nb));
+      NFM_TRY(rows_to_device(m, tmp.as<double>(), m->P.as<double>(), 0.0));
     NFM_HIP_CHECK(hipStreamSynchronize(st));
   }
   NFM_HIP_CHECK(hipMemcpyAsync(m->w.p, w, sizeof(double) * m->d, hipMemcpyHostToDevice, st));
   double sc[SC_COUNT] = {1.0, 1.0, intercept, 0, 0, 0, 0, 0};
   NFM_HIP_CHECK(hipMemcpyAsync(m->sc.p, sc, sizeof(sc), hipMemcpyHostToDevice, st));
-  std::vector<double> lp((size_t)m->Kp, 0.0);
-  for (int s = 0; s < m->k; ++s) lp[s] = lams ? lams[s] : 1.0;
-  NFM_HIP_CHECK(hipMemcpyAsync(m->lams.p, lp.data(), sizeof(double) * m->Kp, hipMemcpyHostToDevice, st));
+  std::vector<double> lp((size_t)m->kc * m->Kp, 0.0);
+  for (int s = 0; s < m->k; ++s) lp[(size_t)(s / m->kb) * m->Kp + s % m->kb] = lams ? lams[s] : 1.0;
+  NFM_HIP_CHECK(hipMemcpyAsync(m->lams.p, lp.data(), sizeof(double) * lp.size(), hipMemcpyHostToDevice, st));
   NFM_HIP_CHECK(hipStreamSynchronize(st));
   m->initialized = true;
   return NFM_OK;
@@ -690,15 +734,14 @@ int32_t nfm_model_get_params(nfm_model* m, double* P, double* w, double* interce
   hipStream_t st = ctx->stream;
   double sc[SC_COUNT];
   NFM_HIP_CHECK(hipMemcpyAsync(sc, m->sc.p, sizeof(sc), hipMemcpyDeviceToHost, st));
-  const int64_t n_ref = (int64_t)m->nb * m->k * m->da;
+  const int64_t n_ref = m->n_ref();
   if (P && n_ref > 0) {
     DevBuf tmp;
     NFM_TRY(tmp.alloc(sizeof(double) * n_ref));
     if (m->cfg.kind == NFM_KIND_FM)
-      NFM_TRY(launch_fm_from_device(ctx, m->P.as<double>(), tmp.as<double>(), m->nb, m->k, m->Kp, m->da, m->sc.as<double>() + SC_SCALE_P));
+      NFM_TRY(fm_params_from_device(m, m->P.as<double>(), tmp.as<double>(), m->sc.as<double>() + SC_SCALE_P));
     else
-      NFM_TRY(launch_rows_from_device(ctx, m->P.as<double>(), tmp.as<double>(), (int64_t)m->nb * m->da, m->k, m->Kp,
-                                      m->sc.as<double>() + SC_SCALE_P, m->nb));
+      NFM_TRY(rows_from_device(m, m->P.as<double>(), tmp.as<double>(), m->sc.as<double>() + SC_SCALE_P));
     NFM_HIP_CHECK(hipMemcpyAsync(P, tmp.p, sizeof(double) * n_ref, hipMemcpyDeviceToHost, st));
     NFM_HIP_CHECK(hipStreamSynchronize(st));
   }
@@ -851,6 +894,7 @@ int32_t nfm_mbpsgd_create(nfm_model* m, const nfm_mbpsgd_cfg* c, nfm_opt** out) 
   NFM_CHECK(c->scheduling >= 0 && c->scheduling <= 3, NFM_ERR_INVALID, "bad scheduling id");
   NFM_CHECK(c->reg >= NFM_REG_L1 && c->reg <= NFM_REG_SQUAREDL21, NFM_ERR_INVALID, "bad regularizer id");
   NFM_CHECK(m->cfg.kind == NFM_KIND_FM, NFM_ERR_UNSUPPORTED, "MBPSGD fits a FactorizationMachine (minibatch_psgd.nim:125-126)");
+  NFM_CHECK(m->kc == 1, NFM_ERR_UNSUPPORTED, "MBPSGD supports n_components <= 128 (the matrix prox needs a feature's factors in one row)");
   if (c->reg == NFM_REG_SQUAREDL12)  // squaredl12.nim:103-105
     NFM_CHECK(m->cfg.degree == 2, NFM_ERR_INVALID, "SquaredL12 supports only degree=2.");
   if (c->reg == NFM_REG_SQUAREDL21) {  // squaredl21.nim:27-28
@@ -911,14 +955,13 @@ int32_t nfm_opt_get_state(nfm_opt* o, double* gsum_P, double* gnorm_P, double* g
   nfm_ctx* ctx = m->ctx;
   NFM_TRY(use_device(ctx));
   if (!o->state_ready) NFM_TRY(adagrad_reset_state(o));
-  const int64_t rows = (int64_t)m->nb * m->da, n_ref = rows * m->k;
-  const int major = m->cfg.kind == NFM_KIND_FFM ? m->nb : 0;  // the state shares the parameters' device layout
+  const int64_t n_ref = m->n_ref();  // (the state shares the parameters' device layout)
   DevBuf tmp;
   NFM_TRY(tmp.alloc(sizeof(double) * std::max<int64_t>(n_ref, 1)));
   for (int which = 0; which < 2; ++which) {
     double* dst = which ? gnorm_P : gsum_P;
     if (!dst || n_ref == 0) continue;
-    NFM_TRY(launch_rows_from_device(ctx, which ? o->N.as<double>() : o->G.as<double>(), tmp.as<double>(), rows, m->k, m->Kp, nullptr, major));
+    NFM_TRY(rows_from_device(m, which ? o->N.as<double>() : o->G.as<double>(), tmp.as<double>(), nullptr));
     NFM_HIP_CHECK(hipMemcpyAsync(dst, tmp.p, sizeof(double) * n_ref, hipMemcpyDeviceToHost, ctx->stream));
     NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   }
@@ -940,18 +983,17 @@ int32_t nfm_opt_set_state(nfm_opt* o, const double* gsum_P, const double* gnorm_
   NFM_TRY(model_of(o, &m));
   nfm_ctx* ctx = m->ctx;
   NFM_TRY(use_device(ctx));
-  const int64_t rows = (int64_t)m->nb * m->da, n_ref = rows * m->k;
-  const int major = m->cfg.kind == NFM_KIND_FFM ? m->nb : 0;  // the state shares the parameters' device layout
+  const int64_t n_ref = m->n_ref();  // (the state shares the parameters' device layout)
   NFM_CHECK(n_ref == 0 || (gsum_P && gnorm_P), NFM_ERR_INVALID, "null state");
   NFM_CHECK(gsum_w && gnorm_w, NFM_ERR_INVALID, "null state");
   DevBuf tmp;
   NFM_TRY(tmp.alloc(sizeof(double) * std::max<int64_t>(n_ref, 1)));
   if (n_ref > 0) {
     NFM_HIP_CHECK(hipMemcpyAsync(tmp.p, gsum_P, sizeof(double) * n_ref, hipMemcpyHostToDevice, ctx->stream));
-    NFM_TRY(launch_rows_to_device(ctx, tmp.as<double>(), o->G.as<double>(), rows, m->k, m->Kp, 0.0, major));
+    NFM_TRY(rows_to_device(m, tmp.as<double>(), o->G.as<double>(), 0.0));
     NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     NFM_HIP_CHECK(hipMemcpyAsync(tmp.p, gnorm_P, sizeof(double) * n_ref, hipMemcpyHostToDevice, ctx->stream));
-    NFM_TRY(launch_rows_to_device(ctx, tmp.as<double>(), o->N.as<double>(), rows, m->k, m->Kp, o->o.eps, major));
+    NFM_TRY(rows_to_device(m, tmp.as<double>(), o->N.as<double>(), o->o.eps));
     NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   }
   NFM_HIP_CHECK(hipMemcpyAsync(o->Gw.p, gsum_w, sizeof(double) * m->d, hipMemcpyHostToDevice, ctx->stream));
@@ -1332,11 +1374,10 @@ int32_t nfm_opt_predict_all_with_grad(nfm_opt* o, nfm_dataset* ds, double* y_pre
     NFM_HIP_CHECK(hipStreamSynchronize(st));
   }
   if (grad_P && m->nP() > 0) {  // device [nb][da][Kp] -> the training layout [nb][da][k]
-    const int64_t rows = (int64_t)m->nb * m->da;
     DevBuf tmp;
-    NFM_TRY(tmp.alloc(sizeof(double) * rows * m->k));
-    NFM_TRY(launch_rows_from_device(ctx, g.as<double>(), tmp.as<double>(), rows, m->k, m->Kp, nullptr, 0));
-    NFM_HIP_CHECK(hipMemcpyAsync(grad_P, tmp.p, sizeof(double) * rows * m->k, hipMemcpyDeviceToHost, st));
+    NFM_TRY(tmp.alloc(sizeof(double) * m->n_ref()));
+    NFM_TRY(rows_from_device(m, g.as<double>(), tmp.as<double>(), nullptr));
+    NFM_HIP_CHECK(hipMemcpyAsync(grad_P, tmp.p, sizeof(double) * m->n_ref(), hipMemcpyDeviceToHost, st));
     NFM_HIP_CHECK(hipStreamSynchronize(st));
   }
   if (grad_w) NFM_HIP_CHECK(hipMemcpyAsync(grad_w, g.as<char>() + bP, sizeof(double) * m->d, hipMemcpyDeviceToHost, st));

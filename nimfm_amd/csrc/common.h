@@ -68,9 +68,15 @@ struct ModelView {
   double* P;
   double* w;
   double* sc;
-  const double* lams;  // [Kp], zero padded
+  const double* lams;  // [kc][Kp], zero padded: block b's factors at lams + (b % kc) * Kp
   int64_t d, da;
   int32_t nb, k, Kp, L, degree, n_aug, kind, fit_linear, fit_intercept, task;
+  // FM with more than 128 factors: the factors of one order are cut into kc device blocks of at most 128 (k = factors per
+  // block, the last one zero padded) -- an ANOVA kernel is a sum over the factors of terms that do not mix them
+  // (kernels.nim:46-64), so kc blocks of the same degree ARE the wide model, and every kernel that walks "orders" takes them
+  // as they come: block b belongs to order b / kc.  kc = 1 otherwise.
+  int32_t kc;
+  __host__ __device__ int deg_of(int b) const { return degree - b / kc; }
   // parameter row (block b, feature j) starts at (b * bs + j * rs) * Kp; every kernel goes through row().
   // FM: order-major (bs = da, rs = 1).  FFM: FEATURE-major (bs = 1, rs = nb): the nb field rows of one feature --
   // what a sample reads and, in the reference's update, writes together -- are one contiguous run of nb * Kp doubles
@@ -194,6 +200,11 @@ int launch_fm_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, 
 // nb_major > 0: the reference tensor is [nb_major][rows / nb_major][k], the device tensor feature-major (ModelView::row)
 int launch_rows_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int64_t rows, int k, int Kp, double pad_value, int nb_major = 0);
 int launch_rows_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int64_t rows, int k, int Kp, const double* scale_dev, int nb_major = 0);
+// FMs with more than 128 factors: reference [no * da][k] <-> device [no * kc][da][Kp] (ModelView::kc)
+int launch_rows_split_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int64_t no, int64_t da, int k, int kc, int kb, int Kp,
+                                double pad_value);
+int launch_rows_split_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int64_t no, int64_t da, int k, int kc, int kb, int Kp,
+                                  const double* scale_dev);
 // P *= sc[SC_SCALE_P], w *= sc[SC_SCALE_W] (if fit_linear), scales := 1  (sgd.nim:99-113)
 int launch_rescale(nfm_ctx* ctx, const ModelView& M);
 int launch_sqnorms(nfm_ctx* ctx, const ModelView& M, double* out2_dev /*{P_sq,w_sq}*/);

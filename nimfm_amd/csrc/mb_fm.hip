@@ -174,10 +174,10 @@ int mb_fm_epoch(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelView& M
                 int64_t it0, double* out2_host, uint64_t data_serial, bool defer_sync) {
   NFM_CHECK(M.kind == NFM_KIND_FM, NFM_ERR_UNSUPPORTED, "mb_fm_epoch: FM only");
   NFM_CHECK(M.degree <= dev::kMaxDeg, NFM_ERR_UNSUPPORTED, "mini-batch mode supports degree <= %d", dev::kMaxDeg);
-  NFM_CHECK(M.Kp == 2 * M.L && M.Kp <= 128, NFM_ERR_UNSUPPORTED, "mini-batch mode supports n_components <= 128");
+  NFM_CHECK(M.Kp == 2 * M.L && M.Kp <= 128, NFM_ERR_UNSUPPORTED, "mini-batch mode: factor blocks of at most 128 (api.hip splits wider FMs)");
   hipStream_t st = ctx->stream;
   int TA = 0;
-  for (int o = 0; o < M.nb; ++o) TA += M.degree - o - 1;
+  for (int o = 0; o < M.nb; ++o) TA += M.deg_of(o) - 1;
   constexpr int kMinGroupsPerBlock = kWavesPerBlock;  // L = 64
   const void* before[] = {W.Abuf.p, W.rec.p, W.partsA.p, W.partsB.p, W.Dtab.p, W.Stab.p, W.Ftab.p, W.out_acc.p, W.itbuf.p, W.hpart.p, W.prox.p};
   NFM_TRY(W.Abuf.ensure(sizeof(double) * (size_t)std::max<int64_t>(P.max_batch, 1) * std::max(TA, 1) * M.Kp));

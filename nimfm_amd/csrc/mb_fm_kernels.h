@@ -100,7 +100,7 @@ __device__ __forceinline__ double row_forward(const PS& ps, const CsrView& X, co
   for (int o = 0; o < M.nb; ++o) {
     const size_t blk = M.row(o, 0) * M.Kp;
     const int rstride = (int)M.rs * M.Kp;
-    const int deg = M.degree - o;
+    const int deg = M.deg_of(o);
     double2 ker;
     if (deg == 2) {
       double2 A1, A2;
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(kBlock, (MODE == 2 || MODE == 4 ? NFM_REG_MINW : 1)
       for (int o = 0; o < M.nb; ++o) {
         const size_t blk = M.row(o, 0) * M.Kp;
         const size_t rstride = (size_t)M.rs * M.Kp;
-        const int deg = M.degree - o;
+        const int deg = M.deg_of(o);
         double2 E[dev::kMaxDeg + 1];
 #pragma unroll
         for (int t = 0; t <= dev::kMaxDeg; ++t) E[t] = {0.0, 0.0};
@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(kBlock) void k_heavy_partial(ColArgs a, HeavyArgs h
   int slot = 0;
   for (int o = 0; o < M.nb; ++o) {  // one partial record per (segment, order)
     WAcc wacc;
-    const int deg = M.degree - o;
+    const int deg = M.deg_of(o);
     col_block<OPT, GEN, 2, L, 1>(a, M.row(o, j) * M.Kp + 2 * l, deg, slot, l, t0, t1, sP, 1.0, 1.0, has_w && o == 0, wacc,
                                  0.0, hv.hpart + ((size_t)(gs - hv.s0) * M.nb + o) * hv.PW + 2 * l, 0, hv.PW);
     slot += deg - 1;
@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(kBlock) void k_heavy_apply(ColArgs a, HeavyArgs hv)
     int slot = 0;
     for (int o = 0; o < M.nb; ++o) {
       WAcc wo;
-      const int deg = M.degree - o;
+      const int deg = M.deg_of(o);
       viol += col_block<OPT, GEN, 2, L, 2>(a, M.row(o, j) * M.Kp + 2 * l, deg, slot, l, 0, 0, sP, sPn, fP, has_w && o == 0,
                                            wo, (double)c, hv.hpart + ((size_t)(sg0 - hv.s0) * M.nb + o) * hv.PW + 2 * l, nseg,
                                            hv.PW, M.nb * hv.PW);
@@ -1635,13 +1635,13 @@ __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
     const bool has_w = M.fit_linear && j < M.d;  // dummy features have no w
     WAcc wacc;
     int slot = 0;
-    if (GEN && OPT != OPT_PSGD && NFM_COL_D3 && M.nb == 2 && M.degree == 3 && a.TA == 3) {
+    if (GEN && OPT != OPT_PSGD && NFM_COL_D3 && M.nb == 2 && M.kc == 1 && M.degree == 3 && a.TA == 3) {
       // degree 3, explicit lower orders (cfg5): both parameter blocks in one walk of the touch list
       viol += col_block_d3<(OPT == OPT_PSGD ? OPT_SGD : OPT), L>(a, j, l, t0, t1, sP, sPn, fP, has_w, wacc);
     } else
     for (int o = 0; o < M.nb; ++o) {
       const size_t e = M.row(o, j) * M.Kp + 2 * l;
-      const int deg = M.degree - o;
+      const int deg = M.deg_of(o);
       viol += col_block<OPT, GEN, TU, L, 0>(a, e, deg, slot, l, t0, t1, sP, sPn, fP, has_w && o == 0, wacc);
       slot += deg - 1;
     }

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void k_fm_predict(CsrView X, ModelView M, d
     for (int o = 0; o < M.nb; ++o) {
       const size_t blk = M.row(o, 0) * M.Kp;
       const int rstride = (int)M.rs * M.Kp;  // doubles between consecutive features' rows of this order
-      const int deg = M.degree - o;
+      const int deg = M.deg_of(o);
       double2 ker;
       if (deg == 2) {
         double2 A1, A2;
@@ -45,7 +45,12 @@ __global__ __launch_bounds__(kBlock) void k_fm_predict(CsrView X, ModelView M, d
         dev::anova_fwd_degn<L, SPLIT>(ps, X, q0, m, m_tot, blk, rstride, slot, l, lane, deg, E);
         ker = dev::pick(E, deg);
       }
-      if (slot == 0) part += ker.x * lam0 + ker.y * lam1;  // every slot holds the same totals
+      if (M.kc == 1) {
+        if (slot == 0) part += ker.x * lam0 + ker.y * lam1;  // every slot holds the same totals
+      } else if (slot == 0) {  // more than 128 factors: block o holds the factors (o % kc) * Kp ... of its order
+        const double* lm = M.lams + (size_t)(o % M.kc) * M.Kp;
+        part += ker.x * lm[2 * l] + ker.y * lm[2 * l + 1];
+      }
     }
     // sum over the sample's L*SPLIT lanes
 #pragma unroll
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void k_fm_predict_orders(CsrView X, ModelVi
   const int lane = threadIdx.x & (kWave - 1);
   const int sidx = lane / LPS, slot = (lane / LT) % SPLIT, l = lane % LT;
   const int o = l >> lgL, ll = l & ((1 << lgL) - 1);
-  const int mydeg = o < M.nb ? M.degree - o : 0;  // (lanes of a padding block: their rows are zero, they add nothing)
+  const int mydeg = o < M.nb ? M.deg_of(o) : 0;  // (lanes of a padding block: their rows are zero, they add nothing)
   const int64_t wave0 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
   const double sw = M.sc[SC_SCALE_W], b = M.sc[SC_INTERCEPT], sP = M.sc[SC_SCALE_P];
@@ -177,7 +182,7 @@ static int launch_fm_predict_orders_LT(nfm_ctx* ctx, const CsrView& X, const Mod
 static int predict_orders(nfm_ctx* ctx, const CsrView& X, const ModelView& M, double* out, bool* handled) {
   *handled = false;
   static const bool on = !(getenv("NFM_PREDICT_ORDERS") && atoi(getenv("NFM_PREDICT_ORDERS")) == 0);
-  if (!on || M.kind != NFM_KIND_FM || M.nb < 2 || M.bs != M.da || M.rs != 1) return NFM_OK;
+  if (!on || M.kind != NFM_KIND_FM || M.nb < 2 || M.kc != 1 || M.bs != M.da || M.rs != 1) return NFM_OK;
   int NBP = 1;
   while (NBP < M.nb) NBP <<= 1;
   const int LT = NBP * M.L;
@@ -287,7 +292,7 @@ static int launch_predict_L(nfm_ctx* ctx, const CsrView& X, const ModelView& M, 
 }
 
 int launch_predict(nfm_ctx* ctx, const CsrView& X, const ModelView& M, double* out) {
-  NFM_CHECK(M.Kp == 2 * M.L, NFM_ERR_UNSUPPORTED, "n_components > 128 is not supported by the wave-per-sample kernels");
+  NFM_CHECK(M.Kp == 2 * M.L, NFM_ERR_UNSUPPORTED, "field-aware models: n_components > 128 is not supported by the wave-per-sample kernels");
   NFM_CHECK(M.kind == NFM_KIND_FFM || M.degree <= dev::kMaxDeg, NFM_ERR_UNSUPPORTED, "degree > %d unsupported", dev::kMaxDeg);
   if (X.n > 0) {
     bool handled = false;

@@ -140,8 +140,9 @@ __global__ void k_sequential(SeqArgs a) {
       for (int q = 0; q < m; ++q) yh += (sw * M.w[X.indices[q0 + q]]) * X.data[q0 + q];
     }
     if (KIND == NFM_KIND_FM) {
+      double tot = 0.0;
       for (int o = 0; o < nb; ++o) {
-        const int deg = M.degree - o;
+        const int deg = M.deg_of(o);
         double A[kSeqMaxDeg + 1];
         double kv = 0.0;
         const size_t blk = M.row(o, 0) * Kp, rstride = (size_t)M.rs * Kp;
@@ -194,9 +195,9 @@ __global__ void k_sequential(SeqArgs a) {
         }
         red[tid] = (act && tid < k) ? kv : 0.0;
         __syncthreads();
-        double tot = 0.0;
+        if (o % M.kc == 0) tot = 0.0;  // (more than 128 factors: the kc blocks of one order continue ONE ascending sum)
         for (int s = 0; s < k; ++s) tot += red[s];  // sgd.nim:172-173, ascending s
-        yh += tot;
+        if (o % M.kc == M.kc - 1) yh += tot;
         __syncthreads();
       }
     } else {

@@ -1773,7 +1773,7 @@ __device__ __forceinline__ void win_worker_fmx(const WinArgs& a, const int slot,
 #pragma unroll
     for (int t = 0; t < DG; ++t) ktot[t] = 0.0;
     for (int o = 0; o < nb; ++o) {
-      const int deg = M.degree - o;
+      const int deg = M.deg_of(o);
       double A[DG + 1];
       double kv;
       if (deg != 2) {  // sgd.nim:152-159

@@ -296,6 +296,48 @@ int launch_rows_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref
   return NFM_OK;
 }
 
+// FMs with more than 128 factors (ModelView::kc): reference [no * da][k] <-> device [no * kc][da][Kp]; device block
+// o * kc + c holds the factors c * kb ... c * kb + kb - 1 of order o
+__global__ void k_rows_split_to_device(const double* __restrict__ src, double* __restrict__ dst, int64_t no, int64_t da, int k, int kc,
+                                       int kb, int Kp, double pad) {
+  const int64_t total = no * kc * da * Kp;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int sl = (int)(e % Kp);
+    const int64_t r = e / Kp;  // device row (o * kc + c) * da + j
+    const int64_t j = r % da, b = r / da;
+    const int64_t o = b / kc;
+    const int s = (int)(b % kc) * kb + sl;
+    dst[e] = (sl < kb && s < k) ? src[(o * da + j) * k + s] : pad;
+  }
+}
+int launch_rows_split_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int64_t no, int64_t da, int k, int kc, int kb, int Kp,
+                                double pad) {
+  if (no == 0 || da == 0) return NFM_OK;
+  hipLaunchKernelGGL(k_rows_split_to_device, dim3(grid_for(no * kc * da * Kp)), dim3(kBlock), 0, ctx->stream, src_ref, dst_dev, no, da, k, kc,
+                     kb, Kp, pad);
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+__global__ void k_rows_split_from_device(const double* __restrict__ src, double* __restrict__ dst, int64_t no, int64_t da, int k, int kc,
+                                         int kb, int Kp, const double* __restrict__ scale) {
+  const double sc = scale ? *scale : 1.0;
+  const int64_t total = no * da * k;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(e % k);
+    const int64_t r = e / k;  // reference row o * da + j
+    const int64_t j = r % da, o = r / da;
+    dst[e] = src[((o * kc + s / kb) * da + j) * Kp + s % kb] * sc;
+  }
+}
+int launch_rows_split_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int64_t no, int64_t da, int k, int kc, int kb, int Kp,
+                                  const double* scale_dev) {
+  if (no == 0 || da == 0) return NFM_OK;
+  hipLaunchKernelGGL(k_rows_split_from_device, dim3(grid_for(no * da * k)), dim3(kBlock), 0, ctx->stream, src_dev, dst_ref, no, da, k, kc, kb,
+                     Kp, scale_dev);
+  NFM_HIP_CHECK(hipGetLastError());
+  return NFM_OK;
+}
+
 // finalize (optimizer/sgd.nim:99-113): with one global scale per tensor it is a dense multiply.
 __global__ void k_rescale(double* __restrict__ p, int64_t n2 /*double2 count*/, const double* __restrict__ scale) {
   const double sc = *scale;
