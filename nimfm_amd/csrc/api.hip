@@ -1150,7 +1150,7 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
       // second visit of the row only when they are a sizeable share of the touches.  With a touch
       // rate lambda = batch * nnz_per_row / d per feature that share is about exp(-lambda).
       const double lambda = (double)o->batch * ((double)ds->v.nnz / (double)std::max<int64_t>(ds->v.n, 1)) / (double)m->d;
-      bool use_singles = o->kind != OPT_PSGD && m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2 && (o->batch == 1 || lambda <= 1.4);
+      bool use_singles = o->kind != OPT_PSGD && m->cfg.kind == NFM_KIND_FM && m->cfg.degree == 2 && m->nb == 1 && (o->batch == 1 || lambda <= 1.4);
       if (const char* env = getenv("NFM_SINGLES")) use_singles = use_singles && atoi(env) != 0;  // tuning override
       bool sort_by_count = m->Kp * (int)sizeof(double) >= 128;  // rows of at least one 128-byte line (plan.hip)
       if (const char* env = getenv("NFM_SORT_BY_COUNT")) sort_by_count = atoi(env) != 0;  // tuning override

@@ -168,3 +168,47 @@ def test_mbpsgd_refuses_wide_models():
     opt = nf.newMBPSGD(maxIter=1, verbose=0)
     with pytest.raises(Exception):
         opt.fit(to_gpu(Xo), rng.standard_normal(100), fm)
+
+
+@pytest.mark.parametrize("solver", ["sgd", "adagrad"])
+def test_minibatch_sparse_regime(solver):
+    """few touches per feature and batch (lambda = B m / d = 0.1): the regime in which narrow degree-2 models update
+    once-touched features in the row phase; wide models have several blocks and take the column phase for everything"""
+    n, d, m, B, k = 2000, 20000, 8, 256, 160
+    Xo = random_csr(n, d, m, seed=41)
+    rng = np.random.default_rng(42)
+    y = rng.standard_normal(n)
+    P0, w0 = rng.standard_normal((1, k, d)) * 0.05, np.zeros(d)
+    P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
+    if solver == "sgd":
+        for e in range(2):
+            b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, b, O.sgd_cfg(), B, it=it)
+        opt = nf.newSGD(maxIter=2, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B)
+    else:
+        cfg = O.adagrad_cfg()
+        st = O.AdaState(1, d, k, d)
+        for e in range(2):
+            b, it, ls, vs = O.fm_adagrad_epoch_mb(Xo, y, 2, P, w, b, cfg, B, st, it=it)
+        b = O.fm_adagrad_finalize(2, P, w, b, cfg, it, st)
+        opt = nf.newAdaGrad(maxIter=2, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B)
+    fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, 0.0)
+    opt.fit(to_gpu(Xo), y, fm)
+    assert abs(fm.intercept - b) < 1e-11
+    assert_close(fm.w, w, 1e-9, 1e-13, "w")
+    assert_close(fm.P, P, 1e-9, 1e-13, "P")
+
+
+def test_minibatch_of_one_is_the_sequential_rule():
+    """batch = 1: the mini-batch rule IS the reference's per-sample step"""
+    n, d, m, k = 150, 60, 6, 140
+    Xo = random_csr(n, d, m, seed=51)
+    rng = np.random.default_rng(52)
+    y = rng.standard_normal(n)
+    P0, w0, b0, n_aug = init_fm(d, 2, k, "explicit", True, scale=0.05)
+    Pf, wf, bf, it, el, ev, _ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, O.sgd_cfg(), 1, 0, perms=None)
+    fm = gpu_fm("regression", 2, k, "explicit", True, True, P0, w0, b0)
+    sgd = nf.newSGD(maxIter=1, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=1)
+    sgd.fit(to_gpu(Xo), y, fm)
+    assert abs(fm.intercept - bf) < 1e-9
+    assert_close(fm.w, wf, 1e-8, 1e-11, "w")
+    assert_close(fm.P, Pf, 1e-8, 1e-11, "P")
