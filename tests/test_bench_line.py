@@ -7,6 +7,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -101,19 +103,24 @@ def test_contract_line_of_a_multi_gpu_run():
     assert out["roofline"]["frac"] == full["roofline"]["frac"]
 
 
-def test_round5_detail_record_gives_a_complete_line():
-    """this round's own detail record (profiles/r05d_default_bench_detail.json) through contract_line: under 6 KB, and the
-    fields round 5 added are there -- the headline's value at the old batch, the best Hogwild setting and the ratio against
-    it, the exact order's flavours and how far the one-term window is from the one-workgroup kernel"""
+@pytest.mark.parametrize("record,batch,frac", [("r05d", 65536, 0.5), ("r05f", 131072, 0.6)])
+def test_round5_detail_record_gives_a_complete_line(record, batch, frac):
+    """this round's own detail records (profiles/r05d_default_bench_detail.json: headline batch 65536; r05f: 131072, the batch
+    bench.py quotes now) through contract_line: under 6 KB, and the fields round 5 added are there -- the headline's value at
+    the old batch, the best Hogwild setting and the ratio against it, the exact order's flavours and how far the one-term
+    window is from the one-workgroup kernel"""
     sys.path.insert(0, ROOT)
     import bench
 
-    full = json.load(open(os.path.join(ROOT, "profiles", "r05d_default_bench_detail.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "%s_default_bench_detail.json" % record)))
     line = bench.contract_line(full)
     assert "\n" not in line and len(line) < 6000, len(line)
     out = json.loads(line)
-    assert out["config"]["batch"] == 65536 and out["value_batch_8192"] and out["value_batch_8192"] < out["value"]
-    assert out["roofline"]["frac"] > 0.5
+    assert out["config"]["batch"] == batch and out["value_batch_8192"] and out["value_batch_8192"] < out["value"]
+    assert out["roofline"]["frac"] > frac
+    if record == "r05f":
+        assert bench.WORKLOADS["headline"]["batch"] == batch  # the record is of the workload table as it stands
+        assert "r05f_headline_B131072_pmc_traffic.json" in full["roofline"]["traffic_source"]  # traffic of THIS batch
     hog = out["cpu_baseline"]["hogwild"]
     sweep = full["cpu_baseline"]["hogwild"]["sweep"]
     assert hog["value"] == max(e["value"] for e in sweep) and len(sweep) >= 4  # the BEST of the sweep is what the line carries
