@@ -1366,6 +1366,125 @@ __device__ __forceinline__ double col_block_d3(const ColArgs& a, int64_t j, int 
   return viol;
 }
 
+// degree 2 with 129 ... 256 factors (ModelView::kc == 2): two parameter blocks of degree 2 (A rows 0 and 1 of the sample).  As
+// col_block_w2: BOTH blocks in one walk of the feature's touch list -- one record and the sample's two A rows per touch -- with
+// the arithmetic and the order of every sum of two col_block<.., MODE 0> calls (bench.py --workload wide256: column phase 2.10 -> 1.68 ms per batch of 32768).
+template <int OPT, int LG>
+__device__ __forceinline__ double col_block_w2(const ColArgs& a, int64_t j, int l, int64_t t0, int64_t t1, double sP,
+                                               double sPn, double fP, bool do_w, WAcc& wacc) {
+  static_assert(OPT == OPT_SGD || OPT == OPT_ADAGRAD, "SGD / AdaGrad");
+  const ModelView& M = a.M;
+  const OptView& O = a.O;
+  const size_t e[2] = {M.row(0, j) * M.Kp + 2 * l, M.row(1, j) * M.Kp + 2 * l};
+  double viol = 0.0;
+  double2 stored[2], g2[2], n2[2], p[2];
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    stored[o] = g2[o] = n2[o] = {0.0, 0.0};
+    if (OPT == OPT_SGD) {
+      stored[o] = dev::ld_stream(M.P + e[o]);
+      p[o].x = sP * stored[o].x;
+      p[o].y = sP * stored[o].y;
+    } else {
+      g2[o] = dev::ld_stream(O.G + e[o]);
+      n2[o] = dev::ld_stream(O.N + e[o]);
+      if (a.use_stored) {
+        p[o] = dev::ld_stream(M.P + e[o]);
+      } else {
+        const double tmp = O.eta0 * ((a.it0p[0] + a.it_b) - 1.0) * O.beta;
+        p[o].x = dev::adagrad_param(g2[o].x, n2[o].x, O.eta0, tmp);
+        p[o].y = dev::adagrad_param(g2[o].y, n2[o].y, O.eta0, tmp);
+        if (O.track_viol) {
+          stored[o] = dev::ld_stream(M.P + e[o]);
+          viol += fabs(stored[o].x - p[o].x) + fabs(stored[o].y - p[o].y);
+          dev::st_stream(M.P + e[o], p[o]);
+        }
+      }
+    }
+  }
+  double2 acc[2] = {{0.0, 0.0}, {0.0, 0.0}}, accn[2] = {{0.0, 0.0}, {0.0, 0.0}};
+  double seta = 0.0;
+  constexpr int TG = 2;
+  const int gbase = (int)(threadIdx.x & (kWave - 1)) - l;
+  for (int64_t tb = t0; tb < t1; tb += LG) {
+    const int64_t tl = tb + l;
+    const int pib_l = tl < t1 ? a.tpos[tl] : 0;
+    const double x_l = tl < t1 ? a.tx[tl] : 0.0;
+    const int cnt = (int)(t1 - tb < LG ? t1 - tb : LG);
+    for (int ub = 0; ub < cnt; ub += TG) {
+      int pib[TG];
+      double x[TG];
+      SampleRec r[TG];
+      double2 Aa[TG], Ab[TG];
+#pragma unroll
+      for (int u = 0; u < TG; ++u) {
+        const int src = gbase + ((ub + u) < LG ? (ub + u) : 0);
+        pib[u] = __shfl(pib_l, src, kWave);
+        x[u] = dev::shfl_d(x_l, src);
+      }
+#pragma unroll
+      for (int u = 0; u < TG; ++u) {
+        r[u] = a.rec[pib[u]];
+        const double* Ar = a.Abuf + (size_t)pib[u] * 2 * M.Kp + 2 * l;
+        Aa[u] = *reinterpret_cast<const double2*>(Ar);
+        Ab[u] = *reinterpret_cast<const double2*>(Ar + M.Kp);
+      }
+#pragma unroll
+      for (int u = 0; u < TG; ++u) {
+        if (ub + u >= cnt) continue;
+        const double xv = x[u];
+        // degree 2 (optimizer/sgd.nim:187-188): dA = x (A[1] - p x), the factors of block 0 and of block 1
+        const double d0x = xv * (Aa[u].x - p[0].x * xv), d0y = xv * (Aa[u].y - p[0].y * xv);
+        const double d1x = xv * (Ab[u].x - p[1].x * xv), d1y = xv * (Ab[u].y - p[1].y * xv);
+        if (OPT == OPT_SGD) {
+          acc[0].x += r[u].etaP * (r[u].dL * d0x);
+          acc[0].y += r[u].etaP * (r[u].dL * d0y);
+          acc[1].x += r[u].etaP * (r[u].dL * d1x);
+          acc[1].y += r[u].etaP * (r[u].dL * d1y);
+          seta += r[u].etaP;
+          if (do_w) {
+            wacc.a0 += r[u].etaw * (r[u].dL * xv);
+            wacc.a1 += r[u].etaw;
+          }
+        } else {
+          const double g0x = r[u].dL * d0x, g0y = r[u].dL * d0y, g1x = r[u].dL * d1x, g1y = r[u].dL * d1y;
+          acc[0].x += g0x;
+          acc[0].y += g0y;
+          accn[0].x += g0x * g0x;
+          accn[0].y += g0y * g0y;
+          acc[1].x += g1x;
+          acc[1].y += g1y;
+          accn[1].x += g1x * g1x;
+          accn[1].y += g1y * g1y;
+          if (do_w) {
+            const double gw = r[u].dL * xv;
+            wacc.a0 += gw;
+            wacc.a1 += gw * gw;
+          }
+        }
+      }
+    }
+  }
+  const double c = dev::touch_div((double)(t1 - t0), O.touch_cap);
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    if (OPT == OPT_SGD) {
+      viol += fabs((acc[o].x + seta * O.beta * p[o].x) / c) + fabs((acc[o].y + seta * O.beta * p[o].y) / c);
+      stored[o].x = stored[o].x * fP - (acc[o].x / c) / sPn;
+      stored[o].y = stored[o].y * fP - (acc[o].y / c) / sPn;
+      dev::st_stream(M.P + e[o], stored[o]);
+    } else {
+      g2[o].x += acc[o].x;
+      g2[o].y += acc[o].y;
+      n2[o].x += accn[o].x;
+      n2[o].y += accn[o].y;
+      dev::st_stream(O.G + e[o], g2[o]);
+      dev::st_stream(O.N + e[o], n2[o]);
+    }
+  }
+  return viol;
+}
+
 // linear term of one feature (fit_linear.nim:41-57); every lane of the feature holds the same sums
 template <int OPT>
 __device__ __forceinline__ double w_epilogue(const ColArgs& a, int64_t j, int l, double c, double sw, double swn, double fw,
@@ -1638,6 +1757,9 @@ __global__ __launch_bounds__(kBlock, NFM_COL_MINW) void k_col_phase(ColArgs a) {
     if (GEN && OPT != OPT_PSGD && NFM_COL_D3 && M.nb == 2 && M.kc == 1 && M.degree == 3 && a.TA == 3) {
       // degree 3, explicit lower orders (cfg5): both parameter blocks in one walk of the touch list
       viol += col_block_d3<(OPT == OPT_PSGD ? OPT_SGD : OPT), L>(a, j, l, t0, t1, sP, sPn, fP, has_w, wacc);
+    } else if (GEN && OPT != OPT_PSGD && NFM_COL_D3 && M.nb == 2 && M.kc == 2 && M.degree == 2 && a.TA == 2) {
+      // 129 ... 256 factors: the two blocks of the one order in one walk
+      viol += col_block_w2<(OPT == OPT_PSGD ? OPT_SGD : OPT), L>(a, j, l, t0, t1, sP, sPn, fP, has_w, wacc);
     } else
     for (int o = 0; o < M.nb; ++o) {
       const size_t e = M.row(o, j) * M.Kp + 2 * l;
