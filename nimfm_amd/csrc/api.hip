@@ -225,6 +225,7 @@ int32_t nfm_ctx_destroy(nfm_ctx* ctx) {
   for (auto& p : ctx->timing.pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
   for (auto e : ctx->timing.pool) (void)hipEventDestroy(e);
   delete ctx->predict_pf;  // (the stream has drained)
+  delete ctx->seq_scratch;
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return NFM_OK;

@@ -122,6 +122,9 @@ struct nfm_ctx {
   // belongs to the context, not to the call: the kernels that read it are still queued on `stream` when the call returns, and
   // a block handed back to the device-memory cache may go to another stream (nfm_decision_function_device never synchronizes)
   nfm::DevBuf* predict_pf = nullptr;
+  // NFM_MODE_SEQUENTIAL, the one-sample-in-flight kernel on rows whose per-sample gradient does not fit the LDS: the
+  // gradient scratch in global memory (seq.hip); on the context for the same reason as predict_pf
+  nfm::DevBuf* seq_scratch = nullptr;
 };
 
 namespace nfm {

@@ -28,6 +28,7 @@ struct SeqArgs {
   int64_t begin, end, it0;
   double* out;
   int m_cap;
+  double* dA_global;  // the one-sample-in-flight kernel's per-sample gradient [nb][m_cap][T] when it does not fit the LDS, else null
 };
 
 constexpr int kSeqMaxDeg = 8;
@@ -46,7 +47,9 @@ __global__ void k_sequential(SeqArgs a) {
   const int T = blockDim.x, tid = threadIdx.x;
   const bool act = tid < M.Kp;
   double* red = lds;         // [T]
-  double* dA = lds + T;      // [nb][m_cap][T]
+  // [nb][m_cap][T]; thread tid only ever touches its own column (.. + tid), so the table may as well live in global memory
+  // (rows of hundreds of entries: dataset.nim puts no bound on a row) -- program order of one thread is all it needs
+  double* dA = a.dA_global ? a.dA_global : lds + T;
   const size_t n_da = (size_t)(M.nb > 0 ? M.nb : 1) * a.m_cap * T;
   double* Pl = dA + n_da;                                        // STAGE: [nb][m_cap][T] stored parameter values
   double* vl = Pl + (STAGE ? n_da : 0);                          // STAGE: [m_cap] values
@@ -1037,7 +1040,7 @@ int launch_sequential(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelV
   int T = ((M.Kp + kWave - 1) / kWave) * kWave;
   if (T < kWave) T = kWave;
   if (m_cap < 1) m_cap = 1;
-  SeqArgs a{X, M, O, perm_dev, begin, end, it0, out2_dev, m_cap};
+  SeqArgs a{X, M, O, perm_dev, begin, end, it0, out2_dev, m_cap, nullptr};
   // The pipelined step (k_sequential_pipe): degree-2 FMs with one order and field-aware models; at most 256 factors and
   // 256 entries per row, at most 64 rows per thread, everything of a sample in LDS.  NFM_SEQ_PIPE=0 switches it off.
   static const bool pipe_on = !(getenv("NFM_SEQ_PIPE") && atoi(getenv("NFM_SEQ_PIPE")) == 0);
@@ -1071,10 +1074,24 @@ int launch_sequential(nfm_ctx* ctx, int opt_kind, const CsrView& X, const ModelV
       return launch_seq_pipe<NFM_KIND_FM, OPT_ADAGRAD>(ctx, a, S, lgS, (int)rc, threads, split_terms, pipe_bytes);
     }
   }
-  const size_t lds_bytes = sizeof(double) * ((size_t)T + (size_t)(M.nb > 0 ? M.nb : 1) * m_cap * T);
-  NFM_CHECK(lds_bytes <= 160 * 1024, NFM_ERR_UNSUPPORTED,
-            "sequential mode needs %zu bytes of LDS for the per-sample gradient (n_blocks=%d, max row nnz=%d, Kp=%d)",
-            lds_bytes, M.nb, m_cap, M.Kp);
+  size_t lds_bytes = sizeof(double) * ((size_t)T + (size_t)(M.nb > 0 ? M.nb : 1) * m_cap * T);
+  if (lds_bytes > 160 * 1024) {
+    // the per-sample gradient does not fit the LDS (long rows, many blocks): global scratch, the reduction buffer stays
+    if (!ctx->seq_scratch) ctx->seq_scratch = new DevBuf();
+    const size_t need = sizeof(double) * (size_t)(M.nb > 0 ? M.nb : 1) * m_cap * T;
+    if (!(ctx->seq_scratch->p && need <= ctx->seq_scratch->bytes)) {
+      NFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (growing: an earlier launch may still use the old block)
+      NFM_TRY(ctx->seq_scratch->alloc(need));
+    }
+    a.dA_global = ctx->seq_scratch->as<double>();
+    lds_bytes = sizeof(double) * (size_t)T;
+    if (M.kind == NFM_KIND_FM) {
+      if (opt_kind == OPT_SGD) return launch_seq_t<NFM_KIND_FM, OPT_SGD, false>(ctx, a, T, lds_bytes);
+      return launch_seq_t<NFM_KIND_FM, OPT_ADAGRAD, false>(ctx, a, T, lds_bytes);
+    }
+    if (opt_kind == OPT_SGD) return launch_seq_t<NFM_KIND_FFM, OPT_SGD, false>(ctx, a, T, lds_bytes);
+    return launch_seq_t<NFM_KIND_FFM, OPT_ADAGRAD, false>(ctx, a, T, lds_bytes);
+  }
   if (M.kind == NFM_KIND_FM) {
     // staged step (entries and parameter values in LDS) when the extra [nb][m_cap][T] + 2 [m_cap] doubles fit
     const size_t n_da = (size_t)(M.nb > 0 ? M.nb : 1) * m_cap * T;

@@ -293,3 +293,70 @@ def test_sequential_ffm_adagrad_is_bit_exact():
     assert ffm.intercept == bf
     assert np.array_equal(ffm.w, wf)
     assert np.array_equal(ffm.P, Pf)
+
+
+def _long_row_csr(n, d, seed, long_every=5, long_m=700, short_m=9):
+    """rows of several hundred entries between short ones (dataset.nim puts no bound on a row; text data has such rows)"""
+    rng = np.random.default_rng(seed)
+    rows, vals, indptr = [], [], [0]
+    for i in range(n):
+        m = long_m if i % long_every == 2 else short_m
+        rows.append(np.sort(rng.choice(d, size=m, replace=False)))
+        vals.append(rng.uniform(-1, 1, size=m) / np.sqrt(m))
+        indptr.append(indptr[-1] + m)
+    return O.Dataset(np.array(indptr), np.concatenate(rows), np.concatenate(vals), n, d)
+
+
+@pytest.mark.parametrize("k,degree", [(64, 2), (24, 3), (200, 2)])
+def test_rows_longer_than_the_lds_gradient_table(k, degree):
+    """NFM_MODE_SEQUENTIAL on rows of 700 entries: the one-sample-in-flight kernel's per-sample gradient ([blocks][row][factors]:
+    358 KB at k = 64) does not fit the 160 KB of LDS and lives in global memory (csrc/seq.hip, SeqArgs::dA_global); before
+    round 5 such a dataset was NFM_ERR_UNSUPPORTED in this mode.  SGD and AdaGrad against the oracle."""
+    n, d = 40, 1500
+    Xo = _long_row_csr(n, d, seed=61)
+    rng = np.random.default_rng(62)
+    y = rng.standard_normal(n)
+    P0, w0, b0, n_aug = init_fm(d, degree, k, "explicit", True, scale=0.05)
+    perms = make_perms(n, 2)
+    X = to_gpu(Xo)
+    Pf, wf, bf, it, el, ev, _ = O.fm_sgd_fit(Xo, y, degree, P0, w0, b0, O.sgd_cfg(), 2, n_aug, perms=perms)
+    fm = gpu_fm("regression", degree, k, "explicit", True, True, P0, w0, b0)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0)
+    sgd.fit(X, y, fm, perms=perms)
+    assert sgd.it == it and abs(fm.intercept - bf) < 1e-9
+    assert_close(fm.w, wf, RTOL, ATOL, "w")
+    assert_close(fm.P, Pf, RTOL, ATOL, "P")
+    assert_close([h[0] for h in sgd.history], ev, 1e-8, 1e-11, "viol")
+    cfg = O.adagrad_cfg()
+    Pf, wf, bf, it, el, ev, _, st = O.fm_adagrad_fit(Xo, y, degree, P0, w0, b0, cfg, 2, n_aug, perms=perms)
+    fm = gpu_fm("regression", degree, k, "explicit", True, True, P0, w0, b0)
+    ada = nf.newAdaGrad(maxIter=2, verbose=0, tol=0)
+    ada.fit(X, y, fm, perms=perms)
+    assert abs(fm.intercept - bf) < 1e-9
+    assert_close(fm.w, wf, RTOL, ATOL, "w")
+    assert_close(fm.P, Pf, RTOL, ATOL, "P")
+
+
+def test_field_aware_rows_longer_than_the_lds_gradient_table():
+    """the same for a field-aware model: 12 fields x 300 entries x k = 8"""
+    n, d, F, k = 30, 900, 12, 8
+    rng = np.random.default_rng(71)
+    rows, vals, flds, indptr = [], [], [], [0]
+    for i in range(n):
+        m = 300 if i % 4 == 1 else 7
+        idx = np.sort(rng.choice(d, size=m, replace=False))
+        rows.append(idx)
+        vals.append(rng.uniform(-1, 1, size=m) / np.sqrt(m))
+        flds.append(idx % F)
+        indptr.append(indptr[-1] + m)
+    Xo = O.Dataset(np.array(indptr), np.concatenate(rows), np.concatenate(vals), n, d, fields=np.concatenate(flds), n_fields=F)
+    y = rng.standard_normal(n)
+    P0, w0, b0 = init_ffm(d, F, k, scale=0.05)
+    perms = make_perms(n, 2)
+    Pf, wf, bf, *_ = O.ffm_sgd_fit(Xo, y, P0, w0, b0, O.sgd_cfg(), 2, perms=perms)
+    ffm = gpu_ffm("regression", k, True, True, P0, w0, b0)
+    sgd = nf.newSGD(maxIter=2, verbose=0, tol=0)
+    sgd.fit(to_gpu(Xo), y, ffm, perms=perms)
+    assert abs(ffm.intercept - bf) < 1e-9
+    assert_close(ffm.w, wf, RTOL, ATOL, "w")
+    assert_close(ffm.P, Pf, RTOL, ATOL, "P")
