@@ -293,7 +293,10 @@ int32_t nfm_opt_set_state(nfm_opt* o, const double* gsum_P, const double* gnorm_
  * perm[begin..end) (perm NULL = identity; perm is the host-side shuffle,
  * sgd.nim:297).  Sub-ranges serve nCalls callbacks (sgd.nim:303-307).  Returns
  * the running sums the reference prints/tests: sum of loss(y_i, yhat_i) and
- * `viol`.  Classification targets are sign()-ed (fm_base.nim:32-34). */
+ * `viol`.  Classification targets are sign()-ed (fm_base.nim:32-34).
+ * A range of more than 2^31 - 1 entries is walked as consecutive pieces
+ * (whole mini-batches): the results are the one call's (not with a
+ * data-parallel group attached; a device-drawn order shuffles inside a piece). */
 int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t begin,
                       int64_t end, double* loss_sum, double* viol_sum);
 /* shuffle = true on the device (NFM_MODE_MINIBATCH): with seed >= 0 every nfm_opt_epoch call WITHOUT an explicit

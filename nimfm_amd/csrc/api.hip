@@ -1047,8 +1047,53 @@ static int dp_epoch_setup(nfm_opt* o, nfm_model* m, const ModelView& M, DpEpoch*
   return NFM_OK;
 }
 
+static int32_t opt_epoch_range(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t begin, int64_t end, double* loss_sum,
+                               double* viol_sum);
+
+// the entries one epoch call may hold (the plan's touch tables and the window's dependency table index them with 32 bits)
+static int64_t max_epoch_nnz() {
+  int64_t cap = (int64_t)2147483647;
+#ifdef NFM_TEST_HOOKS  // (libnimfm_hip_testhooks.so only: lets a test cut a small epoch into pieces)
+  if (const char* env = getenv("NFM_TEST_MAX_EPOCH_NNZ")) cap = atoll(env);
+#endif
+  return cap;
+}
+
 int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t begin, int64_t end, double* loss_sum,
                       double* viol_sum) {
+  NFM_CHECK(o && ds, NFM_ERR_INVALID, "null argument");
+  // A range of more than 2^31 - 1 entries (288 GB hold datasets several times that) is walked as consecutive pieces: an epoch
+  // call IS the sequence of its sub-range calls (sequential mode: any cut; mini-batch mode: cuts at mini-batch boundaries --
+  // tests/test_gpu_fullsize.py holds one call against two), so the results are those of the one call.  The bound on a piece's
+  // entries is samples x the longest row.  Not with a data-parallel group (the exchange points are laid out per call), and a
+  // device-drawn order (nfm_opt_set_shuffle) then shuffles inside each piece.
+  const int64_t row_max = std::max<int64_t>((int64_t)ds->max_row + 8, 1), cap = max_epoch_nnz();
+  const int64_t ns_all = end - begin;
+  if (begin >= 0 && ns_all > 0 && !o->dp && ns_all > cap / row_max && (perm || end <= ds->v.n)) {
+    const int64_t B = o->mode == NFM_MODE_MINIBATCH ? std::max<int64_t>(o->batch, 1) : 1;
+    int64_t piece = cap / row_max / B * B;  // whole mini-batches
+    NFM_CHECK(piece >= B, NFM_ERR_UNSUPPORTED, "one mini-batch of %lld samples may hold more than 2^31-1 entries (longest row %lld)",
+              (long long)B, (long long)row_max);
+    double ls = 0.0, vs = 0.0;
+    for (int64_t p0 = begin; p0 < end;) {
+      // AdaGrad's very first step is a mini-batch of its own (adagrad.nim:171): the piece that holds it is one sample longer
+      const int64_t lead = (o->mode == NFM_MODE_MINIBATCH && o->kind == OPT_ADAGRAD && o->it == 1) ? 1 : 0;
+      const int64_t p1 = std::min(end, p0 + piece - (lead ? B - 1 : 0));
+      double l1 = 0.0, v1 = 0.0;
+      NFM_TRY(opt_epoch_range(o, ds, perm, p0, p1, &l1, &v1));
+      ls += l1;
+      vs += v1;
+      p0 = p1;
+    }
+    if (loss_sum) *loss_sum = ls;
+    if (viol_sum) *viol_sum = vs;
+    return NFM_OK;
+  }
+  return opt_epoch_range(o, ds, perm, begin, end, loss_sum, viol_sum);
+}
+
+static int32_t opt_epoch_range(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t begin, int64_t end, double* loss_sum,
+                               double* viol_sum) {
   NFM_CHECK(o && ds, NFM_ERR_INVALID, "null argument");
   nfm_model* m = nullptr;
   NFM_TRY(model_of(o, &m));

@@ -106,3 +106,40 @@ def test_no_memory_for_the_snapshot_means_the_one_workgroup_kernel(kind):
     for g, h in zip(got[:2], ref[:2]):
         assert np.array_equal(g, h)  # (both ran the one-workgroup kernel: bit for bit whatever the flavour)
     assert got[2] == ref[2] and got[3] == ref[3]
+
+
+@pytest.mark.parametrize("solver,mode", [("sgd", "minibatch"), ("adagrad", "minibatch"), ("sgd", "sequential"), ("adagrad", "sequential")])
+def test_an_epoch_of_more_entries_than_one_call_holds_is_walked_in_pieces(solver, mode):
+    """nfm_opt_epoch cuts a range of more than 2^31 - 1 entries into consecutive pieces (whole mini-batches; AdaGrad's first
+    step stays a mini-batch of its own) -- 288 GB hold such datasets.  NFM_TEST_MAX_EPOCH_NNZ (this build only) lowers the bound
+    so that a 5000-sample epoch becomes several pieces: the fit must equal the uncut one bit for bit (mini-batch mode: cuts at
+    batch boundaries; sequential mode: the one-workgroup kernel on any cut), with and without a permutation."""
+    n, d, m, k, B = 5000, 400, 8, 8, 256
+    Xo = random_csr(n, d, m, seed=81)
+    rng = np.random.default_rng(82)
+    y = rng.standard_normal(n)
+    P0, w0 = rng.standard_normal((1, k, d)) * 0.05, np.zeros(d)
+    perms = np.stack([np.arange(n), np.random.default_rng(83).permutation(n)]).astype(np.int64)
+
+    def run():
+        X = to_gpu(Xo)
+        fm = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True)
+        fm.set_params(P0, w0, 0.0)
+        kw = dict(maxIter=2, verbose=0, tol=0, mode=mode, batch=B) if mode == "minibatch" else dict(maxIter=2, verbose=0, tol=0)
+        opt = nf.newSGD(**kw) if solver == "sgd" else nf.newAdaGrad(**kw)
+        with env(NFM_SEQ_WIN=0):
+            opt.fit(X, y, fm, perms=perms)
+        return np.array(fm.P), np.array(fm.w), fm.intercept, opt.it, list(opt.history)
+
+    ref = run()
+    # (8 + 8 guard entries per row) x 700 samples per piece -> eight pieces, none a whole number of mini-batches before rounding
+    with env(NFM_TEST_MAX_EPOCH_NNZ=16 * 700):
+        got = run()
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), "parameters of the cut epoch differ"
+    if mode == "minibatch":  # (and the bound is really looked at: a piece must hold at least one whole mini-batch)
+        from nimfm_amd._capi import NfmError
+        with env(NFM_TEST_MAX_EPOCH_NNZ=16 * 100), pytest.raises(NfmError, match="one mini-batch of 256 samples"):
+            run()
+    assert got[2] == ref[2] and got[3] == ref[3]
+    assert_close([h[0] for h in got[4]], [h[0] for h in ref[4]], 1e-12, 0, "viol (summed piece by piece)")
+    assert_close([h[1] for h in got[4]], [h[1] for h in ref[4]], 1e-12, 0, "loss")
