@@ -56,7 +56,8 @@ enum { NFM_SCHED_CONSTANT = 0, NFM_SCHED_OPTIMAL = 1, NFM_SCHED_INVSCALING = 2, 
  *   reference's single-thread semantics (optimizer/sgd.nim:294-308,
  *   optimizer/adagrad.nim:164-184): results equal to the CPU path's.  Run as
  *   a dependency window over the chip (0.9-3.0e6 samples/s; degree-2 FMs,
- *   several orders / degree <= 6, field-aware models; n_components <= 64;
+ *   several orders / degree <= 6, field-aware models; n_components <= 64,
+ *   degree-2 FMs <= 128 -- their 128-double rows are read as two blocks of 64;
  *   calls of >= 2048 samples), else one sample in flight (fitLower = augment,
  *   more factors, rows too long for the window's LDS).  With a fitted
  *   intercept the window forms each prediction as intercept + (sum of the

@@ -1143,7 +1143,8 @@ static int32_t opt_epoch_range(nfm_opt* o, nfm_dataset* ds, const int64_t* perm,
       const bool win_trusted = !o->seqwin || o->seqwin->fallbacks < 2;  // two aborted launches: CUs are being held -- no more 1 s waits
       if (!win_trusted && o->seqwin) o->seqwin->snap.release();  // (no more window launches from this optimizer: its snapshot goes back)
       bool have_snap = false;
-      if (snap_pays && win_trusted && seq_window_supported(M, ds->max_row + m->n_aug, ns, ds->v.nnz, ctx->n_cu, o->kind == OPT_ADAGRAD)) {
+      const ModelView Mw = seq_window_view(M);  // (65 ... 128 factors: the table read as two blocks of 64, seqwin.hip)
+      if (snap_pays && win_trusted && seq_window_supported(Mw, ds->max_row + m->n_aug, ns, ds->v.nnz, ctx->n_cu, o->kind == OPT_ADAGRAD)) {
         if (!o->seqwin) o->seqwin.reset(new SeqWin());
         // A model (+ AdaGrad state) beyond half of the free memory has no room for its snapshot: that fit runs in the
         // one-workgroup kernel, which needs none -- it must not fail for want of a safety copy.
@@ -1164,7 +1165,7 @@ static int32_t opt_epoch_range(nfm_opt* o, nfm_dataset* ds, const int64_t* perm,
         NFM_HIP_CHECK(hipMemcpyAsync(sw->snap.p, m->arena.p, m->arena.bytes, hipMemcpyDeviceToDevice, st));
         if (o->kind == OPT_ADAGRAD)
           NFM_HIP_CHECK(hipMemcpyAsync(sw->snap.as<char>() + m->arena.bytes, o->state_arena.p, o->state_arena.bytes, hipMemcpyDeviceToDevice, st));
-        const int rc = launch_sequential_window(ctx, o->kind, ds->v, M, o->o, perm_dev, begin, end, o->it, ds->max_row + m->n_aug,
+        const int rc = launch_sequential_window(ctx, o->kind, ds->v, Mw, o->o, perm_dev, begin, end, o->it, ds->max_row + m->n_aug,
                                                 o->out2.as<double>(), sw, (ds->uid << 20) ^ ds->serial, perm != nullptr);
         if (rc == NFM_WIN_FALLBACK) {
           NFM_HIP_CHECK(hipMemcpyAsync(m->arena.p, sw->snap.p, m->arena.bytes, hipMemcpyDeviceToDevice, st));

@@ -48,6 +48,8 @@ struct SeqWin {           // kept on the optimizer between calls
   uint64_t ds_uid = 0;
   int64_t begin = 0, end = 0, nnz = 0;
 };
+// the model as the window kernels see it (seqwin.hip: a 65 ... 128-factor FM read as two blocks of 64)
+ModelView seq_window_view(const ModelView& M);
 bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz, int n_cu, bool ada);
 // launch_sequential_window's third outcome besides NFM_OK and an error: the window could not run to its end (the kernel does
 // not fit a CU, or a wait inside it timed out and the launch aborted).  Parameters and state of the call may be partly

@@ -3748,6 +3748,27 @@ static bool win_one_term(const ModelView& M) {  // the intercept is fitted: the 
   return !win_no_cond(M) && !(env && atoi(env) != 0);
 }
 
+// A degree-2 FM of 65 ... 128 factors is ONE block of 128-double rows: too wide for the window's workers (rows of at most 64
+// factors).  The same table read as feature-major blocks of 64 -- row(b, j) = 2 j + b in units of 64 doubles, exactly
+// ModelView::row with bs = 1, rs = 2 -- is a two-block model of the same degree (common.h: kc), which the several-orders worker
+// takes as it is: no copy, no second layout.  The factors' sum is then formed block by block -- results within rounding of the
+// one-sample-in-flight kernel, not bit-equal: NFM_SEQ_WIN_EXACT=1 keeps such models on that kernel.
+ModelView seq_window_view(const ModelView& M) {
+  const char* exact = getenv("NFM_SEQ_WIN_EXACT");
+  if (!(M.kind == NFM_KIND_FM && M.nb == 1 && M.kc == 1 && M.degree == 2 && M.n_aug == 0 && M.Kp == 2 * kWave && M.bs == M.da && M.rs == 1 &&
+        !(exact && atoi(exact) != 0)))
+    return M;
+  ModelView V = M;
+  V.nb = 2;
+  V.kc = 2;
+  V.Kp = kWave;
+  V.L = kWave / 2;
+  V.k = kWave;
+  V.bs = 1;
+  V.rs = 2;
+  return V;
+}
+
 bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz, int n_cu, bool ada) {
   const char* env = getenv("NFM_SEQ_WIN");  // 0: off, 1 (default): when it pays, 2: whenever possible (read per call: tests switch it)
   const int mode = env ? atoi(env) : 1;

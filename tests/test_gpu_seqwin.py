@@ -669,3 +669,55 @@ def test_abort_paths_in_the_test_hooks_build():
                        cwd=root, env=envc, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-4000:], r.stderr[-2000:])
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("kind,k,m", [("sgd", 100, 40), ("sgd", 128, 64), ("sgd", 65, 9), ("adagrad", 100, 20), ("adagrad", 128, 30)])
+def test_65_to_128_factors_read_as_two_blocks_of_64(kind, k, m, window_flavour):
+    """A degree-2 FM of 65 ... 128 factors is one block of 128-double rows: the window's workers take rows of at most 64
+    factors, so before round 5 such a model ran its exact order one sample at a time.  The same table read as feature-major
+    blocks of 64 (ModelView::row with bs = 1, rs = 2, seqwin.hip::seq_window_view) is a two-block model of the same degree,
+    which the several-orders worker takes as it is -- in the one-term window (the exact flavour keeps the one-workgroup kernel:
+    its factor sum is one ascending pass).  Held to the one-workgroup kernel and to the oracle; which kernel ran is asked."""
+    n, d = 2500, 700
+    Xo = random_csr(n, d, m, seed=k)
+    rng = np.random.default_rng(k + 1)
+    y = rng.standard_normal(n)
+    perms = make_perms(n, 2)
+    ctx = nf.default_context()
+    before = ctx.timing_get("seq_window_launch")[0]
+    if kind == "sgd":
+        win, (P0, w0, b0) = check_pair(kind, Xo, y, "regression", k, 64, epochs=2, perms=perms)
+    else:
+        # AdaGrad's 1 / sqrt(g_norm) (g_norm starts at eps = 1e-10) amplifies the few-ulp differences of a prediction whose
+        # hundred factors are summed block by block instead of in one pass (tools/seqwin_soak.py saw 1e-10 ... 7e-7 per parameter
+        # for the one-term window itself): held at the reference's own fast-against-slow tolerance (tests/utils.nim:82-105)
+        P0, w0, b0 = rng.standard_normal((1, k, d)) * 0.1 / np.sqrt(k), rng.standard_normal(d) * 0.01, 0.05
+        ref = fit(kind, 0, 64, Xo, y, "regression", k, P0, w0, b0, 2, perms)
+        win = fit(kind, 2, 64, Xo, y, "regression", k, P0, w0, b0, 2, perms)
+        for a_, b_, name in [(win[0], ref[0], "P"), (win[1], ref[1], "w")] + list(zip(win[5][:4], ref[5][:4], ["g_sum.P", "g_norm.P", "g_sum.w", "g_norm.w"])):
+            if window_flavour == "one_term":
+                assert_close(a_, b_, 1e-6, 1e-9, name)
+            else:
+                same_bits(a_, b_, name)
+        assert abs(win[2] - ref[2]) < 1e-9
+    launched = ctx.timing_get("seq_window_launch")[0] - before
+    if window_flavour == "one_term":
+        assert launched >= 2, "the window did not run for %d factors" % k
+    else:
+        assert launched == 0
+    if kind == "sgd":
+        Pf, wf, bf, *_ = O.fm_sgd_fit(Xo, y, 2, P0, w0, b0, O.sgd_cfg(), 2, 0, perms=perms)
+    else:
+        Pf, wf, bf, *_ = O.fm_adagrad_fit(Xo, y, 2, P0, w0, b0, O.adagrad_cfg(), 2, 0, perms=perms)
+    tol = (1e-8, 1e-11) if kind == "sgd" or window_flavour != "one_term" else (1e-6, 1e-9)
+    if kind == "sgd" and k == 100:  # without an intercept: no conductor, the worker sums the prediction itself -- the same view
+        before = ctx.timing_get("seq_window_launch")[0]
+        refn = fit(kind, 0, 64, Xo, y, "regression", k, P0, w0, 0.0, 2, perms, fit_intercept=False)
+        winn = fit(kind, 2, 64, Xo, y, "regression", k, P0, w0, 0.0, 2, perms, fit_intercept=False)
+        assert (ctx.timing_get("seq_window_launch")[0] - before >= 2) == (window_flavour == "one_term")
+        assert_close(winn[0], refn[0], 1e-8, 1e-11, "P, fitIntercept = false")
+        assert_close(winn[1], refn[1], 1e-8, 1e-11, "w, fitIntercept = false")
+        assert winn[2] == 0.0
+    assert_close(win[0], Pf, *tol, "P vs oracle")
+    assert_close(win[1], wf, *tol, "w vs oracle")
+    assert abs(win[2] - bf) < (1e-9 if kind == "sgd" else 1e-7)
