@@ -98,14 +98,17 @@ int32_t nfm_ctx_timing_get(nfm_ctx* ctx, const char* family, int64_t* launches, 
  * dataset.nim:10-13,182-231 (row iterators incl. dummy features, which the
  * kernels generate on the fly) as the thing `fit`/`decisionFunction` iterate.
  * indices/fields are narrowed to int32 on the device.  y may be NULL for
- * predict-only datasets.  Rows may be stored in any order (dataset.nim:597-612),
- * but the column ids inside one row must be DISTINCT: a repeated id is
- * NFM_ERR_UNSUPPORTED at creation (here, in the *_device variant and in every
- * loader).  The reference does not forbid repeats, but what it computes for
- * them is an accident of its scratch layout (the later entry overwrites the
- * earlier one's derivative dA[j], optimizer/sgd.nim:176-188, and the row's
- * parameters are then stepped once per entry with it, :217-223); merge
- * repeated entries before handing a matrix over. */
+ * predict-only datasets.  Rows may be stored in any order (dataset.nim:597-612).
+ * A column id REPEATED inside a row: decisionFunction / predict / score take
+ * it as the reference does (every entry is one more term of the ANOVA
+ * recursion, kernels.nim:46-64); TRAINING needs distinct ids per row --
+ * nfm_opt_epoch and nfm_opt_predict_all_with_grad return NFM_ERR_UNSUPPORTED
+ * naming the first such row.  The reference does not forbid repeats there,
+ * but what its step computes for them is an accident of its lazy scaling and
+ * scratch layout (the row is rescaled once per ENTRY, optimizer/sgd.nim:134-143;
+ * the later entry overwrites the earlier one's derivative dA[j], :176-188, and
+ * the row's parameters are then stepped once per entry with it, :217-223);
+ * merge repeated entries before training on such a matrix. */
 int32_t nfm_dataset_create_csr(nfm_ctx* ctx, int64_t n_samples, int64_t n_features,
                                const int64_t* indptr /*n+1*/, const int64_t* indices /*nnz*/,
                                const double* data /*nnz*/, const int64_t* fields /*nnz or NULL*/,

@@ -26,6 +26,7 @@ struct nfm_dataset {
   DevBuf indptr, indices, data, fields, y;
   bool has_y = false;
   int max_row = 0;
+  int64_t repeats = 0, repeat_row = -1;  // entries that repeat a column id of their row (plan.h: predict-only data)
   int64_t ingest_bytes = 0;  // set by the text loaders (ingest.hip)
   double ingest_upload_ms = 0.0, ingest_parse_ms = 0.0;
   // Cache keys.  uid: process-unique, never reused -- what a Plan is keyed by (a raw nfm_dataset* can be handed out
@@ -330,7 +331,7 @@ int32_t nfm_dataset_create_csr(nfm_ctx* ctx, int64_t n, int64_t d, const int64_t
   ds->v.y = ds->has_y ? ds->y.as<double>() : nullptr;
   ds->v.n = n; ds->v.d = d; ds->v.nnz = nnz; ds->v.n_fields = fields ? (int32_t)n_fields : 0;
   ds->v.max_row = max_row;
-  NFM_TRY(check_rows_distinct(ctx, ds->v));
+  NFM_TRY(check_rows_distinct(ctx, ds->v, &ds->repeats, &ds->repeat_row));
   *out = ds.release();
   return NFM_OK;
 }
@@ -361,7 +362,7 @@ int32_t nfm_dataset_create_csr_device(nfm_ctx* ctx, int64_t n, int64_t d, int64_
   ds->v.indptr = indptr_dev; ds->v.indices = indices_dev; ds->v.data = data_dev; ds->v.fields = fields_dev;
   ds->v.y = y_dev; ds->v.n = n; ds->v.d = d; ds->v.nnz = nnz; ds->v.n_fields = fields_dev ? (int32_t)n_fields : 0;
   ds->v.max_row = (int32_t)mr;
-  NFM_TRY(check_rows_distinct(ctx, ds->v));
+  NFM_TRY(check_rows_distinct(ctx, ds->v, &ds->repeats, &ds->repeat_row));
   *out = ds.release();
   return NFM_OK;
 }
@@ -412,7 +413,7 @@ static int dataset_from_ingest(nfm_ctx* ctx, IngestResult& r, bool with_fields, 
   ds->ingest_bytes = r.bytes;
   ds->ingest_upload_ms = r.upload_ms;
   ds->ingest_parse_ms = r.parse_ms;
-  NFM_TRY(check_rows_distinct(ctx, ds->v));
+  NFM_TRY(check_rows_distinct(ctx, ds->v, &ds->repeats, &ds->repeat_row));
   *out = ds.release();
   return NFM_OK;
 }
@@ -751,6 +752,15 @@ int32_t nfm_model_get_params(nfm_model* m, double* P, double* w, double* interce
   if (w && sc[SC_SCALE_W] != 1.0)
     for (int64_t j = 0; j < m->d; ++j) w[j] *= sc[SC_SCALE_W];
   if (intercept) *intercept = sc[SC_INTERCEPT];
+  return NFM_OK;
+}
+
+// training needs distinct column ids inside every row (plan.h); decisionFunction / score / metrics do not
+static int check_trainable(const nfm_dataset* ds) {
+  NFM_CHECK(ds->repeats == 0, NFM_ERR_UNSUPPORTED,
+            "%lld repeated column ids inside rows (first in row %lld): the ids of one row must be distinct for training -- merge "
+            "repeated entries (decisionFunction, predict and score take the dataset as it is)",
+            (long long)ds->repeats, (long long)ds->repeat_row);
   return NFM_OK;
 }
 
@@ -1103,6 +1113,7 @@ static int32_t opt_epoch_range(nfm_opt* o, nfm_dataset* ds, const int64_t* perm,
             "the optimizer's data-parallel group was destroyed; detach it (nfm_opt_set_dp(o, NULL, 0, 0)) or attach a new one");
   NFM_TRY(check_predict_shapes(m, ds));
   NFM_CHECK(ds->has_y, NFM_ERR_INVALID, "dataset has no targets");
+  NFM_TRY(check_trainable(ds));
   // MBPSGD consumes a stream of sample indices that may wrap past the end of the data (minibatch_psgd.nim:104-108)
   NFM_CHECK(begin >= 0 && begin <= end && (end <= ds->v.n || (o->kind == OPT_PSGD && perm)), NFM_ERR_INVALID,
             "bad sample range [%lld,%lld)", (long long)begin, (long long)end);
@@ -1384,6 +1395,7 @@ int32_t nfm_opt_predict_all_with_grad(nfm_opt* o, nfm_dataset* ds, double* y_pre
   NFM_CHECK(ds->ctx == ctx, NFM_ERR_INVALID, "optimizer and dataset belong to different contexts");
   NFM_TRY(check_predict_shapes(m, ds));
   NFM_CHECK(ds->has_y, NFM_ERR_INVALID, "dataset has no targets");
+  NFM_TRY(check_trainable(ds));
   NFM_TRY(use_device(ctx));
   NFM_TRY(ensure_unit_scale(m));
   hipStream_t st = ctx->stream;

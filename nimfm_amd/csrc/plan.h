@@ -68,10 +68,12 @@ struct CscIndex {
 constexpr int kHeavyTouches = 128;
 constexpr int kHeavySegment = 64;
 
-// NFM_ERR_UNSUPPORTED when a row of X holds a column id twice (every training and predict kernel assumes distinct
-// ids per row; the reference's behaviour for repeats is an accident of its lazy scaling, optimizer/sgd.nim:134-143,
-// 176-188: the second entry overwrites the first one's derivative and the row's parameters are stepped twice with it)
-int check_rows_distinct(nfm_ctx* ctx, const CsrView& X);
+// how many entries repeat a column id of their row, and the first such row (-1: none).  decisionFunction takes repeats as
+// the reference does -- every entry is one more term of the ANOVA recursion (kernels.nim:46-64) -- but every TRAINING kernel
+// assumes distinct ids per row (the reference's behaviour for repeats is an accident of its lazy scaling and scratch layout,
+// optimizer/sgd.nim:134-143, 176-188: the row is rescaled once per entry, the second entry overwrites the first one's
+// derivative and the row's parameters are stepped twice with it): nfm_opt_epoch refuses such a dataset.
+int check_rows_distinct(nfm_ctx* ctx, const CsrView& X, int64_t* n_repeats, int64_t* first_row);
 
 // stream: where the build is enqueued and synchronised (default: the context's); perm_dev: the end - begin sample ids of
 // the epoch already on the device (instead of perm_host)

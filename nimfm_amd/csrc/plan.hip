@@ -238,7 +238,9 @@ __global__ void k_row_order(int64_t n, const int64_t* __restrict__ indptr, const
   if (bad) atomicAdd(count, bad);
 }
 
-int check_rows_distinct(nfm_ctx* ctx, const CsrView& X) {
+int check_rows_distinct(nfm_ctx* ctx, const CsrView& X, int64_t* n_repeats, int64_t* first_row) {
+  *n_repeats = 0;
+  *first_row = -1;
   if (X.n == 0 || X.nnz < 2 || X.max_row < 2) return NFM_OK;
   hipStream_t st = ctx->stream;
   DevBuf stat;
@@ -275,10 +277,8 @@ int check_rows_distinct(nfm_ctx* ctx, const CsrView& X) {
   NFM_TRY(tmp.alloc(bytes));
   NFM_HIP_CHECK(hipcub::DeviceSegmentedRadixSort::SortKeys(tmp.p, bytes, dk, (int)X.nnz, (int)X.n, X.indptr, X.indptr + 1, 0, 32, st));
   NFM_TRY(run(true, dk.Current()));
-  NFM_CHECK(h[0] == 0, NFM_ERR_UNSUPPORTED,
-            "%lld repeated column ids inside rows (first in row %lld): the ids of one row must be distinct -- merge "
-            "repeated entries before creating the dataset",
-            h[0], h[1]);
+  *n_repeats = h[0];
+  *first_row = h[0] ? h[1] : -1;
   return NFM_OK;
 }
 

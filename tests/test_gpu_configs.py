@@ -296,17 +296,43 @@ def test_optimizer_refuses_a_destroyed_model():
     assert ada._h is h2 and ada._epoch(X4, None, 0, n) == (0.0, 0.0)
 
 
-def test_repeated_ids_in_a_row_are_refused():
-    """include/nimfm_hip.h: ids inside one row must be distinct (any storage order is fine)"""
+def test_repeated_ids_in_a_row_predict_but_do_not_train():
+    """A column id repeated inside a row (dataset.nim:597-612 reads it without complaint): decisionFunction takes it as the
+    reference does -- every entry is one more term of the ANOVA recursion (kernels.nim:46-64; field-aware: pairs of equal ids
+    are skipped, field_aware_factorization_machine.nim:66-76) -- while the training kernels need distinct ids per row (what
+    the reference's step computes for a repeat is an accident of its lazy scaling, include/nimfm_hip.h): fit refuses, naming
+    the first such row.  Any storage order is fine."""
     indptr = np.array([0, 3, 6, 8], dtype=np.int64)
     ok = np.array([5, 1, 3, 0, 2, 9, 7, 4], dtype=np.int64)  # unsorted rows, all distinct
     nf.newCSRDataset(np.ones(8), ok, indptr, 3, 10)
     bad = ok.copy()
     bad[5] = 0  # row 1 = [0, 2, 0]
+    vals = np.array([0.5, -1.0, 2.0, 1.5, 0.25, -0.75, 1.0, 3.0])
+    rng = np.random.default_rng(3)
+    Xo = O.Dataset(indptr, bad, vals, 3, 10)
+    X = nf.newCSRDataset(vals, bad, indptr, 3, 10)
+    for degree, fit_lower in [(2, "explicit"), (3, "explicit"), (4, "none")]:
+        no = O.n_orders(degree, fit_lower)
+        P0, w0 = rng.standard_normal((no, 5, 10)) * 0.3, rng.standard_normal(10) * 0.2
+        fm = gpu_fm("regression", degree, 5, fit_lower, True, True, P0, w0, 0.1)
+        assert_close(fm.decisionFunction(X), O.fm_decision_function(Xo, degree, P0, w0, 0.1, 0), 1e-12, 1e-14, "degree %d" % degree)
+    y = np.array([1.0, -1.0, 0.5])
+    sgd = nf.newSGD(maxIter=1, verbose=0, tol=0)
     with pytest.raises(nf.NfmError, match="row 1"):
-        nf.newCSRDataset(np.ones(8), bad, indptr, 3, 10)
+        sgd.fit(X, y, fm)
     with pytest.raises(nf.NfmError, match="distinct"):
-        nf.parseText(b"1 3:1.0 5:2.0 3:0.5\n-1 1:1\n")
-    # sorted rows with an adjacent repeat
-    with pytest.raises(nf.NfmError):
-        nf.newCSRDataset(np.ones(4), np.array([1, 1, 2, 3]), np.array([0, 2, 4]), 2, 5)
+        nf.newSGD(maxIter=1, verbose=0, tol=0, mode="minibatch", batch=2).fit(X, y, fm)
+    # field-aware: ids 3 and 3 in row 0 (fields 0 and 1)
+    fld = np.array([0, 1, 2, 0, 1, 2, 0, 1], dtype=np.int64)
+    idx = np.array([3, 3, 5, 0, 2, 9, 7, 4], dtype=np.int64)
+    Xfo = O.Dataset(indptr, idx, vals, 3, 10, fields=fld, n_fields=3)
+    Xf = nf.newCSRFieldDataset(vals, idx, indptr, fld, 3, 10, 3)
+    Pf, wf = rng.standard_normal((3, 10, 4)) * 0.3, rng.standard_normal(10) * 0.2
+    ffm = gpu_ffm("regression", 4, True, True, Pf, wf, -0.2)
+    assert_close(ffm.decisionFunction(Xf), O.ffm_decision_function(Xfo, Pf, wf, -0.2), 1e-12, 1e-14, "field-aware")
+    # the text loaders accept such a file too; sorted rows with an adjacent repeat
+    Xt, yt = nf.parseText(b"1 3:1.0 5:2.0 3:0.5\n-1 1:1\n")
+    with pytest.raises(nf.NfmError, match="distinct"):
+        nf.newSGD(maxIter=1, verbose=0, tol=0).fit(Xt, yt, gpu_fm("regression", 2, 2, "explicit", True, True, np.zeros((1, 2, Xt.nFeatures)),
+                                                                 np.zeros(Xt.nFeatures), 0.0))
+    nf.newCSRDataset(np.ones(4), np.array([1, 1, 2, 3]), np.array([0, 2, 4]), 2, 5)
