@@ -16,8 +16,8 @@ worst = 0.0
 for case in range(n_cases):
     n = int(rng.integers(1, 2500))
     d = int(rng.integers(2, 600))
-    k = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 20, 32, 50, 64]))
-    max_m = int(min(d, rng.choice([1, 3, 8, 20, 64, 100])))
+    k = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 20, 32, 50, 64, 65, 100, 128, 129, 200, 260]))  # (round 5: no cap on k)
+    max_m = int(min(d, rng.choice([1, 3, 8, 20, 64, 100, 400])))
     B = int(rng.choice([1, 7, 64, 256, 1000, 4096]))
     solver = str(rng.choice(["sgd", "adagrad"]))
     loss = str(rng.choice(["squared", "logistic", "squared_hinge", "huber"]))

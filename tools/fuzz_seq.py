@@ -16,8 +16,8 @@ worst = 0.0
 for case in range(n_cases):
     n = int(rng.integers(1, 400))
     d = int(rng.integers(2, 600))
-    k = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 20, 32, 50, 64]))
-    max_m = int(min(d, rng.choice([1, 3, 8, 20, 64, 100])))
+    k = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 20, 32, 50, 64, 65, 100, 128, 129, 200, 260]))  # (round 5: no cap on k)
+    max_m = int(min(d, rng.choice([1, 3, 8, 20, 64, 100, 400])))
     B = 0
     solver = str(rng.choice(["sgd", "adagrad"]))
     loss = str(rng.choice(["squared", "logistic", "squared_hinge", "huber"]))
@@ -77,7 +77,10 @@ for case in range(n_cases):
         scale = max(1e-3, float(np.abs(P).max()))
         err = max(float(np.abs(mdl.P - P).max()) / scale, float(np.abs(mdl.w - w).max()) / max(1e-3, float(np.abs(w).max())), abs(mdl.intercept - b))
         worst = max(worst, err)
-        if not np.isfinite(err) or err > 1e-8:
+        # (NFM_SEQ_WIN=2 sends even these short fits through the window; AdaGrad there, with 65 ... 128 factors summed block by
+        # block, is held at the reference's own fast-against-slow tolerance: tests/test_gpu_seqwin.py)
+        tol = 1e-6 if (os.environ.get("NFM_SEQ_WIN") == "2" and solver == "adagrad") else 1e-8
+        if not np.isfinite(err) or err > tol:
             print("MISMATCH", tag, "err", err, flush=True)
     except Exception as e:  # noqa: BLE001
         print("ERROR", tag, repr(e)[:300], flush=True)
