@@ -1079,7 +1079,11 @@ int32_t nfm_opt_epoch(nfm_opt* o, nfm_dataset* ds, const int64_t* perm, int64_t 
   // device-drawn order (nfm_opt_set_shuffle) then shuffles inside each piece.
   const int64_t row_max = std::max<int64_t>((int64_t)ds->max_row + 8, 1), cap = max_epoch_nnz();
   const int64_t ns_all = end - begin;
-  if (begin >= 0 && ns_all > 0 && !o->dp && ns_all > cap / row_max && (perm || end <= ds->v.n)) {
+  // (an order over distinct samples holds no more entries than the dataset, however long its longest row is: one outlier row
+  // must not cut every epoch of a small dataset into pieces.  MBPSGD's index stream may wrap, so only the product bounds it.)
+  bool may_exceed = ns_all > cap / row_max;
+  if (may_exceed && o->kind != OPT_PSGD && ns_all <= ds->v.n && ds->v.nnz + 8 * ns_all <= cap) may_exceed = false;
+  if (begin >= 0 && ns_all > 0 && !o->dp && may_exceed && (perm || end <= ds->v.n)) {
     const int64_t B = o->mode == NFM_MODE_MINIBATCH ? std::max<int64_t>(o->batch, 1) : 1;
     int64_t piece = cap / row_max / B * B;  // whole mini-batches
     NFM_CHECK(piece >= B, NFM_ERR_UNSUPPORTED, "one mini-batch of %lld samples may hold more than 2^31-1 entries (longest row %lld)",
