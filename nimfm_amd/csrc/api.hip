@@ -56,6 +56,13 @@ struct nfm_model {
   // (ModelView::kc) -- nb counts DEVICE blocks (orders x kc; fields for field-aware models), no the reference's orders
   int nb = 0, no = 0, kc = 1, kb = 0, n_aug = 0, k = 0, Kp = 0, L = 0;
   int64_t d = 0, da = 0;
+  // a wide FM of ONE order keeps its kc blocks FEATURE-major: the row of a feature is one contiguous run of kc * Kp doubles -- kc
+  // blocks of Kp to the kernels that walk blocks (row(b, j) = j * kc + b), ONE row of kc * Kp factors to the one-sample-in-flight
+  // kernel (seq_row_view: its pipelined step and its single ascending factor sum, as before round 5), blocks of 64 to the window
+  // (seq_window_view).  Several orders: order-major blocks (the views above need one stride per block).
+  bool wide_rows() const { return cfg.kind == NFM_KIND_FM && kc > 1 && no == 1; }
+  int64_t bs_() const { return (cfg.kind == NFM_KIND_FFM || wide_rows()) ? 1 : da; }
+  int64_t rs_() const { return (cfg.kind == NFM_KIND_FFM || wide_rows()) ? nb : 1; }
   // P, w and the scalars live back to back in ONE allocation ([P | w | scalars], each padded to 256 B,
   // padding zero) so the data-parallel exchange is a single collective over the arena
   DevBuf arena, lams;
@@ -65,7 +72,7 @@ struct nfm_model {
     ModelView m{};
     m.P = P.as<double>(); m.w = w.as<double>(); m.sc = sc.as<double>(); m.lams = lams.as<double>();
     m.d = d; m.da = da; m.nb = nb; m.k = kb; m.Kp = Kp; m.L = L; m.kc = kc;
-    if (cfg.kind == NFM_KIND_FFM) { m.bs = 1; m.rs = nb; } else { m.bs = da; m.rs = 1; }
+    m.bs = bs_(); m.rs = rs_();
     m.degree = cfg.kind == NFM_KIND_FFM ? 2 : cfg.degree;
     m.n_aug = n_aug; m.kind = cfg.kind; m.fit_linear = cfg.fit_linear; m.fit_intercept = cfg.fit_intercept;
     m.task = cfg.task;
@@ -82,8 +89,8 @@ static int fm_params_to_device(nfm_model* m, const double* src_ref, double* dst_
   for (int o = 0; o < m->no; ++o)
     for (int c = 0; c < m->kc; ++c) {
       const int kk = std::min(m->kb, m->k - c * m->kb);
-      NFM_TRY(launch_fm_to_device(m->ctx, src_ref + ((size_t)o * m->k + (size_t)c * m->kb) * m->da,
-                                  dst_dev + (size_t)(o * m->kc + c) * m->da * m->Kp, 1, kk, m->Kp, m->da));
+      NFM_TRY(launch_fm_to_device(m->ctx, src_ref + ((size_t)o * m->k + (size_t)c * m->kb) * m->da, dst_dev, 1, kk, m->Kp, m->da, m->bs_(),
+                                  m->rs_(), o * m->kc + c));
     }
   return NFM_OK;
 }
@@ -92,8 +99,8 @@ static int fm_params_from_device(nfm_model* m, const double* src_dev, double* ds
   for (int o = 0; o < m->no; ++o)
     for (int c = 0; c < m->kc; ++c) {
       const int kk = std::min(m->kb, m->k - c * m->kb);
-      NFM_TRY(launch_fm_from_device(m->ctx, src_dev + (size_t)(o * m->kc + c) * m->da * m->Kp,
-                                    dst_ref + ((size_t)o * m->k + (size_t)c * m->kb) * m->da, 1, kk, m->Kp, m->da, scale_dev));
+      NFM_TRY(launch_fm_from_device(m->ctx, src_dev, dst_ref + ((size_t)o * m->k + (size_t)c * m->kb) * m->da, 1, kk, m->Kp, m->da, scale_dev,
+                                    m->bs_(), m->rs_(), o * m->kc + c));
     }
   return NFM_OK;
 }
@@ -101,12 +108,12 @@ static int fm_params_from_device(nfm_model* m, const double* src_dev, double* ds
 static int rows_to_device(nfm_model* m, const double* src_ref, double* dst_dev, double pad) {
   const int major = m->cfg.kind == NFM_KIND_FFM ? m->nb : 0;  // (feature-major field rows, ModelView::row)
   if (m->kc == 1) return launch_rows_to_device(m->ctx, src_ref, dst_dev, (int64_t)m->nb * m->da, m->k, m->Kp, pad, major);
-  return launch_rows_split_to_device(m->ctx, src_ref, dst_dev, m->no, m->da, m->k, m->kc, m->kb, m->Kp, pad);
+  return launch_rows_split_to_device(m->ctx, src_ref, dst_dev, m->no, m->da, m->k, m->kc, m->kb, m->Kp, pad, m->bs_(), m->rs_());
 }
 static int rows_from_device(nfm_model* m, const double* src_dev, double* dst_ref, const double* scale_dev) {
   const int major = m->cfg.kind == NFM_KIND_FFM ? m->nb : 0;
   if (m->kc == 1) return launch_rows_from_device(m->ctx, src_dev, dst_ref, (int64_t)m->nb * m->da, m->k, m->Kp, scale_dev, major);
-  return launch_rows_split_from_device(m->ctx, src_dev, dst_ref, m->no, m->da, m->k, m->kc, m->kb, m->Kp, scale_dev);
+  return launch_rows_split_from_device(m->ctx, src_dev, dst_ref, m->no, m->da, m->k, m->kc, m->kb, m->Kp, scale_dev, m->bs_(), m->rs_());
 }
 
 struct nfm_opt {
@@ -1199,7 +1206,8 @@ static int32_t opt_epoch_range(nfm_opt* o, nfm_dataset* ds, const int64_t* perm,
         }
       }
       if (!windowed)
-        NFM_TRY(launch_sequential(ctx, o->kind, ds->v, M, o->o, perm_dev, begin, end, o->it, ds->max_row + m->n_aug, o->out2.as<double>()));
+        NFM_TRY(launch_sequential(ctx, o->kind, ds->v, seq_row_view(M), o->o, perm_dev, begin, end, o->it, ds->max_row + m->n_aug,
+                                  o->out2.as<double>()));
       NFM_HIP_CHECK(hipMemcpyAsync(out2, o->out2.p, sizeof(out2), hipMemcpyDeviceToHost, st));
       NFM_HIP_CHECK(hipStreamSynchronize(st));
     } else {

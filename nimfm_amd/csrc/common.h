@@ -198,16 +198,20 @@ inline int lanes_for_k(int k) {
 // ---- util.hip ----
 int launch_fill(nfm_ctx* ctx, double* p, int64_t n, double v);
 // reference FM layout [nb][k][da] <-> device [nb][da][Kp]; FFM reference [nb][da][k] <-> device
-int launch_fm_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int nb, int k, int Kp, int64_t da);
-int launch_fm_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int nb, int k, int Kp, int64_t da, const double* scale_dev);
+// (bs, rs, b0): ModelView's block / row strides of the device tensor and the device block the first reference block lands in;
+// 0, 0, 0 = order-major from block 0 (bs = da, rs = 1)
+int launch_fm_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int nb, int k, int Kp, int64_t da, int64_t bs = 0, int64_t rs = 0,
+                        int b0 = 0);
+int launch_fm_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int nb, int k, int Kp, int64_t da, const double* scale_dev,
+                          int64_t bs = 0, int64_t rs = 0, int b0 = 0);
 // nb_major > 0: the reference tensor is [nb_major][rows / nb_major][k], the device tensor feature-major (ModelView::row)
 int launch_rows_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int64_t rows, int k, int Kp, double pad_value, int nb_major = 0);
 int launch_rows_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int64_t rows, int k, int Kp, const double* scale_dev, int nb_major = 0);
 // FMs with more than 128 factors: reference [no * da][k] <-> device [no * kc][da][Kp] (ModelView::kc)
 int launch_rows_split_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int64_t no, int64_t da, int k, int kc, int kb, int Kp,
-                                double pad_value);
+                                double pad_value, int64_t bs, int64_t rs);
 int launch_rows_split_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int64_t no, int64_t da, int k, int kc, int kb, int Kp,
-                                  const double* scale_dev);
+                                  const double* scale_dev, int64_t bs, int64_t rs);
 // P *= sc[SC_SCALE_P], w *= sc[SC_SCALE_W] (if fit_linear), scales := 1  (sgd.nim:99-113)
 int launch_rescale(nfm_ctx* ctx, const ModelView& M);
 int launch_sqnorms(nfm_ctx* ctx, const ModelView& M, double* out2_dev /*{P_sq,w_sq}*/);

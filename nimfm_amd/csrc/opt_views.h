@@ -50,6 +50,20 @@ struct SeqWin {           // kept on the optimizer between calls
 };
 // the model as the window kernels see it (seqwin.hip: a 65 ... 128-factor FM read as two blocks of 64)
 ModelView seq_window_view(const ModelView& M);
+// the model as the one-sample-in-flight kernel sees it: a wide FM of one order whose kc blocks lie feature-major is ONE row of
+// kc * Kp factors per feature (padding zeros inside the row add nothing to the ascending factor sum, sgd.nim:172-173)
+inline ModelView seq_row_view(const ModelView& M) {
+  if (!(M.kind == NFM_KIND_FM && M.kc > 1 && M.nb == M.kc && M.bs == 1 && M.rs == M.nb)) return M;
+  ModelView V = M;
+  V.Kp = M.nb * M.Kp;
+  V.k = V.Kp;
+  V.L = 64;
+  V.nb = 1;
+  V.kc = 1;
+  V.bs = M.da;
+  V.rs = 1;
+  return V;
+}
 bool seq_window_supported(const ModelView& M, int m_cap, int64_t ns, int64_t nnz, int n_cu, bool ada);
 // launch_sequential_window's third outcome besides NFM_OK and an error: the window could not run to its end (the kernel does
 // not fit a CU, or a wait inside it timed out and the launch aborted).  Parameters and state of the call may be partly

@@ -3755,17 +3755,21 @@ static bool win_one_term(const ModelView& M) {  // the intercept is fitted: the 
 // one-sample-in-flight kernel, not bit-equal: NFM_SEQ_WIN_EXACT=1 keeps such models on that kernel.
 ModelView seq_window_view(const ModelView& M) {
   const char* exact = getenv("NFM_SEQ_WIN_EXACT");
-  if (!(M.kind == NFM_KIND_FM && M.nb == 1 && M.kc == 1 && M.degree == 2 && M.n_aug == 0 && M.Kp == 2 * kWave && M.bs == M.da && M.rs == 1 &&
-        !(exact && atoi(exact) != 0)))
-    return M;
+  if (exact && atoi(exact) != 0) return M;
+  if (!(M.kind == NFM_KIND_FM && M.degree == 2 && M.n_aug == 0 && M.Kp == 2 * kWave)) return M;
+  // one block of 128-double rows (65 ... 128 factors), or a wide model of one order whose kc blocks of 128 lie feature-major
+  // (api.hip: wide_rows): either way a feature's row is nb * 128 contiguous doubles = 2 nb blocks of 64
+  const bool one_block = M.nb == 1 && M.kc == 1 && M.bs == M.da && M.rs == 1;
+  const bool wide_rows = M.kc > 1 && M.nb == M.kc && M.bs == 1 && M.rs == M.nb;
+  if (!one_block && !wide_rows) return M;
   ModelView V = M;
-  V.nb = 2;
-  V.kc = 2;
+  V.nb = 2 * M.nb;
+  V.kc = V.nb;
   V.Kp = kWave;
   V.L = kWave / 2;
   V.k = kWave;
   V.bs = 1;
-  V.rs = 2;
+  V.rs = V.nb;
   return V;
 }
 

@@ -204,7 +204,8 @@ int launch_fill(nfm_ctx* ctx, double* p, int64_t n, double v) {
 
 // reference FM model layout [nb][k][da]  ->  device [nb][da][Kp] (zero padded).
 // Tiled through LDS so that both the read (along j) and the write (along s) are coalesced.
-__global__ void k_fm_to_device(const double* __restrict__ src, double* __restrict__ dst, int k, int Kp, int64_t da) {
+__global__ void k_fm_to_device(const double* __restrict__ src, double* __restrict__ dst, int k, int Kp, int64_t da, int64_t bs, int64_t rs,
+                               int b0) {
   __shared__ double tile[32][33];
   const int o = blockIdx.z;
   const int64_t j0 = (int64_t)blockIdx.x * 32;
@@ -219,19 +220,21 @@ __global__ void k_fm_to_device(const double* __restrict__ src, double* __restric
   for (int r = ty; r < 32; r += 8) {
     const int64_t j = j0 + r;
     const int s = s0 + tx;
-    if (j < da && s < Kp) dst[((size_t)o * da + j) * Kp + s] = tile[tx][r];
+    if (j < da && s < Kp) dst[((size_t)(b0 + o) * bs + (size_t)j * rs) * Kp + s] = tile[tx][r];  // ModelView::row
   }
 }
-int launch_fm_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int nb, int k, int Kp, int64_t da) {
+int launch_fm_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int nb, int k, int Kp, int64_t da, int64_t bs, int64_t rs,
+                        int b0) {
   if (nb == 0 || da == 0) return NFM_OK;
+  if (bs == 0) { bs = da; rs = 1; }  // order-major
   dim3 grid((unsigned)((da + 31) / 32), (unsigned)((Kp + 31) / 32), (unsigned)nb);
-  hipLaunchKernelGGL(k_fm_to_device, grid, dim3(kBlock), 0, ctx->stream, src_ref, dst_dev, k, Kp, da);
+  hipLaunchKernelGGL(k_fm_to_device, grid, dim3(kBlock), 0, ctx->stream, src_ref, dst_dev, k, Kp, da, bs, rs, b0);
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }
 
 __global__ void k_fm_from_device(const double* __restrict__ src, double* __restrict__ dst, int k, int Kp, int64_t da,
-                                 const double* __restrict__ scale) {
+                                 const double* __restrict__ scale, int64_t bs, int64_t rs, int b0) {
   __shared__ double tile[32][33];
   const double sc = scale ? *scale : 1.0;
   const int o = blockIdx.z;
@@ -241,7 +244,7 @@ __global__ void k_fm_from_device(const double* __restrict__ src, double* __restr
   for (int r = ty; r < 32; r += 8) {
     const int64_t j = j0 + r;
     const int s = s0 + tx;
-    tile[r][tx] = (j < da && s < Kp) ? src[((size_t)o * da + j) * Kp + s] * sc : 0.0;
+    tile[r][tx] = (j < da && s < Kp) ? src[((size_t)(b0 + o) * bs + (size_t)j * rs) * Kp + s] * sc : 0.0;
   }
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
@@ -251,10 +254,11 @@ __global__ void k_fm_from_device(const double* __restrict__ src, double* __restr
   }
 }
 int launch_fm_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int nb, int k, int Kp, int64_t da,
-                          const double* scale_dev) {
+                          const double* scale_dev, int64_t bs, int64_t rs, int b0) {
   if (nb == 0 || da == 0) return NFM_OK;
+  if (bs == 0) { bs = da; rs = 1; }  // order-major
   dim3 grid((unsigned)((da + 31) / 32), (unsigned)((Kp + 31) / 32), (unsigned)nb);
-  hipLaunchKernelGGL(k_fm_from_device, grid, dim3(kBlock), 0, ctx->stream, src_dev, dst_ref, k, Kp, da, scale_dev);
+  hipLaunchKernelGGL(k_fm_from_device, grid, dim3(kBlock), 0, ctx->stream, src_dev, dst_ref, k, Kp, da, scale_dev, bs, rs, b0);
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }
@@ -299,41 +303,41 @@ int launch_rows_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref
 // FMs with more than 128 factors (ModelView::kc): reference [no * da][k] <-> device [no * kc][da][Kp]; device block
 // o * kc + c holds the factors c * kb ... c * kb + kb - 1 of order o
 __global__ void k_rows_split_to_device(const double* __restrict__ src, double* __restrict__ dst, int64_t no, int64_t da, int k, int kc,
-                                       int kb, int Kp, double pad) {
+                                       int kb, int Kp, double pad, int64_t bs, int64_t rs) {
   const int64_t total = no * kc * da * Kp;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int sl = (int)(e % Kp);
-    const int64_t r = e / Kp;  // device row (o * kc + c) * da + j
+    const int64_t r = e / Kp;  // (block b = o * kc + c, feature j), enumerated block-major
     const int64_t j = r % da, b = r / da;
     const int64_t o = b / kc;
     const int s = (int)(b % kc) * kb + sl;
-    dst[e] = (sl < kb && s < k) ? src[(o * da + j) * k + s] : pad;
+    dst[(b * bs + j * rs) * Kp + sl] = (sl < kb && s < k) ? src[(o * da + j) * k + s] : pad;  // ModelView::row
   }
 }
 int launch_rows_split_to_device(nfm_ctx* ctx, const double* src_ref, double* dst_dev, int64_t no, int64_t da, int k, int kc, int kb, int Kp,
-                                double pad) {
+                                double pad, int64_t bs, int64_t rs) {
   if (no == 0 || da == 0) return NFM_OK;
   hipLaunchKernelGGL(k_rows_split_to_device, dim3(grid_for(no * kc * da * Kp)), dim3(kBlock), 0, ctx->stream, src_ref, dst_dev, no, da, k, kc,
-                     kb, Kp, pad);
+                     kb, Kp, pad, bs, rs);
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }
 __global__ void k_rows_split_from_device(const double* __restrict__ src, double* __restrict__ dst, int64_t no, int64_t da, int k, int kc,
-                                         int kb, int Kp, const double* __restrict__ scale) {
+                                         int kb, int Kp, const double* __restrict__ scale, int64_t bs, int64_t rs) {
   const double sc = scale ? *scale : 1.0;
   const int64_t total = no * da * k;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int s = (int)(e % k);
     const int64_t r = e / k;  // reference row o * da + j
     const int64_t j = r % da, o = r / da;
-    dst[e] = src[((o * kc + s / kb) * da + j) * Kp + s % kb] * sc;
+    dst[e] = src[((o * kc + s / kb) * bs + j * rs) * Kp + s % kb] * sc;
   }
 }
 int launch_rows_split_from_device(nfm_ctx* ctx, const double* src_dev, double* dst_ref, int64_t no, int64_t da, int k, int kc, int kb, int Kp,
-                                  const double* scale_dev) {
+                                  const double* scale_dev, int64_t bs, int64_t rs) {
   if (no == 0 || da == 0) return NFM_OK;
   hipLaunchKernelGGL(k_rows_split_from_device, dim3(grid_for(no * da * k)), dim3(kBlock), 0, ctx->stream, src_dev, dst_ref, no, da, k, kc, kb,
-                     Kp, scale_dev);
+                     Kp, scale_dev, bs, rs);
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
 }

@@ -671,13 +671,17 @@ def test_abort_paths_in_the_test_hooks_build():
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("kind,k,m", [("sgd", 100, 40), ("sgd", 128, 64), ("sgd", 65, 9), ("adagrad", 100, 20), ("adagrad", 128, 30)])
+@pytest.mark.parametrize("kind,k,m", [("sgd", 100, 40), ("sgd", 128, 64), ("sgd", 65, 9), ("adagrad", 100, 20), ("adagrad", 128, 30),
+                                      ("sgd", 200, 24), ("sgd", 300, 10), ("adagrad", 160, 12)])
 def test_65_to_128_factors_read_as_two_blocks_of_64(kind, k, m, window_flavour):
     """A degree-2 FM of 65 ... 128 factors is one block of 128-double rows: the window's workers take rows of at most 64
     factors, so before round 5 such a model ran its exact order one sample at a time.  The same table read as feature-major
     blocks of 64 (ModelView::row with bs = 1, rs = 2, seqwin.hip::seq_window_view) is a two-block model of the same degree,
     which the several-orders worker takes as it is -- in the one-term window (the exact flavour keeps the one-workgroup kernel:
-    its factor sum is one ascending pass).  Held to the one-workgroup kernel and to the oracle; which kernel ran is asked."""
+    its factor sum is one ascending pass).  Held to the one-workgroup kernel and to the oracle; which kernel ran is asked.
+    More than 128 factors (one order): the kc blocks of 128 lie feature-major (api.hip: wide_rows), a feature's row is kc * 128
+    contiguous doubles -- 2 kc blocks of 64 to the window as long as the worker's LDS holds the sample's rows, ONE row to the
+    one-sample-in-flight kernel."""
     n, d = 2500, 700
     Xo = random_csr(n, d, m, seed=k)
     rng = np.random.default_rng(k + 1)
