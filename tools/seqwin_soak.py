@@ -14,7 +14,10 @@ ctx = nf.default_context()
 bad = 0
 FI = os.environ.get("SOAK_NO_INTERCEPT") != "1"
 for name in names:
-    wl = dict(bench.WORKLOADS[name])
+    if name in ("k128", "k200"):  # round 5: 65 ... 128 factors / a wide model of one order, read as blocks of 64 by the window
+        wl = dict(n=n, d=1_000_000, m=32 if name == "k128" else 24, k=128 if name == "k128" else 200, degree=2, solver="sgd", loss="squared", batch=8192)
+    else:
+        wl = dict(bench.WORKLOADS[name])
     wl["d"] = max(2000, wl["d"] // 20)  # twenty times the benchmark's conflict rate
     X, *_keep = bench.make_dataset(torch, nf, ctx, dev, wl, n, 0)
     y = np.random.default_rng(0).standard_normal(n)
@@ -48,6 +51,13 @@ for name in names:
         one_term = FI and os.environ.get("NFM_SEQ_WIN_EXACT") != "1"
         def close(x, y_):
             return bool(np.all(np.abs(np.asarray(x) - np.asarray(y_)) <= 1e-11 + 1e-8 * np.abs(np.asarray(y_))))
+        if name in ("k128", "k200") and os.environ.get("NFM_SEQ_WIN_EXACT") != "1":
+            # the factors summed block by block: SGD at the oracle comparisons' tolerance, AdaGrad (whose 1 / sqrt(g_norm) amplifies
+            # the few-ulp differences) at the reference's own fast-against-slow tolerance (tests/utils.nim:82-105)
+            rt, at = (1e-8, 1e-11) if solver == "sgd" else (1e-6, 1e-9)
+            def close(x, y_):  # noqa: F811
+                return bool(np.all(np.abs(np.asarray(x) - np.asarray(y_)) <= at + rt * np.abs(np.asarray(y_))))
+            one_term = True
         ok = (close(b[0], a[0]) and close(b[1], a[1]) and close(b[2], a[2])) if one_term else same
         rel = float(np.max(np.abs(b[0] - a[0]) / (np.abs(a[0]) + 1e-12 * np.max(np.abs(a[0]))))) if finite else float("nan")
         bad += 0 if (ok and finite) else 1
