@@ -1109,6 +1109,12 @@ def contract_line(full):
                           "bit_equal": x_.get("bit_equal"), "no_intercept": (x_.get("no_intercept") or {}).get("value"),
                           "no_intercept_vs_cpu_port_1_thread": (x_.get("no_intercept") or {}).get("vs_cpu_port_1_thread")} if x_ else None
     out["time_to_target"] = _t2t_compact(full.get("time_to_target"))
+    if out["time_to_target"] and x_ and x_.get("vs_cpu_port_1_thread"):
+        # the speed-ups are against the GPU's OWN exact order; against the one-thread CPU port in that order (which reaches the same
+        # losses: it computes the same parameters) they are that many times exact_order.vs_cpu_port_1_thread
+        out["time_to_target"]["speedup_is_vs"] = "gpu exact order"
+        out["time_to_target"]["vs_cpu_port_1_thread"] = [round(t_["speedup"] * x_["vs_cpu_port_1_thread"], 0) if t_.get("speedup") else None
+                                                         for t_ in out["time_to_target"]["targets"]]
     d_ = full.get("dp")
     out["dp"] = {k_: d_[k_] for k_ in ("combine", "sync_period", "world", "collectives_per_step", "bytes_per_step_per_rank",
                                          "progress_per_epoch") if k_ in d_} if d_ else None
