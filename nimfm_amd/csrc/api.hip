@@ -1240,8 +1240,9 @@ static int32_t opt_epoch_range(nfm_opt* o, nfm_dataset* ds, const int64_t* perm,
           if (!o->plan) o->plan.reset(new Plan());
           TimedLaunch tl(ctx, "plan_build");
           NFM_TRY(gen_permutation(ctx, st, o->shuffle_seed, o->shuffle_epoch, begin, ns, &o->perm_gen));
+          const FeistelKey fk = feistel_key(o->shuffle_seed, o->shuffle_epoch, begin, ns);  // (the order as a function: plan.h)
           NFM_TRY(plan_build(ctx, ds->v, m->n_aug, nullptr, begin, end, o->batch, first_singleton, want_tq, use_singles, sort_by_count,
-                             o->plan.get(), st, o->perm_gen.as<int64_t>(), &ds->csc));
+                             o->plan.get(), st, o->perm_gen.as<int64_t>(), &ds->csc, &fk));
           o->plan->ds_uid = ds->uid;
           o->plan->ds_nnz = ds->v.nnz;
         }
@@ -1330,9 +1331,10 @@ static int32_t opt_epoch_range(nfm_opt* o, nfm_dataset* ds, const int64_t* perm,
             }
           } else {
             rc_next = gen_permutation(ctx, o->plan_stream, o->shuffle_seed, o->shuffle_epoch + 1, begin, ns, &o->perm_next);
+            const FeistelKey fk = feistel_key(o->shuffle_seed, o->shuffle_epoch + 1, begin, ns);
             if (rc_next == NFM_OK)
               rc_next = plan_build(ctx, ds->v, m->n_aug, nullptr, begin, end, o->batch, /*first_singleton=*/false, want_tq, use_singles,
-                                   sort_by_count, o->next_plan.get(), o->plan_stream, o->perm_next.as<int64_t>(), &ds->csc);
+                                   sort_by_count, o->next_plan.get(), o->plan_stream, o->perm_next.as<int64_t>(), &ds->csc, &fk);
             if (rc_next == NFM_OK) o->next_plan_perm = nullptr;
           }
           if (rc_next == NFM_OK) {

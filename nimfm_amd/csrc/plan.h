@@ -75,11 +75,25 @@ constexpr int kHeavySegment = 64;
 // derivative and the row's parameters are stepped twice with it): nfm_opt_epoch refuses such a dataset.
 int check_rows_distinct(nfm_ctx* ctx, const CsrView& X, int64_t* n_repeats, int64_t* first_row);
 
+// The device-drawn order (gen_permutation) is a keyed bijection evaluated per position -- and so is its INVERSE: the column
+// path of plan_build asks "at which position does sample i stand" once per touch, and computes the answer from the key
+// instead of gathering it from a table of the inverse permutation (one 64-byte sector per touch: 640 M of them per epoch of
+// the headline).
+constexpr int kFeistelRounds = 8;
+struct FeistelKey {
+  uint32_t k[kFeistelRounds];
+  uint32_t mask;
+  int h;
+  int64_t ns, begin;  // the order: positions 0 .. ns-1 -> samples begin .. begin+ns-1
+};
+FeistelKey feistel_key(int64_t seed, uint64_t epoch, int64_t begin, int64_t ns);
+
 // stream: where the build is enqueued and synchronised (default: the context's); perm_dev: the end - begin sample ids of
-// the epoch already on the device (instead of perm_host)
+// the epoch already on the device (instead of perm_host); perm_key: perm_dev is gen_permutation's order of this key
 int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end,
                int64_t batch, bool first_singleton, bool want_tq, bool use_singles, bool sort_by_count, Plan* out,
-               hipStream_t stream = nullptr, const int64_t* perm_dev = nullptr, CscIndex* csc = nullptr);
+               hipStream_t stream = nullptr, const int64_t* perm_dev = nullptr, CscIndex* csc = nullptr,
+               const FeistelKey* perm_key = nullptr);
 
 // a random order of the samples begin .. begin+ns-1 drawn on the device from (seed, epoch): int64[ns] in *out
 int gen_permutation(nfm_ctx* ctx, hipStream_t st, int64_t seed, uint64_t epoch, int64_t begin, int64_t ns, DevBuf* out);

@@ -381,6 +381,49 @@ __global__ void k_ipos(int64_t ns, const int64_t* __restrict__ perm, int64_t beg
   }
 }
 
+// ---- the device-drawn order as a function (plan.h: FeistelKey) ----
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  return x ^ (x >> 16);
+}
+__device__ __forceinline__ uint64_t feistel(uint64_t x, const FeistelKey& K) {
+  uint32_t L = (uint32_t)(x >> K.h) & K.mask, R = (uint32_t)x & K.mask;
+#pragma unroll
+  for (int r = 0; r < kFeistelRounds; ++r) {
+    const uint32_t t = L ^ (mix32(R ^ K.k[r]) & K.mask);
+    L = R;
+    R = t;
+  }
+  return ((uint64_t)L << K.h) | R;
+}
+// the inverse: the rounds run backwards (L' = R, R' = L ^ f(R): R = L', L = R' ^ f(L'))
+__device__ __forceinline__ uint64_t feistel_inv(uint64_t x, const FeistelKey& K) {
+  uint32_t L = (uint32_t)(x >> K.h) & K.mask, R = (uint32_t)x & K.mask;
+#pragma unroll
+  for (int r = kFeistelRounds - 1; r >= 0; --r) {
+    const uint32_t t = R ^ (mix32(L ^ K.k[r]) & K.mask);
+    R = L;
+    L = t;
+  }
+  return ((uint64_t)L << K.h) | R;
+}
+// position of sample i in the order of key K (-1: the sample is not in the order's range): the cycle of the restricted
+// bijection is walked backwards
+__device__ __forceinline__ int32_t feistel_position(int64_t i, const FeistelKey& K) {
+  if (i < K.begin || i >= K.begin + K.ns) return -1;
+  uint64_t x = (uint64_t)(i - K.begin);
+  do x = feistel_inv(x, K); while (x >= (uint64_t)K.ns);
+  return (int32_t)x;
+}
+
 // 32-bit forms for the column path (positions and batch sizes below 2^31 there): a 64-bit divide is ~100 instructions
 __device__ __forceinline__ int batch_of32(int32_t rel, uint32_t batch, int first_singleton) {
   if (first_singleton) return rel == 0 ? 0 : 1 + (int)((uint32_t)(rel - 1) / batch);
@@ -391,9 +434,10 @@ __device__ __forceinline__ int batch_of32(int32_t rel, uint32_t batch, int first
 // requested in one go (kCscMaxCol / 64 predicated loads per lane), then the positions of those rows; the counts of the
 // group leave as runs of kCntGroup consecutive ints per batch.
 constexpr int kCntGroup = 4;
+template <bool FEISTEL>  // the positions computed from the order's key instead of gathered from the inverse permutation
 __global__ __launch_bounds__(kBlock) void k_csc_count(int64_t d, const int64_t* __restrict__ cptr, const int32_t* __restrict__ crow,
                                                       const int32_t* __restrict__ ipos, int64_t batch, int first_singleton,
-                                                      int n_batches, int32_t* __restrict__ cnt, int32_t* __restrict__ rpos) {
+                                                      int n_batches, int32_t* __restrict__ cnt, int32_t* __restrict__ rpos, FeistelKey K) {
   extern __shared__ int s_hist[];  // [kWavesPerBlock][kCntGroup][n_batches]
   constexpr int NE = kCscMaxCol / kWave;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
@@ -417,7 +461,8 @@ __global__ __launch_bounds__(kBlock) void k_csc_count(int64_t d, const int64_t* 
       for (int u = 0; u < NE; ++u) {
         const int q = u * kWave + lane;
         if (q < n_c) {
-          const int32_t r = ipos[row[u]];  // a random 4-byte gather per touch: kept in column order for k_csc_fill
+          // (table: a random 4-byte gather per touch); kept in column order for k_csc_fill
+          const int32_t r = FEISTEL ? feistel_position(row[u], K) : ipos[row[u]];
           rpos[e0 + q] = r;
           if (r >= 0) atomicAdd(&hist[f * n_batches + batch_of32(r, batch32, first_singleton)], 1);
         }
@@ -974,7 +1019,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_fill(SegFmt fmt, CsrView X, int 
 template <class KeyT>
 static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_aug, const int64_t* perm_host, const int64_t* perm_given_dev,
                         int64_t begin, int64_t end, int64_t batch, bool first_singleton, bool want_tq, bool use_singles,
-                        bool sort_by_count, Plan* out, CscIndex* csc) {
+                        bool sort_by_count, Plan* out, CscIndex* csc, const FeistelKey* perm_key) {
   static std::atomic<uint64_t> g_serial{0};  // ranks of one process build plans concurrently (dp.h)
   Plan& P = *out;
   P.release();
@@ -1055,12 +1100,16 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
     const int64_t cells = P.n_batches * X.d;
     DevBuf ipos, clash, cnt, ps, rpos;
     NFM_TRY(rpos.alloc(sizeof(int32_t) * X.nnz));
-    NFM_TRY(ipos.alloc(sizeof(int32_t) * X.n));
     NFM_TRY(clash.alloc(sizeof(unsigned long long)));
-    NFM_HIP_CHECK(hipMemsetAsync(ipos.p, 0xFF, sizeof(int32_t) * X.n, st));  // -1: not in this epoch's range
     NFM_HIP_CHECK(hipMemsetAsync(clash.p, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_ipos, dim3(grid1d(ns)), dim3(kBlock), 0, st, ns, perm_dev, begin, ipos.as<int32_t>(),
-                       clash.as<unsigned long long>());
+    static const bool key_on = !(getenv("NFM_PLAN_KEY") && atoi(getenv("NFM_PLAN_KEY")) == 0);  // 0: the table, also for device-drawn orders
+    const bool by_key = key_on && perm_key != nullptr && perm_key->ns == ns && perm_key->begin == begin;
+    if (!by_key) {
+      NFM_TRY(ipos.alloc(sizeof(int32_t) * X.n));
+      NFM_HIP_CHECK(hipMemsetAsync(ipos.p, 0xFF, sizeof(int32_t) * X.n, st));  // -1: not in this epoch's range
+      hipLaunchKernelGGL(k_ipos, dim3(grid1d(ns)), dim3(kBlock), 0, st, ns, perm_dev, begin, ipos.as<int32_t>(),
+                         clash.as<unsigned long long>());
+    }
     NFM_TRY(cnt.alloc(sizeof(int32_t) * (cells + 1)));
     NFM_TRY(ps.alloc(sizeof(uint64_t) * (cells + 1)));
     NFM_HIP_CHECK(hipMemsetAsync(cnt.as<int32_t>() + cells, 0, sizeof(int32_t), st));
@@ -1068,9 +1117,13 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
       const int64_t groups = (X.d + kCntGroup - 1) / kCntGroup;
       int64_t blocks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
       if (blocks > 256 * 16) blocks = 256 * 16;
-      hipLaunchKernelGGL(k_csc_count, dim3((unsigned)blocks), dim3(kBlock), sizeof(int) * kWavesPerBlock * kCntGroup * (size_t)P.n_batches, st, X.d,
-                         csc->cptr.as<int64_t>(), csc->crow.as<int32_t>(), ipos.as<int32_t>(), batch, first_singleton ? 1 : 0,
-                         (int)P.n_batches, cnt.as<int32_t>(), rpos.as<int32_t>());
+      const size_t lds_ = sizeof(int) * kWavesPerBlock * kCntGroup * (size_t)P.n_batches;
+      if (by_key)
+        hipLaunchKernelGGL(k_csc_count<true>, dim3((unsigned)blocks), dim3(kBlock), lds_, st, X.d, csc->cptr.as<int64_t>(), csc->crow.as<int32_t>(),
+                           nullptr, batch, first_singleton ? 1 : 0, (int)P.n_batches, cnt.as<int32_t>(), rpos.as<int32_t>(), *perm_key);
+      else
+        hipLaunchKernelGGL(k_csc_count<false>, dim3((unsigned)blocks), dim3(kBlock), lds_, st, X.d, csc->cptr.as<int64_t>(), csc->crow.as<int32_t>(),
+                           ipos.as<int32_t>(), batch, first_singleton ? 1 : 0, (int)P.n_batches, cnt.as<int32_t>(), rpos.as<int32_t>(), FeistelKey{});
     }
     NFM_HIP_CHECK(hipGetLastError());
     hipcub::TransformInputIterator<uint64_t, CellPack, const int32_t*> packed(cnt.as<int32_t>(), CellPack());
@@ -1431,34 +1484,6 @@ static int plan_build_t(nfm_ctx* ctx, hipStream_t st, const CsrView& X, int n_au
 // value falls below ns ("cycle walking": a bijection of [0, 2^(2h)) restricted that way is a bijection of [0, ns)).
 // No sort, no key collisions, reproducible from (seed, epoch), no host work and no upload; a radix sort of hashed
 // 64-bit keys, which this replaces, cost a tenth of a cfg2 epoch.
-constexpr int kFeistelRounds = 8;
-struct FeistelKey {
-  uint32_t k[kFeistelRounds];
-  uint32_t mask;
-  int h;
-};
-__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-  x ^= x >> 16;
-  x *= 0x7FEB352Du;
-  x ^= x >> 15;
-  x *= 0x846CA68Bu;
-  return x ^ (x >> 16);
-}
-__device__ __forceinline__ uint64_t feistel(uint64_t x, const FeistelKey& K) {
-  uint32_t L = (uint32_t)(x >> K.h) & K.mask, R = (uint32_t)x & K.mask;
-#pragma unroll
-  for (int r = 0; r < kFeistelRounds; ++r) {
-    const uint32_t t = L ^ (mix32(R ^ K.k[r]) & K.mask);
-    L = R;
-    R = t;
-  }
-  return ((uint64_t)L << K.h) | R;
-}
 __global__ void k_perm_feistel(int64_t ns, int64_t begin, FeistelKey K, int64_t* __restrict__ perm) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (int64_t)gridDim.x * blockDim.x) {
     uint64_t x = (uint64_t)i;
@@ -1466,17 +1491,23 @@ __global__ void k_perm_feistel(int64_t ns, int64_t begin, FeistelKey K, int64_t*
     perm[i] = begin + (int64_t)x;
   }
 }
-int gen_permutation(nfm_ctx* ctx, hipStream_t st, int64_t seed, uint64_t epoch, int64_t begin, int64_t ns, DevBuf* out) {
-  NFM_CHECK(ns < (int64_t)2147483647, NFM_ERR_UNSUPPORTED, "more than 2^31-1 samples in one shuffled epoch");
-  NFM_TRY(out->ensure(sizeof(int64_t) * (size_t)std::max<int64_t>(ns, 1)));
-  if (ns == 0) return NFM_OK;
-  FeistelKey K;
+FeistelKey feistel_key(int64_t seed, uint64_t epoch, int64_t begin, int64_t ns) {
+  FeistelKey K{};
   int bits = 1;
   while (((int64_t)1 << bits) < ns) ++bits;
   K.h = (bits + 1) / 2;
   K.mask = (uint32_t)(((uint64_t)1 << K.h) - 1);
   const uint64_t base = mix64((uint64_t)seed * 0x9E3779B97F4A7C15ull + epoch + 0x632BE59BD9B4E019ull);
   for (int r = 0; r < kFeistelRounds; ++r) K.k[r] = (uint32_t)(mix64(base ^ ((uint64_t)(r + 1) * 0xD1342543DE82EF95ull)) >> 32);
+  K.ns = ns;
+  K.begin = begin;
+  return K;
+}
+int gen_permutation(nfm_ctx* ctx, hipStream_t st, int64_t seed, uint64_t epoch, int64_t begin, int64_t ns, DevBuf* out) {
+  NFM_CHECK(ns < (int64_t)2147483647, NFM_ERR_UNSUPPORTED, "more than 2^31-1 samples in one shuffled epoch");
+  NFM_TRY(out->ensure(sizeof(int64_t) * (size_t)std::max<int64_t>(ns, 1)));
+  if (ns == 0) return NFM_OK;
+  const FeistelKey K = feistel_key(seed, epoch, begin, ns);
   hipLaunchKernelGGL(k_perm_feistel, dim3(grid1d(ns)), dim3(kBlock), 0, st, ns, begin, K, out->as<int64_t>());
   NFM_HIP_CHECK(hipGetLastError());
   return NFM_OK;
@@ -1484,7 +1515,7 @@ int gen_permutation(nfm_ctx* ctx, hipStream_t st, int64_t seed, uint64_t epoch, 
 
 int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_host, int64_t begin, int64_t end, int64_t batch,
                bool first_singleton, bool want_tq, bool use_singles, bool sort_by_count, Plan* out, hipStream_t stream,
-               const int64_t* perm_dev, CscIndex* csc) {
+               const int64_t* perm_dev, CscIndex* csc, const FeistelKey* perm_key) {
   hipStream_t st = stream ? stream : ctx->stream;
   // (batch, feature) keys of at most 32 bits -- cfg2: 5 + 17, the headline shape: 11 + 20 -- sort as uint32: a third less
   // traffic in every pass of the radix sort and in the passes that read the sorted keys
@@ -1494,9 +1525,9 @@ int plan_build(nfm_ctx* ctx, const CsrView& X, int n_aug, const int64_t* perm_ho
   while (((int64_t)1 << bbits) < nb) ++bbits;
   if (fbits + bbits <= 32)
     return plan_build_t<uint32_t>(ctx, st, X, n_aug, perm_host, perm_dev, begin, end, batch, first_singleton, want_tq, use_singles,
-                                  sort_by_count, out, csc);
+                                  sort_by_count, out, csc, perm_key);
   return plan_build_t<uint64_t>(ctx, st, X, n_aug, perm_host, perm_dev, begin, end, batch, first_singleton, want_tq, use_singles,
-                                sort_by_count, out, csc);
+                                sort_by_count, out, csc, perm_key);
 }
 
 }  // namespace nfm
