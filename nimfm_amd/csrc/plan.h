@@ -79,7 +79,7 @@ int check_rows_distinct(nfm_ctx* ctx, const CsrView& X, int64_t* n_repeats, int6
 // path of plan_build asks "at which position does sample i stand" once per touch, and computes the answer from the key
 // instead of gathering it from a table of the inverse permutation (one 64-byte sector per touch: 640 M of them per epoch of
 // the headline).
-constexpr int kFeistelRounds = 8;
+constexpr int kFeistelRounds = 4;  // (a round is a full-avalanche 32-bit mix; eight rounds cost the column path 2.6 ms per headline epoch more)
 struct FeistelKey {
   uint32_t k[kFeistelRounds];
   uint32_t mask;
