@@ -673,9 +673,10 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     dp_stats = None
     if use_dp:  # what the exchange moved during the timed steps (nfm_dp_info: this rank's collectives and bytes)
         i1 = run_training.group.info()
-        comb = args.combine if args.combine != "auto" else ("mean" if wl["solver"] == "sgd" else ("sum" if sync_period == 1 else "state_mean"))
+        comb = args.combine if args.combine != "auto" else ("mean" if wl["solver"] == "sgd" else ("sum" if sync_period == 1 else "state_cross"))
         dp_stats = {"combine": comb if wl["solver"] == "sgd" else {"sum": "state increments summed", "mean": "state increments summed",
-                                                                    "state_mean": "state increments averaged"}[comb],
+                                                                    "state_mean": "state increments averaged",
+                                                                    "state_cross": "g_sum increments summed, g_norm + the ranks' agreement (NFM_DP_STATE_CROSS)"}[comb],
                     "sync_period": sync_period, "world": i1["world"],
                     "collectives_per_step": (i1["collectives"] - dp_info0["collectives"]) / steps,
                     "bytes_per_step_per_rank": (i1["bytes"] - dp_info0["bytes"]) / steps,
@@ -683,10 +684,12 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                             "delayed by one period, plus the exact closing exchange of every epoch call"}
         # what N ranks' epoch is worth against ONE rank's epoch over all samples (1.0: throughput IS speed-up), measured with
         # local groups on one GPU on a planted FM (tools/dp_convergence.py); quoted, not measured in this run
-        prog = {"mean": {2: 1.15, 4: 1.20, 8: 1.12}, "state_mean": {2: 1.03, 4: 0.93, 8: 0.75}, "sum": {2: 0.96, 4: 0.98, 8: 1.01}}
+        prog = {"mean": {2: 1.15, 4: 1.20, 8: 1.12}, "state_mean": {2: 1.03, 4: 0.93, 8: 0.75}, "sum": {2: 0.96, 4: 0.98, 8: 1.01},
+                "state_cross": {2: 1.00, 4: 1.02, 8: 1.01}}
         if i1["world"] in (2, 4, 8) and comb in prog and (wl["solver"] == "adagrad" or comb == "mean"):
             dp_stats["progress_per_epoch"] = prog[comb][i1["world"]]
-            dp_stats["progress_source"] = "profiles/r03_dp_convergence.txt (planted FM, local groups of this size on one GPU; not this run)"
+            dp_stats["progress_source"] = ("profiles/r05g_dp_convergence.txt" if comb == "state_cross" else "profiles/r03_dp_convergence.txt") + \
+                                          " (planted FM, local groups of this size on one GPU; not this run)"
 
     # ---- the reference's default shuffle = true (optimizer/sgd.nim:297): every epoch gets a FRESH permutation, so the
     # batch plan is rebuilt for every epoch inside the timed region.
@@ -1023,7 +1026,9 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                        "parallelism": ("%d ranks, one process per GPU, contiguous sample shards; replicas %s in the library over "
                                        "RCCL every %s on a second stream + exactly at the end of every epoch"
                                        % (world, ("increments %s" % ("summed" if args.combine == "sum" else "averaged")) if wl["solver"] == "sgd"
-                                          else ("state increments %s" % ("averaged" if args.combine in ("auto", "state_mean") and sync_period != 1 else "summed")),
+                                          else ("state increments %s" % ("averaged" if args.combine == "state_mean" and sync_period != 1 else
+                                                                         "summed, the squared norm taking the ranks' agreement" if args.combine in ("auto", "state_cross") and sync_period != 1
+                                                                         else "summed")),
                                           ("%d mini-batches" % sync_period) if sync_period else "epoch (no mid-epoch exchange)"))
                        if use_dp else "1 GPU"},
             "last_step": {"mean_loss": last[0] / (n * world), "viol": last[1]}, "predict": pred, "exact_order": exact,
@@ -1170,7 +1175,7 @@ def main():
     ap.add_argument("--sync-period", type=int, default=-1,
                     help="N > 1: mini-batches between exchanges (0 = only at the end of every epoch; default: about every 1e6 samples "
                          "per rank -- 128 mini-batches of 8192, 8 of 131072 -- for epochs of at least four such stretches, else 0)")
-    ap.add_argument("--combine", default="auto", choices=["auto", "mean", "sum", "state_mean"],
+    ap.add_argument("--combine", default="auto", choices=["auto", "mean", "sum", "state_mean", "state_cross"],
                     help="N > 1: how the ranks' increments are combined at an exchange (DESIGN.md section 6); auto = SGD: the mean, "
                          "AdaGrad: the state increments averaged (summed when the ranks exchange after every mini-batch)")
     ap.add_argument("--touch-cap", type=float, default=16.0,

@@ -375,9 +375,15 @@ int32_t nfm_opt_set_dp(nfm_opt* o, nfm_dp* dp, int64_t sync_period, int32_t over
  * exchanges left the held-out RMSE at 2.9 where one rank reaches 1.04, tools/dp_convergence.py); NFM_DP_STATE_MEAN averages
  * the ranks' state increments instead -- the replicas' mean, as stable as one rank at any period.
  * NFM_DP_AUTO (the default of every optimizer, so a host that only calls nfm_opt_set_dp gets it): SGD -- the mean;
- * AdaGrad -- the sum when sync_period == 1, the averaged state increments otherwise (sync_period 0 included).
+ * AdaGrad -- the sum when sync_period == 1, NFM_DP_STATE_CROSS otherwise (sync_period 0 included; rounds 3-4: the averaged state).
  * NFM_DP_STATE_RSQRT: the ranks' increments weighted by 1 / sqrt(world) -- between the sum (weight 1) and the mean (1 / world). */
-enum { NFM_DP_AUTO = -1, NFM_DP_MEAN = 0, NFM_DP_SUM = 1, NFM_DP_STATE_MEAN = 2, NFM_DP_STATE_RSQRT = 3 };
+/* NFM_DP_STATE_CROSS (AdaGrad, round 5): g_sum increments summed; g_norm += sum_r dN_r + gamma ((sum_r dG_r)^2 - sum_r dG_r^2),
+ * gamma = 0.1, never less than before -- the cross products of the ranks' increments inflate the norm where the ranks pushed the
+ * same way from the same stale point (there the plain sum over-shoots) and vanish where they saw different things.  One
+ * all-reduce of the same size (a rank sends dN_r - gamma dG_r^2 for dN_r).  Keeps one rank's progress per epoch at 2 / 4 / 8
+ * ranks for every period, a whole epoch included (profiles/r05g_dp_convergence.txt); NFM_DP_AUTO picks it for AdaGrad beyond
+ * one mini-batch per exchange. */
+enum { NFM_DP_AUTO = -1, NFM_DP_MEAN = 0, NFM_DP_SUM = 1, NFM_DP_STATE_MEAN = 2, NFM_DP_STATE_RSQRT = 3, NFM_DP_STATE_CROSS = 4 };
 int32_t nfm_opt_set_dp_combine(nfm_opt* o, int32_t combine);
 
 /* SGD, NFM_MODE_MINIBATCH: how a mini-batch combines the per-sample steps (optimizer/sgd.nim:205-243) of the `c` samples

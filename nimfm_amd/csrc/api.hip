@@ -1046,8 +1046,11 @@ static int dp_epoch_setup(nfm_opt* o, nfm_model* m, const ModelView& M, DpEpoch*
   // SGD: the ranks' increments averaged unless NFM_DP_SUM; AdaGrad: its state increments summed unless NFM_DP_STATE_MEAN
   // (NFM_DP_AUTO, the default no host has to know about: what DESIGN.md section 6 measured as stable at every period --
   // AdaGrad's SUMMED state over-shoots as soon as the ranks run more than one mini-batch between exchanges)
-  const bool averaged = o->kind == OPT_SGD ? o->dp_combine != NFM_DP_SUM
-                                           : (o->dp_combine == NFM_DP_STATE_MEAN || (o->dp_combine == NFM_DP_AUTO && o->dp_sync_period != 1));
+  // AdaGrad, NFM_DP_AUTO (round 5): the summed state when the ranks exchange after every mini-batch (synchronous data-parallel
+  // AdaGrad), NFM_DP_STATE_CROSS otherwise -- one rank's progress per epoch at 2 / 4 / 8 ranks for every period, where the averaged
+  // state keeps 0.75 of it at 8 ranks and the plain sum diverges (profiles/r05g_dp_convergence.txt)
+  const int ada_rule = (o->kind == OPT_ADAGRAD && o->dp_combine == NFM_DP_AUTO) ? (o->dp_sync_period == 1 ? NFM_DP_SUM : NFM_DP_STATE_CROSS) : o->dp_combine;
+  const bool averaged = o->kind == OPT_SGD ? o->dp_combine != NFM_DP_SUM : ada_rule == NFM_DP_STATE_MEAN;
   de.combine_w = averaged ? 1.0 / (double)o->dp->t->world : 1.0;
   if (o->kind == OPT_ADAGRAD && o->dp_combine == NFM_DP_STATE_RSQRT) de.combine_w = 1.0 / sqrt((double)o->dp->t->world);  // (SGD: the mean)
   if (o->kind == OPT_SGD) {
@@ -1060,6 +1063,16 @@ static int dp_epoch_setup(nfm_opt* o, nfm_model* m, const ModelView& M, DpEpoch*
   } else {
     de.arena = o->state_arena.as<double>();
     de.n = (int64_t)((o->gsc.as<char>() - o->state_arena.as<char>()) / sizeof(double)) + 2;
+    if (ada_rule == NFM_DP_STATE_CROSS) {  // (g_sum, g_norm) pairs of P, w and the intercept (dp.h)
+      auto off = [&](const Span& sp) { return (int64_t)((sp.as<char>() - o->state_arena.as<char>()) / sizeof(double)); };
+      de.combine_w = 1.0;
+      static const double gamma = getenv("NFM_DP_CROSS_GAMMA") ? atof(getenv("NFM_DP_CROSS_GAMMA")) : 0.1;
+      de.cross_gamma = gamma;
+      de.n_pairs = 3;
+      de.pair[0][0] = off(o->G); de.pair[0][1] = off(o->N); de.pair[0][2] = std::max<int64_t>(m->nP(), 0);
+      de.pair[1][0] = off(o->Gw); de.pair[1][1] = off(o->Nw); de.pair[1][2] = m->d;
+      de.pair[2][0] = off(o->gsc); de.pair[2][1] = off(o->gsc) + 1; de.pair[2][2] = 1;
+    }
   }
   return NFM_OK;
 }
@@ -1517,8 +1530,9 @@ int32_t nfm_opt_set_touch_cap(nfm_opt* o, double cap) {
 
 int32_t nfm_opt_set_dp_combine(nfm_opt* o, int32_t combine) {
   NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
-  NFM_CHECK(combine == NFM_DP_AUTO || combine == NFM_DP_MEAN || combine == NFM_DP_SUM || combine == NFM_DP_STATE_MEAN || combine == NFM_DP_STATE_RSQRT,
-            NFM_ERR_INVALID, "combine must be NFM_DP_AUTO, NFM_DP_MEAN, NFM_DP_SUM, NFM_DP_STATE_MEAN or NFM_DP_STATE_RSQRT");
+  NFM_CHECK(combine == NFM_DP_AUTO || combine == NFM_DP_MEAN || combine == NFM_DP_SUM || combine == NFM_DP_STATE_MEAN || combine == NFM_DP_STATE_RSQRT ||
+                combine == NFM_DP_STATE_CROSS,
+            NFM_ERR_INVALID, "combine must be NFM_DP_AUTO, NFM_DP_MEAN, NFM_DP_SUM, NFM_DP_STATE_MEAN, NFM_DP_STATE_RSQRT or NFM_DP_STATE_CROSS");
   o->dp_combine = combine;
   return NFM_OK;
 }

@@ -62,6 +62,15 @@ struct DpEpoch {
   int64_t n_sync = 0;          // mid-epoch sync points every rank reaches (agreed at dp_epoch_begin)
   bool overlap = true;
   double combine_w = 1.0;      // SGD: 1 / world (mean of the ranks' increments, the default) or 1 (their sum); AdaGrad: 1
+  // AdaGrad, NFM_DP_STATE_CROSS: the ranks' g_sum increments are SUMMED, and the squared norm takes what the sum of the ranks'
+  // g_norm increments cannot see -- how far the ranks AGREE: g_norm += sum_r dN_r + gamma ((sum_r dG_r)^2 - sum_r dG_r^2), never
+  // less than before.  Increments formed from the same stale point push the same way; their cross products inflate the norm
+  // exactly where adding them up would over-shoot (what the square of a mini-batch's gradient SUM does for large-batch AdaGrad),
+  // and vanish where the ranks saw different things.  One all-reduce as before: a rank sends dN_r - gamma dG_r^2 in place of dN_r.
+  // pair[q] = {offset of a g_sum span, offset of its g_norm span, length} in the arena (P, w, intercept); n_pairs = 0: off
+  double cross_gamma = 0.0;
+  int n_pairs = 0;
+  int64_t pair[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 };
 
 // a group handle that nfm_dp_destroy has not seen yet (an optimizer may outlive the group it was attached to)

@@ -263,6 +263,103 @@ __global__ void k_sgd_close_apply(double* __restrict__ x, const double* __restri
     }
   }
 }
+// ---- AdaGrad, NFM_DP_STATE_CROSS (dp.h): the same four steps on (g_sum, g_norm) PAIRS ----
+struct CrossPairs {
+  int64_t og[3], on[3], len[3];
+  int n;
+  double gamma;
+};
+__device__ __forceinline__ bool cross_locate(const CrossPairs& c, int64_t p, int64_t& ig, int64_t& in) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (q < c.n) {
+      if (p < c.len[q]) {
+        ig = c.og[q] + p;
+        in = c.on[q] + p;
+        return true;
+      }
+      p -= c.len[q];
+    }
+  }
+  return false;
+}
+// own: what this rank SENDS -- dG, and dN - gamma dG^2
+__global__ void k_cross_own(const double* __restrict__ x, const double* __restrict__ base, double* __restrict__ own, int64_t np, CrossPairs c) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (int64_t)gridDim.x * blockDim.x) {
+    int64_t ig, in;
+    if (!cross_locate(c, p, ig, in)) continue;
+    const double dg = x[ig] - base[ig], dn = x[in] - base[in];
+    own[ig] = dg;
+    own[in] = dn - c.gamma * (dg * dg);
+  }
+}
+// what all ranks agree on from the reduced vector R: g_sum += R_G; g_norm += max(R_N + gamma R_G^2, 0)
+__device__ __forceinline__ void cross_combined(const CrossPairs& c, double Rg, double Rn, double& cg, double& cn) {
+  cg = Rg;
+  const double v = Rn + c.gamma * (Rg * Rg);
+  cn = v > 0.0 ? v : 0.0;
+}
+// delayed arrival: x += combined - (this rank's TRUE increments of that period), base += combined
+__global__ void k_cross_fold(double* __restrict__ x, double* __restrict__ base, const double* __restrict__ R, const double* __restrict__ own,
+                             int64_t np, CrossPairs c) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (int64_t)gridDim.x * blockDim.x) {
+    int64_t ig, in;
+    if (!cross_locate(c, p, ig, in)) continue;
+    double cg, cn;
+    cross_combined(c, R[ig], R[in], cg, cn);
+    const double og = own[ig], on_true = own[in] + c.gamma * (og * og);
+    x[ig] += cg - og;
+    base[ig] += cg;
+    x[in] += cn - on_true;
+    base[in] += cn;
+  }
+}
+// arrival of the previous period and this period's own increments in one pass
+__global__ void k_cross_fold_own(double* __restrict__ x, double* __restrict__ base, const double* __restrict__ R, double* __restrict__ own,
+                                 int64_t np, CrossPairs c) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (int64_t)gridDim.x * blockDim.x) {
+    int64_t ig, in;
+    if (!cross_locate(c, p, ig, in)) continue;
+    double cg, cn;
+    cross_combined(c, R[ig], R[in], cg, cn);
+    const double og = own[ig], on_true = own[in] + c.gamma * (og * og);
+    const double xg = x[ig] + (cg - og), bg = base[ig] + cg, xn = x[in] + (cn - on_true), bn = base[in] + cn;
+    x[ig] = xg;
+    base[ig] = bg;
+    x[in] = xn;
+    base[in] = bn;
+    const double dg = xg - bg;
+    own[ig] = dg;
+    own[in] = (xn - bn) - c.gamma * (dg * dg);
+  }
+}
+// closing: x = base + combined, base = x
+__global__ void k_cross_close(double* __restrict__ x, double* __restrict__ base, const double* __restrict__ R, int64_t np, CrossPairs c) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (int64_t)gridDim.x * blockDim.x) {
+    int64_t ig, in;
+    if (!cross_locate(c, p, ig, in)) continue;
+    double cg, cn;
+    cross_combined(c, R[ig], R[in], cg, cn);
+    const double g = base[ig] + cg, nn = base[in] + cn;
+    x[ig] = g;
+    base[ig] = g;
+    x[in] = nn;
+    base[in] = nn;
+  }
+}
+static CrossPairs cross_of(const DpEpoch& e, int64_t* np) {
+  CrossPairs c{};
+  c.n = e.n_pairs;
+  c.gamma = e.cross_gamma;
+  *np = 0;
+  for (int q = 0; q < e.n_pairs; ++q) {
+    c.og[q] = e.pair[q][0];
+    c.on[q] = e.pair[q][1];
+    c.len[q] = e.pair[q][2];
+    *np += e.pair[q][2];
+  }
+  return c;
+}
 __global__ void k_neg_scales(const double* __restrict__ x, int64_t skip_lo, double* __restrict__ out) {
   out[0] = -x[skip_lo];
   out[1] = -x[skip_lo + 1];
@@ -277,6 +374,12 @@ int dp_fold_pending(DpEpoch& e) {
   hipStream_t st = dp->ctx->stream;
   NFM_HIP_CHECK(hipStreamWaitEvent(st, dp->ev_done, 0));
   const int64_t n = dp->pending_n;
+  if (e.n_pairs > 0) {
+    int64_t np = 0;
+    const CrossPairs c = cross_of(e, &np);
+    hipLaunchKernelGGL(k_cross_fold, dim3(grid_stream(np)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(),
+                       dp->snap.as<double>(), np, c);
+  } else
   hipLaunchKernelGGL(k_inc_fold, dim3(grid_stream(n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(),
                      dp->snap.as<double>(), n, e.skip_lo, e.skip_hi, e.combine_w);
   NFM_HIP_CHECK(hipGetLastError());
@@ -289,6 +392,7 @@ int dp_epoch_begin(DpEpoch& e, int64_t n_full_batches, int64_t n_batches) {
   hipStream_t st = dp->ctx->stream;
   NFM_CHECK(!dp->pending, NFM_ERR_INVALID, "a data-parallel exchange of an earlier call is still pending");
   NFM_TRY(dp->snap.ensure(sizeof(double) * (size_t)e.n));
+  if (e.n_pairs > 0) NFM_HIP_CHECK(hipMemsetAsync(dp->snap.p, 0, sizeof(double) * (size_t)e.n, st));  // (the pair kernels skip the spans' padding)
   NFM_TRY(dp->recv.ensure(sizeof(double) * (size_t)e.n));
   NFM_TRY(dp->scal.ensure(sizeof(double) * 8));
   // the state all ranks agree on (they enter the call with identical replicas; SGD: in true values, both scales 1)
@@ -317,13 +421,21 @@ int dp_after_batch(DpEpoch& e, int64_t b) {
   if (k > e.n_sync) return NFM_OK;
   nfm_dp* dp = e.dp;
   hipStream_t st = dp->ctx->stream;
+  int64_t np_x = 0;
+  const CrossPairs cx = cross_of(e, &np_x);
   if (dp->pending) {
     // the previous period's collective has had a whole period to finish: its result arrives and this period's increments
     // are formed in one pass
     NFM_HIP_CHECK(hipStreamWaitEvent(st, dp->ev_done, 0));
+    if (e.n_pairs > 0)
+      hipLaunchKernelGGL(k_cross_fold_own, dim3(grid_stream(np_x)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(),
+                         dp->snap.as<double>(), np_x, cx);
+    else
     hipLaunchKernelGGL(k_inc_fold_own, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(),
                        dp->snap.as<double>(), e.n, e.skip_lo, e.skip_hi, e.combine_w);
     dp->pending = false;
+  } else if (e.n_pairs > 0) {
+    hipLaunchKernelGGL(k_cross_own, dim3(grid_stream(np_x)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->snap.as<double>(), np_x, cx);
   } else {
     hipLaunchKernelGGL(k_inc_own, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->snap.as<double>(), e.n,
                        e.skip_lo, e.skip_hi);
@@ -356,6 +468,12 @@ int dp_epoch_end(DpEpoch& e, double* sums_dev) {
     NFM_TRY(dp->t->allreduce(dp->snap.as<double>(), dp->recv.as<double>(), e.n, DP_SUM, st));
     hipLaunchKernelGGL(k_sgd_close_apply, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(),
                        dp->scal.as<double>() + 4, e.n, e.seg_w, e.seg_sc, e.skip_lo, e.skip_hi, e.combine_w);
+  } else if (e.n_pairs > 0) {
+    int64_t np = 0;
+    const CrossPairs c = cross_of(e, &np);
+    hipLaunchKernelGGL(k_cross_own, dim3(grid_stream(np)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->snap.as<double>(), np, c);
+    NFM_TRY(dp->t->allreduce(dp->snap.as<double>(), dp->recv.as<double>(), e.n, DP_SUM, st));
+    hipLaunchKernelGGL(k_cross_close, dim3(grid_stream(np)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->recv.as<double>(), np, c);
   } else {
     hipLaunchKernelGGL(k_inc_own, dim3(grid_stream(e.n)), dim3(kBlock), 0, st, e.arena, dp->base.as<double>(), dp->snap.as<double>(), e.n,
                        (int64_t)0, (int64_t)0);

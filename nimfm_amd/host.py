@@ -776,8 +776,8 @@ class _OptimizerBase:
         rank's steps land in the model, as every Hogwild thread's steps do in the reference; acts like a step size times
         the number of ranks where features overlap -- keep syncPeriod small).  The epoch's loss / viol and the step
         counter `it` then cover the samples of ALL ranks."""
-        if combine not in ("auto", "mean", "sum", "state_mean", "state_rsqrt"):
-            raise ValueError("combine must be 'auto', 'mean', 'sum', 'state_mean' or 'state_rsqrt'")
+        if combine not in ("auto", "mean", "sum", "state_mean", "state_rsqrt", "state_cross"):
+            raise ValueError("combine must be 'auto', 'mean', 'sum', 'state_mean', 'state_rsqrt' or 'state_cross'")
         # "auto" is resolved IN THE LIBRARY (NFM_DP_AUTO, the default of every optimizer -- the Nim and C++ hosts only call
         # nfm_opt_set_dp): what tools/dp_convergence.py measured (DESIGN.md section 6): SGD -- the mean at any period; AdaGrad
         # -- the summed state is synchronous data-parallel AdaGrad when the ranks exchange after EVERY mini-batch and
@@ -790,7 +790,7 @@ class _OptimizerBase:
         g = self._dp
         capi.check(capi.lib().nfm_opt_set_dp(self._h, None if g is None else g[0].h, 0 if g is None else g[1],
                                              1 if g is None or g[2] else 0))
-        capi.check(capi.lib().nfm_opt_set_dp_combine(self._h, -1 if g is None else {"auto": -1, "mean": 0, "sum": 1, "state_mean": 2, "state_rsqrt": 3}[g[3]]))
+        capi.check(capi.lib().nfm_opt_set_dp_combine(self._h, -1 if g is None else {"auto": -1, "mean": 0, "sum": 1, "state_mean": 2, "state_rsqrt": 3, "state_cross": 4}[g[3]]))
 
     def _sync_it(self):
         """with a group attached the library advances `it` by the samples of all ranks"""

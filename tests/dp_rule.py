@@ -131,14 +131,35 @@ def _ada_unflat(st, f):
     st.gsum_b.value, st.gnorm_b.value = f[-2], f[-1]
 
 
-def rank_adagrad(epoch_fn, st, n, B, S, it0, overlap, world, w=1.0):
-    """epoch_fn(begin, end, it) -> (loss, viol): the oracle's AdaGrad mini-batch epoch over [begin, end), updating st"""
+def rank_adagrad(epoch_fn, st, n, B, S, it0, overlap, world, w=1.0, cross_gamma=None):
+    """epoch_fn(begin, end, it) -> (loss, viol): the oracle's AdaGrad mini-batch epoch over [begin, end), updating st.
+    cross_gamma (NFM_DP_STATE_CROSS, csrc/dp.h): the g_sum increments are summed and the squared norm takes the ranks' agreement,
+    g_norm += sum_r dN_r + gamma ((sum_r dG_r)^2 - sum_r dG_r^2), never less than before; a rank SENDS dN_r - gamma dG_r^2"""
     bounds = batch_bounds(n, B, it0 == 1)
     nb = len(bounds) - 1
     n_sync = int(-(yield ("max", np.array([-float(n_sync_mine(bounds, B, S))])))[0])
     loss = viol = 0.0
     base = _ada_flat(st)
     pending = None
+    a_, d_ = st.gsum_P.size, st.gsum_w.size
+    pairs = [(slice(0, a_), slice(a_, 2 * a_)), (slice(2 * a_, 2 * a_ + d_), slice(2 * a_ + d_, 2 * a_ + 2 * d_)),
+             (slice(2 * a_ + 2 * d_, 2 * a_ + 2 * d_ + 1), slice(2 * a_ + 2 * d_ + 1, 2 * a_ + 2 * d_ + 2))]
+
+    def sent_of(own):  # what travels
+        if cross_gamma is None:
+            return own.copy()
+        out = own.copy()
+        for g_, n_ in pairs:
+            out[n_] = own[n_] - cross_gamma * (own[g_] * own[g_])
+        return out
+
+    def combined_of(total):  # what all ranks agree on
+        if cross_gamma is None:
+            return w * total
+        out = total.copy()
+        for g_, n_ in pairs:
+            out[n_] = np.maximum(total[n_] + cross_gamma * (total[g_] * total[g_]), 0.0)
+        return out
 
     def run(b0, b1):
         nonlocal loss, viol
@@ -152,23 +173,24 @@ def rank_adagrad(epoch_fn, st, n, B, S, it0, overlap, world, w=1.0):
         if pending is None:
             return
         total, own = pending
-        _ada_unflat(st, _ada_flat(st) + (w * total - own))
-        base = base + w * total
+        comb = combined_of(total)
+        _ada_unflat(st, _ada_flat(st) + (comb - own))
+        base = base + comb
         pending = None
 
     for k in range(1, n_sync + 1):
         run((k - 1) * S, k * S)
         fold()
         own = _ada_flat(st) - base
-        total = yield ("sum", own.copy())
+        total = yield ("sum", sent_of(own))
         pending = (total, own)
         if not overlap:
             fold()
     run(n_sync * S, nb)
     fold()
     own = _ada_flat(st) - base
-    total = yield ("sum", own.copy())
-    _ada_unflat(st, base + w * total)
+    total = yield ("sum", sent_of(own))
+    _ada_unflat(st, base + combined_of(total))
     sums = yield ("sum", np.array([loss, viol, float(n)]))
     return st, sums[0], sums[1], it0 + int(round(sums[2]))
 

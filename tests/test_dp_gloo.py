@@ -75,7 +75,9 @@ def _rank_gens(O, shard, ys, P0, w0, S, overlap, world):
             def ep(lo, hi, it_):
                 hold[0], _, ls, vs = O.fm_adagrad_epoch_mb(shard, ys, 2, P, w, hold[0], cfg, B, st, begin=lo, end=hi, it=it_)
                 return ls, vs
-            st, ls, vs, it = yield from R.rank_adagrad(ep, st, shard.n, B, S, it, overlap, world)
+            # AdaGrad between exchanges of more than one mini-batch: the library's NFM_DP_AUTO is the cross rule (csrc/dp.h,
+            # round 5: g_sum increments summed, g_norm taking the ranks' agreement); one mini-batch per exchange: the plain sum
+            st, ls, vs, it = yield from R.rank_adagrad(ep, st, shard.n, B, S, it, overlap, world, cross_gamma=None if S == 1 else 0.1)
             out.append((ls, vs, it))
         return R._ada_flat(st), out
 

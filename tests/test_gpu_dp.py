@@ -70,12 +70,14 @@ def test_local_group_sgd_and_adagrad_vs_rule(world, S, overlap, combine):
 
 
 @pytest.mark.parametrize("world,S,combine", [(4, 4, "mean"), (8, 2, "mean"), (8, 0, "mean"), (4, 0, "mean"), (4, 3, "state_mean"),
-                                              (8, 0, "state_mean"), (4, 3, "auto"), (4, 0, "auto"), (2, 1, "auto"), (4, 3, "state_rsqrt")])
+                                              (8, 0, "state_mean"), (4, 3, "auto"), (4, 0, "auto"), (2, 1, "auto"), (4, 3, "state_rsqrt"),
+                                              (4, 3, "state_cross"), (8, 0, "state_cross"), (8, 2, "state_cross")])
 def test_local_group_many_ranks_vs_rule(world, S, combine):
     """4 and 8 ranks (tools/dp_convergence.py runs these group sizes), several mid-epoch exchanges per rank; state_mean:
     AdaGrad's state increments averaged instead of summed (NFM_DP_STATE_MEAN; for SGD it is the mean); auto: NFM_DP_AUTO,
     resolved inside the library -- what an optimizer does when its host only ever calls nfm_opt_set_dp (the Nim shim's
-    attach(), nimfm.hpp): SGD the mean, AdaGrad summed at sync_period 1 and averaged otherwise"""
+    attach(), nimfm.hpp): SGD the mean, AdaGrad summed at sync_period 1 and the cross rule otherwise; state_cross
+    (NFM_DP_STATE_CROSS, round 5): AdaGrad's g_sum increments summed, g_norm inflated by the ranks' agreement (csrc/dp.h)"""
     _vs_rule(4003, 300, world, S, True, combine)
 
 
@@ -89,7 +91,7 @@ def test_local_group_sparse_regime_vs_rule(world, S):
 def _vs_rule(N, D, world, S, overlap, combine):
     lib_combine = combine
     if combine == "auto":  # the rule the library is expected to pick by itself
-        combine = "state_mean" if S != 1 else "sum"
+        combine = "state_cross" if S != 1 else "sum"
     full = random_csr(N, D, M, seed=21)
     rng = np.random.default_rng(5)
     y = rng.standard_normal(N)
@@ -109,7 +111,7 @@ def _vs_rule(N, D, world, S, overlap, combine):
                     def ep(P_, w_, b_, lo, hi, it_):
                         b2, _, ls, vs = O.fm_sgd_epoch_mb(shard, ys, 2, P_, w_, b_, cfg, B, begin=lo, end=hi, it=it_)
                         return b2, ls, vs
-                    P, w, b, ls, vs, it = yield from R.rank_sgd(ep, P, w, b, cfg, shard.n, B, S, it, overlap, world, "mean" if lib_combine in ("auto", "state_rsqrt") else combine)
+                    P, w, b, ls, vs, it = yield from R.rank_sgd(ep, P, w, b, cfg, shard.n, B, S, it, overlap, world, "mean" if lib_combine in ("auto", "state_rsqrt", "state_cross") else combine)
                     hist.append((vs, ls / N))
                 return P, w, b, hist, it
 
@@ -126,7 +128,8 @@ def _vs_rule(N, D, world, S, overlap, combine):
                     def ep(lo, hi, it_):
                         hold[0], _, ls, vs = O.fm_adagrad_epoch_mb(shard, ys, 2, P, w, hold[0], cfg, B, st, begin=lo, end=hi, it=it_)
                         return ls, vs
-                    st, ls, vs, it = yield from R.rank_adagrad(ep, st, shard.n, B, S, it, overlap, world, 1.0 / world if combine == "state_mean" else (1.0 / np.sqrt(world) if combine == "state_rsqrt" else 1.0))
+                    st, ls, vs, it = yield from R.rank_adagrad(ep, st, shard.n, B, S, it, overlap, world, 1.0 / world if combine == "state_mean" else (1.0 / np.sqrt(world) if combine == "state_rsqrt" else 1.0),
+                                                                 cross_gamma=0.1 if combine == "state_cross" else None)
                     hist.append((vs, ls / N))
                 bb = O.fm_adagrad_finalize(2, P, w, hold[0], cfg, it, st)
                 return P, w, bb, hist, it

@@ -71,7 +71,9 @@ def make_opt(solver, eta_scale=1.0):
 def single(solver):
     fm = nf.newFactorizationMachine("regression", nComponents=k, warmStart=True)
     fm.set_params(P0, w0, 0.0)
-    make_opt(solver).fit(nf.newCSRDataset(Xtr.data, Xtr.indices, Xtr.indptr, n, d), ytr, fm)
+    opt = make_opt(solver)
+    opt.fit(nf.newCSRDataset(Xtr.data, Xtr.indices, Xtr.indptr, n, d), ytr, fm)
+    single.train = opt.history[-1][1]  # the last epoch's running training loss (what the reference prints)
     return rmse(fm.P, fm.w, fm.intercept)
 
 
@@ -91,6 +93,8 @@ def ranks(solver, world, S, combine="mean", eta_scale=1.0):
             opt.setDataParallel(groups[r], S, True, combine)
             opt.fit(X, ytr[lo:hi], fm)
             res[r] = (fm.P.copy(), fm.w.copy(), fm.intercept)
+            if r == 0:
+                ranks.train = opt.history[-1][1]  # (over the samples of all ranks)
         except BaseException as e:  # noqa: BLE001
             err.append((r, e))
 
@@ -112,22 +116,23 @@ if len(sys.argv) > 3:  # one row in a process of its own: "solver world S one_ra
     solver, world, S, one = sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
     nb = (n // world) // B
     row = []
-    variants = [("mean", 1.0), ("sum", 1.0)] if solver == "sgd" else [("sum", 1.0), ("state_mean", 1.0), ("state_rsqrt", 1.0)]
+    variants = [("mean", 1.0), ("sum", 1.0)] if solver == "sgd" else [("sum", 1.0), ("state_mean", 1.0), ("state_rsqrt", 1.0), ("state_cross", 1.0)]
     for combine, es in variants:
         v = ranks(solver, world, S, combine, es)
         prog = (L0 - v) / (L0 - one) if np.isfinite(v) else float("nan")
-        row.append("%s %.4f (progress %.2f)" % (combine if solver == "sgd" else ("state-" + combine.replace("state_", "")), v, prog))
+        row.append("%s %.4f (progress %.2f; last epoch's training loss %.4f)" % (combine if solver == "sgd" else ("state-" + combine.replace("state_", "")), v, prog,
+                                                                                      getattr(ranks, "train", float("nan"))))
     print("  %d ranks, exchange every %s (%d mini-batches per rank and epoch): %s" % (world, "%d mini-batches" % S if S else "epoch", nb, "; ".join(row)), flush=True)
     sys.exit(0)
 import subprocess  # noqa: E402
 
 print("planted FM: %d train / %d held-out samples, d=%d, m=%d, k=%d, mini-batch %d, %d epochs, SGD touch cap %g; held-out RMSE at start %.4f"
       % (n, nt, d, m, k, B, E, CAP, L0), flush=True)
-for solver in ("sgd", "adagrad"):
+for solver in (os.environ.get("DPC_SOLVERS") or "sgd,adagrad").split(","):
     one = single(solver)
-    print("%s: one rank over all samples: %.4f" % (solver, one), flush=True)
-    for world in (2, 4, 8):
-        for S in (1, 4, 16, 0):
+    print("%s: one rank over all samples: %.4f (last epoch's training loss %.4f)" % (solver, one, getattr(single, "train", float("nan"))), flush=True)
+    for world in [int(v) for v in (os.environ.get("DPC_WORLDS") or "2,4,8").split(",")]:
+        for S in [int(v) for v in (os.environ.get("DPC_PERIODS") or "1,4,16,0").split(",")]:
             out = subprocess.run([sys.executable, os.path.abspath(__file__), str(E), str(CAP), solver, str(world), str(S), repr(one)],
                                  capture_output=True, text=True, timeout=600)
             lines = [ln for ln in out.stdout.splitlines() if ln.startswith("  ")]
