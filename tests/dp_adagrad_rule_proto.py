@@ -1,13 +1,15 @@
-"""CPU prototype (numpy + the oracle's mini-batch AdaGrad, no GPU): how should the ranks' AdaGrad STATE increments be combined at an
+"""(Not a test: a research script that uses the oracle as its engine, which only tests/ may -- kept here for that reason.)
+CPU prototype (numpy + the oracle's mini-batch AdaGrad, no GPU): how should the ranks' AdaGrad STATE increments be combined at an
 exchange?  The library's rules -- sum (over-shoots beyond a few mini-batches per exchange), mean (stable, one rank's progress
 x 0.75 at 8 ranks), 1 / sqrt(world) (good for short periods, diverges a whole epoch apart) -- against candidates, on the planted
 problem of tools/dp_convergence.py.  progress = (L_start - L_run) / (L_start - L_one_rank_over_all_samples).
-usage: python tools/dp_adagrad_rule_proto.py [epochs] [world] [period ...]"""
+usage: python tests/dp_adagrad_rule_proto.py [epochs] [world] [period ...]"""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", ".."))
 import numpy as np  # noqa: E402
 
 import oracle as O  # noqa: E402
