@@ -685,11 +685,16 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         # what N ranks' epoch is worth against ONE rank's epoch over all samples (1.0: throughput IS speed-up), measured with
         # local groups on one GPU on a planted FM (tools/dp_convergence.py); quoted, not measured in this run
         prog = {"mean": {2: 1.15, 4: 1.20, 8: 1.12}, "state_mean": {2: 1.03, 4: 0.93, 8: 0.75}, "sum": {2: 0.96, 4: 0.98, 8: 1.01},
-                "state_cross": {2: 1.00, 4: 1.02, 8: 1.01}}
+                "state_cross": {2: 1.00, 4: 0.74, 8: 1.01}}  # (ranks a whole epoch apart, 4 epochs; 16 mini-batches apart: 0.96 / 1.02 / 1.06)
+        # the same runs' last-epoch TRAINING loss against one rank's (the optimisation progress itself; on that small problem one rank
+        # over-fits from epoch 4 on, which the held-out figure above mixes in): below 1 = further along than one rank over all samples
+        train = {"state_cross": {2: 0.90, 4: 0.94, 8: 1.04}, "state_mean": {2: 1.18, 4: 1.45, 8: 1.64}}
         if i1["world"] in (2, 4, 8) and comb in prog and (wl["solver"] == "adagrad" or comb == "mean"):
             dp_stats["progress_per_epoch"] = prog[comb][i1["world"]]
             dp_stats["progress_source"] = ("profiles/r05g_dp_convergence.txt" if comb == "state_cross" else "profiles/r03_dp_convergence.txt") + \
                                           " (planted FM, local groups of this size on one GPU; not this run)"
+            if comb in train:
+                dp_stats["train_loss_vs_one_rank"] = train[comb][i1["world"]]
 
     # ---- the reference's default shuffle = true (optimizer/sgd.nim:297): every epoch gets a FRESH permutation, so the
     # batch plan is rebuilt for every epoch inside the timed region.
@@ -1122,7 +1127,7 @@ def contract_line(full):
                                                          for t_ in out["time_to_target"]["targets"]]
     d_ = full.get("dp")
     out["dp"] = {k_: d_[k_] for k_ in ("combine", "sync_period", "world", "collectives_per_step", "bytes_per_step_per_rank",
-                                         "progress_per_epoch") if k_ in d_} if d_ else None
+                                         "progress_per_epoch", "train_loss_vs_one_rank") if k_ in d_} if d_ else None
     out["roofline"] = _roof_compact(full.get("roofline"))
     out["cpu_baseline"] = _cpu_compact(full.get("cpu_baseline"))
     c_ = full.get("cpu_baseline") or {}
