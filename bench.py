@@ -44,6 +44,7 @@ WORKLOADS = {
     "cfg2": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768),
     "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="logistic", batch=131072),
     "cfg3": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="squared", batch=8192),
+    "cfg3c": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="squared", batch=8192, ada_cross=0.1),
     "cfg3l": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="logistic", batch=8192),
     # cfg5: higher-order FM, degree 3 with fitLower=explicit -> two parameter blocks (ANOVA degree 3 and 2)
     "cfg5": dict(n=1_000_000, d=100_000, m=32, k=8, degree=3, solver="sgd", loss="squared", batch=32768),
@@ -52,7 +53,10 @@ WORKLOADS = {
     # batch 2048: field-aware AdaGrad has no touch cap to turn -- a batch is ONE step per coordinate -- and at 32768 it does not
     # reach the held-out loss of ten sequential epochs in 40 of its own (time_to_target, measured in round 4: 32768: 13 / 28 /
     # never; 8192: 4 / 8 / 20 epochs; 2048: 2 / 4 / 11 epochs and the best speed-up); "cfg4big" keeps the bandwidth figure
-    "cfg4": dict(n=1_000_000, d=100_000, m=16, k=8, degree=2, solver="adagrad", loss="squared", batch=2048, fields=16),
+    # Round 5: batch 32768 again, with the batch's gradient cross products in g_norm (nfm_opt_set_ada_cross, gamma 0.1): the same
+    # 2 / 4 / 11 epochs to the three targets as batch 2048 needs, at twice the samples per second ("cfg4b2048": rounds 4 / early 5)
+    "cfg4": dict(n=1_000_000, d=100_000, m=16, k=8, degree=2, solver="adagrad", loss="squared", batch=32768, fields=16, ada_cross=0.1),
+    "cfg4b2048": dict(n=1_000_000, d=100_000, m=16, k=8, degree=2, solver="adagrad", loss="squared", batch=2048, fields=16),
     "cfg4big": dict(n=1_000_000, d=100_000, m=16, k=8, degree=2, solver="adagrad", loss="squared", batch=32768, fields=16),
     # cfg4 with three low-cardinality fields (2, 7 and 50 distinct features): their features are touched by a
     # large share of every batch
@@ -451,6 +455,7 @@ T2T = {"planted_w": 0.3, "planted_P": 0.1, "seq_epochs": (1, 3, 10), "mb_epoch_c
 # 27 / 36 / 44 % of the gap in 1 / 3 / 10 sequential epochs (tools/t2t_gpu.py, gpurun_out of round 4)
 T2T_WL = {"headline": dict(n_t=2_000_000, planted_P=0.05, sgd=dict(eta0=0.04, alpha0=1e-6, alpha=1e-5, beta=1e-5)),
           "cfg3": dict(n_t=2_000_000, planted_P=0.05, adagrad=dict(eta0=0.05, alpha0=1e-6, alpha=3e-5, beta=3e-5))}
+T2T_WL["cfg3c"] = T2T_WL["cfg3"]
 
 
 def time_to_target_leg(torch, nf, ctx, dev, wl, name, n, batch, cap, indices, data, fields_t, task, cfg=None, batches=None):
@@ -527,7 +532,7 @@ def time_to_target_leg(torch, nf, ctx, dev, wl, name, n, batch, cap, indices, da
         f_mb = new_model()
         P_i, w_i = np.array(f_mb.P), np.array(f_mb.w)
         o_mb = mk_(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch", batch=batch_,
-                   **({"touchCap": cap} if sgd else {}), **hp)
+                   **({"touchCap": cap} if sgd else {"adaCross": float(wl.get("ada_cross", 0.0))}), **hp)
         o_mb._handle(f_mb, ctx, "minibatch")
         o_mb._epoch(Xt, None, 0, n_t)  # plan + graph built outside the clock, then start again from the same point
         f_mb.set_params(P_i, w_i, 0.0)
@@ -620,7 +625,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         opt = nf.newSGD(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch", batch=batch, touchCap=cap)
     else:
         opt = nf.newAdaGrad(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch",
-                            batch=batch, trackViol=not args.no_viol)
+                            batch=batch, trackViol=not args.no_viol, adaCross=float(wl.get("ada_cross", 0.0)))
     X.set_targets(y)
     opt._handle(fm, ctx, "minibatch")
     sync_period = 0

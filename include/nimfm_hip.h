@@ -396,6 +396,17 @@ int32_t nfm_opt_set_dp_combine(nfm_opt* o, int32_t combine);
  * bench workloads and stayed stable where the plain sum (cap = infinity) diverges on dense coordinates and the
  * intercept.  Deterministic for every value. */
 int32_t nfm_opt_set_touch_cap(nfm_opt* o, double cap);
+/* AdaGrad, NFM_MODE_MINIBATCH (round 5): what a mini-batch adds to a coordinate's g_norm (optimizer/adagrad.nim:122-124 adds
+ * g^2 per sample).  All samples of a batch take their gradients from the batch-start parameters; summing their squares alone
+ * does not see whether they agree, and a coordinate touched by many samples of a batch that push the same way is then stepped
+ * as far as if the samples had been independent observations -- field-aware AdaGrad at batch 32768 needed 13 / 28 / more than
+ * 40 epochs for the held-out loss of 1 / 3 / 10 epochs in the reference's order.  With gamma > 0 the norm grows by
+ *   sum_i g_i^2 + gamma * max((sum_i g_i)^2 - sum_i g_i^2, 0)
+ * -- the cross products of the batch's gradients (what squaring the batch gradient does in large-batch AdaGrad, and what
+ * NFM_DP_STATE_CROSS does for the ranks of a group): 2 / 4 / 11 epochs at batch 32768, as at batch 2048.
+ * A coordinate touched once is not affected, so batch == 1 stays the reference's step.  gamma = 0 (default): off.
+ * Deterministic for every value. */
+int32_t nfm_opt_set_ada_cross(nfm_opt* o, double gamma);
 
 /* ---- host-side random numbers (no device work) ----
  * FactorizationMachine.init draws P with randomNormal (model/factorization_machine.nim:125-139,

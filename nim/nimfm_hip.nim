@@ -120,6 +120,7 @@ proc nfm_dp_destroy*(dp: NfmDp): int32
 proc nfm_opt_set_dp*(o: NfmOpt, dp: NfmDp, syncPeriod: int64, overlap: int32): int32
 proc nfm_opt_set_dp_combine*(o: NfmOpt, combine: int32): int32  # -1 (default): auto (SGD the mean; AdaGrad summed at syncPeriod 1, else the cross rule), 0: mean, 1: sum, 2: averaged state, 3: 1/sqrt(world), 4: cross (g_sum summed, g_norm + the ranks' agreement)
 proc nfm_opt_set_touch_cap*(o: NfmOpt, cap: float64): int32     # SGD mini-batch rule: steps per coordinate summed before averaging sets in
+proc nfm_opt_set_ada_cross*(o: NfmOpt, gamma: float64): int32   # AdaGrad mini-batch rule: weight of the batch's gradient cross products in g_norm
 {.pop.}
 
 proc check*(rc: int32) =

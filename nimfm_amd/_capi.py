@@ -39,7 +39,7 @@ SYMBOLS = [
     "nfm_sgd_create", "nfm_adagrad_create", "nfm_mbpsgd_create", "nfm_opt_predict_all_with_grad", "nfm_opt_set_it", "nfm_opt_get_it", "nfm_opt_get_state",
     "nfm_opt_set_state", "nfm_opt_epoch", "nfm_opt_finalize", "nfm_opt_device_state", "nfm_opt_destroy",
     "nfm_rng_randomize", "nfm_rng_random_normal", "nfm_rng_shuffle",
-    "nfm_dp_unique_id", "nfm_dp_create", "nfm_dp_create_local", "nfm_dp_info", "nfm_dp_destroy", "nfm_opt_set_dp", "nfm_opt_set_dp_combine", "nfm_opt_set_touch_cap",
+    "nfm_dp_unique_id", "nfm_dp_create", "nfm_dp_create_local", "nfm_dp_info", "nfm_dp_destroy", "nfm_opt_set_dp", "nfm_opt_set_dp_combine", "nfm_opt_set_touch_cap", "nfm_opt_set_ada_cross",
     "nfm_opt_set_shuffle", "nfm_opt_get_perm", "nfm_opt_announce_perm",
     "nfm_stream_open", "nfm_stream_shape", "nfm_stream_load_rows", "nfm_stream_prefetch_rows", "nfm_stream_close",
 ]
@@ -169,6 +169,7 @@ def lib():
         "nfm_opt_set_dp": [vp, vp, i64, i32],
         "nfm_opt_set_dp_combine": [vp, i32],
         "nfm_opt_set_touch_cap": [vp, C.c_double],
+        "nfm_opt_set_ada_cross": [vp, C.c_double],
         "nfm_opt_set_shuffle": [vp, i64],
         "nfm_opt_get_perm": [vp, vp, i64],
         "nfm_opt_announce_perm": [vp, vp, i64, i64],

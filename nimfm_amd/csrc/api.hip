@@ -887,6 +887,7 @@ int32_t nfm_adagrad_create(nfm_model* m, const nfm_adagrad_cfg* c, nfm_opt** out
   o->o.eta0 = c->eta0; o->o.alpha0 = c->alpha0; o->o.alpha = c->alpha; o->o.beta = c->beta; o->o.power = 1.0;
   o->o.eps = c->eps; o->o.loss_param = c->loss_param; o->o.loss = c->loss; o->o.sched = 0; o->o.track_viol = c->track_viol;
   o->o.touch_cap = 1.0;
+  o->o.ada_cross = 0.0;
   NFM_TRY(use_device(m->ctx));
   NFM_TRY(o->out2.alloc(sizeof(double) * 2));
   {
@@ -1523,6 +1524,18 @@ int32_t nfm_opt_set_touch_cap(nfm_opt* o, double cap) {
   NFM_CHECK(cap >= 1.0 && cap == cap, NFM_ERR_INVALID, "touch cap must be >= 1");
   if (o->o.touch_cap != cap) {
     o->o.touch_cap = cap;
+    o->W.drop_graph();  // a captured epoch holds the optimizer's parameters by value
+  }
+  return NFM_OK;
+}
+
+int32_t nfm_opt_set_ada_cross(nfm_opt* o, double gamma) {
+  NFM_CHECK(o, NFM_ERR_INVALID, "null optimizer");
+  NFM_CHECK(o->kind == OPT_ADAGRAD && o->mode == NFM_MODE_MINIBATCH, NFM_ERR_UNSUPPORTED,
+            "the cross-product weight belongs to AdaGrad in NFM_MODE_MINIBATCH");
+  NFM_CHECK(gamma >= 0.0 && gamma == gamma, NFM_ERR_INVALID, "the cross-product weight must be >= 0");
+  if (o->o.ada_cross != gamma) {
+    o->o.ada_cross = gamma;
     o->W.drop_graph();  // a captured epoch holds the optimizer's parameters by value
   }
   return NFM_OK;

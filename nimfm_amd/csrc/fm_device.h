@@ -136,6 +136,12 @@ struct PlainParams {  // SGD / predict: scale * stored
   }
 };
 
+// AdaGrad, mini-batch rule: what a coordinate's g_norm grows by, from the batch's sum of gradients and sum of squared gradients
+// (opt_views.h: ada_cross; one touch: acc^2 == accn, nothing changes)
+__device__ __forceinline__ double ada_norm_inc(double acc, double accn, double cross) {
+  const double c = acc * acc - accn;
+  return accn + (cross != 0.0 && c > 0.0 ? cross * c : 0.0);
+}
 // optimizer/adagrad.nim:96-98: P = -(eta0 * g_sum) / (eta0*(it-1)*beta + sqrt(g_norm))
 __device__ __forceinline__ double adagrad_param(double g, double n, double eta0, double tmp) {
   return -(eta0 * g) / (tmp + sqrt(n));

@@ -544,7 +544,9 @@ __device__ __forceinline__ double ffm_unit(const FColArgs& a, int64_t j, int f, 
     st.y = st.y * fP - (acc.y / cd) / sPn;
     ffm_st<4>(M.P + e, st);
   } else {
-    g2.x += acc.x; g2.y += acc.y; n2.x += accn.x; n2.y += accn.y;
+    g2.x += acc.x; g2.y += acc.y;
+    n2.x += dev::ada_norm_inc(acc.x, accn.x, O.ada_cross);
+    n2.y += dev::ada_norm_inc(acc.y, accn.y, O.ada_cross);
     ffm_st<4>(O.G + e, g2);
     ffm_st<4>(O.N + e, n2);
   }
@@ -562,7 +564,7 @@ __device__ __forceinline__ double ffm_unit(const FColArgs& a, int64_t j, int f, 
         M.w[j] = wj;
       }
       O.Gw[j] = gw + a0;
-      O.Nw[j] = nw + a1;
+      O.Nw[j] = nw + dev::ada_norm_inc(a0, a1, O.ada_cross);
     }
   }
   return viol;
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(kBlock) void k_ffm_col_phase(FColArgs a) {
           M.sc[SC_INTERCEPT] = nb_;
         }
         O.gsc[0] += red[2][0];
-        O.gsc[1] += red[3][0];
+        O.gsc[1] += dev::ada_norm_inc(red[2][0], red[3][0], O.ada_cross);
       }
     }
     a.out_acc[0] += red[0][0];

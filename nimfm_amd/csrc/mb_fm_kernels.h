@@ -1234,8 +1234,8 @@ __device__ __forceinline__ double col_block(const ColArgs& a, size_t e, int deg,
   } else {
     g2.x += acc.x;
     g2.y += acc.y;
-    n2.x += accn.x;
-    n2.y += accn.y;
+    n2.x += dev::ada_norm_inc(acc.x, accn.x, O.ada_cross);
+    n2.y += dev::ada_norm_inc(acc.y, accn.y, O.ada_cross);
     dev::st_stream(O.G + e, g2);
     dev::st_stream(O.N + e, n2);
   }
@@ -1357,8 +1357,8 @@ __device__ __forceinline__ double col_block_d3(const ColArgs& a, int64_t j, int 
     } else {
       g2[o].x += acc[o].x;
       g2[o].y += acc[o].y;
-      n2[o].x += accn[o].x;
-      n2[o].y += accn[o].y;
+      n2[o].x += dev::ada_norm_inc(acc[o].x, accn[o].x, O.ada_cross);
+      n2[o].y += dev::ada_norm_inc(acc[o].y, accn[o].y, O.ada_cross);
       dev::st_stream(O.G + e[o], g2[o]);
       dev::st_stream(O.N + e[o], n2[o]);
     }
@@ -1476,8 +1476,8 @@ __device__ __forceinline__ double col_block_w2(const ColArgs& a, int64_t j, int 
     } else {
       g2[o].x += acc[o].x;
       g2[o].y += acc[o].y;
-      n2[o].x += accn[o].x;
-      n2[o].y += accn[o].y;
+      n2[o].x += dev::ada_norm_inc(acc[o].x, accn[o].x, O.ada_cross);
+      n2[o].y += dev::ada_norm_inc(acc[o].y, accn[o].y, O.ada_cross);
       dev::st_stream(O.G + e[o], g2[o]);
       dev::st_stream(O.N + e[o], n2[o]);
     }
@@ -1514,7 +1514,7 @@ __device__ __forceinline__ double w_epilogue(const ColArgs& a, int64_t j, int l,
         M.w[j] = wj;
       }
       O.Gw[j] = gw + wacc.a0;
-      O.Nw[j] = nw + wacc.a1;
+      O.Nw[j] = nw + dev::ada_norm_inc(wacc.a0, wacc.a1, O.ada_cross);
     }
   }
   return viol;
@@ -1705,7 +1705,7 @@ __device__ __forceinline__ void col_closer(const ColArgs& a, double (&red)[5][kB
           M.sc[SC_INTERCEPT] = nb_;
         }
         O.gsc[0] += red[2][0];
-        O.gsc[1] += red[3][0];
+        O.gsc[1] += dev::ada_norm_inc(red[2][0], red[3][0], O.ada_cross);
       }
     }
     a.out_acc[0] += red[0][0];
@@ -2003,8 +2003,8 @@ __global__ __launch_bounds__(kBlock, NFM_COL_SPARSE_MINW) void k_col_sparse(ColA
     } else {
       g2.x += acc.x;
       g2.y += acc.y;
-      n2.x += accn.x;
-      n2.y += accn.y;
+      n2.x += dev::ada_norm_inc(acc.x, accn.x, O.ada_cross);
+      n2.y += dev::ada_norm_inc(acc.y, accn.y, O.ada_cross);
       dev::st_stream(O.G + e, g2);
       dev::st_stream(O.N + e, n2);
       if (do_w && l == 0) {  // fit_linear.nim:50-57
@@ -2014,7 +2014,7 @@ __global__ __launch_bounds__(kBlock, NFM_COL_SPARSE_MINW) void k_col_sparse(ColA
           M.w[j] = wj;
         }
         O.Gw[j] = s.gw + wacc.a0;
-        O.Nw[j] = s.nw + wacc.a1;
+        O.Nw[j] = s.nw + dev::ada_norm_inc(wacc.a0, wacc.a1, O.ada_cross);
       }
     }
   };

@@ -14,6 +14,10 @@ struct OptView {
   // Hogwild threads apply theirs at full strength too, optimizer/sgd_multi.nim:83-101); a coordinate touched c > cap
   // times receives cap / c of the sum.  1 (default): the per-coordinate mean
   double touch_cap;
+  // AdaGrad mini-batch rule (round 5): g_norm of a coordinate grows by the batch's  sum g^2 + ada_cross ((sum g)^2 - sum g^2)  -- the
+  // cross products of the samples' gradients, all taken from the batch-start parameters: the norm sees how far the batch AGREES on a
+  // coordinate (what NFM_DP_STATE_CROSS does for the ranks of a data-parallel group, dp.h).  0 (default): the samples' squares alone
+  double ada_cross;
   int32_t loss, sched, track_viol, pad_;
   // AdaGrad state, device layout: G/N [nb][da][Kp] (padding: G = 0, N = eps), Gw/Nw [d],
   // gsc[0] = g_sum.intercept, gsc[1] = g_norm.intercept

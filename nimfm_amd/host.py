@@ -1115,17 +1115,24 @@ class SGD(_OptimizerBase):
 class AdaGrad(_OptimizerBase):
     def __init__(self, maxIter=100, eta0=0.1, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squared", eps=1e-10,
                  verbose=1, tol=1e-3, shuffle=True, nCalls=-1, mode="sequential", batch=8192, lossParam=1.0,
-                 trackViol=True, deviceShuffle=False):
+                 trackViol=True, deviceShuffle=False, adaCross=0.0):
         super().__init__(maxIter, alpha0, alpha, beta, loss, verbose, tol, shuffle, nCalls, mode, batch, lossParam, deviceShuffle)
         self.eta0, self.eps, self.trackViol = float(eta0), float(eps), bool(trackViol)
+        # mini-batch mode: the weight of the batch's gradient cross products in g_norm (nfm_opt_set_ada_cross; 0 = the samples'
+        # squares alone; 0.1 lets field-aware AdaGrad run at batch 32768 with the epochs-to-target of batch 2048)
+        if not float(adaCross) >= 0.0:
+            raise ValueError("adaCross < 0.")
+        self.adaCross = float(adaCross)
 
     def _create(self, mh, mode):
         cfg = capi.AdaGradCfg(self.eta0, self.alpha0, self.alpha, self.beta, self.eps, self.lossParam,
                               capi.LOSS[self.loss], capi.MODE[mode], int(self.trackViol), 0, self.batch)
         capi.check(capi.lib().nfm_adagrad_create(mh, C.byref(cfg), C.byref(self._h)))
+        if mode == "minibatch" and self.adaCross != 0.0:
+            capi.check(capi.lib().nfm_opt_set_ada_cross(self._h, self.adaCross))
 
     def _cfg_key(self):
-        return super()._cfg_key() + (self.eta0, self.eps, self.trackViol)
+        return super()._cfg_key() + (self.eta0, self.eps, self.trackViol, self.adaCross)
 
     def _per_epoch_callback(self, callback):
         return callback is not None  # adagrad.nim:188-191

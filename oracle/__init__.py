@@ -379,6 +379,20 @@ class _touch_cap:
         self.var.value = self.old
 
 
+class _ada_cross:
+    """the AdaGrad mini-batch rule's cross-product weight for the calls inside (oracle/nimfm_mb.c: orc_mb_ada_cross; 0 = off)"""
+
+    def __init__(self, g):
+        self.g = float(g)
+
+    def __enter__(self):
+        self.var = C.c_double.in_dll(lib(), "orc_mb_ada_cross")
+        self.old, self.var.value = self.var.value, self.g
+
+    def __exit__(self, *a):
+        self.var.value = self.old
+
+
 def fm_sgd_epoch_mb(X, y, degree, P, w, intercept, cfg, batch, n_aug=0, perm=None, begin=0, end=None, it=1, touch_cap=1.0):
     """In place on P (model layout) and w; returns (intercept, it, loss_sum, viol_sum)."""
     if touch_cap != 1.0:
@@ -398,7 +412,10 @@ def fm_sgd_epoch_mb(X, y, degree, P, w, intercept, cfg, batch, n_aug=0, perm=Non
 
 
 def fm_adagrad_epoch_mb(X, y, degree, P, w, intercept, cfg, batch, state, n_aug=0, perm=None, begin=0,
-                        end=None, it=1):
+                        end=None, it=1, ada_cross=0.0):
+    if ada_cross != 0.0:
+        with _ada_cross(ada_cross):
+            return fm_adagrad_epoch_mb(X, y, degree, P, w, intercept, cfg, batch, state, n_aug, perm, begin, end, it)
     O, k, da = P.shape
     assert P.dtype == np.float64 and P.flags.c_contiguous and w.flags.c_contiguous
     y = f64(y)
@@ -438,7 +455,10 @@ def ffm_sgd_epoch_mb(X, y, P, w, intercept, cfg, batch, perm=None, begin=0, end=
     return b.value, itc.value, ls.value, vs.value
 
 
-def ffm_adagrad_epoch_mb(X, y, P, w, intercept, cfg, batch, state, perm=None, begin=0, end=None, it=1):
+def ffm_adagrad_epoch_mb(X, y, P, w, intercept, cfg, batch, state, perm=None, begin=0, end=None, it=1, ada_cross=0.0):
+    if ada_cross != 0.0:
+        with _ada_cross(ada_cross):
+            return ffm_adagrad_epoch_mb(X, y, P, w, intercept, cfg, batch, state, perm, begin, end, it)
     F, d, k = P.shape
     y = f64(y)
     end = X.n if end is None else end

@@ -25,6 +25,15 @@
 /* touch cap of the SGD rule (1: the per-coordinate MEAN of the batch's steps; larger: up to that many of them are
  * SUMMED, the rest averaged in) -- see sgd_epoch_mb */
 double orc_mb_touch_cap = 1.0;
+/* AdaGrad rule (round 5, nfm_opt_set_ada_cross in the library): a coordinate's g_norm grows by the batch's
+ *   sum_i g_i^2 + orc_mb_ada_cross * max((sum_i g_i)^2 - sum_i g_i^2, 0)
+ * -- the cross products of the samples' gradients, all taken from the batch-start parameters (0: the samples' squares alone,
+ * the rule of rounds 1-4; one touch: nothing changes) */
+double orc_mb_ada_cross = 0.0;
+static double mb_norm_inc(double acc, double accn) {
+  const double c = acc * acc - accn;
+  return accn + (orc_mb_ada_cross != 0.0 && c > 0.0 ? orc_mb_ada_cross * c : 0.0);
+}
 
 typedef double (*mb_predict_fn)(const orc_csr* X, int64_t i, int n_blocks, int k, int degree,
                                 int n_aug, const double* Pt, const double* w, double intercept,
@@ -277,10 +286,10 @@ static int ada_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict
           accNw[j] += g * g;
         }
     }
-    for (size_t e = 0; e < np; e++) { gsum_P[e] += accG[e]; gnorm_P[e] += accN[e]; }
+    for (size_t e = 0; e < np; e++) { gsum_P[e] += accG[e]; gnorm_P[e] += mb_norm_inc(accG[e], accN[e]); }
     if (c->fit_linear)
-      for (int64_t j = 0; j < d; j++) { gsum_w[j] += accGw[j]; gnorm_w[j] += accNw[j]; }
-    if (c->fit_intercept) { *gsum_b += accGb; *gnorm_b += accNb; }
+      for (int64_t j = 0; j < d; j++) { gsum_w[j] += accGw[j]; gnorm_w[j] += mb_norm_inc(accGw[j], accNw[j]); }
+    if (c->fit_intercept) { *gsum_b += accGb; *gnorm_b += mb_norm_inc(accGb, accNb); }
     *it += p1 - p0;
     p0 = p1;
     batch_id++;

@@ -58,7 +58,10 @@ def test_cfg5_shape_degree3_sgd_vs_mb_oracle(cap):
     assert_close(sgd.history[0][0], vs, 1e-9, 0, "viol, permuted")
 
 
-def test_cfg4_shape_ffm_adagrad_vs_mb_oracle():
+@pytest.mark.parametrize("gamma", [0.0, 0.1])
+def test_cfg4_shape_ffm_adagrad_vs_mb_oracle(gamma):
+    """BASELINE configs[3] at the batch bench.py quotes it at since round 5 (32768, the dense regime with the refresh pass);
+    gamma = 0.1: WITH the batch's gradient cross products in g_norm (nfm_opt_set_ada_cross), the rule bench.py trains it with"""
     n, d, F, k, B = 6 * 32768 + 4097, 100_000, 16, 8, 32768  # it == 1 singleton + six full batches + a tail
     rng = np.random.default_rng(8)
     per = d // F
@@ -71,11 +74,11 @@ def test_cfg4_shape_ffm_adagrad_vs_mb_oracle():
     cfg = O.adagrad_cfg(loss="squared")
     P, w = P0.copy(), w0.copy()
     st = O.AdaState(F, d, k, d)
-    b, it, ls, vs = O.ffm_adagrad_epoch_mb(Xo, y, P, w, 0.0, cfg, B, st, it=1)
+    b, it, ls, vs = O.ffm_adagrad_epoch_mb(Xo, y, P, w, 0.0, cfg, B, st, it=1, ada_cross=gamma)
     b = O.ffm_adagrad_finalize(P, w, b, cfg, it, st)
     X = to_gpu(Xo)
     ffm = gpu_ffm("regression", k, True, True, P0, w0, 0.0)
-    ada = nf.newAdaGrad(maxIter=1, verbose=0, tol=0, shuffle=False, loss="squared", mode="minibatch", batch=B)
+    ada = nf.newAdaGrad(maxIter=1, verbose=0, tol=0, shuffle=False, loss="squared", mode="minibatch", batch=B, adaCross=gamma)
     ada.fit(X, y, ffm)
     assert ada.it == it == n + 1
     assert abs(ffm.intercept - b) < 1e-11
