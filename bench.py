@@ -36,13 +36,14 @@ WORKLOADS = {
     # name: n, d, m, k, degree, solver, loss   (SURVEY.md 8d / BASELINE.md)
     # cfg2 names no batch size; 32768 keeps the two dependent launches per batch off the critical path
     # (DESIGN.md section 7).  cfg3 uses the 8192 that BASELINE.json states.  The north-star headline (SGD, one GPU) names no batch:
-    # 131072 since round 5 -- the batch with the best seconds-to-target of the sweep 8192 ... 262144 (tools/r5_batch_sweep.sh,
-    # profiles/r05a_headline_batch_sweep.txt, r05f_headline_batch_sweep_big.txt: the same targets in the same number of epochs
-    # as at 8192 / 65536, 26 % / 14 % fewer seconds per epoch; at touch rate lambda = B m / d = 8.4 the column phase writes a row
-    # once per 8 touches; 262144 moves 7 % more samples per second but needs 2 / 4 / 17 epochs instead of 1 / 3 / 8);
-    # `value_batch_8192` on the line is the figure of rounds 1-4.
-    "cfg2": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768),
-    "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="logistic", batch=131072),
+    # 262144 with touch cap 32 since the end of round 5 (131072 / cap 16 before: profiles/r05a_headline_batch_sweep.txt,
+    # r05f_headline_batch_sweep_big.txt).  The sweeps at cap 16 found 262144 needing 2 / 4 / 17 epochs to the three targets where
+    # 131072 needs 1 / 3 / 8; the cap, not the batch, was the reason: at lambda = B m / d = 16.8 touches per coordinate and batch a
+    # cap of 16 already averages half the coordinates' steps.  With cap 32 (about twice lambda, as 16 is for lambda = 8.4) 262144
+    # reaches the targets in 1 / 3 / 7 epochs at 8.37e7 samples/s (profiles/r05h_touch_cap_sweep.txt); 524288 / cap 64 adds 1 %.
+    # `value_batch_8192` on the line is the figure of rounds 1-4.  cfg2: 65536 / cap 32 (1 / 3 / 10 epochs as at 32768 / 16, +7 %).
+    "cfg2": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=65536, touch_cap=32.0),
+    "headline": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="sgd", loss="logistic", batch=262144, touch_cap=32.0),
     "cfg3": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="squared", batch=8192),
     "cfg3c": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="squared", batch=8192, ada_cross=0.1),
     "cfg3l": dict(n=10_000_000, d=1_000_000, m=64, k=64, degree=2, solver="adagrad", loss="logistic", batch=8192),
@@ -620,7 +621,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
     else:
         fm = nf.newFactorizationMachine(task, degree=wl["degree"], nComponents=k, warmStart=True, randomState=1)
     fm.init(X)  # w = 0, P ~ N(0, 0.01^2) (Box-Muller pairs in fill order), intercept = 0 (factorization_machine.nim:125-139)
-    cap = float(args.touch_cap)
+    cap = float(args.touch_cap) if args.touch_cap > 0 else float(wl.get("touch_cap", 16.0))  # (per workload unless --touch-cap says otherwise)
     if wl["solver"] == "sgd":
         opt = nf.newSGD(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch", batch=batch, touchCap=cap)
     else:
@@ -634,7 +635,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         # the exchange lives in the library (csrc/dp.hip): one RCCL communicator per rank, the replicas reconciled every
         # sync_period mini-batches on a second stream beside the next period's mini-batches, exactly at the end of the
         # epoch; torch.distributed only carried the group id (dp.Group.from_torch, in main)
-        # an exchange about every 1e6 samples per rank (128 mini-batches of 8192, 8 of 131072) when the epoch has at least four
+        # an exchange about every 1e6 samples per rank (128 mini-batches of 8192, 4 of 262144) when the epoch has at least four
         # such stretches (half that for two); shorter epochs: the closing exchange only
         sp_ = max(1, 1_048_576 // batch)
         sync_period = args.sync_period if args.sync_period >= 0 else (sp_ if n // batch >= 4 * sp_ else (max(1, sp_ // 2) if n // batch >= 2 * sp_ else 0))
@@ -1184,14 +1185,15 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=1_000_000)
     ap.add_argument("--sync-period", type=int, default=-1,
                     help="N > 1: mini-batches between exchanges (0 = only at the end of every epoch; default: about every 1e6 samples "
-                         "per rank -- 128 mini-batches of 8192, 8 of 131072 -- for epochs of at least four such stretches, else 0)")
+                         "per rank -- 128 mini-batches of 8192, 4 of 262144 -- for epochs of at least four such stretches, else 0)")
     ap.add_argument("--combine", default="auto", choices=["auto", "mean", "sum", "state_mean", "state_cross"],
                     help="N > 1: how the ranks' increments are combined at an exchange (DESIGN.md section 6); auto = SGD: the mean, "
                          "AdaGrad: the state increments averaged (summed when the ranks exchange after every mini-batch)")
-    ap.add_argument("--touch-cap", type=float, default=16.0,
+    ap.add_argument("--touch-cap", type=float, default=0.0,
                     help="SGD mini-batch rule: steps of a batch on one coordinate that are summed before averaging sets in "
-                         "(nfm_opt_set_touch_cap; 1 = the per-coordinate mean, the library's default; 16 matches one "
-                         "sequential epoch's held-out loss per epoch on these workloads, time_to_target measures it)")
+                         "(nfm_opt_set_touch_cap; 1 = the per-coordinate mean, the library's default).  Default: per workload -- "
+                         "about twice the touches a coordinate gets per batch: 16 at lambda = B m / d ~ 10 (cfg5), 32 at ~ 17-21 "
+                         "(headline at 262144, cfg2 at 65536); time_to_target measures what it buys")
     ap.add_argument("--psgd-shape", default="", help="--workload psgd: d,m,k instead of the ml-100k shape")
     args = ap.parse_args()
 

@@ -35,6 +35,11 @@ static double mb_norm_inc(double acc, double accn) {
   return accn + (orc_mb_ada_cross != 0.0 && c > 0.0 ? orc_mb_ada_cross * c : 0.0);
 }
 
+/* EXPERIMENT (tests/sgd_agreement_proto.py; no counterpart in the library): instead of the touch cap, a coordinate's summed steps
+ * are divided by 1 + (c - 1) rho, rho = the samples' agreement on it, ((sum s_i)^2 - sum s_i^2) / ((c - 1) sum s_i^2) clamped to
+ * [0, 1] -- 1: all steps equal (the mean), 0: uncorrelated (the sum).  0: off */
+double orc_mb_sgd_agree = 0.0;
+
 typedef double (*mb_predict_fn)(const orc_csr* X, int64_t i, int n_blocks, int k, int degree,
                                 int n_aug, const double* Pt, const double* w, double intercept,
                                 double* A, double* dA);
@@ -81,6 +86,7 @@ static int sgd_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict
   double* accP = (double*)calloc(np ? np : 1, sizeof(double));
   double* accw = (double*)calloc(d ? d : 1, sizeof(double));
   double* cnt = (double*)calloc(da ? da : 1, sizeof(double));     /* c_j */
+  double* accP2 = (double*)calloc(np ? np : 1, sizeof(double));   /* experiment: sum of squared steps */
   double* setaP = (double*)calloc(da ? da : 1, sizeof(double));   /* sum of eta_P over touching samples */
   double* setaw = (double*)calloc(da ? da : 1, sizeof(double));
   double* A = (double*)calloc((size_t)k * (degree + 2), sizeof(double));
@@ -91,6 +97,7 @@ static int sgd_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict
     const int64_t p1 = p0 + batch < end ? p0 + batch : end;
     const double len = (double)(p1 - p0);
     memset(accP, 0, sizeof(double) * np);
+    if (orc_mb_sgd_agree != 0.0) memset(accP2, 0, sizeof(double) * np);
     memset(accw, 0, sizeof(double) * (size_t)d);
     memset(cnt, 0, sizeof(double) * (size_t)da);
     memset(setaP, 0, sizeof(double) * (size_t)da);
@@ -115,6 +122,7 @@ static int sgd_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict
           for (int s = 0; s < k; s++) {
             const size_t e = ((size_t)o * da + j) * k + s;
             accP[e] += etaP * (dL * dA[e]);
+            if (orc_mb_sgd_agree != 0.0) accP2[e] += (etaP * (dL * dA[e])) * (etaP * (dL * dA[e]));
           }
         if (c->fit_linear && q < r.m) accw[j] += etaw * (dL * r.val[q]);
       }
@@ -130,7 +138,16 @@ static int sgd_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict
       for (int o = 0; o < n_blocks; o++)
         for (int s = 0; s < k; s++) {
           const size_t e = ((size_t)o * da + j) * k + s;
-          if (cj > 0) {
+          if (cj > 0 && orc_mb_sgd_agree != 0.0) {
+            double se = 1.0;
+            if (cnt[j] > 1.0 && accP2[e] > 0.0) {
+              double rho = (accP[e] * accP[e] - accP2[e]) / ((cnt[j] - 1.0) * accP2[e]);
+              rho = rho < 0.0 ? 0.0 : (rho > 1.0 ? 1.0 : rho);
+              se = 1.0 + (cnt[j] - 1.0) * pow(rho, orc_mb_sgd_agree);
+            }
+            viol += fabs((accP[e] + setaP[j] * c->beta * Pt[e]) / se);
+            Pt[e] = DP * Pt[e] - accP[e] / se;
+          } else if (cj > 0) {
             viol += fabs((accP[e] + setaP[j] * c->beta * Pt[e]) / cj);
             Pt[e] = fP * Pt[e] - accP[e] / cj;
           } else {
@@ -157,7 +174,7 @@ static int sgd_epoch_mb(const orc_csr* X, const double* y, mb_predict_fn predict
   }
   *loss_sum = loss;
   *viol_sum = viol;
-  free(dA); free(accP); free(accw); free(cnt); free(setaP); free(setaw); free(A);
+  free(dA); free(accP); free(accP2); free(accw); free(cnt); free(setaP); free(setaw); free(A);
   return 0;
 }
 
