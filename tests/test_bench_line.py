@@ -126,7 +126,6 @@ def test_round5_detail_record_gives_a_complete_line(record, batch, frac):
         assert out["time_to_target"]["speedup_is_vs"] == "gpu exact order" and len(out["time_to_target"]["vs_cpu_port_1_thread"]) == 3
         assert out["value_shuffled"] > 0.86 * out["value"]  # positions of a device-drawn order computed from its key
     if record in ("r05f", "r05g", "r05h"):
-        assert bench.WORKLOADS["headline"]["batch"] == batch  # the record is of the workload table as it stands
         assert "r05f_headline_B131072_pmc_traffic.json" in full["roofline"]["traffic_source"]  # traffic of THIS batch
     hog = out["cpu_baseline"]["hogwild"]
     sweep = full["cpu_baseline"]["hogwild"]["sweep"]

@@ -39,11 +39,12 @@ def problem():
     return Xo, to_gpu(Xo), y, P0, w0
 
 
-@pytest.mark.parametrize("cap", [1.0, 16.0])
-def test_cfg2_fullsize_vs_mb_oracle(problem, cap):
+@pytest.mark.parametrize("cap,B", [(1.0, 32768), (16.0, 32768), (32.0, 65536)])
+def test_cfg2_fullsize_vs_mb_oracle(problem, cap, B):
     """cap = 16 is the rule bench.py trains cfg2 / the headline / cfg5 with (nfm_opt_set_touch_cap: up to 16 of a batch's
     steps on a coordinate summed, as that many Hogwild threads of optimizer/sgd_multi.nim:83-101 would; every feature is
-    touched ~10 times per batch here); cap = 1 the library's default (the per-coordinate mean)"""
+    touched ~10 times per batch here); cap = 1 the library's default (the per-coordinate mean); (32, 65536): what bench.py quotes cfg2 at
+    since the end of round 5 (~21 touches per feature and batch, up to 32 summed)"""
     Xo, X, y, P0, w0 = problem
     P, w, b, it = P0.copy(), w0.copy(), 0.0, 1
     hist = []
@@ -196,13 +197,13 @@ def test_headline_shape_adagrad_vs_mb_oracle(headline_problem):
     assert_close(ada.history[0][0], vs, 1e-9, 0, "viol")
 
 
-# ---- the headline at the batch bench.py quotes since round 5: 131072 (touch rate lambda = B m / d = 8.4: every feature of
-# the model is touched in every batch, a row is written once per ~8 touches, the touch cap of 16 bites on the tail of the
-# Poisson(8.4) touch counts).  Two full batches + a ragged one; cap 16 as in the bench.
-HB2 = 131072
-
-
-def test_headline_shape_at_the_bench_batch_131072():
+# ---- the headline at the batches bench.py quotes since round 5 (touch rate lambda = B m / d = 8.4 / 16.8: every feature of
+# the model is touched in every batch, a row is written once per ~8 / ~17 touches, the touch cap bites on the tail of the
+# Poisson touch counts).  Two full batches + a ragged one; the bench's cap.
+@pytest.mark.parametrize("HB2,cap", [(131072, 16.0), (262144, 32.0)])
+def test_headline_shape_at_the_bench_batch(HB2, cap):
+    """(131072, cap 16): the batch of most of round 5; (262144, cap 32): what bench.py quotes since its end -- lambda = 16.8 touches per
+    coordinate and batch, up to 32 of them summed"""
     n = 2 * HB2 + 4001
     Xo = big_csr(n, HD, HM, 47)
     rng = np.random.default_rng(5)
@@ -210,13 +211,13 @@ def test_headline_shape_at_the_bench_batch_131072():
     P0, w0 = (rng.standard_normal((1, HK, HD)) * 0.01), np.zeros(HD)
     cfg = O.sgd_cfg(loss="logistic")
     P, w = P0.copy(), w0.copy()
-    b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, 0.0, cfg, HB2, it=1, touch_cap=16.0)
+    b, it, ls, vs = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, 0.0, cfg, HB2, it=1, touch_cap=cap)
     # a second epoch over a permuted order (the plan of a shuffled epoch: the bucketing path)
     perm = np.random.default_rng(6).permutation(n).astype(np.int64)
-    b, it, ls2, vs2 = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, b, cfg, HB2, it=it, touch_cap=16.0, perm=perm)
+    b, it, ls2, vs2 = O.fm_sgd_epoch_mb(Xo, y, 2, P, w, b, cfg, HB2, it=it, touch_cap=cap, perm=perm)
     X = to_gpu(Xo)
     fm = gpu_fm("classification", 2, HK, "explicit", True, True, P0, w0, 0.0)
-    sgd = nf.newSGD(maxIter=1, verbose=0, tol=0, shuffle=False, loss="logistic", mode="minibatch", batch=HB2, touchCap=16.0)
+    sgd = nf.newSGD(maxIter=1, verbose=0, tol=0, shuffle=False, loss="logistic", mode="minibatch", batch=HB2, touchCap=cap)
     sgd._handle(fm, X.ctx, "minibatch")
     X.set_targets(y)
     l1, v1 = sgd._epoch(X, None, 0, n)
