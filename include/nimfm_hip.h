@@ -394,7 +394,10 @@ int32_t nfm_opt_set_dp_combine(nfm_opt* o, int32_t combine);
  * makes about 1 / c_bar of the sequential order's progress, c_bar = mean touch count per touched coordinate.  cap =
  * the reference's thread count gives its staleness; 16 matched one sequential epoch's held-out loss per epoch on the
  * bench workloads and stayed stable where the plain sum (cap = infinity) diverges on dense coordinates and the
- * intercept.  Deterministic for every value. */
+ * intercept.  Larger mini-batches want the cap to follow: with cap about twice the batch's mean touch
+ * count per coordinate (batch * nnz-per-row / n_features) the epochs to a held-out loss stay those of the sequential order
+ * (measured up to 32 at batch 262144 of the headline shape and 64 at 524288, profiles/r05h_touch_cap_sweep.txt); a cap
+ * below that rate turns the tail of the batch into the mean.  Deterministic for every value. */
 int32_t nfm_opt_set_touch_cap(nfm_opt* o, double cap);
 /* AdaGrad, NFM_MODE_MINIBATCH (round 5): what a mini-batch adds to a coordinate's g_norm (optimizer/adagrad.nim:122-124 adds
  * g^2 per sample).  All samples of a batch take their gradients from the batch-start parameters; summing their squares alone
