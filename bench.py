@@ -55,8 +55,10 @@ WORKLOADS = {
     # reach the held-out loss of ten sequential epochs in 40 of its own (time_to_target, measured in round 4: 32768: 13 / 28 /
     # never; 8192: 4 / 8 / 20 epochs; 2048: 2 / 4 / 11 epochs and the best speed-up); "cfg4big" keeps the bandwidth figure
     # Round 5: batch 32768 again, with the batch's gradient cross products in g_norm (nfm_opt_set_ada_cross, gamma 0.1): the same
-    # 2 / 4 / 11 epochs to the three targets as batch 2048 needs, at twice the samples per second ("cfg4b2048": rounds 4 / early 5)
-    "cfg4": dict(n=1_000_000, d=100_000, m=16, k=8, degree=2, solver="adagrad", loss="squared", batch=32768, fields=16, ada_cross=0.1),
+    # 2 / 4 / 11 epochs to the three targets as batch 2048 needs, at twice the samples per second ("cfg4b2048": rounds 4 / early 5);
+    # 65536 (the end of round 5): 2 / 4 / 12 epochs, every target in fewer seconds than at 32768 (speed-ups 31 / 48 / 55 against
+    # 25 / 39 / 48), 6.3e7 samples/s, frac 0.53 (32768: 5.0e7, 0.43; 131072: 7.2e7, 0.60, but 2 / 5 / 14 epochs and no faster to the targets)
+    "cfg4": dict(n=1_000_000, d=100_000, m=16, k=8, degree=2, solver="adagrad", loss="squared", batch=65536, fields=16, ada_cross=0.1),
     "cfg4b2048": dict(n=1_000_000, d=100_000, m=16, k=8, degree=2, solver="adagrad", loss="squared", batch=2048, fields=16),
     "cfg4big": dict(n=1_000_000, d=100_000, m=16, k=8, degree=2, solver="adagrad", loss="squared", batch=32768, fields=16),
     # cfg4 with three low-cardinality fields (2, 7 and 50 distinct features): their features are touched by a
@@ -935,19 +937,26 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
             dist.barrier()
         opt.setDataParallel(None)
     if rank == 0:
-        ctx.timing_reset()
+        # five epochs, each timed on its own; the figures are those of the MEDIAN epoch (by the time of a mini-batch's launches), so that one
+        # stall of the box -- seen once: a row phase average of 1.70 ms in two epochs whose timed region ran it at 1.41 -- does not
+        # stand for the kernel; every epoch's figure is kept beside it ("pair_ms_epochs")
+        fams_ = ("row_phase", "singles", "col_phase", "heavy_partial", "heavy_apply", "refresh", "schedule")
         ctx.timing_enable(True)
-        reps = 2
+        reps, epochs_ = 5, []
         for _ in range(reps):
+            ctx.timing_reset()
             opt._epoch(X, None, 0, n)
             opt.it += n
-        ctx.synchronize()
-        fam = {f: ctx.timing_get(f) for f in ("row_phase", "singles", "col_phase", "heavy_partial", "heavy_apply", "refresh", "schedule")}
+            ctx.synchronize()
+            fam_ = {f: ctx.timing_get(f) for f in fams_}
+            ms_ = {f: (fam_[f][1] / fam_[f][0] if fam_[f][0] else 0.0) for f in fam_}
+            pair_ = (ms_["row_phase"] + ms_["singles"] + ms_["col_phase"]
+                     + (fam_["heavy_partial"][1] + fam_["heavy_apply"][1] + fam_["refresh"][1]) / max(fam_["row_phase"][0], 1))
+            epochs_.append((pair_, fam_, ms_))
         ctx.timing_enable(False)
-        n_batches = fam["row_phase"][0] / reps
-        per_batch_ms = {f: (fam[f][1] / fam[f][0] if fam[f][0] else 0.0) for f in fam}
-        pair_ms = (per_batch_ms["row_phase"] + per_batch_ms["singles"] + per_batch_ms["col_phase"]
-                   + (fam["heavy_partial"][1] + fam["heavy_apply"][1] + fam["refresh"][1]) / max(fam["row_phase"][0], 1))
+        pair_ms, fam, per_batch_ms = sorted(epochs_, key=lambda e_: e_[0])[reps // 2]
+        n_batches = fam["row_phase"][0]
+        reps = 1  # (fam holds ONE epoch's counts)
         bps = algorithmic_bytes_per_sample(wl["solver"], m, k, n_orders, F)
         units = n / n_batches
         achieved = bps * units / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
@@ -966,6 +975,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                 "algorithmic_bytes_per_minibatch": bps * units,
                 "bytes_per_sample": bps, "samples_per_launch": units,
                 "avg_ms": {f: round(per_batch_ms[f], 5) for f in per_batch_ms},
+                "avg_over": "the median of 5 epochs, each timed on its own", "pair_ms_epochs": [round(e_[0], 5) for e_ in epochs_],
                 "launches_per_step": {f: fam[f][0] / reps for f in fam}}
 
     cpu = None
@@ -1068,7 +1078,7 @@ def _roof_compact(r):
         return None
     return {"bound": r["bound"], "kernel": _short(r.get("kernel"), 100), "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
             "frac": r["frac"], "traffic": r.get("traffic"), "traffic_source": _short(r.get("traffic_source"), 60) if r.get("traffic_source") else None,
-            "algorithmic_bytes_per_launch_pair": r.get("algorithmic_bytes_per_minibatch"),
+            "algorithmic_bytes_per_launch_pair": r.get("algorithmic_bytes_per_minibatch"), "avg_over": r.get("avg_over"),
             "avg_ms": {k_: v_ for k_, v_ in (r.get("avg_ms") or {}).items() if v_}}
 
 

@@ -58,11 +58,11 @@ def test_cfg5_shape_degree3_sgd_vs_mb_oracle(cap):
     assert_close(sgd.history[0][0], vs, 1e-9, 0, "viol, permuted")
 
 
-@pytest.mark.parametrize("gamma", [0.0, 0.1])
-def test_cfg4_shape_ffm_adagrad_vs_mb_oracle(gamma):
-    """BASELINE configs[3] at the batch bench.py quotes it at since round 5 (32768, the dense regime with the refresh pass);
-    gamma = 0.1: WITH the batch's gradient cross products in g_norm (nfm_opt_set_ada_cross), the rule bench.py trains it with"""
-    n, d, F, k, B = 6 * 32768 + 4097, 100_000, 16, 8, 32768  # it == 1 singleton + six full batches + a tail
+@pytest.mark.parametrize("gamma,B", [(0.0, 32768), (0.1, 32768), (0.1, 65536)])
+def test_cfg4_shape_ffm_adagrad_vs_mb_oracle(gamma, B):
+    """BASELINE configs[3] at the batches bench.py quotes it at since round 5 (32768, then 65536: the dense regime with the refresh
+    pass); gamma = 0.1: WITH the batch's gradient cross products in g_norm (nfm_opt_set_ada_cross), the rule bench.py trains it with"""
+    n, d, F, k = 6 * 32768 + 4097, 100_000, 16, 8  # it == 1 singleton + six (three) full batches + a tail
     rng = np.random.default_rng(8)
     per = d // F
     idx = rng.integers(0, per, size=(n, F)) + np.arange(F) * per  # field f owns [f d/F, (f+1) d/F) (tests/utils.nim:66-68)
