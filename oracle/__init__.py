@@ -76,14 +76,14 @@ class variant:
     def __enter__(self):
         global _lib
         self.prev = _lib
-        if self.name == "timing":
-            if "timing" not in _libs:
-                so = os.path.join(_HERE, "_build", "libnimfm_oracle_timing.so")
+        if self.name in ("timing", "fma"):  # ("fma": contraction on -- tools/fuzz_mb.py's conditioning yardstick, never a parity build)
+            if self.name not in _libs:
+                so = os.path.join(_HERE, "_build", "libnimfm_oracle_%s.so" % self.name)
                 if os.path.exists(so):
                     os.remove(so)  # -march=native: never reuse a build made on another host
-                subprocess.check_call(["make", "-C", _HERE, "-s", "timing"])
-                _libs["timing"] = _load(so)
-            _lib = _libs["timing"]
+                subprocess.check_call(["make", "-C", _HERE, "-s", self.name])
+                _libs[self.name] = _load(so)
+            _lib = _libs[self.name]
         else:
             _lib = None
             lib()

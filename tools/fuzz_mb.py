@@ -1,13 +1,17 @@
 """Random mini-batch configurations against the CPU restatement of the rule (oracle/nimfm_mb.c): shapes, batch sizes,
 orders, solvers, losses, row lengths (ragged, empty rows, a few very popular features), with and without a permutation.
 Not part of the test suite -- a robustness sweep to run on a GPU box after kernel or plan changes.
-usage: python tools/fuzz_mb.py [n_cases] [seed]"""
+usage: python tools/fuzz_mb.py [n_cases] [seed]      (FUZZ_CPU_TWIN=1: no GPU -- the oracle's parity build against its -O3 -march=native
+build on the same draws: what two correct implementations of the rule differ by, case by case)"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, R + "/tests")
 import numpy as np
-import nimfm_amd as nf, oracle as O
-from gpu_common import gpu_ffm, gpu_fm, to_gpu
+import oracle as O
+CPU_TWIN = os.environ.get("FUZZ_CPU_TWIN") == "1"  # no GPU: two CPU builds of the rule against each other (how ill-conditioned is a draw)
+if not CPU_TWIN:
+    import nimfm_amd as nf
+    from gpu_common import gpu_ffm, gpu_fm, to_gpu
 from common import init_ffm
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -24,6 +28,8 @@ for case in range(n_cases):
     degree = int(rng.choice([2, 2, 2, 3]))
     ffm = degree == 2 and rng.random() < 0.25 and k <= 16
     hot = rng.random() < 0.3  # a few features that most samples have
+    cap = float(rng.choice([1.0, 1.0, 2.0, 16.0, 32.0]))    # SGD: nfm_opt_set_touch_cap (round 5: the bench runs 16 / 32)
+    gamma = float(rng.choice([0.0, 0.0, 0.1, 0.5]))         # AdaGrad: nfm_opt_set_ada_cross (round 5)
     rows, vals, indptr = [], [], [0]
     for i in range(n):
         m = 0 if rng.random() < 0.05 else int(rng.integers(1, max_m + 1))
@@ -43,8 +49,31 @@ for case in range(n_cases):
         y = np.sign(y) + (y == 0)
     epochs = 2
     perms = np.stack([rng.permutation(n) for _ in range(epochs)]).astype(np.int64) if rng.random() < 0.6 else None
-    tag = "case %d: n=%d d=%d k=%d m<=%d B=%d %s %s deg=%d ffm=%s hot=%s perm=%s" % (case, n, d, k, max_m, B, solver, loss, degree, ffm, hot, perms is not None)
+    tag = "case %d: n=%d d=%d k=%d m<=%d B=%d %s %s deg=%d ffm=%s hot=%s perm=%s cap=%g gamma=%g" % (case, n, d, k, max_m, B, solver, loss, degree, ffm, hot, perms is not None, cap, gamma)
     try:
+        def cpu_fit(Xo, P0, w0, b0, F):
+            """the rule on the CPU (oracle/nimfm_mb.c) from this start: (P, w, b)"""
+            P, w, b, it = P0.copy(), w0.copy(), b0, 1
+            pe = lambda e: None if perms is None else perms[e]
+            if solver == "sgd":
+                cfg = O.sgd_cfg(eta0=0.01, loss=loss)
+                for e in range(epochs):
+                    if F:
+                        b, it, _, _ = O.ffm_sgd_epoch_mb(Xo, y, P, w, b, cfg, B, perm=pe(e), it=it, touch_cap=cap)
+                    else:
+                        b, it, _, _ = O.fm_sgd_epoch_mb(Xo, y, degree, P, w, b, cfg, B, perm=pe(e), it=it, touch_cap=cap)
+            else:
+                cfg = O.adagrad_cfg(loss=loss)
+                st = O.AdaState(F if F else degree - 1, d, k, d)
+                for e in range(epochs):
+                    if F:
+                        b, it, _, _ = O.ffm_adagrad_epoch_mb(Xo, y, P, w, b, cfg, B, st, perm=pe(e), it=it, ada_cross=gamma)
+                    else:
+                        b, it, _, _ = O.fm_adagrad_epoch_mb(Xo, y, degree, P, w, b, cfg, B, st, perm=pe(e), it=it, ada_cross=gamma)
+                b = O.ffm_adagrad_finalize(P, w, b, cfg, it, st) if F else O.fm_adagrad_finalize(degree, P, w, b, cfg, it, st)
+            return P, w, b
+
+        F = 0
         if ffm:
             F = int(rng.integers(2, 9))
             field_of = rng.integers(0, F, size=d)
@@ -52,39 +81,22 @@ for case in range(n_cases):
             if np.diff(Xo.indptr).max(initial=0) > 64:
                 continue
             P0, w0, b0 = init_ffm(d, F, k, scale=0.05)
-            P, w, b, it = P0.copy(), w0.copy(), b0, 1
-            mdl = gpu_ffm(task, k, True, True, P0, w0, b0)
-            if solver == "sgd":
-                cfg = O.sgd_cfg(eta0=0.01, loss=loss)
-                for e in range(epochs):
-                    b, it, _, _ = O.ffm_sgd_epoch_mb(Xo, y, P, w, b, cfg, B, perm=None if perms is None else perms[e], it=it)
-                opt = nf.newSGD(maxIter=epochs, eta0=0.01, loss=loss, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B)
-            else:
-                cfg = O.adagrad_cfg(loss=loss)
-                st = O.AdaState(F, d, k, d)
-                for e in range(epochs):
-                    b, it, _, _ = O.ffm_adagrad_epoch_mb(Xo, y, P, w, b, cfg, B, st, perm=None if perms is None else perms[e], it=it)
-                b = O.ffm_adagrad_finalize(P, w, b, cfg, it, st)
-                opt = nf.newAdaGrad(maxIter=epochs, loss=loss, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B)
         else:
             Xo = O.Dataset(np.array(indptr), idx, val, n, d)
-            nb = degree - 1
-            P0, w0, b0 = rng.standard_normal((nb, k, d)) * 0.05, rng.standard_normal(d) * 0.01, 0.1
-            P, w, b, it = P0.copy(), w0.copy(), b0, 1
-            mdl = gpu_fm(task, degree, k, "explicit", True, True, P0, w0, b0)
+            P0, w0, b0 = rng.standard_normal((degree - 1, k, d)) * 0.05, rng.standard_normal(d) * 0.01, 0.1
+        P, w, b = cpu_fit(Xo, P0, w0, b0, F)
+        if CPU_TWIN:  # the yardstick: the SAME rule and sources built with fused multiply-adds (oracle/Makefile target fma) against the parity build
+            with O.variant("fma"):
+                P2, w2, b2 = cpu_fit(Xo, P0, w0, b0, F)
+            class _M: pass
+            mdl = _M(); mdl.P, mdl.w, mdl.intercept = P2, w2, b2
+        else:
+            mdl = gpu_ffm(task, k, True, True, P0, w0, b0) if F else gpu_fm(task, degree, k, "explicit", True, True, P0, w0, b0)
             if solver == "sgd":
-                cfg = O.sgd_cfg(eta0=0.01, loss=loss)
-                for e in range(epochs):
-                    b, it, _, _ = O.fm_sgd_epoch_mb(Xo, y, degree, P, w, b, cfg, B, perm=None if perms is None else perms[e], it=it)
-                opt = nf.newSGD(maxIter=epochs, eta0=0.01, loss=loss, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B)
+                opt = nf.newSGD(maxIter=epochs, eta0=0.01, loss=loss, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B, touchCap=cap)
             else:
-                cfg = O.adagrad_cfg(loss=loss)
-                st = O.AdaState(nb, d, k, d)
-                for e in range(epochs):
-                    b, it, _, _ = O.fm_adagrad_epoch_mb(Xo, y, degree, P, w, b, cfg, B, st, perm=None if perms is None else perms[e], it=it)
-                b = O.fm_adagrad_finalize(degree, P, w, b, cfg, it, st)
-                opt = nf.newAdaGrad(maxIter=epochs, loss=loss, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B)
-        opt.fit(to_gpu(Xo), y, mdl, perms=perms)
+                opt = nf.newAdaGrad(maxIter=epochs, loss=loss, verbose=0, tol=0, shuffle=False, mode="minibatch", batch=B, adaCross=gamma)
+            opt.fit(to_gpu(Xo), y, mdl, perms=perms)
         if not np.isfinite(P).all() or float(np.abs(P).max()) > 1e3:
             print("diverged on the CPU as well (step size too large for this draw), skipped:", tag, flush=True)
             continue
