@@ -76,7 +76,7 @@ class variant:
     def __enter__(self):
         global _lib
         self.prev = _lib
-        if self.name in ("timing", "fma"):  # ("fma": contraction on -- tools/fuzz_mb.py's conditioning yardstick, never a parity build)
+        if self.name in ("timing", "fma"):  # ("fma": contraction on -- tests/fuzz_mb.py's conditioning yardstick, never a parity build)
             if self.name not in _libs:
                 so = os.path.join(_HERE, "_build", "libnimfm_oracle_%s.so" % self.name)
                 if os.path.exists(so):

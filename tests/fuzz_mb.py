@@ -1,7 +1,7 @@
 """Random mini-batch configurations against the CPU restatement of the rule (oracle/nimfm_mb.c): shapes, batch sizes,
 orders, solvers, losses, row lengths (ragged, empty rows, a few very popular features), with and without a permutation.
 Not part of the test suite -- a robustness sweep to run on a GPU box after kernel or plan changes.
-usage: python tools/fuzz_mb.py [n_cases] [seed]      (FUZZ_CPU_TWIN=1: no GPU -- the oracle's parity build against its -O3 -march=native
+usage: python tests/fuzz_mb.py [n_cases] [seed]      (FUZZ_CPU_TWIN=1: no GPU -- the oracle's parity build against its -O3 -march=native
 build on the same draws: what two correct implementations of the rule differ by, case by case)"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,7 +1,7 @@
 """Random configurations of NFM_MODE_SEQUENTIAL (the reference's sample-by-sample order) against the reference-faithful CPU
 restatement: shapes, orders, solvers, losses, ragged / empty rows, popular features, with and without a permutation.
 Not part of the test suite -- a robustness sweep to run on a GPU box after changes to csrc/seq.hip.
-usage: python tools/fuzz_seq.py [n_cases] [seed]"""
+usage: python tests/fuzz_seq.py [n_cases] [seed]"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, R + "/tests")

@@ -2,7 +2,7 @@
 (loss.nim:33-48) and Huber (loss.nim:84-93, sign quirk kept) -- x SGD / AdaGrad x FM (degree 2 and 3) / field-aware,
 on seeded random shapes (ragged rows, empty rows, unsorted storage order, a few very popular features, with and without
 a permutation per epoch), against the CPU restatement of the rule (oracle/nimfm_mb.c: O.*_epoch_mb).  The cases are the
-generator of tools/fuzz_mb.py with fixed seeds."""
+generator of tests/fuzz_mb.py with fixed seeds."""
 import itertools
 
 import numpy as np
