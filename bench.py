@@ -753,6 +753,25 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         value_b8192 = round(n * 3 / (time.perf_counter() - t8), 1)
         del opt8
 
+    # ---- AdaGrad without the stopping criterion's sum (trackViol = false): adagrad.nim:99 adds |P_old - P_new| per coordinate, which is
+    # what makes a single-touch row SIX streams (g_sum, g_norm and the parameters as last stored, read and written) instead of four;
+    # a caller that fits with tol <= 0 never reads it.  A secondary figure -- `value` always tracks it, as the reference does. ----
+    value_no_viol = None
+    if wl["solver"] == "adagrad" and rank == 0 and world == 1 and not args.no_viol and not args.no_shuffled:
+        optv = nf.newAdaGrad(maxIter=1, loss=wl["loss"], verbose=0, tol=0, shuffle=False, mode="minibatch",
+                             batch=batch, trackViol=False, adaCross=float(wl.get("ada_cross", 0.0)))
+        optv._handle(fm, ctx, "minibatch")
+        optv.it = opt.it
+        for ev in range(4):
+            if ev == 1:
+                fence()
+                tv = time.perf_counter()
+            optv._epoch(X, None, 0, n)
+            optv.it += n
+        fence()
+        value_no_viol = round(n * 3 / (time.perf_counter() - tv), 1)
+        del optv
+
     # ---- predict samples/s (the metric's second half): decisionFunction over the shard, output on device ----
     pred = None
     if rank == 0:
@@ -1020,7 +1039,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
         if exact.get("no_intercept"):  # (the CPU port's step costs the same with or without the intercept's three flops)
             exact["no_intercept"]["vs_cpu_port_1_thread"] = round(exact["no_intercept"]["value"] / cpu["value"], 2)
     return {"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "steps": steps, "warmup": warmup,
-            "value_batch_8192": value_b8192,
+            "value_batch_8192": value_b8192, "value_no_viol": value_no_viol,
             "value_shuffled": None if math.isnan(value_shuffled) else round(value_shuffled, 1),
             "value_shuffled_host_perm": None if math.isnan(value_shuffled_host) else round(value_shuffled_host, 1),
             "shuffled_note": "%d epochs, each over a fresh random order drawn on the device, the next epoch's batch plan built on "
@@ -1103,7 +1122,7 @@ def _extra_compact(e):
     return {"workload": _short(e["config"]["workload"], 130), "value": e["value"], "ms_per_step": e["ms_per_step"], "steps": e["steps"],
             "batch": e["config"]["batch"], "frac": roof.get("frac"),
             "traffic_ratio": round(traffic / alg, 3) if traffic and alg else None,
-            "value_shuffled": e.get("value_shuffled"),
+            "value_shuffled": e.get("value_shuffled"), **({"value_no_viol": e["value_no_viol"]} if e.get("value_no_viol") else {}),
             "predict": (e.get("predict") or {}).get("value"), "predict_frac": (e.get("predict") or {}).get("roofline_frac"),
             "exact_order": (e.get("exact_order") or {}).get("value"), "exact_bit_equal": (e.get("exact_order") or {}).get("bit_equal"),
             "exact_max_rel_diff": (e.get("exact_order") or {}).get("max_rel_diff"),
