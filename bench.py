@@ -71,7 +71,8 @@ WORKLOADS = {
     "tiny": dict(n=50_000, d=5_000, m=16, k=8, degree=2, solver="sgd", loss="logistic", batch=4096),
     # more than 128 factors (round 5: the factors of an order as device blocks of at most 128, csrc/common.h ModelView::kc):
     # the headline's data with k = 256 (two blocks of 128: 1 KB rows, 2 GB of parameters) and k = 200 (two blocks of 100)
-    "wide256": dict(n=2_000_000, d=1_000_000, m=64, k=256, degree=2, solver="sgd", loss="logistic", batch=32768),
+    # (batch 32768 / cap 16: 1.40e7 samples/s, 0.46 of the roofline; 131072 / 16: 2.22e7, 0.74; 262144 / 32, the headline's setting: 2.41e7, 0.80)
+    "wide256": dict(n=2_000_000, d=1_000_000, m=64, k=256, degree=2, solver="sgd", loss="logistic", batch=262144, touch_cap=32.0),
     "wide200a": dict(n=2_000_000, d=1_000_000, m=64, k=200, degree=2, solver="adagrad", loss="squared", batch=8192),
     # cfg2 with Zipf(1.1) feature popularity: a few features are touched by most samples of a batch
     "cfg2z": dict(n=1_000_000, d=100_000, m=32, k=16, degree=2, solver="sgd", loss="logistic", batch=32768, zipf=1.1),
