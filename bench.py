@@ -1048,7 +1048,7 @@ def run_training(args, name, torch, nf, dist, rank, world, dev, ctx, primary):
                              "over by the host (upload, validation, plan build, un-graphed launches all in the timed region)"
                              % (ks, kh),
             "config": {"workload": "%s: synthetic CSR %dx%d, %d nnz/row, k=%d, %s %s loss, mini-batch %d, "
-                                   "mode=minibatch" % (name, n, d, m, k, wl["solver"].upper(), wl["loss"], batch),
+                                   "mode=minibatch, fixed order (value_shuffled: a fresh order per epoch)" % (name, n, d, m, k, wl["solver"].upper(), wl["loss"], batch),
                        "update_rule": "this library's deterministic mini-batch rule (all samples of a batch see the batch-start "
                                       "parameters; per coordinate the batch's per-sample steps are %s, DESIGN.md section 4) -- NOT the "
                                       "reference's sample-by-sample order, which NFM_MODE_SEQUENTIAL reproduces (exact_order: its "
@@ -1120,7 +1120,7 @@ def _extra_compact(e):
     roof, t = e.get("roofline") or {}, _t2t_compact(e.get("time_to_target"))
     traffic = roof.get("traffic")
     alg = roof.get("algorithmic_bytes_per_minibatch")
-    return {"workload": _short(e["config"]["workload"], 130), "value": e["value"], "ms_per_step": e["ms_per_step"], "steps": e["steps"],
+    return {"workload": _short(e["config"]["workload"], 170), "value": e["value"], "ms_per_step": e["ms_per_step"], "steps": e["steps"],
             "batch": e["config"]["batch"], "frac": roof.get("frac"),
             "traffic_ratio": round(traffic / alg, 3) if traffic and alg else None,
             "value_shuffled": e.get("value_shuffled"), **({"value_no_viol": e["value_no_viol"]} if e.get("value_no_viol") else {}),
@@ -1142,7 +1142,7 @@ def contract_line(full):
     cfg = full["config"]
     out = {k_: full[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                    "scaling", "vs_baseline", "dtype", "data")}
-    out["config"] = {"workload": _short(cfg["workload"], 160), "batch": cfg.get("batch"), "touch_cap": cfg.get("touch_cap"),
+    out["config"] = {"workload": _short(cfg["workload"], 180), "batch": cfg.get("batch"), "touch_cap": cfg.get("touch_cap"),
                      "update_rule": _short(cfg.get("update_rule_short") or cfg.get("update_rule"), 120), "parallelism": _short(cfg.get("parallelism"), 120)}
     out["value_shuffled"] = full.get("value_shuffled")
     out["value_batch_8192"] = full.get("value_batch_8192")

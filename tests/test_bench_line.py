@@ -103,7 +103,7 @@ def test_contract_line_of_a_multi_gpu_run():
     assert out["roofline"]["frac"] == full["roofline"]["frac"]
 
 
-@pytest.mark.parametrize("record,batch,frac", [("r05d", 65536, 0.5), ("r05f", 131072, 0.6), ("r05g", 131072, 0.6), ("r05h", 131072, 0.6), ("r05i", 262144, 0.68), ("r05j", 262144, 0.68), ("r05k", 262144, 0.68)])
+@pytest.mark.parametrize("record,batch,frac", [("r05d", 65536, 0.5), ("r05f", 131072, 0.6), ("r05g", 131072, 0.6), ("r05h", 131072, 0.6), ("r05i", 262144, 0.68), ("r05j", 262144, 0.68), ("r05k", 262144, 0.68), ("r05l", 262144, 0.68)])
 def test_round5_detail_record_gives_a_complete_line(record, batch, frac):
     """this round's own detail records (profiles/r05d_default_bench_detail.json: headline batch 65536; r05f: 131072, the batch
     bench.py quotes now) through contract_line: under 6 KB, and the fields round 5 added are there -- the headline's value at
@@ -118,9 +118,11 @@ def test_round5_detail_record_gives_a_complete_line(record, batch, frac):
     out = json.loads(line)
     assert out["config"]["batch"] == batch and out["value_batch_8192"] and out["value_batch_8192"] < out["value"]
     assert out["roofline"]["frac"] > frac
-    if record == "r05k":  # AdaGrad without the stopping criterion's sum beside the figure that tracks it (the figure quoted)
+    if record == "r05l":  # the wording says which of the two rates `value` is
+        assert "fixed order (value_shuffled: a fresh order per epoch)" in out["config"]["workload"] and len(line) < 5400
+    if record in ("r05k", "r05l"):  # AdaGrad without the stopping criterion's sum beside the figure that tracks it (the figure quoted)
         assert out["extra"]["cfg3"]["value_no_viol"] > 1.15 * out["extra"]["cfg3"]["value"] and "value_no_viol" not in out["extra"]["cfg2"]
-    if record in ("r05j", "r05k"):  # cfg4 at batch 65536; the roofline leg's figures are those of the median of five epochs
+    if record in ("r05j", "r05k", "r05l"):  # cfg4 at batch 65536; the roofline leg's figures are those of the median of five epochs
         c4 = out["extra"]["cfg4"]
         assert c4["batch"] == 65536 == bench.WORKLOADS["cfg4"]["batch"] and c4["frac"] > 0.5 and c4["reached"] is True and min(c4["t2t_speedup"]) > 25
         assert "median of 5 epochs" in out["roofline"]["avg_over"] and len(full["roofline"]["pair_ms_epochs"]) == 5
@@ -128,12 +130,12 @@ def test_round5_detail_record_gives_a_complete_line(record, batch, frac):
         c4 = out["extra"]["cfg4"]
         assert c4["batch"] == 32768 and c4["frac"] > 0.4 and c4["reached"] is True and min(c4["t2t_speedup"]) > 20
         assert bench.WORKLOADS["cfg4"]["ada_cross"] == 0.1
-    if record in ("r05g", "r05h", "r05i", "r05j", "r05k"):  # (the line says what time_to_target's speed-ups are against)
+    if record in ("r05g", "r05h", "r05i", "r05j", "r05k", "r05l"):  # (the line says what time_to_target's speed-ups are against)
         assert out["time_to_target"]["speedup_is_vs"] == "gpu exact order" and len(out["time_to_target"]["vs_cpu_port_1_thread"]) == 3
         assert out["value_shuffled"] > 0.86 * out["value"]  # positions of a device-drawn order computed from its key
     if record in ("r05f", "r05g", "r05h"):
         assert "r05f_headline_B131072_pmc_traffic.json" in full["roofline"]["traffic_source"]  # traffic of THIS batch
-    if record in ("r05i", "r05j", "r05k"):  # the workload table as it stands: the headline at 262144 / cap 32, cfg2 at 65536 / cap 32, PMC of THAT batch
+    if record in ("r05i", "r05j", "r05k", "r05l"):  # the workload table as it stands: the headline at 262144 / cap 32, cfg2 at 65536 / cap 32, PMC of THAT batch
         assert bench.WORKLOADS["headline"]["batch"] == batch and bench.WORKLOADS["headline"]["touch_cap"] == 32.0
         assert bench.WORKLOADS["cfg2"]["batch"] == 65536 == out["extra"]["cfg2"]["batch"] and out["extra"]["cfg2"]["frac"] > 0.65
         assert "r05i_headline_B262144_pmc_traffic.json" in full["roofline"]["traffic_source"] and out["config"]["touch_cap"] == 32.0
