@@ -10,5 +10,5 @@ from ._capi import NfmError, NotFittedError, build, lib  # noqa: F401
 from .host import (L1, L21, MBPSGD, SquaredL12, SquaredL21, newL1, newL21, newMBPSGD, predictAllWithGrad, newSquaredL12, newSquaredL21,  # noqa: F401
                    AdaGrad, Context, CSRDataset, StreamCSRDataset, NimRand, randomNormal, randomize, FactorizationMachine, FieldAwareFactorizationMachine, SGD,  # noqa: F401
                    accuracy, convertSVMLightFile, default_context, expit, load, loadFFMFile, loadSVMLightFile, newAdaGrad, newCSRDataset, newCSRFieldDataset,
-                   newFactorizationMachine, newFieldAwareFactorizationMachine, newSGD, newStreamCSRDataset, parseText, rmse,
+                   newFactorizationMachine, newFieldAwareFactorizationMachine, newSGD, newStreamCSRDataset, parseText, rmse, suggestTouchCap,
                    set_default_context)

@@ -1149,6 +1149,22 @@ class AdaGrad(_OptimizerBase):
         return gs, gn, gsw, gnw, gsb.value, gnb.value
 
 
+def suggestTouchCap(X, batch):
+    """A touch cap for `newSGD(mode="minibatch", batch=batch, touchCap=...)` on dataset X (anything with nSamples, nFeatures,
+    nnz): about twice the mean number of a batch's samples that touch one coordinate, lambda = batch * (entries per row) /
+    nFeatures, as a power of two between 16 and 64 -- the settings measured to keep the epochs to a held-out loss of the
+    reference's sample order (profiles/r05h_touch_cap_sweep.txt: 16 up to lambda ~ 10, 32 at 17-21,
+    64 at 34).  Not a default: the library's own default stays 1, the per-coordinate mean (include/nimfm_hip.h)."""
+    n, d, nnz = int(X.nSamples), int(X.nFeatures), int(X.nnz)
+    if n <= 0 or d <= 0 or int(batch) < 1:
+        raise ValueError("suggestTouchCap: empty dataset or batch < 1.")
+    lam = min(int(batch), n) * (nnz / n) / d
+    cap = 16.0
+    while cap < 64.0 and 2.0 * lam > cap * 2.0 ** 0.5:  # (to the nearest power of two in the logarithm)
+        cap *= 2.0
+    return cap
+
+
 def newSGD(maxIter=100, eta0=0.01, alpha0=1e-6, alpha=1e-3, beta=1e-3, loss="squared", scheduling="optimal",
            power=1.0, verbose=1, tol=1e-3, shuffle=True, nCalls=-1, **gpu):
     return SGD(maxIter, eta0, alpha0, alpha, beta, loss, scheduling, power, verbose, tol, shuffle, nCalls, **gpu)
