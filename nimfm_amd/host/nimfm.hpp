@@ -245,6 +245,7 @@ class SGD {
   int maxIter; double eta0, alpha0, alpha, beta; L loss; SchedulingKind scheduling; double power;
   int verbose; double tol; bool shuffle; int nCalls; int64_t it = 1;
   int mode = NFM_MODE_SEQUENTIAL; int64_t batch = 8192;
+  double touchCap = 1.0;  // mini-batch mode: nfm_opt_set_touch_cap (1 = the per-coordinate mean; about twice the touches per coordinate and batch)
   // newSGD, optimizer/sgd.nim:23-52
   explicit SGD(int maxIter_ = 100, double eta0_ = 0.01, double alpha0_ = 1e-6, double alpha_ = 1e-3, double beta_ = 1e-3,
                L loss_ = L(), SchedulingKind scheduling_ = optimal, double power_ = 1.0, int verbose_ = 1, double tol_ = 1e-3,
@@ -269,14 +270,15 @@ class SGD {
       if (o_) nfm_opt_destroy(o_);
       nfm_sgd_cfg c{eta0, alpha0, alpha, beta, power, loss.param, L::id, (int32_t)scheduling, md, 0, bsz};
       check(nfm_sgd_create(m, &c, &o_));
-      m_ = m; md_ = md; b_ = bsz;
+      m_ = m; md_ = md; b_ = bsz; cap_ = 1.0;
     }
+    if (md == NFM_MODE_MINIBATCH && cap_ != touchCap) { check(nfm_opt_set_touch_cap(o_, touchCap)); cap_ = touchCap; }
     if (md == NFM_MODE_MINIBATCH) check(nfm_opt_set_dp(o_, group, syncPeriod, 1));
     detail::run_fit<SGD>(*this, o_, X, fm, callback, nCalls <= 0 || md == NFM_MODE_MINIBATCH);
   }
 
  private:
-  nfm_opt* o_ = nullptr; nfm_model* m_ = nullptr; int md_ = -1; int64_t b_ = -1;
+  nfm_opt* o_ = nullptr; nfm_model* m_ = nullptr; int md_ = -1; int64_t b_ = -1; double cap_ = 1.0;
 };
 
 template <class L = Squared>
@@ -284,6 +286,8 @@ class AdaGrad {
  public:
   int maxIter; double eta0, alpha0, alpha, beta; L loss; double eps; int verbose; double tol; bool shuffle; int nCalls;
   int64_t it = 1; int mode = NFM_MODE_SEQUENTIAL; int64_t batch = 8192;
+  double adaCross = 0.0;   // mini-batch mode: nfm_opt_set_ada_cross (weight of the batch's gradient cross products in g_norm; 0.1 at large batches)
+  bool trackViol = true;   // adagrad.nim:99's sum |P_old - P_new| (the stopping criterion); false saves the stored-parameter round trip
   // newAdaGrad, optimizer/adagrad.nim:20-44
   explicit AdaGrad(int maxIter_ = 100, double eta0_ = 0.1, double alpha0_ = 1e-6, double alpha_ = 1e-3, double beta_ = 1e-3,
                    L loss_ = L(), double eps_ = 1e-10, int verbose_ = 1, double tol_ = 1e-3, bool shuffle_ = true,
@@ -301,18 +305,19 @@ class AdaGrad {
     nfm_model* m = fm.push();
     const int md = (maxThreads != 0 || group) ? NFM_MODE_MINIBATCH : mode;
     const int64_t bsz = miniBatchSize > 0 ? miniBatchSize : batch;
-    if (!o_ || m_ != m || md_ != md || b_ != bsz) {
+    if (!o_ || m_ != m || md_ != md || b_ != bsz || tv_ != trackViol) {
       if (o_) nfm_opt_destroy(o_);
-      nfm_adagrad_cfg c{eta0, alpha0, alpha, beta, eps, loss.param, L::id, md, 1, 0, bsz};
+      nfm_adagrad_cfg c{eta0, alpha0, alpha, beta, eps, loss.param, L::id, md, trackViol ? 1 : 0, 0, bsz};
       check(nfm_adagrad_create(m, &c, &o_));
-      m_ = m; md_ = md; b_ = bsz;
+      m_ = m; md_ = md; b_ = bsz; tv_ = trackViol; cross_ = 0.0;
     }
+    if (md == NFM_MODE_MINIBATCH && cross_ != adaCross) { check(nfm_opt_set_ada_cross(o_, adaCross)); cross_ = adaCross; }
     if (md == NFM_MODE_MINIBATCH) check(nfm_opt_set_dp(o_, group, syncPeriod, 1));
     detail::run_fit<AdaGrad>(*this, o_, X, fm, callback, true);
   }
 
  private:
-  nfm_opt* o_ = nullptr; nfm_model* m_ = nullptr; int md_ = -1; int64_t b_ = -1;
+  nfm_opt* o_ = nullptr; nfm_model* m_ = nullptr; int md_ = -1; int64_t b_ = -1; bool tv_ = true; double cross_ = 0.0;
 };
 
 // regularizer/{l1,l21,squaredl12,squaredl21}.nim: the penalties with a matrix proximal operator

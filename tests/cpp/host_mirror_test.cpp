@@ -63,6 +63,29 @@ int main() {
       CHECK(sgd.it == 20 * n + 1);
     }
   }
+  {  // the mini-batch rule's knobs (include/nimfm_hip.h: nfm_opt_set_touch_cap, nfm_opt_set_ada_cross, track_viol): a touch cap sums the
+     // steps of the samples of a batch that share a coordinate instead of averaging them; the cross products only
+     // change AdaGrad's state where a batch touches a coordinate several times; without the stopping criterion's sum the fit is the same
+    FactorizationMachine f1(regression, 2, k), f16(regression, 2, k);
+    f1.init(X); f16.init(X);
+    const double start = f1.score(X, y);
+    SGD<Squared> s1(1, 0.01, 1e-9, 1e-9, 1e-9, Squared(), optimal, 1.0, 0, 0.0, false), s16(1, 0.01, 1e-9, 1e-9, 1e-9, Squared(), optimal, 1.0, 0, 0.0, false);
+    s1.batch = s16.batch = 64;
+    s16.touchCap = 16.0;
+    s1.fit(X, y, f1, 4);
+    s16.fit(X, y, f16, 4);
+    CHECK(f1.score(X, y) < start && f16.score(X, y) < start && f16.P != f1.P);
+    FactorizationMachine g0(regression, 2, k), g1(regression, 2, k), g2(regression, 2, k);
+    AdaGrad<Squared> a0(2, 0.1, 1e-6, 1e-3, 1e-3, Squared(), 1e-10, 0, 0.0, false), a1(2, 0.1, 1e-6, 1e-3, 1e-3, Squared(), 1e-10, 0, 0.0, false),
+        a2(2, 0.1, 1e-6, 1e-3, 1e-3, Squared(), 1e-10, 0, 0.0, false);
+    a0.batch = a1.batch = a2.batch = 64;
+    a1.adaCross = 0.1;
+    a2.trackViol = false;
+    a0.fit(X, y, g0, 4);
+    a1.fit(X, y, g1, 4);
+    a2.fit(X, y, g2, 4);
+    CHECK(g0.P != g1.P && g0.P == g2.P && g0.w == g2.w && g0.intercept == g2.intercept);
+  }
   {  // fitLinear = false => w stays 0; fitIntercept = false => intercept 0 (test_sgd.nim:16-55)
     FactorizationMachine fm(regression, 2, k, explicit_, false, false);
     SGD<Squared> sgd(5, 0.01, 1e-6, 1e-3, 1e-3, Squared(), optimal, 1.0, 0, 0.0);
