@@ -26,7 +26,7 @@ proc statePull(o: NfmOpt, s, n: Params) =
 
 proc hipFitAdaGrad[L, FM, DS](self: AdaGrad[L], X: DS, y: seq[float64], fm: FM, m: NfmModel, stateShape: array[3, int],
                               mode: int32, batch: int, callback: (AdaGrad[L], FM)->void, group: HipGroup = nil,
-                              syncPeriod = 0) =
+                              syncPeriod = 0, adaCross = 0.0) =
   var yy = fm.checkTarget(y)
   if yy.len != X.nSamples: raise newException(ValueError, "len(y) != nSamples")
   check nfm_dataset_set_targets(X.handle, addr yy[0])
@@ -39,6 +39,7 @@ proc hipFitAdaGrad[L, FM, DS](self: AdaGrad[L], X: DS, y: seq[float64], fm: FM, 
   var o: NfmOpt
   check nfm_adagrad_create(m, addr cfg, addr o)
   attach(o, group, syncPeriod)
+  if mode == nfmModeMinibatch and adaCross != 0.0: check nfm_opt_set_ada_cross(o, adaCross)
   if self.it != 1: statePush(o, self.g_sum, self.g_norm)   # a warm start continues from the object's state
   let fc = HipFitCfg(maxIter: self.maxIter, verbose: self.verbose, nCalls: self.nCalls, tol: self.tol,
                      alpha0: self.alpha0, alpha: self.alpha, beta: self.beta, shuffle: self.shuffle,
@@ -64,11 +65,12 @@ proc fit*[L](self: AdaGrad[L], X: HipCSRDataset, y: seq[float64], fm: Factorizat
 
 proc fit*[L](self: AdaGrad[L], X: HipCSRDataset, y: seq[float64], fm: FactorizationMachine, maxThreads: int,
              callback: (AdaGrad[L], FactorizationMachine)->void = nil, miniBatchSize: int = defaultBatch(),
-             syncPeriod: int = 0, group: HipGroup = nil) =
+             syncPeriod: int = 0, group: HipGroup = nil, adaCross: float64 = 0.0) =
   ## optimizer/adagrad_multi.nim:39-115 -> the deterministic mini-batch mode; maxThreads only selects it, the mode's own
-  ## knobs are the defaulted miniBatchSize / syncPeriod / group (hip_sgd.nim)
+  ## knobs are the defaulted miniBatchSize / syncPeriod / group (hip_sgd.nim) and adaCross: the weight of the batch's gradient
+  ## cross products in g_norm (nfm_opt_set_ada_cross; 0.1 lets batches of ten touches per coordinate learn like small ones)
   discard maxThreads
   fm.init(X)
   let m = push(fm, fm.P.shape[2] - fm.nAugments)
   hipFitAdaGrad(self, X, y, fm, m, [fm.P.shape[0], fm.P.shape[2], fm.P.shape[1]], nfmModeMinibatch, miniBatchSize, callback,
-                group, syncPeriod)
+                group, syncPeriod, adaCross)

@@ -14,7 +14,7 @@ proc fit*[L](self: AdaGrad[L], X: HipCSRFieldDataset, y: seq[float64], ffm: Fiel
 
 proc fit*[L](self: AdaGrad[L], X: HipCSRFieldDataset, y: seq[float64], ffm: FieldAwareFactorizationMachine,
              maxThreads: int, callback: (AdaGrad[L], FieldAwareFactorizationMachine)->void = nil,
-             miniBatchSize: int = defaultBatch(), syncPeriod: int = 0, group: HipGroup = nil) =
-  discard maxThreads  # selects the mini-batch mode; its knobs are the defaulted arguments (hip_sgd.nim)
+             miniBatchSize: int = defaultBatch(), syncPeriod: int = 0, group: HipGroup = nil, adaCross: float64 = 0.0) =
+  discard maxThreads  # selects the mini-batch mode; its knobs are the defaulted arguments (hip_sgd.nim, hip_adagrad.nim)
   ffm.init(X)
-  hipFitAdaGrad(self, X, y, ffm, push(ffm), ffm.P.shape, nfmModeMinibatch, miniBatchSize, callback, group, syncPeriod)
+  hipFitAdaGrad(self, X, y, ffm, push(ffm), ffm.P.shape, nfmModeMinibatch, miniBatchSize, callback, group, syncPeriod, adaCross)

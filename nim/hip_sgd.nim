@@ -7,7 +7,8 @@
 import nimfm_hip
 
 proc hipFitSGD[L](self: SGD[L], X: HipCSRDataset, y: seq[float64], fm: FactorizationMachine, mode: int32,
-                  batch: int, callback: (SGD[L], FactorizationMachine)->void, group: HipGroup = nil, syncPeriod = 0) =
+                  batch: int, callback: (SGD[L], FactorizationMachine)->void, group: HipGroup = nil, syncPeriod = 0,
+                  touchCap = 1.0) =
   fm.init(X)                                    # generic over the dataset: factorization_machine.nim:125-139
   var yy = fm.checkTarget(y)                    # fm_base.nim:29-36 (the device applies the same rule by task)
   if yy.len != X.nSamples: raise newException(ValueError, "len(y) != nSamples")
@@ -20,6 +21,7 @@ proc hipFitSGD[L](self: SGD[L], X: HipCSRDataset, y: seq[float64], fm: Factoriza
   var o: NfmOpt
   check nfm_sgd_create(m, addr cfg, addr o)
   attach(o, group, syncPeriod)
+  if mode == nfmModeMinibatch and touchCap != 1.0: check nfm_opt_set_touch_cap(o, touchCap)
   let fc = HipFitCfg(maxIter: self.maxIter, verbose: self.verbose, nCalls: self.nCalls, tol: self.tol,
                      alpha0: self.alpha0, alpha: self.alpha, beta: self.beta, shuffle: self.shuffle,
                      callbackEveryEpochOnly: true, minibatch: mode == nfmModeMinibatch)
@@ -41,10 +43,12 @@ proc fit*[L](self: SGD[L], X: HipCSRDataset, y: seq[float64], fm: FactorizationM
 
 proc fit*[L](self: SGD[L], X: HipCSRDataset, y: seq[float64], fm: FactorizationMachine, maxThreads: int,
              callback: (SGD[L], FactorizationMachine)->void = nil, miniBatchSize: int = defaultBatch(),
-             syncPeriod: int = 0, group: HipGroup = nil) =
+             syncPeriod: int = 0, group: HipGroup = nil, touchCap: float64 = 1.0) =
   ## optimizer/sgd_multi.nim:40-120: the Hogwild overload is served by the deterministic mini-batch mode.  `maxThreads`
   ## keeps its place in the signature and only selects this mode: a thread count is not a batch size.  The knobs of the
   ## mode are explicit and defaulted: `miniBatchSize` (NIMFM_HIP_BATCH, else 8192), and across GPUs -- one process per
-  ## GPU, X being this rank's slice -- `group` with `syncPeriod` mini-batches between exchanges.
+  ## GPU, X being this rank's slice -- `group` with `syncPeriod` mini-batches between exchanges.  `touchCap`: how many of a
+  ## batch's steps on one coordinate are summed before averaging sets in (nfm_opt_set_touch_cap; 1 = the mean; about twice
+  ## miniBatchSize * entries per row / nFeatures keeps the sequential order's epochs to a given loss, INTEGRATION.md).
   discard maxThreads
-  hipFitSGD(self, X, y, fm, nfmModeMinibatch, miniBatchSize, callback, group, syncPeriod)
+  hipFitSGD(self, X, y, fm, nfmModeMinibatch, miniBatchSize, callback, group, syncPeriod, touchCap)

@@ -10,7 +10,7 @@ import nimfm_hip
 
 proc hipFitSGDFFM[L](self: SGD[L], X: HipCSRFieldDataset, y: seq[float64], ffm: FieldAwareFactorizationMachine,
                      mode: int32, batch: int, callback: (SGD[L], FieldAwareFactorizationMachine)->void,
-                     group: HipGroup = nil, syncPeriod = 0) =
+                     group: HipGroup = nil, syncPeriod = 0, touchCap = 1.0) =
   ffm.init(X)                                   # nimfm_hip.init: field_aware_factorization_machine.nim:79-92
   var yy = ffm.checkTarget(y)
   if yy.len != X.nSamples: raise newException(ValueError, "len(y) != nSamples")
@@ -24,6 +24,7 @@ proc hipFitSGDFFM[L](self: SGD[L], X: HipCSRFieldDataset, y: seq[float64], ffm: 
   var o: NfmOpt
   check nfm_sgd_create(m, addr cfg, addr o)
   attach(o, group, syncPeriod)
+  if mode == nfmModeMinibatch and touchCap != 1.0: check nfm_opt_set_touch_cap(o, touchCap)
   let fc = HipFitCfg(maxIter: self.maxIter, verbose: self.verbose, nCalls: self.nCalls, tol: self.tol,
                      alpha0: self.alpha0, alpha: self.alpha, beta: self.beta, shuffle: self.shuffle,
                      callbackEveryEpochOnly: true, minibatch: mode == nfmModeMinibatch)
@@ -45,7 +46,7 @@ proc fit*[L](self: SGD[L], X: HipCSRFieldDataset, y: seq[float64], ffm: FieldAwa
 
 proc fit*[L](self: SGD[L], X: HipCSRFieldDataset, y: seq[float64], ffm: FieldAwareFactorizationMachine,
              maxThreads: int, callback: (SGD[L], FieldAwareFactorizationMachine)->void = nil,
-             miniBatchSize: int = defaultBatch(), syncPeriod: int = 0, group: HipGroup = nil) =
+             miniBatchSize: int = defaultBatch(), syncPeriod: int = 0, group: HipGroup = nil, touchCap: float64 = 1.0) =
   ## optimizer/sgd_ffm_multi.nim -> the deterministic mini-batch mode; maxThreads only selects it (hip_sgd.nim)
   discard maxThreads
-  hipFitSGDFFM(self, X, y, ffm, nfmModeMinibatch, miniBatchSize, callback, group, syncPeriod)
+  hipFitSGDFFM(self, X, y, ffm, nfmModeMinibatch, miniBatchSize, callback, group, syncPeriod, touchCap)

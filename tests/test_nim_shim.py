@@ -127,6 +127,10 @@ def test_max_threads_is_never_read_as_a_batch_size():
     for name in ("hip_sgd.nim", "hip_adagrad.nim", "hip_sgd_ffm.nim", "hip_adagrad_ffm.nim"):
         src = open(os.path.join(NIM, name)).read()
         assert "maxThreads >=" not in src and "maxThreads else" not in src, name
-        sig = re.search(r"maxThreads: int,\s*callback:[^=]*= nil,\s*miniBatchSize: int = defaultBatch\(\),\s*syncPeriod: int = 0, group: HipGroup = nil\)", src)
+        # (round 5: followed by the rule's own defaulted knob -- touchCap for SGD, adaCross for AdaGrad)
+        knob = "touchCap: float64 = 1.0" if "sgd" in name else "adaCross: float64 = 0.0"
+        sig = re.search(r"maxThreads: int,\s*callback:[^=]*= nil,\s*miniBatchSize: int = defaultBatch\(\),\s*syncPeriod: int = 0, group: HipGroup = nil, "
+                        + re.escape(knob) + r"\)", src)
         assert sig, name
+        assert ("nfm_opt_set_touch_cap(o, touchCap)" if "sgd" in name else "adaCross)") in src, name
         assert "discard maxThreads" in src, name
