@@ -63,6 +63,11 @@ def _parser():
     tr.add_argument("--mode", default="sequential", choices=["sequential", "minibatch"],
                     help="sequential = the reference's single-thread order; minibatch = the deterministic data-parallel rule")
     tr.add_argument("--batch", type=int, default=8192)
+    tr.add_argument(*_both("touchCap"), dest="touchCap", default="1",
+                    help="minibatch SGD: steps of a batch on one coordinate summed before averaging sets in (1: the mean; auto: "
+                         "about twice the touches per coordinate and batch, nimfm_amd.suggestTouchCap)")
+    tr.add_argument(*_both("adaCross"), dest="adaCross", type=float, default=0.0,
+                    help="minibatch AdaGrad: weight of the batch's gradient cross products in g_norm (0.1 for large batches)")
     tr.add_argument("--shuffle", default="true")
     te.add_argument("--test", required=True)
     te.add_argument("--load", required=True)
@@ -130,9 +135,10 @@ def main(argv=None):
                            scheduling=args.scheduling, power=args.power, verbose=args.verbose, tol=args.tol,
                            shuffle=_flag(args.shuffle), lossParam=args.threshold)
     elif args.solver == "sgd":
-        opt = nf.newSGD(scheduling=args.scheduling, power=args.power, **common)
+        cap = nf.suggestTouchCap(X, args.batch) if str(args.touchCap).lower() == "auto" else float(args.touchCap)
+        opt = nf.newSGD(scheduling=args.scheduling, power=args.power, touchCap=cap, **common)
     else:
-        opt = nf.newAdaGrad(**common)
+        opt = nf.newAdaGrad(adaCross=args.adaCross, **common)
     opt.fit(X, y, fm)
     if args.test:
         _eval(nf, fm, task, args.test, args.predict, args.nFeatures, args.verbose)

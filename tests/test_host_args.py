@@ -39,3 +39,15 @@ def test_suggested_touch_cap_is_what_the_bench_settings_were_measured_at():
     assert nf.suggestTouchCap(small, 1_000_000) == 16.0  # (the batch cannot exceed the dataset)
     with pytest.raises(ValueError):
         nf.suggestTouchCap(types.SimpleNamespace(nSamples=0, nFeatures=5, nnz=0), 8)
+
+
+def test_cli_takes_the_mini_batch_knobs():
+    """`python -m nimfm_amd train ... --mode minibatch --batch B --touchCap auto|c --adaCross g` (both spellings of an option, as for
+    the reference's own options); the defaults are the library's (the mean, no cross products)"""
+    from nimfm_amd import cli
+    base = ["train", "-t", "r", "--train", "a.svm"]
+    a = cli._parser().parse_args(base)
+    assert a.touchCap == "1" and a.adaCross == 0.0 and a.mode == "sequential"
+    a = cli._parser().parse_args(base + ["--mode", "minibatch", "--batch", "65536", "--touch-cap", "auto", "--ada-cross", "0.1"])
+    assert a.touchCap == "auto" and a.adaCross == 0.1 and a.batch == 65536
+    assert cli._parser().parse_args(base + ["--touchCap", "32"]).touchCap == "32"
